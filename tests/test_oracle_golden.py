@@ -1,0 +1,161 @@
+"""Pins the CPU oracle (oracle/rpca_oracle.py) against every known-answer vector the
+reference's own tests hold for the hot path (tests/golden/reference_vectors.json, transcribed from
+/root/reference/test/runtests.jl) and re-expresses its statistical tests with our own seeded RNG
+and the reference's thresholds."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import rpca_oracle as O
+
+
+def test_rpca_5x5_known_answer(golden):          # test/runtests.jl:141-165
+    g = golden["rpca_5x5"]
+    D = np.array(g["D"])
+    A, E, s, sv, info = O.rpca(D, nonnegE=True, nonnegA=True)
+    assert np.allclose(A, np.array(g["A"]), rtol=0, atol=g["atol"])
+    assert np.allclose(E, np.array(g["E"]), rtol=0, atol=g["atol"])
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+    assert info.converged
+
+
+def test_rpca_5x5_residual_flags_off(golden):    # test/runtests.jl:168-169
+    D = np.array(golden["rpca_5x5"]["D"])
+    A, E, *_ = O.rpca(D)
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+
+
+def test_hankel_identities(golden):              # test/runtests.jl:293-299
+    for key in ("hankel_L2", "hankel_L3_lag2"):
+        g = golden[key]
+        X = O.hankel(np.array(g["x"]), g["L"], g["lag"])
+        assert X.dtype.kind == "i"
+        assert np.array_equal(X, np.array(g["X"]))
+    g = golden["ishankel_true"]
+    A = O.hankel(np.array(g["x"]), g["L"])
+    assert O.ishankel(A)
+    rng = np.random.default_rng(0)
+    assert not O.ishankel(A + 0.1 * rng.standard_normal(A.shape))
+
+
+def _y(T=1000):
+    y = np.sin(0.1 * np.arange(1, T + 1))
+    return y / np.quantile(np.abs(y), 0.9)
+
+
+def test_unhankel_round_trips(golden):           # test/runtests.jl:355-376
+    T = golden["unhankel"]["T"]
+    y = _y(T)
+    H = O.hankel(y, 2)
+    assert O.ishankel(H)
+    assert np.array_equal(O.unhankel(H), y)
+    assert np.array_equal(O.unhankel(O.hankel(y, 2, 2), 2, T), y)
+    yh = O.unhankel(O.hankel(y, 5, 2), 2, T)
+    assert np.allclose(yh[:-1], y[:-1]) and yh[-1] == 0.0
+    y2 = np.random.default_rng(1).standard_normal(T)
+    yy = np.column_stack([y, y2])
+    yh = O.unhankel(O.hankel(yy, 5, 2), 2, T, 2)
+    assert np.allclose(yh[:-1], yy[:-1])
+
+
+def test_hankel_asserts():                        # src/robustPCA.jl:79-80
+    with pytest.raises(AssertionError):
+        O.hankel(np.arange(10.0), 6)
+    with pytest.raises(AssertionError):
+        O.hankel(np.arange(20.0), 2, 3)
+
+
+def test_tls_equals_tls_inplace():                # test/runtests.jl:43
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(3)
+    A = rng.standard_normal((50, 3))
+    An = A + rng.standard_normal(A.shape)
+    yn = A @ x + 0.01 * rng.standard_normal(50)
+    xa = O.tls(An, yn)
+    xb = O.tls_inplace(np.column_stack([An, yn]), 3)[:, 0]
+    assert np.allclose(xa, xb)
+    assert np.linalg.norm(x - xa) < 1
+
+
+def test_soft_th_forms():                         # src/robustPCA.jl:1-7
+    x = np.array([-3.0, -0.5, 0.0, 0.5, 3.0])
+    assert np.array_equal(O.soft_th(x, 1.0), [-2.0, 0.0, 0.0, 0.0, 2.0])
+    m = 0.3
+    r = O.soft_th(x, 1.0, m)
+    assert r[1] == m and r[2] == m and r[3] == m       # exactly l inside the dead zone
+    assert np.allclose(r, [-2.0, m, m, m, 2.0])
+    z = np.array([3 + 4j, 0.1j])
+    w = O.soft_th(z, 1.0)
+    assert np.allclose(np.abs(w), [4.0, 0.0]) and np.allclose(np.angle(w[0]), np.angle(z[0]))
+
+
+def test_missing_values_lowrankfilter():          # test/runtests.jl:172-185 (20 trials, < 0.025)
+    rng = np.random.default_rng(0)
+    res = []
+    for _ in range(6):
+        N = 500
+        y = np.sin(0.1 * np.arange(1, N + 1)) + 0.1 * rng.standard_normal(N)
+        miss = rng.random(N) < 0.1
+        yn = y + miss * 1e2
+        yf = O.lowrankfilter(yn, 40)
+        res.append(np.mean((y - yf) ** 2) / np.mean(y ** 2))
+    assert np.mean(res) < 0.025
+
+
+def test_complex_rpca():                          # test/runtests.jl:187-199
+    rng = np.random.default_rng(0)
+    c = lambda *s: (rng.standard_normal(s) + 1j * rng.standard_normal(s)) / math.sqrt(2)
+    u, v = c(100), c(20)
+    E = c(100, 20) * 10 * (rng.random((100, 20)) < 0.01)
+    A = np.outer(u, v.conj())
+    Ah, Eh, s, sv, _ = O.rpca(A + E)
+    assert np.sum(np.abs(Eh - E) ** 2) / np.sum(np.abs(E) ** 2) < 1e-5
+    assert np.sum(np.abs(Ah - A) ** 2) / np.sum(np.abs(A) ** 2) < 1e-5
+
+
+def test_rtls_beats_tls():                        # test/runtests.jl:221-235 (>0.9 over 1000 trials)
+    rng = np.random.default_rng(0)
+    wins, n = 0, 60
+    for _ in range(n):
+        x = rng.standard_normal(3)
+        A = rng.standard_normal((50, 3))
+        s = 50
+        An = A + s * rng.standard_normal(A.shape) * (rng.random(A.shape) < 0.1)
+        y = A @ x
+        yn = y + s * rng.standard_normal(50) * (rng.random(50) < 0.1)
+        xt = O.tls(An, yn)
+        xr = O.rtls(An, yn)
+        wins += np.linalg.norm(x - xr) < np.linalg.norm(x - xt)
+    assert wins / n > 0.8
+
+
+def test_soft_hankel_moves_closer_and_exact_hankel():   # test/runtests.jl:296-348
+    rng = np.random.default_rng(0)
+    A = O.hankel(np.arange(1.0, 9.0), 4)
+    An = A + 0.1 * rng.standard_normal(A.shape)
+    Anc = An.copy()
+    O.soft_hankel_(An, 0.1)
+    assert np.sum((An - A) ** 2) < np.sum((Anc - A) ** 2)
+    wins, n = 0, 200
+    for _ in range(n):
+        y = rng.standard_normal(100)
+        H = O.hankel(y, 5)
+        A1, *_ = O.rpca(H, nukeA=False)
+        A2, E2, *_ = O.rpca(H, nukeA=False, hankel=True)
+        assert O.ishankel(A2) and O.ishankel(E2)          # exact
+        wins += np.mean((A2 - H) ** 2) < np.mean((A1 - H) ** 2)
+    assert wins / n > 0.8
+
+
+def test_lowrankfilter_sine_spikes():             # test/runtests.jl:378-381, 401-405
+    T = 1000
+    y = _y(T)
+    rng = np.random.default_rng(0)
+    n = 20 * rng.standard_normal(T) * (rng.random(T) < 0.01) + 0.1 * rng.standard_normal(T)
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+    yf = qn(O.lowrankfilter(y + n))
+    assert np.mean((y - yf) ** 2) / np.mean(n ** 2) < 0.001
+    n = rng.standard_normal(T)
+    yf = qn(O.lowrankfilter(y + n, sv=2))
+    assert np.mean((y - yf) ** 2) / np.mean(n ** 2) < 0.05
