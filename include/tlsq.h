@@ -1,0 +1,191 @@
+/* tlsq.h — C ABI of libtlsqhip.so: MI355X (gfx950) robust-PCA / low-rank-recovery engine.
+ *
+ * Drop-in boundary for the `rpca`, `lowrankfilter`, `hankel`, `unhankel`, `tls!` and `rtls`
+ * entry points of baggepinnen/TotalLeastSquares.jl (reference paths below are relative to
+ * /root/reference).  The reference has no FFI of its own; these are the entry points a thin Julia
+ * `ccall` shim (julia/TotalLeastSquaresHIP.jl) binds in place of the Julia bodies.
+ *
+ * Conventions
+ *  - All matrices are COLUMN-MAJOR (Julia native) with an explicit leading dimension, 64-bit sizes.
+ *  - The caller owns every input and output buffer.  `memory` in the options says whether the
+ *    pointers are host pointers (TLSQ_MEM_HOST: Julia `Array`s through `Ptr{T}`) or device pointers
+ *    already resident in this GPU's HBM (TLSQ_MEM_DEVICE).  The library never retains a caller
+ *    pointer after a call returns and never frees caller memory.
+ *  - Every entry point returns an int status: 0 OK, >0 non-fatal (TLSQ_MAXITER = the reference's
+ *    `@warn "Maximum number of iterations reached"`, src/robustPCA.jl:232), <0 fatal.  No C++
+ *    exception or exit() crosses the ABI.  tlsq_last_error(h) gives the text of the last failure.
+ *  - A handle is bound to ONE GPU and is used by one host thread at a time.  All calls block until
+ *    the device work has completed.  Multi-GPU = one process (or one handle) per GPU, row-sharded,
+ *    joined by tlsq_comm_init (RCCL over xGMI): the only exchanged data are N x N Gram matrices.
+ *  - There is NO CPU fallback: without a GPU (or for complex element types) calls fail with
+ *    TLSQ_ERR_HIP / TLSQ_ERR_UNSUPPORTED.
+ */
+#ifndef TLSQ_H
+#define TLSQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tlsq_handle_s* tlsq_handle;
+
+enum {
+    TLSQ_OK = 0,
+    TLSQ_MAXITER = 1,           /* src/robustPCA.jl:232 — a warning in the reference, not an error */
+    TLSQ_ERR_ARG = -1,          /* bad size / NULL / the reference's @assert (src/robustPCA.jl:79-80) */
+    TLSQ_ERR_HIP = -2,          /* HIP runtime error, no device */
+    TLSQ_ERR_OOM = -3,
+    TLSQ_ERR_COMM = -4,         /* RCCL error */
+    TLSQ_ERR_UNSUPPORTED = -5,  /* e.g. N too large for the LDS-resident Jacobi, complex T */
+    TLSQ_ERR_NOCONV = -6        /* small eigensolver did not converge */
+};
+
+enum { TLSQ_MEM_HOST = 0, TLSQ_MEM_DEVICE = 1 };
+enum { TLSQ_SVD_FULL = 0, TLSQ_SVD_RANDOMIZED = 1 };       /* the `svd` hook, src/robustPCA.jl:168,193-197 */
+enum { TLSQ_OPNORM_EXACT = 0, TLSQ_OPNORM_POWER = 1 };     /* the `opnorm` hook, src/robustPCA.jl:169,177,225 */
+
+/* Keyword arguments of rpca (src/robustPCA.jl:156-170).  Fill with tlsq_rpca_opts_default() first;
+ * NaN / <=0 sentinels resolve to the reference's defaults at call time (they depend on T, M, N). */
+typedef struct tlsq_rpca_opts {
+    double  lambda;      /* NaN -> 1/sqrt(max(M_global,N))   (:157) */
+    int64_t maxrank;     /* <=0 -> typemax(Int)              (:158) */
+    int64_t iters;       /* <=0 -> 1000                      (:159) */
+    double  tol;         /* NaN -> sqrt(eps(real(T)))        (:160) */
+    double  rho;         /* NaN -> 1.5                       (:161) */
+    int32_t nonnegA;     /* (:163) */
+    int32_t nonnegE;     /* (:164) */
+    int32_t hankel;      /* (:165) */
+    int32_t nukeA;       /* (:167) default 1 */
+    int32_t svd_mode;    /* TLSQ_SVD_*    */
+    int32_t opnorm_mode; /* TLSQ_OPNORM_* */
+    int32_t opnorm_mvps; /* power-iteration mat-vec pairs for TLSQ_OPNORM_POWER (rnorm(x, mvps)) */
+    int32_t memory;      /* TLSQ_MEM_* for every matrix/vector pointer of the call */
+    int64_t m_global;    /* total rows over all ranks when row-sharded; 0 -> M (single GPU) */
+    uint64_t seed;       /* randomized modes */
+    /* live `verbose` hook (src/robustPCA.jl:226): called on the calling thread after each iteration */
+    void (*on_iter)(int64_t k, double cost, int64_t svp, void* user);
+    void* user;
+} tlsq_rpca_opts;
+
+/* Per-call report.  cost_hist / svp_hist are optional caller-provided arrays of hist_capacity entries. */
+typedef struct tlsq_rpca_info {
+    int64_t iters_done;
+    int32_t converged;
+    int32_t reserved;
+    double  final_cost;
+    double  final_mu;
+    double  d_norm;          /* opnorm(D), src/robustPCA.jl:177 */
+    double* cost_hist;
+    int64_t* svp_hist;
+    int64_t hist_capacity;
+    int64_t jacobi_sweeps;   /* total sweeps of the small eigensolver */
+    /* wall/device time in ms */
+    double ms_total, ms_loop, ms_h2d, ms_d2h;
+    double ms_shrink, ms_update, ms_gram, ms_eig, ms_rebuild, ms_opnorm;
+} tlsq_rpca_info;
+
+const char* tlsq_version(void);
+void        tlsq_rpca_opts_default(tlsq_rpca_opts* o);
+
+int  tlsq_create(int device_id, tlsq_handle* out);
+int  tlsq_destroy(tlsq_handle h);
+const char* tlsq_last_error(tlsq_handle h);
+/* hipStream_t the handle launches on (as void*), so a caller can time it with HIP events */
+void* tlsq_stream(tlsq_handle h);
+/* block until everything queued on the handle's stream has completed (the tlsq_k_* entry points are
+ * asynchronous on that stream; all other entry points synchronise before returning) */
+int   tlsq_synchronize(tlsq_handle h);
+
+/* ---- multi-GPU (row sharding, one handle per GPU) -------------------------------------------- */
+#define TLSQ_UNIQUE_ID_BYTES 128
+int tlsq_comm_unique_id(unsigned char id[TLSQ_UNIQUE_ID_BYTES]);              /* rank 0, then broadcast */
+int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[TLSQ_UNIQUE_ID_BYTES]);
+int tlsq_comm_destroy(tlsq_handle h);
+
+/* ---- rpca: src/robustPCA.jl:156-239 ----------------------------------------------------------
+ * D  M x N (ldD)  in;  A, E  M x N out;  optional (may be NULL): U M x d (ldU), S d, Vt d x N (ldVt),
+ * d = min(M_global,N) — the SVD of the last Z = D-E+Y/mu (the reference's returned `s`, :194,:238).
+ * *sv = estimated rank (:204,:238).  When row-sharded, M/D/A/E/U are the local shard. */
+int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
+                  const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE,
+                  double* U, int64_t ldU, double* S, double* Vt, int64_t ldVt,
+                  int64_t* sv, tlsq_rpca_info* info);
+int tlsq_rpca_f32(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t ldD,
+                  const tlsq_rpca_opts* opts, float* A, int64_t ldA, float* E, int64_t ldE,
+                  float* U, int64_t ldU, float* S, float* Vt, int64_t ldVt,
+                  int64_t* sv, tlsq_rpca_info* info);
+
+/* ---- Hankel lag embedding / anti-diagonal averaging ------------------------------------------
+ * hankel:   src/robustPCA.jl:76-92   x (Nx x Dch, ldx) -> X (K x L*Dch, ldX), K=(Nx-L)/lag+1
+ * unhankel: src/robustPCA.jl:28-39,53-68   A (K x L*Dch) -> y (Nx x Dch, ldy)
+ * soft_hankel: src/robustPCA.jl:9-21  in place on A (K x L)
+ * `memory` = TLSQ_MEM_* for all pointers of the call. */
+int tlsq_hankel_f64(tlsq_handle h, const double* x, int64_t Nx, int64_t Dch, int64_t ldx,
+                    int64_t L, int64_t lag, double* X, int64_t ldX, int memory);
+int tlsq_unhankel_f64(tlsq_handle h, const double* A, int64_t K, int64_t LD, int64_t ldA,
+                      int64_t lag, int64_t Nx, int64_t Dch, double* y, int64_t ldy, int memory);
+int tlsq_soft_hankel_f64(tlsq_handle h, double* A, int64_t K, int64_t L, int64_t ldA,
+                         double eps, int memory);
+int tlsq_hankel_f32(tlsq_handle h, const float* x, int64_t Nx, int64_t Dch, int64_t ldx,
+                    int64_t L, int64_t lag, float* X, int64_t ldX, int memory);
+int tlsq_unhankel_f32(tlsq_handle h, const float* A, int64_t K, int64_t LD, int64_t ldA,
+                      int64_t lag, int64_t Nx, int64_t Dch, float* y, int64_t ldy, int memory);
+int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t ldA,
+                         float eps, int memory);
+
+/* ---- lowrankfilter: src/robustPCA.jl:119-128 --------------------------------------------------
+ * y (Nx x Dch, ldy) -> yf (Nx x Dch, ldyf).  n = embedding size (<=0 -> min(Nx/20,2000)),
+ * sv>0 -> plain rank-sv truncation (:123-126).  opts->tol NaN -> 1e-3 (the lowrankfilter default).
+ * The Hankel matrix is built, factored and averaged on the device; it never visits the host. */
+int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy,
+                           int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
+                           double* yf, int64_t ldyf, tlsq_rpca_info* info);
+
+/* ---- tls! / rtls: src/TotalLeastSquares.jl:63-69, 152-156 -------------------------------------
+ * tls:  Ay (M x ncols, ldAy; NOT destroyed, unlike svd!) , n = columns of A -> x (n x q), q=ncols-n
+ * rtls: A (M x n), y (M x q) -> x (n x q) via rpca([A y]; nukeA=false) then tls!(s, n).
+ * tls_from_vt: the `tls!(s::SVD, n)` method on a caller-held Vt (ncols x ncols, HOST memory). */
+int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int64_t ldAy,
+                 int64_t n, double* x, int64_t ldx, int memory);
+int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA,
+                  const double* y, int64_t q, int64_t ldy, const tlsq_rpca_opts* opts,
+                  double* x, int64_t ldx, tlsq_rpca_info* info);
+int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n,
+                         double* x, int64_t ldx);
+
+/* ---- kernel-level entry points (DEVICE pointers; used by the parity tests and bench.py) -------
+ * shrink sweep  (src/robustPCA.jl:188-192):  E = soft_th((D-A)+inv_mu*Y, thr) [max(E,0)]; Z=(D-E)+inv_mu*Y
+ * update sweep  (src/robustPCA.jl:217-222):  [A=max(A,0)]; R=(D-A)-E; Y=Y+mu*R
+ * All arrays contiguous M x N (ld = M), n = M*N elements. */
+int tlsq_k_shrink_f64(tlsq_handle h, const double* D, const double* A, const double* Y, double* E,
+                      double* Z, int64_t n, double inv_mu, double thr, int nonnegE);
+int tlsq_k_update_f64(tlsq_handle h, const double* D, double* A, const double* E, double* Y,
+                      double* R, int64_t n, double mu, int nonnegA);
+int tlsq_k_shrink_f32(tlsq_handle h, const float* D, const float* A, const float* Y, float* E,
+                      float* Z, int64_t n, float inv_mu, float thr, int nonnegE);
+int tlsq_k_update_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y,
+                      float* R, int64_t n, float mu, int nonnegA);
+/* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
+int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
+                    double* G, int64_t ldG);
+/* C (M x Q, ldC) = Z (M x K, ldZ) * W (K x Q, ldW) */
+int tlsq_k_gemm_nn_f64(tlsq_handle h, const double* Z, int64_t M, int64_t K, int64_t ldZ,
+                       const double* W, int64_t Q, int64_t ldW, double* C, int64_t ldC);
+/* C (M x Q, ldC) = T (M x K, ldT) * V' , V is Q x K (ldV) */
+int tlsq_k_gemm_nt_f64(tlsq_handle h, const double* T, int64_t M, int64_t K, int64_t ldT,
+                       const double* V, int64_t Q, int64_t ldV, double* C, int64_t ldC);
+/* symmetric PSD eigen-decomposition of G (N x N): lam (N, descending), V (N x N, ldV; may be NULL) */
+int tlsq_k_symeig_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam,
+                      double* V, int64_t ldV, int64_t* sweeps);
+/* sigma_max of Z (M x N, ldZ) — the default `opnorm` */
+int tlsq_k_opnorm_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
+                      double* sigma_max);
+/* max |x_i| over n contiguous elements — norm(Y, Inf) of src/robustPCA.jl:178 */
+int tlsq_k_maxabs_f64(tlsq_handle h, const double* x, int64_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLSQ_H */

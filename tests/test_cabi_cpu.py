@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/tlsq.h declares, resolves option defaults like the reference, and fails loudly without a GPU."""
+import ctypes as C
+import math
+import os
+import re
+import subprocess
+
+import pytest
+
+import tlsq_amd
+from tlsq_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "tlsq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tlsq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = L.load()
+    declared = _declared()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tlsq.h but not exported"
+    assert sorted(L.EXPORTS) == declared
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (tlsq_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+
+
+def test_version_and_default_opts():
+    lib = L.load()
+    assert b"gfx950" in lib.tlsq_version()
+    o = L.RpcaOpts()
+    lib.tlsq_rpca_opts_default(C.byref(o))
+    assert math.isnan(o.lambda_) and math.isnan(o.tol) and math.isnan(o.rho)   # -> reference defaults
+    assert o.nukeA == 1 and o.iters == 0 and o.maxrank == 0
+    assert o.memory == L.MEM_HOST and o.svd_mode == L.SVD_FULL
+
+
+def test_struct_sizes_match_header():
+    # natural alignment, no packing: these are the sizes the Julia shim's struct mirrors must have
+    assert C.sizeof(L.RpcaOpts) == 104
+    assert C.sizeof(L.RpcaInfo) == 152
+
+
+def test_tls_from_vt_is_host_only_math():
+    """tls!(s::SVD, n) (src/TotalLeastSquares.jl:65-69): the tiny V-partition solve needs no GPU."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    Ay = rng.standard_normal((50, 5))
+    _, _, Vt = np.linalg.svd(Ay, full_matrices=False)
+    n = 3
+    V = Vt.T
+    expect = -V[:n, n:] @ np.linalg.inv(V[n:, n:])
+    Vtf = np.asfortranarray(Vt)
+    x = np.empty((n, 2), order="F")
+    st = L.load().tlsq_tls_from_vt_f64(C.c_void_p(Vtf.ctypes.data), 5, 5, n, C.c_void_p(x.ctypes.data), n)
+    assert st == 0
+    assert np.allclose(x, expect, rtol=1e-12, atol=1e-12)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(tlsq_amd.TlsqError):
+        tlsq_amd.Engine(0)
+
+
+def test_product_never_imports_oracle():
+    """The product path must not reach into oracle/ (grep the package sources)."""
+    pkg = os.path.join(ROOT, "totalleastsquares.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "rpca_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

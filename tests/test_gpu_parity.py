@@ -1,0 +1,423 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs, against the reference's golden vectors, and — at the full
+BASELINE sizes — through size-independent properties.
+
+Tolerances (fp64):  sweeps / hankel family: bit-exact;  Gram / GEMM: 1e-13 relative (different
+summation order);  rpca A, E vs oracle: ||ΔA||_F/||A||_F, ||ΔE||_F/||E||_F <= 1e-8 with identical
+iteration count and per-iteration svp;  the reference's 5x5 table: its own atol 1e-6.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import tlsq_amd
+    e = tlsq_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def to_dev(torch, a):
+    """column-major device copy of a 1-D / 2-D numpy array; returns a tensor whose data_ptr is the matrix"""
+    a = np.asarray(a)
+    if a.ndim == 1:
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a.T)).cuda()      # (N, M) C-order == (M, N) F-order
+
+
+def to_host(t, shape=None):
+    a = t.cpu().numpy()
+    return a if a.ndim == 1 else a.T
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+# --------------------------------------------------------------------------------------------
+# sweeps: bit-exact against the reference's expression order
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,n", [(np.float64, 100003), (np.float64, 8), (np.float64, 1), (np.float32, 65537)])
+@pytest.mark.parametrize("nonneg", [0, 1])
+def test_shrink_update_sweeps_bitexact(eng, torch_mod, dt, n, nonneg):
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    rng = np.random.default_rng(1)
+    D, A, Y = (rng.standard_normal(n).astype(dt) for _ in range(3))
+    E0 = rng.standard_normal(n).astype(dt)
+    inv_mu, thr, mu = dt(3.7), dt(0.9), dt(0.27)
+    # oracle expressions (src/robustPCA.jl:188-192, 217-222)
+    t = inv_mu * Y
+    E = O.soft_th((D - A) + t, thr).astype(dt)
+    if nonneg:
+        E = np.maximum(E, 0)
+    Z = (D - E) + t
+    A2 = np.maximum(A, 0) if nonneg else A
+    R = (D - A2) - E0
+    Y2 = Y + mu * R
+    suf = "f64" if dt == np.float64 else "f32"
+    sc = C.c_double if dt == np.float64 else C.c_float
+    dD, dA, dY, dE0 = (to_dev(torch, x) for x in (D, A, Y, E0))
+    dE, dZ, dR = (torch.empty_like(dD) for _ in range(3))
+    torch.cuda.synchronize()
+    assert getattr(eng.lib, "tlsq_k_shrink_" + suf)(eng.h, dptr(dD), dptr(dA), dptr(dY), dptr(dE), dptr(dZ), n,
+                                                    sc(inv_mu), sc(thr), nonneg) == 0
+    eng.synchronize()
+    assert np.array_equal(to_host(dE), E)
+    assert np.array_equal(to_host(dZ), Z)
+    assert getattr(eng.lib, "tlsq_k_update_" + suf)(eng.h, dptr(dD), dptr(dA), dptr(dE0), dptr(dY), dptr(dR), n,
+                                                    sc(mu), nonneg) == 0
+    eng.synchronize()
+    assert np.array_equal(to_host(dR), R)
+    assert np.array_equal(to_host(dY), Y2)
+    assert np.array_equal(to_host(dA), A2)
+
+
+def test_maxabs(eng, torch_mod):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(1_000_003)
+    x[777] = -9.25
+    out = C.c_double()
+    d = to_dev(torch_mod, x)
+    torch_mod.cuda.synchronize()
+    assert eng.lib.tlsq_k_maxabs_f64(eng.h, dptr(d), x.size, C.byref(out)) == 0
+    assert out.value == np.max(np.abs(x))
+
+
+# --------------------------------------------------------------------------------------------
+# MFMA contractions
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N", [(500, 50), (5, 5), (50, 4), (1000, 37), (777, 130), (2000, 128), (20000, 512),
+                                 (3, 40)])
+def test_gram(eng, torch_mod, M, N):
+    torch = torch_mod
+    rng = np.random.default_rng(3)
+    Z = rng.standard_normal((M, N)) * np.exp(rng.standard_normal(N))[None, :]
+    dZ = to_dev(torch, Z)
+    dG = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_gram_f64(eng.h, dptr(dZ), M, N, M, dptr(dG), N) == 0
+    eng.synchronize()
+    G = to_host(dG)
+    ref = Z.T @ Z
+    assert np.array_equal(G, G.T)                                   # mirrored exactly
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert np.max(np.abs(G - ref) / scale) < 1e-13
+
+
+@pytest.mark.parametrize("M,K,Q", [(500, 50, 7), (1000, 128, 16), (333, 37, 37), (20000, 512, 16), (4096, 512, 512),
+                                   (50, 4, 1)])
+def test_gemm_nn_nt(eng, torch_mod, M, K, Q):
+    torch = torch_mod
+    rng = np.random.default_rng(4)
+    Z = rng.standard_normal((M, K))
+    W = rng.standard_normal((K, Q))
+    dZ, dW = to_dev(torch, Z), to_dev(torch, W)
+    dC = torch.zeros((Q, M), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_gemm_nn_f64(eng.h, dptr(dZ), M, K, M, dptr(dW), Q, K, dptr(dC), M) == 0
+    eng.synchronize()
+    ref = Z @ W
+    assert relerr(to_host(dC), ref) < 1e-13
+    # NT: C = T * V',  T (M x Q), V (K x Q)  -> (M x K)
+    T = ref
+    V = rng.standard_normal((K, Q))
+    dT, dV = to_dev(torch, T), to_dev(torch, V)
+    dC2 = torch.zeros((K, M), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_gemm_nt_f64(eng.h, dptr(dT), M, Q, M, dptr(dV), K, K, dptr(dC2), M) == 0
+    eng.synchronize()
+    assert relerr(to_host(dC2), T @ V.T) < 1e-13
+
+
+# --------------------------------------------------------------------------------------------
+# Jacobi eigensolver / opnorm
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,rank", [(5, 5), (4, 2), (37, 37), (50, 10), (128, 128), (512, 40), (512, 512), (1, 1),
+                                    (2, 2), (300, 300)])
+def test_symeig(eng, torch_mod, N, rank):
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((max(2 * N, 8), rank)) @ rng.standard_normal((rank, N))
+    G = X.T @ X
+    G = (G + G.T) / 2
+    dG = to_dev(torch, G)
+    dl = torch.zeros(N, dtype=torch.float64, device="cuda")
+    dV = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    sweeps = C.c_int64()
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_symeig_f64(eng.h, dptr(dG), N, N, dptr(dl), dptr(dV), N, C.byref(sweeps)) == 0, \
+        eng.lib.tlsq_last_error(eng.h)
+    lam, V = to_host(dl), to_host(dV)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.all(np.diff(lam) <= 0)
+    assert np.max(np.abs(lam - ref)) < 1e-12 * max(ref[0], 1e-300) * math.sqrt(N)
+    assert np.max(np.abs(V.T @ V - np.eye(N))) < 1e-13 * N
+    assert np.linalg.norm(G @ V - V * lam[None, :]) < 1e-12 * np.linalg.norm(G) * math.sqrt(N)
+    assert sweeps.value <= 20
+
+
+@pytest.mark.parametrize("M,N", [(500, 50), (20000, 512), (7, 9)])
+def test_opnorm(eng, torch_mod, M, N):
+    rng = np.random.default_rng(6)
+    Z = rng.standard_normal((M, N))
+    d = to_dev(torch_mod, Z)
+    out = C.c_double()
+    torch_mod.cuda.synchronize()
+    assert eng.lib.tlsq_k_opnorm_f64(eng.h, dptr(d), M, N, M, C.byref(out)) == 0
+    assert abs(out.value - sla.svdvals(Z)[0]) < 1e-12 * out.value
+
+
+# --------------------------------------------------------------------------------------------
+# Hankel family: golden vectors + exact equality with the oracle
+# --------------------------------------------------------------------------------------------
+def test_hankel_golden(eng, golden):
+    import tlsq_amd
+    for key in ("hankel_L2", "hankel_L3_lag2"):                      # test/runtests.jl:293-294
+        g = golden[key]
+        X = eng.hankel(np.array(g["x"], dtype=np.float64), g["L"], g["lag"])
+        assert np.array_equal(X, np.array(g["X"], dtype=np.float64))
+    g = golden["ishankel_true"]                                      # :296-299
+    A = eng.hankel(np.array(g["x"], dtype=np.float64), g["L"])
+    assert tlsq_amd.ishankel(A)
+    assert not tlsq_amd.ishankel(A + 0.1 * np.random.default_rng(0).standard_normal(A.shape))
+    with pytest.raises(AssertionError):                              # src/robustPCA.jl:79-80
+        eng.hankel(np.arange(10.0), 6)
+    with pytest.raises(AssertionError):
+        eng.hankel(np.arange(20.0), 2, 3)
+
+
+def test_unhankel_round_trips(eng, golden):                          # test/runtests.jl:355-376
+    import tlsq_amd
+    T = golden["unhankel"]["T"]
+    y = np.sin(0.1 * np.arange(1, T + 1))
+    y = y / np.quantile(np.abs(y), 0.9)
+    H = eng.hankel(y, 2)
+    assert tlsq_amd.ishankel(H)
+    assert np.array_equal(eng.unhankel(H), y)
+    assert np.array_equal(eng.unhankel(eng.hankel(y, 2, 2), 2, T), y)
+    yh = eng.unhankel(eng.hankel(y, 5, 2), 2, T)
+    assert np.allclose(yh[:-1], y[:-1]) and yh[-1] == 0.0
+    y2 = np.random.default_rng(1).standard_normal(T)
+    yy = np.column_stack([y, y2])
+    yh = eng.unhankel(eng.hankel(yy, 5, 2), 2, T, 2)
+    assert np.allclose(yh[:-1], yy[:-1])
+
+
+@pytest.mark.parametrize("Nx,Dch,L,lag", [(1000, 1, 50, 1), (1000, 2, 20, 1), (1001, 3, 7, 3), (64, 1, 32, 1),
+                                          (5000, 1, 256, 4)])
+def test_hankel_family_equals_oracle(eng, Nx, Dch, L, lag):
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((Nx, Dch)) if Dch > 1 else rng.standard_normal(Nx)
+    X = eng.hankel(x, L, lag)
+    assert np.array_equal(X, O.hankel(x, L, lag))
+    A = X + 0.01 * rng.standard_normal(X.shape)
+    y = eng.unhankel(A, lag, Nx, Dch)
+    assert np.array_equal(y, O.unhankel(A, lag, Nx, Dch))           # same summation order -> same bits
+    if Dch == 1 and lag == 1:
+        B = A.copy(order="F")
+        ref = O.soft_hankel_(A.copy(), 0.05)
+        got = eng.soft_hankel_(B, 0.05)
+        assert np.array_equal(got, ref)
+    xf = x.astype(np.float32)
+    assert np.array_equal(eng.hankel(xf, L, lag), O.hankel(xf, L, lag))
+
+
+# --------------------------------------------------------------------------------------------
+# rpca: golden vector, oracle parity, flags
+# --------------------------------------------------------------------------------------------
+def test_rpca_5x5_golden(eng, golden):                               # test/runtests.jl:141-169
+    g = golden["rpca_5x5"]
+    D = np.array(g["D"])
+    A, E, s, sv = eng.rpca(D, nonnegE=True, nonnegA=True)
+    assert np.allclose(A, np.array(g["A"]), rtol=0, atol=g["atol"])
+    assert np.allclose(E, np.array(g["E"]), rtol=0, atol=g["atol"])
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+    A, E, s, sv = eng.rpca(D)
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+
+
+def _compare_with_oracle(eng, D, tolA=1e-8, **kw):
+    from oracle import rpca_oracle as O
+    Ao, Eo, so, svo, io = O.rpca(D, **kw)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+    assert rep.iters_done == io.iters_done, (rep.iters_done, io.iters_done)
+    assert rep.svp_hist == io.svp_hist
+    assert sv == svo
+    assert rep.converged == io.converged
+    assert np.allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=0)
+    assert relerr(A, Ao) <= tolA, relerr(A, Ao)
+    assert relerr(E, Eo) <= tolA, relerr(E, Eo)
+    d = min(D.shape)
+    assert np.allclose(s.S[:d], so[1][:d], rtol=1e-9, atol=1e-9 * so[1][0])
+    return A, E, s, sv, rep
+
+
+def test_rpca_c1_vs_oracle(eng):
+    """BASELINE config 1: 500x50 fp64, rank 5, 5% sparse."""
+    from oracle import rpca_oracle as O
+    D, A0, S0 = O.synth_lowrank_sparse(500, 50, 5, seed=0)
+    A, E, s, sv, rep = _compare_with_oracle(eng, D)
+    assert sv == 5 and rep.converged
+    assert relerr(A, A0) < 1e-6
+    # returned SVD object: U S Vt reproduces the last Z's dominant part, U has orthonormal columns
+    r = sv
+    U, S, Vt = s.U[:, :r], s.S[:r], s.Vt[:r, :]
+    assert np.max(np.abs(U.T @ U - np.eye(r))) < 1e-10
+    assert np.max(np.abs(Vt @ Vt.T - np.eye(r))) < 1e-12
+
+
+def test_rpca_shrunken_c2_vs_oracle(eng):
+    from oracle import rpca_oracle as O
+    D, A0, _ = O.synth_lowrank_sparse(2000, 128, 8, seed=1)
+    A, E, s, sv, rep = _compare_with_oracle(eng, D)
+    assert sv == 8
+
+
+def test_rpca_flags_vs_oracle(eng):
+    from oracle import rpca_oracle as O
+    D, _, _ = O.synth_lowrank_sparse(300, 40, 4, seed=2)
+    _compare_with_oracle(eng, D, nukeA=False)
+    _compare_with_oracle(eng, np.abs(D), nonnegA=True, nonnegE=True)
+    _compare_with_oracle(eng, D, lam=0.08, rho=1.3, tol=1e-6)
+    _compare_with_oracle(eng, D.T.copy())                            # wide matrix, M < N
+
+
+def test_rpca_maxiter_warns(eng):
+    from oracle import rpca_oracle as O
+    D, _, _ = O.synth_lowrank_sparse(200, 30, 3, seed=3)
+    with pytest.warns(UserWarning, match="Maximum number of iterations reached"):
+        A, E, s, sv, rep = eng.rpca(D, iters=3, return_report=True)
+    assert rep.iters_done == 3 and not rep.converged
+    Ao, Eo, _, _, io = O.rpca(D, iters=3)
+    assert relerr(A, Ao) < 1e-9 and relerr(E, Eo) < 1e-9
+
+
+def test_rpca_hankel_flag_exact_hankel(eng):                         # test/runtests.jl:321-348
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(0)
+    wins, n = 0, 40
+    for _ in range(n):
+        y = rng.standard_normal(100)
+        H = O.hankel(y, 5)
+        A1, *_ = eng.rpca(H, nukeA=False)
+        A2, E2, *_ = eng.rpca(H, nukeA=False, hankel=True)
+        assert tlsq_amd.ishankel(A2) and tlsq_amd.ishankel(E2)       # exact
+        wins += np.mean((A2 - H) ** 2) < np.mean((A1 - H) ** 2)
+    assert wins / n > 0.7
+    y = rng.standard_normal(1000)
+    H = O.hankel(y, 50)
+    A2, E2, *_ = eng.rpca(H, nukeA=False, hankel=True)
+    assert tlsq_amd.ishankel(A2) and tlsq_amd.ishankel(E2)
+
+
+def test_rpca_unsupported_paths_fail_loudly(eng):
+    import tlsq_amd
+    with pytest.raises(tlsq_amd.TlsqError):
+        eng.rpca(np.ones((4, 4)) * (1 + 1j))
+    with pytest.raises(tlsq_amd.TlsqError):
+        eng.rpca(np.ones((4, 4)), svd=lambda Z, k: None)
+
+
+# --------------------------------------------------------------------------------------------
+# lowrankfilter / tls / rtls
+# --------------------------------------------------------------------------------------------
+def test_lowrankfilter_vs_oracle_and_thresholds(eng):                # test/runtests.jl:378-381,401-405
+    from oracle import rpca_oracle as O
+    T = 1000
+    y = np.sin(0.1 * np.arange(1, T + 1))
+    y = y / np.quantile(np.abs(y), 0.9)
+    rng = np.random.default_rng(0)
+    n = 20 * rng.standard_normal(T) * (rng.random(T) < 0.01) + 0.1 * rng.standard_normal(T)
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+    yf, rep = eng.lowrankfilter(y + n, return_report=True)
+    yo = O.lowrankfilter(y + n)
+    assert relerr(yf, yo) < 1e-8
+    assert np.mean((y - qn(yf)) ** 2) / np.mean(n ** 2) < 0.001
+    n2 = rng.standard_normal(T)
+    yf2 = eng.lowrankfilter(y + n2, sv=2)
+    assert relerr(yf2, O.lowrankfilter(y + n2, sv=2)) < 1e-8
+    assert np.mean((y - qn(yf2)) ** 2) / np.mean(n2 ** 2) < 0.05
+    # multi-channel, lag 2
+    yy = np.column_stack([np.sin(0.1 * np.arange(T)), np.sin(0.3 * np.arange(T))]) + 0.1 * rng.standard_normal((T, 2))
+    assert relerr(eng.lowrankfilter(yy, 20, lag=2), O.lowrankfilter(yy, 20, lag=2)) < 1e-8
+
+
+def test_missing_values(eng):                                        # test/runtests.jl:172-185
+    rng = np.random.default_rng(0)
+    res = []
+    for _ in range(8):
+        N = 500
+        y = np.sin(0.1 * np.arange(1, N + 1)) + 0.1 * rng.standard_normal(N)
+        yn = y + (rng.random(N) < 0.1) * 1e2
+        yf = eng.lowrankfilter(yn, 40)
+        res.append(np.mean((y - yf) ** 2) / np.mean(y ** 2))
+    assert np.mean(res) < 0.025
+
+
+def test_tls_and_rtls(eng):                                          # test/runtests.jl:43, 221-235
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(3)
+    A = rng.standard_normal((50, 3))
+    An = A + rng.standard_normal(A.shape)
+    yn = A @ x + 0.01 * rng.standard_normal(50)
+    xt = eng.tls_(np.column_stack([An, yn]), 3)[:, 0]
+    assert np.allclose(xt, O.tls(An, yn), rtol=1e-9, atol=1e-11)
+    wins, n = 0, 40
+    for _ in range(n):
+        x = rng.standard_normal(3)
+        A = rng.standard_normal((50, 3))
+        An = A + 50 * rng.standard_normal(A.shape) * (rng.random(A.shape) < 0.1)
+        y = A @ x
+        yn = y + 50 * rng.standard_normal(50) * (rng.random(50) < 0.1)
+        xr = eng.rtls(An, yn)
+        xo = O.rtls(An, yn)
+        assert np.allclose(xr, xo, rtol=1e-6, atol=1e-8)
+        xt = eng.tls_(np.column_stack([An, yn]), 3)[:, 0]
+        wins += np.linalg.norm(x - xr) < np.linalg.norm(x - xt)
+    assert wins / n > 0.8
+    # tls!(s::SVD, n) on the SVD returned by rpca
+    AA = np.column_stack([An, yn])
+    _, _, s, _ = eng.rpca(AA, nukeA=False)
+    assert np.allclose(eng.tls_(s, 3)[:, 0], xr, rtol=1e-10, atol=1e-12)
+
+
+# --------------------------------------------------------------------------------------------
+# full BASELINE size (config 2): size-independent properties (the oracle takes minutes here)
+# --------------------------------------------------------------------------------------------
+def test_rpca_c2_full_size_properties(eng):
+    from oracle import rpca_oracle as O
+    M, N, r = 20000, 512, 16
+    D, A0, S0 = O.synth_lowrank_sparse(M, N, r, seed=0)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False)
+    assert rep.converged and sv == r
+    assert all(v == r for v in rep.svp_hist[5:])
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+    assert relerr(A, A0) < 1e-6                                       # exact recovery regime
+    assert np.linalg.matrix_rank(A[:2000], tol=1e-6 * s.S[0]) == r
+    assert np.mean((E != 0) == (S0 != 0)) > 0.999
+    # idempotence-like property: running on the recovered D' = A + E gives the same split
+    A2, E2, *_ = eng.rpca(A + E, want_U=False)
+    assert relerr(A2, A) < 1e-6

@@ -1,0 +1,11 @@
+"""tlsq-hip: MI355X-native robust PCA / low-rank recovery (drop-in for the rpca / lowrankfilter /
+tls! / rtls path of baggepinnen/TotalLeastSquares.jl).  See DESIGN.md and INTEGRATION.md.
+
+The directory name contains a dot, so import it through the repo-root shim:  `import tlsq_amd`.
+"""
+from . import _lib  # noqa: F401
+from .engine import (SVD, Engine, TlsqError, default_engine, hankel, ishankel, lowrankfilter, rpca,  # noqa: F401
+                     rtls, soft_hankel_, tls_, unhankel)
+
+__all__ = ["SVD", "Engine", "TlsqError", "default_engine", "hankel", "ishankel", "lowrankfilter", "rpca",
+           "rtls", "soft_hankel_", "tls_", "unhankel"]

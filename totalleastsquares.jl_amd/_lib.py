@@ -1,0 +1,109 @@
+"""ctypes binding of libtlsqhip.so — mirrors include/tlsq.h one to one.
+
+There is deliberately no fallback: if the shared object is missing or a GPU call fails, an exception
+is raised (the product path never routes through oracle/ or any CPU implementation).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtlsqhip.so")
+
+TLSQ_OK, TLSQ_MAXITER = 0, 1
+TLSQ_ERR_ARG, TLSQ_ERR_HIP, TLSQ_ERR_OOM, TLSQ_ERR_COMM, TLSQ_ERR_UNSUPPORTED, TLSQ_ERR_NOCONV = -1, -2, -3, -4, -5, -6
+MEM_HOST, MEM_DEVICE = 0, 1
+SVD_FULL, SVD_RANDOMIZED = 0, 1
+OPNORM_EXACT, OPNORM_POWER = 0, 1
+UNIQUE_ID_BYTES = 128
+
+ON_ITER = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_int64, C.c_void_p)
+
+
+class RpcaOpts(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("maxrank", C.c_int64), ("iters", C.c_int64),
+                ("tol", C.c_double), ("rho", C.c_double),
+                ("nonnegA", C.c_int32), ("nonnegE", C.c_int32), ("hankel", C.c_int32),
+                ("nukeA", C.c_int32), ("svd_mode", C.c_int32), ("opnorm_mode", C.c_int32),
+                ("opnorm_mvps", C.c_int32), ("memory", C.c_int32),
+                ("m_global", C.c_int64), ("seed", C.c_uint64),
+                ("on_iter", ON_ITER), ("user", C.c_void_p)]
+
+
+class RpcaInfo(C.Structure):
+    _fields_ = [("iters_done", C.c_int64), ("converged", C.c_int32), ("reserved", C.c_int32),
+                ("final_cost", C.c_double), ("final_mu", C.c_double), ("d_norm", C.c_double),
+                ("cost_hist", C.POINTER(C.c_double)), ("svp_hist", C.POINTER(C.c_int64)),
+                ("hist_capacity", C.c_int64), ("jacobi_sweeps", C.c_int64),
+                ("ms_total", C.c_double), ("ms_loop", C.c_double), ("ms_h2d", C.c_double),
+                ("ms_d2h", C.c_double), ("ms_shrink", C.c_double), ("ms_update", C.c_double),
+                ("ms_gram", C.c_double), ("ms_eig", C.c_double), ("ms_rebuild", C.c_double),
+                ("ms_opnorm", C.c_double)]
+
+
+# every symbol include/tlsq.h declares (tests check that the .so exports all of them)
+EXPORTS = [
+    "tlsq_version", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_destroy", "tlsq_last_error",
+    "tlsq_stream", "tlsq_synchronize", "tlsq_comm_unique_id", "tlsq_comm_init", "tlsq_comm_destroy",
+    "tlsq_rpca_f64", "tlsq_rpca_f32",
+    "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
+    "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
+    "tlsq_lowrankfilter_f64", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
+    "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
+    "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64",
+    "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64",
+]
+
+_lib = None
+
+
+def load():
+    """Load libtlsqhip.so; raises if it has not been built (python totalleastsquares.jl_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing — build it with `python totalleastsquares.jl_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl, flt = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_float
+    P = C.POINTER
+    lib.tlsq_version.restype = C.c_char_p
+    lib.tlsq_rpca_opts_default.argtypes = [P(RpcaOpts)]
+    lib.tlsq_rpca_opts_default.restype = None
+    lib.tlsq_create.argtypes = [i32, P(vp)]
+    lib.tlsq_destroy.argtypes = [vp]
+    lib.tlsq_last_error.argtypes = [vp]
+    lib.tlsq_last_error.restype = C.c_char_p
+    lib.tlsq_stream.argtypes = [vp]
+    lib.tlsq_stream.restype = vp
+    lib.tlsq_synchronize.argtypes = [vp]
+    lib.tlsq_comm_unique_id.argtypes = [C.c_char_p]
+    lib.tlsq_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
+    lib.tlsq_comm_destroy.argtypes = [vp]
+    lib.tlsq_rpca_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, i64, vp,
+                                  vp, i64, P(i64), P(RpcaInfo)]
+    lib.tlsq_rpca_f32.argtypes = lib.tlsq_rpca_f64.argtypes
+    for suf, sc in (("f64", dbl), ("f32", flt)):
+        getattr(lib, "tlsq_hankel_" + suf).argtypes = [vp, vp, i64, i64, i64, i64, i64, vp, i64, i32]
+        getattr(lib, "tlsq_unhankel_" + suf).argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, vp, i64, i32]
+        getattr(lib, "tlsq_soft_hankel_" + suf).argtypes = [vp, vp, i64, i64, i64, sc, i32]
+        getattr(lib, "tlsq_k_shrink_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, sc, i32]
+        getattr(lib, "tlsq_k_update_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, i32]
+    lib.tlsq_lowrankfilter_f64.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, P(RpcaOpts), vp, i64,
+                                           P(RpcaInfo)]
+    lib.tlsq_tls_f64.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64, i32]
+    lib.tlsq_rtls_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, P(RpcaOpts), vp, i64, P(RpcaInfo)]
+    lib.tlsq_tls_from_vt_f64.argtypes = [vp, i64, i64, i64, vp, i64]
+    lib.tlsq_k_gram_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]
+    lib.tlsq_k_gemm_nn_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
+    lib.tlsq_k_gemm_nt_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
+    lib.tlsq_k_symeig_f64.argtypes = [vp, vp, i64, i64, vp, vp, i64, P(i64)]
+    lib.tlsq_k_opnorm_f64.argtypes = [vp, vp, i64, i64, i64, P(dbl)]
+    lib.tlsq_k_maxabs_f64.argtypes = [vp, vp, i64, P(dbl)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        if name not in ("tlsq_version", "tlsq_last_error", "tlsq_stream", "tlsq_rpca_opts_default"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib

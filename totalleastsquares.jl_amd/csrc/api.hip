@@ -1,0 +1,1019 @@
+// Host side of libtlsqhip.so: handle/workspace management, the inexact-ALM driver for rpca
+// (src/robustPCA.jl:156-239 under /root/reference), lowrankfilter (:119-128), tls!/rtls
+// (src/TotalLeastSquares.jl:63-69,152-156), the RCCL row-shard exchange, and the C ABI of include/tlsq.h.
+// All arithmetic on M x N data runs in the HIP kernels of sweeps.hip / gemm.hip / jacobi.hip /
+// hankel.hip; the host only does O(N) bookkeeping (rank count, sort, the q x q TLS partition solve).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "common.hpp"
+
+namespace tlsq {
+
+// ------------------------------------------------------------------------------------------------
+// errors / workspace
+// ------------------------------------------------------------------------------------------------
+int set_err(Handle* h, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+int ws_get(Handle* h, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    DevBuf& b = h->ws[slot];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            TLSQ_HIP(h, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = (bytes + 255) & ~size_t(255);
+        TLSQ_HIP(h, hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL (loaded lazily; single-GPU use never touches it)
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static bool rccl_load() {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return false;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        dlclose(lib);
+        return false;
+    }
+    g_rccl.lib = lib;
+    return true;
+}
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+};
+
+#define TLSQ_NCCL(h, expr)                                                                     \
+    do {                                                                                       \
+        ncclResult_t _r = (expr);                                                              \
+        if (_r != ncclSuccess)                                                                 \
+            return set_err((h), TLSQ_ERR_COMM, "%s failed: %s", #expr,                         \
+                           g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error"); \
+    } while (0)
+
+// in-place sum of an N x N Gram over the row shards (the one real exchange of the path)
+static int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
+    if (h->nranks <= 1 || !h->comm) return TLSQ_OK;
+    TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
+    return TLSQ_OK;
+}
+
+static int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op) {
+    if (h->nranks <= 1 || !h->comm) return TLSQ_OK;
+    void* slot;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
+    double* d = reinterpret_cast<double*>(reinterpret_cast<char*>(slot) + 256);
+    TLSQ_HIP(h, hipMemcpyAsync(d, v, 8, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(comm_allreduce(h, d, 1, op));
+    TLSQ_HIP(h, hipMemcpyAsync(v, d, 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+static int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                  int64_t cols, size_t esz, hipMemcpyKind kind) {
+    if (rows <= 0 || cols <= 0) return TLSQ_OK;
+    if (ldd == rows && lds == rows) {
+        TLSQ_HIP(h, hipMemcpyAsync(dst, src, (size_t)rows * cols * esz, kind, h->stream));
+    } else {
+        TLSQ_HIP(h, hipMemcpy2DAsync(dst, (size_t)ldd * esz, src, (size_t)lds * esz, (size_t)rows * esz,
+                                     (size_t)cols, kind, h->stream));
+    }
+    return TLSQ_OK;
+}
+
+struct PhaseTimer {
+    Handle* h;
+    bool on;
+    int n = 0;
+    explicit PhaseTimer(Handle* hh, bool enable) : h(hh), on(enable) {}
+    void mark() {
+        if (on && n < 16) (void)hipEventRecord(h->ev[n++], h->stream);
+    }
+    // call after a stream sync; adds elapsed(ev[i], ev[i+1]) to *acc[i]
+    void collect(double** acc) {
+        if (!on) {
+            n = 0;
+            return;
+        }
+        for (int i = 0; i + 1 < n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess && acc[i]) *acc[i] += ms;
+        }
+        n = 0;
+    }
+};
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// sigma_max via Gram + eigenvalues only.  Z: device M x N (ld). uses WS_G, WS_B, WS_LAM.
+static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double* out,
+                       int64_t* sweeps) {
+    void *G, *B, *lam;
+    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
+    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    int64_t sw = 0;
+    TLSQ_TRY(symeig_f64(h, (const double*)G, N, N, (double*)B, nullptr, false, (double*)lam, &sw));
+    if (sweeps) *sweeps += sw;
+    std::vector<double> hl((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double mx = 0.0;
+    for (double v : hl) mx = v > mx ? v : mx;
+    *out = std::sqrt(mx);
+    return TLSQ_OK;
+}
+
+// Decomposition of the Gram of Z: V (device, N x N), sigma (host, unsorted), order (descending)
+struct SmallSvd {
+    std::vector<double> sigma;  // per column of V
+    std::vector<int32_t> order; // indices sorted by sigma descending
+};
+
+static int svd_via_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
+                        SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
+    void *G, *B, *V, *lam;
+    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
+    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    if (pt) pt->mark();
+    int64_t sw = 0;
+    TLSQ_TRY(symeig_f64(h, (const double*)G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw));
+    if (sweeps) *sweeps += sw;
+    s.sigma.resize((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto& v : s.sigma) v = std::sqrt(v);
+    s.order.resize((size_t)N);
+    std::iota(s.order.begin(), s.order.end(), 0);
+    std::stable_sort(s.order.begin(), s.order.end(),
+                     [&](int32_t a, int32_t b) { return s.sigma[a] > s.sigma[b]; });
+    *V_out = (double*)V;
+    return TLSQ_OK;
+}
+
+// Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'   with r = sel.size() columns
+static int rebuild_lowrank(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
+                           const double* V, const std::vector<int32_t>& sel,
+                           const std::vector<double>& g, double* Aout, int64_t ldA) {
+    const int64_t r = (int64_t)sel.size();
+    if (r == 0) {  // svp = 0  =>  A = 0 (mul! with inner dimension 0, src/robustPCA.jl:207-208)
+        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * 8, 0, (size_t)M * 8, (size_t)N, h->stream));
+        return TLSQ_OK;
+    }
+    void *Vg, *Vs, *T, *aux;
+    TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * r * 8, &Vg));
+    TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
+    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T));
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
+    int32_t* dsel = (int32_t*)aux;
+    double* dg = (double*)((char*)aux + ((r * 4 + 7) / 8) * 8);
+    TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)r * 4, hipMemcpyHostToDevice, h->stream));
+    TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)r * 8, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
+    // T (M x r) = Z * Vg
+    TLSQ_TRY(gemm_f64(h, true, false, (const double*)Vg, N, Z, ldZ, (double*)T, M, r, M, N, false));
+    // A (M x N) = T * Vs'
+    TLSQ_TRY(gemm_f64(h, false, false, (const double*)Vs, N, (const double*)T, M, Aout, ldA, N, M, r,
+                      false));
+    // the async H2D above read from `sel`/`g` host vectors: make sure they are consumed before return
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+struct ResolvedOpts {
+    double lambda, tol, rho;
+    int64_t maxrank, iters, m_global;
+    bool nonnegA, nonnegE, hankel, nukeA;
+};
+
+static ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {
+    ResolvedOpts r;
+    r.m_global = (o && o->m_global > 0) ? o->m_global : M;
+    const int64_t mx = std::max(r.m_global, N);
+    r.lambda = (o && !std::isnan(o->lambda)) ? o->lambda : 1.0 / std::sqrt((double)mx);  // :157
+    r.maxrank = (o && o->maxrank > 0) ? o->maxrank : std::numeric_limits<int64_t>::max();  // :158
+    r.iters = (o && o->iters > 0) ? o->iters : 1000;                                     // :159
+    r.tol = (o && !std::isnan(o->tol)) ? o->tol : default_tol;                           // :160
+    r.rho = (o && !std::isnan(o->rho)) ? o->rho : 1.5;                                   // :161
+    r.nonnegA = o && o->nonnegA;
+    r.nonnegE = o && o->nonnegE;
+    r.hankel = o && o->hankel;
+    r.nukeA = o ? (o->nukeA != 0) : true;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the ALM loop on device-resident, contiguous (ld = M) panels D, A, E.
+// Vt_host (d x N, ld d) / S_host (d) / U_dev (M x d, ld M) optional.
+// ------------------------------------------------------------------------------------------------
+static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                     const tlsq_rpca_opts* opts, double* A, double* E, double* U_dev, double* S_host,
+                     double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info) {
+    const int64_t n = M * N;
+    const bool timing = info != nullptr;
+    void *Yv, *Zv, *Rv;
+    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * 8, &Yv));
+    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * 8, &Zv));
+    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * 8, &Rv));
+    double *Y = (double*)Yv, *Z = (double*)Zv, *R = (double*)Rv;
+    int64_t sweeps = 0;
+
+    // ---- setup, src/robustPCA.jl:171-184 ----
+    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 8, h->stream));  // :174
+    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 8, h->stream));
+    double norm2 = 0.0;
+    TLSQ_TRY(opnorm_gram(h, D, M, N, M, &norm2, &sweeps));         // :177 opnorm(Y), Y = copy(D)
+    double maxabs = 0.0;
+    TLSQ_TRY(launch_maxabs<double>(h, D, n, &maxabs));             // :178 norm(Y, Inf)
+    TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
+    const double lam = ro.lambda;
+    const double norminf = maxabs / lam;
+    const double dual_norm = std::max(norm2, norminf);             // :179
+    const double d_norm = norm2;                                   // :180
+    TLSQ_TRY(launch_div_scalar<double>(h, D, Y, n, dual_norm));    // :181
+    double mu = 1.25 / norm2;                                      // :182
+    const double mubar = mu * 1.0e7;                               // :183
+    int64_t sv = 10, svp = 10;                                     // :184
+    if (info) {
+        info->d_norm = d_norm;
+        info->iters_done = 0;
+        info->converged = 0;
+    }
+    SmallSvd s;
+    double* V = nullptr;
+    double cost = std::numeric_limits<double>::quiet_NaN();
+    bool converged = false;
+    void* meanws = nullptr;
+    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * 8, &meanws));
+
+    PhaseTimer pt(h, timing);
+    double zero_sink = 0.0;
+    double* acc[8] = {info ? &info->ms_shrink : &zero_sink, info ? &info->ms_gram : &zero_sink,
+                      info ? &info->ms_eig : &zero_sink,    info ? &info->ms_rebuild : &zero_sink,
+                      info ? &info->ms_update : &zero_sink, info ? &info->ms_opnorm : &zero_sink,
+                      nullptr,                              nullptr};
+    const double t_loop0 = now_ms();
+    int64_t k = 0;
+    for (k = 1; k <= ro.iters; ++k) {                              // :186
+        const double inv_mu = 1.0 / mu;
+        const double thr = lam / mu;
+        pt.mark();
+        TLSQ_TRY(launch_shrink<double>(h, D, A, Y, E, Z, n, inv_mu, thr, ro.nonnegE ? 1 : 0));  // :188-192
+        pt.mark();
+        TLSQ_TRY(svd_via_gram(h, Z, M, N, M, &V, s, &sweeps, &pt));                           // :193-194
+        pt.mark();
+        svp = 0;                                                   // :198
+        for (int64_t i = 0; i < N; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> g((size_t)svp);
+        for (int64_t p = 0; p < svp; ++p) {
+            sel[p] = s.order[p];
+            const double sg = s.sigma[sel[p]];
+            g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+        }
+        TLSQ_TRY(rebuild_lowrank(h, Z, M, N, M, V, sel, g, A, M));
+        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<double>(h, A, M, N, M, thr, (double*)meanws));  // :214-216
+        pt.mark();
+        TLSQ_TRY(launch_update<double>(h, D, A, E, Y, R, n, mu, ro.nonnegA ? 1 : 0));         // :217-222
+        pt.mark();
+        mu = std::min(mu * ro.rho, mubar);                         // :223
+        double rn = 0.0;
+        TLSQ_TRY(opnorm_gram(h, R, M, N, M, &rn, &sweeps));        // :225
+        pt.mark();
+        cost = rn / d_norm;
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        pt.collect(acc);
+        if (info) {
+            info->iters_done = k;
+            if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
+            if (info->svp_hist && k <= info->hist_capacity) info->svp_hist[k - 1] = svp;
+        }
+        if (opts && opts->on_iter) opts->on_iter(k, cost, svp, opts->user);  // :226
+        if (cost < ro.tol) {                                       // :228
+            converged = true;
+            break;
+        }
+    }
+    if (k > ro.iters) k = ro.iters;
+    if (ro.hankel) TLSQ_TRY(launch_soft_hankel<double>(h, E, M, N, M, lam / mu, (double*)meanws));  // :234-236
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_loop = now_ms() - t_loop0;
+        info->converged = converged ? 1 : 0;
+        info->final_cost = cost;
+        info->final_mu = mu;
+        info->jacobi_sweeps = sweeps;
+    }
+    if (sv_out) *sv_out = sv;
+
+    // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
+    const int64_t d = std::min(ro.m_global, N);
+    if (S_host && V)
+        for (int64_t p = 0; p < d; ++p) S_host[p] = s.sigma[s.order[p]];
+    if (Vt_host && V) {
+        std::vector<double> hv((size_t)N * N);
+        TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (int64_t p = 0; p < d; ++p) {
+            const double* col = hv.data() + (size_t)s.order[p] * N;
+            for (int64_t j = 0; j < N; ++j) Vt_host[p + j * ldVt] = col[j];
+        }
+    }
+    if (U_dev && V) {
+        // U = Z V diag(1/sigma); columns with sigma == 0 are returned as zeros
+        std::vector<int32_t> sel((size_t)d);
+        std::vector<double> g((size_t)d);
+        for (int64_t p = 0; p < d; ++p) {
+            sel[p] = s.order[p];
+            const double sg = s.sigma[sel[p]];
+            g[p] = sg > 0.0 ? 1.0 / sg : 0.0;
+        }
+        void *Vg, *aux;
+        TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * d * 8, &Vg));
+        TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)d * 16, &aux));
+        int32_t* dsel = (int32_t*)aux;
+        double* dg = (double*)((char*)aux + ((d * 4 + 7) / 8) * 8);
+        TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)d * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, d, (double*)Vg, nullptr));
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)Vg, N, Z, M, U_dev, M, d, M, N, false));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return converged ? TLSQ_OK : TLSQ_MAXITER;  // :232
+}
+
+static int check_handle(tlsq_handle h) { return h ? TLSQ_OK : TLSQ_ERR_ARG; }
+
+// solve X * V22 = -V21 for X (n x q); V = Vt' where Vt is (ncols x ncols, ldVt) — TotalLeastSquares.jl:65-69
+static int tls_partition_solve(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n, double* x,
+                               int64_t ldx) {
+    const int64_t q = ncols - n;
+    if (n <= 0 || q <= 0) return TLSQ_ERR_ARG;
+    // V[i][j] = Vt[j + i*ldVt].  V21 = V[0:n, n:], V22 = V[n:, n:]
+    // X V22 = -V21  <=>  V22' X' = -V21'.  Build M = V22' (q x q): M[a][b] = V22[b][a] = V[n+b][n+a] = Vt[(n+a) + (n+b)*ldVt]
+    std::vector<double> Mq((size_t)q * q), rhs((size_t)q * n);
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t b = 0; b < q; ++b) Mq[a * q + b] = Vt[(n + a) + (n + b) * ldVt];
+    // rhs[a][i] = -V21'[a][i] = -V21[i][a] = -V[i][n+a] = -Vt[(n+a) + i*ldVt]
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t i = 0; i < n; ++i) rhs[a * n + i] = -Vt[(n + a) + i * ldVt];
+    // LU with partial pivoting on Mq (row-major), applied to rhs
+    for (int64_t c = 0; c < q; ++c) {
+        int64_t piv = c;
+        double best = std::fabs(Mq[c * q + c]);
+        for (int64_t r2 = c + 1; r2 < q; ++r2)
+            if (std::fabs(Mq[r2 * q + c]) > best) best = std::fabs(Mq[r2 * q + c]), piv = r2;
+        if (piv != c) {
+            for (int64_t b = 0; b < q; ++b) std::swap(Mq[c * q + b], Mq[piv * q + b]);
+            for (int64_t i = 0; i < n; ++i) std::swap(rhs[c * n + i], rhs[piv * n + i]);
+        }
+        const double pv = Mq[c * q + c];
+        for (int64_t r2 = c + 1; r2 < q; ++r2) {
+            const double f = Mq[r2 * q + c] / pv;
+            if (f == 0.0) continue;
+            for (int64_t b = c; b < q; ++b) Mq[r2 * q + b] -= f * Mq[c * q + b];
+            for (int64_t i = 0; i < n; ++i) rhs[r2 * n + i] -= f * rhs[c * n + i];
+        }
+    }
+    for (int64_t c = q - 1; c >= 0; --c) {
+        for (int64_t i = 0; i < n; ++i) {
+            double v = rhs[c * n + i];
+            for (int64_t b = c + 1; b < q; ++b) v -= Mq[c * q + b] * rhs[b * n + i];
+            rhs[c * n + i] = v / Mq[c * q + c];
+        }
+    }
+    // rhs = X' (q x n)  ->  x[i + a*ldx] = X[i][a]
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = rhs[a * n + i];
+    return TLSQ_OK;
+}
+
+}  // namespace tlsq
+
+using namespace tlsq;
+
+// ---- Hankel family ------------------------------------------------------------------------------
+template <typename T>
+static int hankel_impl(tlsq_handle h, const T* x, int64_t Nx, int64_t Dch, int64_t ldx, int64_t L,
+                       int64_t lag, T* X, int64_t ldX, int memory) {
+    TLSQ_TRY(check_handle(h));
+    if (!x || !X || Nx <= 0 || Dch <= 0 || L <= 0 || lag <= 0 || ldx < Nx)
+        return set_err(h, TLSQ_ERR_ARG, "hankel: bad argument");
+    if (!(2 * L <= Nx))  // @assert L <= N/2   src/robustPCA.jl:79
+        return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
+    if (!(lag <= L))     // @assert lag <= L   src/robustPCA.jl:80
+        return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
+    const int64_t K = (Nx - L) / lag + 1;
+    if (ldX < K) return set_err(h, TLSQ_ERR_ARG, "hankel: ldX < K");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    if (memory == TLSQ_MEM_DEVICE) {
+        TLSQ_TRY(launch_hankel<T>(h, x, Nx, Dch, ldx, L, lag, X, ldX));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    void *dx, *dX;
+    TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * sizeof(T), &dx));
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)K * L * Dch * sizeof(T), &dX));
+    TLSQ_TRY(copy2d(h, dx, Nx, x, ldx, Nx, Dch, sizeof(T), hipMemcpyHostToDevice));
+    TLSQ_TRY(launch_hankel<T>(h, (const T*)dx, Nx, Dch, Nx, L, lag, (T*)dX, K));
+    TLSQ_TRY(copy2d(h, X, ldX, dX, K, K, L * Dch, sizeof(T), hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+template <typename T>
+static int unhankel_impl(tlsq_handle h, const T* A, int64_t K, int64_t LD, int64_t ldA, int64_t lag,
+                         int64_t Nx, int64_t Dch, T* y, int64_t ldy, int memory) {
+    TLSQ_TRY(check_handle(h));
+    if (!A || !y || K <= 0 || LD <= 0 || Dch <= 0 || lag <= 0 || ldA < K || Nx <= 0 || ldy < Nx ||
+        LD % Dch != 0)
+        return set_err(h, TLSQ_ERR_ARG, "unhankel: bad argument");
+    const int64_t L = LD / Dch;
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    if (memory == TLSQ_MEM_DEVICE) {
+        TLSQ_TRY(launch_unhankel<T>(h, A, K, L, Dch, ldA, lag, Nx, y, ldy));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    void *dA, *dy;
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)K * LD * sizeof(T), &dA));
+    TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * sizeof(T), &dy));
+    TLSQ_TRY(copy2d(h, dA, K, A, ldA, K, LD, sizeof(T), hipMemcpyHostToDevice));
+    TLSQ_TRY(launch_unhankel<T>(h, (const T*)dA, K, L, Dch, K, lag, Nx, (T*)dy, Nx));
+    TLSQ_TRY(copy2d(h, y, ldy, dy, Nx, Nx, Dch, sizeof(T), hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+template <typename T>
+static int soft_hankel_impl(tlsq_handle h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, int memory) {
+    TLSQ_TRY(check_handle(h));
+    if (!A || K <= 0 || L <= 0 || ldA < K) return set_err(h, TLSQ_ERR_ARG, "soft_hankel: bad argument");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    void* mws;
+    TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(K + L) * sizeof(T), &mws));
+    if (memory == TLSQ_MEM_DEVICE) {
+        TLSQ_TRY(launch_soft_hankel<T>(h, A, K, L, ldA, eps, (T*)mws));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    void* dA;
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)K * L * sizeof(T), &dA));
+    TLSQ_TRY(copy2d(h, dA, K, A, ldA, K, L, sizeof(T), hipMemcpyHostToDevice));
+    TLSQ_TRY(launch_soft_hankel<T>(h, (T*)dA, K, L, K, eps, (T*)mws));
+    TLSQ_TRY(copy2d(h, A, ldA, dA, K, K, L, sizeof(T), hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* tlsq_version(void) { return "tlsq-hip 0.1.0 (gfx950)"; }
+
+void tlsq_rpca_opts_default(tlsq_rpca_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->lambda = std::numeric_limits<double>::quiet_NaN();
+    o->tol = std::numeric_limits<double>::quiet_NaN();
+    o->rho = std::numeric_limits<double>::quiet_NaN();
+    o->maxrank = 0;
+    o->iters = 0;
+    o->nukeA = 1;
+    o->svd_mode = TLSQ_SVD_FULL;
+    o->opnorm_mode = TLSQ_OPNORM_EXACT;
+    o->opnorm_mvps = 10;
+    o->memory = TLSQ_MEM_HOST;
+}
+
+int tlsq_create(int device_id, tlsq_handle* out) {
+    if (!out) return TLSQ_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;  // no GPU: fail loudly
+    if (device_id < 0 || device_id >= ndev) return TLSQ_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return TLSQ_ERR_HIP;
+    tlsq_handle h = new (std::nothrow) tlsq_handle_s();
+    if (!h) return TLSQ_ERR_OOM;
+    h->device = device_id;
+    h->ws.resize(WS_COUNT);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return TLSQ_ERR_HIP;
+    }
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete h;
+            return TLSQ_ERR_HIP;
+        }
+    h->pinned_bytes = 1 << 16;
+    if (hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        return TLSQ_ERR_OOM;
+    }
+    *out = h;
+    return TLSQ_OK;
+}
+
+int tlsq_destroy(tlsq_handle h) {
+    if (!h) return TLSQ_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    tlsq_comm_destroy(h);
+    for (auto& b : h->ws)
+        if (b.p) (void)hipFree(b.p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return TLSQ_OK;
+}
+
+const char* tlsq_last_error(tlsq_handle h) { return h ? h->err.c_str() : "null handle"; }
+void* tlsq_stream(tlsq_handle h) { return h ? (void*)h->stream : nullptr; }
+int tlsq_synchronize(tlsq_handle h) {
+    TLSQ_TRY(check_handle(h));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+int tlsq_comm_unique_id(unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
+    if (!id) return TLSQ_ERR_ARG;
+    if (!rccl_load()) return TLSQ_ERR_COMM;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return TLSQ_ERR_COMM;
+    static_assert(sizeof(u) == TLSQ_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, TLSQ_UNIQUE_ID_BYTES);
+    return TLSQ_OK;
+}
+
+int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
+    TLSQ_TRY(check_handle(h));
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return set_err(h, TLSQ_ERR_ARG, "bad comm args");
+    tlsq_comm_destroy(h);
+    if (nranks == 1) {
+        h->nranks = 1;
+        h->rank = 0;
+        return TLSQ_OK;
+    }
+    if (!rccl_load()) return set_err(h, TLSQ_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, TLSQ_UNIQUE_ID_BYTES);
+    h->comm = new Comm();
+    ncclResult_t r = g_rccl.CommInitRank(&h->comm->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        delete h->comm;
+        h->comm = nullptr;
+        return set_err(h, TLSQ_ERR_COMM, "ncclCommInitRank failed: %s",
+                       g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    h->nranks = nranks;
+    h->rank = rank;
+    return TLSQ_OK;
+}
+
+int tlsq_comm_destroy(tlsq_handle h) {
+    if (!h) return TLSQ_OK;
+    if (h->comm) {
+        if (h->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm->comm);
+        delete h->comm;
+        h->comm = nullptr;
+    }
+    h->nranks = 1;
+    h->rank = 0;
+    return TLSQ_OK;
+}
+
+int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
+                  const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE, double* U,
+                  int64_t ldU, double* S, double* Vt, int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
+        return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    if (opts && opts->svd_mode != TLSQ_SVD_FULL)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: svd_mode RANDOMIZED is not built yet");
+    if (opts && opts->opnorm_mode != TLSQ_OPNORM_EXACT)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: opnorm_mode POWER is not built yet");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    if (info) {
+        double* ch = info->cost_hist;
+        int64_t* sh = info->svp_hist;
+        int64_t cap = info->hist_capacity;
+        memset(info, 0, sizeof(*info));
+        info->cost_hist = ch;
+        info->svp_hist = sh;
+        info->hist_capacity = cap;
+    }
+    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(std::numeric_limits<double>::epsilon()));
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const int64_t n = M * N;
+    const int64_t d = std::min(ro.m_global, N);
+    if (U && ldU < M) return set_err(h, TLSQ_ERR_ARG, "rpca: ldU < M");
+    if (Vt && ldVt < d) return set_err(h, TLSQ_ERR_ARG, "rpca: ldVt < min(M,N)");
+
+    const double* dD = D;
+    double *dA = A, *dE = E, *dU = U;
+    void* p;
+    double th = now_ms();
+    if (!dev || ldD != M) {
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * 8, &p));
+        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        dD = (const double*)p;
+    }
+    if (!dev || ldA != M) {
+        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * 8, &p));
+        dA = (double*)p;
+    }
+    if (!dev || ldE != M) {
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * 8, &p));
+        dE = (double*)p;
+    }
+    if (U && (!dev || ldU != M)) {
+        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * 8, &p));
+        dU = (double*)p;
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_h2d = now_ms() - th;
+
+    // S / Vt are small: always produced on the host, then copied if the caller's memory is on the device
+    std::vector<double> hS, hVt;
+    double* S_host = nullptr;
+    double* Vt_host = nullptr;
+    int64_t ldVt_host = d;
+    if (S) {
+        if (dev) {
+            hS.resize((size_t)d);
+            S_host = hS.data();
+        } else
+            S_host = S;
+    }
+    if (Vt) {
+        if (dev) {
+            hVt.resize((size_t)d * N);
+            Vt_host = hVt.data();
+        } else {
+            Vt_host = Vt;
+            ldVt_host = ldVt;
+        }
+    }
+    int status = rpca_core(h, dD, M, N, ro, opts, dA, dE, dU, S_host, Vt_host, ldVt_host, sv, info);
+    if (status < 0) return status;
+
+    th = now_ms();
+    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, 8, back));
+    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, 8, back));
+    if (U && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, 8, back));
+    if (dev && S) TLSQ_HIP(h, hipMemcpyAsync(S, hS.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+    if (dev && Vt) TLSQ_TRY(copy2d(h, Vt, ldVt, hVt.data(), d, d, N, 8, hipMemcpyHostToDevice));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_d2h = now_ms() - th;
+        info->ms_total = now_ms() - t0;
+    }
+    return status;
+}
+
+int tlsq_rpca_f32(tlsq_handle h, const float*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, float*,
+                  int64_t, float*, int64_t, float*, int64_t, float*, float*, int64_t, int64_t*,
+                  tlsq_rpca_info*) {
+    TLSQ_TRY(check_handle(h));
+    return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_f32: the fp32 ALM loop is not built yet (fp32 sweeps/hankel are)");
+}
+
+// ---- Hankel family (templates hankel_impl/unhankel_impl/soft_hankel_impl live above extern "C") ----
+int tlsq_hankel_f64(tlsq_handle h, const double* x, int64_t Nx, int64_t Dch, int64_t ldx, int64_t L,
+                    int64_t lag, double* X, int64_t ldX, int memory) {
+    return hankel_impl<double>(h, x, Nx, Dch, ldx, L, lag, X, ldX, memory);
+}
+int tlsq_hankel_f32(tlsq_handle h, const float* x, int64_t Nx, int64_t Dch, int64_t ldx, int64_t L,
+                    int64_t lag, float* X, int64_t ldX, int memory) {
+    return hankel_impl<float>(h, x, Nx, Dch, ldx, L, lag, X, ldX, memory);
+}
+int tlsq_unhankel_f64(tlsq_handle h, const double* A, int64_t K, int64_t LD, int64_t ldA, int64_t lag,
+                      int64_t Nx, int64_t Dch, double* y, int64_t ldy, int memory) {
+    return unhankel_impl<double>(h, A, K, LD, ldA, lag, Nx, Dch, y, ldy, memory);
+}
+int tlsq_unhankel_f32(tlsq_handle h, const float* A, int64_t K, int64_t LD, int64_t ldA, int64_t lag,
+                      int64_t Nx, int64_t Dch, float* y, int64_t ldy, int memory) {
+    return unhankel_impl<float>(h, A, K, LD, ldA, lag, Nx, Dch, y, ldy, memory);
+}
+int tlsq_soft_hankel_f64(tlsq_handle h, double* A, int64_t K, int64_t L, int64_t ldA, double eps,
+                         int memory) {
+    return soft_hankel_impl<double>(h, A, K, L, ldA, eps, memory);
+}
+int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t ldA, float eps,
+                         int memory) {
+    return soft_hankel_impl<float>(h, A, K, L, ldA, eps, memory);
+}
+
+// ---- lowrankfilter: src/robustPCA.jl:119-128 -----------------------------------------------------
+int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy,
+                           int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts, double* yf,
+                           int64_t ldyf, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!y || !yf || Nx <= 0 || Dch <= 0 || ldy < Nx || ldyf < Nx)
+        return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: bad argument");
+    if (n <= 0) n = std::min<int64_t>(Nx / 20, 2000);  // :119
+    if (lag <= 0) lag = 1;
+    if (!(2 * n <= Nx)) return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
+    if (!(lag <= n)) return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
+    if (opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: randomized svd/opnorm modes are not built yet");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    if (info) {
+        double* ch = info->cost_hist;
+        int64_t* sh = info->svp_hist;
+        int64_t cap = info->hist_capacity;
+        memset(info, 0, sizeof(*info));
+        info->cost_hist = ch;
+        info->svp_hist = sh;
+        info->hist_capacity = cap;
+    }
+    const double t0 = now_ms();
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const int64_t K = (Nx - n) / lag + 1, LD = n * Dch;
+    void *dy, *H, *A, *E;
+    TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * 8, &dy));
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)K * LD * 8, &H));
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)K * LD * 8, &A));
+    TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    TLSQ_TRY(launch_hankel<double>(h, (const double*)dy, Nx, Dch, Nx, n, lag, (double*)H, K));  // :120
+    int status = TLSQ_OK;
+    if (sv <= 0) {                                                                            // :121-122
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)K * LD * 8, &E));
+        const ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
+        status = rpca_core(h, (const double*)H, K, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
+                           nullptr, 0, nullptr, info);
+        if (status < 0) return status;
+    } else {                                                                                  // :123-126
+        SmallSvd s;
+        double* V = nullptr;
+        int64_t sweeps = 0;
+        TLSQ_TRY(svd_via_gram(h, (const double*)H, K, LD, K, &V, s, &sweeps, nullptr));
+        const int64_t r = std::min<int64_t>(sv, std::min(K, LD));
+        std::vector<int32_t> sel((size_t)r);
+        std::vector<double> g((size_t)r, 1.0);
+        for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
+        TLSQ_TRY(rebuild_lowrank(h, (const double*)H, K, LD, K, V, sel, g, (double*)A, K));
+        if (info) info->jacobi_sweeps = sweeps;
+    }
+    // :127  (dy is reused for the filtered signal)
+    TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, K, lag, Nx, (double*)dy, Nx));
+    TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_total = now_ms() - t0;
+    return status;
+}
+
+// ---- tls! / rtls ---------------------------------------------------------------------------------
+int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n, double* x,
+                         int64_t ldx) {
+    if (!Vt || !x || ncols <= 0 || n <= 0 || n >= ncols || ldVt < ncols || ldx < n) return TLSQ_ERR_ARG;
+    return tls_partition_solve(Vt, ncols, ldVt, n, x, ldx);
+}
+
+// full right-singular basis of a device matrix (M x nc, ld) as Vt on the host (nc x nc)
+static int vt_of(tlsq_handle h, const double* dAy, int64_t M, int64_t nc, int64_t ld,
+                 std::vector<double>& Vt) {
+    SmallSvd s;
+    double* V = nullptr;
+    int64_t sweeps = 0;
+    TLSQ_TRY(svd_via_gram(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
+    std::vector<double> hv((size_t)nc * nc);
+    TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)nc * nc * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    Vt.resize((size_t)nc * nc);
+    for (int64_t p2 = 0; p2 < nc; ++p2)
+        for (int64_t j = 0; j < nc; ++j) Vt[p2 + j * nc] = hv[(size_t)s.order[p2] * nc + j];
+    return TLSQ_OK;
+}
+
+int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
+                 double* x, int64_t ldx, int memory) {
+    TLSQ_TRY(check_handle(h));
+    if (!Ay || !x || M <= 0 || ncols <= 1 || n <= 0 || n >= ncols || ldAy < M || ldx < n)
+        return set_err(h, TLSQ_ERR_ARG, "tls: bad argument");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double* dAy = Ay;
+    int64_t ld = ldAy;
+    if (memory != TLSQ_MEM_DEVICE) {
+        void* p;
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)M * ncols * 8, &p));
+        TLSQ_TRY(copy2d(h, p, M, Ay, ldAy, M, ncols, 8, hipMemcpyHostToDevice));
+        dAy = (const double*)p;
+        ld = M;
+    }
+    std::vector<double> Vt;
+    TLSQ_TRY(vt_of(h, dAy, M, ncols, ld, Vt));
+    const int64_t q = ncols - n;
+    if (memory == TLSQ_MEM_DEVICE) {
+        std::vector<double> hx((size_t)n * q);
+        int st = tls_partition_solve(Vt.data(), ncols, ncols, n, hx.data(), n);
+        if (st < 0) return set_err(h, st, "tls: partition solve failed");
+        TLSQ_TRY(copy2d(h, x, ldx, hx.data(), n, n, q, 8, hipMemcpyHostToDevice));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    int st = tls_partition_solve(Vt.data(), ncols, ncols, n, x, ldx);
+    if (st < 0) return set_err(h, st, "tls: partition solve failed");
+    return TLSQ_OK;
+}
+
+int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA, const double* y,
+                  int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, double* x, int64_t ldx,
+                  tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!A || !y || !x || M <= 0 || n <= 0 || q <= 0 || ldA < M || ldy < M || ldx < n)
+        return set_err(h, TLSQ_ERR_ARG, "rtls: bad argument");
+    if (opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rtls: randomized svd/opnorm modes are not built yet");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    if (info) {
+        double* ch = info->cost_hist;
+        int64_t* sh = info->svp_hist;
+        int64_t cap = info->hist_capacity;
+        memset(info, 0, sizeof(*info));
+        info->cost_hist = ch;
+        info->svp_hist = sh;
+        info->hist_capacity = cap;
+    }
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const int64_t nc = n + q;
+    void *AA, *Ah, *Eh;
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)M * nc * 8, &AA));
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)M * nc * 8, &Ah));
+    TLSQ_TRY(ws_get(h, WS_E, (size_t)M * nc * 8, &Eh));
+    const hipMemcpyKind kin = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    TLSQ_TRY(copy2d(h, AA, M, A, ldA, M, n, 8, kin));                                  // AA = [A y]  :153
+    TLSQ_TRY(copy2d(h, (double*)AA + (size_t)M * n, M, y, ldy, M, q, 8, kin));
+    ResolvedOpts ro = resolve(opts, M, nc, std::sqrt(std::numeric_limits<double>::epsilon()));
+    ro.nukeA = false;                                                                 // :154
+    std::vector<double> Vt((size_t)nc * nc, 0.0);
+    const int64_t d = std::min(ro.m_global, nc);
+    if (d < nc) return set_err(h, TLSQ_ERR_ARG, "rtls: needs M >= n+q");
+    int status = rpca_core(h, (const double*)AA, M, nc, ro, opts, (double*)Ah, (double*)Eh, nullptr,
+                           nullptr, Vt.data(), nc, nullptr, info);
+    if (status < 0) return status;
+    std::vector<double> hx((size_t)n * q);
+    int st = tls_partition_solve(Vt.data(), nc, nc, n, hx.data(), n);                 // :155
+    if (st < 0) return set_err(h, st, "rtls: partition solve failed");
+    if (dev) {
+        TLSQ_TRY(copy2d(h, x, ldx, hx.data(), n, n, q, 8, hipMemcpyHostToDevice));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    } else {
+        for (int64_t a = 0; a < q; ++a)
+            for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = hx[i + a * n];
+    }
+    return status;
+}
+
+// ---- kernel-level entry points (device pointers) ---------------------------------------------------
+int tlsq_k_shrink_f64(tlsq_handle h, const double* D, const double* A, const double* Y, double* E,
+                      double* Z, int64_t n, double inv_mu, double thr, int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    return launch_shrink<double>(h, D, A, Y, E, Z, n, inv_mu, thr, nonnegE);
+}
+int tlsq_k_update_f64(tlsq_handle h, const double* D, double* A, const double* E, double* Y, double* R,
+                      int64_t n, double mu, int nonnegA) {
+    TLSQ_TRY(check_handle(h));
+    return launch_update<double>(h, D, A, E, Y, R, n, mu, nonnegA);
+}
+int tlsq_k_shrink_f32(tlsq_handle h, const float* D, const float* A, const float* Y, float* E, float* Z,
+                      int64_t n, float inv_mu, float thr, int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    return launch_shrink<float>(h, D, A, Y, E, Z, n, inv_mu, thr, nonnegE);
+}
+int tlsq_k_update_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
+                      int64_t n, float mu, int nonnegA) {
+    TLSQ_TRY(check_handle(h));
+    return launch_update<float>(h, D, A, E, Y, R, n, mu, nonnegA);
+}
+int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
+                    int64_t ldG) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !G || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "gram: bad argument");
+    return gram_f64(h, Z, M, N, ldZ, G, ldG);
+}
+int tlsq_k_gemm_nn_f64(tlsq_handle h, const double* Z, int64_t M, int64_t K, int64_t ldZ, const double* W,
+                       int64_t Q, int64_t ldW, double* C, int64_t ldC) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !W || !C || ldZ < M || ldW < K || ldC < M) return set_err(h, TLSQ_ERR_ARG, "gemm_nn: bad argument");
+    return gemm_f64(h, true, false, W, ldW, Z, ldZ, C, ldC, Q, M, K, false);
+}
+int tlsq_k_gemm_nt_f64(tlsq_handle h, const double* T, int64_t M, int64_t K, int64_t ldT, const double* V,
+                       int64_t Q, int64_t ldV, double* C, int64_t ldC) {
+    TLSQ_TRY(check_handle(h));
+    if (!T || !V || !C || ldT < M || ldV < Q || ldC < M) return set_err(h, TLSQ_ERR_ARG, "gemm_nt: bad argument");
+    return gemm_f64(h, false, false, V, ldV, T, ldT, C, ldC, Q, M, K, false);
+}
+int tlsq_k_symeig_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam, double* V,
+                      int64_t ldV, int64_t* sweeps) {
+    TLSQ_TRY(check_handle(h));
+    if (!G || !lam || N <= 0 || ldG < N || (V && ldV < N)) return set_err(h, TLSQ_ERR_ARG, "symeig: bad argument");
+    void *B, *Vw, *lamw;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &Vw));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lamw));
+    int64_t sw = 0;
+    TLSQ_TRY(symeig_f64(h, G, N, ldG, (double*)B, (double*)Vw, V != nullptr, (double*)lamw, &sw));
+    if (sweeps) *sweeps = sw;
+    // sort descending on the host, permute V columns on the device
+    std::vector<double> hl((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lamw, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<int32_t> order((size_t)N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return hl[a] > hl[b]; });
+    std::vector<double> sorted((size_t)N);
+    for (int64_t i = 0; i < N; ++i) sorted[i] = hl[order[i]];
+    TLSQ_HIP(h, hipMemcpyAsync(lam, sorted.data(), (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (V) {
+        void *aux, *Vs;
+        TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)N * 16, &aux));
+        TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * N * 8, &Vs));
+        TLSQ_HIP(h, hipMemcpyAsync(aux, order.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(launch_gather_scale(h, (const double*)Vw, N, (const int32_t*)aux, nullptr, N, nullptr,
+                                     (double*)Vs));
+        TLSQ_TRY(copy2d(h, V, ldV, Vs, N, N, N, 8, hipMemcpyDeviceToDevice));
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+int tlsq_k_opnorm_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
+                      double* sigma_max) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !sigma_max || N <= 0 || ldZ < M) return set_err(h, TLSQ_ERR_ARG, "opnorm: bad argument");
+    return opnorm_gram(h, Z, M, N, ldZ, sigma_max, nullptr);
+}
+int tlsq_k_maxabs_f64(tlsq_handle h, const double* x, int64_t n, double* out) {
+    TLSQ_TRY(check_handle(h));
+    if (!x || !out) return set_err(h, TLSQ_ERR_ARG, "maxabs: bad argument");
+    return launch_maxabs<double>(h, x, n, out);
+}
+
+}  // extern "C"

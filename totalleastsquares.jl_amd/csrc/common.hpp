@@ -1,0 +1,117 @@
+// Internal declarations shared by the HIP translation units of libtlsqhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tlsq.h"
+
+namespace tlsq {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Comm;  // RCCL state (api.hip)
+
+struct Handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[16] = {};
+    std::string err;
+    // grow-only device workspace, keyed by slot
+    std::vector<DevBuf> ws;
+    // pinned host scratch for small readbacks
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    Comm* comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+}  // namespace tlsq
+
+struct tlsq_handle_s : tlsq::Handle {};
+
+namespace tlsq {
+
+int set_err(Handle* h, int code, const char* fmt, ...);
+
+#define TLSQ_HIP(h, expr)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return tlsq::set_err((h), _e == hipErrorOutOfMemory ? TLSQ_ERR_OOM : TLSQ_ERR_HIP, \
+                                 "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                                 __FILE__, __LINE__);                                       \
+    } while (0)
+
+#define TLSQ_TRY(expr)              \
+    do {                            \
+        int _s = (expr);            \
+        if (_s < 0) return _s;      \
+    } while (0)
+
+// workspace slot: returns a device pointer of at least `bytes` (grow-only, contents not preserved on growth)
+int ws_get(Handle* h, int slot, size_t bytes, void** out);
+
+enum WsSlot {
+    WS_D = 0, WS_A, WS_E, WS_Y, WS_Z, WS_R,      // M x N panels
+    WS_G, WS_B, WS_V, WS_VG, WS_VS, WS_T,        // N x N / M x r
+    WS_SLAB,                                     // split-K partial slabs
+    WS_SCAL,                                     // small scalars / counters
+    WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
+    WS_COUNT
+};
+
+// ---------------- sweeps.hip ----------------
+template <typename T>
+int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int64_t n, T inv_mu,
+                  T thr, int nonnegE);
+template <typename T>
+int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu, int nonnegA);
+// Y = D / s  (src/robustPCA.jl:181), contiguous n
+template <typename T>
+int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s);
+// out[0] = max |x_i|  (device scalar, as double bits in a uint64 slot)
+template <typename T>
+int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
+template <typename T>
+int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
+
+// ---------------- gemm.hip ----------------
+// Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j), i<P, j<Q, k<K
+//   A_KC: Aop(i,k) = A[k + i*lda]   else  A[i + k*lda]
+//   B_KC: Bop(k,j) = B[k + j*ldb]   else  B[j + k*ldb]
+// `splits`>1: deterministic split over K through slabs + fixed-order reduction.
+// `symmetric`: only tiles with ti>=tj are computed, the reduction mirrors (Gram).
+int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, const double* B,
+             int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
+int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
+
+// ---------------- jacobi.hip ----------------
+// One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal
+// columns, lam_dev[i] = ||B[:,i]|| (unsorted), V orthogonal (ld N) unless want_v == false.
+// B and V are workspace buffers owned by the caller (N*N each).
+int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
+               bool want_v, double* lam_dev, int64_t* sweeps_out);
+// Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
+int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
+                        const double* g_dev, int64_t r, double* Vg, double* Vs);
+
+// ---------------- hankel.hip ----------------
+template <typename T>
+int launch_hankel(Handle* h, const T* x, int64_t Nx, int64_t Dch, int64_t ldx, int64_t L,
+                  int64_t lag, T* X, int64_t ldX);
+template <typename T>
+int launch_unhankel(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA,
+                    int64_t lag, int64_t Nx, T* y, int64_t ldy);
+template <typename T>
+int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, T* mean_ws);
+
+}  // namespace tlsq

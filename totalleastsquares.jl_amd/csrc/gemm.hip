@@ -1,0 +1,241 @@
+// fp64 MFMA contractions of the rpca loop (gfx950, v_mfma_f64_16x16x4_f64):
+//   Gram        G = Z'Z            (stands in for LAPACK gesdd's work on Z, src/robustPCA.jl:194,225)
+//   rebuild     A = (Z Vg) Vs'     (the two mul! of src/robustPCA.jl:207-208 / 211-212)
+// One LDS-tiled kernel, 128x128x16 workgroup tile, 4 waves x (64x64 = 4x4 MFMA tiles), register-staged
+// double buffering (one barrier per K stage), XCD-aware block remap, deterministic split-K via slabs.
+//
+//   Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j)      (the contiguous output index j sits on the MFMA column)
+//     A_KC: Aop(i,k) = A[k + i*lda]   else  A[i + k*lda]
+//     B_KC: Bop(k,j) = B[k + j*ldb]   else  B[j + k*ldb]
+#include "common.hpp"
+
+namespace tlsq {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TI = 128, TJ = 128, TK = 16;
+constexpr int LDK = TK + 2;    // K-contiguous panel  [128][18]: (i*18 + k) distinct mod 32 over a half-wave
+constexpr int LDM = TI + 16;   // MN-contiguous panel [16][144]: (k*144 + i) distinct mod 32 over a half-wave
+constexpr int PANEL = 2304;    // doubles per panel (128*18 == 16*144)
+
+template <bool KC>
+__device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t ld, int64_t r0,
+                                           int64_t rmax, int64_t k0, int64_t kmax, double (&reg)[8]) {
+    const int t = threadIdx.x;
+    if (KC) {  // X[k + r*ld]: 16 consecutive k per r
+        const int k = t & 15, rr = t >> 4;
+        const int64_t kg = k0 + k;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int64_t r = r0 + rr + 16 * s;
+            reg[s] = (r < rmax && kg < kmax) ? X[kg + r * ld] : 0.0;
+        }
+    } else {  // X[r + k*ld]: 128 consecutive r per k
+        const int r = t & 127, kk = t >> 7;
+        const int64_t rg = r0 + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int64_t kg = k0 + kk + 2 * s;
+            reg[s] = (rg < rmax && kg < kmax) ? X[rg + kg * ld] : 0.0;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void panel_store(double* __restrict__ sm, const double (&reg)[8]) {
+    const int t = threadIdx.x;
+    if (KC) {
+        const int k = t & 15, rr = t >> 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sm[(rr + 16 * s) * LDK + k] = reg[s];
+    } else {
+        const int r = t & 127, kk = t >> 7;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sm[(kk + 2 * s) * LDM + r] = reg[s];
+    }
+}
+
+// element (r, k) of a panel, r in [0,128), k in [0,16)
+template <bool KC>
+__device__ __forceinline__ double panel_at(const double* __restrict__ sm, int r, int k) {
+    return KC ? sm[r * LDK + k] : sm[k * LDM + r];
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ B, int64_t ldb,
+                                                     double* __restrict__ C, int64_t ldc, int64_t P,
+                                                     int64_t Q, int64_t K, int64_t kchunk,
+                                                     int64_t slab_stride, int nti, int ntj,
+                                                     int symmetric) {
+    __shared__ double smem[4 * PANEL];  // A[2], B[2]
+    // XCD-aware remap: blocks b and b+8 share an XCD's L2 -> give every XCD a contiguous run of tiles
+    const int nb = nti * ntj;
+    const int cpx = (nb + 7) / 8;
+    const int lin = (int)(blockIdx.x % 8) * cpx + (int)(blockIdx.x / 8);
+    if (lin >= nb) return;
+    const int ti = lin % nti, tj = lin / nti;
+    if (symmetric && tj > ti) return;
+    const int z = blockIdx.y;
+    const int64_t kbeg = (int64_t)z * kchunk;
+    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    double* __restrict__ Cz = C + (int64_t)z * slab_stride;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double ra[8], rb[8];
+    const int64_t nstage = (kend > kbeg) ? (kend - kbeg + TK - 1) / TK : 0;
+    if (nstage > 0) {
+        panel_load<A_KC>(A, lda, i0, P, kbeg, kend, ra);
+        panel_load<B_KC>(B, ldb, j0, Q, kbeg, kend, rb);
+        panel_store<A_KC>(smem, ra);
+        panel_store<B_KC>(smem + 2 * PANEL, rb);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fk = lane >> 4;
+    // which 16-wide tiles of this wave hold any real row / column
+    bool liveA[4], liveB[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        liveA[a] = (i0 + wi * 64 + a * 16) < P;
+        liveB[a] = (j0 + wj * 64 + a * 16) < Q;
+    }
+
+    for (int64_t s = 0; s < nstage; ++s) {
+        const int cur = (int)(s & 1);
+        const bool more = (s + 1 < nstage);
+        if (more) {
+            const int64_t kn = kbeg + (s + 1) * TK;
+            panel_load<A_KC>(A, lda, i0, P, kn, kend, ra);
+            panel_load<B_KC>(B, ldb, j0, Q, kn, kend, rb);
+        }
+        const double* __restrict__ sa = smem + cur * PANEL;
+        const double* __restrict__ sb = smem + (2 + cur) * PANEL;
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 4) {
+            double fa[4], fb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                fa[a] = panel_at<A_KC>(sa, wi * 64 + a * 16 + fr, kk + fk);
+                fb[a] = panel_at<B_KC>(sb, wj * 64 + a * 16 + fr, kk + fk);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (!liveA[a]) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (!liveB[b]) continue;
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            panel_store<A_KC>(smem + (cur ^ 1) * PANEL, ra);
+            panel_store<B_KC>(smem + (2 + (cur ^ 1)) * PANEL, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column j = lane&15, rows i = (lane>>4) + 4*reg of each 16x16 tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t j = j0 + wj * 64 + b * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wi * 64 + a * 16 + fk + 4 * r;
+                if (i < P && j < Q) Cz[j + i * ldc] = acc[a][b][r];
+            }
+        }
+    }
+}
+
+// C[j + i*ldc] = sum_z slab[z][j + i*lds]   (fixed order -> deterministic);
+// symmetric: only tiles ti>=tj were computed, mirror into both triangles.
+__global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ slab, int64_t lds_,
+                                                     int64_t slab_stride, int nsplit,
+                                                     double* __restrict__ C, int64_t ldc, int64_t P,
+                                                     int64_t Q, int symmetric) {
+    const int64_t total = P * Q;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t j = e % Q, i = e / Q;
+        if (symmetric && (j / TJ) > (i / TI)) continue;
+        double s = 0.0;
+        for (int zz = 0; zz < nsplit; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
+        C[j + i * ldc] = s;
+        if (symmetric) C[i + j * ldc] = s;
+    }
+}
+
+static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q,
+                       int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric) {
+    const int nti = (int)((P + TI - 1) / TI), ntj = (int)((Q + TJ - 1) / TJ);
+    const int nb = nti * ntj;
+    const int cpx = (nb + 7) / 8;
+    dim3 grid(8 * cpx, nsplit), block(256);
+#define GO(AK, BK)                                                                                 \
+    hipLaunchKernelGGL((k_gemm_f64<AK, BK>), grid, block, 0, h->stream, A, lda, B, ldb, C, ldc, P, Q, \
+                       K, kchunk, slab_stride, nti, ntj, symmetric ? 1 : 0)
+    if (A_KC && B_KC) GO(true, true);
+    else if (A_KC && !B_KC) GO(true, false);
+    else if (!A_KC && !B_KC) GO(false, false);
+    else GO(false, true);
+#undef GO
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, const double* B,
+             int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric) {
+    if (P <= 0 || Q <= 0) return TLSQ_OK;
+    const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
+    const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
+    // split K so that the launch has >= ~256 workgroups (one per CU), each with >= 4 K stages
+    int64_t nsplit = 1;
+    if (tiles < 256) {
+        nsplit = (256 + tiles - 1) / tiles;
+        const int64_t maxsplit = (K + 4 * TK - 1) / (4 * TK);
+        if (nsplit > maxsplit) nsplit = maxsplit;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int64_t kchunk = (K + nsplit - 1) / nsplit;
+    kchunk = (kchunk + TK - 1) / TK * TK;
+    if (kchunk < TK) kchunk = TK;
+    nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
+    if (nsplit == 1 && !symmetric)
+        return launch_gemm(h, A_KC, B_KC, A, lda, B, ldb, C, ldc, P, Q, K, 1, kchunk, 0, false);
+    // slabs: nsplit x (P rows of Q contiguous)
+    const int64_t slab_stride = P * Q;
+    void* slab;
+    TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * sizeof(double), &slab));
+    TLSQ_TRY(launch_gemm(h, A_KC, B_KC, A, lda, B, ldb, (double*)slab, Q, P, Q, K, (int)nsplit, kchunk,
+                         slab_stride, symmetric));
+    int64_t g = (P * Q + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, Q,
+                       slab_stride, (int)nsplit, C, ldc, P, Q, symmetric ? 1 : 0);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG) {
+    if (M <= 0) {
+        TLSQ_HIP(h, hipMemset2DAsync(G, ldG * sizeof(double), 0, N * sizeof(double), N, h->stream));
+        return TLSQ_OK;
+    }
+    return gemm_f64(h, true, true, Z, ldZ, Z, ldZ, G, ldG, N, N, M, true);
+}
+
+}  // namespace tlsq

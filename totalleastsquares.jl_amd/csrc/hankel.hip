@@ -1,0 +1,132 @@
+// Hankel lag embedding, anti-diagonal averaging and soft_hankel! — pure HBM-bound index kernels.
+//   hankel       /root/reference/src/robustPCA.jl:76-92
+//   unhankel     /root/reference/src/robustPCA.jl:28-39 (lag==1,D==1) and :53-68 (general)
+//   soft_hankel! /root/reference/src/robustPCA.jl:9-21
+// Indices are computed arithmetically (the reference materialises an index-Hankel matrix, :60).
+// Every output sample sums its anti-diagonal sequentially in the reference's order (increasing
+// column index), so results match the reference's `mean` / scatter-add bit for bit.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace tlsq {
+
+// X[k + (d + Dch*l)*ldX] = x[(k*lag + l) + d*ldx]
+template <typename T>
+__global__ __launch_bounds__(256) void k_hankel(const T* __restrict__ x, int64_t ldx, int64_t K,
+                                                int64_t L, int64_t Dch, int64_t lag,
+                                                T* __restrict__ X, int64_t ldX) {
+    const int64_t c = blockIdx.y;  // column of X
+    const int64_t d = c % Dch, l = c / Dch;
+    const T* __restrict__ src = x + d * ldx + l;
+    T* __restrict__ dst = X + c * ldX;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += stride)
+        dst[k] = src[k * lag];
+}
+
+// y[n + d*ldy] = (sum_{l : (n-l)%lag==0, 0<=(n-l)/lag<K} A[(n-l)/lag + (d+Dch*l)*ldA]) / max(count,1)
+template <typename T>
+__global__ __launch_bounds__(256) void k_unhankel(const T* __restrict__ A, int64_t K, int64_t L,
+                                                  int64_t Dch, int64_t ldA, int64_t lag, int64_t Nx,
+                                                  T* __restrict__ y, int64_t ldy) {
+    const int64_t d = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < Nx; n += stride) {
+        T tot = T(0);
+        int64_t cnt = 0;
+        // l ranges over n - lag*k, k in [0,K): l >= 0, l < L
+        int64_t lmax = n < L - 1 ? n : L - 1;
+        if (lag == 1) {
+            int64_t lmin = n - (K - 1);
+            if (lmin < 0) lmin = 0;
+            for (int64_t l = lmin; l <= lmax; ++l) {
+                const T v = A[(n - l) + (d + Dch * l) * ldA];
+                tot = (cnt == 0) ? v : tot + v;
+                ++cnt;
+            }
+        } else {
+            for (int64_t l = n % lag; l <= lmax; l += lag) {
+                const int64_t k = (n - l) / lag;
+                if (k < K) {
+                    const T v = A[k + (d + Dch * l) * ldA];
+                    tot = (cnt == 0) ? v : tot + v;
+                    ++cnt;
+                }
+            }
+        }
+        y[n + d * ldy] = cnt > 0 ? tot / (T)cnt : T(0);
+    }
+}
+
+// A[k + l*ldA] = soft_th(A[k + l*ldA], eps, m[k+l]),  soft_th(x,e,m) = max(x-e,m) + min(x+e,m) - m
+template <typename T>
+__global__ __launch_bounds__(256) void k_soft_toward(T* __restrict__ A, int64_t K, int64_t ldA,
+                                                     const T* __restrict__ m, T eps) {
+    const int64_t l = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += stride) {
+        const T x = A[k + l * ldA];
+        const T mm = m[k + l];
+        const T a = x - eps, b = x + eps;
+        const T hi = (a > mm || a != a) ? a : mm;   // max(x-e, m)
+        const T lo = (b < mm || b != b) ? b : mm;   // min(x+e, m)
+        A[k + l * ldA] = (hi + lo) - mm;
+    }
+}
+
+static inline int gx(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    return (int)g;
+}
+
+template <typename T>
+int launch_hankel(Handle* h, const T* x, int64_t Nx, int64_t Dch, int64_t ldx, int64_t L,
+                  int64_t lag, T* X, int64_t ldX) {
+    const int64_t K = (Nx - L) / lag + 1;
+    const int64_t cols = L * Dch;
+    if (K <= 0 || cols <= 0) return TLSQ_OK;
+    if (cols > 65535)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "hankel: L*D=%lld exceeds 65535", (long long)cols);
+    hipLaunchKernelGGL((k_hankel<T>), dim3(gx(K), (unsigned)cols), dim3(256), 0, h->stream, x, ldx, K,
+                       L, Dch, lag, X, ldX);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_unhankel(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA,
+                    int64_t lag, int64_t Nx, T* y, int64_t ldy) {
+    if (Nx <= 0 || Dch <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_unhankel<T>), dim3(gx(Nx), (unsigned)Dch), dim3(256), 0, h->stream, A, K, L,
+                       Dch, ldA, lag, Nx, y, ldy);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, T* mean_ws) {
+    if (K <= 0 || L <= 0) return TLSQ_OK;
+    if (L > 65535)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "soft_hankel: L=%lld exceeds 65535", (long long)L);
+    // anti-diagonal means (length K+L-1), then shrink every element towards its diagonal's mean
+    TLSQ_TRY(launch_unhankel<T>(h, A, K, L, 1, ldA, 1, K + L - 1, mean_ws, K + L - 1));
+    hipLaunchKernelGGL((k_soft_toward<T>), dim3(gx(K), (unsigned)L), dim3(256), 0, h->stream, A, K,
+                       ldA, (const T*)mean_ws, eps);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+#define INST(T)                                                                                       \
+    template int launch_hankel<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t, T*, \
+                                  int64_t);                                                           \
+    template int launch_unhankel<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t,   \
+                                    int64_t, T*, int64_t);                                            \
+    template int launch_soft_hankel<T>(Handle*, T*, int64_t, int64_t, int64_t, T, T*);
+INST(double)
+INST(float)
+#undef INST
+
+}  // namespace tlsq

@@ -1,0 +1,292 @@
+// Small dense symmetric eigensolver: one-sided (Hestenes) block Jacobi, LDS-resident column pairs.
+//
+// Replaces the LAPACK work behind `LinearAlgebra.svd!(Z)` / `opnorm` (src/robustPCA.jl:194,225 under
+// /root/reference) once Z has been reduced to its N x N Gram matrix G = Z'Z:  the right singular
+// vectors of Z are the eigenvectors V of G and sigma_i = sqrt(lambda_i).
+//
+// Method: iterate on B = G*V (initially B = G, V = I).  A plane rotation of columns (p,q) of B and V
+// that makes B[:,p] _|_ B[:,q] is a Jacobi step on B'B = V'G^2V; at convergence the columns of B are
+// lambda_i * v_i, so ||B[:,i]|| = lambda_i.  Columns are grouped into blocks of b columns; one
+// workgroup owns a block pair per round (round-robin tournament over blocks), keeps its 2b columns of B
+// and of V in LDS (2b*N*16 bytes <= 160 KiB/CU), and runs a full inner tournament over those 2b
+// columns with one 64-lane wave per column pair (wave-shuffle reductions for the three dot products).
+// No two-sided row updates, no LAPACK, deterministic (fixed pair order, fixed reduction trees).
+#include "common.hpp"
+
+namespace tlsq {
+
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// round-robin tournament: pair `idx` of round `r` among n (even) players
+__device__ __forceinline__ void rr_pair(int n, int r, int idx, int& p, int& q) {
+    const int m = n - 1;
+    if (idx == 0) {
+        p = r % m;
+        q = m;
+    } else {
+        p = (r + idx) % m;
+        q = (r - idx + m) % m;
+    }
+}
+
+// params[0] = floor2 (squared column-norm noise floor)
+template <bool WANT_V>
+__global__ __launch_bounds__(512) void k_jacobi_round(double* __restrict__ B, double* __restrict__ V, int N, int b, int nblk,
+                               int round, double tol, const double* __restrict__ params,
+                               unsigned int* __restrict__ rot_count) {
+    // dynamic LDS only (keeps the base 16-byte aligned): sB[2b][N], sV[2b][N] (if WANT_V), rotation counter
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int nslot = 2 * b;
+    double* sB = sm;
+    double* sV = sm + (size_t)nslot * N;
+    unsigned int& s_rot = *reinterpret_cast<unsigned int*>(sm + (size_t)nslot * N * (WANT_V ? 2 : 1));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bp, bq;
+    rr_pair(nblk, round, blockIdx.x, bp, bq);
+    if (threadIdx.x == 0) s_rot = 0;
+
+    // ---- load the 2b columns (global column-major, ld = N) ----
+    for (int s = w; s < nslot; s += b) {
+        const int col = (s < b) ? bp * b + s : bq * b + (s - b);
+        if (col < N) {
+            for (int row = lane; row < N; row += 64) {
+                sB[(size_t)s * N + row] = B[(size_t)col * N + row];
+                if (WANT_V) sV[(size_t)s * N + row] = V[(size_t)col * N + row];
+            }
+        }
+    }
+    __syncthreads();
+    const double floor2 = params[0];
+
+    // ---- inner tournament over the 2b slots: wave w owns pair w of each inner round ----
+    const int nin = nslot - 1;
+    unsigned int my_rot = 0;
+    for (int ir = 0; ir < nin; ++ir) {
+        int s1, s2;
+        rr_pair(nslot, ir, w, s1, s2);
+        if (s1 > s2) {
+            int t = s1;
+            s1 = s2;
+            s2 = t;
+        }
+        const int c1 = (s1 < b) ? bp * b + s1 : bq * b + (s1 - b);
+        const int c2 = (s2 < b) ? bp * b + s2 : bq * b + (s2 - b);
+        if (c1 < N && c2 < N) {
+            double* x = sB + (size_t)s1 * N;
+            double* y = sB + (size_t)s2 * N;
+            double a = 0.0, bb = 0.0, c = 0.0;
+            for (int row = lane; row < N; row += 64) {
+                const double xv = x[row], yv = y[row];
+                a += xv * xv;
+                bb += yv * yv;
+                c += xv * yv;
+            }
+            a = wave_allsum(a);
+            bb = wave_allsum(bb);
+            c = wave_allsum(c);
+            const double lim = tol * sqrt(a * bb);
+            const double mn = a < bb ? a : bb;
+            if (fabs(c) > lim && mn > floor2) {
+                const double zeta = (bb - a) / (2.0 * c);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t);
+                const double sn = cs * t;
+                for (int row = lane; row < N; row += 64) {
+                    const double xv = x[row], yv = y[row];
+                    x[row] = cs * xv - sn * yv;
+                    y[row] = sn * xv + cs * yv;
+                }
+                if (WANT_V) {
+                    double* vx = sV + (size_t)s1 * N;
+                    double* vy = sV + (size_t)s2 * N;
+                    for (int row = lane; row < N; row += 64) {
+                        const double xv = vx[row], yv = vy[row];
+                        vx[row] = cs * xv - sn * yv;
+                        vy[row] = sn * xv + cs * yv;
+                    }
+                }
+                ++my_rot;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && my_rot) atomicAdd(&s_rot, my_rot);
+    __syncthreads();
+
+    // ---- store back ----
+    for (int s = w; s < nslot; s += b) {
+        const int col = (s < b) ? bp * b + s : bq * b + (s - b);
+        if (col < N) {
+            for (int row = lane; row < N; row += 64) {
+                B[(size_t)col * N + row] = sB[(size_t)s * N + row];
+                if (WANT_V) V[(size_t)col * N + row] = sV[(size_t)s * N + row];
+            }
+        }
+    }
+    if (threadIdx.x == 0 && s_rot) atomicAdd(rot_count, s_rot);
+}
+
+// B = G (ld -> N), V = I
+__global__ __launch_bounds__(256) void k_jacobi_init(const double* __restrict__ G, int64_t ldG,
+                                                     double* __restrict__ B, double* __restrict__ V,
+                                                     int N, int want_v) {
+    const int64_t total = (int64_t)N * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e % N, c = e / N;
+        B[e] = G[r + c * ldG];
+        if (want_v) V[e] = (r == c) ? 1.0 : 0.0;
+    }
+}
+
+// params[0] = (N*eps)^2 * ||G||_F^2 ; single workgroup, fixed reduction order
+__global__ __launch_bounds__(1024) void k_fro_floor(const double* __restrict__ B, int N,
+                                                    double* __restrict__ params, double factor2) {
+    __shared__ double sw[16];
+    const int64_t total = (int64_t)N * N;
+    double s = 0.0;
+    for (int64_t e = threadIdx.x; e < total; e += 1024) {
+        const double v = B[e];
+        s += v * v;
+    }
+    s = wave_allsum(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sw[k];
+        params[0] = factor2 * t;
+        params[1] = t;
+    }
+}
+
+// lam[i] = ||B[:,i]||_2, one wave per column
+__global__ __launch_bounds__(256) void k_colnorm(const double* __restrict__ B, int N,
+                                                 double* __restrict__ lam) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    double s = 0.0;
+    for (int row = lane; row < N; row += 64) {
+        const double v = B[(size_t)col * N + row];
+        s += v * v;
+    }
+    s = wave_allsum(s);
+    if (lane == 0) lam[col] = sqrt(s);
+}
+
+__global__ __launch_bounds__(256) void k_gather_scale(const double* __restrict__ V, int N,
+                                                      const int32_t* __restrict__ sel,
+                                                      const double* __restrict__ g, int r,
+                                                      double* __restrict__ Vg,
+                                                      double* __restrict__ Vs) {
+    const int64_t total = (int64_t)N * r;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t row = e % N, p = e / N;
+        const double v = V[(int64_t)sel[p] * N + row];
+        if (Vs) Vs[e] = v;
+        if (Vg) Vg[e] = g[p] * v;
+    }
+}
+
+static int pick_block(int64_t N, bool want_v) {
+    // 2b columns of B (and of V) resident in LDS; leave headroom below 160 KiB
+    const int64_t budget = 150 * 1024;
+    const int64_t per_col = N * 8 * (want_v ? 2 : 1);
+    int64_t b = budget / (2 * per_col);
+    if (b > 8) b = 8;  // 8 waves = 512 threads per workgroup
+    const int64_t half = (N + 1) / 2;
+    if (b > half) b = half;
+    return (int)b;
+}
+
+int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,
+               double* lam_dev, int64_t* sweeps_out) {
+    if (sweeps_out) *sweeps_out = 0;
+    if (N <= 0) return TLSQ_OK;
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* params = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 64);
+    unsigned int* rot = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 128);
+
+    int64_t g = (N * N + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_jacobi_init, dim3((int)g), dim3(256), 0, h->stream, G, ldG, B, V, (int)N,
+                       want_v ? 1 : 0);
+    TLSQ_HIP(h, hipGetLastError());
+    if (N == 1) {
+        hipLaunchKernelGGL(k_colnorm, dim3(1), dim3(256), 0, h->stream, (const double*)B, 1, lam_dev);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double nf = (double)N * eps;
+    hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params,
+                       nf * nf);
+    TLSQ_HIP(h, hipGetLastError());
+
+    const int b = pick_block(N, want_v);
+    if (b < 1)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED,
+                       "N=%lld too large for the LDS-resident Jacobi eigensolver", (long long)N);
+    int nblk = (int)((N + b - 1) / b);
+    if (nblk & 1) ++nblk;
+    const size_t lds = (size_t)2 * b * N * 8 * (want_v ? 2 : 1) + 16;
+    if (want_v) {
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_round<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_round<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    double tol = 2.0 * eps * sqrt((double)N);
+    if (tol < 4.0 * eps) tol = 4.0 * eps;
+    const int max_sweeps = 40;
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+        for (int r = 0; r < nblk - 1; ++r) {
+            if (want_v)
+                hipLaunchKernelGGL(k_jacobi_round<true>, dim3(nblk / 2), dim3(64 * b), lds, h->stream, B,
+                                   V, (int)N, b, nblk, r, tol, (const double*)params, rot);
+            else
+                hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * b), lds, h->stream,
+                                   B, V, (int)N, b, nblk, r, tol, (const double*)params, rot);
+        }
+        TLSQ_HIP(h, hipGetLastError());
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        unsigned int nrot;
+        memcpy(&nrot, h->pinned, 4);
+        if (nrot == 0) {
+            ++sweep;
+            break;
+        }
+    }
+    if (sweeps_out) *sweeps_out = sweep;
+    hipLaunchKernelGGL(k_colnorm, dim3((int)((N + 3) / 4)), dim3(256), 0, h->stream, (const double*)B,
+                       (int)N, lam_dev);
+    TLSQ_HIP(h, hipGetLastError());
+    if (sweep >= max_sweeps)
+        return set_err(h, TLSQ_ERR_NOCONV, "Jacobi eigensolver did not converge in %d sweeps (N=%lld)",
+                       max_sweeps, (long long)N);
+    return TLSQ_OK;
+}
+
+int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
+                        const double* g_dev, int64_t r, double* Vg, double* Vs) {
+    if (r <= 0) return TLSQ_OK;
+    int64_t g = (N * r + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_gather_scale, dim3((int)g), dim3(256), 0, h->stream, V, (int)N, sel_dev, g_dev,
+                       (int)r, Vg, Vs);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+}  // namespace tlsq

@@ -1,0 +1,238 @@
+// Elementwise ALM sweeps of rpca — HBM-bound, 16-byte coalesced loads/stores, grid-stride.
+//
+//   shrink sweep  = /root/reference/src/robustPCA.jl:188-192  (E-step + Z build, 3 reads / 2 writes)
+//   update sweep  = /root/reference/src/robustPCA.jl:217-222  (residual + dual update, 4 reads / 2 writes)
+//
+// Floating-point contraction is OFF in this file: Julia does not fuse a*b+c, and the parity tests
+// compare these kernels bit-for-bit with the oracle (same expression order as the reference).
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace tlsq {
+
+template <typename T>
+__device__ __forceinline__ T pos_part(T a) {  // max(a, 0) with Julia's NaN propagation
+    return (a > T(0) || a != a) ? a : T(0);
+}
+template <typename T>
+__device__ __forceinline__ T neg_part(T b) {  // min(b, 0)
+    return (b < T(0) || b != b) ? b : T(0);
+}
+template <typename T>
+__device__ __forceinline__ T soft_th(T x, T e) {  // robustPCA.jl:1
+    return pos_part(x - e) + neg_part(x + e);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_shrink(const T* __restrict__ D, const T* __restrict__ A,
+                                                const T* __restrict__ Y, T* __restrict__ E,
+                                                T* __restrict__ Z, int64_t n, T inv_mu, T thr,
+                                                int nonnegE) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        V d = reinterpret_cast<const V*>(D)[i];
+        V a = reinterpret_cast<const V*>(A)[i];
+        V y = reinterpret_cast<const V*>(Y)[i];
+        V e, z;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            T t = inv_mu * y[c];                     // (1/μ) .* Y
+            T ee = soft_th((d[c] - a[c]) + t, thr);  // soft_th.(D .- A .+ (1/μ).*Y, λ/μ)   :188
+            if (nonnegE) ee = pos_part(ee);          // :189-191
+            e[c] = ee;
+            z[c] = (d[c] - ee) + t;                  // Z .= D .- E .+ (1/μ).*Y              :192
+        }
+        reinterpret_cast<V*>(E)[i] = e;
+        reinterpret_cast<V*>(Z)[i] = z;
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) {  // tail
+        T t = inv_mu * Y[i];
+        T ee = soft_th((D[i] - A[i]) + t, thr);
+        if (nonnegE) ee = pos_part(ee);
+        E[i] = ee;
+        Z[i] = (D[i] - ee) + t;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_update(const T* __restrict__ D, T* __restrict__ A,
+                                                const T* __restrict__ E, T* __restrict__ Y,
+                                                T* __restrict__ R, int64_t n, T mu, int nonnegA) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        V d = reinterpret_cast<const V*>(D)[i];
+        V a = reinterpret_cast<const V*>(A)[i];
+        V e = reinterpret_cast<const V*>(E)[i];
+        V y = reinterpret_cast<const V*>(Y)[i];
+        V r;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            if (nonnegA) a[c] = pos_part(a[c]);  // A .= max.(A,0)   :217-219
+            T z = (d[c] - a[c]) - e[c];          // @. Z = D - A - E :221
+            r[c] = z;
+            y[c] = y[c] + mu * z;                // @. Y = Y + μ*Z   :222
+        }
+        if (nonnegA) reinterpret_cast<V*>(A)[i] = a;
+        reinterpret_cast<V*>(R)[i] = r;
+        reinterpret_cast<V*>(Y)[i] = y;
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) {
+        T a = A[i];
+        if (nonnegA) {
+            a = pos_part(a);
+            A[i] = a;
+        }
+        T z = (D[i] - a) - E[i];
+        R[i] = z;
+        Y[i] = Y[i] + mu * z;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_div_scalar(const T* __restrict__ D, T* __restrict__ Y,
+                                                    int64_t n, T s) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        V d = reinterpret_cast<const V*>(D)[i];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) d[c] = d[c] / s;  // Y ./= dual_norm   :181
+        reinterpret_cast<V*>(Y)[i] = d;
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) Y[i] = D[i] / s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_clamp_nonneg(T* __restrict__ A, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        A[i] = pos_part(A[i]);
+}
+
+// max |x_i| : per-lane running max -> wave shuffle -> LDS across the 4 waves -> one atomicMax per block
+// on the bit pattern (monotone for non-negative IEEE-754 values).
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxabs(const T* __restrict__ x, int64_t n,
+                                                unsigned long long* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = fabs((double)x[i]);
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int k = 1; k < 4; ++k) r = sm[k] > r ? sm[k] : r;
+        atomicMax(out, (unsigned long long)__double_as_longlong(r));
+    }
+}
+
+static inline int grid_for(int64_t work_items) {
+    int64_t g = (work_items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)g;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int64_t n, T inv_mu,
+                  T thr, int nonnegE) {
+    if (n <= 0) return TLSQ_OK;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(Z)) {
+        hipLaunchKernelGGL((k_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream,
+                           D, A, Y, E, Z, n, inv_mu, thr, nonnegE);
+    } else {
+        hipLaunchKernelGGL((k_shrink<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Y, E,
+                           Z, n, inv_mu, thr, nonnegE);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu,
+                  int nonnegA) {
+    if (n <= 0) return TLSQ_OK;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R)) {
+        hipLaunchKernelGGL((k_update<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream,
+                           D, A, E, Y, R, n, mu, nonnegA);
+    } else {
+        hipLaunchKernelGGL((k_update<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, E, Y,
+                           R, n, mu, nonnegA);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s) {
+    if (n <= 0) return TLSQ_OK;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(D) && aligned16(Y)) {
+        hipLaunchKernelGGL((k_div_scalar<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0,
+                           h->stream, D, Y, n, s);
+    } else {
+        hipLaunchKernelGGL((k_div_scalar<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, Y, n,
+                           s);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_clamp_nonneg(Handle* h, T* A, int64_t n) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_clamp_nonneg<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, A, n);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out) {
+    void* slot;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(slot);
+    TLSQ_HIP(h, hipMemsetAsync(d, 0, 8, h->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL((k_maxabs<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, x, n, d);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, d, 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(host_out, h->pinned, 8);
+    return TLSQ_OK;
+}
+
+#define INST(T)                                                                                   \
+    template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
+    template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
+    template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
+    template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
+    template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);
+INST(double)
+INST(float)
+#undef INST
+
+}  // namespace tlsq

@@ -1,0 +1,345 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as baggepinnen/TotalLeastSquares.jl
+(paths relative to /root/reference):
+
+    rpca(D; λ, maxrank, iters, tol, ρ, verbose, nonnegA, nonnegE, hankel, nukeA)   src/robustPCA.jl:156-239
+    lowrankfilter(y, n; sv, lag, tol, ...)                                         src/robustPCA.jl:119-128
+    hankel(x, L, lag) / unhankel(A[, lag, N, D]) / ishankel(A)                     src/robustPCA.jl:76-106, 28-68
+    tls!(Ay, n) / tls!(s, n) / rtls(A, y)                                          src/TotalLeastSquares.jl:63-69, 152-156
+
+The Julia shim (julia/TotalLeastSquaresHIP.jl) binds the same C entry points with `ccall`; Julia is not
+present in the build image, so this ctypes mirror is the host side that is actually exercised by tests.
+numpy arrays are passed as HOST pointers (column-major copies are made when needed); every matrix
+operation runs in libtlsqhip.so on the GPU — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib as L
+
+SVD = namedtuple("SVD", ["U", "S", "Vt"])
+SVD.V = property(lambda s: s.Vt.conj().T)
+
+
+class TlsqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"tlsq error {code}: {msg}")
+        self.code = code
+
+
+def _f(a, dtype=np.float64):
+    """column-major host array of the given dtype"""
+    return np.asfortranarray(np.asarray(a, dtype=dtype))
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class RpcaReport:
+    """Python view of tlsq_rpca_info."""
+
+    def __init__(self, info, cost, svp):
+        self.iters_done = int(info.iters_done)
+        self.converged = bool(info.converged)
+        self.final_cost = float(info.final_cost)
+        self.final_mu = float(info.final_mu)
+        self.d_norm = float(info.d_norm)
+        self.cost_hist = cost[: self.iters_done].tolist()
+        self.svp_hist = svp[: self.iters_done].tolist()
+        self.jacobi_sweeps = int(info.jacobi_sweeps)
+        self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
+
+
+class Engine:
+    """One handle = one GPU (tlsq_create)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.tlsq_create(int(device), C.byref(h))
+        if st != 0:
+            raise TlsqError(st, "tlsq_create failed (no MI355X visible? there is no CPU fallback)")
+        self.h = h
+        self.device = device
+        self.nranks, self.rank = 1, 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tlsq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _check(self, st):
+        if st < 0:
+            raise TlsqError(st, self.lib.tlsq_last_error(self.h).decode())
+        return st
+
+    def stream(self):
+        return self.lib.tlsq_stream(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.tlsq_synchronize(self.h))
+
+    def make_opts(self, *, lam=None, maxrank=None, iters=None, tol=None, rho=None, nonnegA=False,
+                  nonnegE=False, hankel=False, nukeA=True, memory=L.MEM_HOST, m_global=0,
+                  svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, on_iter=None):
+        o = L.RpcaOpts()
+        self.lib.tlsq_rpca_opts_default(C.byref(o))
+        if lam is not None:
+            o.lambda_ = float(lam)
+        if maxrank is not None:
+            o.maxrank = int(min(maxrank, 2 ** 62))
+        if iters is not None:
+            o.iters = int(iters)
+        if tol is not None:
+            o.tol = float(tol)
+        if rho is not None:
+            o.rho = float(rho)
+        o.nonnegA, o.nonnegE, o.hankel, o.nukeA = int(nonnegA), int(nonnegE), int(hankel), int(nukeA)
+        o.memory = memory
+        o.m_global = int(m_global)
+        o.svd_mode, o.opnorm_mode = svd_mode, opnorm_mode
+        if on_iter is not None:
+            o.on_iter = on_iter
+        return o
+
+    @staticmethod
+    def _info(capacity):
+        cost = np.zeros(max(capacity, 1), dtype=np.float64)
+        svp = np.zeros(max(capacity, 1), dtype=np.int64)
+        info = L.RpcaInfo()
+        info.cost_hist = cost.ctypes.data_as(C.POINTER(C.c_double))
+        info.svp_hist = svp.ctypes.data_as(C.POINTER(C.c_int64))
+        info.hist_capacity = capacity
+        return info, cost, svp
+
+    # -- multi-GPU --------------------------------------------------------------------------------
+    def unique_id(self) -> bytes:
+        buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        st = self.lib.tlsq_comm_unique_id(buf)
+        if st != 0:
+            raise TlsqError(st, "tlsq_comm_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes):
+        self._check(self.lib.tlsq_comm_init(self.h, nranks, rank, C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)))
+        self.nranks, self.rank = nranks, rank
+
+    # -- rpca -------------------------------------------------------------------------------------
+    def rpca(self, D, *, lam=None, maxrank=None, iters=1000, tol=None, rho=None, verbose=False,
+             nonnegA=False, nonnegE=False, hankel=False, nukeA=True, svd=None, opnorm=None,
+             want_U=True, return_report=False, m_global=0, **kwargs):
+        """A, E, s, sv = rpca(D; ...) — src/robustPCA.jl:156-239.  Unknown kwargs are swallowed like the
+        reference's `kwargs...` (:170).  `svd`/`opnorm` hooks: only the defaults run on the GPU."""
+        if svd is not None or opnorm is not None:
+            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED,
+                            "custom svd/opnorm hooks cannot run on the GPU path (randomized modes not built yet)")
+        D = np.asarray(D)
+        if np.iscomplexobj(D):
+            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "complex element types are not supported on the GPU path")
+        if D.dtype != np.float64:
+            D = D.astype(np.float64)
+        Df = _f(D)
+        M, N = Df.shape
+        d = min(max(m_global, M), N)
+        A = np.empty((M, N), dtype=np.float64, order="F")
+        E = np.empty((M, N), dtype=np.float64, order="F")
+        U = np.empty((M, d), dtype=np.float64, order="F") if want_U else None
+        S = np.empty(d, dtype=np.float64)
+        Vt = np.empty((d, N), dtype=np.float64, order="F")
+        cb = None
+        if verbose:
+            def _print(k, cost, svp, user):
+                print(f"{k} cost: {float(f'{cost:.4g}')}")                 # :226
+            cb = L.ON_ITER(_print)
+        o = self.make_opts(lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, nonnegA=nonnegA,
+                           nonnegE=nonnegE, hankel=hankel, nukeA=nukeA, m_global=m_global, on_iter=cb)
+        info, cost, svp = self._info(int(iters))
+        sv = C.c_int64(0)
+        st = self._check(self.lib.tlsq_rpca_f64(
+            self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
+            _ptr(U) if U is not None else None, M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
+        rep = RpcaReport(info, cost, svp)
+        if verbose and rep.converged:
+            print("converged")                                             # :229
+        if st == L.TLSQ_MAXITER:                                           # :232
+            warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: "
+                          f"{tol if tol is not None else math.sqrt(np.finfo(np.float64).eps)}")
+        s = SVD(U, S, Vt)
+        if return_report:
+            return A, E, s, int(sv.value), rep
+        return A, E, s, int(sv.value)
+
+    # -- hankel family ----------------------------------------------------------------------------
+    def hankel(self, x, L_, lag=1):
+        """src/robustPCA.jl:76-92 (float64/float32 on the GPU; other eltypes are converted to float64)."""
+        x = np.asarray(x)
+        dt = np.float32 if x.dtype == np.float32 else np.float64
+        x2 = _f(x.reshape(x.shape[0], -1), dt)
+        Nx, Dch = x2.shape
+        assert L_ <= Nx / 2, f"L has to be less than N/2 = {Nx / 2}"        # :79
+        assert lag <= L_, "lag must be <= L"                                # :80
+        K = (Nx - L_) // lag + 1
+        X = np.empty((K, L_ * Dch), dtype=dt, order="F")
+        fn = self.lib.tlsq_hankel_f32 if dt == np.float32 else self.lib.tlsq_hankel_f64
+        self._check(fn(self.h, _ptr(x2), Nx, Dch, Nx, L_, lag, _ptr(X), K, L.MEM_HOST))
+        return X
+
+    def unhankel(self, A, lag=None, N=None, D=1):
+        """src/robustPCA.jl:28-39 and :53-68."""
+        A = np.asarray(A)
+        dt = np.float32 if A.dtype == np.float32 else np.float64
+        Af = _f(A, dt)
+        K, LD = Af.shape
+        if lag is None:
+            lag, D = 1, 1
+            N = LD + K - 1
+        if lag == 1 and D == 1:
+            N = LD + K - 1                                                  # :54 -> unhankel(A)
+        y = np.empty((N, D), dtype=dt, order="F")
+        fn = self.lib.tlsq_unhankel_f32 if dt == np.float32 else self.lib.tlsq_unhankel_f64
+        self._check(fn(self.h, _ptr(Af), K, LD, K, lag, N, D, _ptr(y), N, L.MEM_HOST))
+        return y[:, 0].copy() if D == 1 else y
+
+    def soft_hankel_(self, A, eps):
+        """In place soft_hankel! — src/robustPCA.jl:9-21.  Returns the (column-major) result."""
+        Af = _f(A)
+        K, L_ = Af.shape
+        self._check(self.lib.tlsq_soft_hankel_f64(self.h, _ptr(Af), K, L_, K, float(eps), L.MEM_HOST))
+        if isinstance(A, np.ndarray) and A.dtype == np.float64:
+            A[...] = Af
+        return Af
+
+    def lowrankfilter(self, y, n=None, *, sv=0, lag=1, tol=1e-3, svd=None, return_report=False, **kw):
+        """src/robustPCA.jl:119-128."""
+        if svd is not None or kw.get("opnorm") is not None:
+            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom svd/opnorm hooks cannot run on the GPU path")
+        kw.pop("opnorm", None)
+        y = np.asarray(y, dtype=np.float64)
+        y2 = _f(y.reshape(y.shape[0], -1))
+        Nx, Dch = y2.shape
+        if n is None:
+            n = min(Nx // 20, 2000)
+        assert n <= Nx / 2, f"L has to be less than N/2 = {Nx / 2}"
+        assert lag <= n, "lag must be <= L"
+        iters = int(kw.pop("iters", 1000))
+        verbose = kw.pop("verbose", False)
+        allowed = {k: kw[k] for k in ("lam", "maxrank", "rho", "nonnegA", "nonnegE", "hankel", "nukeA") if k in kw}
+        cb = None
+        if verbose:
+            cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
+        o = self.make_opts(iters=iters, tol=tol, on_iter=cb, **allowed)
+        info, cost, svp = self._info(iters)
+        yf = np.empty((Nx, Dch), dtype=np.float64, order="F")
+        st = self._check(self.lib.tlsq_lowrankfilter_f64(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag),
+                                                         int(sv), C.byref(o), _ptr(yf), Nx, C.byref(info)))
+        rep = RpcaReport(info, cost, svp)
+        if st == L.TLSQ_MAXITER:
+            warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: {tol}")
+        out = yf[:, 0].copy() if y.ndim == 1 else yf
+        return (out, rep) if return_report else out
+
+    # -- tls! / rtls ------------------------------------------------------------------------------
+    def tls_(self, Ay, n):
+        """tls!(Ay, n) or tls!(s::SVD, n) — src/TotalLeastSquares.jl:63-69."""
+        if isinstance(Ay, SVD):
+            Vt = _f(Ay.Vt)
+            nc = Vt.shape[1]
+            if Vt.shape[0] != nc:
+                raise TlsqError(L.TLSQ_ERR_ARG, "tls!(s, n) needs the full ncols x ncols Vt")
+            x = np.empty((n, nc - n), dtype=np.float64, order="F")
+            st = self.lib.tlsq_tls_from_vt_f64(_ptr(Vt), nc, nc, n, _ptr(x), n)
+            if st < 0:
+                raise TlsqError(st, "tls_from_vt failed")
+            return x
+        Af = _f(Ay)
+        M, nc = Af.shape
+        x = np.empty((n, nc - n), dtype=np.float64, order="F")
+        self._check(self.lib.tlsq_tls_f64(self.h, _ptr(Af), M, nc, M, n, _ptr(x), n, L.MEM_HOST))
+        return x
+
+    def rtls(self, A, y, *, return_report=False, **kw):
+        """rtls(A, y; kwargs...) — src/TotalLeastSquares.jl:152-156."""
+        A = _f(A)
+        yv = np.asarray(y, dtype=np.float64)
+        y2 = _f(yv.reshape(yv.shape[0], -1))
+        M, n = A.shape
+        q = y2.shape[1]
+        iters = int(kw.pop("iters", 1000))
+        kw.pop("nukeA", None)
+        kw.pop("verbose", None)
+        o = self.make_opts(iters=iters, **{k: v for k, v in kw.items()
+                                           if k in ("lam", "maxrank", "tol", "rho", "nonnegA", "nonnegE", "hankel")})
+        info, cost, svp = self._info(iters)
+        x = np.empty((n, q), dtype=np.float64, order="F")
+        st = self._check(self.lib.tlsq_rtls_f64(self.h, _ptr(A), M, n, M, _ptr(y2), q, M, C.byref(o),
+                                                _ptr(x), n, C.byref(info)))
+        rep = RpcaReport(info, cost, svp)
+        if st == L.TLSQ_MAXITER:
+            warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}")
+        out = x[:, 0].copy() if yv.ndim == 1 else x
+        return (out, rep) if return_report else out
+
+
+def ishankel(A):
+    """src/robustPCA.jl:94-106 — exact test of constant anti-diagonals (host-side test helper)."""
+    A = np.asarray(A)
+    K, L_ = A.shape
+    F = np.fliplr(A)
+    for off in range(-(K - 1), L_):
+        v = np.diagonal(F, off)
+        if np.any(v != v[0]):
+            return False
+    return True
+
+
+_default = None
+
+
+def default_engine() -> Engine:
+    global _default
+    if _default is None:
+        _default = Engine(0)
+    return _default
+
+
+def rpca(D, **kw):
+    return default_engine().rpca(D, **kw)
+
+
+def lowrankfilter(y, n=None, **kw):
+    return default_engine().lowrankfilter(y, n, **kw)
+
+
+def hankel(x, L_, lag=1):
+    return default_engine().hankel(x, L_, lag)
+
+
+def unhankel(A, lag=None, N=None, D=1):
+    return default_engine().unhankel(A, lag, N, D)
+
+
+def soft_hankel_(A, eps):
+    return default_engine().soft_hankel_(A, eps)
+
+
+def tls_(Ay, n):
+    return default_engine().tls_(Ay, n)
+
+
+def rtls(A, y, **kw):
+    return default_engine().rtls(A, y, **kw)
