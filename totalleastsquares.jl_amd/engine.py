@@ -184,6 +184,20 @@ class Engine:
             return A, E, s, int(sv.value), rep
         return A, E, s, int(sv.value)
 
+    def rpca_device(self, dD, M, N, dA, dE, *, dU=None, dS=None, dVt=None, iters=1000, m_global=0,
+                    **optkw):
+        """rpca on DEVICE-resident column-major panels (raw device addresses as ints): D (M x N, ld M) in,
+        A, E (M x N) out, optional U (M x d), S (d), Vt (d x N).  Nothing crosses PCIe except O(N) scalars.
+        Returns (sv, RpcaReport, status)."""
+        o = self.make_opts(iters=iters, memory=L.MEM_DEVICE, m_global=m_global, **optkw)
+        info, cost, svp = self._info(int(iters))
+        sv = C.c_int64(0)
+        d = min(max(m_global, M), N)
+        vp = lambda x: C.c_void_p(int(x)) if x else None
+        st = self._check(self.lib.tlsq_rpca_f64(self.h, vp(dD), M, N, M, C.byref(o), vp(dA), M, vp(dE), M,
+                                                vp(dU), M, vp(dS), vp(dVt), d, C.byref(sv), C.byref(info)))
+        return int(sv.value), RpcaReport(info, cost, svp), st
+
     # -- hankel family ----------------------------------------------------------------------------
     def hankel(self, x, L_, lag=1):
         """src/robustPCA.jl:76-92 (float64/float32 on the GPU; other eltypes are converted to float64)."""
