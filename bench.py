@@ -133,6 +133,7 @@ def main():
                           if ms.get("gram") else None, "peak": 78.6,
                           "note": "Gram(Z) only; flops counted as full 2MN^2"},
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
+            "svd_step": {"full_jacobi": rep.eig_full, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
         }
         out["gram_mfma"]["tflops"] = (2.0 * Ml * N * N) / (ms["gram"] / iters_total * 1e-3) / 1e12 if ms.get("gram") else None
         if world == 1 and args.cpu_iters > 0:

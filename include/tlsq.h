@@ -84,6 +84,9 @@ typedef struct tlsq_rpca_info {
     /* wall/device time in ms */
     double ms_total, ms_loop, ms_h2d, ms_d2h;
     double ms_shrink, ms_update, ms_gram, ms_eig, ms_rebuild, ms_opnorm;
+    /* how the SVD step of each iteration was served: full Jacobi decompositions vs warm-started subspace
+     * iterations (and the total number of subspace steps) */
+    int64_t eig_full, eig_fast, subspace_steps;
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);

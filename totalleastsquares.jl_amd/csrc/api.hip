@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -165,6 +166,15 @@ static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
     TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    // Lanczos on the N x N Gram (residual bound 1e-13 relative); exact Jacobi eigenvalues as the fallback
+    double lmax = 0.0;
+    int steps = 0;
+    int st = lanczos_lmax_f64(h, (const double*)G, N, N, 1e-13, 1000, &lmax, &steps);
+    if (st < 0) return st;
+    if (st == 0) {
+        *out = std::sqrt(lmax);
+        return TLSQ_OK;
+    }
     int64_t sw = 0;
     TLSQ_TRY(symeig_f64(h, (const double*)G, N, N, (double*)B, nullptr, false, (double*)lam, &sw));
     if (sweeps) *sweeps += sw;
@@ -177,34 +187,182 @@ static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t
     return TLSQ_OK;
 }
 
-// Decomposition of the Gram of Z: V (device, N x N), sigma (host, unsorted), order (descending)
+// Decomposition of the Gram of Z: V (device, N x ncols, ld N), sigma (host, per column of V), order (descending)
 struct SmallSvd {
-    std::vector<double> sigma;  // per column of V
-    std::vector<int32_t> order; // indices sorted by sigma descending
+    std::vector<double> sigma;   // per column of V
+    std::vector<int32_t> order;  // column indices sorted by sigma descending
+    int64_t ncols = 0;           // N for a full decomposition, p for a subspace one
 };
 
-static int svd_via_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
-                        SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
-    void *G, *B, *V, *lam;
+static void sort_desc(SmallSvd& s) {
+    s.order.resize(s.sigma.size());
+    std::iota(s.order.begin(), s.order.end(), 0);
+    std::stable_sort(s.order.begin(), s.order.end(),
+                     [&](int32_t a, int32_t b) { return s.sigma[a] > s.sigma[b]; });
+}
+
+// G (WS_G) = Z'Z summed over the row shards
+static int gram_allreduce(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** G_out) {
+    void* G;
     TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    *G_out = (double*)G;
+    return TLSQ_OK;
+}
+
+// full eigen-decomposition of G by the block Jacobi solver: V in WS_V
+static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps) {
+    void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
     TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
-    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
-    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
-    if (pt) pt->mark();
     int64_t sw = 0;
-    TLSQ_TRY(symeig_f64(h, (const double*)G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw));
+    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw));
     if (sweeps) *sweeps += sw;
     s.sigma.resize((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     for (auto& v : s.sigma) v = std::sqrt(v);
-    s.order.resize((size_t)N);
-    std::iota(s.order.begin(), s.order.end(), 0);
-    std::stable_sort(s.order.begin(), s.order.end(),
-                     [&](int32_t a, int32_t b) { return s.sigma[a] > s.sigma[b]; });
+    s.ncols = N;
+    sort_desc(s);
     *V_out = (double*)V;
+    return TLSQ_OK;
+}
+
+static int svd_via_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
+                        SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
+    double* G;
+    TLSQ_TRY(gram_allreduce(h, Z, M, N, ld, &G));
+    if (pt) pt->mark();
+    return eig_full(h, G, N, V_out, s, sweeps);
+}
+
+// ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
+struct SubspaceState {
+    bool valid = false;
+    int64_t p = 0;       // columns of X (WS_SX, N x p)
+    int64_t fast = 0, full = 0, steps = 0;
+};
+
+// upload a column selection and gather X = V[:, sel]
+static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
+    const int64_t r = (int64_t)sel.size();
+    if (r == 0) return TLSQ_OK;
+    void* aux;
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16 + 64, &aux));
+    TLSQ_HIP(h, hipMemcpyAsync(aux, sel.data(), (size_t)r * 4, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(launch_gather_scale(h, V, N, (const int32_t*)aux, nullptr, r, nullptr, X));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+// Try to get the sigma_i >= inv_mu pairs of G from the block carried in st.  *ok = false -> caller must run
+// the full solver.  On success V_out (N x p) / s describe the Ritz pairs (all p of them; the wanted ones are
+// converged, the rest only bound the count).
+static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, SubspaceState& st,
+                        double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
+    *ok = false;
+    if (!st.valid || st.p < 3) return TLSQ_OK;
+    const int64_t p = st.p;
+    void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
+    TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * p * 8, &X));
+    TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
+    TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
+    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * p * 8, &XN));
+    TLSQ_TRY(ws_get(h, WS_SGX, (size_t)N * p * 8, &GX));
+    TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
+    TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
+    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
+    double* theta_dev = (double*)lam;
+    double* res_dev = theta_dev + p;
+    double* stat_dev = res_dev + p;
+    double* lamH_dev = stat_dev + 8;
+    std::vector<double> host((size_t)2 * p + 8);
+    const int max_steps = 10;
+    int64_t svp = 0;
+    bool conv = false;
+    for (int step = 0; step < max_steps; ++step) {
+        ++st.steps;
+        // Q = orth(G X)
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)X, N, G, N, (double*)Q, N, p, N, N, false));
+        TLSQ_TRY(launch_cgs2(h, (double*)Q, N, p, stat_dev));
+        // Rayleigh-Ritz: H = Q' (G Q)
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, p, N, N, false));
+        TLSQ_TRY(gemm_f64(h, true, true, (const double*)GQ, N, (const double*)Q, N, (double*)H, p, p, p, N, false));
+        int64_t sw = 0;
+        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw));
+        if (sweeps) *sweeps += sw;
+        // X' = Q S,  G X' = (G Q) S
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)S, p, (const double*)Q, N, (double*)XN, N, p, N, p, false));
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)S, p, (const double*)GQ, N, (double*)GX, N, p, N, p, false));
+        TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)XN, N, p, theta_dev));
+        TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)XN, theta_dev, N, p, res_dev));
+        TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 1) * 8, hipMemcpyDeviceToHost,
+                                   h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        std::swap(X, XN);  // X now holds the Ritz vectors
+        s.sigma.resize((size_t)p);
+        double tmax = 0.0;
+        bool finite = true;
+        for (int64_t i = 0; i < p; ++i) {
+            const double t = host[i];
+            if (!std::isfinite(t) || !std::isfinite(host[p + i])) finite = false;
+            tmax = std::max(tmax, t);
+            s.sigma[i] = std::sqrt(std::max(t, 0.0));
+        }
+        if (!finite) break;
+        s.ncols = p;
+        sort_desc(s);
+        svp = 0;
+        for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        if (svp > p - 2) break;  // the block may not contain every sigma >= 1/mu: let the full solver decide
+        bool good = true;
+        for (int64_t i = 0; i < svp; ++i) good = good && (host[p + s.order[i]] <= 2e-13 * tmax);
+        if (good) {
+            conv = true;
+            break;
+        }
+    }
+    // keep the workspace slot convention: the current block lives in WS_SX
+    if (X != h->ws[WS_SX].p) {
+        TLSQ_HIP(h, hipMemcpyAsync(h->ws[WS_SX].p, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+        X = h->ws[WS_SX].p;
+    }
+    if (!conv) return TLSQ_OK;
+    // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
+    TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+    if (svp > 0) {
+        void *Vg, *Vs;
+        TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
+        TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> th((size_t)svp);
+        for (int64_t i = 0; i < svp; ++i) {
+            sel[i] = s.order[i];
+            th[i] = host[sel[i]];
+        }
+        int32_t* dsel = (int32_t*)aux;
+        double* dth = (double*)((char*)aux + ((svp * 4 + 7) / 8) * 8);
+        TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)svp * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(dth, th.data(), (size_t)svp * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
+        TLSQ_TRY(gemm_f64(h, false, false, (const double*)Vs, N, (const double*)Vg, N, (double*)GD, N, N, N, svp,
+                          false));
+        TLSQ_TRY(launch_sub(h, G, (const double*)GD, (double*)GD, N * N));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    } else {
+        TLSQ_HIP(h, hipMemcpyAsync(GD, G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    double lmax = 0.0;
+    int steps = 0;
+    int lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps);
+    if (lst < 0) return lst;
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;  // ambiguous: full solver decides
+    *V_out = (double*)X;
+    *ok = true;
     return TLSQ_OK;
 }
 
@@ -234,6 +392,27 @@ static int rebuild_lowrank(Handle* h, const double* Z, int64_t M, int64_t N, int
                       false));
     // the async H2D above read from `sel`/`g` host vectors: make sure they are consumed before return
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+// Carry the dominant block (svp + pad Ritz/eigen vectors, sorted) to the next ALM iteration: WS_SX = V[:, top].
+// Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
+static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
+                       SubspaceState& sub) {
+    const int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(8, svp / 4));
+    if (want > pmax || want > s.ncols || want < 3) {
+        sub.valid = false;
+        return TLSQ_OK;
+    }
+    std::vector<int32_t> keep((size_t)want);
+    for (int64_t p = 0; p < want; ++p) keep[p] = s.order[p];
+    void *tmp, *X;
+    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * want * 8, &tmp));
+    TLSQ_TRY(gather_cols(h, V, N, keep, (double*)tmp));          // out of place (V may be WS_SX itself)
+    TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * want * 8, &X));
+    TLSQ_HIP(h, hipMemcpyAsync(X, tmp, (size_t)N * want * 8, hipMemcpyDeviceToDevice, h->stream));
+    sub.p = want;
+    sub.valid = true;
     return TLSQ_OK;
 }
 
@@ -298,6 +477,13 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
     }
     SmallSvd s;
     double* V = nullptr;
+    // warm-started subspace iteration for k >= 2 (falls back to the full Jacobi solver whenever it cannot
+    // certify the count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
+    SubspaceState sub;
+    const int64_t pmax = subspace_max_block(N);
+    const char* force_full = getenv("TLSQ_FULL_EIG");
+    const bool use_subspace = !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
+    bool v_is_full = false;
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
     void* meanws = nullptr;
@@ -317,10 +503,21 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         pt.mark();
         TLSQ_TRY(launch_shrink<double>(h, D, A, Y, E, Z, n, inv_mu, thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark();
-        TLSQ_TRY(svd_via_gram(h, Z, M, N, M, &V, s, &sweeps, &pt));                           // :193-194
+        double* G = nullptr;                                                                  // :193-194
+        TLSQ_TRY(gram_allreduce(h, Z, M, N, M, &G));
+        pt.mark();
+        bool fast_ok = false;
+        if (use_subspace) TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+        if (!fast_ok) {
+            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+            ++sub.full;
+        } else {
+            ++sub.fast;
+        }
+        v_is_full = !fast_ok;
         pt.mark();
         svp = 0;                                                   // :198
-        for (int64_t i = 0; i < N; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
         sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
         std::vector<int32_t> sel((size_t)svp);
         std::vector<double> g((size_t)svp);
@@ -330,6 +527,7 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
             g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
         }
         TLSQ_TRY(rebuild_lowrank(h, Z, M, N, M, V, sel, g, A, M));
+        if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<double>(h, A, M, N, M, thr, (double*)meanws));  // :214-216
         pt.mark();
         TLSQ_TRY(launch_update<double>(h, D, A, E, Y, R, n, mu, ro.nonnegA ? 1 : 0));         // :217-222
@@ -361,11 +559,21 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         info->final_cost = cost;
         info->final_mu = mu;
         info->jacobi_sweeps = sweeps;
+        info->eig_full = sub.full;
+        info->eig_fast = sub.fast;
+        info->subspace_steps = sub.steps;
     }
     if (sv_out) *sv_out = sv;
 
     // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
     const int64_t d = std::min(ro.m_global, N);
+    if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
+        // the last iteration used the subspace path: the caller wants the complete SVD of the last Z
+        double* G = nullptr;
+        TLSQ_TRY(gram_allreduce(h, Z, M, N, M, &G));
+        TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+        if (info) info->jacobi_sweeps = sweeps;
+    }
     if (S_host && V)
         for (int64_t p = 0; p < d; ++p) S_host[p] = s.sigma[s.order[p]];
     if (Vt_host && V) {

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -66,6 +68,7 @@ enum WsSlot {
     WS_SLAB,                                     // split-K partial slabs
     WS_SCAL,                                     // small scalars / counters
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
+    WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_COUNT
 };
 
@@ -103,6 +106,20 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);
+
+// ---------------- lanczos.hip ----------------
+// lambda_max(G) to relative accuracy rel_tol (residual bound of the Ritz pair); returns 1 (and the best
+// estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.
+int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
+                     double* lmax, int* steps_used);
+
+// ---------------- subspace.hip ----------------
+int subspace_max_block(int64_t N);
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
+int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
+                      double* res);
+int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
+int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
 
 // ---------------- hankel.hip ----------------
 template <typename T>

@@ -34,23 +34,31 @@ __device__ __forceinline__ void rr_pair(int n, int r, int idx, int& p, int& q) {
 }
 
 // params[0] = floor2 (squared column-norm noise floor)
+// One workgroup = one block pair (2b column slots).  Waves loop over the b column pairs of each inner round.
+// When the whole matrix is a single block pair (nblk == 2) the kernel can run `max_inner_sweeps` complete
+// sweeps by itself (stops early after a sweep without rotations) and reports the number in sweeps_done.
 template <bool WANT_V>
-__global__ __launch_bounds__(512) void k_jacobi_round(double* __restrict__ B, double* __restrict__ V, int N, int b, int nblk,
-                               int round, double tol, const double* __restrict__ params,
-                               unsigned int* __restrict__ rot_count) {
+__global__ __launch_bounds__(1024) void k_jacobi_round(double* __restrict__ B, double* __restrict__ V, int N,
+                                                       int b, int nblk, int round, double tol,
+                                                       const double* __restrict__ params,
+                                                       unsigned int* __restrict__ rot_count,
+                                                       int max_inner_sweeps, int* __restrict__ sweeps_done) {
     // dynamic LDS only (keeps the base 16-byte aligned): sB[2b][N], sV[2b][N] (if WANT_V), rotation counter
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int nslot = 2 * b;
     double* sB = sm;
     double* sV = sm + (size_t)nslot * N;
-    unsigned int& s_rot = *reinterpret_cast<unsigned int*>(sm + (size_t)nslot * N * (WANT_V ? 2 : 1));
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned int* s_cnt = reinterpret_cast<unsigned int*>(sm + (size_t)nslot * N * (WANT_V ? 2 : 1));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int bp, bq;
     rr_pair(nblk, round, blockIdx.x, bp, bq);
-    if (threadIdx.x == 0) s_rot = 0;
+    if (threadIdx.x == 0) {
+        s_cnt[0] = 0;  // rotations in the current sweep
+        s_cnt[1] = 0;  // total
+    }
 
     // ---- load the 2b columns (global column-major, ld = N) ----
-    for (int s = w; s < nslot; s += b) {
+    for (int s = w; s < nslot; s += nw) {
         const int col = (s < b) ? bp * b + s : bq * b + (s - b);
         if (col < N) {
             for (int row = lane; row < N; row += 64) {
@@ -62,63 +70,79 @@ __global__ __launch_bounds__(512) void k_jacobi_round(double* __restrict__ B, do
     __syncthreads();
     const double floor2 = params[0];
 
-    // ---- inner tournament over the 2b slots: wave w owns pair w of each inner round ----
+    // ---- inner tournament over the 2b slots ----
     const int nin = nslot - 1;
-    unsigned int my_rot = 0;
-    for (int ir = 0; ir < nin; ++ir) {
-        int s1, s2;
-        rr_pair(nslot, ir, w, s1, s2);
-        if (s1 > s2) {
-            int t = s1;
-            s1 = s2;
-            s2 = t;
-        }
-        const int c1 = (s1 < b) ? bp * b + s1 : bq * b + (s1 - b);
-        const int c2 = (s2 < b) ? bp * b + s2 : bq * b + (s2 - b);
-        if (c1 < N && c2 < N) {
-            double* x = sB + (size_t)s1 * N;
-            double* y = sB + (size_t)s2 * N;
-            double a = 0.0, bb = 0.0, c = 0.0;
-            for (int row = lane; row < N; row += 64) {
-                const double xv = x[row], yv = y[row];
-                a += xv * xv;
-                bb += yv * yv;
-                c += xv * yv;
-            }
-            a = wave_allsum(a);
-            bb = wave_allsum(bb);
-            c = wave_allsum(c);
-            const double lim = tol * sqrt(a * bb);
-            const double mn = a < bb ? a : bb;
-            if (fabs(c) > lim && mn > floor2) {
-                const double zeta = (bb - a) / (2.0 * c);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t);
-                const double sn = cs * t;
-                for (int row = lane; row < N; row += 64) {
-                    const double xv = x[row], yv = y[row];
-                    x[row] = cs * xv - sn * yv;
-                    y[row] = sn * xv + cs * yv;
+    int sweep = 0;
+    for (; sweep < max_inner_sweeps; ++sweep) {
+        unsigned int my_rot = 0;
+        for (int ir = 0; ir < nin; ++ir) {
+            for (int pi = w; pi < b; pi += nw) {
+                int s1, s2;
+                rr_pair(nslot, ir, pi, s1, s2);
+                if (s1 > s2) {
+                    int t = s1;
+                    s1 = s2;
+                    s2 = t;
                 }
-                if (WANT_V) {
-                    double* vx = sV + (size_t)s1 * N;
-                    double* vy = sV + (size_t)s2 * N;
+                const int c1 = (s1 < b) ? bp * b + s1 : bq * b + (s1 - b);
+                const int c2 = (s2 < b) ? bp * b + s2 : bq * b + (s2 - b);
+                if (c1 < N && c2 < N) {
+                    double* x = sB + (size_t)s1 * N;
+                    double* y = sB + (size_t)s2 * N;
+                    double a = 0.0, bb = 0.0, c = 0.0;
                     for (int row = lane; row < N; row += 64) {
-                        const double xv = vx[row], yv = vy[row];
-                        vx[row] = cs * xv - sn * yv;
-                        vy[row] = sn * xv + cs * yv;
+                        const double xv = x[row], yv = y[row];
+                        a += xv * xv;
+                        bb += yv * yv;
+                        c += xv * yv;
+                    }
+                    a = wave_allsum(a);
+                    bb = wave_allsum(bb);
+                    c = wave_allsum(c);
+                    const double lim = tol * sqrt(a * bb);
+                    const double mn = a < bb ? a : bb;
+                    if (fabs(c) > lim && mn > floor2) {
+                        const double zeta = (bb - a) / (2.0 * c);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + t * t);
+                        const double sn = cs * t;
+                        for (int row = lane; row < N; row += 64) {
+                            const double xv = x[row], yv = y[row];
+                            x[row] = cs * xv - sn * yv;
+                            y[row] = sn * xv + cs * yv;
+                        }
+                        if (WANT_V) {
+                            double* vx = sV + (size_t)s1 * N;
+                            double* vy = sV + (size_t)s2 * N;
+                            for (int row = lane; row < N; row += 64) {
+                                const double xv = vx[row], yv = vy[row];
+                                vx[row] = cs * xv - sn * yv;
+                                vy[row] = sn * xv + cs * yv;
+                            }
+                        }
+                        ++my_rot;
                     }
                 }
-                ++my_rot;
             }
+            __syncthreads();
         }
+        if (lane == 0 && my_rot) atomicAdd(&s_cnt[0], my_rot);
         __syncthreads();
+        const unsigned int r = s_cnt[0];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_cnt[1] += r;
+            s_cnt[0] = 0;
+        }
+        if (r == 0) {
+            ++sweep;
+            break;
+        }
     }
-    if (lane == 0 && my_rot) atomicAdd(&s_rot, my_rot);
     __syncthreads();
 
     // ---- store back ----
-    for (int s = w; s < nslot; s += b) {
+    for (int s = w; s < nslot; s += nw) {
         const int col = (s < b) ? bp * b + s : bq * b + (s - b);
         if (col < N) {
             for (int row = lane; row < N; row += 64) {
@@ -127,7 +151,10 @@ __global__ __launch_bounds__(512) void k_jacobi_round(double* __restrict__ B, do
             }
         }
     }
-    if (threadIdx.x == 0 && s_rot) atomicAdd(rot_count, s_rot);
+    if (threadIdx.x == 0) {
+        if (s_cnt[1]) atomicAdd(rot_count, s_cnt[1]);
+        if (sweeps_done) *sweeps_done = sweep;
+    }
 }
 
 // B = G (ld -> N), V = I
@@ -194,14 +221,18 @@ __global__ __launch_bounds__(256) void k_gather_scale(const double* __restrict__
     }
 }
 
-static int pick_block(int64_t N, bool want_v) {
+static int pick_block(int64_t N, bool want_v, bool* single) {
     // 2b columns of B (and of V) resident in LDS; leave headroom below 160 KiB
     const int64_t budget = 150 * 1024;
     const int64_t per_col = N * 8 * (want_v ? 2 : 1);
+    const int64_t half = (N + 1) / 2;
+    *single = false;
+    if (2 * half * per_col <= budget) {  // the whole matrix is one block pair: one workgroup, no host loop
+        *single = true;
+        return (int)half;
+    }
     int64_t b = budget / (2 * per_col);
     if (b > 8) b = 8;  // 8 waves = 512 threads per workgroup
-    const int64_t half = (N + 1) / 2;
-    if (b > half) b = half;
     return (int)b;
 }
 
@@ -213,6 +244,7 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
     double* params = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 64);
     unsigned int* rot = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 128);
+    int* sweeps_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 136);
 
     int64_t g = (N * N + 255) / 256;
     if (g > 1024) g = 1024;
@@ -230,13 +262,16 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
                        nf * nf);
     TLSQ_HIP(h, hipGetLastError());
 
-    const int b = pick_block(N, want_v);
+    bool single = false;
+    const int b = pick_block(N, want_v, &single);
     if (b < 1)
         return set_err(h, TLSQ_ERR_UNSUPPORTED,
                        "N=%lld too large for the LDS-resident Jacobi eigensolver", (long long)N);
     int nblk = (int)((N + b - 1) / b);
     if (nblk & 1) ++nblk;
+    if (nblk < 2) nblk = 2;
     const size_t lds = (size_t)2 * b * N * 8 * (want_v ? 2 : 1) + 16;
+    const int nwaves = b < 16 ? b : 16;
     if (want_v) {
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_round<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -248,31 +283,52 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     if (tol < 4.0 * eps) tol = 4.0 * eps;
     const int max_sweeps = 40;
     int sweep = 0;
-    for (; sweep < max_sweeps; ++sweep) {
-        TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
-        for (int r = 0; r < nblk - 1; ++r) {
-            if (want_v)
-                hipLaunchKernelGGL(k_jacobi_round<true>, dim3(nblk / 2), dim3(64 * b), lds, h->stream, B,
-                                   V, (int)N, b, nblk, r, tol, (const double*)params, rot);
-            else
-                hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * b), lds, h->stream,
-                                   B, V, (int)N, b, nblk, r, tol, (const double*)params, rot);
-        }
+    bool converged = false;
+    if (single && nblk == 2) {
+        TLSQ_HIP(h, hipMemsetAsync(rot, 0, 16, h->stream));
+        if (want_v)
+            hipLaunchKernelGGL(k_jacobi_round<true>, dim3(1), dim3(64 * nwaves), lds, h->stream, B, V, (int)N,
+                               b, nblk, 0, tol, (const double*)params, rot, max_sweeps, sweeps_dev);
+        else
+            hipLaunchKernelGGL(k_jacobi_round<false>, dim3(1), dim3(64 * nwaves), lds, h->stream, B, V, (int)N,
+                               b, nblk, 0, tol, (const double*)params, rot, max_sweeps, sweeps_dev);
         TLSQ_HIP(h, hipGetLastError());
-        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        unsigned int nrot;
-        memcpy(&nrot, h->pinned, 4);
-        if (nrot == 0) {
-            ++sweep;
-            break;
+        int sd;
+        memcpy(&sd, h->pinned, 4);
+        sweep = sd;
+        converged = sd < max_sweeps;
+    } else {
+        for (; sweep < max_sweeps; ++sweep) {
+            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+            for (int r = 0; r < nblk - 1; ++r) {
+                if (want_v)
+                    hipLaunchKernelGGL(k_jacobi_round<true>, dim3(nblk / 2), dim3(64 * nwaves), lds, h->stream,
+                                       B, V, (int)N, b, nblk, r, tol, (const double*)params, rot, 1,
+                                       (int*)nullptr);
+                else
+                    hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * nwaves), lds,
+                                       h->stream, B, V, (int)N, b, nblk, r, tol, (const double*)params, rot, 1,
+                                       (int*)nullptr);
+            }
+            TLSQ_HIP(h, hipGetLastError());
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            unsigned int nrot;
+            memcpy(&nrot, h->pinned, 4);
+            if (nrot == 0) {
+                ++sweep;
+                converged = true;
+                break;
+            }
         }
     }
     if (sweeps_out) *sweeps_out = sweep;
     hipLaunchKernelGGL(k_colnorm, dim3((int)((N + 3) / 4)), dim3(256), 0, h->stream, (const double*)B,
                        (int)N, lam_dev);
     TLSQ_HIP(h, hipGetLastError());
-    if (sweep >= max_sweeps)
+    if (!converged)
         return set_err(h, TLSQ_ERR_NOCONV, "Jacobi eigensolver did not converge in %d sweeps (N=%lld)",
                        max_sweeps, (long long)N);
     return TLSQ_OK;

@@ -1,0 +1,248 @@
+// lambda_max of a symmetric PSD N x N matrix by Lanczos — the default `opnorm` of rpca
+// (/root/reference/src/robustPCA.jl:177,225: opnorm(Z) = sigma_max(Z) = sqrt(lambda_max(Z'Z)), which the
+// reference gets from a full LAPACK gesdd('N') every iteration).
+//
+// One persistent 1024-thread workgroup runs a chunk of Lanczos steps without host interaction: the
+// matrix (N*N*8 bytes, 2 MB at N=512) is streamed from L2 once per step, 16 waves each own N/16 columns
+// (G symmetric: column j == row j, so the dot products read contiguous memory), the Krylov vectors live
+// in LDS.  alpha/beta are written to global memory; the host evaluates the largest Ritz value of the
+// tridiagonal and a residual bound and decides whether another chunk is needed.
+#include "common.hpp"
+
+namespace tlsq {
+
+constexpr int LZ_WGS = 64;       // workgroups per step-kernel
+constexpr int LZ_THREADS = 256;  // 4 waves
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum4(double v, double* red) {
+    v = wsum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One Lanczos step per launch (the kernel boundary is the grid-wide dependency; ~5 us per step).
+// Launch j:
+//   phase A (every workgroup, redundantly and identically): finish step j-1 from the partial dot products
+//     of launch j-1:  alpha = q.u,  w = u - alpha q - beta_prev q_prev,  beta = ||w||,  q_new = w/beta
+//   phase B: this workgroup's rows of u_new = G q_new (G symmetric: row r == column r, contiguous) and its
+//     partial of q_new . u_new.
+// Vectors rotate through 3 buffers, u and the partials through 2, so no launch overwrites what its own
+// (slower) workgroups still read.  Workgroup 0 records alpha_{j-1}, beta_{j-1}.
+// layout of `st` (doubles): [0..8) header {beta_prev, breakdown, ...}; vec[3][N]; u[2][N]; part[2][LZ_WGS]
+__global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __restrict__ G, int64_t ldG,
+                                                             int N, double* __restrict__ st,
+                                                             double* __restrict__ ab, int maxsteps, int j) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* q = sm;           // N  (q_new)
+    double* red = sm + N;     // 4
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* vec = st + 8;
+    double* ubuf = vec + 3 * (size_t)N;
+    double* part = ubuf + 2 * (size_t)N;
+    double* vnew = vec + (size_t)(j % 3) * N;
+    if (st[1] != 0.0) return;  // breakdown flagged by an earlier launch
+    if (j == 0) {
+        // deterministic pseudo-random start vector (integer hash), normalised
+        double nrm = 0.0;
+        for (int i = tid; i < N; i += LZ_THREADS) {
+            unsigned int x = (unsigned int)i * 2654435761u + 12345u;
+            x ^= x >> 16;
+            x *= 2246822519u;
+            x ^= x >> 13;
+            x *= 3266489917u;
+            x ^= x >> 16;
+            const double v = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+            q[i] = v;
+            nrm += v * v;
+        }
+        nrm = block_sum4(nrm, red);
+        const double inv = 1.0 / sqrt(nrm);
+        for (int i = tid; i < N; i += LZ_THREADS) q[i] *= inv;
+    } else {
+        const double* qc = vec + (size_t)((j + 2) % 3) * N;   // q_{j-1}  (buffer (j-1)%3)
+        const double* qp = vec + (size_t)((j + 1) % 3) * N;   // q_{j-2}  (buffer (j-2)%3)
+        const double* u = ubuf + (size_t)((j + 1) % 2) * N;   // u of launch j-1
+        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS;
+        double alpha = 0.0;
+        for (int k = 0; k < LZ_WGS; ++k) alpha += pp[k];
+        const double beta_prev = (j >= 2) ? ab[maxsteps + (j - 2)] : 0.0;
+        double nn = 0.0;
+        for (int i = tid; i < N; i += LZ_THREADS) {
+            double v = u[i] - alpha * qc[i];
+            if (j >= 2) v -= beta_prev * qp[i];
+            q[i] = v;
+            nn += v * v;
+        }
+        const double beta = sqrt(block_sum4(nn, red));
+        if (blockIdx.x == 0 && tid == 0) {
+            ab[j - 1] = alpha;
+            ab[maxsteps + (j - 1)] = beta;
+            st[2] = (double)j;  // completed (alpha,beta) pairs
+        }
+        if (!(beta > 1e-290)) {
+            if (blockIdx.x == 0 && tid == 0) st[1] = 1.0;
+            return;
+        }
+        const double inv = 1.0 / beta;
+        for (int i = tid; i < N; i += LZ_THREADS) q[i] *= inv;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = tid; i < N; i += LZ_THREADS) vnew[i] = q[i];
+    // phase B: rows [r0, r1) of u_new = G q_new
+    double* unew = ubuf + (size_t)(j % 2) * N;
+    const int rows_per = (N + LZ_WGS - 1) / LZ_WGS;
+    const int r0 = blockIdx.x * rows_per;
+    const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
+    double pacc = 0.0;
+    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
+        const double* __restrict__ col = G + (int64_t)r * ldG;
+        double acc = 0.0;
+        for (int c = lane; c < N; c += 64) acc += col[c] * q[c];
+        acc = wsum(acc);
+        if (lane == 0) {
+            unew[r] = acc;
+            pacc += acc * q[r];
+        }
+    }
+    // partial of q_new . u_new over this workgroup's rows (lane 0 of each wave holds a piece)
+    __syncthreads();
+    if (lane == 0) red[w] = pacc;
+    __syncthreads();
+    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- host: largest eigenvalue of the symmetric tridiagonal (alpha[0..m), beta[0..m-1)) + residual bound
+static int sturm_count_below(const double* a, const double* b, int m, double x) {
+    // number of eigenvalues < x
+    int cnt = 0;
+    double d = 1.0;
+    for (int i = 0; i < m; ++i) {
+        const double off = (i == 0) ? 0.0 : b[i - 1] * b[i - 1];
+        d = (a[i] - x) - (i == 0 ? 0.0 : off / d);
+        if (d == 0.0) d = -1e-300;
+        if (d < 0.0) ++cnt;
+    }
+    return cnt;
+}
+
+static double tridiag_lmax(const double* a, const double* b, int m, double* last_comp) {
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < m; ++i) {
+        const double r = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i + 1 < m ? fabs(b[i]) : 0.0);
+        lo = std::min(lo, a[i] - r);
+        hi = std::max(hi, a[i] + r);
+    }
+    // bisection for the largest eigenvalue: count_below(x) == m  <=>  x > lambda_max
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (!(mid > lo && mid < hi)) break;
+        if (sturm_count_below(a, b, m, mid) >= m) hi = mid; else lo = mid;
+    }
+    const double theta = 0.5 * (lo + hi);
+    // eigenvector by the three-term recurrence from the top (stable for the extreme eigenvalue when run
+    // towards the small components), normalised; we only need |s_m| / ||s||
+    if (last_comp) {
+        std::vector<double> s((size_t)m);
+        // inverse iteration with a slightly shifted theta (2 steps) using Thomas algorithm w/o pivoting
+        std::vector<double> x((size_t)m, 1.0), c((size_t)m), dd((size_t)m);
+        const double shift = theta + 1e-14 * std::max(fabs(theta), 1e-300) + 1e-300;
+        for (int rep = 0; rep < 3; ++rep) {
+            // solve (T - shift I) y = x
+            double piv = a[0] - shift;
+            if (piv == 0.0) piv = 1e-300;
+            dd[0] = piv;
+            for (int i = 1; i < m; ++i) {
+                c[i - 1] = b[i - 1] / dd[i - 1];
+                dd[i] = (a[i] - shift) - c[i - 1] * b[i - 1];
+                if (dd[i] == 0.0) dd[i] = 1e-300;
+            }
+            std::vector<double> y = x;
+            for (int i = 1; i < m; ++i) y[i] -= c[i - 1] * y[i - 1];
+            y[m - 1] /= dd[m - 1];
+            for (int i = m - 2; i >= 0; --i) y[i] = (y[i] - b[i] * y[i + 1]) / dd[i];
+            double nn = 0.0;
+            for (double v : y) nn += v * v;
+            nn = sqrt(nn);
+            if (!(nn > 0.0) || !std::isfinite(nn)) break;
+            for (int i = 0; i < m; ++i) x[i] = y[i] / nn;
+        }
+        *last_comp = fabs(x[m - 1]);
+    }
+    return theta;
+}
+
+// returns TLSQ_OK and *lmax, or 1 if the requested accuracy was not reached in max_steps (caller falls back)
+int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
+                     double* lmax, int* steps_used) {
+    if (N <= 0) {
+        *lmax = 0.0;
+        return TLSQ_OK;
+    }
+    if (max_steps > (int)N) max_steps = (int)N;
+    if (max_steps < 1) max_steps = 1;
+    const int cap = max_steps + 2;
+    void* stv;
+    const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS + 2 * (size_t)cap + 16;
+    TLSQ_TRY(ws_get(h, WS_AUX4, st_doubles * 8, &stv));
+    double* st = (double*)stv;
+    double* ab = st + 8 + 5 * (size_t)N + 2 * LZ_WGS;
+    const size_t lds = (size_t)(N + 8) * 8;
+    if (lds > 150 * 1024 || (size_t)(2 * cap) * 8 + 64 > h->pinned_bytes) return 1;
+    if (lds > 48 * 1024)
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lanczos_step),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TLSQ_HIP(h, hipMemsetAsync(st, 0, 64, h->stream));
+    std::vector<double> hab((size_t)2 * cap);
+    int launched = 0;  // launches issued; launch j completes the pair (alpha_{j-1}, beta_{j-1})
+    double theta = 0.0;
+    int chunk = 16;
+    while (launched < max_steps + 1) {
+        const int n = std::min(chunk, max_steps + 1 - launched);
+        for (int k = 0; k < n; ++k, ++launched)
+            hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), lds, h->stream, G, ldG, (int)N,
+                               st, ab, cap, launched);
+        TLSQ_HIP(h, hipGetLastError());
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, st, 64, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, ab, (size_t)2 * cap * 8, hipMemcpyDeviceToHost,
+                                   h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        double hs[8];
+        memcpy(hs, h->pinned, 64);
+        memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * cap * 8);
+        const int m = (int)hs[2];
+        const bool broke = hs[1] != 0.0;
+        if (m <= 0) {
+            if (broke) break;
+            continue;
+        }
+        const double* a = hab.data();
+        const double* b = hab.data() + cap;
+        double sm = 0.0;
+        theta = tridiag_lmax(a, b, m, &sm);
+        if (steps_used) *steps_used = m;
+        if (broke || m >= (int)N) {
+            *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        const double bound = fabs(b[m - 1]) * sm;  // ||G y - theta y|| for the Ritz pair
+        if (bound <= rel_tol * fabs(theta)) {
+            *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        if (chunk < 64) chunk *= 2;
+    }
+    *lmax = theta > 0.0 ? theta : 0.0;
+    return 1;
+}
+
+}  // namespace tlsq

@@ -1,0 +1,159 @@
+// Warm-started subspace iteration for the dominant eigenpairs of the N x N Gram matrix G = Z'Z.
+//
+// After the first ALM iteration the singular-value threshold step of rpca (/root/reference/src/robustPCA.jl:
+// 193-213) only needs (i) the singular pairs with sigma_i >= 1/mu and (ii) their exact count `svp`.  The
+// dominant right singular subspace moves slowly between ALM iterations, so instead of a full N x N
+// eigen-decomposition we iterate on a block X (N x p, p = svp_prev + pad) taken from the previous iteration:
+//     Q = orth(G X)   (CGS2, LDS resident)        H = Q'GQ  (p x p)     H = S Theta S'  (Jacobi, one WG)
+//     X <- Q S ;  residuals ||G x_i - theta_i x_i||
+// until the wanted pairs are converged to ~1e-13 ||G||, then certify the count with a Lanczos bound on
+// lambda_max of the deflated matrix G - X_r Theta_r X_r'.  Any failure (slow convergence, rank growth
+// beyond the block, ambiguous certificate) makes the caller fall back to the full Jacobi solver.
+#include "common.hpp"
+
+namespace tlsq {
+
+constexpr int SS_THREADS = 1024;
+
+__device__ __forceinline__ double ss_wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// In-place orthonormalisation of the p columns of Y (N x p, ld N) by classical Gram-Schmidt with one
+// re-orthogonalisation pass (CGS2).  Whole panel in LDS.  status[0] = min over columns of
+// ||y_j after projection|| / ||y_j before|| (tiny => numerically dependent column).
+__global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int N, int p,
+                                                     double* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* sY = sm;                    // p * N
+    double* sd = sm + (size_t)p * N;    // p dots
+    double* red = sd + p;               // 16
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = SS_THREADS / 64;
+    for (int e = tid; e < N * p; e += SS_THREADS) sY[e] = Y[e];
+    __syncthreads();
+    double minratio = 1.0;
+    for (int j = 0; j < p; ++j) {
+        double* yj = sY + (size_t)j * N;
+        // original norm
+        double nn = 0.0;
+        for (int r = tid; r < N; r += SS_THREADS) nn += yj[r] * yj[r];
+        nn = ss_wsum(nn);
+        if (lane == 0) red[w] = nn;
+        __syncthreads();
+        double n0 = 0.0;
+        for (int k = 0; k < nw; ++k) n0 += red[k];
+        __syncthreads();
+        for (int pass = 0; pass < 2 && j > 0; ++pass) {
+            for (int i = w; i < j; i += nw) {  // d_i = q_i . y_j
+                const double* qi = sY + (size_t)i * N;
+                double d = 0.0;
+                for (int r = lane; r < N; r += 64) d += qi[r] * yj[r];
+                d = ss_wsum(d);
+                if (lane == 0) sd[i] = d;
+            }
+            __syncthreads();
+            for (int r = tid; r < N; r += SS_THREADS) {  // y_j -= Q_{<j} d
+                double acc = yj[r];
+                for (int i = 0; i < j; ++i) acc -= sd[i] * sY[(size_t)i * N + r];
+                yj[r] = acc;
+            }
+            __syncthreads();
+        }
+        double n1 = 0.0;
+        for (int r = tid; r < N; r += SS_THREADS) n1 += yj[r] * yj[r];
+        n1 = ss_wsum(n1);
+        if (lane == 0) red[w] = n1;
+        __syncthreads();
+        double n1s = 0.0;
+        for (int k = 0; k < nw; ++k) n1s += red[k];
+        __syncthreads();
+        const double ratio = n0 > 0.0 ? sqrt(n1s / n0) : 0.0;
+        minratio = ratio < minratio ? ratio : minratio;
+        const double inv = n1s > 0.0 ? 1.0 / sqrt(n1s) : 0.0;
+        for (int r = tid; r < N; r += SS_THREADS) yj[r] *= inv;
+        __syncthreads();
+    }
+    for (int e = tid; e < N * p; e += SS_THREADS) Y[e] = sY[e];
+    if (tid == 0) status[0] = minratio;
+}
+
+// res[i] = || GX[:,i] - theta[i] * X[:,i] ||_2   (one wave per column)
+__global__ __launch_bounds__(256) void k_ritz_resid(const double* __restrict__ GX,
+                                                    const double* __restrict__ X,
+                                                    const double* __restrict__ theta, int N, int p,
+                                                    double* __restrict__ res) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= p) return;
+    const double th = theta[col];
+    double s = 0.0;
+    for (int r = lane; r < N; r += 64) {
+        const double v = GX[(size_t)col * N + r] - th * X[(size_t)col * N + r];
+        s += v * v;
+    }
+    s = ss_wsum(s);
+    if (lane == 0) res[col] = sqrt(s);
+}
+
+// theta[i] = H-eigenvalue i recovered as the Rayleigh quotient x_i . (G x_i)  (one wave per column)
+__global__ __launch_bounds__(256) void k_rayleigh(const double* __restrict__ GX, const double* __restrict__ X,
+                                                  int N, int p, double* __restrict__ theta) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= p) return;
+    double s = 0.0;
+    for (int r = lane; r < N; r += 64) s += GX[(size_t)col * N + r] * X[(size_t)col * N + r];
+    s = ss_wsum(s);
+    if (lane == 0) theta[col] = s;
+}
+
+// Gd = G - C   (N x N contiguous)
+__global__ __launch_bounds__(256) void k_sub(const double* __restrict__ G, const double* __restrict__ Cc,
+                                             double* __restrict__ Gd, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) Gd[i] = G[i] - Cc[i];
+}
+
+int subspace_max_block(int64_t N) {
+    // CGS2 keeps the N x p panel in LDS
+    const int64_t budget = 140 * 1024;
+    int64_t p = budget / (N * 8) - 1;
+    if (p > 96) p = 96;  // the p x p Rayleigh-Ritz problem must fit the single-workgroup Jacobi
+    return p < 0 ? 0 : (int)p;
+}
+
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) {
+    const size_t lds = (size_t)(p * N + p + 16) * 8;
+    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_cgs2, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
+                      double* res) {
+    hipLaunchKernelGGL(k_ritz_resid, dim3((int)((p + 3) / 4)), dim3(256), 0, h->stream, GX, X, theta, (int)N,
+                       (int)p, res);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta) {
+    hipLaunchKernelGGL(k_rayleigh, dim3((int)((p + 3) / 4)), dim3(256), 0, h->stream, GX, X, (int)N, (int)p,
+                       theta);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_sub, dim3((int)g), dim3(256), 0, h->stream, G, Cc, Gd, n);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+}  // namespace tlsq

@@ -55,6 +55,8 @@ class RpcaReport:
         self.cost_hist = cost[: self.iters_done].tolist()
         self.svp_hist = svp[: self.iters_done].tolist()
         self.jacobi_sweeps = int(info.jacobi_sweeps)
+        self.eig_full, self.eig_fast = int(info.eig_full), int(info.eig_fast)
+        self.subspace_steps = int(info.subspace_steps)
         self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
 
 
