@@ -1,0 +1,181 @@
+# TotalLeastSquaresHIP.jl — thin `ccall` shim over libtlsqhip.so (include/tlsq.h).
+#
+# Drop-in for the rpca / lowrankfilter / hankel / unhankel / tls! / rtls entry points of
+# baggepinnen/TotalLeastSquares.jl (reference signatures: src/robustPCA.jl:76,28,53,119,156;
+# src/TotalLeastSquares.jl:63,65,152).  Host code stays in Julia; every M x N operation runs on the
+# MI355X behind the C ABI.  NOTE: the build image has no `julia` binary, so this file is not executed by
+# the test-suite; it is mirrored line for line by the ctypes harness
+# `totalleastsquares.jl_amd/engine.py`, which is.  Struct layouts are checked there
+# (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts)=104, sizeof(info)=176).
+module TotalLeastSquaresHIP
+
+using LinearAlgebra, Libdl
+
+export rpca, lowrankfilter, hankel, unhankel, ishankel, tls!, rtls
+
+const LIB = Ref{String}(get(ENV, "TLSQ_LIB", joinpath(@__DIR__, "..", "totalleastsquares.jl_amd", "libtlsqhip.so")))
+
+const TLSQ_OK, TLSQ_MAXITER = Cint(0), Cint(1)
+const MEM_HOST = Cint(0)
+
+# mirrors `struct tlsq_rpca_opts` (include/tlsq.h)
+mutable struct RpcaOpts
+    lambda::Cdouble; maxrank::Int64; iters::Int64; tol::Cdouble; rho::Cdouble
+    nonnegA::Int32; nonnegE::Int32; hankel::Int32; nukeA::Int32
+    svd_mode::Int32; opnorm_mode::Int32; opnorm_mvps::Int32; memory::Int32
+    m_global::Int64; seed::UInt64
+    on_iter::Ptr{Cvoid}; user::Ptr{Cvoid}
+    RpcaOpts() = new()
+end
+
+# mirrors `struct tlsq_rpca_info`
+mutable struct RpcaInfo
+    iters_done::Int64; converged::Int32; reserved::Int32
+    final_cost::Cdouble; final_mu::Cdouble; d_norm::Cdouble
+    cost_hist::Ptr{Cdouble}; svp_hist::Ptr{Int64}; hist_capacity::Int64; jacobi_sweeps::Int64
+    ms_total::Cdouble; ms_loop::Cdouble; ms_h2d::Cdouble; ms_d2h::Cdouble
+    ms_shrink::Cdouble; ms_update::Cdouble; ms_gram::Cdouble; ms_eig::Cdouble; ms_rebuild::Cdouble; ms_opnorm::Cdouble
+    eig_full::Int64; eig_fast::Int64; subspace_steps::Int64
+    RpcaInfo() = new()
+end
+
+const HANDLE = Ref{Ptr{Cvoid}}(C_NULL)
+
+function handle()
+    if HANDLE[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:tlsq_create, LIB[]), Cint, (Cint, Ref{Ptr{Cvoid}}), 0, h)
+        st == 0 || error("tlsq_create failed ($st): no MI355X visible; there is no CPU fallback")
+        HANDLE[] = h[]
+    end
+    HANDLE[]
+end
+
+lasterr() = unsafe_string(ccall((:tlsq_last_error, LIB[]), Cstring, (Ptr{Cvoid},), handle()))
+check(st) = st < 0 ? (st == -1 ? throw(AssertionError(lasterr())) : error("tlsq error $st: $(lasterr())")) : st
+
+_print_iter(k::Int64, cost::Cdouble, svp::Int64, ::Ptr{Cvoid}) =
+    (println("$(k) cost: $(round(cost, sigdigits=4))"); nothing)      # src/robustPCA.jl:226
+
+"""
+    A, E, s, sv = rpca(D; λ, maxrank, iters, tol, ρ, verbose, nonnegA, nonnegE, hankel, nukeA)
+
+Same contract as the reference (src/robustPCA.jl:156-239).  `svd`/`opnorm` hooks other than the defaults
+are not supported on the GPU path (TLSQ_ERR_UNSUPPORTED); complex element types are rejected.
+"""
+function rpca(D::AbstractMatrix{Float64};
+              λ = 1.0 / sqrt(maximum(size(D))), maxrank = typemax(Int), iters::Int = 1000,
+              tol = sqrt(eps(Float64)), ρ = 1.5, verbose::Bool = false, nonnegA::Bool = false,
+              nonnegE::Bool = false, hankel::Bool = false, nukeA = true,
+              svd = LinearAlgebra.svd!, opnorm = LinearAlgebra.opnorm, kwargs...)
+    (svd ∈ (LinearAlgebra.svd, LinearAlgebra.svd!) && opnorm === LinearAlgebra.opnorm) ||
+        error("custom svd/opnorm hooks cannot run on the GPU path")
+    Dm = Matrix(D)
+    M, N = size(Dm); d = min(M, N)
+    A = Matrix{Float64}(undef, M, N); E = similar(A)
+    U = Matrix{Float64}(undef, M, d); S = Vector{Float64}(undef, d); Vt = Matrix{Float64}(undef, d, N)
+    o = RpcaOpts()
+    ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
+    o.lambda = λ; o.maxrank = min(maxrank, typemax(Int64) ÷ 2); o.iters = iters; o.tol = tol; o.rho = ρ
+    o.nonnegA = nonnegA; o.nonnegE = nonnegE; o.hankel = hankel; o.nukeA = nukeA ? 1 : 0
+    o.memory = MEM_HOST
+    verbose && (o.on_iter = @cfunction(_print_iter, Cvoid, (Int64, Cdouble, Int64, Ptr{Cvoid})))
+    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    sv = Ref{Int64}(0)
+    st = check(ccall((:tlsq_rpca_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+         Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}, Ref{RpcaInfo}),
+        handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info))
+    verbose && info.converged != 0 && println("converged")            # src/robustPCA.jl:229
+    st == TLSQ_MAXITER &&
+        @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"   # :232
+    A, E, SVD(U, S, Vt), sv[]
+end
+
+function hankel(x::AbstractVecOrMat{Float64}, L, lag = 1)             # src/robustPCA.jl:76-92
+    xm = Matrix(reshape(x, size(x, 1), :)); N, D = size(xm)
+    @assert L <= N / 2 "L has to be less than N/2 = $(N/2)"
+    @assert lag <= L "lag must be <= L"
+    K = (N - L) ÷ lag + 1
+    X = Matrix{Float64}(undef, K, L * D)
+    check(ccall((:tlsq_hankel_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+        handle(), xm, N, D, N, L, lag, X, K, MEM_HOST))
+    X
+end
+
+unhankel(A::AbstractMatrix{Float64}) = unhankel(A, 1, size(A, 1) + size(A, 2) - 1, 1)   # :28-39
+function unhankel(A::AbstractMatrix{Float64}, lag, N, D = 1)          # src/robustPCA.jl:53-68
+    Am = Matrix(A); K, LD = size(Am)
+    lag == 1 && D == 1 && (N = K + LD - 1)
+    y = Matrix{Float64}(undef, N, D)
+    check(ccall((:tlsq_unhankel_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+        handle(), Am, K, LD, K, lag, N, D, y, N, MEM_HOST))
+    D == 1 ? vec(y) : y
+end
+
+function ishankel(A)                                                   # src/robustPCA.jl:94-106 (host)
+    K, L = size(A)
+    for k = 1:K+L-1
+        ri = min(K, k):-1:max(k - L, 1); ci = max(1, k - K + 1):L
+        val = A[ri[1], ci[1]]
+        for (r, c) in zip(ri, ci)
+            A[r, c] != val && return false
+        end
+    end
+    true
+end
+
+function lowrankfilter(y::AbstractVecOrMat{Float64}, n = min(size(y, 1) ÷ 20, 2000);
+                       sv = 0, lag = 1, tol = 1e-3, svd = LinearAlgebra.svd!, kwargs...)   # :119-128
+    svd ∈ (LinearAlgebra.svd, LinearAlgebra.svd!) || error("custom svd hooks cannot run on the GPU path")
+    ym = Matrix(reshape(y, size(y, 1), :)); N, D = size(ym)
+    @assert n <= N / 2 "L has to be less than N/2 = $(N/2)"
+    @assert lag <= n "lag must be <= L"
+    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
+    o.tol = tol; o.memory = MEM_HOST
+    for (k, v) in kwargs
+        k === :λ && (o.lambda = v); k === :ρ && (o.rho = v); k === :iters && (o.iters = v)
+        k === :maxrank && (o.maxrank = v); k === :nonnegA && (o.nonnegA = v); k === :nonnegE && (o.nonnegE = v)
+        k === :hankel && (o.hankel = v); k === :nukeA && (o.nukeA = v ? 1 : 0)
+    end
+    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    yf = Matrix{Float64}(undef, N, D)
+    st = check(ccall((:tlsq_lowrankfilter_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64,
+         Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info))
+    st == TLSQ_MAXITER && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
+    y isa AbstractVector ? vec(yf) : yf
+end
+
+function tls!(Ay::AbstractMatrix{Float64}, n::Integer)                 # src/TotalLeastSquares.jl:63
+    Am = Matrix(Ay); M, nc = size(Am)
+    x = Matrix{Float64}(undef, n, nc - n)
+    check(ccall((:tlsq_tls_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+        handle(), Am, M, nc, M, n, x, n, MEM_HOST))
+    x
+end
+
+function tls!(s::SVD, n::Integer)                                      # src/TotalLeastSquares.jl:65-69
+    Vt = Matrix(s.Vt); nc = size(Vt, 2)
+    x = Matrix{Float64}(undef, n, nc - n)
+    st = ccall((:tlsq_tls_from_vt_f64, LIB[]), Cint, (Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64),
+               Vt, nc, nc, n, x, n)
+    st < 0 && error("tlsq_tls_from_vt_f64 failed ($st)")
+    x
+end
+
+function rtls(A::AbstractArray{Float64}, y::AbstractArray{Float64}; kwargs...)   # :152-156
+    Am = Matrix(A); ym = Matrix(reshape(y, size(y, 1), :)); M, n = size(Am); q = size(ym, 2)
+    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o); o.memory = MEM_HOST
+    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    x = Matrix{Float64}(undef, n, q)
+    check(ccall((:tlsq_rtls_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},
+         Int64, Ref{RpcaInfo}), handle(), Am, M, n, M, ym, q, M, o, x, n, info))
+    y isa AbstractVector ? vec(x) : x
+end
+
+end # module

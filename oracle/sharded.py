@@ -1,0 +1,61 @@
+"""Row-sharded restatement of the rpca loop — TEST INFRASTRUCTURE (see rpca_oracle.py header).
+
+Same structure as the multi-GPU path of libtlsqhip.so: every rank owns a contiguous row
+block of D; the only exchanges are sum-all-reduces of N x N Gram matrices (SVD step and opnorm) and one
+scalar max at setup; the small N x N eigenproblem is replicated.  `allreduce(array, op)` is supplied by
+the caller (torch.distributed with gloo in tests/test_dist_cpu.py).  Follows
+/root/reference/src/robustPCA.jl:156-239 line for line otherwise.
+"""
+import math
+
+import numpy as np
+
+from . import rpca_oracle as O
+
+
+def rpca_sharded(D_local, M_global, allreduce, lam=None, iters=1000, tol=None, rho=1.5, nukeA=True):
+    D = np.asfortranarray(D_local, dtype=np.float64)
+    Ml, N = D.shape
+    if lam is None:
+        lam = 1.0 / math.sqrt(max(M_global, N))
+    if tol is None:
+        tol = math.sqrt(np.finfo(np.float64).eps)
+
+    def opnorm_sharded(X):
+        G = allreduce(X.T @ X, "sum")
+        return math.sqrt(max(np.linalg.eigvalsh(G)[-1], 0.0))
+
+    A = np.zeros_like(D)
+    E = np.zeros_like(D)
+    Y = D.copy()
+    norm2 = opnorm_sharded(Y)
+    norminf = float(allreduce(np.array([np.max(np.abs(Y)) if Y.size else 0.0]), "max")[0]) / lam
+    dual = max(norm2, norminf)
+    Y /= dual
+    mu = 1.25 / norm2
+    mubar = mu * 1e7
+    sv = 10
+    svp_hist, cost_hist = [], []
+    converged = False
+    for k in range(1, iters + 1):
+        inv_mu = 1.0 / mu
+        E = O.soft_th((D - A) + inv_mu * Y, lam / mu)
+        Z = (D - E) + inv_mu * Y
+        G = allreduce(Z.T @ Z, "sum")
+        w, V = np.linalg.eigh(G)
+        w, V = w[::-1], V[:, ::-1]
+        S = np.sqrt(np.maximum(w, 0.0))
+        svp = int(np.sum(S >= inv_mu))
+        sv = max(svp, 1)
+        g = (S[:svp] - inv_mu) / S[:svp] if nukeA else np.ones(svp)
+        A = (Z @ (V[:, :svp] * g)) @ V[:, :svp].T
+        R = (D - A) - E
+        Y = Y + mu * R
+        mu = min(mu * rho, mubar)
+        cost = opnorm_sharded(R) / norm2
+        svp_hist.append(svp)
+        cost_hist.append(cost)
+        if cost < tol:
+            converged = True
+            break
+    return A, E, sv, dict(iters_done=k, svp_hist=svp_hist, cost_hist=cost_hist, converged=converged)

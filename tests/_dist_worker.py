@@ -1,0 +1,58 @@
+"""Worker for tests/test_dist_cpu.py: run under torch.distributed.run with the gloo backend (CPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from tlsq_amd import dist as tdist
+    from oracle import rpca_oracle as O
+    from oracle.sharded import rpca_sharded
+
+    res = {"rank": rank, "world": world}
+    # --- env plumbing + partition
+    r2, w2, _ = tdist.env_rank_world()
+    res["env_ok"] = (r2 == rank and w2 == world)
+    M, N = 1001, 40
+    lo, hi = tdist.row_partition(M, world, rank)
+    spans = [None] * world
+    dist.all_gather_object(spans, (lo, hi))
+    res["partition_ok"] = (spans[0][0] == 0 and spans[-1][1] == M and
+                           all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)) and
+                           max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1)
+    # --- unique-id exchange (what Engine.unique_id() feeds on the GPU box)
+    uid = tdist.exchange_unique_id(lambda: bytes((7 * i + 3) % 256 for i in range(128)), rank, world)
+    res["uid_ok"] = uid == bytes((7 * i + 3) % 256 for i in range(128))
+
+    # --- row-sharded rpca (Gram all-reduce) == single-process LAPACK oracle
+    def allreduce(a, op):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+        return t.numpy()
+
+    D, A0, _ = O.synth_lowrank_sparse(M, N, 4, seed=11)
+    A, E, sv, info = rpca_sharded(D[lo:hi], M, allreduce)
+    Ao, Eo, _, svo, io = O.rpca(D)
+    res["iters"] = (info["iters_done"], io.iters_done)
+    res["svp_same"] = info["svp_hist"] == io.svp_hist
+    res["sv"] = (sv, svo)
+    res["relA"] = float(np.linalg.norm(A - Ao[lo:hi]) / np.linalg.norm(Ao[lo:hi]))
+    res["relE"] = float(np.linalg.norm(E - Eo[lo:hi]) / np.linalg.norm(Eo[lo:hi]))
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
