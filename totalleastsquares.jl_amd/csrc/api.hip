@@ -157,26 +157,22 @@ static double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// sigma_max via Gram + eigenvalues only.  Z: device M x N (ld). uses WS_G, WS_B, WS_LAM.
-static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double* out,
-                       int64_t* sweeps) {
-    void *G, *B, *lam;
-    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
-    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
-    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
-    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
-    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
-    // Lanczos on the N x N Gram (residual bound 1e-13 relative); exact Jacobi eigenvalues as the fallback
+// sqrt(lambda_max) of the Gram already sitting in G (N x N, ld N): Lanczos to the requested relative residual
+// bound, exact Jacobi eigenvalues as the fallback.  uses WS_B, WS_LAM.
+static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps) {
     double lmax = 0.0;
     int steps = 0;
-    int st = lanczos_lmax_f64(h, (const double*)G, N, N, 1e-13, 1000, &lmax, &steps);
+    int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps);
     if (st < 0) return st;
     if (st == 0) {
         *out = std::sqrt(lmax);
         return TLSQ_OK;
     }
+    void *B, *lam;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     int64_t sw = 0;
-    TLSQ_TRY(symeig_f64(h, (const double*)G, N, N, (double*)B, nullptr, false, (double*)lam, &sw));
+    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, nullptr, false, (double*)lam, &sw));
     if (sweeps) *sweeps += sw;
     std::vector<double> hl((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
@@ -185,6 +181,16 @@ static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t
     for (double v : hl) mx = v > mx ? v : mx;
     *out = std::sqrt(mx);
     return TLSQ_OK;
+}
+
+// sigma_max of Z (device M x N, ld) = the default `opnorm`; uses WS_G.
+static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double* out,
+                       int64_t* sweeps, double rel_tol = 1e-13) {
+    void* G;
+    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    return sigma_max_of_gram(h, (const double*)G, N, rel_tol, out, sweeps);
 }
 
 // Decomposition of the Gram of Z: V (device, N x ncols, ld N), sigma (host, per column of V), order (descending)
@@ -241,7 +247,9 @@ static int svd_via_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_
 // ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
 struct SubspaceState {
     bool valid = false;
+    bool allow_cold = true;
     int64_t p = 0;       // columns of X (WS_SX, N x p)
+    int64_t ntop = 0;    // the first ntop columns of X were >= 1/mu in the iteration that produced them
     int64_t fast = 0, full = 0, steps = 0;
 };
 
@@ -263,10 +271,19 @@ static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<
 static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, SubspaceState& st,
                         double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
     *ok = false;
-    if (!st.valid || st.p < 3) return TLSQ_OK;
+    const bool cold = !st.valid;
+    if (cold) {
+        // no block yet (first ALM iteration): start from a pseudo-random block of 10 + 8 columns — 10 is the
+        // reference's initial rank guess `sv = 10` (src/robustPCA.jl:184)
+        if (!st.allow_cold) return TLSQ_OK;
+        st.p = std::min<int64_t>(std::min<int64_t>(18, subspace_max_block(N)), N);
+        if (st.p < 3) return TLSQ_OK;
+    }
+    if (st.p < 3) return TLSQ_OK;
     const int64_t p = st.p;
     void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
     TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * p * 8, &X));
+    if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, 0x9E3779B9u));
     TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
     TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
     TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * p * 8, &XN));
@@ -281,19 +298,27 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     double* stat_dev = res_dev + p;
     double* lamH_dev = stat_dev + 8;
     std::vector<double> host((size_t)2 * p + 8);
-    const int max_steps = 10;
+    const int max_steps = cold ? 30 : 10;
+    const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
     int64_t svp = 0;
     bool conv = false;
+    double prev_maxres = 0.0;
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
-        // Q = orth(G X)
+        // Q = orth([G^2 X_top, G X_pad]) on the first step (the block arrives sorted: the first ntop columns are
+        // the previous iteration's dominant vectors; squaring their convergence factor saves a whole step),
+        // Q = orth(G X) afterwards
         TLSQ_TRY(gemm_f64(h, true, false, (const double*)X, N, G, N, (double*)Q, N, p, N, N, false));
+        if (step == 0 && ntop > 0) {
+            TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, ntop, N, N, false));
+            TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * ntop * 8, hipMemcpyDeviceToDevice, h->stream));
+        }
         TLSQ_TRY(launch_cgs2(h, (double*)Q, N, p, stat_dev));
         // Rayleigh-Ritz: H = Q' (G Q)
         TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, p, N, N, false));
         TLSQ_TRY(gemm_f64(h, true, true, (const double*)GQ, N, (const double*)Q, N, (double*)H, p, p, p, N, false));
         int64_t sw = 0;
-        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw));
+        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
         if (sweeps) *sweeps += sw;
         // X' = Q S,  G X' = (G Q) S
         TLSQ_TRY(gemm_f64(h, true, false, (const double*)S, p, (const double*)Q, N, (double*)XN, N, p, N, p, false));
@@ -320,11 +345,18 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
         if (svp > p - 2) break;  // the block may not contain every sigma >= 1/mu: let the full solver decide
         bool good = true;
-        for (int64_t i = 0; i < svp; ++i) good = good && (host[p + s.order[i]] <= 2e-13 * tmax);
+        double maxres = 0.0;
+        for (int64_t i = 0; i < svp; ++i) {
+            good = good && (host[p + s.order[i]] <= 2e-13 * tmax);
+            maxres = std::max(maxres, host[p + s.order[i]]);
+        }
         if (good) {
             conv = true;
             break;
         }
+        // hopeless (no spectral gap behind the block): stop early and let the full solver run
+        if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
+        prev_maxres = maxres;
     }
     // keep the workspace slot convention: the current block lives in WS_SX
     if (X != h->ws[WS_SX].p) {
@@ -358,7 +390,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     }
     double lmax = 0.0;
     int steps = 0;
-    int lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps);
+    int lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
     if (lst < 0) return lst;
     if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;  // ambiguous: full solver decides
     *V_out = (double*)X;
@@ -412,6 +444,7 @@ static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s,
     TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * want * 8, &X));
     TLSQ_HIP(h, hipMemcpyAsync(X, tmp, (size_t)N * want * 8, hipMemcpyDeviceToDevice, h->stream));
     sub.p = want;
+    sub.ntop = svp;
     sub.valid = true;
     return TLSQ_OK;
 }
@@ -534,9 +567,13 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         pt.mark();
         mu = std::min(mu * ro.rho, mubar);                         // :223
         double rn = 0.0;
-        TLSQ_TRY(opnorm_gram(h, R, M, N, M, &rn, &sweeps));        // :225
-        pt.mark();
+        TLSQ_TRY(opnorm_gram(h, R, M, N, M, &rn, &sweeps, 1e-8));  // :225
         cost = rn / d_norm;
+        if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {           // too close to call: full accuracy
+            TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N, 1e-13, &rn, &sweeps));
+            cost = rn / d_norm;
+        }
+        pt.mark();
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         pt.collect(acc);
         if (info) {

@@ -101,8 +101,9 @@ int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, doub
 // One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal
 // columns, lam_dev[i] = ||B[:,i]|| (unsorted), V orthogonal (ld N) unless want_v == false.
 // B and V are workspace buffers owned by the caller (N*N each).
+// async_small: when the matrix fits the single-workgroup path, do not read the sweep count back (no host sync).
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
-               bool want_v, double* lam_dev, int64_t* sweeps_out);
+               bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false);
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);
@@ -110,8 +111,9 @@ int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* se
 // ---------------- lanczos.hip ----------------
 // lambda_max(G) to relative accuracy rel_tol (residual bound of the Ritz pair); returns 1 (and the best
 // estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.
+// accept_below > 0: also stop (status 0) as soon as 2.5 * estimate < accept_below after >= 16 steps.
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used);
+                     double* lmax, int* steps_used, double accept_below = 0.0);
 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);
@@ -120,6 +122,7 @@ int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
 int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
+int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);
 
 // ---------------- hankel.hip ----------------
 template <typename T>

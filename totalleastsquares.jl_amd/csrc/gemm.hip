@@ -7,6 +7,8 @@
 //   Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j)      (the contiguous output index j sits on the MFMA column)
 //     A_KC: Aop(i,k) = A[k + i*lda]   else  A[i + k*lda]
 //     B_KC: Bop(k,j) = B[k + j*ldb]   else  B[j + k*ldb]
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace tlsq {
@@ -203,9 +205,14 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
     const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
     const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
     // split K so that the launch has >= ~256 workgroups (one per CU), each with >= 4 K stages
+    static const int64_t target_wgs = [] {
+        const char* e = getenv("TLSQ_GEMM_WGS");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 ? v : 256);   // one workgroup per CU (512 and 768 measured the same on C2)
+    }();
     int64_t nsplit = 1;
-    if (tiles < 256) {
-        nsplit = (256 + tiles - 1) / tiles;
+    if (tiles < target_wgs) {
+        nsplit = (target_wgs + tiles - 1) / tiles;
         const int64_t maxsplit = (K + 4 * TK - 1) / (4 * TK);
         if (nsplit > maxsplit) nsplit = maxsplit;
         if (nsplit < 1) nsplit = 1;

@@ -237,7 +237,7 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
 }
 
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,
-               double* lam_dev, int64_t* sweeps_out) {
+               double* lam_dev, int64_t* sweeps_out, bool async_small) {
     if (sweeps_out) *sweeps_out = 0;
     if (N <= 0) return TLSQ_OK;
     void* scal;
@@ -293,12 +293,18 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
             hipLaunchKernelGGL(k_jacobi_round<false>, dim3(1), dim3(64 * nwaves), lds, h->stream, B, V, (int)N,
                                b, nblk, 0, tol, (const double*)params, rot, max_sweeps, sweeps_dev);
         TLSQ_HIP(h, hipGetLastError());
-        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        int sd;
-        memcpy(&sd, h->pinned, 4);
-        sweep = sd;
-        converged = sd < max_sweeps;
+        if (async_small) {
+            // caller does not want a host round trip here: it validates the result itself (residuals)
+            sweep = 0;
+            converged = true;
+        } else {
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            int sd;
+            memcpy(&sd, h->pinned, 4);
+            sweep = sd;
+            converged = sd < max_sweeps;
+        }
     } else {
         for (; sweep < max_sweeps; ++sweep) {
             TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));

@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void k_sub(const double* __restrict__ G, const
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) Gd[i] = G[i] - Cc[i];
 }
 
+// deterministic pseudo-random fill in (-0.5, 0.5) (integer hash of the element index)
+__global__ __launch_bounds__(256) void k_fill_hash(double* __restrict__ X, int64_t n, unsigned int seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        unsigned int x = (unsigned int)i * 2654435761u + seed;
+        x ^= x >> 16;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        x *= 3266489917u;
+        x ^= x >> 16;
+        X[i] = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+    }
+}
+
+int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
+    int64_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_fill_hash, dim3((int)g), dim3(256), 0, h->stream, X, n, seed);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int subspace_max_block(int64_t N) {
     // CGS2 keeps the N x p panel in LDS
     const int64_t budget = 140 * 1024;
