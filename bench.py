@@ -79,7 +79,8 @@ def main():
         torch.cuda.synchronize()
 
     def solve():
-        return eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M)
+        # like a non-verbose reference call: no per-iteration cost history requested
+        return eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False)
 
     for _ in range(args.warmup):
         solve()

@@ -69,7 +69,9 @@ typedef struct tlsq_rpca_opts {
     void* user;
 } tlsq_rpca_opts;
 
-/* Per-call report.  cost_hist / svp_hist are optional caller-provided arrays of hist_capacity entries. */
+/* Per-call report.  cost_hist / svp_hist are optional caller-provided arrays of hist_capacity entries.
+ * When neither cost_hist nor opts->on_iter is given, the per-iteration opnorm is only resolved far enough to
+ * settle `cost < tol` (src/robustPCA.jl:228); final_cost is exact whenever the loop ends. */
 typedef struct tlsq_rpca_info {
     int64_t iters_done;
     int32_t converged;

@@ -429,3 +429,20 @@ def test_rpca_c2_full_size_properties(eng):
     # idempotence-like property: running on the recovered D' = A + E gives the same split
     A2, E2, *_ = eng.rpca(A + E, want_U=False)
     assert relerr(A2, A) < 1e-6
+
+
+def test_rpca_device_mode_and_decision_only_cost(eng, torch_mod):
+    """Device-pointer entry (no PCIe traffic) and the decision-only opnorm mode (no cost history requested):
+    same iterations, svp trajectory, A and E as the host-pointer / exact-cost call."""
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    D, _, _ = O.synth_lowrank_sparse(3000, 96, 6, seed=5)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    dD = to_dev(torch, D)
+    dA, dE = torch.empty_like(dD), torch.empty_like(dD)
+    torch.cuda.synchronize()
+    for want_hist in (True, False):
+        sv2, rep2, st = eng.rpca_device(dD.data_ptr(), 3000, 96, dA.data_ptr(), dE.data_ptr(), want_hist=want_hist)
+        assert st == 0 and sv2 == sv and rep2.iters_done == rep.iters_done and rep2.svp_hist == rep.svp_hist
+        assert np.array_equal(to_host(dA), A) and np.array_equal(to_host(dE), E)
+        assert abs(rep2.final_cost - rep.final_cost) <= 1e-6 * rep.final_cost

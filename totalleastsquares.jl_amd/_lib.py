@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtlsqhip.so")
+LIB_PATH = os.environ.get("TLSQ_LIB") or os.path.join(_HERE, "libtlsqhip.so")  # TLSQ_LIB: development builds
 
 TLSQ_OK, TLSQ_MAXITER = 0, 1
 TLSQ_ERR_ARG, TLSQ_ERR_HIP, TLSQ_ERR_OOM, TLSQ_ERR_COMM, TLSQ_ERR_UNSUPPORTED, TLSQ_ERR_NOCONV = -1, -2, -3, -4, -5, -6

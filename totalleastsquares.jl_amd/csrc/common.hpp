@@ -112,8 +112,9 @@ int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* se
 // lambda_max(G) to relative accuracy rel_tol (residual bound of the Ritz pair); returns 1 (and the best
 // estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.
 // accept_below > 0: also stop (status 0) as soon as 2.5 * estimate < accept_below after >= 16 steps.
+// stop_above > 0: also stop (status 0) as soon as the Ritz value (a lower bound of lambda_max) reaches stop_above.
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used, double accept_below = 0.0);
+                     double* lmax, int* steps_used, double accept_below = 0.0, double stop_above = 0.0);
 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);

@@ -11,6 +11,11 @@
 
 #include "common.hpp"
 
+// development-only ablation builds (tools/kbench.py): 0 = product
+#ifndef TLSQ_GEMM_ABLATE
+#define TLSQ_GEMM_ABLATE 0
+#endif
+
 namespace tlsq {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -20,40 +25,82 @@ constexpr int LDK = TK + 2;    // K-contiguous panel  [128][18]: (i*18 + k) dist
 constexpr int LDM = TI + 16;   // MN-contiguous panel [16][144]: (k*144 + i) distinct mod 32 over a half-wave
 constexpr int PANEL = 2304;    // doubles per panel (128*18 == 16*144)
 
-template <bool KC>
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---- global -> registers -> LDS staging of one 128 x 16 operand panel (8 doubles per thread) ----
+// FULL: the panel is entirely inside the matrix and 16-byte aligned -> unguarded double2 loads.
+template <bool KC, bool FULL>
 __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t ld, int64_t r0,
                                            int64_t rmax, int64_t k0, int64_t kmax, double (&reg)[8]) {
     const int t = threadIdx.x;
-    if (KC) {  // X[k + r*ld]: 16 consecutive k per r
-        const int k = t & 15, rr = t >> 4;
-        const int64_t kg = k0 + k;
+    if (FULL) {
+        if (KC) {  // X[k + r*ld]: thread takes k = 2*(t&7)..+1 of rows (t>>3) + 32 s
+            const int k = (t & 7) * 2, rr = t >> 3;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int64_t r = r0 + rr + 16 * s;
-            reg[s] = (r < rmax && kg < kmax) ? X[kg + r * ld] : 0.0;
+            for (int s = 0; s < 4; ++s) {
+                const d2 v = *reinterpret_cast<const d2*>(X + (k0 + k) + (r0 + rr + 32 * s) * ld);
+                reg[2 * s] = v[0];
+                reg[2 * s + 1] = v[1];
+            }
+        } else {  // X[r + k*ld]: thread takes r = 2*(t&63)..+1 of k = (t>>6) + 4 s
+            const int r = (t & 63) * 2, kk = t >> 6;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const d2 v = *reinterpret_cast<const d2*>(X + (r0 + r) + (k0 + kk + 4 * s) * ld);
+                reg[2 * s] = v[0];
+                reg[2 * s + 1] = v[1];
+            }
         }
-    } else {  // X[r + k*ld]: 128 consecutive r per k
-        const int r = t & 127, kk = t >> 7;
-        const int64_t rg = r0 + r;
+    } else {
+        if (KC) {  // X[k + r*ld]: 16 consecutive k per r
+            const int k = t & 15, rr = t >> 4;
+            const int64_t kg = k0 + k;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int64_t kg = k0 + kk + 2 * s;
-            reg[s] = (rg < rmax && kg < kmax) ? X[rg + kg * ld] : 0.0;
+            for (int s = 0; s < 8; ++s) {
+                const int64_t r = r0 + rr + 16 * s;
+                const bool ok = (r < rmax && kg < kmax);
+                const double v = X[ok ? kg + r * ld : 0];  // always-valid address, then select (no branch)
+                reg[s] = ok ? v : 0.0;
+            }
+        } else {  // X[r + k*ld]: 128 consecutive r per k
+            const int r = t & 127, kk = t >> 7;
+            const int64_t rg = r0 + r;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int64_t kg = k0 + kk + 2 * s;
+                const bool ok = (rg < rmax && kg < kmax);
+                const double v = X[ok ? rg + kg * ld : 0];
+                reg[s] = ok ? v : 0.0;
+            }
         }
     }
 }
 
-template <bool KC>
+template <bool KC, bool FULL>
 __device__ __forceinline__ void panel_store(double* __restrict__ sm, const double (&reg)[8]) {
     const int t = threadIdx.x;
-    if (KC) {
-        const int k = t & 15, rr = t >> 4;
+    if (FULL) {
+        if (KC) {
+            const int k = (t & 7) * 2, rr = t >> 3;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sm[(rr + 16 * s) * LDK + k] = reg[s];
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<d2*>(sm + (rr + 32 * s) * LDK + k) = d2{reg[2 * s], reg[2 * s + 1]};
+        } else {
+            const int r = (t & 63) * 2, kk = t >> 6;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<d2*>(sm + (kk + 4 * s) * LDM + r) = d2{reg[2 * s], reg[2 * s + 1]};
+        }
     } else {
-        const int r = t & 127, kk = t >> 7;
+        if (KC) {
+            const int k = t & 15, rr = t >> 4;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sm[(kk + 2 * s) * LDM + r] = reg[s];
+            for (int s = 0; s < 8; ++s) sm[(rr + 16 * s) * LDK + k] = reg[s];
+        } else {
+            const int r = t & 127, kk = t >> 7;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sm[(kk + 2 * s) * LDM + r] = reg[s];
+        }
     }
 }
 
@@ -63,14 +110,101 @@ __device__ __forceinline__ double panel_at(const double* __restrict__ sm, int r,
     return KC ? sm[r * LDK + k] : sm[k * LDM + r];
 }
 
+// NA = number of live 16-row MFMA tiles of this wave along i (1, 2 or 4); j always uses 4.
+// FULL = interior tile (no bounds checks, vector loads).
+template <bool A_KC, bool B_KC, bool FULL, int NA>
+__device__ __forceinline__ void gemm_body(const double* __restrict__ A, int64_t lda,
+                                          const double* __restrict__ B, int64_t ldb,
+                                          double* __restrict__ Cz, int64_t ldc, int64_t P, int64_t Q,
+                                          int64_t kbeg, int64_t kend, int64_t i0, int64_t j0,
+                                          double* __restrict__ smem) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    d4 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double ra[8], rb[8];
+    const int64_t nstage = (kend > kbeg) ? (kend - kbeg + TK - 1) / TK : 0;
+    if (nstage > 0) {
+        panel_load<A_KC, FULL>(A, lda, i0, P, kbeg, kend, ra);
+        panel_load<B_KC, FULL>(B, ldb, j0, Q, kbeg, kend, rb);
+        panel_store<A_KC, FULL>(smem, ra);
+        panel_store<B_KC, FULL>(smem + 2 * PANEL, rb);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+
+    for (int64_t s = 0; s < nstage; ++s) {
+        const int cur = (int)(s & 1);
+        const bool more = (s + 1 < nstage);
+        if (more && TLSQ_GEMM_ABLATE != 1) {   // ablation build 1: no global loads after the first stage
+            const int64_t kn = kbeg + (s + 1) * TK;
+            panel_load<A_KC, FULL>(A, lda, i0, P, kn, kend, ra);
+            panel_load<B_KC, FULL>(B, ldb, j0, Q, kn, kend, rb);
+        }
+        const double* __restrict__ sa = smem + cur * PANEL;
+        const double* __restrict__ sb = smem + (2 + cur) * PANEL;
+        // fragments of k-step q+1 are fetched from LDS while the 4*NA MFMAs of k-step q issue
+        double fa[2][NA], fb[2][4];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) fa[0][a] = panel_at<A_KC>(sa, wi * 64 + a * 16 + fr, fk);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[0][b] = panel_at<B_KC>(sb, wj * 64 + b * 16 + fr, fk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = q & 1, nbuf = cb ^ 1;
+            if (q < 3) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    fa[nbuf][a] = panel_at<A_KC>(sa, wi * 64 + a * 16 + fr, 4 * (q + 1) + fk);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    fb[nbuf][b] = panel_at<B_KC>(sb, wj * 64 + b * 16 + fr, 4 * (q + 1) + fk);
+            }
+#if TLSQ_GEMM_ABLATE == 2   // ablation build 2: no MFMAs (keeps the LDS reads alive)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) asm volatile("" ::"v"(fa[cb][a]), "v"(fb[cb][a]));
+#else
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cb][a], fb[cb][b], acc[a][b], 0, 0, 0);
+#endif
+        }
+        if (more) {
+            panel_store<A_KC, FULL>(smem + (cur ^ 1) * PANEL, ra);
+            panel_store<B_KC, FULL>(smem + (2 + (cur ^ 1)) * PANEL, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column j = lane&15, rows i = (lane>>4) + 4*reg of each 16x16 tile
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t j = j0 + wj * 64 + b * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wi * 64 + a * 16 + fk + 4 * r;
+                if (FULL || (i < P && j < Q)) Cz[j + i * ldc] = acc[a][b][r];
+            }
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ A, int64_t lda,
                                                      const double* __restrict__ B, int64_t ldb,
                                                      double* __restrict__ C, int64_t ldc, int64_t P,
                                                      int64_t Q, int64_t K, int64_t kchunk,
                                                      int64_t slab_stride, int nti, int ntj,
-                                                     int symmetric) {
-    __shared__ double smem[4 * PANEL];  // A[2], B[2]
+                                                     int symmetric, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
     // XCD-aware remap: blocks b and b+8 share an XCD's L2 -> give every XCD a contiguous run of tiles
     const int nb = nti * ntj;
     const int cpx = (nb + 7) / 8;
@@ -82,83 +216,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ 
     const int64_t kbeg = (int64_t)z * kchunk;
     const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     double* __restrict__ Cz = C + (int64_t)z * slab_stride;
-
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wi = w & 1, wj = w >> 1;
     const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
-
-    d4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-
-    double ra[8], rb[8];
-    const int64_t nstage = (kend > kbeg) ? (kend - kbeg + TK - 1) / TK : 0;
-    if (nstage > 0) {
-        panel_load<A_KC>(A, lda, i0, P, kbeg, kend, ra);
-        panel_load<B_KC>(B, ldb, j0, Q, kbeg, kend, rb);
-        panel_store<A_KC>(smem, ra);
-        panel_store<B_KC>(smem + 2 * PANEL, rb);
-    }
-    __syncthreads();
-
-    const int fr = lane & 15, fk = lane >> 4;
-    // which 16-wide tiles of this wave hold any real row / column
-    bool liveA[4], liveB[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        liveA[a] = (i0 + wi * 64 + a * 16) < P;
-        liveB[a] = (j0 + wj * 64 + a * 16) < Q;
-    }
-
-    for (int64_t s = 0; s < nstage; ++s) {
-        const int cur = (int)(s & 1);
-        const bool more = (s + 1 < nstage);
-        if (more) {
-            const int64_t kn = kbeg + (s + 1) * TK;
-            panel_load<A_KC>(A, lda, i0, P, kn, kend, ra);
-            panel_load<B_KC>(B, ldb, j0, Q, kn, kend, rb);
-        }
-        const double* __restrict__ sa = smem + cur * PANEL;
-        const double* __restrict__ sb = smem + (2 + cur) * PANEL;
-#pragma unroll
-        for (int kk = 0; kk < TK; kk += 4) {
-            double fa[4], fb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                fa[a] = panel_at<A_KC>(sa, wi * 64 + a * 16 + fr, kk + fk);
-                fb[a] = panel_at<B_KC>(sb, wj * 64 + a * 16 + fr, kk + fk);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (!liveA[a]) continue;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (!liveB[b]) continue;
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-                }
-            }
-        }
-        if (more) {
-            panel_store<A_KC>(smem + (cur ^ 1) * PANEL, ra);
-            panel_store<B_KC>(smem + (2 + (cur ^ 1)) * PANEL, rb);
-        }
-        __syncthreads();
-    }
-
-    // epilogue: lane holds column j = lane&15, rows i = (lane>>4) + 4*reg of each 16x16 tile
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int64_t j = j0 + wj * 64 + b * 16 + fr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t i = i0 + wi * 64 + a * 16 + fk + 4 * r;
-                if (i < P && j < Q) Cz[j + i * ldc] = acc[a][b][r];
-            }
-        }
+    const bool full = vec_ok && (i0 + TI <= P) && (j0 + TJ <= Q) && ((kend - kbeg) % TK == 0);
+    if (full) {
+#if TLSQ_GEMM_ABLATE == 3   // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        gemm_body<A_KC, B_KC, true, 4>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+#if TLSQ_GEMM_ABLATE == 3
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && lin == 5 && z == 3 && kend - kbeg > 256)
+            printf("gemm clk: %llu cycles, %llu x10ns -> %.3f GHz, %.1f us\n", t1 - t0, r1 - r0,
+                   (double)(t1 - t0) / (double)(r1 - r0) * 0.1, (double)(r1 - r0) * 0.01);
+#endif
+    } else {
+        // live 16-row tiles along i for the widest wave (wave-uniform by construction: depends on blockIdx only)
+        const int64_t rows = P - i0;  // > 0
+        if (rows <= 16)
+            gemm_body<A_KC, B_KC, false, 1>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+        else if (rows <= 32)
+            gemm_body<A_KC, B_KC, false, 2>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+        else
+            gemm_body<A_KC, B_KC, false, 4>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
     }
 }
 
@@ -187,9 +266,13 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t
     const int nb = nti * ntj;
     const int cpx = (nb + 7) / 8;
     dim3 grid(8 * cpx, nsplit), block(256);
+    // 16-byte vector loads need even leading dimensions, 16-byte aligned bases and an even K chunk
+    const int vec_ok = ((lda % 2) == 0 && (ldb % 2) == 0 && (kchunk % 2) == 0 &&
+                        (reinterpret_cast<uintptr_t>(A) % 16) == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0)
+                           ? 1 : 0;
 #define GO(AK, BK)                                                                                 \
     hipLaunchKernelGGL((k_gemm_f64<AK, BK>), grid, block, 0, h->stream, A, lda, B, ldb, C, ldc, P, Q, \
-                       K, kchunk, slab_stride, nti, ntj, symmetric ? 1 : 0)
+                       K, kchunk, slab_stride, nti, ntj, symmetric ? 1 : 0, vec_ok)
     if (A_KC && B_KC) GO(true, true);
     else if (A_KC && !B_KC) GO(true, false);
     else if (!A_KC && !B_KC) GO(false, false);
@@ -212,7 +295,8 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
     }();
     int64_t nsplit = 1;
     if (tiles < target_wgs) {
-        nsplit = (target_wgs + tiles - 1) / tiles;
+        nsplit = target_wgs / tiles;   // floor: never more workgroups than the target (no tail wave)
+        if (nsplit < 1) nsplit = 1;
         const int64_t maxsplit = (K + 4 * TK - 1) / (4 * TK);
         if (nsplit > maxsplit) nsplit = maxsplit;
         if (nsplit < 1) nsplit = 1;

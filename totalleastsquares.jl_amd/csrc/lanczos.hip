@@ -183,7 +183,7 @@ static double tridiag_lmax(const double* a, const double* b, int m, double* last
 
 // returns TLSQ_OK and *lmax, or 1 if the requested accuracy was not reached in max_steps (caller falls back)
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used, double accept_below) {
+                     double* lmax, int* steps_used, double accept_below, double stop_above) {
     if (N <= 0) {
         *lmax = 0.0;
         return TLSQ_OK;
@@ -237,6 +237,11 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
         const double bound = fabs(b[m - 1]) * sm;  // ||G y - theta y|| for the Ritz pair
         if (bound <= rel_tol * fabs(theta)) {
             *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        // the Ritz value is a lower bound of lambda_max: "is lambda_max >= X?" is settled as soon as it passes X
+        if (stop_above > 0.0 && theta >= stop_above) {
+            *lmax = theta;
             return TLSQ_OK;
         }
         // early accept for "is lambda_max clearly below X?" questions: the Ritz value is a lower bound that is

@@ -187,12 +187,14 @@ class Engine:
         return A, E, s, int(sv.value)
 
     def rpca_device(self, dD, M, N, dA, dE, *, dU=None, dS=None, dVt=None, iters=1000, m_global=0,
-                    **optkw):
+                    want_hist=True, **optkw):
         """rpca on DEVICE-resident column-major panels (raw device addresses as ints): D (M x N, ld M) in,
         A, E (M x N) out, optional U (M x d), S (d), Vt (d x N).  Nothing crosses PCIe except O(N) scalars.
         Returns (sv, RpcaReport, status)."""
         o = self.make_opts(iters=iters, memory=L.MEM_DEVICE, m_global=m_global, **optkw)
         info, cost, svp = self._info(int(iters))
+        if not want_hist:   # no per-iteration cost requested: the library only settles cost < tol (see tlsq.h)
+            info.cost_hist = None
         sv = C.c_int64(0)
         d = min(max(m_global, M), N)
         vp = lambda x: C.c_void_p(int(x)) if x else None
