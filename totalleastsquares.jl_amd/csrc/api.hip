@@ -306,13 +306,19 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     double prev_maxres = 0.0;
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
-        // Q = orth([G^2 X_top, G X_pad]) on the first step (the block arrives sorted: the first ntop columns are
-        // the previous iteration's dominant vectors; squaring their convergence factor saves a whole step),
-        // Q = orth(G X) afterwards
+        // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
+        // vectors; q-1 extra multiplications of those columns cost one skinny GEMM each and raise their
+        // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
+        // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
+        // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
         TLSQ_TRY(gemm_f64(h, true, false, (const double*)X, N, G, N, (double*)Q, N, p, N, N, false));
-        if (step == 0 && ntop > 0) {
-            TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, ntop, N, N, false));
-            TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * ntop * 8, hipMemcpyDeviceToDevice, h->stream));
+        {
+            const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
+            const int q = cold ? 2 : 3;
+            for (int t = 1; t < q && nt > 0; ++t) {
+                TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, nt, N, N, false));
+                TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
+            }
         }
         TLSQ_TRY(launch_cgs2(h, (double*)Q, N, p, stat_dev));
         // Rayleigh-Ritz: H = Q' (G Q)
@@ -329,7 +335,6 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 1) * 8, hipMemcpyDeviceToHost,
                                    h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        std::swap(X, XN);  // X now holds the Ritz vectors
         s.sigma.resize((size_t)p);
         double tmax = 0.0;
         bool finite = true;
@@ -339,18 +344,45 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
             tmax = std::max(tmax, t);
             s.sigma[i] = std::sqrt(std::max(t, 0.0));
         }
-        if (!finite) break;
+        if (!finite) {
+            st.valid = false;
+            break;
+        }
         s.ncols = p;
         sort_desc(s);
+        // keep the block sorted by Ritz value: X = X'[:, order]
+        {
+            std::vector<double> res_sorted((size_t)p), th_sorted((size_t)p), sg_sorted((size_t)p);
+            for (int64_t i = 0; i < p; ++i) {
+                res_sorted[i] = host[p + s.order[i]];
+                th_sorted[i] = host[s.order[i]];
+                sg_sorted[i] = s.sigma[s.order[i]];
+            }
+            TLSQ_HIP(h, hipMemcpyAsync(aux, s.order.data(), (size_t)p * 4, hipMemcpyHostToDevice, h->stream));
+            TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
+                                         (double*)X));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            for (int64_t i = 0; i < p; ++i) {
+                host[i] = th_sorted[i];
+                host[p + i] = res_sorted[i];
+                s.sigma[i] = sg_sorted[i];
+            }
+            std::iota(s.order.begin(), s.order.end(), 0);
+        }
         svp = 0;
         for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
         if (svp > p - 2) break;  // the block may not contain every sigma >= 1/mu: let the full solver decide
         bool good = true;
         double maxres = 0.0;
         for (int64_t i = 0; i < svp; ++i) {
-            good = good && (host[p + s.order[i]] <= 2e-13 * tmax);
-            maxres = std::max(maxres, host[p + s.order[i]]);
+            good = good && (host[p + i] <= 2e-13 * tmax);
+            maxres = std::max(maxres, host[p + i]);
         }
+        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "  subspace step %d: p=%lld ntop=%lld svp=%lld maxres/tmax=%.3e tail/tau=%.3f cold=%d\n", step,
+                    (long long)p, (long long)ntop, (long long)svp, maxres / tmax,
+                    svp < p ? s.sigma[s.order[svp]] / inv_mu : 0.0, (int)cold);
         if (good) {
             conv = true;
             break;
@@ -358,11 +390,6 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         // hopeless (no spectral gap behind the block): stop early and let the full solver run
         if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
         prev_maxres = maxres;
-    }
-    // keep the workspace slot convention: the current block lives in WS_SX
-    if (X != h->ws[WS_SX].p) {
-        TLSQ_HIP(h, hipMemcpyAsync(h->ws[WS_SX].p, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
-        X = h->ws[WS_SX].p;
     }
     if (!conv) return TLSQ_OK;
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
@@ -433,15 +460,19 @@ static int rebuild_lowrank(Handle* h, const double* Z, int64_t M, int64_t N, int
 static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
                        SubspaceState& sub) {
     const int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(8, svp / 4));
-    if (want > pmax || want > s.ncols || want < 3) {
+    if (want > pmax || want < 3) {
         sub.valid = false;
         return TLSQ_OK;
     }
-    std::vector<int32_t> keep((size_t)want);
-    for (int64_t p = 0; p < want; ++p) keep[p] = s.order[p];
+    // the sorted vectors we have (a subspace result only carries p of them); any missing pad columns are
+    // pseudo-random — the next iteration's CGS2 orthogonalises them against the rest
+    const int64_t have = std::min<int64_t>(want, s.ncols);
+    std::vector<int32_t> keep((size_t)have);
+    for (int64_t p = 0; p < have; ++p) keep[p] = s.order[p];
     void *tmp, *X;
     TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * want * 8, &tmp));
     TLSQ_TRY(gather_cols(h, V, N, keep, (double*)tmp));          // out of place (V may be WS_SX itself)
+    if (have < want) TLSQ_TRY(launch_fill_hash(h, (double*)tmp + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
     TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * want * 8, &X));
     TLSQ_HIP(h, hipMemcpyAsync(X, tmp, (size_t)N * want * 8, hipMemcpyDeviceToDevice, h->stream));
     sub.p = want;
