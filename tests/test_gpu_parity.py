@@ -344,7 +344,9 @@ def test_rpca_unsupported_paths_fail_loudly(eng):
     with pytest.raises(tlsq_amd.TlsqError):
         eng.rpca(np.ones((4, 4)) * (1 + 1j))
     with pytest.raises(tlsq_amd.TlsqError):
-        eng.rpca(np.ones((4, 4)), svd=lambda Z, k: None)
+        eng.rpca(np.ones((4, 4)), svd=lambda Z, k: None)           # arbitrary closures cannot run on the GPU
+    with pytest.raises(tlsq_amd.TlsqError):
+        eng.rpca(np.ones((4, 4)), opnorm=lambda X: 1.0)
 
 
 # --------------------------------------------------------------------------------------------
@@ -446,3 +448,72 @@ def test_rpca_device_mode_and_decision_only_cost(eng, torch_mod):
         assert st == 0 and sv2 == sv and rep2.iters_done == rep.iters_done and rep2.svp_hist == rep.svp_hist
         assert np.array_equal(to_host(dA), A) and np.array_equal(to_host(dE), E)
         assert abs(rep2.final_cost - rep.final_cost) <= 1e-6 * rep.final_cost
+
+
+# --------------------------------------------------------------------------------------------
+# fp32, the svd / opnorm hook modes, wide matrices
+# --------------------------------------------------------------------------------------------
+def test_rpca_f32_vs_oracle(eng):
+    """fp32 ALM loop (tlsq_rpca_f32): relative error <= 1e-3 vs the fp32 oracle, iterations within +-1
+    (SURVEY.md section 8c); tol defaults to sqrt(eps(Float32))."""
+    from oracle import rpca_oracle as O
+    D, A0, _ = O.synth_lowrank_sparse(1500, 96, 6, seed=7, dtype=np.float32)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert Ao.dtype == np.float32
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    assert A.dtype == np.float32 and E.dtype == np.float32 and s.S.dtype == np.float32
+    assert abs(rep.iters_done - io.iters_done) <= 1 and sv == svo
+    assert relerr(A.astype(np.float64), Ao.astype(np.float64)) < 1e-3
+    assert relerr(E.astype(np.float64), Eo.astype(np.float64)) < 1e-3
+    assert relerr(A.astype(np.float64), A0.astype(np.float64)) < 1e-3
+
+
+def test_wide_matrix_singular_values(eng):
+    """M < N is solved on the transposed problem: the returned singular values are accurate (no
+    structurally-zero Gram eigenvalues) and U, Vt keep their roles."""
+    from oracle import rpca_oracle as O
+    D, _, _ = O.synth_lowrank_sparse(300, 40, 4, seed=2)
+    Dw = D.T.copy()
+    Ao, Eo, so, svo, io = O.rpca(Dw)
+    A, E, s, sv, rep = eng.rpca(Dw, return_report=True)
+    assert rep.iters_done == io.iters_done and sv == svo
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    assert np.allclose(s.S, so[1], rtol=1e-6, atol=1e-9 * so[1][0])
+    r = sv
+    assert s.U.shape == (40, 40) and s.Vt.shape == (40, 300)
+    assert np.max(np.abs(s.U[:, :r].T @ s.U[:, :r] - np.eye(r))) < 1e-10
+    assert np.max(np.abs(s.Vt[:r] @ s.Vt[:r].T - np.eye(r))) < 1e-10
+    Zr = (s.U[:, :r] * s.S[:r]) @ s.Vt[:r]
+    assert relerr(Zr, (so[0][:, :r] * so[1][:r]) @ so[2][:r]) < 1e-8
+
+
+def test_hook_modes_lowrankfilter_thresholds(eng):               # test/runtests.jl:383-398
+    T = 1000
+    y = np.sin(0.1 * np.arange(1, T + 1))
+    y = y / np.quantile(np.abs(y), 0.9)
+    rng = np.random.default_rng(0)
+    n = 20 * rng.standard_normal(T) * (rng.random(T) < 0.01) + 0.1 * rng.standard_normal(T)
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+    err = lambda yf: np.mean((y - qn(yf)) ** 2) / np.mean(n ** 2)
+    assert err(eng.lowrankfilter(y + n, opnorm=("power", 10))) < 0.001
+    assert err(eng.lowrankfilter(y + n, svd="randomized")) < 0.05
+    assert err(eng.lowrankfilter(y + n, opnorm=("power", 10), svd="randomized")) < 0.05
+    assert err(eng.lowrankfilter(y + n, opnorm=("power", 10), svd="randomized", maxrank=5)) < 0.05
+
+
+def test_hook_modes_rpca_close_to_exact(eng):
+    """svd='randomized' = the reference's `svd(Z, sv)` hook: full SVD at k = 1, rank-sv randomized SVD afterwards
+    (the rank estimate cannot grow after iteration 1, src/robustPCA.jl:193-204).  opnorm=('power', mvps) = the
+    rnorm upper-bound estimator: it over-estimates ||D||_2, which changes mu_0 and the cost scale, so only the
+    fixed point is compared."""
+    from oracle import rpca_oracle as O
+    D, A0, _ = O.synth_lowrank_sparse(2000, 128, 8, seed=1)
+    A, E, s, sv, rep0 = eng.rpca(D, return_report=True)
+    Ar, Er, sr, svr, rep = eng.rpca(D, svd="randomized", return_report=True)
+    assert svr == sv and rep.converged and rep.iters_done == rep0.iters_done
+    assert rep.svp_hist == rep0.svp_hist
+    assert relerr(Ar, A) < 1e-6 and relerr(Ar, A0) < 1e-6
+    Ap, Ep, sp, svp_, repp = eng.rpca(D, opnorm=("power", 10), return_report=True)
+    assert repp.converged and svp_ == sv
+    assert relerr(Ap, A0) < 1e-5
+    assert repp.d_norm >= rep0.d_norm                      # rnorm is an upper bound

@@ -184,14 +184,46 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
     return TLSQ_OK;
 }
 
+template <typename T>
+struct Prec {
+    static constexpr int f32 = std::is_same<T, float>::value ? 1 : 0;
+};
+
 // sigma_max of Z (device M x N, ld) = the default `opnorm`; uses WS_G.
-static int opnorm_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double* out,
+template <typename T>
+static int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double* out,
                        int64_t* sweeps, double rel_tol = 1e-13, double stop_above_sigma = 0.0) {
     void* G;
     TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
-    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
     TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
     return sigma_max_of_gram(h, (const double*)G, N, rel_tol, out, sweeps, stop_above_sigma);
+}
+
+// The `opnorm = x -> rnorm(x, mvps)` hook of the reference's tests (test/runtests.jl:384-398,
+// RandomizedLinAlg.rnorm): probabilistic upper bound  alpha*sqrt(2/pi)*max_i ||Z w_i||,  w_i ~ N(0,I),
+// i = 1..mvps, alpha = 0.05^(-1/mvps)  (Halko, Martinsson, Tropp 2011, Lemma 4.1).  One skinny GEMM over Z.
+template <typename T>
+static int opnorm_power(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, int mvps, uint64_t seed,
+                        double* out) {
+    if (mvps < 1) mvps = 1;
+    if (mvps > 64) mvps = 64;
+    void *Om, *T1, *nn;
+    TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * mvps * 8, &Om));
+    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * mvps * 8, &T1));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 64) * 8, &nn));
+    TLSQ_TRY(launch_fill_gauss(h, (double*)Om, N * mvps, (unsigned int)(seed * 2654435761ull + 0x1234567u)));
+    TLSQ_TRY(gemm_mixed(h, true, false, Om, 0, N, Z, Prec<T>::f32, ld, T1, 0, M, mvps, M, N, false));
+    TLSQ_TRY(launch_colsumsq(h, (const double*)T1, M, M, mvps, (double*)nn));
+    TLSQ_TRY(comm_allreduce(h, (double*)nn, (size_t)mvps, ncclSum));
+    std::vector<double> hn((size_t)mvps);
+    TLSQ_HIP(h, hipMemcpyAsync(hn.data(), nn, (size_t)mvps * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double mx = 0.0;
+    for (double v : hn) mx = std::max(mx, v);
+    const double alpha = std::pow(0.05, -1.0 / (double)mvps);
+    *out = alpha * std::sqrt(2.0 / M_PI) * std::sqrt(mx);
+    return TLSQ_OK;
 }
 
 // Decomposition of the Gram of Z: V (device, N x ncols, ld N), sigma (host, per column of V), order (descending)
@@ -209,10 +241,11 @@ static void sort_desc(SmallSvd& s) {
 }
 
 // G (WS_G) = Z'Z summed over the row shards
-static int gram_allreduce(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** G_out) {
+template <typename T>
+static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out) {
     void* G;
     TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
-    TLSQ_TRY(gram_f64(h, Z, M, N, ld, (double*)G, N));
+    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
     TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
     *G_out = (double*)G;
     return TLSQ_OK;
@@ -237,10 +270,11 @@ static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, Small
     return TLSQ_OK;
 }
 
-static int svd_via_gram(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
+template <typename T>
+static int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
                         SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
     double* G;
-    TLSQ_TRY(gram_allreduce(h, Z, M, N, ld, &G));
+    TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, ld, &G));
     if (pt) pt->mark();
     return eig_full(h, G, N, V_out, s, sweeps);
 }
@@ -251,6 +285,10 @@ struct SubspaceState {
     bool allow_cold = true;
     int64_t p = 0;       // columns of X (WS_SX, N x p)
     int64_t ntop = 0;    // the first ntop columns of X were >= 1/mu in the iteration that produced them
+    // hook mode (`svd = rsvd`-style user hook, src/robustPCA.jl:195-197): rank-`hook_rank` randomized SVD from a
+    // fresh random block, fixed number of passes, no convergence test and no count certificate
+    int64_t hook_rank = 0;
+    uint64_t hook_seed = 0;
     int64_t fast = 0, full = 0, steps = 0;
 };
 
@@ -272,8 +310,12 @@ static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<
 static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, SubspaceState& st,
                         double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
     *ok = false;
-    const bool cold = !st.valid;
-    if (cold) {
+    const bool hook = st.hook_rank > 0;
+    const bool cold = hook || !st.valid;
+    if (hook) {
+        st.p = std::min<int64_t>(std::min<int64_t>(st.hook_rank + 10, subspace_max_block(N)), N);
+        if (st.p < st.hook_rank || st.p < 3) return TLSQ_OK;   // block too large for this path: full solver + truncation
+    } else if (cold) {
         // no block yet (first ALM iteration): start from a pseudo-random block of 10 + 8 columns — 10 is the
         // reference's initial rank guess `sv = 10` (src/robustPCA.jl:184)
         if (!st.allow_cold) return TLSQ_OK;
@@ -284,7 +326,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     const int64_t p = st.p;
     void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
     TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * p * 8, &X));
-    if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, 0x9E3779B9u));
+    if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, hook ? (unsigned int)(st.hook_seed * 2654435761ull + 77u) : 0x9E3779B9u));
     TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
     TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
     TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * p * 8, &XN));
@@ -299,7 +341,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     double* stat_dev = res_dev + p;
     double* lamH_dev = stat_dev + 8;
     std::vector<double> host((size_t)2 * p + 8);
-    const int max_steps = cold ? 30 : 10;
+    const int max_steps = hook ? 2 : (cold ? 30 : 10);
     const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
     int64_t svp = 0;
     bool conv = false;
@@ -371,6 +413,13 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         }
         svp = 0;
         for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        if (hook) {
+            if (step + 1 < max_steps) continue;
+            s.ncols = std::min<int64_t>(st.hook_rank, p);   // rank-sv truncation, like `svd(Z, sv)`
+            *V_out = (double*)X;
+            *ok = true;
+            return TLSQ_OK;
+        }
         if (svp > p - 2) break;  // the block may not contain every sigma >= 1/mu: let the full solver decide
         bool good = true;
         double maxres = 0.0;
@@ -427,29 +476,29 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
 }
 
 // Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'   with r = sel.size() columns
-static int rebuild_lowrank(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
+template <typename T>
+static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
                            const double* V, const std::vector<int32_t>& sel,
-                           const std::vector<double>& g, double* Aout, int64_t ldA) {
+                           const std::vector<double>& g, T* Aout, int64_t ldA) {
     const int64_t r = (int64_t)sel.size();
     if (r == 0) {  // svp = 0  =>  A = 0 (mul! with inner dimension 0, src/robustPCA.jl:207-208)
-        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * 8, 0, (size_t)M * 8, (size_t)N, h->stream));
+        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
         return TLSQ_OK;
     }
-    void *Vg, *Vs, *T, *aux;
+    void *Vg, *Vs, *T1, *aux;
     TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * r * 8, &Vg));
     TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
-    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T));
+    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T1));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
     int32_t* dsel = (int32_t*)aux;
     double* dg = (double*)((char*)aux + ((r * 4 + 7) / 8) * 8);
     TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)r * 4, hipMemcpyHostToDevice, h->stream));
     TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)r * 8, hipMemcpyHostToDevice, h->stream));
     TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
-    // T (M x r) = Z * Vg
-    TLSQ_TRY(gemm_f64(h, true, false, (const double*)Vg, N, Z, ldZ, (double*)T, M, r, M, N, false));
+    // T (M x r, fp64) = Z * Vg
+    TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
     // A (M x N) = T * Vs'
-    TLSQ_TRY(gemm_f64(h, false, false, (const double*)Vs, N, (const double*)T, M, Aout, ldA, N, M, r,
-                      false));
+    TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, T1, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
     // the async H2D above read from `sel`/`g` host vectors: make sure they are consumed before return
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
@@ -504,34 +553,41 @@ static ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// the ALM loop on device-resident, contiguous (ld = M) panels D, A, E.
-// Vt_host (d x N, ld d) / S_host (d) / U_dev (M x d, ld M) optional.
+// the ALM loop on device-resident, contiguous (ld = M) panels D, A, E of element type T (fp64 or fp32).
+// The small N x N work (Gram matrices, eigenvectors, singular values) is always fp64.
+// Vt_host (d x N, ld ldVt, fp64) / S_host (d, fp64) / U_dev (M x d, ld M, T) optional.
 // ------------------------------------------------------------------------------------------------
-static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
-                     const tlsq_rpca_opts* opts, double* A, double* E, double* U_dev, double* S_host,
+template <typename T>
+static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                     const tlsq_rpca_opts* opts, T* A, T* E, T* U_dev, double* S_host,
                      double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info) {
     const int64_t n = M * N;
     const bool timing = info != nullptr;
     void *Yv, *Zv, *Rv;
-    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * 8, &Yv));
-    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * 8, &Zv));
-    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * 8, &Rv));
-    double *Y = (double*)Yv, *Z = (double*)Zv, *R = (double*)Rv;
+    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * sizeof(T), &Yv));
+    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
+    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
+    T *Y = (T*)Yv, *Z = (T*)Zv, *R = (T*)Rv;
     int64_t sweeps = 0;
+    const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
+    const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
+    const int mvps = opts && opts->opnorm_mvps > 0 ? opts->opnorm_mvps : 10;
+    const uint64_t seed = opts ? opts->seed : 0;
 
     // ---- setup, src/robustPCA.jl:171-184 ----
-    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 8, h->stream));  // :174
-    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 8, h->stream));
+    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
+    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
     double norm2 = 0.0;
-    TLSQ_TRY(opnorm_gram(h, D, M, N, M, &norm2, &sweeps));         // :177 opnorm(Y), Y = copy(D)
+    if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
+    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
-    TLSQ_TRY(launch_maxabs<double>(h, D, n, &maxabs));             // :178 norm(Y, Inf)
+    TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));                  // :178 norm(Y, Inf)
     TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
     const double lam = ro.lambda;
     const double norminf = maxabs / lam;
     const double dual_norm = std::max(norm2, norminf);             // :179
     const double d_norm = norm2;                                   // :180
-    TLSQ_TRY(launch_div_scalar<double>(h, D, Y, n, dual_norm));    // :181
+    TLSQ_TRY(launch_div_scalar<T>(h, D, Y, n, (T)dual_norm));      // :181
     double mu = 1.25 / norm2;                                      // :182
     const double mubar = mu * 1.0e7;                               // :183
     int64_t sv = 10, svp = 10;                                     // :184
@@ -542,17 +598,17 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
     }
     SmallSvd s;
     double* V = nullptr;
-    // warm-started subspace iteration for k >= 2 (falls back to the full Jacobi solver whenever it cannot
-    // certify the count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
+    // warm-started subspace iteration (falls back to the full Jacobi solver whenever it cannot certify the
+    // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
     SubspaceState sub;
     const int64_t pmax = subspace_max_block(N);
     const char* force_full = getenv("TLSQ_FULL_EIG");
-    const bool use_subspace = !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
+    const bool use_subspace = !hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
     bool v_is_full = false;
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
     void* meanws = nullptr;
-    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * 8, &meanws));
+    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * sizeof(T), &meanws));
 
     PhaseTimer pt(h, timing);
     double zero_sink = 0.0;
@@ -566,23 +622,33 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         const double inv_mu = 1.0 / mu;
         const double thr = lam / mu;
         pt.mark();
-        TLSQ_TRY(launch_shrink<double>(h, D, A, Y, E, Z, n, inv_mu, thr, ro.nonnegE ? 1 : 0));  // :188-192
+        TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark();
-        double* G = nullptr;                                                                  // :193-194
-        TLSQ_TRY(gram_allreduce(h, Z, M, N, M, &G));
+        double* G = nullptr;                                                                   // :193-194
+        TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
         pt.mark();
         bool fast_ok = false;
-        if (use_subspace) TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+        if (hook_svd && k >= 2) {
+            // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
+            SubspaceState rs;
+            rs.hook_rank = sv;
+            rs.hook_seed = seed + (uint64_t)k;
+            TLSQ_TRY(svd_subspace(h, G, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
+            sub.steps += rs.steps;
+        } else if (use_subspace) {
+            TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+        }
         if (!fast_ok) {
             TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+            if (hook_svd && k >= 2) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
             ++sub.full;
         } else {
             ++sub.fast;
         }
-        v_is_full = !fast_ok;
+        v_is_full = !fast_ok && !(hook_svd && k >= 2);
         pt.mark();
         svp = 0;                                                   // :198
-        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
         sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
         std::vector<int32_t> sel((size_t)svp);
         std::vector<double> g((size_t)svp);
@@ -591,24 +657,29 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
             const double sg = s.sigma[sel[p]];
             g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
         }
-        TLSQ_TRY(rebuild_lowrank(h, Z, M, N, M, V, sel, g, A, M));
+        TLSQ_TRY(rebuild_lowrank<T>(h, Z, M, N, M, V, sel, g, A, M));
         if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
-        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<double>(h, A, M, N, M, thr, (double*)meanws));  // :214-216
+        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
         pt.mark();
-        TLSQ_TRY(launch_update<double>(h, D, A, E, Y, R, n, mu, ro.nonnegA ? 1 : 0));         // :217-222
+        TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));         // :217-222
         pt.mark();
         mu = std::min(mu * ro.rho, mubar);                         // :223
         double rn = 0.0;
-        // When nobody looks at the per-iteration cost (no cost_hist, no verbose hook) only the DECISION
-        // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is settled
-        // ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is always exact.
-        const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
-        const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
-        TLSQ_TRY(opnorm_gram(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma));  // :225
-        cost = rn / d_norm;
-        if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {           // too close to call: full accuracy
-            TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N, 1e-13, &rn, &sweeps));
+        if (hook_opnorm) {
+            TLSQ_TRY(opnorm_power<T>(h, R, M, N, M, mvps, seed + 7919ull * (uint64_t)k, &rn));   // :225 hook
             cost = rn / d_norm;
+        } else {
+            // When nobody looks at the per-iteration cost (no cost_hist, no verbose hook) only the DECISION
+            // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
+            // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
+            const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
+            const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
+            TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma));  // :225
+            cost = rn / d_norm;
+            if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
+                TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N, 1e-13, &rn, &sweeps));
+                cost = rn / d_norm;
+            }
         }
         pt.mark();
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -625,7 +696,7 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         }
     }
     if (k > ro.iters) k = ro.iters;
-    if (ro.hankel) TLSQ_TRY(launch_soft_hankel<double>(h, E, M, N, M, lam / mu, (double*)meanws));  // :234-236
+    if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, E, M, N, M, (T)(lam / mu), (T*)meanws));  // :234-236
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) {
         info->ms_loop = now_ms() - t_loop0;
@@ -642,9 +713,9 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
     // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
     const int64_t d = std::min(ro.m_global, N);
     if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
-        // the last iteration used the subspace path: the caller wants the complete SVD of the last Z
+        // the last iteration used a subspace path: the caller wants the complete SVD of the last Z
         double* G = nullptr;
-        TLSQ_TRY(gram_allreduce(h, Z, M, N, M, &G));
+        TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
         TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
         if (info) info->jacobi_sweeps = sweeps;
     }
@@ -676,7 +747,7 @@ static int rpca_core(Handle* h, const double* D, int64_t M, int64_t N, const Res
         TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)d * 4, hipMemcpyHostToDevice, h->stream));
         TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
         TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, d, (double*)Vg, nullptr));
-        TLSQ_TRY(gemm_f64(h, true, false, (const double*)Vg, N, Z, M, U_dev, M, d, M, N, false));
+        TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, M, U_dev, Prec<T>::f32, M, d, M, N, false));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     }
     return converged ? TLSQ_OK : TLSQ_MAXITER;  // :232
@@ -807,6 +878,131 @@ static int soft_hankel_impl(tlsq_handle h, T* A, int64_t K, int64_t L, int64_t l
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// rpca entry (both precisions): staging of caller memory, M < N handled on the transposed problem
+// ------------------------------------------------------------------------------------------------
+static void reset_info(tlsq_rpca_info* info) {
+    if (!info) return;
+    double* ch = info->cost_hist;
+    int64_t* sh = info->svp_hist;
+    int64_t cap = info->hist_capacity;
+    memset(info, 0, sizeof(*info));
+    info->cost_hist = ch;
+    info->svp_hist = sh;
+    info->hist_capacity = cap;
+}
+
+template <typename T>
+static int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      T* A, int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt,
+                      int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
+        return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    reset_info(info);
+    const double eps_t = (double)std::numeric_limits<T>::epsilon();
+    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(eps_t));     // tol = sqrt(eps(real(T)))  (:160)
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const size_t es = sizeof(T);
+    const int64_t n = M * N;
+    const int64_t d = std::min(ro.m_global, N);
+    if (U && ldU < M) return set_err(h, TLSQ_ERR_ARG, "rpca: ldU < M");
+    if (Vt && ldVt < d) return set_err(h, TLSQ_ERR_ARG, "rpca: ldVt < min(M,N)");
+    // rpca is invariant under transposition (elementwise sweeps, singular-value thresholding, lambda =
+    // 1/sqrt(max(M,N))).  A wide unsharded D is solved as its tall transpose: the Gram matrix is then M x M
+    // and has no structurally-zero eigenvalues (accuracy of the Gram route).
+    const bool transposed = (M < N) && ro.m_global == M && !h->comm;
+
+    const T* dD = D;
+    T *dA = A, *dE = E, *dU = U;
+    void* p;
+    double th = now_ms();
+    if (!dev || ldD != M) {
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * es, &p));
+        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        dD = (const T*)p;
+    }
+    if (!dev || ldA != M) {
+        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * es, &p));
+        dA = (T*)p;
+    }
+    if (!dev || ldE != M) {
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * es, &p));
+        dE = (T*)p;
+    }
+    if (U && !transposed && (!dev || ldU != M)) {
+        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * es, &p));
+        dU = (T*)p;
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_h2d = now_ms() - th;
+
+    // S / Vt are small: always produced on the host in fp64, then converted / copied to the caller's memory
+    std::vector<double> hS((size_t)(S ? d : 0)), hVt((size_t)(Vt ? d * N : 0));
+    int status;
+    if (!transposed) {
+        status = rpca_core<T>(h, dD, M, N, ro, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
+                              Vt ? hVt.data() : nullptr, d, sv, info);
+        if (status < 0) return status;
+    } else {
+        // D' (N x M) -> A', E' ; the SVD of Z' = Z^T swaps the roles of U and V
+        void *Dt, *At, *Et, *Ut = nullptr;
+        TLSQ_TRY(ws_get(h, WS_DT, (size_t)n * es, &Dt));
+        TLSQ_TRY(ws_get(h, WS_AT, (size_t)n * es, &At));
+        TLSQ_TRY(ws_get(h, WS_ET, (size_t)n * es, &Et));
+        if (Vt) TLSQ_TRY(ws_get(h, WS_UT, (size_t)N * d * es, &Ut));   // U' (N x d): its transpose is Vt
+        TLSQ_TRY(launch_transpose<T>(h, dD, M, N, (T*)Dt));
+        ResolvedOpts rt = ro;
+        rt.m_global = N;
+        std::vector<double> hVtT((size_t)(U ? d * M : 0));            // Vt' (d x M): its transpose is U
+        status = rpca_core<T>(h, (const T*)Dt, N, M, rt, opts, (T*)At, (T*)Et, Vt ? (T*)Ut : nullptr,
+                              S ? hS.data() : nullptr, U ? hVtT.data() : nullptr, d, sv, info);
+        if (status < 0) return status;
+        TLSQ_TRY(launch_transpose<T>(h, (const T*)At, N, M, dA));
+        TLSQ_TRY(launch_transpose<T>(h, (const T*)Et, N, M, dE));
+        if (Vt) {   // Vt (d x N) = U'^T
+            std::vector<T> hu((size_t)N * d);
+            TLSQ_HIP(h, hipMemcpyAsync(hu.data(), Ut, (size_t)N * d * es, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            for (int64_t pcol = 0; pcol < d; ++pcol)
+                for (int64_t j = 0; j < N; ++j) hVt[pcol + j * d] = (double)hu[j + pcol * N];
+        }
+        if (U) {    // U (M x d) = Vt'^T, delivered below through a host staging copy
+            std::vector<T> hu((size_t)M * d);
+            for (int64_t pcol = 0; pcol < d; ++pcol)
+                for (int64_t i = 0; i < M; ++i) hu[i + pcol * M] = (T)hVtT[pcol + i * d];
+            TLSQ_TRY(copy2d(h, U, ldU, hu.data(), M, M, d, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+    }
+
+    th = now_ms();
+    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
+    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
+    if (U && !transposed && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
+    std::vector<T> tS, tVt;
+    if (S) {
+        tS.resize((size_t)d);
+        for (int64_t i = 0; i < d; ++i) tS[i] = (T)hS[i];
+        TLSQ_HIP(h, hipMemcpyAsync(S, tS.data(), (size_t)d * es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
+                                   h->stream));
+    }
+    if (Vt) {
+        tVt.resize((size_t)d * N);
+        for (size_t i = 0; i < tVt.size(); ++i) tVt[i] = (T)hVt[i];
+        TLSQ_TRY(copy2d(h, Vt, ldVt, tVt.data(), d, d, N, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_d2h = now_ms() - th;
+        info->ms_total = now_ms() - t0;
+    }
+    return status;
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -932,99 +1128,13 @@ int tlsq_comm_destroy(tlsq_handle h) {
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE, double* U,
                   int64_t ldU, double* S, double* Vt, int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
-    TLSQ_TRY(check_handle(h));
-    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
-        return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
-    if (opts && opts->svd_mode != TLSQ_SVD_FULL)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: svd_mode RANDOMIZED is not built yet");
-    if (opts && opts->opnorm_mode != TLSQ_OPNORM_EXACT)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: opnorm_mode POWER is not built yet");
-    TLSQ_HIP(h, hipSetDevice(h->device));
-    const double t0 = now_ms();
-    if (info) {
-        double* ch = info->cost_hist;
-        int64_t* sh = info->svp_hist;
-        int64_t cap = info->hist_capacity;
-        memset(info, 0, sizeof(*info));
-        info->cost_hist = ch;
-        info->svp_hist = sh;
-        info->hist_capacity = cap;
-    }
-    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(std::numeric_limits<double>::epsilon()));
-    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const int64_t n = M * N;
-    const int64_t d = std::min(ro.m_global, N);
-    if (U && ldU < M) return set_err(h, TLSQ_ERR_ARG, "rpca: ldU < M");
-    if (Vt && ldVt < d) return set_err(h, TLSQ_ERR_ARG, "rpca: ldVt < min(M,N)");
-
-    const double* dD = D;
-    double *dA = A, *dE = E, *dU = U;
-    void* p;
-    double th = now_ms();
-    if (!dev || ldD != M) {
-        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * 8, &p));
-        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-        dD = (const double*)p;
-    }
-    if (!dev || ldA != M) {
-        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * 8, &p));
-        dA = (double*)p;
-    }
-    if (!dev || ldE != M) {
-        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * 8, &p));
-        dE = (double*)p;
-    }
-    if (U && (!dev || ldU != M)) {
-        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * 8, &p));
-        dU = (double*)p;
-    }
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) info->ms_h2d = now_ms() - th;
-
-    // S / Vt are small: always produced on the host, then copied if the caller's memory is on the device
-    std::vector<double> hS, hVt;
-    double* S_host = nullptr;
-    double* Vt_host = nullptr;
-    int64_t ldVt_host = d;
-    if (S) {
-        if (dev) {
-            hS.resize((size_t)d);
-            S_host = hS.data();
-        } else
-            S_host = S;
-    }
-    if (Vt) {
-        if (dev) {
-            hVt.resize((size_t)d * N);
-            Vt_host = hVt.data();
-        } else {
-            Vt_host = Vt;
-            ldVt_host = ldVt;
-        }
-    }
-    int status = rpca_core(h, dD, M, N, ro, opts, dA, dE, dU, S_host, Vt_host, ldVt_host, sv, info);
-    if (status < 0) return status;
-
-    th = now_ms();
-    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, 8, back));
-    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, 8, back));
-    if (U && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, 8, back));
-    if (dev && S) TLSQ_HIP(h, hipMemcpyAsync(S, hS.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
-    if (dev && Vt) TLSQ_TRY(copy2d(h, Vt, ldVt, hVt.data(), d, d, N, 8, hipMemcpyHostToDevice));
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) {
-        info->ms_d2h = now_ms() - th;
-        info->ms_total = now_ms() - t0;
-    }
-    return status;
+    return rpca_entry<double>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
 }
 
-int tlsq_rpca_f32(tlsq_handle h, const float*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, float*,
-                  int64_t, float*, int64_t, float*, int64_t, float*, float*, int64_t, int64_t*,
-                  tlsq_rpca_info*) {
-    TLSQ_TRY(check_handle(h));
-    return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_f32: the fp32 ALM loop is not built yet (fp32 sweeps/hankel are)");
+int tlsq_rpca_f32(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t ldD,
+                  const tlsq_rpca_opts* opts, float* A, int64_t ldA, float* E, int64_t ldE, float* U,
+                  int64_t ldU, float* S, float* Vt, int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
+    return rpca_entry<float>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
 }
 
 // ---- Hankel family (templates hankel_impl/unhankel_impl/soft_hankel_impl live above extern "C") ----
@@ -1064,8 +1174,6 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
     if (lag <= 0) lag = 1;
     if (!(2 * n <= Nx)) return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
     if (!(lag <= n)) return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
-    if (opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT))
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: randomized svd/opnorm modes are not built yet");
     TLSQ_HIP(h, hipSetDevice(h->device));
     if (info) {
         double* ch = info->cost_hist;
@@ -1089,19 +1197,19 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
     if (sv <= 0) {                                                                            // :121-122
         TLSQ_TRY(ws_get(h, WS_E, (size_t)K * LD * 8, &E));
         const ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
-        status = rpca_core(h, (const double*)H, K, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
+        status = rpca_core<double>(h, (const double*)H, K, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
                            nullptr, 0, nullptr, info);
         if (status < 0) return status;
     } else {                                                                                  // :123-126
         SmallSvd s;
         double* V = nullptr;
         int64_t sweeps = 0;
-        TLSQ_TRY(svd_via_gram(h, (const double*)H, K, LD, K, &V, s, &sweeps, nullptr));
+        TLSQ_TRY(svd_via_gram<double>(h, (const double*)H, K, LD, K, &V, s, &sweeps, nullptr));
         const int64_t r = std::min<int64_t>(sv, std::min(K, LD));
         std::vector<int32_t> sel((size_t)r);
         std::vector<double> g((size_t)r, 1.0);
         for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
-        TLSQ_TRY(rebuild_lowrank(h, (const double*)H, K, LD, K, V, sel, g, (double*)A, K));
+        TLSQ_TRY(rebuild_lowrank<double>(h, (const double*)H, K, LD, K, V, sel, g, (double*)A, K));
         if (info) info->jacobi_sweeps = sweeps;
     }
     // :127  (dy is reused for the filtered signal)
@@ -1125,7 +1233,7 @@ static int vt_of(tlsq_handle h, const double* dAy, int64_t M, int64_t nc, int64_
     SmallSvd s;
     double* V = nullptr;
     int64_t sweeps = 0;
-    TLSQ_TRY(svd_via_gram(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
+    TLSQ_TRY(svd_via_gram<double>(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
     std::vector<double> hv((size_t)nc * nc);
     TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)nc * nc * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -1172,8 +1280,6 @@ int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t 
     TLSQ_TRY(check_handle(h));
     if (!A || !y || !x || M <= 0 || n <= 0 || q <= 0 || ldA < M || ldy < M || ldx < n)
         return set_err(h, TLSQ_ERR_ARG, "rtls: bad argument");
-    if (opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT))
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rtls: randomized svd/opnorm modes are not built yet");
     TLSQ_HIP(h, hipSetDevice(h->device));
     if (info) {
         double* ch = info->cost_hist;
@@ -1198,7 +1304,7 @@ int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t 
     std::vector<double> Vt((size_t)nc * nc, 0.0);
     const int64_t d = std::min(ro.m_global, nc);
     if (d < nc) return set_err(h, TLSQ_ERR_ARG, "rtls: needs M >= n+q");
-    int status = rpca_core(h, (const double*)AA, M, nc, ro, opts, (double*)Ah, (double*)Eh, nullptr,
+    int status = rpca_core<double>(h, (const double*)AA, M, nc, ro, opts, (double*)Ah, (double*)Eh, nullptr,
                            nullptr, Vt.data(), nc, nullptr, info);
     if (status < 0) return status;
     std::vector<double> hx((size_t)n * q);
@@ -1290,7 +1396,7 @@ int tlsq_k_opnorm_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int6
                       double* sigma_max) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !sigma_max || N <= 0 || ldZ < M) return set_err(h, TLSQ_ERR_ARG, "opnorm: bad argument");
-    return opnorm_gram(h, Z, M, N, ldZ, sigma_max, nullptr);
+    return opnorm_gram<double>(h, Z, M, N, ldZ, sigma_max, nullptr);
 }
 int tlsq_k_maxabs_f64(tlsq_handle h, const double* x, int64_t n, double* out) {
     TLSQ_TRY(check_handle(h));

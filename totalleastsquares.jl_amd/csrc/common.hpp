@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <cmath>
 #include <algorithm>
 #include <string>
@@ -69,6 +70,7 @@ enum WsSlot {
     WS_SCAL,                                     // small scalars / counters
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
+    WS_DT, WS_AT, WS_ET, WS_UT,                                            // transposed problem (M < N)
     WS_COUNT
 };
 
@@ -86,6 +88,12 @@ template <typename T>
 int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
+// dst (N x M, ld N) = src' for src (M x N, ld M)
+template <typename T>
+int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst);
+// dst[i] = (Tdst) src[i]
+template <typename TS, typename TD>
+int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n);
 
 // ---------------- gemm.hip ----------------
 // Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j), i<P, j<Q, k<K
@@ -96,6 +104,11 @@ int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, const double* B,
              int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
 int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
+// mixed-precision storage: operands / result may be fp32 in memory (x_f32 != 0), arithmetic is fp64 MFMA.
+// instantiated operand type pairs (A,B): (f64,f64), (f32,f32), (f64,f32); layouts (KC,KC), (KC,MN), (MN,MN).
+int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
+               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
+int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
 
 // ---------------- jacobi.hip ----------------
 // One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal
@@ -124,6 +137,8 @@ int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
 int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);
+int launch_fill_gauss(Handle* h, double* X, int64_t n, unsigned int seed);
+int launch_colsumsq(Handle* h, const double* B, int64_t rows, int64_t ld, int64_t cols, double* out);
 
 // ---------------- hankel.hip ----------------
 template <typename T>

@@ -29,26 +29,29 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ---- global -> registers -> LDS staging of one 128 x 16 operand panel (8 doubles per thread) ----
 // FULL: the panel is entirely inside the matrix and 16-byte aligned -> unguarded double2 loads.
-template <bool KC, bool FULL>
-__device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t ld, int64_t r0,
+// The operands may be fp32 in memory (the fp32 rpca path): they are widened to fp64 while being staged, the
+// contraction itself always runs on the fp64 MFMA.
+template <bool KC, bool FULL, typename TX>
+__device__ __forceinline__ void panel_load(const TX* __restrict__ X, int64_t ld, int64_t r0,
                                            int64_t rmax, int64_t k0, int64_t kmax, double (&reg)[8]) {
+    typedef TX x2 __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
     if (FULL) {
         if (KC) {  // X[k + r*ld]: thread takes k = 2*(t&7)..+1 of rows (t>>3) + 32 s
             const int k = (t & 7) * 2, rr = t >> 3;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const d2 v = *reinterpret_cast<const d2*>(X + (k0 + k) + (r0 + rr + 32 * s) * ld);
-                reg[2 * s] = v[0];
-                reg[2 * s + 1] = v[1];
+                const x2 v = *reinterpret_cast<const x2*>(X + (k0 + k) + (r0 + rr + 32 * s) * ld);
+                reg[2 * s] = (double)v[0];
+                reg[2 * s + 1] = (double)v[1];
             }
         } else {  // X[r + k*ld]: thread takes r = 2*(t&63)..+1 of k = (t>>6) + 4 s
             const int r = (t & 63) * 2, kk = t >> 6;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const d2 v = *reinterpret_cast<const d2*>(X + (r0 + r) + (k0 + kk + 4 * s) * ld);
-                reg[2 * s] = v[0];
-                reg[2 * s + 1] = v[1];
+                const x2 v = *reinterpret_cast<const x2*>(X + (r0 + r) + (k0 + kk + 4 * s) * ld);
+                reg[2 * s] = (double)v[0];
+                reg[2 * s + 1] = (double)v[1];
             }
         }
     } else {
@@ -59,7 +62,7 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
             for (int s = 0; s < 8; ++s) {
                 const int64_t r = r0 + rr + 16 * s;
                 const bool ok = (r < rmax && kg < kmax);
-                const double v = X[ok ? kg + r * ld : 0];  // always-valid address, then select (no branch)
+                const double v = (double)X[ok ? kg + r * ld : 0];  // always-valid address, then select (no branch)
                 reg[s] = ok ? v : 0.0;
             }
         } else {  // X[r + k*ld]: 128 consecutive r per k
@@ -69,7 +72,7 @@ __device__ __forceinline__ void panel_load(const double* __restrict__ X, int64_t
             for (int s = 0; s < 8; ++s) {
                 const int64_t kg = k0 + kk + 2 * s;
                 const bool ok = (rg < rmax && kg < kmax);
-                const double v = X[ok ? rg + kg * ld : 0];
+                const double v = (double)X[ok ? rg + kg * ld : 0];
                 reg[s] = ok ? v : 0.0;
             }
         }
@@ -112,10 +115,10 @@ __device__ __forceinline__ double panel_at(const double* __restrict__ sm, int r,
 
 // NA = number of live 16-row MFMA tiles of this wave along i (1, 2 or 4); j always uses 4.
 // FULL = interior tile (no bounds checks, vector loads).
-template <bool A_KC, bool B_KC, bool FULL, int NA>
-__device__ __forceinline__ void gemm_body(const double* __restrict__ A, int64_t lda,
-                                          const double* __restrict__ B, int64_t ldb,
-                                          double* __restrict__ Cz, int64_t ldc, int64_t P, int64_t Q,
+template <bool A_KC, bool B_KC, bool FULL, int NA, typename TA, typename TB>
+__device__ __forceinline__ void gemm_body(const TA* __restrict__ A, int64_t lda,
+                                          const TB* __restrict__ B, int64_t ldb,
+                                          void* __restrict__ Cv, int c_f32, int64_t ldc, int64_t P, int64_t Q,
                                           int64_t kbeg, int64_t kend, int64_t i0, int64_t j0,
                                           double* __restrict__ smem) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -129,8 +132,8 @@ __device__ __forceinline__ void gemm_body(const double* __restrict__ A, int64_t 
     double ra[8], rb[8];
     const int64_t nstage = (kend > kbeg) ? (kend - kbeg + TK - 1) / TK : 0;
     if (nstage > 0) {
-        panel_load<A_KC, FULL>(A, lda, i0, P, kbeg, kend, ra);
-        panel_load<B_KC, FULL>(B, ldb, j0, Q, kbeg, kend, rb);
+        panel_load<A_KC, FULL, TA>(A, lda, i0, P, kbeg, kend, ra);
+        panel_load<B_KC, FULL, TB>(B, ldb, j0, Q, kbeg, kend, rb);
         panel_store<A_KC, FULL>(smem, ra);
         panel_store<B_KC, FULL>(smem + 2 * PANEL, rb);
     }
@@ -142,8 +145,8 @@ __device__ __forceinline__ void gemm_body(const double* __restrict__ A, int64_t 
         const bool more = (s + 1 < nstage);
         if (more && TLSQ_GEMM_ABLATE != 1) {   // ablation build 1: no global loads after the first stage
             const int64_t kn = kbeg + (s + 1) * TK;
-            panel_load<A_KC, FULL>(A, lda, i0, P, kn, kend, ra);
-            panel_load<B_KC, FULL>(B, ldb, j0, Q, kn, kend, rb);
+            panel_load<A_KC, FULL, TA>(A, lda, i0, P, kn, kend, ra);
+            panel_load<B_KC, FULL, TB>(B, ldb, j0, Q, kn, kend, rb);
         }
         const double* __restrict__ sa = smem + cur * PANEL;
         const double* __restrict__ sb = smem + (2 + cur) * PANEL;
@@ -191,16 +194,19 @@ __device__ __forceinline__ void gemm_body(const double* __restrict__ A, int64_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = i0 + wi * 64 + a * 16 + fk + 4 * r;
-                if (FULL || (i < P && j < Q)) Cz[j + i * ldc] = acc[a][b][r];
+                if (FULL || (i < P && j < Q)) {
+                    if (c_f32) reinterpret_cast<float*>(Cv)[j + i * ldc] = (float)acc[a][b][r];
+                    else reinterpret_cast<double*>(Cv)[j + i * ldc] = acc[a][b][r];
+                }
             }
         }
     }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ A, int64_t lda,
-                                                     const double* __restrict__ B, int64_t ldb,
-                                                     double* __restrict__ C, int64_t ldc, int64_t P,
+template <bool A_KC, bool B_KC, typename TA, typename TB>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(const TA* __restrict__ A, int64_t lda,
+                                                     const TB* __restrict__ B, int64_t ldb,
+                                                     void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
                                                      int64_t Q, int64_t K, int64_t kchunk,
                                                      int64_t slab_stride, int nti, int ntj,
                                                      int symmetric, int vec_ok) {
@@ -215,14 +221,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ 
     const int z = blockIdx.y;
     const int64_t kbeg = (int64_t)z * kchunk;
     const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    double* __restrict__ Cz = C + (int64_t)z * slab_stride;
+    // split-K slabs are always fp64; a direct (nsplit == 1) store may be fp32
+    void* __restrict__ Cz = c_f32 ? (void*)(reinterpret_cast<float*>(C) + (int64_t)z * slab_stride)
+                                  : (void*)(reinterpret_cast<double*>(C) + (int64_t)z * slab_stride);
     const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
     const bool full = vec_ok && (i0 + TI <= P) && (j0 + TJ <= Q) && ((kend - kbeg) % TK == 0);
     if (full) {
 #if TLSQ_GEMM_ABLATE == 3   // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
         const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        gemm_body<A_KC, B_KC, true, 4>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+        gemm_body<A_KC, B_KC, true, 4, TA, TB>(A, lda, B, ldb, Cz, c_f32, ldc, P, Q, kbeg, kend, i0, j0, smem);
 #if TLSQ_GEMM_ABLATE == 3
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0 && lin == 5 && z == 3 && kend - kbeg > 256)
@@ -233,19 +241,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ 
         // live 16-row tiles along i for the widest wave (wave-uniform by construction: depends on blockIdx only)
         const int64_t rows = P - i0;  // > 0
         if (rows <= 16)
-            gemm_body<A_KC, B_KC, false, 1>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+            gemm_body<A_KC, B_KC, false, 1, TA, TB>(A, lda, B, ldb, Cz, c_f32, ldc, P, Q, kbeg, kend, i0, j0, smem);
         else if (rows <= 32)
-            gemm_body<A_KC, B_KC, false, 2>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+            gemm_body<A_KC, B_KC, false, 2, TA, TB>(A, lda, B, ldb, Cz, c_f32, ldc, P, Q, kbeg, kend, i0, j0, smem);
         else
-            gemm_body<A_KC, B_KC, false, 4>(A, lda, B, ldb, Cz, ldc, P, Q, kbeg, kend, i0, j0, smem);
+            gemm_body<A_KC, B_KC, false, 4, TA, TB>(A, lda, B, ldb, Cz, c_f32, ldc, P, Q, kbeg, kend, i0, j0, smem);
     }
 }
 
 // C[j + i*ldc] = sum_z slab[z][j + i*lds]   (fixed order -> deterministic);
-// symmetric: only tiles ti>=tj were computed, mirror into both triangles.
+// symmetric: only tiles ti>=tj were computed, mirror into both triangles.  C may be fp32.
 __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ slab, int64_t lds_,
                                                      int64_t slab_stride, int nsplit,
-                                                     double* __restrict__ C, int64_t ldc, int64_t P,
+                                                     void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
                                                      int64_t Q, int symmetric) {
     const int64_t total = P * Q;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -254,40 +262,55 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
         if (symmetric && (j / TJ) > (i / TI)) continue;
         double s = 0.0;
         for (int zz = 0; zz < nsplit; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
-        C[j + i * ldc] = s;
-        if (symmetric) C[i + j * ldc] = s;
+        if (c_f32) {
+            reinterpret_cast<float*>(C)[j + i * ldc] = (float)s;
+            if (symmetric) reinterpret_cast<float*>(C)[i + j * ldc] = (float)s;
+        } else {
+            reinterpret_cast<double*>(C)[j + i * ldc] = s;
+            if (symmetric) reinterpret_cast<double*>(C)[i + j * ldc] = s;
+        }
     }
 }
 
-static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda,
-                       const double* B, int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q,
-                       int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric) {
+static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda,
+                       const void* B, int b_f32, int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P,
+                       int64_t Q, int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric) {
     const int nti = (int)((P + TI - 1) / TI), ntj = (int)((Q + TJ - 1) / TJ);
     const int nb = nti * ntj;
     const int cpx = (nb + 7) / 8;
     dim3 grid(8 * cpx, nsplit), block(256);
-    // 16-byte vector loads need even leading dimensions, 16-byte aligned bases and an even K chunk
+    // 2-element vector loads need even leading dimensions, aligned bases and an even K chunk
+    const uintptr_t am = a_f32 ? 8 : 16, bm = b_f32 ? 8 : 16;
     const int vec_ok = ((lda % 2) == 0 && (ldb % 2) == 0 && (kchunk % 2) == 0 &&
-                        (reinterpret_cast<uintptr_t>(A) % 16) == 0 && (reinterpret_cast<uintptr_t>(B) % 16) == 0)
+                        (reinterpret_cast<uintptr_t>(A) % am) == 0 && (reinterpret_cast<uintptr_t>(B) % bm) == 0)
                            ? 1 : 0;
-#define GO(AK, BK)                                                                                 \
-    hipLaunchKernelGGL((k_gemm_f64<AK, BK>), grid, block, 0, h->stream, A, lda, B, ldb, C, ldc, P, Q, \
-                       K, kchunk, slab_stride, nti, ntj, symmetric ? 1 : 0, vec_ok)
-    if (A_KC && B_KC) GO(true, true);
-    else if (A_KC && !B_KC) GO(true, false);
-    else if (!A_KC && !B_KC) GO(false, false);
-    else GO(false, true);
+#define GO2(AK, BK, TA, TB)                                                                              \
+    hipLaunchKernelGGL((k_gemm_f64<AK, BK, TA, TB>), grid, block, 0, h->stream, (const TA*)A, lda,       \
+                       (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj,         \
+                       symmetric ? 1 : 0, vec_ok)
+#define GO(TA, TB)                                         \
+    do {                                                   \
+        if (A_KC && B_KC) GO2(true, true, TA, TB);         \
+        else if (A_KC && !B_KC) GO2(true, false, TA, TB);  \
+        else if (!A_KC && !B_KC) GO2(false, false, TA, TB); \
+        else return set_err(h, TLSQ_ERR_UNSUPPORTED, "gemm: operand layout (MN,KC) is not instantiated"); \
+    } while (0)
+    if (!a_f32 && !b_f32) GO(double, double);
+    else if (a_f32 && b_f32) GO(float, float);
+    else if (!a_f32 && b_f32) GO(double, float);
+    else return set_err(h, TLSQ_ERR_UNSUPPORTED, "gemm: operand types (f32, f64) are not instantiated");
 #undef GO
+#undef GO2
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
 
-int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, const double* B,
-             int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric) {
+int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
+               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric) {
     if (P <= 0 || Q <= 0) return TLSQ_OK;
     const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
     const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
-    // split K so that the launch has >= ~256 workgroups (one per CU), each with >= 4 K stages
+    // split K so that the launch has ~256 workgroups (one per CU), each with >= 4 K stages
     static const int64_t target_wgs = [] {
         const char* e = getenv("TLSQ_GEMM_WGS");
         const long v = e ? atol(e) : 0;
@@ -306,27 +329,37 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
     if (kchunk < TK) kchunk = TK;
     nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     if (nsplit == 1 && !symmetric)
-        return launch_gemm(h, A_KC, B_KC, A, lda, B, ldb, C, ldc, P, Q, K, 1, kchunk, 0, false);
-    // slabs: nsplit x (P rows of Q contiguous)
+        return launch_gemm(h, A_KC, B_KC, A, a_f32, lda, B, b_f32, ldb, C, c_f32, ldc, P, Q, K, 1, kchunk, 0, false);
+    // slabs (always fp64): nsplit x (P rows of Q contiguous)
     const int64_t slab_stride = P * Q;
     void* slab;
     TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * sizeof(double), &slab));
-    TLSQ_TRY(launch_gemm(h, A_KC, B_KC, A, lda, B, ldb, (double*)slab, Q, P, Q, K, (int)nsplit, kchunk,
+    TLSQ_TRY(launch_gemm(h, A_KC, B_KC, A, a_f32, lda, B, b_f32, ldb, slab, 0, Q, P, Q, K, (int)nsplit, kchunk,
                          slab_stride, symmetric));
     int64_t g = (P * Q + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, Q,
-                       slab_stride, (int)nsplit, C, ldc, P, Q, symmetric ? 1 : 0);
+                       slab_stride, (int)nsplit, C, c_f32, ldc, P, Q, symmetric ? 1 : 0);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
 
-int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG) {
+int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, const double* B,
+             int64_t ldb, double* C, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric) {
+    return gemm_mixed(h, A_KC, B_KC, A, 0, lda, B, 0, ldb, C, 0, ldc, P, Q, K, symmetric);
+}
+
+// G (fp64, N x N) = Z'Z for Z of either precision
+int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG) {
     if (M <= 0) {
         TLSQ_HIP(h, hipMemset2DAsync(G, ldG * sizeof(double), 0, N * sizeof(double), N, h->stream));
         return TLSQ_OK;
     }
-    return gemm_f64(h, true, true, Z, ldZ, Z, ldZ, G, ldG, N, N, M, true);
+    return gemm_mixed(h, true, true, Z, z_f32, ldZ, Z, z_f32, ldZ, G, 0, ldG, N, N, M, true);
+}
+
+int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG) {
+    return gram_any(h, Z, 0, M, N, ldZ, G, ldG);
 }
 
 }  // namespace tlsq

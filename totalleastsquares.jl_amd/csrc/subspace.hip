@@ -130,6 +130,55 @@ __global__ __launch_bounds__(256) void k_fill_hash(double* __restrict__ X, int64
     }
 }
 
+__device__ __forceinline__ unsigned int hash_u32(unsigned int x) {
+    x ^= x >> 16;
+    x *= 2246822519u;
+    x ^= x >> 13;
+    x *= 3266489917u;
+    x ^= x >> 16;
+    return x;
+}
+
+// deterministic standard-normal fill (Box-Muller on two integer hashes of the element index)
+__global__ __launch_bounds__(256) void k_fill_gauss(double* __restrict__ X, int64_t n, unsigned int seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned int a = hash_u32((unsigned int)i * 2654435761u + seed);
+        const unsigned int b = hash_u32((unsigned int)i * 40503u + (seed ^ 0x68E31DA4u) + 0x9E3779B9u);
+        const double u1 = ((double)a + 1.0) / 4294967297.0;   // (0,1)
+        const double u2 = ((double)b + 0.5) / 4294967296.0;
+        X[i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+}
+
+int launch_fill_gauss(Handle* h, double* X, int64_t n, unsigned int seed) {
+    int64_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_fill_gauss, dim3((int)g), dim3(256), 0, h->stream, X, n, seed);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// out[c] = sum_r B[r + c*ld]^2   (one workgroup per column, fixed reduction order)
+__global__ __launch_bounds__(256) void k_colsumsq(const double* __restrict__ B, int64_t rows, int64_t ld,
+                                                  double* __restrict__ out) {
+    __shared__ double sw[4];
+    const double* __restrict__ col = B + (int64_t)blockIdx.x * ld;
+    double s = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) s += col[r] * col[r];
+    s = ss_wsum(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+int launch_colsumsq(Handle* h, const double* B, int64_t rows, int64_t ld, int64_t cols, double* out) {
+    if (cols <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL(k_colsumsq, dim3((int)cols), dim3(256), 0, h->stream, B, rows, ld, out);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
     int64_t g = (n + 255) / 256;
     if (g > 1024) g = 1024;

@@ -145,6 +145,32 @@ __global__ __launch_bounds__(256) void k_maxabs(const T* __restrict__ x, int64_t
     }
 }
 
+// LDS-tiled transpose: dst (N x M, ld N) = src' , src (M x N, ld M), both column-major
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, int64_t M, int64_t N,
+                                                   T* __restrict__ dst) {
+    __shared__ T tile[32][33];
+    const int64_t m0 = (int64_t)blockIdx.x * 32, n0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + tx, n = n0 + ty + 8 * r;
+        if (m < M && n < N) tile[ty + 8 * r][tx] = src[m + n * M];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + tx, m = m0 + ty + 8 * r;
+        if (m < M && n < N) dst[n + m * N] = tile[tx][ty + 8 * r];
+    }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_convert(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (TD)src[i];
+}
+
 static inline int grid_for(int64_t work_items) {
     int64_t g = (work_items + 255) / 256;
     if (g < 1) g = 1;
@@ -225,12 +251,35 @@ int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out) {
     return TLSQ_OK;
 }
 
+template <typename T>
+int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst) {
+    if (M <= 0 || N <= 0) return TLSQ_OK;
+    dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
+    if (grid.y > 65535) return set_err(h, TLSQ_ERR_UNSUPPORTED, "transpose: N too large");
+    hipLaunchKernelGGL((k_transpose<T>), grid, dim3(256), 0, h->stream, src, M, N, dst);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename TS, typename TD>
+int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_convert<TS, TD>), dim3(grid_for(n)), dim3(256), 0, h->stream, src, dst, n);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template int launch_convert<double, float>(Handle*, const double*, float*, int64_t);
+template int launch_convert<float, double>(Handle*, const float*, double*, int64_t);
+template int launch_convert<double, double>(Handle*, const double*, double*, int64_t);
+template int launch_convert<float, float>(Handle*, const float*, float*, int64_t);
+
 #define INST(T)                                                                                   \
     template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
-    template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);
+    template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
+    template int launch_transpose<T>(Handle*, const T*, int64_t, int64_t, T*);
 INST(double)
 INST(float)
 #undef INST

@@ -96,9 +96,30 @@ class Engine:
     def synchronize(self):
         self._check(self.lib.tlsq_synchronize(self.h))
 
+    @staticmethod
+    def _hook_modes(svd, opnorm):
+        """Map the reference's `svd` / `opnorm` keyword hooks (src/robustPCA.jl:168-169) onto the built-in
+        modes.  None = LinearAlgebra.svd! / opnorm.  "randomized" (or "rsvd", "rsvd_fnkz", "tsvd") = rank-sv
+        randomized SVD for k >= 2;  "power" / ("power", mvps) = the rnorm(x, mvps) estimator.  Arbitrary
+        callables cannot run on the GPU."""
+        svd_mode, opn_mode, mvps = L.SVD_FULL, L.OPNORM_EXACT, 10
+        if svd is not None:
+            if isinstance(svd, str) and svd.lower() in ("randomized", "rsvd", "rsvd_fnkz", "tsvd"):
+                svd_mode = L.SVD_RANDOMIZED
+            else:
+                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom svd hooks cannot run on the GPU path; use svd='randomized'")
+        if opnorm is not None:
+            if isinstance(opnorm, tuple) and len(opnorm) == 2 and str(opnorm[0]).lower() in ("power", "rnorm"):
+                opn_mode, mvps = L.OPNORM_POWER, int(opnorm[1])
+            elif isinstance(opnorm, str) and opnorm.lower() in ("power", "rnorm"):
+                opn_mode = L.OPNORM_POWER
+            else:
+                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom opnorm hooks cannot run on the GPU path; use opnorm=('power', mvps)")
+        return svd_mode, opn_mode, mvps
+
     def make_opts(self, *, lam=None, maxrank=None, iters=None, tol=None, rho=None, nonnegA=False,
                   nonnegE=False, hankel=False, nukeA=True, memory=L.MEM_HOST, m_global=0,
-                  svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, on_iter=None):
+                  svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, opnorm_mvps=10, seed=0, on_iter=None):
         o = L.RpcaOpts()
         self.lib.tlsq_rpca_opts_default(C.byref(o))
         if lam is not None:
@@ -115,6 +136,7 @@ class Engine:
         o.memory = memory
         o.m_global = int(m_global)
         o.svd_mode, o.opnorm_mode = svd_mode, opnorm_mode
+        o.opnorm_mvps, o.seed = int(opnorm_mvps), int(seed)
         if on_iter is not None:
             o.on_iter = on_iter
         return o
@@ -147,32 +169,31 @@ class Engine:
              want_U=True, return_report=False, m_global=0, **kwargs):
         """A, E, s, sv = rpca(D; ...) — src/robustPCA.jl:156-239.  Unknown kwargs are swallowed like the
         reference's `kwargs...` (:170).  `svd`/`opnorm` hooks: only the defaults run on the GPU."""
-        if svd is not None or opnorm is not None:
-            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED,
-                            "custom svd/opnorm hooks cannot run on the GPU path (randomized modes not built yet)")
+        svd_mode, opn_mode, mvps = self._hook_modes(svd, opnorm)
         D = np.asarray(D)
         if np.iscomplexobj(D):
             raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "complex element types are not supported on the GPU path")
-        if D.dtype != np.float64:
-            D = D.astype(np.float64)
-        Df = _f(D)
+        dt = np.float32 if D.dtype == np.float32 else np.float64
+        Df = _f(D, dt)
         M, N = Df.shape
         d = min(max(m_global, M), N)
-        A = np.empty((M, N), dtype=np.float64, order="F")
-        E = np.empty((M, N), dtype=np.float64, order="F")
-        U = np.empty((M, d), dtype=np.float64, order="F") if want_U else None
-        S = np.empty(d, dtype=np.float64)
-        Vt = np.empty((d, N), dtype=np.float64, order="F")
+        A = np.empty((M, N), dtype=dt, order="F")
+        E = np.empty((M, N), dtype=dt, order="F")
+        U = np.empty((M, d), dtype=dt, order="F") if want_U else None
+        S = np.empty(d, dtype=dt)
+        Vt = np.empty((d, N), dtype=dt, order="F")
         cb = None
         if verbose:
             def _print(k, cost, svp, user):
                 print(f"{k} cost: {float(f'{cost:.4g}')}")                 # :226
             cb = L.ON_ITER(_print)
         o = self.make_opts(lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, nonnegA=nonnegA,
-                           nonnegE=nonnegE, hankel=hankel, nukeA=nukeA, m_global=m_global, on_iter=cb)
+                           nonnegE=nonnegE, hankel=hankel, nukeA=nukeA, m_global=m_global, on_iter=cb,
+                           svd_mode=svd_mode, opnorm_mode=opn_mode, opnorm_mvps=mvps, seed=kwargs.get("seed", 0))
         info, cost, svp = self._info(int(iters))
         sv = C.c_int64(0)
-        st = self._check(self.lib.tlsq_rpca_f64(
+        fn = self.lib.tlsq_rpca_f32 if dt == np.float32 else self.lib.tlsq_rpca_f64
+        st = self._check(fn(
             self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
             _ptr(U) if U is not None else None, M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
         rep = RpcaReport(info, cost, svp)
@@ -180,7 +201,7 @@ class Engine:
             print("converged")                                             # :229
         if st == L.TLSQ_MAXITER:                                           # :232
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: "
-                          f"{tol if tol is not None else math.sqrt(np.finfo(np.float64).eps)}")
+                          f"{tol if tol is not None else math.sqrt(np.finfo(dt).eps)}")
         s = SVD(U, S, Vt)
         if return_report:
             return A, E, s, int(sv.value), rep
@@ -244,9 +265,7 @@ class Engine:
 
     def lowrankfilter(self, y, n=None, *, sv=0, lag=1, tol=1e-3, svd=None, return_report=False, **kw):
         """src/robustPCA.jl:119-128."""
-        if svd is not None or kw.get("opnorm") is not None:
-            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom svd/opnorm hooks cannot run on the GPU path")
-        kw.pop("opnorm", None)
+        svd_mode, opn_mode, mvps = self._hook_modes(svd, kw.pop("opnorm", None))
         y = np.asarray(y, dtype=np.float64)
         y2 = _f(y.reshape(y.shape[0], -1))
         Nx, Dch = y2.shape
@@ -260,7 +279,8 @@ class Engine:
         cb = None
         if verbose:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
-        o = self.make_opts(iters=iters, tol=tol, on_iter=cb, **allowed)
+        o = self.make_opts(iters=iters, tol=tol, on_iter=cb, svd_mode=svd_mode, opnorm_mode=opn_mode,
+                           opnorm_mvps=mvps, seed=kw.pop("seed", 0), **allowed)
         info, cost, svp = self._info(iters)
         yf = np.empty((Nx, Dch), dtype=np.float64, order="F")
         st = self._check(self.lib.tlsq_lowrankfilter_f64(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag),
