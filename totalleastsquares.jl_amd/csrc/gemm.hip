@@ -208,17 +208,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const TA* __restrict__ A, i
                                                      const TB* __restrict__ B, int64_t ldb,
                                                      void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
                                                      int64_t Q, int64_t K, int64_t kchunk,
-                                                     int64_t slab_stride, int nti, int ntj,
+                                                     int64_t slab_stride, int nti, int ntj, int nsplit,
                                                      int symmetric, int vec_ok) {
     __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
-    // XCD-aware remap: blocks b and b+8 share an XCD's L2 -> give every XCD a contiguous run of tiles
-    const int nb = nti * ntj;
-    const int cpx = (nb + 7) / 8;
-    const int lin = (int)(blockIdx.x % 8) * cpx + (int)(blockIdx.x / 8);
-    if (lin >= nb) return;
-    const int ti = lin % nti, tj = lin / nti;
-    if (symmetric && tj > ti) return;
-    const int z = blockIdx.y;
+    // Work items = (K split z, active tile t), z-major.  Blocks b and b+8 share an XCD (and its L2), so every
+    // XCD gets a contiguous run of work items: neighbours share z (the same rows of the operands) and the
+    // eight XCDs carry equal loads — also for symmetric launches, where only tiles with tj <= ti exist.
+    const int ntiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
+    const int64_t nwork = (int64_t)ntiles * nsplit;
+    const int64_t cpx = (nwork + 7) / 8;
+    const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
+    if (item >= nwork) return;
+    const int z = (int)(item / ntiles);
+    const int t = (int)(item % ntiles);
+    int ti, tj;
+    if (symmetric) {   // t -> (ti, tj) with tj <= ti, row-wise enumeration of the lower triangle
+        ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        ti = t % nti;
+        tj = t / nti;
+    }
     const int64_t kbeg = (int64_t)z * kchunk;
     const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     // split-K slabs are always fp64; a direct (nsplit == 1) store may be fp32
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const TA* __restrict__ A, i
         gemm_body<A_KC, B_KC, true, 4, TA, TB>(A, lda, B, ldb, Cz, c_f32, ldc, P, Q, kbeg, kend, i0, j0, smem);
 #if TLSQ_GEMM_ABLATE == 3
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x == 0 && lin == 5 && z == 3 && kend - kbeg > 256)
+        if (threadIdx.x == 0 && t == 2 && z == 3 && kend - kbeg > 256)
             printf("gemm clk: %llu cycles, %llu x10ns -> %.3f GHz, %.1f us\n", t1 - t0, r1 - r0,
                    (double)(t1 - t0) / (double)(r1 - r0) * 0.1, (double)(r1 - r0) * 0.01);
 #endif
@@ -276,9 +288,11 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
                        const void* B, int b_f32, int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P,
                        int64_t Q, int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric) {
     const int nti = (int)((P + TI - 1) / TI), ntj = (int)((Q + TJ - 1) / TJ);
-    const int nb = nti * ntj;
-    const int cpx = (nb + 7) / 8;
-    dim3 grid(8 * cpx, nsplit), block(256);
+    const int64_t ntiles = symmetric ? (int64_t)nti * (nti + 1) / 2 : (int64_t)nti * ntj;
+    const int64_t nwork = ntiles * nsplit;
+    const int64_t cpx = (nwork + 7) / 8;
+    if (8 * cpx > 2147483647LL) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gemm: grid too large");
+    dim3 grid((unsigned)(8 * cpx)), block(256);
     // 2-element vector loads need even leading dimensions, aligned bases and an even K chunk
     const uintptr_t am = a_f32 ? 8 : 16, bm = b_f32 ? 8 : 16;
     const int vec_ok = ((lda % 2) == 0 && (ldb % 2) == 0 && (kchunk % 2) == 0 &&
@@ -286,7 +300,7 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
                            ? 1 : 0;
 #define GO2(AK, BK, TA, TB)                                                                              \
     hipLaunchKernelGGL((k_gemm_f64<AK, BK, TA, TB>), grid, block, 0, h->stream, (const TA*)A, lda,       \
-                       (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj,         \
+                       (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj, nsplit, \
                        symmetric ? 1 : 0, vec_ok)
 #define GO(TA, TB)                                         \
     do {                                                   \
