@@ -45,6 +45,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int
         double n0 = 0.0;
         for (int k = 0; k < nw; ++k) n0 += red[k];
         __syncthreads();
+        double n1s = n0;
         for (int pass = 0; pass < 2 && j > 0; ++pass) {
             for (int i = w; i < j; i += nw) {  // d_i = q_i . y_j
                 const double* qi = sY + (size_t)i * N;
@@ -54,21 +55,26 @@ __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int
                 if (lane == 0) sd[i] = d;
             }
             __syncthreads();
+            double n1 = 0.0;
             for (int r = tid; r < N; r += SS_THREADS) {  // y_j -= Q_{<j} d
                 double acc = yj[r];
                 for (int i = 0; i < j; ++i) acc -= sd[i] * sY[(size_t)i * N + r];
                 yj[r] = acc;
+                n1 += acc * acc;
             }
+            n1 = ss_wsum(n1);
+            if (lane == 0) red[w] = n1;
             __syncthreads();
+            const double before = n1s;
+            n1s = 0.0;
+            for (int k = 0; k < nw; ++k) n1s += red[k];
+            __syncthreads();
+            // "twice is enough": a second pass only when the first one removed a sizeable part of the column
+            if (n1s > 0.5 * before) break;
         }
-        double n1 = 0.0;
-        for (int r = tid; r < N; r += SS_THREADS) n1 += yj[r] * yj[r];
-        n1 = ss_wsum(n1);
-        if (lane == 0) red[w] = n1;
-        __syncthreads();
-        double n1s = 0.0;
-        for (int k = 0; k < nw; ++k) n1s += red[k];
-        __syncthreads();
+        if (j == 0) {
+            n1s = n0;
+        }
         const double ratio = n0 > 0.0 ? sqrt(n1s / n0) : 0.0;
         minratio = ratio < minratio ? ratio : minratio;
         const double inv = n1s > 0.0 ? 1.0 / sqrt(n1s) : 0.0;
