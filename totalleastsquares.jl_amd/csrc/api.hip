@@ -353,25 +353,25 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
         // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
         // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
-        TLSQ_TRY(gemm_f64(h, true, false, (const double*)X, N, G, N, (double*)Q, N, p, N, N, false));
+        TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)X, (double*)Q, N, p));
         {
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
             const int q = cold ? 2 : 3;
             for (int t = 1; t < q && nt > 0; ++t) {
-                TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, nt, N, N, false));
+                TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, nt));
                 TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
             }
         }
         TLSQ_TRY(launch_cgs2(h, (double*)Q, N, p, stat_dev));
         // Rayleigh-Ritz: H = Q' (G Q)
-        TLSQ_TRY(gemm_f64(h, true, false, (const double*)Q, N, G, N, (double*)GQ, N, p, N, N, false));
-        TLSQ_TRY(gemm_f64(h, true, true, (const double*)GQ, N, (const double*)Q, N, (double*)H, p, p, p, N, false));
+        TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, p));
+        TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
         int64_t sw = 0;
         TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
         if (sweeps) *sweeps += sw;
         // X' = Q S,  G X' = (G Q) S
-        TLSQ_TRY(gemm_f64(h, true, false, (const double*)S, p, (const double*)Q, N, (double*)XN, N, p, N, p, false));
-        TLSQ_TRY(gemm_f64(h, true, false, (const double*)S, p, (const double*)GQ, N, (double*)GX, N, p, N, p, false));
+        TLSQ_TRY(launch_panel_rot2(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)XN, (double*)GX,
+                                   N, p));
         TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)XN, N, p, theta_dev));
         TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)XN, theta_dev, N, p, res_dev));
         TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 1) * 8, hipMemcpyDeviceToHost,
@@ -428,6 +428,12 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
             maxres = std::max(maxres, host[p + i]);
         }
         static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        if (dbg) {
+            int sd = -1;
+            void* scal = h->ws[WS_SCAL].p;
+            (void)hipMemcpy(&sd, (char*)scal + 136, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "  [small eig sweeps %d]", sd);
+        }
         if (dbg)
             fprintf(stderr, "  subspace step %d: p=%lld ntop=%lld svp=%lld maxres/tmax=%.3e tail/tau=%.3f cold=%d\n", step,
                     (long long)p, (long long)ntop, (long long)svp, maxres / tmax,

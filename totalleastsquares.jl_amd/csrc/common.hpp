@@ -136,6 +136,10 @@ int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
 int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
+int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
+int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p);
+int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
+                      int64_t N, int64_t p);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);
 int launch_fill_gauss(Handle* h, double* X, int64_t n, unsigned int seed);
 int launch_colsumsq(Handle* h, const double* B, int64_t rows, int64_t ld, int64_t cols, double* out);

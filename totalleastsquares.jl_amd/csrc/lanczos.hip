@@ -205,7 +205,9 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
     std::vector<double> hab((size_t)2 * cap);
     int launched = 0;  // launches issued; launch j completes the pair (alpha_{j-1}, beta_{j-1})
     double theta = 0.0;
-    int chunk = accept_below > 0.0 ? 9 : 16;   // launch j completes pair j-1: 9 launches = 8 pairs
+    // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
+    // first few Ritz values: start with 4 pairs and double
+    int chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;
     while (launched < max_steps + 1) {
         const int n = std::min(chunk, max_steps + 1 - launched);
         for (int k = 0; k < n; ++k, ++launched)
@@ -246,7 +248,8 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
         }
         // early accept for "is lambda_max clearly below X?" questions: the Ritz value is a lower bound that is
         // already within ~15 % of lambda_max after 16 steps even on flat (noise-like) spectra
-        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 8 && 5.0 * theta < accept_below))) {
+        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 8 && 5.0 * theta < accept_below) ||
+                                   (m >= 4 && 10.0 * theta < accept_below))) {
             *lmax = theta > 0.0 ? theta : 0.0;
             return TLSQ_OK;
         }

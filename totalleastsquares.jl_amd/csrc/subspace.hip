@@ -193,6 +193,102 @@ int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
     return TLSQ_OK;
 }
 
+// ---- skinny products of the subspace iteration (N x N symmetric G, N x p panels, p <= 64) -------------------
+// These are a few MFLOP each: they are latency-bound, so each one is a single small launch (no split-K slabs).
+
+// Y (N x p) = G * X.   Workgroup = 8 output rows x 32 panel columns; X is staged through LDS in 256-row
+// slices (coalesced), the 8 rows of G (= columns, G symmetric) are read straight from L2 as broadcasts.
+constexpr int SK_KT = 256;
+__global__ __launch_bounds__(256) void k_symm_skinny(const double* __restrict__ G, int64_t ldG,
+                                                     const double* __restrict__ X, double* __restrict__ Y,
+                                                     int N, int p) {
+    __shared__ double sX[SK_KT * 33];
+    __shared__ double sG[8 * SK_KT];
+    const int tid = threadIdx.x;
+    const int c = tid & 31, ri = tid >> 5;
+    const int r0 = blockIdx.x * 8;
+    for (int c0 = 0; c0 < p; c0 += 32) {
+        double acc = 0.0;
+        for (int k0 = 0; k0 < N; k0 += SK_KT) {
+            const int kn = (N - k0 < SK_KT) ? N - k0 : SK_KT;
+            __syncthreads();
+            for (int e = tid; e < kn * 32; e += 256) {      // X slice: column cc, row kk (coalesced over kk)
+                const int kk = e % kn, cc = e / kn;
+                sX[kk * 33 + cc] = (c0 + cc < p) ? X[(size_t)(c0 + cc) * N + k0 + kk] : 0.0;
+            }
+            for (int e = tid; e < kn * 8; e += 256) {       // 8 rows of G (contiguous: G symmetric)
+                const int kk = e % kn, rr = e / kn;
+                sG[rr * SK_KT + kk] = (r0 + rr < N) ? G[(int64_t)(r0 + rr) * ldG + k0 + kk] : 0.0;
+            }
+            __syncthreads();
+            const double* g = sG + ri * SK_KT;
+#pragma unroll 8
+            for (int kk = 0; kk < kn; ++kk) acc += g[kk] * sX[kk * 33 + c];
+        }
+        if (r0 + ri < N && c0 + c < p) Y[(size_t)(c0 + c) * N + r0 + ri] = acc;
+    }
+}
+
+// H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
+__global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
+                                                  double* __restrict__ H, int N, int p) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= p * p) return;
+    const int i = e % p, j = e / p;
+    const double* a = A + (size_t)i * N;
+    const double* b = B + (size_t)j * N;
+    double s = 0.0;
+    for (int r = lane; r < N; r += 64) s += a[r] * b[r];
+    s = ss_wsum(s);
+    if (lane == 0) H[i + (size_t)j * p] = s;
+}
+
+// X1 = Q * S and X2 = GQ * S  (N x p panels, S p x p, ld p): thread per output element, S from LDS
+__global__ __launch_bounds__(256) void k_panel_rot2(const double* __restrict__ Q, const double* __restrict__ GQ,
+                                                    const double* __restrict__ S, double* __restrict__ X1,
+                                                    double* __restrict__ X2, int N, int p) {
+    extern __shared__ __attribute__((aligned(16))) double sS[];
+    for (int e = threadIdx.x; e < p * p; e += 256) sS[e] = S[e];
+    __syncthreads();
+    const int64_t total = (int64_t)N * p;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e % N), c = (int)(e / N);
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < p; ++k) {
+            const double sv = sS[k + c * p];
+            a1 += Q[(size_t)k * N + r] * sv;
+            a2 += GQ[(size_t)k * N + r] * sv;
+        }
+        X1[e] = a1;
+        X2[e] = a2;
+    }
+}
+
+int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p) {
+    if (p <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL(k_symm_skinny, dim3((int)((N + 7) / 8)), dim3(256), 0, h->stream, G, ldG, X, Y, (int)N,
+                       (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p) {
+    hipLaunchKernelGGL(k_panel_tn, dim3((int)((p * p + 3) / 4)), dim3(256), 0, h->stream, A, B, H, (int)N, (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
+                      int64_t N, int64_t p) {
+    int64_t g = (N * p + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_panel_rot2, dim3((int)g), dim3(256), (size_t)p * p * 8, h->stream, Q, GQ, S, X1, X2, (int)N,
+                       (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int subspace_max_block(int64_t N) {
     // CGS2 keeps the N x p panel in LDS
     const int64_t budget = 140 * 1024;
