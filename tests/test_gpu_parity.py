@@ -517,3 +517,27 @@ def test_hook_modes_rpca_close_to_exact(eng):
     assert repp.converged and svp_ == sv
     assert relerr(Ap, A0) < 1e-5
     assert repp.d_norm >= rep0.d_norm                      # rnorm is an upper bound
+
+
+def test_rccl_path_single_rank(torch_mod):
+    """The in-library RCCL exchange (unique id, ncclCommInitRank, in-place ncclAllReduce of the Gram matrix and
+    of the setup scalar on the handle's stream) exercised with a one-rank communicator on this GPU."""
+    import os
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    os.environ["TLSQ_FORCE_COMM"] = "1"
+    try:
+        e = tlsq_amd.Engine(0)
+        uid = e.unique_id()
+        assert len(uid) == 128 and any(uid)
+        e.comm_init(1, 0, uid)
+        D, _, _ = O.synth_lowrank_sparse(600, 48, 4, seed=9)
+        A, E, s, sv, rep = e.rpca(D, return_report=True, m_global=600)
+        e.close()
+    finally:
+        os.environ.pop("TLSQ_FORCE_COMM", None)
+    e2 = tlsq_amd.Engine(0)
+    A2, E2, s2, sv2, rep2 = e2.rpca(D, return_report=True)
+    e2.close()
+    assert sv == sv2 and rep.iters_done == rep2.iters_done
+    assert np.array_equal(A, A2) and np.array_equal(E, E2)

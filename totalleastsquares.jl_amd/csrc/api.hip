@@ -98,13 +98,13 @@ struct Comm {
 
 // in-place sum of an N x N Gram over the row shards (the one real exchange of the path)
 static int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
-    if (h->nranks <= 1 || !h->comm) return TLSQ_OK;
+    if (!h->comm) return TLSQ_OK;
     TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
     return TLSQ_OK;
 }
 
 static int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op) {
-    if (h->nranks <= 1 || !h->comm) return TLSQ_OK;
+    if (!h->comm) return TLSQ_OK;
     void* slot;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
     double* d = reinterpret_cast<double*>(reinterpret_cast<char*>(slot) + 256);
@@ -252,13 +252,20 @@ static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t l
 }
 
 // full eigen-decomposition of G by the block Jacobi solver: V in WS_V
-static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps) {
+static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps,
+                    bool allow_warm = false) {
     void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
     TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     int64_t sw = 0;
-    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw));
+    // consecutive ALM iterations see nearly the same eigenvectors: reuse them (cold restart every 8th time so
+    // that rounding drift in the accumulated rotations cannot build up)
+    const bool warm = allow_warm && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
+    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw, false, warm));
+    h->warm_n = N;
+    h->warm_uses = warm ? h->warm_uses + 1 : 0;
+    if (getenv("TLSQ_DEBUG")) fprintf(stderr, "  full eig N=%lld warm=%d sweeps=%lld\n", (long long)N, (int)warm, (long long)sw);
     if (sweeps) *sweeps += sw;
     s.sigma.resize((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
@@ -610,7 +617,8 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     const int64_t pmax = subspace_max_block(N);
     const char* force_full = getenv("TLSQ_FULL_EIG");
     const bool use_subspace = !hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
-    bool v_is_full = false;
+    bool v_is_full = false, prev_full = false;
+    h->warm_n = 0;   // nothing from an earlier call is reused
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
     void* meanws = nullptr;
@@ -645,13 +653,14 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
         }
         if (!fast_ok) {
-            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, prev_full));
             if (hook_svd && k >= 2) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
             ++sub.full;
         } else {
             ++sub.fast;
         }
         v_is_full = !fast_ok && !(hook_svd && k >= 2);
+        prev_full = !fast_ok;
         pt.mark();
         svp = 0;                                                   // :198
         for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
@@ -1097,7 +1106,9 @@ int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[T
     TLSQ_TRY(check_handle(h));
     if (nranks < 1 || rank < 0 || rank >= nranks || !id) return set_err(h, TLSQ_ERR_ARG, "bad comm args");
     tlsq_comm_destroy(h);
-    if (nranks == 1) {
+    // a single rank needs no communicator (TLSQ_FORCE_COMM=1 creates one anyway: exercises the RCCL path on one GPU)
+    const char* force = getenv("TLSQ_FORCE_COMM");
+    if (nranks == 1 && !(force && force[0] == '1')) {
         h->nranks = 1;
         h->rank = 0;
         return TLSQ_OK;

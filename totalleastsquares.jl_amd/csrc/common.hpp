@@ -35,6 +35,9 @@ struct Handle {
     size_t pinned_bytes = 0;
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
+    // warm start of the full Jacobi solver: WS_V holds the eigenvectors of the previous full decomposition
+    int64_t warm_n = 0;      // its size (0 = nothing to reuse)
+    int warm_uses = 0;       // consecutive warm starts (reset to a cold start now and then: drift control)
 };
 
 }  // namespace tlsq
@@ -116,7 +119,9 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
 // B and V are workspace buffers owned by the caller (N*N each).
 // async_small: when the matrix fits the single-workgroup path, do not read the sweep count back (no host sync).
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
-               bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false);
+               bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false,
+               bool warm_v = false);
+// warm_v: V holds the previous decomposition's eigenvectors (orthogonal): start from B = G*V.
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);

@@ -484,7 +484,7 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
 }
 
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,
-               double* lam_dev, int64_t* sweeps_out, bool async_small) {
+               double* lam_dev, int64_t* sweeps_out, bool async_small, bool warm_v) {
     if (sweeps_out) *sweeps_out = 0;
     if (N <= 0) return TLSQ_OK;
     void* scal;
@@ -519,9 +519,15 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     }
     int64_t g = (N * N + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_jacobi_init, dim3((int)g), dim3(256), 0, h->stream, G, ldG, B, V, (int)N,
-                       want_v ? 1 : 0);
-    TLSQ_HIP(h, hipGetLastError());
+    if (warm_v && want_v && N > 64) {
+        // warm start: V already holds an orthogonal matrix that nearly diagonalises G (the previous ALM
+        // iteration's eigenvectors): iterate on B = G*V instead of B = G, V = I
+        TLSQ_TRY(gemm_f64(h, true, false, (const double*)V, N, G, ldG, B, N, N, N, N, false));
+    } else {
+        hipLaunchKernelGGL(k_jacobi_init, dim3((int)g), dim3(256), 0, h->stream, G, ldG, B, V, (int)N,
+                           want_v ? 1 : 0);
+        TLSQ_HIP(h, hipGetLastError());
+    }
     if (N == 1) {
         hipLaunchKernelGGL(k_colnorm, dim3(1), dim3(256), 0, h->stream, (const double*)B, 1, lam_dev);
         TLSQ_HIP(h, hipGetLastError());
