@@ -114,7 +114,6 @@ def main():
         sweep_ms_per_iter = (ms["shrink"] + ms["update"]) / iters_total
         alg_bytes = 11.0 * Ml * N * 8                     # K1 R3/W2 + K2 R4/W2 passes
         achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
-        gram_flops = 2.0 * (2.0 * Ml * N * N)             # two Gram matrices per iteration (Z and residual)
         out = {
             "metric": "rpca ALM iters/sec on 20000x512 fp64 D",
             "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -130,13 +129,28 @@ def main():
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes},
             "phases_ms_per_iter": {k: v / iters_total for k, v in ms.items()
                                    if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")},
-            "gram_mfma": {"tflops": gram_flops / (max(ms["gram"], 1e-9) / iters_total * 1e-3) / 1e12
-                          if ms.get("gram") else None, "peak": 78.6,
-                          "note": "Gram(Z) only; flops counted as full 2MN^2"},
+            "roofline_mfma": None,
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
             "svd_step": {"full_jacobi": rep.eig_full, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
         }
-        out["gram_mfma"]["tflops"] = (2.0 * Ml * N * N) / (ms["gram"] / iters_total * 1e-3) / 1e12 if ms.get("gram") else None
+        # HBM bytes of the two sweep kernels from the committed PMC run (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_sweeps.json")) as f:
+                pmc = json.load(f)
+            if Ml == 20000 and N == 512:
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_iteration_shrink_plus_update"]
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_sweeps.json (rocprofv3 --pmc, separate passes)"
+        except OSError:
+            pass
+        # second roofline: the Gram kernel (fp64 MFMA, v_mfma_f64_16x16x4_f64), flops actually executed
+        # (only the lower-triangular 128x128 tiles of Z'Z are computed)
+        nt = (N + 127) // 128
+        gram_flops = 2.0 * Ml * 128 * 128 * (nt * (nt + 1) // 2)
+        if ms.get("gram"):
+            tf = gram_flops / (ms["gram"] / iters_total * 1e-3) / 1e12
+            out["roofline_mfma"] = {"kernel": "k_gemm_f64<KC,KC> Gram(Z) + slab reduce", "bound": "mfma",
+                                    "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                    "flops_per_launch": gram_flops, "ms_per_launch": ms["gram"] / iters_total}
         if world == 1 and args.cpu_iters > 0:
             ncores = os.cpu_count() or 1
             O.rpca(D[:2000], iters=1)                     # warm LAPACK/OpenMP
