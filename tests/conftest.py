@@ -1,6 +1,11 @@
 import os
 import sys
 
+# before numpy/scipy load their BLAS: the oracle's LAPACK calls on small matrices are 50x slower with one thread
+# per host core (256 on the GPU box) than with a handful
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -541,3 +541,36 @@ def test_rccl_path_single_rank(torch_mod):
     e2.close()
     assert sv == sv2 and rep.iters_done == rep2.iters_done
     assert np.array_equal(A, A2) and np.array_equal(E, E2)
+
+
+def test_fuzz_parity(eng):
+    """Randomised shapes / ranks / noise levels / flags (tools/fuzz_parity.py), including runs of 40-120 ALM
+    iterations where 1/mu reaches the resolution of the plain Gram route and the two-level decomposition takes
+    over.  Bar: no exceptions, >= 97 % of the cases with the oracle's exact iteration count and svp trajectory,
+    every A, E within 1e-6 ||D||."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    done, bad, exc, worst = fz.run_cases(eng, seed=0, ncase=100, budget_s=120.0, verbose=True)
+    assert exc == 0
+    assert done >= 40
+    assert bad <= 0.03 * done + 1, (done, bad)
+    assert worst < 1e-6
+
+
+def test_long_run_converges_like_the_reference(eng):
+    """A case that needs 39 iterations (1/mu ends at ~2e-7 ||D||_2): without the two-level decomposition the
+    plain Gram route miscounts singular values near the threshold and never converges."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(123)
+    M, N, r = 1500, 130, 38
+    D = rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.1)
+    Ao, Eo, so, svo, io = O.rpca(D, iters=120)
+    A, E, s, sv, rep = eng.rpca(D, iters=120, return_report=True)
+    assert io.iters_done >= 36
+    assert rep.iters_done == io.iters_done and rep.converged == io.converged
+    assert rep.svp_hist == io.svp_hist and sv == svo
+    assert relerr(A, Ao) < 1e-7 and relerr(E, Eo) < 1e-7

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: many small/medium rpca problems (shapes, ranks, noise, flags) GPU vs oracle.
+Reports every case whose iteration count / svp history / sv differs or whose A,E error exceeds 1e-8.
+    python tools/fuzz_parity.py [seed] [ncases]
+Also imported by tests/test_gpu_parity.py::test_fuzz_parity."""
+import os, sys, time, warnings
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")   # LAPACK on tiny matrices crawls with 256 threads
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def make_case(rng):
+    M = int(rng.choice([5, 8, 20, 50, 51, 100, 300, 600, 1500]))
+    N = int(rng.choice([3, 4, 5, 8, 17, 40, 64, 100, 130]))
+    r = int(rng.integers(1, max(2, min(M, N) // 3 + 1)))
+    noise = float(rng.choice([0.0, 0.0, 1e-6, 1e-3, 1e-1]))
+    frac = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
+    scale = float(rng.choice([1e-3, 1.0, 1e4]))
+    D = (rng.standard_normal((M, r)) @ rng.standard_normal((r, N))
+         + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < frac)
+         + noise * rng.standard_normal((M, N))) * scale
+    kw = dict(nukeA=bool(rng.random() < 0.7), nonnegA=bool(rng.random() < 0.1), nonnegE=bool(rng.random() < 0.1),
+              iters=int(rng.choice([120, 60])))
+    if rng.random() < 0.2:
+        kw["lam"] = float(rng.uniform(0.02, 0.5))
+    return D, kw, f"{M}x{N} r={r} noise={noise} frac={frac} scale={scale}"
+
+
+def run_cases(eng, seed, ncase, budget_s=300.0, verbose=True):
+    """returns (cases_run, trajectory_mismatches, exceptions, worst_err)"""
+    from oracle import rpca_oracle as O
+    warnings.simplefilter("ignore")
+    try:   # LAPACK on tiny matrices crawls with one thread per host core (256 on the GPU box)
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=4)
+    except Exception:   # noqa: BLE001
+        pass
+    rng = np.random.default_rng(seed)
+    bad = exc = done = 0
+    worst = 0.0
+    t0 = time.time()
+    for it in range(ncase):
+        D, kw, desc = make_case(rng)
+        try:
+            A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+        except Exception as e:   # noqa: BLE001
+            exc += 1
+            if verbose:
+                print(f"case {it} {desc} {kw}: GPU EXCEPTION {e}", flush=True)
+            continue
+        Ao, Eo, so, svo, io = O.rpca(D, **kw)
+        done += 1
+        dn = max(np.linalg.norm(D), 1e-300)
+        ea, ee = np.linalg.norm(A - Ao) / dn, np.linalg.norm(E - Eo) / dn
+        same = (rep.iters_done == io.iters_done) and (rep.svp_hist == io.svp_hist) and sv == svo
+        worst = max(worst, ea, ee)
+        if not same or ea > 1e-8 or ee > 1e-8:
+            bad += 1
+            k = next((i for i, (a, b) in enumerate(zip(rep.svp_hist, io.svp_hist)) if a != b), None)
+            if verbose:
+                print(f"case {it} {desc} {kw}: iters {rep.iters_done}/{io.iters_done} sv {sv}/{svo} "
+                      f"first svp diff at k={k} errA={ea:.1e} errE={ee:.1e}", flush=True)
+        if time.time() - t0 > budget_s:
+            if verbose:
+                print("time budget reached at case", it, flush=True)
+            break
+    return done, bad, exc, worst
+
+
+if __name__ == "__main__":
+    import tlsq_amd
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+    eng = tlsq_amd.Engine(0)
+    t0 = time.time()
+    done, bad, exc, worst = run_cases(eng, seed, ncase, float(os.environ.get("FUZZ_BUDGET_S", "300")))
+    print(f"{done} cases, {bad} mismatches, {exc} exceptions, worst err {worst:.2e}, {time.time()-t0:.0f}s")

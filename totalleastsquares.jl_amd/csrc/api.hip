@@ -253,18 +253,20 @@ static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t l
 
 // full eigen-decomposition of G by the block Jacobi solver: V in WS_V
 static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps,
-                    bool allow_warm = false) {
+                    bool allow_warm = false, int vslot = WS_V) {
     void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
-    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
+    TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     int64_t sw = 0;
     // consecutive ALM iterations see nearly the same eigenvectors: reuse them (cold restart every 8th time so
     // that rounding drift in the accumulated rotations cannot build up)
-    const bool warm = allow_warm && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
+    const bool warm = allow_warm && vslot == WS_V && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
     TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw, false, warm));
-    h->warm_n = N;
-    h->warm_uses = warm ? h->warm_uses + 1 : 0;
+    if (vslot == WS_V) {
+        h->warm_n = N;
+        h->warm_uses = warm ? h->warm_uses + 1 : 0;
+    }
     if (getenv("TLSQ_DEBUG")) fprintf(stderr, "  full eig N=%lld warm=%d sweeps=%lld\n", (long long)N, (int)warm, (long long)sw);
     if (sweeps) *sweeps += sw;
     s.sigma.resize((size_t)N);
@@ -565,6 +567,71 @@ static ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, doubl
     return r;
 }
 
+// ---- two-level ("precise") decomposition for late ALM iterations ------------------------------------
+// The plain Gram route resolves singular values only down to ~sqrt(N eps) sigma_max.  When the threshold
+// 1/mu approaches that level (after ~33 iterations; mu is capped at 1e7 mu_0, src/robustPCA.jl:183) the
+// spectrum is split:  level 1 = eigenpairs of G = Z'Z with sigma >= 1e-3 sigma_max (accurate in the plain
+// route);  level 2 = eigenpairs of the Gram matrix of the explicitly deflated panel
+//     Z_perp = Z - (Z V_B) V_B'          (computed in the working precision, written to `scratch`)
+// whose own noise floor is sqrt(N eps) * 1e-3 sigma_max ~ 1e-9 sigma_max — below the smallest threshold the
+// reference can reach (0.8e-7 ||D||_2).  Both levels use the full Jacobi solver.  On return Vc (WS_VC, N x
+// s.ncols) holds [V_B, tail vectors] sorted by singular value; s.ncols counts only what may matter (all of
+// level 1, and the level-2 pairs above `keep_above`).
+template <typename T>
+static int svd_two_level(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double keep_above,
+                         double** V_out, SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
+    double* G = nullptr;
+    TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+    if (pt) pt->mark();
+    double* V1 = nullptr;
+    SmallSvd s1;
+    TLSQ_TRY(eig_full(h, G, N, &V1, s1, sweeps, false, WS_V));
+    const double top = s1.sigma[s1.order[0]];
+    std::vector<int32_t> big;
+    for (int64_t i = 0; i < N; ++i)
+        if (s1.sigma[s1.order[i]] >= 1e-3 * top && s1.sigma[s1.order[i]] > 0.0) big.push_back(s1.order[i]);
+    const int64_t nb = (int64_t)big.size();
+    void* Vc;
+    TLSQ_TRY(ws_get(h, WS_VC, (size_t)N * N * 8, &Vc));
+    s.sigma.clear();
+    if (nb > 0) TLSQ_TRY(gather_cols(h, V1, N, big, (double*)Vc));
+    for (int64_t i = 0; i < nb; ++i) s.sigma.push_back(s1.sigma[big[i]]);
+    if (nb < N) {
+        // Z_perp = Z - (Z V_B) V_B'
+        const T* Zp = Z;
+        if (nb > 0) {
+            void* T1;
+            TLSQ_TRY(ws_get(h, WS_T, (size_t)M * nb * 8, &T1));
+            TLSQ_TRY(gemm_mixed(h, true, false, Vc, 0, N, Z, Prec<T>::f32, M, T1, 0, M, nb, M, N, false));
+            TLSQ_TRY(gemm_mixed(h, false, false, Vc, 0, N, T1, 0, M, scratch, Prec<T>::f32, M, N, M, nb, false));
+            TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
+            Zp = scratch;
+        }
+        double* G2 = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, Zp, M, N, M, &G2));
+        double* V2 = nullptr;
+        SmallSvd s2;
+        TLSQ_TRY(eig_full(h, G2, N, &V2, s2, sweeps, false, WS_V2));
+        // level-2 pairs, largest first; the nb smallest ones are the deflated directions
+        std::vector<int32_t> tail;
+        const double top2 = s2.sigma[s2.order[0]];
+        const double res2 = std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * top2;
+        for (int64_t i = 0; i < N - nb; ++i) {
+            const double sg = s2.sigma[s2.order[i]];
+            if (sg >= keep_above && sg >= res2 && sg < 1e-3 * top * 1.01) tail.push_back(s2.order[i]);
+        }
+        if (!tail.empty()) {
+            TLSQ_TRY(gather_cols(h, V2, N, tail, (double*)Vc + (size_t)N * nb));
+            for (size_t i = 0; i < tail.size(); ++i) s.sigma.push_back(s2.sigma[tail[i]]);
+        }
+    }
+    s.ncols = (int64_t)s.sigma.size();
+    s.order.resize((size_t)s.ncols);
+    std::iota(s.order.begin(), s.order.end(), 0);   // already sorted: level 1 descending, then level 2 descending
+    *V_out = (double*)Vc;
+    return TLSQ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the ALM loop on device-resident, contiguous (ld = M) panels D, A, E of element type T (fp64 or fp32).
 // The small N x N work (Gram matrices, eigenvectors, singular values) is always fp64.
@@ -618,6 +685,8 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     const char* force_full = getenv("TLSQ_FULL_EIG");
     const bool use_subspace = !hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
     bool v_is_full = false, prev_full = false;
+    double sigma_top_prev = 0.0;
+    int64_t n_precise = 0;
     h->warm_n = 0;   // nothing from an earlier call is reused
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
@@ -638,10 +707,19 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         pt.mark();
         TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark();
+        // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
+        const bool precise = !hook_svd && sigma_top_prev > 0.0 &&
+                             inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
         double* G = nullptr;                                                                   // :193-194
+        bool fast_ok = false;
+        if (precise) {
+            TLSQ_TRY(svd_two_level<T>(h, Z, M, N, R, inv_mu, &V, s, &sweeps, &pt));
+            sub.valid = false;
+            ++sub.full;
+            ++n_precise;
+        } else {
         TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
         pt.mark();
-        bool fast_ok = false;
         if (hook_svd && k >= 2) {
             // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
             SubspaceState rs;
@@ -659,11 +737,20 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         } else {
             ++sub.fast;
         }
-        v_is_full = !fast_ok && !(hook_svd && k >= 2);
-        prev_full = !fast_ok;
+        }   // !precise
+        v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2);
+        prev_full = !precise && !fast_ok;
         pt.mark();
+        // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
+        // singular values below sigma_res = sqrt(8 N eps) * sigma_max cannot be told from zero.
+        // The reference's threshold 1/mu only drops that low after ~36 iterations (mu_bar = 1e7 mu_0); from
+        // there on unresolved values are treated as zero instead of being counted at random.
+        const double sigma_top = s.ncols > 0 ? s.sigma[s.order[0]] : 0.0;
+        sigma_top_prev = sigma_top;
+        const double sigma_res = precise ? 0.0 : std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
+        const double count_thr = std::max(inv_mu, sigma_res);
         svp = 0;                                                   // :198
-        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
+        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= count_thr) ? 1 : 0;
         sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
         std::vector<int32_t> sel((size_t)svp);
         std::vector<double> g((size_t)svp);
@@ -673,7 +760,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
         }
         TLSQ_TRY(rebuild_lowrank<T>(h, Z, M, N, M, V, sel, g, A, M));
-        if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (use_subspace && !precise) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
         pt.mark();
         TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));         // :217-222
@@ -722,6 +809,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         info->eig_full = sub.full;
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
+        info->reserved = (int32_t)n_precise;   // iterations served by the two-level decomposition
     }
     if (sv_out) *sv_out = sv;
 

@@ -73,7 +73,8 @@ enum WsSlot {
     WS_SCAL,                                     // small scalars / counters
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
-    WS_DT, WS_AT, WS_ET, WS_UT,                                            // transposed problem (M < N)
+    WS_DT, WS_AT, WS_ET, WS_UT,
+    WS_V2, WS_VC,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
 };
 
@@ -94,6 +95,9 @@ int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 // dst (N x M, ld N) = src' for src (M x N, ld M)
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst);
+// out = a - b
+template <typename T>
+int launch_diff(Handle* h, const T* a, const T* b, T* out, int64_t n);
 // dst[i] = (Tdst) src[i]
 template <typename TS, typename TD>
 int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n);

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_jacobi_small2(const double* __restrict_
                     // own rounding level — so that is the attainable target; two numerically-zero diagonals are left alone
                     const double mx = a11 > a22 ? a11 : a22;
                     double thr = tol * sqrt(a11 * a22);
-                    if (thr < 8.8817841970012523e-16 * mx) thr = 8.8817841970012523e-16 * mx;
+                    if (thr < 3.5527136788005009e-15 * mx) thr = 3.5527136788005009e-15 * mx;   // 16 eps
                     if (fabs(h12) > thr && mx > dfloor) {
                         const double zeta = (h22 - h11) / (2.0 * h12);
                         const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -383,6 +383,13 @@ __global__ __launch_bounds__(256) void k_jacobi_small2(const double* __restrict_
                     sH[c * LD + p1] = cs * x - sn * y;
                     sH[c * LD + q1] = sn * x + cs * y;
                 }
+            }
+            __syncthreads();
+            // the rotated pair's off-diagonal entry is zero by construction: store it as such (rounding would
+            // otherwise leave ~eps*max(h_pp,h_qq) behind and re-trigger the pair forever)
+            if (tid < npair && s_sn[tid] != 0.0) {
+                sH[s_q[tid] * LD + s_p[tid]] = 0.0;
+                sH[s_p[tid] * LD + s_q[tid]] = 0.0;
             }
             __syncthreads();
         }
@@ -500,10 +507,10 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         if (tol0 < 4.0 * eps0) tol0 = 4.0 * eps0;
         const int max_sweeps0 = 40;
         if (want_v)
-            hipLaunchKernelGGL(k_jacobi_small2<true>, dim3(1), dim3(256), 0, h->stream, G, ldG, B, V, lam_dev,
+            hipLaunchKernelGGL(k_jacobi_small<true>, dim3(1), dim3(1024), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
         else
-            hipLaunchKernelGGL(k_jacobi_small2<false>, dim3(1), dim3(256), 0, h->stream, G, ldG, B, V, lam_dev,
+            hipLaunchKernelGGL(k_jacobi_small<false>, dim3(1), dim3(1024), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
         TLSQ_HIP(h, hipGetLastError());
         if (async_small) return TLSQ_OK;   // the caller validates the result itself (residuals)

@@ -165,6 +165,14 @@ __global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, in
     }
 }
 
+// out = a - b (contiguous n)
+template <typename T>
+__global__ __launch_bounds__(256) void k_diff(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                              int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] - b[i];
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void k_convert(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -260,6 +268,16 @@ int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst) {
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
+
+template <typename T>
+int launch_diff(Handle* h, const T* a, const T* b, T* out, int64_t n) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_diff<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, a, b, out, n);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template int launch_diff<double>(Handle*, const double*, const double*, double*, int64_t);
+template int launch_diff<float>(Handle*, const float*, const float*, float*, int64_t);
 
 template <typename TS, typename TD>
 int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n) {
