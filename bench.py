@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--rows", type=int, default=20000)
     ap.add_argument("--cols", type=int, default=512)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--cpu-iters", type=int, default=6, help="ALM iterations of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=24, help="ALM iterations of the CPU-oracle sample (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -153,14 +153,36 @@ def main():
                                     "flops_per_launch": gram_flops, "ms_per_launch": ms["gram"] / iters_total}
         if world == 1 and args.cpu_iters > 0:
             ncores = os.cpu_count() or 1
-            O.rpca(D[:2000], iters=1)                     # warm LAPACK/OpenMP
+            # LAPACK gesdd on a 20000x512 panel does not scale to hundreds of threads: pick the best of a few
+            # thread counts on one iteration, then time the sample with it (a fair best-effort host baseline)
+            best_t, best_n = None, ncores
+            try:
+                from threadpoolctl import threadpool_limits
+            except Exception:   # noqa: BLE001
+                threadpool_limits = None
+            cands = sorted({c for c in (8, 16, 32, 64, ncores) if c <= ncores})
+            if threadpool_limits is not None:
+                O.rpca(D[:2000], iters=1)                 # warm LAPACK/OpenMP
+                for c in cands:
+                    with threadpool_limits(limits=c):
+                        tq = time.perf_counter()
+                        O.rpca(D, iters=1)
+                        tq = time.perf_counter() - tq
+                    if best_t is None or tq < best_t:
+                        best_t, best_n = tq, c
+            ctx = threadpool_limits(limits=best_n) if threadpool_limits is not None else None
+            if ctx is not None:
+                ctx.__enter__()
             tc = time.perf_counter()
             _, _, _, _, ci = O.rpca(D, iters=args.cpu_iters)
             tc = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": ci.iters_done / tc, "unit": "iters/s", "cores": ncores, "kind": "port",
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+            out["cpu_baseline"] = {"value": ci.iters_done / tc, "unit": "iters/s", "cores": best_n, "kind": "port",
+                                   "host_cores_available": ncores,
                                    "sample": f"first {ci.iters_done} ALM iterations of the same {M}x{N} D "
-                                             f"(oracle: LAPACK gesdd x2 per iteration + fused OpenMP sweeps), "
-                                             f"{tc:.1f} s"}
+                                             f"(oracle: LAPACK gesdd x2 per iteration + fused OpenMP sweeps; "
+                                             f"thread count chosen as the fastest of {cands}), {tc:.1f} s"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
