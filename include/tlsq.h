@@ -184,6 +184,10 @@ int tlsq_k_gemm_nt_f64(tlsq_handle h, const double* T, int64_t M, int64_t K, int
 /* symmetric PSD eigen-decomposition of G (N x N): lam (N, descending), V (N x N, ldV; may be NULL) */
 int tlsq_k_symeig_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam,
                       double* V, int64_t ldV, int64_t* sweeps);
+/* the same through the Cholesky-preconditioned route used inside the ALM loop (Jacobi on chol(G + delta I), no
+ * eigenvector accumulation): eigenvectors of numerically-zero eigenvalues are returned as zero columns */
+int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam, double* V,
+                           int64_t ldV, int64_t* sweeps);
 /* sigma_max of Z (M x N, ldZ) — the default `opnorm` */
 int tlsq_k_opnorm_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                       double* sigma_max);

@@ -574,3 +574,34 @@ def test_long_run_converges_like_the_reference(eng):
     assert rep.iters_done == io.iters_done and rep.converged == io.converged
     assert rep.svp_hist == io.svp_hist and sv == svo
     assert relerr(A, Ao) < 1e-7 and relerr(E, Eo) < 1e-7
+
+
+@pytest.mark.parametrize("N,rank,spread", [(100, 100, 1.0), (128, 128, 1e-6), (512, 40, 1.0), (512, 512, 1e-5), (300, 300, 1e-7),
+                                           (65, 10, 1.0)])
+def test_symeig_cholesky_route(eng, torch_mod, N, rank, spread):
+    """Jacobi on the Cholesky factor (the full solver of the ALM loop): eigenvalues to N eps lambda_max, the
+    eigenvectors of resolved eigenvalues orthonormal with small residual, far fewer sweeps on graded spectra."""
+    torch = torch_mod
+    rng = np.random.default_rng(11)
+    sv = np.geomspace(1.0, spread, rank) if spread < 1.0 else np.ones(rank) * rng.uniform(0.5, 2.0, rank)
+    U, _ = np.linalg.qr(rng.standard_normal((max(2 * N, 8), rank)))
+    W, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    X = (U * sv) @ W[:, :rank].T
+    G = X.T @ X
+    G = (G + G.T) / 2
+    dG = to_dev(torch, G)
+    dl = torch.zeros(N, dtype=torch.float64, device="cuda")
+    dV = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    sweeps = C.c_int64()
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_symeig_chol_f64(eng.h, dptr(dG), N, N, dptr(dl), dptr(dV), N, C.byref(sweeps)) == 0, \
+        eng.lib.tlsq_last_error(eng.h)
+    lam, V = to_host(dl), to_host(dV)
+    ref = np.linalg.eigvalsh(G)[::-1]
+    assert np.all(np.diff(lam) <= 0)
+    assert np.max(np.abs(lam - ref)) < 16 * N * 2.2e-16 * ref[0]
+    keep = lam > 1e3 * N * 2.2e-16 * ref[0]                       # resolved eigenvalues
+    Vk = V[:, keep]
+    assert np.max(np.abs(Vk.T @ Vk - np.eye(Vk.shape[1]))) < 1e-9
+    assert np.linalg.norm(G @ Vk - Vk * lam[keep][None, :]) < 1e-11 * np.linalg.norm(G) * math.sqrt(N)
+    assert sweeps.value <= 16

@@ -252,27 +252,48 @@ static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t l
 }
 
 // full eigen-decomposition of G by the block Jacobi solver: V in WS_V
+// does the full solver go through the Cholesky factor (zero columns for numerically-zero eigenvalues)?
+static bool chol_route(int64_t N) {
+    static const bool no_chol = [] { const char* e = getenv("TLSQ_NO_CHOL"); return e && e[0] == '1'; }();
+    return N > 64 && !no_chol;
+}
+
 static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps,
-                    bool allow_warm = false, int vslot = WS_V) {
+                    bool allow_warm = false, int vslot = WS_V, bool need_all_vectors = false) {
     void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
     TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     int64_t sw = 0;
-    // consecutive ALM iterations see nearly the same eigenvectors: reuse them (cold restart every 8th time so
-    // that rounding drift in the accumulated rotations cannot build up)
-    const bool warm = allow_warm && vslot == WS_V && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
-    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw, false, warm));
-    if (vslot == WS_V) {
-        h->warm_n = N;
-        h->warm_uses = warm ? h->warm_uses + 1 : 0;
-    }
-    if (getenv("TLSQ_DEBUG")) fprintf(stderr, "  full eig N=%lld warm=%d sweeps=%lld\n", (long long)N, (int)warm, (long long)sw);
-    if (sweeps) *sweeps += sw;
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
     s.sigma.resize((size_t)N);
-    TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    for (auto& v : s.sigma) v = std::sqrt(v);
+    if (chol_route(N) && !need_all_vectors) {
+        // Cholesky-preconditioned route: Jacobi on L = chol(G + delta I); far fewer sweeps on graded spectra and
+        // no eigenvector accumulation.  Vectors of numerically-zero eigenvalues come back as zero columns, which
+        // is fine for the ALM loop (only sigma_i >= 1/mu are used).
+        double delta = 0.0;
+        TLSQ_TRY(symeig_chol_f64(h, G, N, N, (double*)B, (double*)V, (double*)lam, &delta, &sw));
+        if (vslot == WS_V) h->warm_n = 0;
+        if (dbg) fprintf(stderr, "  full eig (chol) N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
+        if (sweeps) *sweeps += sw;
+        TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& v : s.sigma) v = std::sqrt(std::max(v * v - delta, 0.0));   // sigma(L)^2 = lambda + delta
+    } else {
+        // consecutive ALM iterations see nearly the same eigenvectors: reuse them (cold restart every 8th time so
+        // that rounding drift in the accumulated rotations cannot build up)
+        const bool warm = allow_warm && vslot == WS_V && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
+        TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw, false, warm));
+        if (vslot == WS_V) {
+            h->warm_n = N;
+            h->warm_uses = warm ? h->warm_uses + 1 : 0;
+        }
+        if (dbg) fprintf(stderr, "  full eig N=%lld warm=%d sweeps=%lld\n", (long long)N, (int)warm, (long long)sw);
+        if (sweeps) *sweeps += sw;
+        TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& v : s.sigma) v = std::sqrt(v);
+    }
     s.ncols = N;
     sort_desc(s);
     *V_out = (double*)V;
@@ -285,7 +306,7 @@ static int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld,
     double* G;
     TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, ld, &G));
     if (pt) pt->mark();
-    return eig_full(h, G, N, V_out, s, sweeps);
+    return eig_full(h, G, N, V_out, s, sweeps, false, WS_V, true);   // callers (tls!, SSA truncation) want every vector
 }
 
 // ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
@@ -738,7 +759,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             ++sub.fast;
         }
         }   // !precise
-        v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2);
+        v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2) && !chol_route(N);
         prev_full = !precise && !fast_ok;
         pt.mark();
         // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
@@ -819,7 +840,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         // the last iteration used a subspace path: the caller wants the complete SVD of the last Z
         double* G = nullptr;
         TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
-        TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+        TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, false, WS_V, true));
         if (info) info->jacobi_sweeps = sweeps;
     }
     if (S_host && V)
@@ -1494,6 +1515,37 @@ int tlsq_k_symeig_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, do
                                      (double*)Vs));
         TLSQ_TRY(copy2d(h, V, ldV, Vs, N, N, N, 8, hipMemcpyDeviceToDevice));
     }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam, double* V,
+                           int64_t ldV, int64_t* sweeps) {
+    TLSQ_TRY(check_handle(h));
+    if (!G || !lam || !V || N <= 0 || ldG < N || ldV < N) return set_err(h, TLSQ_ERR_ARG, "symeig_chol: bad argument");
+    void *B, *Vw, *lamw;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &Vw));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lamw));
+    int64_t sw = 0;
+    double delta = 0.0;
+    TLSQ_TRY(symeig_chol_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw));
+    if (sweeps) *sweeps = sw;
+    std::vector<double> hl((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lamw, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto& v : hl) v = std::max(v * v - delta, 0.0);
+    std::vector<int32_t> order((size_t)N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return hl[a] > hl[b]; });
+    std::vector<double> sorted((size_t)N);
+    for (int64_t i = 0; i < N; ++i) sorted[i] = hl[order[i]];
+    TLSQ_HIP(h, hipMemcpyAsync(lam, sorted.data(), (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    void *aux, *Vs;
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)N * 16, &aux));
+    TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * N * 8, &Vs));
+    TLSQ_HIP(h, hipMemcpyAsync(aux, order.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(launch_gather_scale(h, (const double*)Vw, N, (const int32_t*)aux, nullptr, N, nullptr, (double*)Vs));
+    TLSQ_TRY(copy2d(h, V, ldV, Vs, N, N, N, 8, hipMemcpyDeviceToDevice));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }

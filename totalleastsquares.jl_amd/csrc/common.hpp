@@ -130,6 +130,16 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);
 
+// ---------------- cholesky.hip ----------------
+// L (N x N, ld N) = chol(G + delta I) with delta = 2 N eps max_i G_ii (stats_dev[1] = delta); T = N x N scratch.
+int cholesky_shifted(Handle* h, const double* G, int64_t ldG, int64_t N, double* L, double* T, double* stats_dev);
+int launch_normalize_cols(Handle* h, const double* B, int64_t N, double* V, double* sig);
+// Eigen-decomposition of the PSD matrix G through its Cholesky factor: one-sided Jacobi on L (no eigenvector
+// accumulation), V = normalised columns of the rotated L, sig_dev[i] = singular values of L = sqrt(lambda_i + delta).
+// Columns belonging to numerically-zero eigenvalues come back as zero vectors.
+int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev,
+                    double* delta_host, int64_t* sweeps_out);
+
 // ---------------- lanczos.hip ----------------
 // lambda_max(G) to relative accuracy rel_tol (residual bound of the Ritz pair); returns 1 (and the best
 // estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.

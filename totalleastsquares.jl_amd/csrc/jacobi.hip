@@ -15,10 +15,27 @@
 
 namespace tlsq {
 
+// Wave-wide all-reduce without the LDS crossbar: four DPP steps inside each row of 16 lanes (quad_perm,
+// quad_perm, row_half_mirror, row_mirror), then the four row totals are read with v_readlane and summed.
+// (__shfl_xor compiles to ds_bpermute_b32: six dependent LDS round trips per fp64 reduction.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_allsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_perm<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);   // row_half_mirror
+    v += dpp_perm<0x140>(v);   // row_mirror
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
 // round-robin tournament: pair `idx` of round `r` among n (even) players
@@ -49,6 +66,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_round(double* __restrict__ B, d
     double* sB = sm;
     double* sV = sm + (size_t)nslot * N;
     unsigned int* s_cnt = reinterpret_cast<unsigned int*>(sm + (size_t)nslot * N * (WANT_V ? 2 : 1));
+    double* sN = sm + (size_t)nslot * N * (WANT_V ? 2 : 1) + 2;   // cached squared column norms, one per slot
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int bp, bq;
     rr_pair(nblk, round, blockIdx.x, bp, bq);
@@ -71,9 +89,19 @@ __global__ __launch_bounds__(1024) void k_jacobi_round(double* __restrict__ B, d
     const double floor2 = params[0];
 
     // ---- inner tournament over the 2b slots ----
+    // The squared column norms are computed once per sweep and then carried through the rotations
+    // (a' = a - t c, b' = b + t c), so a pair costs one dot product + one wave reduction instead of three.
     const int nin = nslot - 1;
     int sweep = 0;
     for (; sweep < max_inner_sweeps; ++sweep) {
+        for (int sl = w; sl < nslot; sl += nw) {
+            const double* xcol = sB + (size_t)sl * N;
+            double nn = 0.0;
+            for (int row = lane; row < N; row += 64) nn += xcol[row] * xcol[row];
+            nn = wave_allsum(nn);
+            if (lane == 0) sN[sl] = nn;
+        }
+        __syncthreads();
         unsigned int my_rot = 0;
         for (int ir = 0; ir < nin; ++ir) {
             for (int pi = w; pi < b; pi += nw) {
@@ -89,35 +117,75 @@ __global__ __launch_bounds__(1024) void k_jacobi_round(double* __restrict__ B, d
                 if (c1 < N && c2 < N) {
                     double* x = sB + (size_t)s1 * N;
                     double* y = sB + (size_t)s2 * N;
-                    double a = 0.0, bb = 0.0, c = 0.0;
-                    for (int row = lane; row < N; row += 64) {
-                        const double xv = x[row], yv = y[row];
-                        a += xv * xv;
-                        bb += yv * yv;
-                        c += xv * yv;
+                    // Rows are handled in chunks of 8 per lane (512 rows): all 16 LDS reads of a chunk are issued
+                    // before the first use, and for N <= 512 the columns stay in registers from the dot products
+                    // to the rotation (one LDS round trip instead of three).
+                    constexpr int RC = 8;
+                    const int nchunk = (N + 64 * RC - 1) / (64 * RC);
+                    double xr[RC], yr[RC];
+                    const double a = sN[s1], bb = sN[s2];
+                    double c = 0.0;
+                    for (int ch = nchunk - 1; ch >= 0; --ch) {   // chunk 0 last: it is the one kept in registers
+#pragma unroll
+                        for (int i = 0; i < RC; ++i) {
+                            const int row = lane + 64 * (ch * RC + i);
+                            xr[i] = row < N ? x[row] : 0.0;
+                            yr[i] = row < N ? y[row] : 0.0;
+                        }
+#pragma unroll
+                        for (int i = 0; i < RC; ++i) c += xr[i] * yr[i];
                     }
-                    a = wave_allsum(a);
-                    bb = wave_allsum(bb);
                     c = wave_allsum(c);
-                    const double lim = tol * sqrt(a * bb);
                     const double mn = a < bb ? a : bb;
-                    if (fabs(c) > lim && mn > floor2) {
-                        const double zeta = (bb - a) / (2.0 * c);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    if (c * c > tol * tol * a * bb && mn > floor2) {
+                        // tan(theta) of the Jacobi rotation, smaller root of t^2 + 2 zeta t - 1 = 0 with
+                        // zeta = (bb - a)/(2c), written so that it needs one sqrt and one division:
+                        //   t = 2 c sgn(d) / (|d| + sqrt(d^2 + 4 c^2)),  d = bb - a
+                        const double d = bb - a;
+                        const double t = (d >= 0.0 ? 2.0 : -2.0) * c / (fabs(d) + sqrt(d * d + 4.0 * c * c));
                         const double cs = 1.0 / sqrt(1.0 + t * t);
                         const double sn = cs * t;
-                        for (int row = lane; row < N; row += 64) {
-                            const double xv = x[row], yv = y[row];
-                            x[row] = cs * xv - sn * yv;
-                            y[row] = sn * xv + cs * yv;
+                        if (lane == 0) {
+                            const double na = a - t * c, nb2 = bb + t * c;
+                            sN[s1] = na > 0.0 ? na : 0.0;
+                            sN[s2] = nb2 > 0.0 ? nb2 : 0.0;
+                        }
+                        for (int ch = 0; ch < nchunk; ++ch) {
+                            if (ch > 0) {
+#pragma unroll
+                                for (int i = 0; i < RC; ++i) {
+                                    const int row = lane + 64 * (ch * RC + i);
+                                    xr[i] = row < N ? x[row] : 0.0;
+                                    yr[i] = row < N ? y[row] : 0.0;
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < RC; ++i) {
+                                const int row = lane + 64 * (ch * RC + i);
+                                if (row < N) {
+                                    x[row] = cs * xr[i] - sn * yr[i];
+                                    y[row] = sn * xr[i] + cs * yr[i];
+                                }
+                            }
                         }
                         if (WANT_V) {
                             double* vx = sV + (size_t)s1 * N;
                             double* vy = sV + (size_t)s2 * N;
-                            for (int row = lane; row < N; row += 64) {
-                                const double xv = vx[row], yv = vy[row];
-                                vx[row] = cs * xv - sn * yv;
-                                vy[row] = sn * xv + cs * yv;
+                            for (int ch = 0; ch < nchunk; ++ch) {
+#pragma unroll
+                                for (int i = 0; i < RC; ++i) {
+                                    const int row = lane + 64 * (ch * RC + i);
+                                    xr[i] = row < N ? vx[row] : 0.0;
+                                    yr[i] = row < N ? vy[row] : 0.0;
+                                }
+#pragma unroll
+                                for (int i = 0; i < RC; ++i) {
+                                    const int row = lane + 64 * (ch * RC + i);
+                                    if (row < N) {
+                                        vx[row] = cs * xr[i] - sn * yr[i];
+                                        vy[row] = sn * xr[i] + cs * yr[i];
+                                    }
+                                }
                             }
                         }
                         ++my_rot;
@@ -486,7 +554,8 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
         return (int)half;
     }
     int64_t b = budget / (2 * per_col);
-    if (b > 8) b = 8;  // 8 waves = 512 threads per workgroup
+    const int64_t bcap = want_v ? 8 : 16;   // waves per workgroup (1024 threads at most)
+    if (b > bcap) b = bcap;
     return (int)b;
 }
 
@@ -554,7 +623,7 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     int nblk = (int)((N + b - 1) / b);
     if (nblk & 1) ++nblk;
     if (nblk < 2) nblk = 2;
-    const size_t lds = (size_t)2 * b * N * 8 * (want_v ? 2 : 1) + 16;
+    const size_t lds = (size_t)2 * b * N * 8 * (want_v ? 2 : 1) + 16 + (size_t)2 * b * 8;
     const int nwaves = b < 16 ? b : 16;
     if (want_v) {
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_round<true>),
@@ -621,6 +690,74 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     if (!converged)
         return set_err(h, TLSQ_ERR_NOCONV, "Jacobi eigensolver did not converge in %d sweeps (N=%lld)",
                        max_sweeps, (long long)N);
+    return TLSQ_OK;
+}
+
+// Eigen-decomposition of the PSD matrix G through its Cholesky factor (cholesky.hip): one-sided Jacobi on the
+// columns of L = chol(G + delta I) with no eigenvector accumulation; the eigenvectors of G are the normalised
+// columns of the rotated L and sig = column norms = sqrt(lambda + delta).
+int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev,
+                    double* delta_host, int64_t* sweeps_out) {
+    if (sweeps_out) *sweeps_out = 0;
+    if (N <= 0) return TLSQ_OK;
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* params = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 64);
+    unsigned int* rot = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 128);
+    double* stats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 192);
+    TLSQ_TRY(cholesky_shifted(h, G, ldG, N, B, V /* scratch */, stats));
+    const double eps = 2.220446049250313e-16;
+    int sweep = 0;
+    bool converged = true;
+    if (N >= 2) {
+        const double nf = (double)N * eps;
+        hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params, nf * nf);
+        TLSQ_HIP(h, hipGetLastError());
+        bool single = false;
+        int b = pick_block(N, false, &single);
+        if (b > 16) b = 16;
+        if (b < 1)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "N=%lld too large for the LDS-resident Jacobi eigensolver",
+                           (long long)N);
+        int nblk = (int)((N + b - 1) / b);
+        if (nblk & 1) ++nblk;
+        if (nblk < 2) nblk = 2;
+        const size_t lds = (size_t)2 * b * N * 8 + 16 + (size_t)2 * b * 8;
+        const int nwaves = b < 16 ? b : 16;
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_round<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        double tol = 2.0 * eps * sqrt((double)N);
+        if (tol < 4.0 * eps) tol = 4.0 * eps;
+        const int max_sweeps = 40;
+        converged = false;
+        for (; sweep < max_sweeps; ++sweep) {
+            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+            for (int r = 0; r < nblk - 1; ++r)
+                hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * nwaves), lds, h->stream, B,
+                                   (double*)nullptr, (int)N, b, nblk, r, tol, (const double*)params, rot, 1,
+                                   (int*)nullptr);
+            TLSQ_HIP(h, hipGetLastError());
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            unsigned int nrot;
+            memcpy(&nrot, h->pinned, 4);
+            if (nrot == 0) {
+                ++sweep;
+                converged = true;
+                break;
+            }
+        }
+    }
+    if (sweeps_out) *sweeps_out = sweep;
+    TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, stats, 16, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double st[2];
+    memcpy(st, h->pinned, 16);
+    if (delta_host) *delta_host = st[1];
+    if (!converged)
+        return set_err(h, TLSQ_ERR_NOCONV, "Jacobi (Cholesky route) did not converge in 40 sweeps (N=%lld)",
+                       (long long)N);
     return TLSQ_OK;
 }
 
