@@ -172,6 +172,14 @@ int tlsq_k_shrink_f32(tlsq_handle h, const float* D, const float* A, const float
                       float* Z, int64_t n, float inv_mu, float thr, int nonnegE);
 int tlsq_k_update_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y,
                       float* R, int64_t n, float mu, int nonnegA);
+/* fused sweep used inside the loop for k >= 2: update of iteration k and shrink of iteration k+1 in one pass
+ * (reads D, A, E, Y; writes R, Y, En = E_{k+1}, Zn = Z_{k+1}; 8 array passes instead of 11) */
+int tlsq_k_update_shrink_f64(tlsq_handle h, const double* D, double* A, const double* E, double* Y, double* R,
+                             double* En, double* Zn, int64_t n, double mu, int nonnegA, double inv_mu_next,
+                             double thr_next, int nonnegE);
+int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
+                             float* En, float* Zn, int64_t n, float mu, int nonnegA, float inv_mu_next,
+                             float thr_next, int nonnegE);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

@@ -605,3 +605,34 @@ def test_symeig_cholesky_route(eng, torch_mod, N, rank, spread):
     assert np.max(np.abs(Vk.T @ Vk - np.eye(Vk.shape[1]))) < 1e-9
     assert np.linalg.norm(G @ Vk - Vk * lam[keep][None, :]) < 1e-11 * np.linalg.norm(G) * math.sqrt(N)
     assert sweeps.value <= 16
+
+
+@pytest.mark.parametrize("dt,n", [(np.float64, 100003), (np.float32, 65537)])
+@pytest.mark.parametrize("nonneg", [0, 1])
+def test_fused_update_shrink_bitexact(eng, torch_mod, dt, n, nonneg):
+    """The fused sweep (update of iteration k + shrink of iteration k+1, 8 passes) produces exactly the bits of the
+    two separate reference statements (src/robustPCA.jl:217-223 then :188-192)."""
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    rng = np.random.default_rng(21)
+    D, A, E, Y = (rng.standard_normal(n).astype(dt) for _ in range(4))
+    mu, inv_mu_n, thr_n = dt(0.27), dt(2.9), dt(0.4)
+    A2 = np.maximum(A, 0) if nonneg else A
+    R = (D - A2) - E
+    Y2 = Y + mu * R
+    t = inv_mu_n * Y2
+    En = O.soft_th((D - A2) + t, thr_n).astype(dt)
+    if nonneg:
+        En = np.maximum(En, 0)
+    Zn = (D - En) + t
+    suf = "f64" if dt == np.float64 else "f32"
+    sc = C.c_double if dt == np.float64 else C.c_float
+    dD, dA, dE, dY = (to_dev(torch, x) for x in (D, A, E, Y))
+    dR, dEn, dZn = (torch.empty_like(dD) for _ in range(3))
+    torch.cuda.synchronize()
+    assert getattr(eng.lib, "tlsq_k_update_shrink_" + suf)(eng.h, dptr(dD), dptr(dA), dptr(dE), dptr(dY), dptr(dR),
+                                                           dptr(dEn), dptr(dZn), n, sc(mu), nonneg, sc(inv_mu_n),
+                                                           sc(thr_n), nonneg) == 0
+    eng.synchronize()
+    for got, ref in ((dR, R), (dY, Y2), (dEn, En), (dZn, Zn), (dA, A2)):
+        assert np.array_equal(to_host(got), ref)

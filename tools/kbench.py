@@ -59,6 +59,10 @@ def main():
         n = M * N
         us1 = timeit(eng, lambda: lib.tlsq_k_shrink_f64(h, p(D), p(A_), p(Y), p(E), p(Zz), n, 3.0, 0.5, 0), a.reps)
         us2 = timeit(eng, lambda: lib.tlsq_k_update_f64(h, p(D), p(A_), p(E), p(Y), p(R), n, 0.3, 0), a.reps)
+        En, Zn = (torch.empty_like(D) for _ in range(2))
+        us3 = timeit(eng, lambda: lib.tlsq_k_update_shrink_f64(h, p(D), p(A_), p(E), p(Y), p(R), p(En), p(Zn), n, 0.3, 0,
+                                                                 3.0, 0.5, 0), a.reps)
+        print(f"fused update+shrink {us3:.1f} us: {8*n*8/us3/1e6:.2f} TB/s actual, {11*n*8/us3/1e6:.2f} TB/s algorithmic")
         print(f"shrink {us1:.1f} us {5*n*8/us1/1e6:.2f} TB/s | update {us2:.1f} us {6*n*8/us2/1e6:.2f} TB/s | "
               f"11 passes {11*n*8/(us1+us2)/1e6:.2f} TB/s")
     if a.what in ("symeig", "all"):

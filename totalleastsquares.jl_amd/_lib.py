@@ -50,6 +50,7 @@ EXPORTS = [
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
     "tlsq_lowrankfilter_f64", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
+    "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32",
     "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
     "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64",
 ]
@@ -91,6 +92,7 @@ def load():
         getattr(lib, "tlsq_soft_hankel_" + suf).argtypes = [vp, vp, i64, i64, i64, sc, i32]
         getattr(lib, "tlsq_k_shrink_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, sc, i32]
         getattr(lib, "tlsq_k_update_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, i32]
+        getattr(lib, "tlsq_k_update_shrink_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, sc, i32, sc, sc, i32]
     lib.tlsq_lowrankfilter_f64.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, P(RpcaOpts), vp, i64,
                                            P(RpcaInfo)]
     lib.tlsq_tls_f64.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64, i32]

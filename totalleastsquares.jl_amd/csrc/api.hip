@@ -668,7 +668,17 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * sizeof(T), &Yv));
     TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
     TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
-    T *Y = (T*)Yv, *Z = (T*)Zv, *R = (T*)Rv;
+    T *Y = (T*)Yv, *R = (T*)Rv;
+    // E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
+    // must survive in case iteration k is the last one
+    void *E2v, *Z2v;
+    TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
+    TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+    T* Ebuf[2] = {E, (T*)E2v};
+    T* Zbuf[2] = {(T*)Zv, (T*)Z2v};
+    int cur = 0;                 // index of the buffers holding E_k, Z_k
+    bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
+    static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
     int64_t sweeps = 0;
     const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
     const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
@@ -725,8 +735,11 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     for (k = 1; k <= ro.iters; ++k) {                              // :186
         const double inv_mu = 1.0 / mu;
         const double thr = lam / mu;
+        T* E = Ebuf[cur];
+        T* Z = Zbuf[cur];
         pt.mark();
-        TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
+        if (!have_next)
+            TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark();
         // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
         const bool precise = !hook_svd && sigma_top_prev > 0.0 &&
@@ -784,9 +797,18 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         if (use_subspace && !precise) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
         pt.mark();
-        TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));         // :217-222
+        const double mu_next = std::min(mu * ro.rho, mubar);       // :223
+        const bool fuse = !no_fuse && k < ro.iters;
+        if (fuse) {
+            // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
+            TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
+                                             ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
+                                             ro.nonnegE ? 1 : 0));
+        } else {
+            TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
+        }
         pt.mark();
-        mu = std::min(mu * ro.rho, mubar);                         // :223
+        mu = mu_next;
         double rn = 0.0;
         if (hook_opnorm) {
             TLSQ_TRY(opnorm_power<T>(h, R, M, N, M, mvps, seed + 7919ull * (uint64_t)k, &rn));   // :225 hook
@@ -817,8 +839,17 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             converged = true;
             break;
         }
+        if (fuse) {
+            cur ^= 1;
+            have_next = true;
+        } else {
+            have_next = false;
+        }
     }
     if (k > ro.iters) k = ro.iters;
+    T* Z = Zbuf[cur];
+    if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
+        TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, E, M, N, M, (T)(lam / mu), (T*)meanws));  // :234-236
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) {
@@ -1466,6 +1497,18 @@ int tlsq_k_update_f32(tlsq_handle h, const float* D, float* A, const float* E, f
                       int64_t n, float mu, int nonnegA) {
     TLSQ_TRY(check_handle(h));
     return launch_update<float>(h, D, A, E, Y, R, n, mu, nonnegA);
+}
+int tlsq_k_update_shrink_f64(tlsq_handle h, const double* D, double* A, const double* E, double* Y, double* R,
+                             double* En, double* Zn, int64_t n, double mu, int nonnegA, double inv_mu_next,
+                             double thr_next, int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    return launch_update_shrink<double>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE);
+}
+int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
+                             float* En, float* Zn, int64_t n, float mu, int nonnegA, float inv_mu_next,
+                             float thr_next, int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE);
 }
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
                     int64_t ldG) {

@@ -74,7 +74,7 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
+    WS_V2, WS_VC, WS_E2, WS_Z2,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
 };
 
@@ -84,6 +84,10 @@ int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int
                   T thr, int nonnegE);
 template <typename T>
 int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu, int nonnegA);
+// fused update(k) + shrink(k+1): R_k, Y_k, E_{k+1} (En), Z_{k+1} (Zn) in one pass
+template <typename T>
+int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE);
 // Y = D / s  (src/robustPCA.jl:181), contiguous n
 template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s);

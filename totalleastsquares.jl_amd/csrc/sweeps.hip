@@ -95,6 +95,63 @@ __global__ __launch_bounds__(256) void k_update(const T* __restrict__ D, T* __re
     }
 }
 
+// Fused update(k) + shrink(k+1): one pass reads D, A, E_k, Y and writes R_k, Y_k, E_{k+1}, Z_{k+1}
+// (8 array passes instead of the 11 of k_update followed by k_shrink; arithmetic and expression order unchanged:
+//  src/robustPCA.jl:217-223 for iteration k, then :188-192 for iteration k+1 with mu_{k+1}).
+// E_{k+1}, Z_{k+1} go to buffers of their own: if iteration k turns out to be the last one, E_k and Z_k are
+// the results.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, T* __restrict__ A,
+                                                       const T* __restrict__ E, T* __restrict__ Y,
+                                                       T* __restrict__ R, T* __restrict__ En, T* __restrict__ Zn,
+                                                       int64_t n, T mu, int nonnegA, T inv_mu_n, T thr_n,
+                                                       int nonnegE) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        V d = reinterpret_cast<const V*>(D)[i];
+        V a = reinterpret_cast<const V*>(A)[i];
+        V e = reinterpret_cast<const V*>(E)[i];
+        V y = reinterpret_cast<const V*>(Y)[i];
+        V r, en, zn;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            if (nonnegA) a[c] = pos_part(a[c]);          // A .= max.(A,0)            :217-219
+            T z = (d[c] - a[c]) - e[c];                  // @. Z = D - A - E          :221
+            r[c] = z;
+            y[c] = y[c] + mu * z;                        // @. Y = Y + mu*Z           :222
+            T t = inv_mu_n * y[c];                       // next iteration, mu_{k+1}  :188
+            T ee = soft_th((d[c] - a[c]) + t, thr_n);
+            if (nonnegE) ee = pos_part(ee);              //                           :189-191
+            en[c] = ee;
+            zn[c] = (d[c] - ee) + t;                     //                           :192
+        }
+        if (nonnegA) reinterpret_cast<V*>(A)[i] = a;
+        reinterpret_cast<V*>(R)[i] = r;
+        reinterpret_cast<V*>(Y)[i] = y;
+        reinterpret_cast<V*>(En)[i] = en;
+        reinterpret_cast<V*>(Zn)[i] = zn;
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) {
+        T a = A[i];
+        if (nonnegA) {
+            a = pos_part(a);
+            A[i] = a;
+        }
+        T z = (D[i] - a) - E[i];
+        R[i] = z;
+        T y = Y[i] + mu * z;
+        Y[i] = y;
+        T t = inv_mu_n * y;
+        T ee = soft_th((D[i] - a) + t, thr_n);
+        if (nonnegE) ee = pos_part(ee);
+        En[i] = ee;
+        Zn[i] = (D[i] - ee) + t;
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_div_scalar(const T* __restrict__ D, T* __restrict__ Y,
                                                     int64_t n, T s) {
@@ -221,6 +278,22 @@ int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n
 }
 
 template <typename T>
+int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE) {
+    if (n <= 0) return TLSQ_OK;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R) && aligned16(En) && aligned16(Zn)) {
+        hipLaunchKernelGGL((k_update_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, E,
+                           Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE);
+    } else {
+        hipLaunchKernelGGL((k_update_shrink<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, E, Y, R, En,
+                           Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s) {
     if (n <= 0) return TLSQ_OK;
     constexpr int VEC = 16 / sizeof(T);
@@ -294,6 +367,8 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
 #define INST(T)                                                                                   \
     template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
+    template int launch_update_shrink<T>(Handle*, const T*, T*, const T*, T*, T*, T*, T*, int64_t, T, int, T, T, \
+                                         int);                                                     \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
