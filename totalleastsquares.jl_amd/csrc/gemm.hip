@@ -331,8 +331,11 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
         return (int64_t)(v > 0 ? v : 256);   // one workgroup per CU (512 and 768 measured the same on C2)
     }();
     int64_t nsplit = 1;
-    if (tiles < target_wgs) {
-        nsplit = target_wgs / tiles;   // floor: never more workgroups than the target (no tail wave)
+    // skinny outputs (P <= 32 rows of MFMA work per tile) are bandwidth/latency bound, not MFMA bound: they want
+    // several workgroups per CU in flight, so split K further
+    const int64_t want_wgs = (P <= 32 && !symmetric) ? 4 * target_wgs : target_wgs;
+    if (tiles < want_wgs) {
+        nsplit = want_wgs / tiles;   // floor: never more workgroups than the target (no tail wave)
         if (nsplit < 1) nsplit = 1;
         const int64_t maxsplit = (K + 4 * TK - 1) / (4 * TK);
         if (nsplit > maxsplit) nsplit = maxsplit;
