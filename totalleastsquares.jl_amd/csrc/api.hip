@@ -1069,11 +1069,28 @@ static int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t l
     // 1/sqrt(max(M,N))).  A wide unsharded D is solved as its tall transpose: the Gram matrix is then M x M
     // and has no structurally-zero eigenvalues (accuracy of the Gram route).
     const bool transposed = (M < N) && ro.m_global == M && !h->comm;
+    // the small-matrix solvers of this release keep their panels in LDS: the Gram dimension is limited
+    if ((transposed ? M : N) > 2048)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED,
+                       "rpca: min(M,N) = %lld exceeds 2048, the largest Gram dimension the LDS-resident eigensolvers "
+                       "of this release handle", (long long)(transposed ? M : N));
+
+    // The panels the MFMA kernels stream (Z, R, ...) inherit the row count of the working problem as their leading
+    // dimension.  The Gram kernel reads 16-row (128-byte) segments of every column: when the leading dimension is
+    // not a multiple of 16 every segment straddles two cache lines (measured 3x slower at 9,999,745 rows), and an
+    // odd one also forces 8-byte loads.  So the row count is padded with zero rows to a multiple of 16 in private
+    // panels — zero rows change nothing in the algorithm (lambda and d use the true size through m_global).
+    const int64_t Mw = transposed ? N : M;          // rows of the working (tall) problem
+    const int64_t Nw = transposed ? M : N;
+    const bool pad = (Mw % 16 != 0) && !ro.hankel;  // soft_hankel! would see the extra rows: keep the exact shape there
+    const int64_t Mp = pad ? (Mw + 15) / 16 * 16 : Mw;
+    const size_t nw = (size_t)Mp * Nw;
 
     const T* dD = D;
     T *dA = A, *dE = E, *dU = U;
     void* p;
     double th = now_ms();
+    const bool priv = !dev || transposed || pad;    // work on private panels?
     if (!dev || ldD != M) {
         TLSQ_TRY(ws_get(h, WS_D, (size_t)n * es, &p));
         TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -1087,49 +1104,64 @@ static int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t l
         TLSQ_TRY(ws_get(h, WS_E, (size_t)n * es, &p));
         dE = (T*)p;
     }
-    if (U && !transposed && (!dev || ldU != M)) {
+    if (U && !transposed && !pad && (!dev || ldU != M)) {
         TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * es, &p));
         dU = (T*)p;
     }
+    (void)priv;
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) info->ms_h2d = now_ms() - th;
 
     // S / Vt are small: always produced on the host in fp64, then converted / copied to the caller's memory
     std::vector<double> hS((size_t)(S ? d : 0)), hVt((size_t)(Vt ? d * N : 0));
     int status;
-    if (!transposed) {
+    if (!transposed && !pad) {
         status = rpca_core<T>(h, dD, M, N, ro, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
                               Vt ? hVt.data() : nullptr, d, sv, info);
         if (status < 0) return status;
     } else {
-        // D' (N x M) -> A', E' ; the SVD of Z' = Z^T swaps the roles of U and V
-        void *Dt, *At, *Et, *Ut = nullptr;
-        TLSQ_TRY(ws_get(h, WS_DT, (size_t)n * es, &Dt));
-        TLSQ_TRY(ws_get(h, WS_AT, (size_t)n * es, &At));
-        TLSQ_TRY(ws_get(h, WS_ET, (size_t)n * es, &Et));
-        if (Vt) TLSQ_TRY(ws_get(h, WS_UT, (size_t)N * d * es, &Ut));   // U' (N x d): its transpose is Vt
-        TLSQ_TRY(launch_transpose<T>(h, dD, M, N, (T*)Dt));
-        ResolvedOpts rt = ro;
-        rt.m_global = N;
-        std::vector<double> hVtT((size_t)(U ? d * M : 0));            // Vt' (d x M): its transpose is U
-        status = rpca_core<T>(h, (const T*)Dt, N, M, rt, opts, (T*)At, (T*)Et, Vt ? (T*)Ut : nullptr,
-                              S ? hS.data() : nullptr, U ? hVtT.data() : nullptr, d, sv, info);
+        // working copies: Dw (Mp x Nw) = D or D', zero pad row; Aw, Ew results; Uw (Mp x d) left vectors of Zw
+        void *Dw, *Aw, *Ew, *Uw = nullptr;
+        TLSQ_TRY(ws_get(h, WS_DT, nw * es, &Dw));
+        TLSQ_TRY(ws_get(h, WS_AT, nw * es, &Aw));
+        TLSQ_TRY(ws_get(h, WS_ET, nw * es, &Ew));
+        const bool need_Uw = transposed ? (Vt != nullptr) : (U != nullptr);
+        if (need_Uw) TLSQ_TRY(ws_get(h, WS_UT, (size_t)Mp * d * es, &Uw));
+        if (pad) TLSQ_HIP(h, hipMemsetAsync(Dw, 0, nw * es, h->stream));
+        if (transposed) TLSQ_TRY(launch_transpose<T>(h, dD, M, M, N, (T*)Dw, Mp));
+        else TLSQ_TRY(copy2d(h, Dw, Mp, dD, M, M, N, es, hipMemcpyDeviceToDevice));
+        ResolvedOpts rw = ro;
+        rw.m_global = transposed ? N : ro.m_global;
+        std::vector<double> hVtW((size_t)d * Nw);                      // right vectors of the working problem
+        status = rpca_core<T>(h, (const T*)Dw, Mp, Nw, rw, opts, (T*)Aw, (T*)Ew, need_Uw ? (T*)Uw : nullptr,
+                              S ? hS.data() : nullptr, (transposed ? (U != nullptr) : (Vt != nullptr)) ? hVtW.data() : nullptr,
+                              d, sv, info);
         if (status < 0) return status;
-        TLSQ_TRY(launch_transpose<T>(h, (const T*)At, N, M, dA));
-        TLSQ_TRY(launch_transpose<T>(h, (const T*)Et, N, M, dE));
-        if (Vt) {   // Vt (d x N) = U'^T
-            std::vector<T> hu((size_t)N * d);
-            TLSQ_HIP(h, hipMemcpyAsync(hu.data(), Ut, (size_t)N * d * es, hipMemcpyDeviceToHost, h->stream));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            for (int64_t pcol = 0; pcol < d; ++pcol)
-                for (int64_t j = 0; j < N; ++j) hVt[pcol + j * d] = (double)hu[j + pcol * N];
-        }
-        if (U) {    // U (M x d) = Vt'^T, delivered below through a host staging copy
-            std::vector<T> hu((size_t)M * d);
-            for (int64_t pcol = 0; pcol < d; ++pcol)
-                for (int64_t i = 0; i < M; ++i) hu[i + pcol * M] = (T)hVtT[pcol + i * d];
-            TLSQ_TRY(copy2d(h, U, ldU, hu.data(), M, M, d, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (transposed) {
+            TLSQ_TRY(launch_transpose<T>(h, (const T*)Aw, Mp, N, M, dA, M));
+            TLSQ_TRY(launch_transpose<T>(h, (const T*)Ew, Mp, N, M, dE, M));
+            if (Vt) {   // Vt (d x N) = Uw^T  (Uw is N(+1) x d, ld Mp)
+                std::vector<T> hu((size_t)Mp * d);
+                TLSQ_HIP(h, hipMemcpyAsync(hu.data(), Uw, (size_t)Mp * d * es, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                for (int64_t pcol = 0; pcol < d; ++pcol)
+                    for (int64_t j = 0; j < N; ++j) hVt[pcol + j * d] = (double)hu[j + pcol * Mp];
+            }
+            if (U) {    // U (M x d) = VtW^T
+                std::vector<T> hu((size_t)M * d);
+                for (int64_t pcol = 0; pcol < d; ++pcol)
+                    for (int64_t i = 0; i < M; ++i) hu[i + pcol * M] = (T)hVtW[pcol + i * d];
+                TLSQ_TRY(copy2d(h, U, ldU, hu.data(), M, M, d, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
+        } else {
+            TLSQ_TRY(copy2d(h, dA, M, Aw, Mp, M, N, es, hipMemcpyDeviceToDevice));
+            TLSQ_TRY(copy2d(h, dE, M, Ew, Mp, M, N, es, hipMemcpyDeviceToDevice));
+            if (Vt) hVt = hVtW;
+            if (U) {
+                TLSQ_TRY(copy2d(h, U, ldU, Uw, Mp, M, d, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
         }
     }
 
@@ -1137,7 +1169,7 @@ static int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t l
     const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
     if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
-    if (U && !transposed && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
+    if (U && !transposed && !pad && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
     std::vector<T> tS, tVt;
     if (S) {
         tS.resize((size_t)d);
@@ -1344,33 +1376,38 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
     const double t0 = now_ms();
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
     const int64_t K = (Nx - n) / lag + 1, LD = n * Dch;
+    // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
+    // hankel option of rpca works on the exact shape
+    const int64_t Kp = (opts && opts->hankel) ? K : (K + 15) / 16 * 16;
     void *dy, *H, *A, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * 8, &dy));
-    TLSQ_TRY(ws_get(h, WS_D, (size_t)K * LD * 8, &H));
-    TLSQ_TRY(ws_get(h, WS_A, (size_t)K * LD * 8, &A));
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * 8, &H));
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * 8, &A));
+    if (Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * 8, h->stream));
     TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    TLSQ_TRY(launch_hankel<double>(h, (const double*)dy, Nx, Dch, Nx, n, lag, (double*)H, K));  // :120
+    TLSQ_TRY(launch_hankel<double>(h, (const double*)dy, Nx, Dch, Nx, n, lag, (double*)H, Kp));  // :120
     int status = TLSQ_OK;
     if (sv <= 0) {                                                                            // :121-122
-        TLSQ_TRY(ws_get(h, WS_E, (size_t)K * LD * 8, &E));
-        const ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
-        status = rpca_core<double>(h, (const double*)H, K, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * 8, &E));
+        ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
+        ro.m_global = K;
+        status = rpca_core<double>(h, (const double*)H, Kp, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
                            nullptr, 0, nullptr, info);
         if (status < 0) return status;
     } else {                                                                                  // :123-126
         SmallSvd s;
         double* V = nullptr;
         int64_t sweeps = 0;
-        TLSQ_TRY(svd_via_gram<double>(h, (const double*)H, K, LD, K, &V, s, &sweeps, nullptr));
+        TLSQ_TRY(svd_via_gram<double>(h, (const double*)H, Kp, LD, Kp, &V, s, &sweeps, nullptr));
         const int64_t r = std::min<int64_t>(sv, std::min(K, LD));
         std::vector<int32_t> sel((size_t)r);
         std::vector<double> g((size_t)r, 1.0);
         for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
-        TLSQ_TRY(rebuild_lowrank<double>(h, (const double*)H, K, LD, K, V, sel, g, (double*)A, K));
+        TLSQ_TRY(rebuild_lowrank<double>(h, (const double*)H, Kp, LD, Kp, V, sel, g, (double*)A, Kp));
         if (info) info->jacobi_sweeps = sweeps;
     }
     // :127  (dy is reused for the filtered signal)
-    TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, K, lag, Nx, (double*)dy, Nx));
+    TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, Kp, lag, Nx, (double*)dy, Nx));
     TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) info->ms_total = now_ms() - t0;

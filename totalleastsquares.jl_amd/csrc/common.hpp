@@ -96,9 +96,9 @@ template <typename T>
 int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
-// dst (N x M, ld N) = src' for src (M x N, ld M)
+// dst (N x M, ld ldd) = src' for src (M x N, ld lds)
 template <typename T>
-int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst);
+int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd);
 // out = a - b
 template <typename T>
 int launch_diff(Handle* h, const T* a, const T* b, T* out, int64_t n);

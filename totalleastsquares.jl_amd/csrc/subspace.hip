@@ -24,14 +24,19 @@ __device__ __forceinline__ double ss_wsum(double v) {
 // In-place orthonormalisation of the p columns of Y (N x p, ld N) by classical Gram-Schmidt with one
 // re-orthogonalisation pass (CGS2).  Whole panel in LDS.  status[0] = min over columns of
 // ||y_j after projection|| / ||y_j before|| (tiny => numerically dependent column).
+template <bool IN_LDS>
 __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int N, int p,
                                                      double* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* sY = sm;                    // p * N
-    double* sd = sm + (size_t)p * N;    // p dots
-    double* red = sd + p;               // 16
+    // IN_LDS: the whole panel lives in LDS.  Otherwise it stays in global memory (L2-resident, a single
+    // workgroup reads back its own stores after a barrier) and LDS only holds the dot products.
+    double* sY = IN_LDS ? sm : Y;
+    double* sd = IN_LDS ? sm + (size_t)p * N : sm;    // p dots
+    double* red = sd + p;                              // 16
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = SS_THREADS / 64;
-    for (int e = tid; e < N * p; e += SS_THREADS) sY[e] = Y[e];
+    if (IN_LDS) {
+        for (int e = tid; e < N * p; e += SS_THREADS) sY[e] = Y[e];
+    }
     __syncthreads();
     double minratio = 1.0;
     for (int j = 0; j < p; ++j) {
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int
             }
             n1 = ss_wsum(n1);
             if (lane == 0) red[w] = n1;
+            if (!IN_LDS) __threadfence_block();
             __syncthreads();
             const double before = n1s;
             n1s = 0.0;
@@ -79,9 +85,12 @@ __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int
         minratio = ratio < minratio ? ratio : minratio;
         const double inv = n1s > 0.0 ? 1.0 / sqrt(n1s) : 0.0;
         for (int r = tid; r < N; r += SS_THREADS) yj[r] *= inv;
+        if (!IN_LDS) __threadfence_block();
         __syncthreads();
     }
-    for (int e = tid; e < N * p; e += SS_THREADS) Y[e] = sY[e];
+    if (IN_LDS) {
+        for (int e = tid; e < N * p; e += SS_THREADS) Y[e] = sY[e];
+    }
     if (tid == 0) status[0] = minratio;
 }
 
@@ -289,19 +298,25 @@ int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double
     return TLSQ_OK;
 }
 
+static bool cgs2_fits_lds(int64_t N, int64_t p) { return (size_t)(p * N + p + 16) * 8 <= 144 * 1024; }
+
 int subspace_max_block(int64_t N) {
-    // CGS2 keeps the N x p panel in LDS
-    const int64_t budget = 140 * 1024;
-    int64_t p = budget / (N * 8) - 1;
-    if (p > 96) p = 96;  // the p x p Rayleigh-Ritz problem must fit the single-workgroup Jacobi
-    return p < 0 ? 0 : (int)p;
+    // CGS2 keeps the N x p panel in LDS when it fits and works out of L2 otherwise; the p x p Rayleigh-Ritz
+    // problem goes to the single-launch Jacobi up to 64 and to the block solver above
+    (void)N;
+    return 96;
 }
 
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) {
-    const size_t lds = (size_t)(p * N + p + 16) * 8;
-    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_cgs2, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+    if (cgs2_fits_lds(N, p)) {
+        const size_t lds = (size_t)(p * N + p + 16) * 8;
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+    } else {
+        const size_t lds = (size_t)(p + 16) * 8;
+        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+    }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

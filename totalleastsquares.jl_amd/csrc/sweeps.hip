@@ -202,23 +202,23 @@ __global__ __launch_bounds__(256) void k_maxabs(const T* __restrict__ x, int64_t
     }
 }
 
-// LDS-tiled transpose: dst (N x M, ld N) = src' , src (M x N, ld M), both column-major
+// LDS-tiled transpose: dst (N x M, ld ldd) = src' , src (M x N, ld lds), both column-major
 template <typename T>
-__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, int64_t M, int64_t N,
-                                                   T* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, int64_t lds, int64_t M, int64_t N,
+                                                   T* __restrict__ dst, int64_t ldd) {
     __shared__ T tile[32][33];
     const int64_t m0 = (int64_t)blockIdx.x * 32, n0 = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + tx, n = n0 + ty + 8 * r;
-        if (m < M && n < N) tile[ty + 8 * r][tx] = src[m + n * M];
+        if (m < M && n < N) tile[ty + 8 * r][tx] = src[m + n * lds];
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t n = n0 + tx, m = m0 + ty + 8 * r;
-        if (m < M && n < N) dst[n + m * N] = tile[tx][ty + 8 * r];
+        if (m < M && n < N) dst[n + m * ldd] = tile[tx][ty + 8 * r];
     }
 }
 
@@ -333,11 +333,11 @@ int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out) {
 }
 
 template <typename T>
-int launch_transpose(Handle* h, const T* src, int64_t M, int64_t N, T* dst) {
+int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
     if (grid.y > 65535) return set_err(h, TLSQ_ERR_UNSUPPORTED, "transpose: N too large");
-    hipLaunchKernelGGL((k_transpose<T>), grid, dim3(256), 0, h->stream, src, M, N, dst);
+    hipLaunchKernelGGL((k_transpose<T>), grid, dim3(256), 0, h->stream, src, lds, M, N, dst, ldd);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -372,7 +372,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
-    template int launch_transpose<T>(Handle*, const T*, int64_t, int64_t, T*);
+    template int launch_transpose<T>(Handle*, const T*, int64_t, int64_t, int64_t, T*, int64_t);
 INST(double)
 INST(float)
 #undef INST
