@@ -11,9 +11,10 @@ ranks).  N>1 row-shards the SAME 20000x512 problem (strong scaling) and exchange
 with RCCL inside libtlsqhip.so.
 
 Extra objects on the JSON line:
-  roofline      shrink+update sweeps (HBM-bound): 11*M*N*8 algorithmic bytes per ALM iteration divided by
-                the sweeps' device time measured with HIP events on the library's stream inside the timed
-                solves (tlsq_rpca_info.ms_shrink + ms_update).
+  roofline      ALM sweeps (HBM-bound): the bytes the shipped fused form has to move (8 passes over M*N*8 per
+                iteration + 5 for the lone shrink at k=1; SURVEY.md §8d's unfused figure is 11 and is reported
+                beside it) divided by the sweeps' device time measured with HIP events on the library's
+                stream inside the timed solves (tlsq_rpca_info.ms_shrink + ms_update).
   cpu_baseline  the oracle (oracle/rpca_oracle.py: LAPACK gesdd + fused OpenMP sweeps) timed on this box's
                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -112,7 +113,15 @@ def main():
     if rank == 0:
         value = iters_total / dt
         sweep_ms_per_iter = (ms["shrink"] + ms["update"]) / iters_total
-        alg_bytes = 11.0 * Ml * N * 8                     # K1 R3/W2 + K2 R4/W2 passes
+        # Bytes the sweeps have to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11
+        # passes per iteration); the shipped path fuses K2(k) with K1(k+1) (R4/W4 = 8 passes) and runs one plain
+        # K1 (5 passes) at k = 1, so the roofline is priced against the bytes of THAT form - the smaller figure.
+        fused = os.environ.get("TLSQ_NO_FUSED_SWEEP", "0") != "1"
+        array_bytes = float(Ml) * N * 8
+        if fused:
+            alg_bytes = (5.0 + 8.0 * rep.iters_done) / rep.iters_done * array_bytes
+        else:
+            alg_bytes = 11.0 * array_bytes
         achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
         out = {
             "metric": "rpca ALM iters/sec on 20000x512 fp64 D",
@@ -124,9 +133,11 @@ def main():
                        "rows_per_gpu": Ml, "iters_per_solve": rep.iters_done, "sv": sv,
                        "converged": rep.converged, "residual": resid, "rel_err_A": rel_a,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_update_shrink (fused ALM sweep) + k_shrink at k=1" if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes},
+                         "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
+                         "passes_per_iter": alg_bytes / array_bytes,
+                         "survey_11_pass_equivalent_GBps": 11.0 * array_bytes / (sweep_ms_per_iter * 1e-3) / 1e9},
             "phases_ms_per_iter": {k: v / iters_total for k, v in ms.items()
                                    if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")},
             "roofline_mfma": None,
@@ -138,9 +149,17 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_sweeps.json")) as f:
                 pmc = json.load(f)
             if Ml == 20000 and N == 512:
-                out["roofline"]["traffic"] = pmc["hbm_bytes_per_iteration_shrink_plus_update"]
+                sk = pmc["sweep_kernels"]
+                if fused and "k_update_shrink" in sk:
+                    tr = (sk["k_shrink"]["hbm_bytes_per_launch"] +
+                          rep.iters_done * sk["k_update_shrink"]["hbm_bytes_per_launch"]) / rep.iters_done
+                elif not fused and "k_update" in sk:
+                    tr = sk["k_shrink"]["hbm_bytes_per_launch"] + sk["k_update"]["hbm_bytes_per_launch"]
+                else:
+                    tr = None
+                out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_source"] = "profiles/r01_pmc_sweeps.json (rocprofv3 --pmc, separate passes)"
-        except OSError:
+        except (OSError, KeyError):
             pass
         # second roofline: the Gram kernel (fp64 MFMA, v_mfma_f64_16x16x4_f64), flops actually executed
         # (only the lower-triangular 128x128 tiles of Z'Z are computed)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter passes into the per-kernel HBM-traffic table kept under profiles/.
+
+usage: summarize_pmc.py <fetch_dir> <write_dir> <out_csv> [<out_json>]
+
+<fetch_dir>/<write_dir> are the -d directories of two separate passes
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <fetch_dir> -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <write_dir> -- python3 bench.py ...
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+(MI355X_MICROARCH.md, HBM section), so the fetch figure is doubled.  Only tlsq:: kernels are kept.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def collect(d, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter or "tlsq::" not in row["Kernel_Name"]:
+                    continue
+                a = acc[row["Kernel_Name"]]
+                a[0] += 1
+                a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, out_csv = sys.argv[1:4]
+    out_json = sys.argv[4] if len(sys.argv) > 4 else None
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in sorted(fe, key=lambda k: -fe[k][1]):
+        n, kb = fe[k]
+        wn, wkb = wr.get(k, (0, 0.0))
+        favg = kb / n
+        wavg = wkb / wn if wn else 0.0
+        fb, wb = favg * 1024 * 2, wavg * 1024
+        rows.append((k, n, round(favg, 1), int(fb), round(wavg, 1), int(wb), int(fb + wb)))
+    with open(out_csv, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "dispatches", "FETCH_SIZE_avg_KB", "fetch_bytes_corrected_x2", "WRITE_SIZE_avg_KB",
+                    "write_bytes", "hbm_bytes_per_launch"])
+        w.writerows(rows)
+    if out_json:
+        per = {}
+        for r in rows:
+            short = r[0].split("tlsq::")[1].split("<")[0].split("(")[0]
+            if short in ("k_shrink", "k_update", "k_update_shrink"):
+                per[short] = {"dispatches": r[1], "hbm_bytes_per_launch": r[6]}
+        with open(out_json, "w") as fh:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled "
+                                 "(gfx950), python3 bench.py --steps 1 --warmup 0 --cpu-iters 0",
+                       "sweep_kernels": per}, fh, indent=1)
+    for r in rows[:12]:
+        print(r[0][:70], r[1], r[6])
+
+
+if __name__ == "__main__":
+    main()

@@ -363,7 +363,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     TLSQ_TRY(ws_get(h, WS_SGX, (size_t)N * p * 8, &GX));
     TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
     TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
-    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
+    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)std::max<int64_t>(p * p, 32 * 32 + 32) * 8, &HB));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
     double* theta_dev = (double*)lam;
@@ -392,7 +392,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
                 TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
             }
         }
-        TLSQ_TRY(launch_cgs2(h, (double*)Q, N, p, stat_dev));
+        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, (double*)HB, N, p, stat_dev));
         // Rayleigh-Ritz: H = Q' (G Q)
         TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
@@ -799,25 +799,50 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         pt.mark();
         const double mu_next = std::min(mu * ro.rho, mubar);       // :223
         const bool fuse = !no_fuse && k < ro.iters;
+        // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
+        // side; while that lower bound of the cost is clearly above tol the iteration cannot be the last one and
+        // the Gram + Lanczos evaluation of opnorm(R) is skipped altogether.
+        const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
+        double* sumsq_dev = nullptr;
+        if (fuse && !want_exact_cost && !hook_opnorm) {
+            void* scal;
+            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+            sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 320);
+            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 8, h->stream));
+        }
         if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
-                                             ro.nonnegE ? 1 : 0));
+                                             ro.nonnegE ? 1 : 0, sumsq_dev));
         } else {
             TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
         }
         pt.mark();
         mu = mu_next;
         double rn = 0.0;
-        if (hook_opnorm) {
+        bool cost_skipped = false;
+        if (sumsq_dev) {
+            double fro2 = 0.0;
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            memcpy(&fro2, h->pinned, 8);
+            TLSQ_TRY(comm_allreduce_host_scalar(h, &fro2, ncclSum));
+            const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
+            if (lower > 2.0 * ro.tol) {
+                cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
+                cost_skipped = true;
+            }
+        }
+        if (cost_skipped) {
+            // nothing to evaluate
+        } else if (hook_opnorm) {
             TLSQ_TRY(opnorm_power<T>(h, R, M, N, M, mvps, seed + 7919ull * (uint64_t)k, &rn));   // :225 hook
             cost = rn / d_norm;
         } else {
             // When nobody looks at the per-iteration cost (no cost_hist, no verbose hook) only the DECISION
             // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
             // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
-            const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
             const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
             TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma));  // :225
             cost = rn / d_norm;
@@ -1539,13 +1564,13 @@ int tlsq_k_update_shrink_f64(tlsq_handle h, const double* D, double* A, const do
                              double* En, double* Zn, int64_t n, double mu, int nonnegA, double inv_mu_next,
                              double thr_next, int nonnegE) {
     TLSQ_TRY(check_handle(h));
-    return launch_update_shrink<double>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE);
+    return launch_update_shrink<double>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr);
 }
 int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
                              float* En, float* Zn, int64_t n, float mu, int nonnegA, float inv_mu_next,
                              float thr_next, int nonnegE) {
     TLSQ_TRY(check_handle(h));
-    return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE);
+    return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr);
 }
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
                     int64_t ldG) {

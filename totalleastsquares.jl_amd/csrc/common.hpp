@@ -86,8 +86,9 @@ template <typename T>
 int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu, int nonnegA);
 // fused update(k) + shrink(k+1): R_k, Y_k, E_{k+1} (En), Z_{k+1} (Zn) in one pass
 template <typename T>
+// sumsq (optional, device): += ||R_k||_F^2 (atomic adds: used only as a bound, never as a result)
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
-                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE);
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq = nullptr);
 // Y = D / s  (src/robustPCA.jl:181), contiguous n
 template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s);
@@ -154,7 +155,8 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);
-int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged = false);
+int launch_orth(Handle* h, double* Y, double* tmp, double* W, double* Lbuf, int64_t N, int64_t p, double* status_dev);
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);

@@ -230,9 +230,14 @@ __global__ __launch_bounds__(1024) void k_jacobi_round(double* __restrict__ B, d
 // workgroup; a 32-lane half-wave owns one column pair per inner round (lane = row, rows <= 64), so a
 // 24 x 24 Rayleigh-Ritz problem needs no inter-wave traffic beyond one barrier per inner round.
 __device__ __forceinline__ double half_allsum(double v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-    return v;
+    // sum over the 32 lanes of this half-wave: DPP inside each row of 16, then the two row totals of the half
+    v += dpp_perm<0xB1>(v);
+    v += dpp_perm<0x4E>(v);
+    v += dpp_perm<0x141>(v);
+    v += dpp_perm<0x140>(v);
+    const double lo = read_lane(v, 0) + read_lane(v, 16);
+    const double hi = read_lane(v, 32) + read_lane(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
 }
 
 template <bool WANT_V>
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     __shared__ double sB[64 * 65];
     __shared__ double sV[WANT_V ? 64 * 65 : 1];
     __shared__ double red[16];
+    __shared__ double sN[64];
     __shared__ unsigned int s_rot;
     const int LD = 65;
     const int tid = threadIdx.x;
@@ -269,6 +275,14 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         unsigned int my_rot = 0;
+        // squared column norms, refreshed once per sweep and updated by the rotation formulas in between
+        for (int c = hw; c < N; c += 32) {
+            const double* x = sB + c * LD;
+            const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0;
+            const double ssum = half_allsum(v0 * v0 + v1 * v1);
+            if (hl == 0) sN[c] = ssum;
+        }
+        __syncthreads();
         for (int ir = 0; ir < nslot - 1; ++ir) {
             if (hw < npair) {
                 int s1, s2;
@@ -284,15 +298,20 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
                     const int r0 = hl, r1 = hl + 32;
                     const double x0 = r0 < N ? x[r0] : 0.0, y0 = r0 < N ? y[r0] : 0.0;
                     const double x1 = r1 < N ? x[r1] : 0.0, y1 = r1 < N ? y[r1] : 0.0;
-                    const double a = half_allsum(x0 * x0 + x1 * x1);
-                    const double bb = half_allsum(y0 * y0 + y1 * y1);
+                    const double a = sN[s1], bb = sN[s2];
                     const double c = half_allsum(x0 * y0 + x1 * y1);
                     const double mn = a < bb ? a : bb;
-                    if (fabs(c) > tol * sqrt(a * bb) && mn > floor2) {
-                        const double zeta = (bb - a) / (2.0 * c);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = 1.0 / sqrt(1.0 + t * t);
+                    if (c * c > tol * tol * a * bb && mn > floor2) {
+                        // t = 2 c sgn(d) / (|d| + sqrt(d^2 + 4 c^2)), d = bb - a  (one sqrt, one division)
+                        const double d = bb - a;
+                        const double t = (d >= 0.0 ? 2.0 : -2.0) * c / (fabs(d) + sqrt(d * d + 4.0 * c * c));
+                        const double cs = rsqrt(1.0 + t * t);
                         const double sn = cs * t;
+                        if (hl == 0) {
+                            const double na = a - t * c, nb2 = bb + t * c;
+                            sN[s1] = na > 0.0 ? na : 0.0;
+                            sN[s2] = nb2 > 0.0 ? nb2 : 0.0;
+                        }
                         if (r0 < N) {
                             x[r0] = cs * x0 - sn * y0;
                             y[r0] = sn * x0 + cs * y0;

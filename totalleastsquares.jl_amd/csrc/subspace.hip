@@ -26,8 +26,9 @@ __device__ __forceinline__ double ss_wsum(double v) {
 // ||y_j after projection|| / ||y_j before|| (tiny => numerically dependent column).
 template <bool IN_LDS>
 __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int N, int p,
-                                                     double* __restrict__ status) {
+                                                     double* __restrict__ status, int only_if_flagged) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (only_if_flagged && status[1] == 0.0) return;   // CholeskyQR2 already did the job
     // IN_LDS: the whole panel lives in LDS.  Otherwise it stays in global memory (L2-resident, a single
     // workgroup reads back its own stores after a barrier) and LDS only holds the dot products.
     double* sY = IN_LDS ? sm : Y;
@@ -205,38 +206,157 @@ int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
 // ---- skinny products of the subspace iteration (N x N symmetric G, N x p panels, p <= 64) -------------------
 // These are a few MFLOP each: they are latency-bound, so each one is a single small launch (no split-K slabs).
 
-// Y (N x p) = G * X.   Workgroup = 8 output rows x 32 panel columns; X is staged through LDS in 256-row
-// slices (coalesced), the 8 rows of G (= columns, G symmetric) are read straight from L2 as broadcasts.
-constexpr int SK_KT = 256;
-__global__ __launch_bounds__(256) void k_symm_skinny(const double* __restrict__ G, int64_t ldG,
-                                                     const double* __restrict__ X, double* __restrict__ Y,
-                                                     int N, int p) {
-    __shared__ double sX[SK_KT * 33];
-    __shared__ double sG[8 * SK_KT];
-    const int tid = threadIdx.x;
-    const int c = tid & 31, ri = tid >> 5;
-    const int r0 = blockIdx.x * 8;
-    for (int c0 = 0; c0 < p; c0 += 32) {
-        double acc = 0.0;
-        for (int k0 = 0; k0 < N; k0 += SK_KT) {
-            const int kn = (N - k0 < SK_KT) ? N - k0 : SK_KT;
-            __syncthreads();
-            for (int e = tid; e < kn * 32; e += 256) {      // X slice: column cc, row kk (coalesced over kk)
-                const int kk = e % kn, cc = e / kn;
-                sX[kk * 33 + cc] = (c0 + cc < p) ? X[(size_t)(c0 + cc) * N + k0 + kk] : 0.0;
+// ---- CholeskyQR2 for panels of up to 32 columns ------------------------------------------------------------
+// orth(Y) in four small launches instead of the column-sequential CGS2 (which costs ~4 us per column):
+//     W = Y'Y (k_panel_tn)  ->  L L' = D^-1/2 W D^-1/2,  Q1 = Y D^-1/2 L^-T (k_chol_trsm)
+// twice.  The first factorisation checks its pivots (= squared distance of each unit-norm column from the span
+// of the previous ones): a pivot below 1e-5 means the panel is too ill-conditioned for this route; status[1] is
+// then set, every later CholeskyQR launch returns at once with Y untouched, and k_cgs2 (which otherwise returns
+// at once) does the work.  status[0] = sqrt(min pivot), the same "min ratio" CGS2 reports.
+constexpr int CQ_PMAX = 32;
+constexpr int CQ_LD = 33;
+
+// One wave: sL <- Cholesky factor (lower) of D^-1/2 W D^-1/2, sD <- D^-1/2.  Returns 0, or 1 when a pivot is
+// below `thresh` (or W is not finite / has a non-positive diagonal).  *minpiv_out = smallest pivot.
+__device__ __forceinline__ int chol_scaled_wave(const double* __restrict__ W, int p, double* sL, double* sD,
+                                                double thresh, double* minpiv_out) {
+    const int lane = threadIdx.x;
+    const bool act = lane < p;
+    for (int e = lane; e < p * p; e += 64) sL[(e % p) + (e / p) * CQ_LD] = W[e];
+    __syncthreads();
+    const double dii = act ? sL[lane + lane * CQ_LD] : 1.0;
+    const bool bad = !(dii > 0.0) || !(dii < 1.0e300);
+    const double sc = bad ? 0.0 : 1.0 / sqrt(dii);
+    if (act) sD[lane] = sc;
+    __syncthreads();
+    if (act)
+        for (int j = 0; j < p; ++j) sL[lane + j * CQ_LD] *= sc * sD[j];
+    int fail = __any(bad && act) ? 1 : 0;
+    __syncthreads();
+    double minpiv = 1.0;
+    for (int k = 0; k < p && !fail; ++k) {
+        double sv = 0.0;
+        if (act && lane >= k) {
+            double s0 = sL[lane + k * CQ_LD], s1 = 0.0;
+            int m = 0;
+            for (; m + 1 < k; m += 2) {
+                s0 -= sL[lane + m * CQ_LD] * sL[k + m * CQ_LD];
+                s1 -= sL[lane + (m + 1) * CQ_LD] * sL[k + (m + 1) * CQ_LD];
             }
-            for (int e = tid; e < kn * 8; e += 256) {       // 8 rows of G (contiguous: G symmetric)
-                const int kk = e % kn, rr = e / kn;
-                sG[rr * SK_KT + kk] = (r0 + rr < N) ? G[(int64_t)(r0 + rr) * ldG + k0 + kk] : 0.0;
-            }
-            __syncthreads();
-            const double* g = sG + ri * SK_KT;
-#pragma unroll 8
-            for (int kk = 0; kk < kn; ++kk) acc += g[kk] * sX[kk * 33 + c];
+            if (m < k) s0 -= sL[lane + m * CQ_LD] * sL[k + m * CQ_LD];
+            sv = s0 + s1;
         }
-        if (r0 + ri < N && c0 + c < p) Y[(size_t)(c0 + c) * N + r0 + ri] = acc;
+        const double piv = __shfl(sv, k, 64);
+        if (!(piv >= thresh)) {
+            fail = 1;
+            break;
+        }
+        minpiv = piv < minpiv ? piv : minpiv;
+        const double rl = rsqrt(piv);
+        __syncthreads();
+        if (act && lane >= k) sL[lane + k * CQ_LD] = sv * rl;   // diagonal: piv / sqrt(piv) = sqrt(piv)
+        __syncthreads();
+    }
+    *minpiv_out = minpiv;
+    return fail;
+}
+
+// Qout = Yin * D^-1/2 * L^-T with L L' = D^-1/2 W D^-1/2 (W = Yin'Yin from k_panel_tn): every workgroup (one
+// wave) factors the small matrix itself - same code, same bits - and then runs the forward substitution along
+// its 64 panel rows (one thread per row).
+__global__ __launch_bounds__(64) void k_chol_trsm(const double* __restrict__ Yin, const double* __restrict__ W,
+                                                  double* __restrict__ status, double* __restrict__ Qout, int N,
+                                                  int p, int pass) {
+    __shared__ double sL[CQ_PMAX * CQ_LD];
+    __shared__ double sD[CQ_PMAX], sI[CQ_PMAX];
+    if (pass == 2 && status[1] != 0.0) return;
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x * 64 + lane;
+    // the row of the panel first: the loads overlap the factorisation
+    double yv[CQ_PMAX];
+#pragma unroll
+    for (int j = 0; j < CQ_PMAX; ++j) yv[j] = (j < p && r < N) ? Yin[r + (size_t)j * N] : 0.0;
+    double minpiv;
+    const int fail = chol_scaled_wave(W, p, sL, sD, pass == 1 ? 1.0e-5 : 1.0e-300, &minpiv);
+    if (pass == 1 && blockIdx.x == 0 && lane == 0) {
+        status[0] = fail ? 0.0 : sqrt(minpiv);
+        status[1] = fail ? 1.0 : 0.0;
+    }
+    if (fail) return;
+    if (lane < p) sI[lane] = 1.0 / sL[lane + lane * CQ_LD];
+    __syncthreads();
+    if (r >= N) return;
+    double q[CQ_PMAX];
+#pragma unroll
+    for (int j = 0; j < CQ_PMAX; ++j) {
+        if (j < p) {
+            double sv = yv[j] * sD[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) sv -= q[i] * sL[j + i * CQ_LD];
+            q[j] = sv * sI[j];
+            Qout[r + (size_t)j * N] = q[j];
+        }
     }
 }
+
+// Y (N x p) = G * X for symmetric G.  Workgroup = 64 output rows x SK_JC panel columns, 8 waves; lane = output
+// row, so G[r, c] (= G[c, r]) is one coalesced 512-byte read per wave and c, the X slice (SK_KB rows x SK_JC
+// columns) is staged in LDS as [c][j] and read as broadcasts, and no cross-lane reduction is needed.  The waves
+// split the inner dimension; their partial sums meet in LDS and are added in a fixed order (deterministic).
+constexpr int SK_JC = 8;
+constexpr int SK_KB = 512;
+constexpr int SK_WAVES = 8;
+constexpr int SK_CW = SK_KB / SK_WAVES;   // 64 inner indices per wave and round
+__global__ __launch_bounds__(SK_WAVES * 64) void k_symm_skinny(const double* __restrict__ G, int64_t ldG,
+                                                               const double* __restrict__ X,
+                                                               double* __restrict__ Y, int N, int p) {
+    __shared__ __attribute__((aligned(16))) double sX[SK_KB * SK_JC];
+    __shared__ double sP[SK_WAVES * SK_JC * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = blockIdx.x * 64 + lane;
+    const int j0 = blockIdx.y * SK_JC;
+    const int nj = (p - j0 < SK_JC) ? p - j0 : SK_JC;
+    const bool rin = r < N;
+    double acc[SK_JC];
+#pragma unroll
+    for (int j = 0; j < SK_JC; ++j) acc[j] = 0.0;
+    for (int kb = 0; kb < N; kb += SK_KB) {
+        const int kn = (N - kb < SK_KB) ? N - kb : SK_KB;
+        __syncthreads();
+        for (int e = tid; e < SK_KB * SK_JC; e += SK_WAVES * 64) {
+            const int c = e % SK_KB, j = e / SK_KB;
+            sX[c * SK_JC + j] = (c < kn && j < nj) ? X[(size_t)(j0 + j) * N + kb + c] : 0.0;
+        }
+        __syncthreads();
+        const int cb = w * SK_CW;
+#pragma unroll 1
+        for (int q = 0; q < SK_CW; q += 16) {
+            double g[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = cb + q + i;
+                g[i] = (rin && c < kn) ? G[r + (int64_t)(kb + c) * ldG] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double* xs = sX + (cb + q + i) * SK_JC;
+#pragma unroll
+                for (int j = 0; j < SK_JC; ++j) acc[j] += g[i] * xs[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SK_JC; ++j) sP[(w * SK_JC + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    {
+        const int j = tid >> 6;   // SK_WAVES == SK_JC: thread (j, lane) owns one output
+        double sum = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < SK_WAVES; ++ww) sum += sP[(ww * SK_JC + j) * 64 + lane];
+        if (rin && j < nj) Y[(size_t)(j0 + j) * N + r] = sum;
+    }
+}
+static_assert(SK_WAVES == SK_JC, "final reduction maps one wave to one panel column");
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
 __global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
@@ -276,8 +396,8 @@ __global__ __launch_bounds__(256) void k_panel_rot2(const double* __restrict__ Q
 
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p) {
     if (p <= 0) return TLSQ_OK;
-    hipLaunchKernelGGL(k_symm_skinny, dim3((int)((N + 7) / 8)), dim3(256), 0, h->stream, G, ldG, X, Y, (int)N,
-                       (int)p);
+    hipLaunchKernelGGL(k_symm_skinny, dim3((int)((N + 63) / 64), (int)((p + SK_JC - 1) / SK_JC)),
+                       dim3(SK_WAVES * 64), 0, h->stream, G, ldG, X, Y, (int)N, (int)p);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -307,18 +427,37 @@ int subspace_max_block(int64_t N) {
     return 96;
 }
 
-int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) {
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged) {
     if (cgs2_fits_lds(N, p)) {
         const size_t lds = (size_t)(p * N + p + 16) * 8;
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev,
+                           only_if_flagged ? 1 : 0);
     } else {
         const size_t lds = (size_t)(p + 16) * 8;
-        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev,
+                           only_if_flagged ? 1 : 0);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
+}
+
+// Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, Lbuf: 32*32 + 32 doubles, status: 2 doubles.
+int launch_orth(Handle* h, double* Y, double* tmp, double* W, double* Lbuf, int64_t N, int64_t p, double* status_dev) {
+    static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
+    if (p > CQ_PMAX || no_cholqr) return launch_cgs2(h, Y, N, p, status_dev, false);
+    (void)Lbuf;
+    const dim3 rows((int)((N + 63) / 64));
+    for (int pass = 1; pass <= 2; ++pass) {
+        const double* in = pass == 1 ? Y : tmp;
+        double* out = pass == 1 ? tmp : Y;
+        TLSQ_TRY(launch_panel_tn(h, in, in, W, N, p));
+        hipLaunchKernelGGL(k_chol_trsm, rows, dim3(64), 0, h->stream, in, (const double*)W, status_dev, out, (int)N,
+                           (int)p, pass);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return launch_cgs2(h, Y, N, p, status_dev, true);
 }
 
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,

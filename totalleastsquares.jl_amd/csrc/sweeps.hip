@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
                                                        const T* __restrict__ E, T* __restrict__ Y,
                                                        T* __restrict__ R, T* __restrict__ En, T* __restrict__ Zn,
                                                        int64_t n, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                                       int nonnegE) {
+                                                       int nonnegE, double* __restrict__ sumsq) {
     using V = T __attribute__((ext_vector_type(VEC)));
     const int64_t nv = n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double ss = 0.0;   // ||R||_F^2 of this thread's elements (a bound for the convergence test, not a result)
     for (int64_t i = tid; i < nv; i += stride) {
         V d = reinterpret_cast<const V*>(D)[i];
         V a = reinterpret_cast<const V*>(A)[i];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
         for (int c = 0; c < VEC; ++c) {
             if (nonnegA) a[c] = pos_part(a[c]);          // A .= max.(A,0)            :217-219
             T z = (d[c] - a[c]) - e[c];                  // @. Z = D - A - E          :221
+            ss += (double)z * (double)z;
             r[c] = z;
             y[c] = y[c] + mu * z;                        // @. Y = Y + mu*Z           :222
             T t = inv_mu_n * y[c];                       // next iteration, mu_{k+1}  :188
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
             A[i] = a;
         }
         T z = (D[i] - a) - E[i];
+        ss += (double)z * (double)z;
         R[i] = z;
         T y = Y[i] + mu * z;
         Y[i] = y;
@@ -149,6 +152,15 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
         if (nonnegE) ee = pos_part(ee);
         En[i] = ee;
         Zn[i] = (D[i] - ee) + t;
+    }
+    if (sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+        __shared__ double sw[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) sw[w] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq, (sw[0] + sw[1]) + (sw[2] + sw[3]));
     }
 }
 
@@ -279,15 +291,15 @@ int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n
 
 template <typename T>
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
-                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE) {
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq) {
     if (n <= 0) return TLSQ_OK;
     constexpr int VEC = 16 / sizeof(T);
     if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R) && aligned16(En) && aligned16(Zn)) {
         hipLaunchKernelGGL((k_update_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, E,
-                           Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE);
+                           Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq);
     } else {
         hipLaunchKernelGGL((k_update_shrink<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, E, Y, R, En,
-                           Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE);
+                           Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
@@ -368,7 +380,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
     template int launch_update_shrink<T>(Handle*, const T*, T*, const T*, T*, T*, T*, T*, int64_t, T, int, T, T, \
-                                         int);                                                     \
+                                         int, double*);                                                     \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
