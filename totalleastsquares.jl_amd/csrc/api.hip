@@ -322,15 +322,36 @@ struct SubspaceState {
     int64_t fast = 0, full = 0, steps = 0;
 };
 
+// Stream-ordered upload of a small host array through the pinned ring: no host synchronisation, and `src` may be
+// freed or overwritten as soon as this returns.  A slot is only reused after the ring has wrapped, and wrapping
+// synchronises the stream first.
+static int upload_async(Handle* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return TLSQ_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > h->up_bytes) {   // never the case for the index lists this is meant for
+        TLSQ_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    if (h->up_off + need > h->up_bytes) {
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        h->up_off = 0;
+    }
+    char* stage = reinterpret_cast<char*>(h->up_ring) + h->up_off;
+    memcpy(stage, src, bytes);
+    h->up_off += need;
+    TLSQ_HIP(h, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    return TLSQ_OK;
+}
+
 // upload a column selection and gather X = V[:, sel]
 static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
     const int64_t r = (int64_t)sel.size();
     if (r == 0) return TLSQ_OK;
     void* aux;
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16 + 64, &aux));
-    TLSQ_HIP(h, hipMemcpyAsync(aux, sel.data(), (size_t)r * 4, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(upload_async(h, aux, sel.data(), (size_t)r * 4));
     TLSQ_TRY(launch_gather_scale(h, V, N, (const int32_t*)aux, nullptr, r, nullptr, X));
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }
 
@@ -363,7 +384,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     TLSQ_TRY(ws_get(h, WS_SGX, (size_t)N * p * 8, &GX));
     TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
     TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
-    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)std::max<int64_t>(p * p, 32 * 32 + 32) * 8, &HB));
+    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
     double* theta_dev = (double*)lam;
@@ -376,6 +397,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     int64_t svp = 0;
     bool conv = false;
     double prev_maxres = 0.0;
+    bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
         // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
@@ -387,12 +409,16 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         {
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
             const int q = cold ? 2 : 3;
+            // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
+            bool in_q = true;
             for (int t = 1; t < q && nt > 0; ++t) {
-                TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, nt));
-                TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
+                TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)(in_q ? Q : GQ), (double*)(in_q ? GQ : Q), N, nt));
+                in_q = !in_q;
             }
+            if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
         }
-        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, (double*)HB, N, p, stat_dev));
+        bool used_cholqr = false;
+        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr));
         // Rayleigh-Ritz: H = Q' (G Q)
         TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
@@ -404,9 +430,16 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
                                    N, p));
         TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)XN, N, p, theta_dev));
         TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)XN, theta_dev, N, p, res_dev));
-        TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 1) * 8, hipMemcpyDeviceToHost,
+        TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
                                    h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (used_cholqr && host[2 * p + 1] != 0.0) {
+            // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
+            force_cgs2 = true;
+            --step;
+            --st.steps;
+            continue;
+        }
         s.sigma.resize((size_t)p);
         double tmax = 0.0;
         bool finite = true;
@@ -430,10 +463,9 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
                 th_sorted[i] = host[s.order[i]];
                 sg_sorted[i] = s.sigma[s.order[i]];
             }
-            TLSQ_HIP(h, hipMemcpyAsync(aux, s.order.data(), (size_t)p * 4, hipMemcpyHostToDevice, h->stream));
+            TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
             TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
                                          (double*)X));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
             for (int64_t i = 0; i < p; ++i) {
                 host[i] = th_sorted[i];
                 host[p + i] = res_sorted[i];
@@ -491,13 +523,10 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         }
         int32_t* dsel = (int32_t*)aux;
         double* dth = (double*)((char*)aux + ((svp * 4 + 7) / 8) * 8);
-        TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)svp * 4, hipMemcpyHostToDevice, h->stream));
-        TLSQ_HIP(h, hipMemcpyAsync(dth, th.data(), (size_t)svp * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)svp * 4));
+        TLSQ_TRY(upload_async(h, dth, th.data(), (size_t)svp * 8));
         TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
-        TLSQ_TRY(gemm_f64(h, false, false, (const double*)Vs, N, (const double*)Vg, N, (double*)GD, N, N, N, svp,
-                          false));
-        TLSQ_TRY(launch_sub(h, G, (const double*)GD, (double*)GD, N * N));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        TLSQ_TRY(launch_deflate(h, G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
     } else {
         TLSQ_HIP(h, hipMemcpyAsync(GD, G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -528,15 +557,13 @@ static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
     int32_t* dsel = (int32_t*)aux;
     double* dg = (double*)((char*)aux + ((r * 4 + 7) / 8) * 8);
-    TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)r * 4, hipMemcpyHostToDevice, h->stream));
-    TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)r * 8, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)r * 4));
+    TLSQ_TRY(upload_async(h, dg, g.data(), (size_t)r * 8));
     TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
     // A (M x N) = T * Vs'
     TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, T1, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
-    // the async H2D above read from `sel`/`g` host vectors: make sure they are consumed before return
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }
 
@@ -807,8 +834,8 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         if (fuse && !want_exact_cost && !hook_opnorm) {
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-            sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 320);
-            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 8, h->stream));
+            sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);   // 64 partial sums
+            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));
         }
         if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
@@ -823,10 +850,11 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         double rn = 0.0;
         bool cost_skipped = false;
         if (sumsq_dev) {
-            double fro2 = 0.0;
-            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 8, hipMemcpyDeviceToHost, h->stream));
+            double fro2 = 0.0, part[64];
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            memcpy(&fro2, h->pinned, 8);
+            memcpy(part, h->pinned, 512);
+            for (double v : part) fro2 += v;
             TLSQ_TRY(comm_allreduce_host_scalar(h, &fro2, ncclSum));
             const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
             if (lower > 2.0 * ro.tol) {
@@ -1262,6 +1290,12 @@ int tlsq_create(int device_id, tlsq_handle* out) {
         delete h;
         return TLSQ_ERR_OOM;
     }
+    h->up_bytes = 1 << 18;
+    if (hipHostMalloc(&h->up_ring, h->up_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipHostFree(h->pinned);
+        delete h;
+        return TLSQ_ERR_OOM;
+    }
     *out = h;
     return TLSQ_OK;
 }
@@ -1274,6 +1308,7 @@ int tlsq_destroy(tlsq_handle h) {
     for (auto& b : h->ws)
         if (b.p) (void)hipFree(b.p);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->up_ring) (void)hipHostFree(h->up_ring);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);

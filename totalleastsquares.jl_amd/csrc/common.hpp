@@ -33,6 +33,10 @@ struct Handle {
     // pinned host scratch for small readbacks
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // pinned staging ring for small host->device uploads (index lists, scale factors): the copy is asynchronous
+    // and the host may reuse its own buffer at once; see upload_async() in api.hip
+    void* up_ring = nullptr;
+    size_t up_bytes = 0, up_off = 0;
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
     // warm start of the full Jacobi solver: WS_V holds the eigenvectors of the previous full decomposition
@@ -86,7 +90,7 @@ template <typename T>
 int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu, int nonnegA);
 // fused update(k) + shrink(k+1): R_k, Y_k, E_{k+1} (En), Z_{k+1} (Zn) in one pass
 template <typename T>
-// sumsq (optional, device): += ||R_k||_F^2 (atomic adds: used only as a bound, never as a result)
+// sumsq (optional, device, 64 doubles): their sum += ||R_k||_F^2 (atomic adds: a bound, never a result)
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
                          int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq = nullptr);
 // Y = D / s  (src/robustPCA.jl:181), contiguous n
@@ -156,11 +160,17 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged = false);
-int launch_orth(Handle* h, double* Y, double* tmp, double* W, double* Lbuf, int64_t N, int64_t p, double* status_dev);
+int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
+                bool allow_cholqr, bool* used_cholqr);
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
 int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
+template <typename TA>
+int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64_t ldx, double* Y, int64_t ldy,
+                     int64_t R, int64_t K, int64_t p);
+int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
+                   int64_t r);
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
 int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,

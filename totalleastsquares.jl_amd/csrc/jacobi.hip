@@ -252,10 +252,11 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     __shared__ unsigned int s_rot;
     const int LD = 65;
     const int tid = threadIdx.x;
-    const int hw = tid >> 5, hl = tid & 31;   // half-wave index (0..31), lane within it
+    const int hw = tid >> 5, hl = tid & 31;   // half-wave index, lane within it
+    const int nthr = blockDim.x, nhw = nthr >> 5;   // the launcher sizes the block to the number of pairs
     // init + ||G||_F^2
     double fro = 0.0;
-    for (int e = tid; e < N * N; e += 1024) {
+    for (int e = tid; e < N * N; e += nthr) {
         const int r = e % N, c = e / N;
         const double v = G[r + (int64_t)c * ldG];
         sB[c * LD + r] = v;
@@ -267,8 +268,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     if (tid == 0) s_rot = 0;
     __syncthreads();
     double fsum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) fsum += red[k];
+    for (int k = 0; k < (nthr >> 6); ++k) fsum += red[k];
     const double floor2 = nfloor * nfloor * fsum;
     const int nslot = (N + 1) & ~1;          // even number of tournament players
     const int npair = nslot / 2;             // <= 32
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     for (; sweep < max_sweeps; ++sweep) {
         unsigned int my_rot = 0;
         // squared column norms, refreshed once per sweep and updated by the rotation formulas in between
-        for (int c = hw; c < N; c += 32) {
+        for (int c = hw; c < N; c += nhw) {
             const double* x = sB + c * LD;
             const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0;
             const double ssum = half_allsum(v0 * v0 + v1 * v1);
@@ -351,13 +351,13 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
         }
     }
     __syncthreads();
-    for (int e = tid; e < N * N; e += 1024) {
+    for (int e = tid; e < N * N; e += nthr) {
         const int r = e % N, c = e / N;
         Bout[e] = sB[c * LD + r];
         if (WANT_V) Vout[e] = sV[c * LD + r];
     }
     // lam[c] = ||B[:,c]||: half-wave per column
-    for (int c = hw; c < N; c += 32) {
+    for (int c = hw; c < N; c += nhw) {
         const double* x = sB + c * LD;
         const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0;
         const double ssum = half_allsum(v0 * v0 + v1 * v1);
@@ -594,11 +594,14 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         double tol0 = 2.0 * eps0 * sqrt((double)N);
         if (tol0 < 4.0 * eps0) tol0 = 4.0 * eps0;
         const int max_sweeps0 = 40;
+        // one half-wave per column pair; whole waves only
+        const int npair0 = (int)((N + 1) / 2);
+        const int nthr0 = ((npair0 * 32 + 63) / 64) * 64;
         if (want_v)
-            hipLaunchKernelGGL(k_jacobi_small<true>, dim3(1), dim3(1024), 0, h->stream, G, ldG, B, V, lam_dev,
+            hipLaunchKernelGGL(k_jacobi_small<true>, dim3(1), dim3(nthr0), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
         else
-            hipLaunchKernelGGL(k_jacobi_small<false>, dim3(1), dim3(1024), 0, h->stream, G, ldG, B, V, lam_dev,
+            hipLaunchKernelGGL(k_jacobi_small<false>, dim3(1), dim3(nthr0), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
         TLSQ_HIP(h, hipGetLastError());
         if (async_small) return TLSQ_OK;   // the caller validates the result itself (residuals)

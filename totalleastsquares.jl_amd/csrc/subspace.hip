@@ -211,8 +211,9 @@ int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
 //     W = Y'Y (k_panel_tn)  ->  L L' = D^-1/2 W D^-1/2,  Q1 = Y D^-1/2 L^-T (k_chol_trsm)
 // twice.  The first factorisation checks its pivots (= squared distance of each unit-norm column from the span
 // of the previous ones): a pivot below 1e-5 means the panel is too ill-conditioned for this route; status[1] is
-// then set, every later CholeskyQR launch returns at once with Y untouched, and k_cgs2 (which otherwise returns
-// at once) does the work.  status[0] = sqrt(min pivot), the same "min ratio" CGS2 reports.
+// then set, every later CholeskyQR launch returns at once with Y untouched, and the host (which reads the status
+// with the Ritz residuals anyway) repeats the step with k_cgs2.  status[0] = sqrt(min pivot), the same "min
+// ratio" CGS2 reports.
 constexpr int CQ_PMAX = 32;
 constexpr int CQ_LD = 33;
 
@@ -237,13 +238,21 @@ __device__ __forceinline__ int chol_scaled_wave(const double* __restrict__ W, in
     for (int k = 0; k < p && !fail; ++k) {
         double sv = 0.0;
         if (act && lane >= k) {
-            double s0 = sL[lane + k * CQ_LD], s1 = 0.0;
+            double s0 = sL[lane + k * CQ_LD], s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int m = 0;
-            for (; m + 1 < k; m += 2) {
-                s0 -= sL[lane + m * CQ_LD] * sL[k + m * CQ_LD];
-                s1 -= sL[lane + (m + 1) * CQ_LD] * sL[k + (m + 1) * CQ_LD];
+            for (; m + 3 < k; m += 4) {
+                const double a0 = sL[lane + m * CQ_LD], b0 = sL[k + m * CQ_LD];
+                const double a1 = sL[lane + (m + 1) * CQ_LD], b1 = sL[k + (m + 1) * CQ_LD];
+                const double a2 = sL[lane + (m + 2) * CQ_LD], b2 = sL[k + (m + 2) * CQ_LD];
+                const double a3 = sL[lane + (m + 3) * CQ_LD], b3 = sL[k + (m + 3) * CQ_LD];
+                s0 -= a0 * b0;
+                s1 -= a1 * b1;
+                s2 -= a2 * b2;
+                s3 -= a3 * b3;
             }
-            if (m < k) s0 -= sL[lane + m * CQ_LD] * sL[k + m * CQ_LD];
+            for (; m < k; ++m) s0 -= sL[lane + m * CQ_LD] * sL[k + m * CQ_LD];
+            s0 += s2;
+            s1 += s3;
             sv = s0 + s1;
         }
         const double piv = __shfl(sv, k, 64);
@@ -299,64 +308,97 @@ __global__ __launch_bounds__(64) void k_chol_trsm(const double* __restrict__ Yin
     }
 }
 
-// Y (N x p) = G * X for symmetric G.  Workgroup = 64 output rows x SK_JC panel columns, 8 waves; lane = output
-// row, so G[r, c] (= G[c, r]) is one coalesced 512-byte read per wave and c, the X slice (SK_KB rows x SK_JC
-// columns) is staged in LDS as [c][j] and read as broadcasts, and no cross-lane reduction is needed.  The waves
-// split the inner dimension; their partial sums meet in LDS and are added in a fixed order (deterministic).
-constexpr int SK_JC = 8;
+// Y (R x p) = A (R x K) * X (K x p), p small: the tall-skinny product behind Y = G X (G symmetric, R = K = N) and
+// behind T = Z V_svp (R = M rows of the data panel).  Workgroup = 64 rows x JC panel columns, 8 waves; lane = row,
+// so A[r, c] is one coalesced read per wave and c, the X slice (SK_KB rows x JC columns) is staged in LDS as
+// [c][j] and read as broadcasts, and no cross-lane reduction is needed.  The waves split the inner dimension;
+// their partial sums meet in LDS and are added in a fixed order (deterministic).  A is read exactly once when
+// p <= JC.
 constexpr int SK_KB = 512;
 constexpr int SK_WAVES = 8;
 constexpr int SK_CW = SK_KB / SK_WAVES;   // 64 inner indices per wave and round
-__global__ __launch_bounds__(SK_WAVES * 64) void k_symm_skinny(const double* __restrict__ G, int64_t ldG,
-                                                               const double* __restrict__ X,
-                                                               double* __restrict__ Y, int N, int p) {
-    __shared__ __attribute__((aligned(16))) double sX[SK_KB * SK_JC];
-    __shared__ double sP[SK_WAVES * SK_JC * 64];
+template <typename TA, int JC>
+__global__ __launch_bounds__(SK_WAVES * 64) void k_skinny_mm(const TA* __restrict__ A, int64_t lda,
+                                                             const double* __restrict__ X, int64_t ldx,
+                                                             double* __restrict__ Y, int64_t ldy, int64_t R,
+                                                             int K, int p) {
+    extern __shared__ __attribute__((aligned(16))) double sk_sm[];   // max(SK_KB, SK_WAVES * 64) * JC doubles
+    double* sX = sk_sm;
+    double* sP = sk_sm;   // reused after the last round
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = blockIdx.x * 64 + lane;
-    const int j0 = blockIdx.y * SK_JC;
-    const int nj = (p - j0 < SK_JC) ? p - j0 : SK_JC;
-    const bool rin = r < N;
-    double acc[SK_JC];
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    const int j0 = blockIdx.y * JC;
+    const int nj = (p - j0 < JC) ? p - j0 : JC;
+    const bool rin = r < R;
+    double acc[JC];
 #pragma unroll
-    for (int j = 0; j < SK_JC; ++j) acc[j] = 0.0;
-    for (int kb = 0; kb < N; kb += SK_KB) {
-        const int kn = (N - kb < SK_KB) ? N - kb : SK_KB;
+    for (int j = 0; j < JC; ++j) acc[j] = 0.0;
+    for (int kb = 0; kb < K; kb += SK_KB) {
+        const int kn = (K - kb < SK_KB) ? K - kb : SK_KB;
         __syncthreads();
-        for (int e = tid; e < SK_KB * SK_JC; e += SK_WAVES * 64) {
+        for (int e = tid; e < SK_KB * JC; e += SK_WAVES * 64) {
             const int c = e % SK_KB, j = e / SK_KB;
-            sX[c * SK_JC + j] = (c < kn && j < nj) ? X[(size_t)(j0 + j) * N + kb + c] : 0.0;
+            sX[c * JC + j] = (c < kn && j < nj) ? X[(size_t)(j0 + j) * ldx + kb + c] : 0.0;
         }
         __syncthreads();
         const int cb = w * SK_CW;
+        const TA* Ar = A + r + (int64_t)(kb + cb) * lda;
+        // 16 reads of A in flight per lane; the next 16 are issued before the current ones are consumed.  The
+        // scheduling barriers keep the compiler from hoisting every LDS read of the round (=> spills).
+        TA gc[16], gn[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gc[i] = (rin && cb + i < kn) ? Ar[(int64_t)i * lda] : (TA)0;
 #pragma unroll 1
-        for (int q = 0; q < SK_CW; q += 16) {
-            double g[16];
+        for (int q = 0; q < SK_CW / 16; ++q) {
+            if (q + 1 < SK_CW / 16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = cb + q + i;
-                g[i] = (rin && c < kn) ? G[r + (int64_t)(kb + c) * ldG] : 0.0;
+                for (int i = 0; i < 16; ++i) {
+                    const int c = cb + (q + 1) * 16 + i;
+                    gn[i] = (rin && c < kn) ? Ar[(int64_t)((q + 1) * 16 + i) * lda] : (TA)0;
+                }
+            }
+            constexpr int IB = 32 / JC;
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += IB) {
+#pragma unroll
+                for (int i = i0; i < i0 + IB; ++i) {
+                    const double* xs = sX + (cb + q * 16 + i) * JC;
+                    const double gv = (double)gc[i];
+#pragma unroll
+                    for (int j = 0; j < JC; ++j) acc[j] += gv * xs[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double* xs = sX + (cb + q + i) * SK_JC;
-#pragma unroll
-                for (int j = 0; j < SK_JC; ++j) acc[j] += g[i] * xs[j];
-            }
+            for (int i = 0; i < 16; ++i) gc[i] = gn[i];
         }
     }
-#pragma unroll
-    for (int j = 0; j < SK_JC; ++j) sP[(w * SK_JC + j) * 64 + lane] = acc[j];
     __syncthreads();
-    {
-        const int j = tid >> 6;   // SK_WAVES == SK_JC: thread (j, lane) owns one output
+#pragma unroll
+    for (int j = 0; j < JC; ++j) sP[(w * JC + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    for (int o = tid; o < JC * 64; o += SK_WAVES * 64) {
+        const int j = o >> 6, l = o & 63;
         double sum = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < SK_WAVES; ++ww) sum += sP[(ww * SK_JC + j) * 64 + lane];
-        if (rin && j < nj) Y[(size_t)(j0 + j) * N + r] = sum;
+        for (int ww = 0; ww < SK_WAVES; ++ww) sum += sP[(ww * JC + j) * 64 + l];
+        const int64_t rr = (int64_t)blockIdx.x * 64 + l;
+        if (rr < R && j < nj) Y[(size_t)(j0 + j) * ldy + rr] = sum;
     }
 }
-static_assert(SK_WAVES == SK_JC, "final reduction maps one wave to one panel column");
+
+// GD = G - Vs * Vg'  (N x N, rank-r deflation for the count certificate; Vs, Vg: N x r, ld N)
+__global__ __launch_bounds__(256) void k_deflate(const double* __restrict__ G, int64_t ldG,
+                                                 const double* __restrict__ Vs, const double* __restrict__ Vg,
+                                                 double* __restrict__ GD, int N, int r) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        double sv = G[i + (int64_t)j * ldG];
+        for (int k = 0; k < r; ++k) sv -= Vs[i + (size_t)k * N] * Vg[j + (size_t)k * N];
+        GD[e] = sv;
+    }
+}
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
 __global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
@@ -394,10 +436,51 @@ __global__ __launch_bounds__(256) void k_panel_rot2(const double* __restrict__ Q
     }
 }
 
+template <typename TA>
+int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64_t ldx, double* Y, int64_t ldy,
+                     int64_t R, int64_t K, int64_t p) {
+    if (p <= 0 || R <= 0) return TLSQ_OK;
+    const int64_t gx = (R + 63) / 64;
+    if (p <= 8) {
+        const size_t lds = (size_t)SK_KB * 8 * 8;
+        hipLaunchKernelGGL((k_skinny_mm<TA, 8>), dim3((unsigned)gx, 1), dim3(SK_WAVES * 64), lds, h->stream, A, lda, X,
+                           ldx, Y, ldy, R, (int)K, (int)p);
+    } else {
+        const size_t lds = (size_t)SK_KB * 16 * 8;
+        static bool attr_done = false;
+        if (!attr_done) {
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_mm<double, 16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_mm<float, 16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((k_skinny_mm<TA, 16>), dim3((unsigned)gx, (unsigned)((p + 15) / 16)), dim3(SK_WAVES * 64), lds,
+                           h->stream, A, lda, X, ldx, Y, ldy, R, (int)K, (int)p);
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template int launch_skinny_mm<double>(Handle*, const double*, int64_t, const double*, int64_t, double*, int64_t,
+                                      int64_t, int64_t, int64_t);
+template int launch_skinny_mm<float>(Handle*, const float*, int64_t, const double*, int64_t, double*, int64_t, int64_t,
+                                     int64_t, int64_t);
+
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p) {
+    // symmetric G: column c of G doubles as row c, so the generic kernel's coalesced A[r, c] reads apply as is.
+    // 8 columns per workgroup keeps the grid wide for these latency-bound N x N products.
     if (p <= 0) return TLSQ_OK;
-    hipLaunchKernelGGL(k_symm_skinny, dim3((int)((N + 63) / 64), (int)((p + SK_JC - 1) / SK_JC)),
-                       dim3(SK_WAVES * 64), 0, h->stream, G, ldG, X, Y, (int)N, (int)p);
+    hipLaunchKernelGGL((k_skinny_mm<double, 8>), dim3((unsigned)((N + 63) / 64), (unsigned)((p + 7) / 8)),
+                       dim3(SK_WAVES * 64), (size_t)SK_KB * 8 * 8, h->stream, G, ldG, X, N, Y, N, N, (int)N, (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
+                   int64_t r) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_deflate, dim3((int)g), dim3(256), 0, h->stream, G, ldG, Vs, Vg, GD, (int)N, (int)r);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -443,11 +526,12 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, 
     return TLSQ_OK;
 }
 
-// Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, Lbuf: 32*32 + 32 doubles, status: 2 doubles.
-int launch_orth(Handle* h, double* Y, double* tmp, double* W, double* Lbuf, int64_t N, int64_t p, double* status_dev) {
+// Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, status: 2 doubles.
+int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
+                bool allow_cholqr, bool* used_cholqr) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
-    if (p > CQ_PMAX || no_cholqr) return launch_cgs2(h, Y, N, p, status_dev, false);
-    (void)Lbuf;
+    *used_cholqr = allow_cholqr && p <= CQ_PMAX && !no_cholqr;
+    if (!*used_cholqr) return launch_cgs2(h, Y, N, p, status_dev, false);
     const dim3 rows((int)((N + 63) / 64));
     for (int pass = 1; pass <= 2; ++pass) {
         const double* in = pass == 1 ? Y : tmp;
@@ -457,7 +541,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, double* Lbuf, int6
                            (int)p, pass);
     }
     TLSQ_HIP(h, hipGetLastError());
-    return launch_cgs2(h, Y, N, p, status_dev, true);
+    return TLSQ_OK;   // status[1] != 0: Y is untouched and the caller has to redo the step with CGS2
 }
 
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,

@@ -111,11 +111,25 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double ss = 0.0;   // ||R||_F^2 of this thread's elements (a bound for the convergence test, not a result)
+#ifndef TLSQ_SWEEP_UNROLL
+#define TLSQ_SWEEP_UNROLL 1
+#endif
+#ifndef TLSQ_SWEEP_NT
+#define TLSQ_SWEEP_NT 1   // streaming panels: nothing is re-read before ~0.6 GB of other traffic
+#endif
+#if TLSQ_SWEEP_NT
+#define SW_LD(p, i) __builtin_nontemporal_load(reinterpret_cast<const V*>(p) + (i))
+#define SW_ST(p, i, v) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p) + (i))
+#else
+#define SW_LD(p, i) (reinterpret_cast<const V*>(p)[i])
+#define SW_ST(p, i, v) (reinterpret_cast<V*>(p)[i] = (v))
+#endif
+#pragma unroll TLSQ_SWEEP_UNROLL
     for (int64_t i = tid; i < nv; i += stride) {
-        V d = reinterpret_cast<const V*>(D)[i];
-        V a = reinterpret_cast<const V*>(A)[i];
-        V e = reinterpret_cast<const V*>(E)[i];
-        V y = reinterpret_cast<const V*>(Y)[i];
+        V d = SW_LD(D, i);
+        V a = SW_LD(A, i);
+        V e = SW_LD(E, i);
+        V y = SW_LD(Y, i);
         V r, en, zn;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
@@ -130,12 +144,14 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
             en[c] = ee;
             zn[c] = (d[c] - ee) + t;                     //                           :192
         }
-        if (nonnegA) reinterpret_cast<V*>(A)[i] = a;
-        reinterpret_cast<V*>(R)[i] = r;
-        reinterpret_cast<V*>(Y)[i] = y;
-        reinterpret_cast<V*>(En)[i] = en;
-        reinterpret_cast<V*>(Zn)[i] = zn;
+        if (nonnegA) SW_ST(A, i, a);
+        SW_ST(R, i, r);
+        SW_ST(Y, i, y);
+        SW_ST(En, i, en);
+        SW_ST(Zn, i, zn);
     }
+#undef SW_LD
+#undef SW_ST
     for (int64_t i = nv * VEC + tid; i < n; i += stride) {
         T a = A[i];
         if (nonnegA) {
@@ -160,7 +176,8 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (lane == 0) sw[w] = ss;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sumsq, (sw[0] + sw[1]) + (sw[2] + sw[3]));
+        // 64 accumulators (the host adds them up): one address would serialise tens of thousands of atomics
+        if (threadIdx.x == 0) atomicAdd(sumsq + (blockIdx.x & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
     }
 }
 
@@ -249,9 +266,14 @@ __global__ __launch_bounds__(256) void k_convert(const TS* __restrict__ src, TD*
 }
 
 static inline int grid_for(int64_t work_items) {
+    static const int64_t cap = [] {
+        const char* e = getenv("TLSQ_SWEEP_GRID");   // tuning knob (tools/kbench.py)
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 ? v : 2048);          // 256 CUs x 8 blocks, grid-stride the rest
+    }();
     int64_t g = (work_items + 255) / 256;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    if (g > cap) g = cap;
     return (int)g;
 }
 
