@@ -8,6 +8,7 @@ iteration count and per-iteration svp;  the reference's 5x5 tab
 """
 import ctypes as C
 import math
+import warnings
 
 import numpy as np
 import pytest
@@ -337,6 +338,33 @@ def test_rpca_hankel_flag_exact_hankel(eng):                         # test/runt
     H = O.hankel(y, 50)
     A2, E2, *_ = eng.rpca(H, nukeA=False, hankel=True)
     assert tlsq_amd.ishankel(A2) and tlsq_amd.ishankel(E2)
+
+
+
+def test_rpca_large_mode_vs_oracle_and_planted(eng):
+    """min(M,N) > 2048: no dense eigensolver applies, every SVD step comes from the certified subspace iteration
+    with a growing block.  First iterations against the oracle, the converged run against the planted matrix."""
+    from oracle import rpca_oracle as O
+    M, N, r = 2600, 2080, 6
+    D, A0, _ = O.synth_lowrank_sparse(M, N, r, seed=11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                        # both sides stop at iters=6 with the reference's @warn
+        A, E, s, sv, rep = eng.rpca(D, iters=6, return_report=True, want_U=False)
+        Ao, Eo, so, svo, io = O.rpca(D, iters=6)
+    assert rep.svp_hist == io.svp_hist and sv == svo
+    assert rep.eig_full == 0                                   # nothing fell back to a dense solver
+    assert relerr(A, Ao) < 1e-9 and relerr(E, Eo) < 1e-9
+    np.testing.assert_allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
+    # leading singular values of the last Z are returned, the unresolved rest is NaN
+    k = int(np.isfinite(s.S).sum())
+    assert sv <= k < N
+    np.testing.assert_allclose(s.S[:sv], so[1][:sv], rtol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                         # must converge: no max-iteration warning
+        A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False)
+    assert rep.converged and sv == r and rep.eig_full == 0
+    assert relerr(A, A0) < 1e-6
+    assert relerr(A + E, D) < 1e-7
 
 
 def test_rpca_unsupported_paths_fail_loudly(eng):

@@ -157,6 +157,11 @@ static double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Largest Gram dimension the LDS-resident full Jacobi solvers handle.  Above it ("large mode") rpca relies on the
+// certified subspace iteration alone; see rpca_core.
+static constexpr int64_t kFullEigMaxN = 2048;
+static constexpr int64_t kGramMaxN = 16384;
+
 // sqrt(lambda_max) of the Gram already sitting in G (N x N, ld N): Lanczos to the requested relative residual
 // bound, exact Jacobi eigenvalues as the fallback.  uses WS_B, WS_LAM.
 static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
@@ -165,7 +170,7 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
     int steps = 0;
     int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
     if (st < 0) return st;
-    if (st == 0) {
+    if (st == 0 || N > kFullEigMaxN) {   // large mode: no dense fallback; the Lanczos value after 1000 steps stands
         *out = std::sqrt(lmax);
         return TLSQ_OK;
     }
@@ -320,6 +325,11 @@ struct SubspaceState {
     int64_t hook_rank = 0;
     uint64_t hook_seed = 0;
     int64_t fast = 0, full = 0, steps = 0;
+    // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
+    enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4 };
+    int fail = FAIL_NONE;
+    int64_t cold_p = 18;   // block size of a cold start
+    int extra_steps = 0;   // added to the step budget (retries in large mode)
 };
 
 // Stream-ordered upload of a small host array through the pinned ring: no host synchronisation, and `src` may be
@@ -370,13 +380,18 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         // no block yet (first ALM iteration): start from a pseudo-random block of 10 + 8 columns — 10 is the
         // reference's initial rank guess `sv = 10` (src/robustPCA.jl:184)
         if (!st.allow_cold) return TLSQ_OK;
-        st.p = std::min<int64_t>(std::min<int64_t>(18, subspace_max_block(N)), N);
+        st.p = std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(18, st.cold_p), subspace_max_block(N)), N);
         if (st.p < 3) return TLSQ_OK;
     }
     if (st.p < 3) return TLSQ_OK;
+    st.fail = SubspaceState::FAIL_NONE;
     const int64_t p = st.p;
     void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
-    TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * p * 8, &X));
+    {   // the block lives in WS_SX across calls and may grow: reserve the largest block once (ws_get reallocates)
+        const int64_t pcap = std::max<int64_t>(p, std::min<int64_t>(subspace_max_block(N), N));
+        TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * pcap * 8, &X));
+        TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * pcap * 8, &XN));
+    }
     if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, hook ? (unsigned int)(st.hook_seed * 2654435761ull + 77u) : 0x9E3779B9u));
     TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
     TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
@@ -392,7 +407,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     double* stat_dev = res_dev + p;
     double* lamH_dev = stat_dev + 8;
     std::vector<double> host((size_t)2 * p + 8);
-    const int max_steps = hook ? 2 : (cold ? 30 : 10);
+    const int max_steps = hook ? 2 : (cold ? 30 : 10) + st.extra_steps;
     const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
     int64_t svp = 0;
     bool conv = false;
@@ -451,6 +466,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         }
         if (!finite) {
             st.valid = false;
+            st.fail = SubspaceState::FAIL_NUMERIC;
             break;
         }
         s.ncols = p;
@@ -482,7 +498,10 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
             *ok = true;
             return TLSQ_OK;
         }
-        if (svp > p - 2) break;  // the block may not contain every sigma >= 1/mu: let the full solver decide
+        if (svp > p - 2) {  // the block may not contain every sigma >= 1/mu: full solver, or a larger block
+            st.fail = SubspaceState::FAIL_SMALL;
+            break;
+        }
         bool good = true;
         double maxres = 0.0;
         for (int64_t i = 0; i < svp; ++i) {
@@ -508,7 +527,10 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
         prev_maxres = maxres;
     }
-    if (!conv) return TLSQ_OK;
+    if (!conv) {
+        if (st.fail == SubspaceState::FAIL_NONE) st.fail = SubspaceState::FAIL_NOCONV;
+        return TLSQ_OK;
+    }
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
     TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
     if (svp > 0) {
@@ -534,7 +556,10 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     int steps = 0;
     int lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
     if (lst < 0) return lst;
-    if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;  // ambiguous: full solver decides
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) {  // ambiguous: full solver decides (or a larger block)
+        st.fail = SubspaceState::FAIL_CERT;
+        return TLSQ_OK;
+    }
     *V_out = (double*)X;
     *ok = true;
     return TLSQ_OK;
@@ -571,7 +596,8 @@ static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
 // Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
 static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
                        SubspaceState& sub) {
-    const int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(8, svp / 4));
+    int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(8, svp / 4));
+    if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
     if (want > pmax || want < 3) {
         sub.valid = false;
         return TLSQ_OK;
@@ -741,7 +767,12 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     SubspaceState sub;
     const int64_t pmax = subspace_max_block(N);
     const char* force_full = getenv("TLSQ_FULL_EIG");
-    const bool use_subspace = !hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24;
+    // Large mode (N > 2048): the full Jacobi solvers do not apply (their column blocks live in LDS); every SVD step
+    // has to be served by the certified subspace iteration, whose block is enlarged on demand.  Ranks beyond
+    // the largest block (subspace_max_block) are reported as TLSQ_ERR_UNSUPPORTED, and the two-level refinement
+    // of very late iterations is not available.
+    const bool large = N > kFullEigMaxN;
+    const bool use_subspace = large || (!hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24);
     bool v_is_full = false, prev_full = false;
     double sigma_top_prev = 0.0;
     int64_t n_precise = 0;
@@ -769,7 +800,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark();
         // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
-        const bool precise = !hook_svd && sigma_top_prev > 0.0 &&
+        const bool precise = !large && !hook_svd && sigma_top_prev > 0.0 &&
                              inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
@@ -791,6 +822,35 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         } else if (use_subspace) {
             TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
         }
+        if (!fast_ok && large && !(hook_svd && k >= 2)) {
+            // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry
+            for (int attempt = 0; !fast_ok && attempt < 10; ++attempt) {
+                const int why = sub.fail;
+                const bool grow = why == SubspaceState::FAIL_SMALL || why == SubspaceState::FAIL_CERT ||
+                                  why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
+                const int64_t cap = std::min<int64_t>(pmax, N);
+                if (grow) {
+                    const int64_t newp = std::min<int64_t>(cap, sub.p + std::max<int64_t>(16, sub.p / 2));
+                    if (newp == sub.p && why == SubspaceState::FAIL_SMALL) break;   // the rank exceeds the largest block
+                    if (sub.valid && newp > sub.p) {
+                        double* X = (double*)h->ws[WS_SX].p;
+                        TLSQ_TRY(launch_fill_hash(h, X + (size_t)N * sub.p, N * (newp - sub.p),
+                                                  0xC2B2AE35u + (unsigned int)(k * 131 + attempt)));
+                        sub.p = newp;
+                    } else {
+                        sub.cold_p = newp;
+                    }
+                }
+                sub.extra_steps = 10;
+                TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+                sub.extra_steps = 0;
+            }
+        }
+        if (!fast_ok && large)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED,
+                           "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
+                           "(block of %lld columns, reason %d): rank too large for this release",
+                           (long long)N, (long long)kFullEigMaxN, (long long)k, (long long)sub.p, sub.fail);
         if (!fast_ok) {
             TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, prev_full));
             if (hook_svd && k >= 2) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
@@ -920,6 +980,43 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
 
     // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
     const int64_t d = std::min(ro.m_global, N);
+    if ((S_host || Vt_host || U_dev) && V && large) {
+        // large mode: only the Ritz triplets of the last block are available; the rest of S is NaN and the
+        // corresponding vectors are zero (documented in include/tlsq.h)
+        const int64_t have = std::min<int64_t>(s.ncols, d);
+        if (S_host)
+            for (int64_t p = 0; p < d; ++p)
+                S_host[p] = p < have ? s.sigma[s.order[p]] : std::numeric_limits<double>::quiet_NaN();
+        if (Vt_host) {
+            std::vector<double> hv((size_t)N * have);
+            TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * have * 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            for (int64_t p = 0; p < d; ++p)
+                for (int64_t j = 0; j < N; ++j)
+                    Vt_host[p + j * ldVt] = p < have ? hv[(size_t)s.order[p] * N + j] : 0.0;
+        }
+        if (U_dev) {
+            TLSQ_HIP(h, hipMemsetAsync(U_dev, 0, (size_t)M * d * sizeof(T), h->stream));
+            std::vector<int32_t> sel((size_t)have);
+            std::vector<double> g((size_t)have);
+            for (int64_t p = 0; p < have; ++p) {
+                sel[p] = s.order[p];
+                const double sg = s.sigma[sel[p]];
+                g[p] = sg > 0.0 ? 1.0 / sg : 0.0;
+            }
+            void *Vg, *aux;
+            TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * have * 8, &Vg));
+            TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)have * 16 + 64, &aux));
+            int32_t* dsel = (int32_t*)aux;
+            double* dg = (double*)((char*)aux + ((have * 4 + 7) / 8) * 8);
+            TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)have * 4));
+            TLSQ_TRY(upload_async(h, dg, g.data(), (size_t)have * 8));
+            TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, have, (double*)Vg, nullptr));
+            TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, M, U_dev, Prec<T>::f32, M, have, M, N, false));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        return converged ? TLSQ_OK : TLSQ_MAXITER;
+    }
     if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
         // the last iteration used a subspace path: the caller wants the complete SVD of the last Z
         double* G = nullptr;
@@ -1123,10 +1220,9 @@ static int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t l
     // and has no structurally-zero eigenvalues (accuracy of the Gram route).
     const bool transposed = (M < N) && ro.m_global == M && !h->comm;
     // the small-matrix solvers of this release keep their panels in LDS: the Gram dimension is limited
-    if ((transposed ? M : N) > 2048)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED,
-                       "rpca: min(M,N) = %lld exceeds 2048, the largest Gram dimension the LDS-resident eigensolvers "
-                       "of this release handle", (long long)(transposed ? M : N));
+    if ((transposed ? M : N) > kGramMaxN)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: min(M,N) = %lld exceeds %lld, the largest Gram dimension of this "
+                       "release", (long long)(transposed ? M : N), (long long)kGramMaxN);
 
     // The panels the MFMA kernels stream (Z, R, ...) inherit the row count of the working problem as their leading
     // dimension.  The Gram kernel reads 16-row (128-byte) segments of every column: when the leading dimension is

@@ -470,6 +470,8 @@ int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X,
     // symmetric G: column c of G doubles as row c, so the generic kernel's coalesced A[r, c] reads apply as is.
     // 8 columns per workgroup keeps the grid wide for these latency-bound N x N products.
     if (p <= 0) return TLSQ_OK;
+    if (N >= 1024 && p > 8)   // G no longer sits in L2: re-reading it per 8 columns costs more than the narrower grid
+        return launch_skinny_mm<double>(h, G, ldG, X, N, Y, N, N, N, p);
     hipLaunchKernelGGL((k_skinny_mm<double, 8>), dim3((unsigned)((N + 63) / 64), (unsigned)((p + 7) / 8)),
                        dim3(SK_WAVES * 64), (size_t)SK_KB * 8 * 8, h->stream, G, ldG, X, N, Y, N, N, (int)N, (int)p);
     TLSQ_HIP(h, hipGetLastError());
@@ -506,8 +508,7 @@ static bool cgs2_fits_lds(int64_t N, int64_t p) { return (size_t)(p * N + p + 16
 int subspace_max_block(int64_t N) {
     // CGS2 keeps the N x p panel in LDS when it fits and works out of L2 otherwise; the p x p Rayleigh-Ritz
     // problem goes to the single-launch Jacobi up to 64 and to the block solver above
-    (void)N;
-    return 96;
+    return N > 2048 ? 192 : 96;   // large mode has no dense fallback: give the block more room
 }
 
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged) {
