@@ -162,6 +162,23 @@ int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int6
 int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA,
                   const double* y, int64_t q, int64_t ldy, const tlsq_rpca_opts* opts,
                   double* x, int64_t ldx, tlsq_rpca_info* info);
+
+/* ---- batched tiny problems ---------------------------------------------------------
+ * The reference's typical use is a loop over thousands of independent small problems
+ * (test/runtests.jl:205-235: `rtls(A, y)` on 50x4 ... 500x6 matrices).  These entry points run `batch` such
+ * problems in one launch, one workgroup per problem with all panels in LDS; each problem follows
+ * src/robustPCA.jl:156-239 exactly like tlsq_rpca_f64 (both SVDs of an iteration are one-sided Jacobi SVDs of the
+ * panel itself, so there is no Gram-route accuracy limit).  Problems are stored back to back: D is M x N x batch
+ * (column-major M x N blocks, ld = M), likewise A, E; optional per-problem outputs S (N), Vt (N x N, ld N), sv,
+ * iters, status (0 converged / 1 iteration limit), cost (final).  N <= 16, M >= N; the hankel flag, hook modes
+ * and on_iter are not available (TLSQ_ERR_UNSUPPORTED).  Returns TLSQ_MAXITER when any problem hit the limit. */
+int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
+                          const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,
+                          int32_t* iters, int32_t* status, double* cost);
+/* x_b = rtls(A_b, y_b) for b = 1..batch (src/TotalLeastSquares.jl:152-156): A is M x n x batch, y is M x q x batch,
+ * x is n x q x batch. */
+int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64_t M, int64_t n, int64_t q,
+                          int64_t batch, const tlsq_rpca_opts* opts, double* x, int32_t* iters, int32_t* status);
 int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n,
                          double* x, int64_t ldx);
 

@@ -178,4 +178,17 @@ function rtls(A::AbstractArray{Float64}, y::AbstractArray{Float64}; kwargs...)  
     y isa AbstractVector ? vec(x) : x
 end
 
+# Many small problems at once (the loop of test/runtests.jl:205-235 as one launch): A is M x n x B, y is M x B
+# (or M x q x B); returns x as n x B (n x q x B).  One workgroup per problem, everything in LDS.
+function rtls(A::AbstractArray{Float64,3}, y::AbstractArray{Float64}; kwargs...)
+    M, n, B = size(A); ym = reshape(y, M, :, B); q = size(ym, 2)
+    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o); o.memory = MEM_HOST
+    x = Array{Float64}(undef, n, q, B); iters = Vector{Int32}(undef, B); status = Vector{Int32}(undef, B)
+    st = check(ccall((:tlsq_rtls_batched_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},
+         Ptr{Int32}, Ptr{Int32}), handle(), Array(A), Array(ym), M, n, q, B, o, x, iters, status))
+    st == 1 && @warn "Maximum number of iterations reached in $(sum(status)) of $B problems"
+    ndims(y) == 2 ? reshape(x, n, B) : x
+end
+
 end # module

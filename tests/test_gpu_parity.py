@@ -445,6 +445,72 @@ def test_tls_and_rtls(eng):                                          # test/runt
 # --------------------------------------------------------------------------------------------
 # full BASELINE size (config 2): size-independent properties (the oracle takes minutes here)
 # --------------------------------------------------------------------------------------------
+
+# --------------------------------------------------------------------------------------------
+# batched tiny problems: one workgroup per problem, everything in LDS
+# --------------------------------------------------------------------------------------------
+def _rtls_problem_stack(rng, B, M, n, sigma):
+    """The reference's own rtls test problems (test/runtests.jl:219-226), B of them."""
+    x0 = rng.standard_normal((B, n))
+    A0 = rng.standard_normal((B, M, n))
+    An = A0 + sigma * rng.standard_normal(A0.shape) * (rng.random(A0.shape) < 0.1)
+    y0 = np.einsum("bmn,bn->bm", A0, x0)
+    yn = y0 + sigma * rng.standard_normal(y0.shape) * (rng.random(y0.shape) < 0.1)
+    return x0, An, yn
+
+
+@pytest.mark.parametrize("M,n,sigma", [(50, 3, 50.0), (500, 5, 5.0), (2000, 4, 5.0)])
+def test_rtls_batched_vs_oracle(eng, M, n, sigma):
+    """x, iteration count per problem against the oracle's rtls; 2000x5 does not fit LDS (global-scratch variant)."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(100 + M)
+    B = 12
+    x0, An, yn = _rtls_problem_stack(rng, B, M, n, sigma)
+    x, it, st = eng.rtls_batched(An, yn, return_status=True)
+    assert x.shape == (B, n) and not st.any()
+    for b in range(B):
+        Ao, Eo, so, svo, io = O.rpca(np.c_[An[b], yn[b]], nukeA=False)
+        assert it[b] == io.iters_done, (b, it[b], io.iters_done)
+        xo = O.rtls(An[b], yn[b])
+        np.testing.assert_allclose(x[b], np.ravel(xo), rtol=1e-7, atol=1e-9)
+    # the batched entry point agrees with the per-problem one
+    x1 = eng.rtls(An[0], yn[0])
+    np.testing.assert_allclose(x[0], np.ravel(x1), rtol=1e-7, atol=1e-9)
+
+
+def test_rpca_batched_vs_oracle_and_reference_statistics(eng):
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(7)
+    B, M, N = 10, 300, 8
+    D = np.stack([O.synth_lowrank_sparse(M, N, 2, seed=50 + b)[0] for b in range(B)])
+    A, E, S, Vt, sv, it, st, cost = eng.rpca_batched(D)
+    assert not st.any()
+    for b in range(B):
+        Ao, Eo, so, svo, io = O.rpca(D[b])
+        assert (sv[b], it[b]) == (svo, io.iters_done)
+        assert relerr(A[b], Ao) < 1e-8 and relerr(E[b], Eo) < 1e-8
+        np.testing.assert_allclose(S[b], so[1], rtol=1e-10, atol=1e-13 * so[1][0])   # no Gram route: all of S is accurate
+        assert abs(cost[b] - io.cost_hist[-1]) <= 1e-6 * io.cost_hist[-1] + 1e-12
+    # flags
+    A2, E2, *_ = eng.rpca_batched(np.abs(D), nonnegA=True, nonnegE=True)
+    Ao, Eo, *_ = O.rpca(np.abs(D[3]), nonnegA=True, nonnegE=True)
+    assert relerr(A2[3], Ao) < 1e-8 and relerr(E2[3], Eo) < 1e-8
+    # the reference's statistical rtls test (test/runtests.jl:219-235): rtls beats tls on > 90 % of 1000 problems
+    x0, An, yn = _rtls_problem_stack(rng, 1000, 50, 3, 50.0)
+    xr = eng.rtls_batched(An, yn)
+    xt = np.stack([np.ravel(O.tls(An[b], yn[b])) for b in range(1000)])
+    wins = np.linalg.norm(x0 - xr, axis=1) < np.linalg.norm(x0 - xt, axis=1)
+    assert wins.mean() > 0.9, wins.mean()
+
+
+def test_batched_unsupported_shapes_fail_loudly(eng):
+    import tlsq_amd
+    with pytest.raises(tlsq_amd.TlsqError):
+        eng.rpca_batched(np.ones((2, 40, 17)))            # N > 16
+    with pytest.raises(tlsq_amd.TlsqError):
+        eng.rpca_batched(np.ones((2, 3, 5)))              # wide problems
+
+
 def test_rpca_c2_full_size_properties(eng):
     from oracle import rpca_oracle as O
     M, N, r = 20000, 512, 16

@@ -78,7 +78,7 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC, WS_E2, WS_Z2,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
+    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
 };
 
@@ -171,6 +171,12 @@ int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64
                      int64_t R, int64_t K, int64_t p);
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
                    int64_t r);
+// batched.hip: one workgroup per tiny rpca problem
+size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds);
+int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,
+                      double rho, int64_t iters, int64_t maxrank, bool nonnegA, bool nonnegE, bool nukeA, double* A,
+                      double* E, double* S, double* Vt, int64_t* sv, int32_t* it, int32_t* st, double* cost,
+                      double* scratch);
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
 int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
