@@ -163,6 +163,15 @@ int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t 
                   const double* y, int64_t q, int64_t ldy, const tlsq_rpca_opts* opts,
                   double* x, int64_t ldx, tlsq_rpca_info* info);
 
+/* ---- ComplexF64 rpca: the complex soft_th method (src/robustPCA.jl:3-7; test/runtests.jl:187-199) -------------
+ * D, A, E are interleaved (re, im) complex M x N matrices, column-major, leading dimensions in complex elements;
+ * S (optional) receives the min(M,N) singular values of the last Z.  Spectral steps run on the realified
+ * 2M x 2N panel with the real path's kernels (full decompositions, N <= 1024).  nonnegA / nonnegE / hankel (no
+ * complex method in the reference either), hook modes and row sharding: TLSQ_ERR_UNSUPPORTED.  The singular
+ * vectors of `s` are not returned in this release. */
+int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                  double* A, int64_t ldA, double* E, int64_t ldE, double* S, int64_t* sv, tlsq_rpca_info* info);
+
 /* ---- batched tiny problems ---------------------------------------------------------
  * The reference's typical use is a loop over thousands of independent small problems
  * (test/runtests.jl:205-235: `rtls(A, y)` on 50x4 ... 500x6 matrices).  These entry points run `batch` such

@@ -178,6 +178,21 @@ function rtls(A::AbstractArray{Float64}, y::AbstractArray{Float64}; kwargs...)  
     y isa AbstractVector ? vec(x) : x
 end
 
+# ComplexF64 data: the complex soft_th method, src/robustPCA.jl:3-7.  `s` carries the singular values only.
+function rpca(D::AbstractMatrix{ComplexF64}; λ = 1 / sqrt(maximum(size(D))), iters = 1000, tol = sqrt(eps()), ρ = 1.5,
+              nukeA = true, kwargs...)
+    Dm = Matrix(D); M, N = size(Dm)
+    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
+    o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA; o.memory = MEM_HOST
+    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    A = similar(Dm); E = similar(Dm); S = Vector{Float64}(undef, min(M, N)); sv = Ref{Int64}(0)
+    st = check(ccall((:tlsq_rpca_c64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{ComplexF64}, Int64, Ptr{ComplexF64},
+         Int64, Ptr{Float64}, Ref{Int64}, Ref{RpcaInfo}), handle(), Dm, M, N, M, o, A, M, E, M, S, sv, info))
+    st == 1 && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
+    A, E, (S = S,), sv[]
+end
+
 # Many small problems at once (the loop of test/runtests.jl:205-235 as one launch): A is M x n x B, y is M x B
 # (or M x q x B); returns x as n x B (n x q x B).  One workgroup per problem, everything in LDS.
 function rtls(A::AbstractArray{Float64,3}, y::AbstractArray{Float64}; kwargs...)

@@ -367,10 +367,39 @@ def test_rpca_large_mode_vs_oracle_and_planted(eng):
     assert relerr(A + E, D) < 1e-7
 
 
+def test_rpca_complex_vs_oracle_and_reference_thresholds(eng):        # test/runtests.jl:187-199
+    """ComplexF64: the complex soft_th method (src/robustPCA.jl:3-7).  The reference's own test problem (rank-1
+    u v' plus 1 % sparse outliers, 100 x 20) against its thresholds, and the whole trajectory against the oracle."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(42)
+    crandn = lambda *sh: (rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) / np.sqrt(2)
+    u, v = crandn(100), crandn(20)
+    E0 = crandn(100, 20) * 10 * (rng.random((100, 20)) < 0.01)
+    A0 = np.outer(u, v.conj())
+    D = A0 + E0
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    assert rep.converged and sv == 1
+    assert np.sum(np.abs(E - E0) ** 2) / np.sum(np.abs(E0) ** 2) < 1e-5
+    assert np.sum(np.abs(A - A0) ** 2) / np.sum(np.abs(A0) ** 2) < 1e-5
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert (rep.iters_done, sv, rep.svp_hist) == (io.iters_done, svo, io.svp_hist)
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    np.testing.assert_allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(s.S[:sv], so[1][:sv], rtol=1e-9)
+    # a larger one (Cholesky-route eigensolver on the 2N x 2N realified Gram), rank 3, nukeA = false too
+    M, N, r = 400, 48, 3
+    D = crandn(M, r) @ crandn(r, N) + crandn(M, N) * 10 * (rng.random((M, N)) < 0.05)
+    for kw in ({}, {"nukeA": False}, {"lam": 0.07, "rho": 1.3, "tol": 1e-6}):
+        A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+        Ao, Eo, so, svo, io = O.rpca(D, **kw)
+        assert (rep.iters_done, sv, rep.svp_hist) == (io.iters_done, svo, io.svp_hist), kw
+        assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8, kw
+
+
 def test_rpca_unsupported_paths_fail_loudly(eng):
     import tlsq_amd
     with pytest.raises(tlsq_amd.TlsqError):
-        eng.rpca(np.ones((4, 4)) * (1 + 1j))
+        eng.rpca(np.ones((4, 4)) * (1 + 1j), nonnegA=True)           # max.(A, 0) has no complex method
     with pytest.raises(tlsq_amd.TlsqError):
         eng.rpca(np.ones((4, 4)), svd=lambda Z, k: None)           # arbitrary closures cannot run on the GPU
     with pytest.raises(tlsq_amd.TlsqError):

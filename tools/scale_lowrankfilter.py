@@ -12,12 +12,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=10_000_000)
 ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--check", action="store_true", help="compare with the CPU oracle (small N only)")
+ap.add_argument("--no-hist", action="store_true", help="do not ask for the per-iteration cost (what a plain Julia call does)")
 a = ap.parse_args()
 y, noise = O.synth_series(a.N, seed=0)
 yn = y + noise
 eng = tlsq_amd.Engine(0)
 t0 = time.perf_counter()
-yf, rep = eng.lowrankfilter(yn, a.n, return_report=True)
+yf, rep = eng.lowrankfilter(yn, a.n, return_report=True, cost_history=not a.no_hist)
 dt = time.perf_counter() - t0
 qn = lambda x: x / np.quantile(np.abs(x), 0.9)
 ratio = np.mean((y - qn(yf)) ** 2) / np.mean(noise ** 2)

@@ -49,7 +49,7 @@ EXPORTS = [
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
     "tlsq_lowrankfilter_f64", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
-    "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64",
+    "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_c64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32",
     "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
@@ -99,6 +99,7 @@ def load():
     lib.tlsq_tls_f64.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64, i32]
     lib.tlsq_rtls_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, P(RpcaOpts), vp, i64, P(RpcaInfo)]
     lib.tlsq_tls_from_vt_f64.argtypes = [vp, i64, i64, i64, vp, i64]
+    lib.tlsq_rpca_c64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, P(i64), P(RpcaInfo)]
     lib.tlsq_rpca_batched_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tlsq_rtls_batched_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, P(RpcaOpts), vp, vp, vp]
     lib.tlsq_k_gram_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]

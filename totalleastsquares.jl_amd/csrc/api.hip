@@ -1058,6 +1058,121 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     return converged ? TLSQ_OK : TLSQ_MAXITER;  // :232
 }
 
+// ------------------------------------------------------------------------------------------------
+// ComplexF64 rpca (src/robustPCA.jl:156-239 with the complex soft_th of :3-7; test/runtests.jl:187-199).
+// D, A, E: device, interleaved complex, M x N, ld = M.  The sweeps are complex kernels (complex.hip); every
+// spectral step runs on the realified 2M x 2N panel with the real path's Gram / eigen / rebuild kernels.  The
+// eigenvalues of the realified Gram come in equal pairs: consecutive sorted values are grouped, the pair mean
+// decides sigma_i >= 1/mu, and both eigenvectors of a pair are selected together, so the rebuilt matrix keeps the
+// realified structure.  Full decompositions only (no subspace tier): a coverage path, not a tuned one.
+// ------------------------------------------------------------------------------------------------
+static int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                             const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
+                             tlsq_rpca_info* info) {
+    const int64_t n = M * N, M2 = 2 * M, N2 = 2 * N;
+    const int64_t d = std::min(M, N);
+    void *Yv, *Zv, *Rv, *Wv, *ARv;
+    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * 16, &Yv));
+    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * 16, &Zv));
+    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * 16, &Rv));
+    TLSQ_TRY(ws_get(h, WS_DT, (size_t)n * 32, &Wv));    // realified panel
+    TLSQ_TRY(ws_get(h, WS_AT, (size_t)n * 32, &ARv));   // realified A
+    double *Y = (double*)Yv, *Z = (double*)Zv, *R = (double*)Rv, *W = (double*)Wv, *AR = (double*)ARv;
+    int64_t sweeps = 0;
+    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 16, h->stream));            // :174
+    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 16, h->stream));
+    double norm2 = 0.0, maxabs = 0.0;
+    TLSQ_TRY(launch_realify(h, D, M, N, W));
+    TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &norm2, &sweeps));         // :177
+    TLSQ_TRY(launch_cmaxabs(h, D, n, &maxabs));                               // :178
+    const double lam = ro.lambda;
+    const double dual_norm = std::max(norm2, maxabs / lam);                   // :179
+    const double d_norm = norm2;                                              // :180
+    TLSQ_TRY(launch_cdiv(h, D, Y, n, dual_norm));                             // :181
+    double mu = 1.25 / norm2;                                                 // :182
+    const double mubar = mu * 1.0e7;                                          // :183
+    int64_t sv = 10, svp = 10;                                                // :184
+    if (info) {
+        info->d_norm = d_norm;
+        info->iters_done = 0;
+        info->converged = 0;
+    }
+    h->warm_n = 0;
+    SmallSvd s;
+    double* V = nullptr;
+    std::vector<double> sig_pairs;
+    double cost = std::numeric_limits<double>::quiet_NaN();
+    bool converged = false;
+    int64_t n_full = 0;
+    const double t_loop0 = now_ms();
+    int64_t k = 0;
+    for (k = 1; k <= ro.iters; ++k) {                                         // :186
+        const double inv_mu = 1.0 / mu, thr = lam / mu;
+        TLSQ_TRY(launch_cshrink(h, D, A, Y, E, Z, n, inv_mu, thr));           // :188-192
+        TLSQ_TRY(launch_realify(h, Z, M, N, W));
+        double* G = nullptr;
+        TLSQ_TRY(gram_allreduce<double>(h, W, M2, N2, M2, &G));               // :194
+        TLSQ_TRY(eig_full(h, G, N2, &V, s, &sweeps, false));
+        ++n_full;
+        // pairs of equal eigenvalues -> singular values of the complex Z
+        sig_pairs.assign((size_t)d, 0.0);
+        for (int64_t i = 0; i < d; ++i) {
+            const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
+            sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
+        }
+        const double sigma_res = std::sqrt(8.0 * (double)N2 * 2.220446049250313e-16) * sig_pairs[0];
+        const double count_thr = std::max(inv_mu, sigma_res);
+        svp = 0;                                                              // :198
+        for (int64_t i = 0; i < d; ++i) svp += (sig_pairs[i] >= count_thr) ? 1 : 0;
+        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);                 // :199-204
+        std::vector<int32_t> sel((size_t)(2 * svp));
+        std::vector<double> g((size_t)(2 * svp));
+        for (int64_t i = 0; i < svp; ++i) {
+            const double sg = sig_pairs[i];
+            const double gi = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+            sel[2 * i] = s.order[2 * i];
+            sel[2 * i + 1] = s.order[2 * i + 1];
+            g[2 * i] = g[2 * i + 1] = gi;
+        }
+        TLSQ_TRY(rebuild_lowrank<double>(h, W, M2, N2, M2, V, sel, g, AR, M2));
+        TLSQ_TRY(launch_unrealify(h, AR, M, N, A));
+        TLSQ_TRY(launch_cupdate(h, D, A, E, Y, R, n, mu));                    // :221-222
+        mu = std::min(mu * ro.rho, mubar);                                    // :223
+        double rn = 0.0;
+        TLSQ_TRY(launch_realify(h, R, M, N, W));
+        TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &rn, &sweeps, 1e-8));  // :225
+        cost = rn / d_norm;
+        if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {
+            TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N2, 1e-13, &rn, &sweeps));
+            cost = rn / d_norm;
+        }
+        if (info) {
+            info->iters_done = k;
+            if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
+            if (info->svp_hist && k <= info->hist_capacity) info->svp_hist[k - 1] = svp;
+        }
+        if (opts && opts->on_iter) opts->on_iter(k, cost, svp, opts->user);   // :226
+        if (cost < ro.tol) {                                                  // :228
+            converged = true;
+            break;
+        }
+    }
+    if (k > ro.iters) k = ro.iters;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_loop = now_ms() - t_loop0;
+        info->converged = converged ? 1 : 0;
+        info->final_cost = cost;
+        info->final_mu = mu;
+        info->jacobi_sweeps = sweeps;
+        info->eig_full = n_full;
+    }
+    if (sv_out) *sv_out = sv;
+    if (S_host)
+        for (int64_t i = 0; i < d; ++i) S_host[i] = i < (int64_t)sig_pairs.size() ? sig_pairs[i] : 0.0;
+    return converged ? TLSQ_OK : TLSQ_MAXITER;                                // :232
+}
+
 static int check_handle(tlsq_handle h) { return h ? TLSQ_OK : TLSQ_ERR_ARG; }
 
 // solve X * V22 = -V21 for X (n x q); V = Vt' where Vt is (ncols x ncols, ldVt) — TotalLeastSquares.jl:65-69
@@ -1667,6 +1782,58 @@ int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t 
         for (int64_t a = 0; a < q; ++a)
             for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = hx[i + a * n];
     }
+    return status;
+}
+
+// ---- ComplexF64 rpca ---------------------------------------------------------------------------------------
+int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                  double* A, int64_t ldA, double* E, int64_t ldE, double* S, int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
+        return set_err(h, TLSQ_ERR_ARG, "rpca_c64: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    if (opts && (opts->nonnegA || opts->nonnegE || opts->hankel))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_c64: nonnegA / nonnegE / hankel are not defined for complex data "
+                       "(the reference's max.(A, 0) / soft_hankel! have no complex method)");
+    if (opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_c64: hook modes are not available for complex data");
+    if (h->comm || (opts && opts->m_global > 0 && opts->m_global != M))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_c64: row sharding is not available for complex data");
+    if (2 * N > kFullEigMaxN)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_c64: N = %lld; the complex path handles N <= %lld", (long long)N,
+                       (long long)(kFullEigMaxN / 2));
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    reset_info(info);
+    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(std::numeric_limits<double>::epsilon()));
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const int64_t n = M * N;
+    const double* dD = D;
+    double *dA = A, *dE = E;
+    void* p;
+    if (!dev || ldD != M) {
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * 16, &p));
+        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, 16, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        dD = (const double*)p;
+    }
+    if (!dev || ldA != M) {
+        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * 16, &p));
+        dA = (double*)p;
+    }
+    if (!dev || ldE != M) {
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * 16, &p));
+        dE = (double*)p;
+    }
+    const int64_t d = std::min(M, N);
+    std::vector<double> hS((size_t)(S ? d : 0));
+    const int status = rpca_core_complex(h, dD, M, N, ro, opts, dA, dE, S ? hS.data() : nullptr, sv, info);
+    if (status < 0) return status;
+    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, 16, back));
+    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, 16, back));
+    if (S) TLSQ_HIP(h, hipMemcpyAsync(S, hS.data(), (size_t)d * 8, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
+                                      h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_total = now_ms() - t0;
     return status;
 }
 

@@ -159,18 +159,26 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);
-int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged = false);
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr);
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);
-int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n);
 template <typename TA>
 int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64_t ldx, double* Y, int64_t ldy,
                      int64_t R, int64_t K, int64_t p);
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
                    int64_t r);
+// complex.hip: ComplexF64 sweeps + realification (panels are interleaved re/im, n counts complex elements)
+int launch_cshrink(Handle* h, const double* D, const double* A, const double* Y, double* E, double* Z, int64_t n,
+                   double inv_mu, double thr);
+int launch_cupdate(Handle* h, const double* D, const double* A, const double* E, double* Y, double* R, int64_t n,
+                   double mu);
+int launch_cdiv(Handle* h, const double* D, double* Y, int64_t n, double s);
+int launch_realify(Handle* h, const double* Z, int64_t M, int64_t N, double* W);
+int launch_unrealify(Handle* h, const double* AR, int64_t M, int64_t N, double* A);
+int launch_cmaxabs(Handle* h, const double* x, int64_t n, double* host_out);
 // batched.hip: one workgroup per tiny rpca problem
 size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds);
 int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,

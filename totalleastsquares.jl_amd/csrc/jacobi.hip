@@ -366,138 +366,6 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
 }
 
-// Two-sided (classical) Jacobi for the same small symmetric problems: the rotation of pair (p,q) comes
-// from H_pp, H_qq, H_pq alone (no dot products, no cross-lane reductions), the N/2 disjoint pairs of a
-// tournament round are applied as a column pass (H, V) and a row pass (H) with three barriers per round.
-// Input is symmetrised on load; on exit lam = diag(H), V = eigenvectors, Bout = the rotated H.
-template <bool WANT_V>
-__global__ __launch_bounds__(256) void k_jacobi_small2(const double* __restrict__ G, int64_t ldG,
-                                                        double* __restrict__ Bout, double* __restrict__ Vout,
-                                                        double* __restrict__ lam, int N, double tol, double nfloor,
-                                                        int max_sweeps, int* __restrict__ sweeps_done) {
-    __shared__ double sH[64 * 65];
-    __shared__ double sV[WANT_V ? 64 * 65 : 1];
-    __shared__ double red[4];
-    __shared__ double s_cs[32], s_sn[32];
-    __shared__ int s_p[32], s_q[32];
-    __shared__ unsigned int s_rot;
-    const int LD = 65;
-    const int tid = threadIdx.x;
-    double fro = 0.0;
-    for (int e = tid; e < N * N; e += 256) {
-        const int r = e % N, c = e / N;
-        const double v = 0.5 * (G[r + (int64_t)c * ldG] + G[c + (int64_t)r * ldG]);
-        sH[c * LD + r] = v;
-        if (WANT_V) sV[c * LD + r] = (r == c) ? 1.0 : 0.0;
-        fro += v * v;
-    }
-    fro = wave_allsum(fro);
-    if ((tid & 63) == 0) red[tid >> 6] = fro;
-    if (tid == 0) s_rot = 0;
-    __syncthreads();
-    double fsum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) fsum += red[k];
-    const double dfloor = nfloor * sqrt(fsum);   // diagonal entries below this are numerically zero
-    const int nslot = (N + 1) & ~1;
-    const int npair = nslot / 2;                 // <= 32
-    int sweep = 0;
-    for (; sweep < max_sweeps; ++sweep) {
-        for (int ir = 0; ir < nslot - 1; ++ir) {
-            // phase A: rotation parameters of this round's pairs
-            if (tid < npair) {
-                int s1, s2;
-                rr_pair(nslot, ir, tid, s1, s2);
-                if (s1 > s2) {
-                    const int t = s1;
-                    s1 = s2;
-                    s2 = t;
-                }
-                double cs = 1.0, sn = 0.0;
-                if (s2 < N) {
-                    const double h11 = sH[s1 * LD + s1], h22 = sH[s2 * LD + s2], h12 = sH[s2 * LD + s1];
-                    const double a11 = fabs(h11), a22 = fabs(h22);
-                    // relative criterion between resolved eigenvalues, absolute (N eps ||H||_F) against / among
-                    // numerically-zero ones (their coupling cannot be driven below the rounding level)
-                    // h12 is only known to ~eps*max(h11,h22) (the row/column passes mix entries of that size), and
-                    // a coupling of that size moves a well separated small eigenvalue by h12^2/h11 — far below its
-                    // own rounding level — so that is the attainable target; two numerically-zero diagonals are left alone
-                    const double mx = a11 > a22 ? a11 : a22;
-                    double thr = tol * sqrt(a11 * a22);
-                    if (thr < 3.5527136788005009e-15 * mx) thr = 3.5527136788005009e-15 * mx;   // 16 eps
-                    if (fabs(h12) > thr && mx > dfloor) {
-                        const double zeta = (h22 - h11) / (2.0 * h12);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        cs = 1.0 / sqrt(1.0 + t * t);
-                        sn = cs * t;
-                        atomicAdd(&s_rot, 1u);
-                    }
-                } else {
-                    s2 = s1;   // dummy pair: identity
-                }
-                s_p[tid] = s1;
-                s_q[tid] = s2;
-                s_cs[tid] = cs;
-                s_sn[tid] = sn;
-            }
-            __syncthreads();
-            // phase B: columns p,q of H and of V   (item = pair * N + row)
-            for (int e = tid; e < npair * N; e += 256) {
-                const int pr = e / N, r = e % N;
-                const double sn = s_sn[pr];
-                if (sn != 0.0) {
-                    const double cs = s_cs[pr];
-                    const int p1 = s_p[pr], q1 = s_q[pr];
-                    const double x = sH[p1 * LD + r], y = sH[q1 * LD + r];
-                    sH[p1 * LD + r] = cs * x - sn * y;
-                    sH[q1 * LD + r] = sn * x + cs * y;
-                    if (WANT_V) {
-                        const double u = sV[p1 * LD + r], w = sV[q1 * LD + r];
-                        sV[p1 * LD + r] = cs * u - sn * w;
-                        sV[q1 * LD + r] = sn * u + cs * w;
-                    }
-                }
-            }
-            __syncthreads();
-            // phase C: rows p,q of H   (item = pair * N + column)
-            for (int e = tid; e < npair * N; e += 256) {
-                const int pr = e / N, c = e % N;
-                const double sn = s_sn[pr];
-                if (sn != 0.0) {
-                    const double cs = s_cs[pr];
-                    const int p1 = s_p[pr], q1 = s_q[pr];
-                    const double x = sH[c * LD + p1], y = sH[c * LD + q1];
-                    sH[c * LD + p1] = cs * x - sn * y;
-                    sH[c * LD + q1] = sn * x + cs * y;
-                }
-            }
-            __syncthreads();
-            // the rotated pair's off-diagonal entry is zero by construction: store it as such (rounding would
-            // otherwise leave ~eps*max(h_pp,h_qq) behind and re-trigger the pair forever)
-            if (tid < npair && s_sn[tid] != 0.0) {
-                sH[s_q[tid] * LD + s_p[tid]] = 0.0;
-                sH[s_p[tid] * LD + s_q[tid]] = 0.0;
-            }
-            __syncthreads();
-        }
-        const unsigned int r = s_rot;
-        __syncthreads();
-        if (tid == 0) s_rot = 0;
-        __syncthreads();
-        if (r == 0) {
-            ++sweep;
-            break;
-        }
-    }
-    for (int e = tid; e < N * N; e += 256) {
-        const int r = e % N, c = e / N;
-        Bout[e] = sH[c * LD + r];
-        if (WANT_V) Vout[e] = sV[c * LD + r];
-    }
-    for (int c = tid; c < N; c += 256) lam[c] = fabs(sH[c * LD + c]);
-    if (tid == 0 && sweeps_done) *sweeps_done = sweep;
-}
-
 // B = G (ld -> N), V = I
 __global__ __launch_bounds__(256) void k_jacobi_init(const double* __restrict__ G, int64_t ldG,
                                                      double* __restrict__ B, double* __restrict__ V,

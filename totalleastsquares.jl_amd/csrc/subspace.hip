@@ -26,9 +26,8 @@ __device__ __forceinline__ double ss_wsum(double v) {
 // ||y_j after projection|| / ||y_j before|| (tiny => numerically dependent column).
 template <bool IN_LDS>
 __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int N, int p,
-                                                     double* __restrict__ status, int only_if_flagged) {
+                                                     double* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (only_if_flagged && status[1] == 0.0) return;   // CholeskyQR2 already did the job
     // IN_LDS: the whole panel lives in LDS.  Otherwise it stays in global memory (L2-resident, a single
     // workgroup reads back its own stores after a barrier) and LDS only holds the dot products.
     double* sY = IN_LDS ? sm : Y;
@@ -123,13 +122,6 @@ __global__ __launch_bounds__(256) void k_rayleigh(const double* __restrict__ GX,
     for (int r = lane; r < N; r += 64) s += GX[(size_t)col * N + r] * X[(size_t)col * N + r];
     s = ss_wsum(s);
     if (lane == 0) theta[col] = s;
-}
-
-// Gd = G - C   (N x N contiguous)
-__global__ __launch_bounds__(256) void k_sub(const double* __restrict__ G, const double* __restrict__ Cc,
-                                             double* __restrict__ Gd, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) Gd[i] = G[i] - Cc[i];
 }
 
 // deterministic pseudo-random fill in (-0.5, 0.5) (integer hash of the element index)
@@ -511,17 +503,15 @@ int subspace_max_block(int64_t N) {
     return N > 2048 ? 192 : 96;   // large mode has no dense fallback: give the block more room
 }
 
-int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev, bool only_if_flagged) {
+int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) {
     if (cgs2_fits_lds(N, p)) {
         const size_t lds = (size_t)(p * N + p + 16) * 8;
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev,
-                           only_if_flagged ? 1 : 0);
+        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
     } else {
         const size_t lds = (size_t)(p + 16) * 8;
-        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev,
-                           only_if_flagged ? 1 : 0);
+        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
@@ -532,7 +522,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
                 bool allow_cholqr, bool* used_cholqr) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
     *used_cholqr = allow_cholqr && p <= CQ_PMAX && !no_cholqr;
-    if (!*used_cholqr) return launch_cgs2(h, Y, N, p, status_dev, false);
+    if (!*used_cholqr) return launch_cgs2(h, Y, N, p, status_dev);
     const dim3 rows((int)((N + 63) / 64));
     for (int pass = 1; pass <= 2; ++pass) {
         const double* in = pass == 1 ? Y : tmp;
@@ -556,14 +546,6 @@ int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta) {
     hipLaunchKernelGGL(k_rayleigh, dim3((int)((p + 3) / 4)), dim3(256), 0, h->stream, GX, X, (int)N, (int)p,
                        theta);
-    TLSQ_HIP(h, hipGetLastError());
-    return TLSQ_OK;
-}
-
-int launch_sub(Handle* h, const double* G, const double* Cc, double* Gd, int64_t n) {
-    int64_t g = (n + 255) / 256;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_sub, dim3((int)g), dim3(256), 0, h->stream, G, Cc, Gd, n);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

@@ -142,11 +142,12 @@ class Engine:
         return o
 
     @staticmethod
-    def _info(capacity):
+    def _info(capacity, cost_history=True):
         cost = np.zeros(max(capacity, 1), dtype=np.float64)
         svp = np.zeros(max(capacity, 1), dtype=np.int64)
         info = L.RpcaInfo()
-        info.cost_hist = cost.ctypes.data_as(C.POINTER(C.c_double))
+        if cost_history:   # asking for it makes the library evaluate opnorm(residual) exactly in every iteration
+            info.cost_hist = cost.ctypes.data_as(C.POINTER(C.c_double))
         info.svp_hist = svp.ctypes.data_as(C.POINTER(C.c_int64))
         info.hist_capacity = capacity
         return info, cost, svp
@@ -172,7 +173,11 @@ class Engine:
         svd_mode, opn_mode, mvps = self._hook_modes(svd, opnorm)
         D = np.asarray(D)
         if np.iscomplexobj(D):
-            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "complex element types are not supported on the GPU path")
+            if svd_mode != L.SVD_FULL or opn_mode != L.OPNORM_EXACT:
+                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "hook modes are not available for complex data")
+            return self._rpca_complex(D, lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, verbose=verbose,
+                                      nonnegA=nonnegA, nonnegE=nonnegE, hankel=hankel, nukeA=nukeA,
+                                      return_report=return_report)
         dt = np.float32 if D.dtype == np.float32 else np.float64
         Df = _f(D, dt)
         M, N = Df.shape
@@ -206,6 +211,29 @@ class Engine:
         if return_report:
             return A, E, s, int(sv.value), rep
         return A, E, s, int(sv.value)
+
+    def _rpca_complex(self, D, *, lam, maxrank, iters, tol, rho, verbose, nonnegA, nonnegE, hankel, nukeA,
+                      return_report):
+        """ComplexF64 data (src/robustPCA.jl:3-7): `s` carries the singular values only (U, Vt are None)."""
+        Df = np.asfortranarray(D, dtype=np.complex128)
+        M, N = Df.shape
+        A = np.empty((M, N), dtype=np.complex128, order="F")
+        E = np.empty((M, N), dtype=np.complex128, order="F")
+        S = np.empty(min(M, N))
+        cb = None
+        if verbose:
+            cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
+        o = self.make_opts(lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, nonnegA=nonnegA, nonnegE=nonnegE,
+                           hankel=hankel, nukeA=nukeA, on_iter=cb)
+        info, cost, svp = self._info(int(iters))
+        sv = C.c_int64(0)
+        st = self._check(self.lib.tlsq_rpca_c64(self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
+                                                _ptr(S), C.byref(sv), C.byref(info)))
+        rep = RpcaReport(info, cost, svp)
+        if st == L.TLSQ_MAXITER:
+            warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}")
+        s = SVD(None, S, None)
+        return (A, E, s, int(sv.value), rep) if return_report else (A, E, s, int(sv.value))
 
     def rpca_device(self, dD, M, N, dA, dE, *, dU=None, dS=None, dVt=None, iters=1000, m_global=0,
                     want_hist=True, **optkw):
@@ -263,8 +291,10 @@ class Engine:
             A[...] = Af
         return Af
 
-    def lowrankfilter(self, y, n=None, *, sv=0, lag=1, tol=1e-3, svd=None, return_report=False, **kw):
-        """src/robustPCA.jl:119-128."""
+    def lowrankfilter(self, y, n=None, *, sv=0, lag=1, tol=1e-3, svd=None, return_report=False,
+                      cost_history=True, **kw):
+        """src/robustPCA.jl:119-128.  cost_history=False: like a plain Julia call, nobody looks at the
+        per-iteration cost, so the library only settles `cost < tol` (same result, less work)."""
         svd_mode, opn_mode, mvps = self._hook_modes(svd, kw.pop("opnorm", None))
         y = np.asarray(y, dtype=np.float64)
         y2 = _f(y.reshape(y.shape[0], -1))
@@ -281,7 +311,7 @@ class Engine:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
         o = self.make_opts(iters=iters, tol=tol, on_iter=cb, svd_mode=svd_mode, opnorm_mode=opn_mode,
                            opnorm_mvps=mvps, seed=kw.pop("seed", 0), **allowed)
-        info, cost, svp = self._info(iters)
+        info, cost, svp = self._info(iters, cost_history)
         yf = np.empty((Nx, Dch), dtype=np.float64, order="F")
         st = self._check(self.lib.tlsq_lowrankfilter_f64(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag),
                                                          int(sv), C.byref(o), _ptr(yf), Nx, C.byref(info)))
