@@ -183,7 +183,7 @@ function rpca(D::AbstractMatrix{ComplexF64}; λ = 1 / sqrt(maximum(size(D))), it
               nukeA = true, kwargs...)
     Dm = Matrix(D); M, N = size(Dm)
     o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
-    o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA; o.memory = MEM_HOST
+    o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA ? 1 : 0; o.memory = MEM_HOST
     info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
     A = similar(Dm); E = similar(Dm); S = Vector{Float64}(undef, min(M, N)); sv = Ref{Int64}(0)
     st = check(ccall((:tlsq_rpca_c64, LIB[]), Cint,

@@ -911,11 +911,11 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         bool cost_skipped = false;
         if (sumsq_dev) {
             double fro2 = 0.0, part[64];
+            TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
             TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
             memcpy(part, h->pinned, 512);
             for (double v : part) fro2 += v;
-            TLSQ_TRY(comm_allreduce_host_scalar(h, &fro2, ncclSum));
             const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
             if (lower > 2.0 * ro.tol) {
                 cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
