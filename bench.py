@@ -12,7 +12,7 @@ with RCCL inside libtlsqhip.so.
 
 Extra objects on the JSON line:
   roofline      ALM sweeps (HBM-bound): the bytes the shipped fused form has to move (8 passes over M*N*8 per
-                iteration + 5 for the lone shrink at k=1; SURVEY.md §8d's unfused figure is 11 and is reported
+                iteration, 7 for panels of 2^26+ elements, + 5 for the lone shrink at k=1; SURVEY.md §8d's unfused figure is 11 and is reported
                 beside it) divided by the sweeps' device time measured with HIP events on the library's
                 stream inside the timed solves (tlsq_rpca_info.ms_shrink + ms_update).
   cpu_baseline  the oracle (oracle/rpca_oracle.py: LAPACK gesdd + fused OpenMP sweeps) timed on this box's
@@ -117,9 +117,14 @@ def main():
         # passes per iteration); the shipped path fuses K2(k) with K1(k+1) (R4/W4 = 8 passes) and runs one plain
         # K1 (5 passes) at k = 1, so the roofline is priced against the bytes of THAT form - the smaller figure.
         fused = os.environ.get("TLSQ_NO_FUSED_SWEEP", "0") != "1"
+        # large panels (>= 2^26 elements): the rebuild A = T Vs' is folded in as well (A stays in registers):
+        # R D,E,Y / W R,Y,E',Z' = 7 passes
+        fused_rebuild = (fused and os.environ.get("TLSQ_NO_FUSED_REBUILD", "0") != "1" and Ml % 2 == 0 and
+                         (Ml * N >= 1 << 26 or os.environ.get("TLSQ_FUSED_REBUILD", "0") == "1"))
         array_bytes = float(Ml) * N * 8
+        sweep_passes = 7.0 if fused_rebuild else 8.0
         if fused:
-            alg_bytes = (5.0 + 8.0 * rep.iters_done) / rep.iters_done * array_bytes
+            alg_bytes = (5.0 + sweep_passes * rep.iters_done) / rep.iters_done * array_bytes
         else:
             alg_bytes = 11.0 * array_bytes
         achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
@@ -133,7 +138,7 @@ def main():
                        "rows_per_gpu": Ml, "iters_per_solve": rep.iters_done, "sv": sv,
                        "converged": rep.converged, "residual": resid, "rel_err_A": rel_a,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_update_shrink (fused ALM sweep) + k_shrink at k=1" if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
                          "passes_per_iter": alg_bytes / array_bytes,
@@ -150,9 +155,10 @@ def main():
                 pmc = json.load(f)
             if Ml == 20000 and N == 512:
                 sk = pmc["sweep_kernels"]
-                if fused and "k_update_shrink" in sk:
+                kname = "k_rebuild_update_shrink" if fused_rebuild else "k_update_shrink"
+                if fused and kname in sk:
                     tr = (sk["k_shrink"]["hbm_bytes_per_launch"] +
-                          rep.iters_done * sk["k_update_shrink"]["hbm_bytes_per_launch"]) / rep.iters_done
+                          rep.iters_done * sk[kname]["hbm_bytes_per_launch"]) / rep.iters_done
                 elif not fused and "k_update" in sk:
                     tr = sk["k_shrink"]["hbm_bytes_per_launch"] + sk["k_update"]["hbm_bytes_per_launch"]
                 else:

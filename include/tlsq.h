@@ -211,6 +211,11 @@ int tlsq_k_update_shrink_f64(tlsq_handle h, const double* D, double* A, const do
 int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
                              float* En, float* Zn, int64_t n, float mu, int nonnegA, float inv_mu_next,
                              float thr_next, int nonnegE);
+/* the sweep of large panels (>= 2^26 elements): as above, but A = Tm * Vs' (Tm M x r ld M, Vs N x r ld N, r <= 32, M
+ * even) is formed in registers and never stored: reads D, E, Y, writes R, Y, En, Zn (7 array passes) */
+int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* E,
+                                     double* Y, double* R, double* En, double* Zn, int64_t M, int64_t N, int64_t r,
+                                     double mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

@@ -759,3 +759,51 @@ def test_fused_update_shrink_bitexact(eng, torch_mod, dt, n, nonneg):
     eng.synchronize()
     for got, ref in ((dR, R), (dY, Y2), (dEn, En), (dZn, Zn), (dA, A2)):
         assert np.array_equal(to_host(got), ref)
+
+
+@pytest.mark.parametrize("M,N,r,nonneg", [(4096, 96, 16, 0), (1000, 130, 5, 1), (70000, 64, 29, 0), (300, 7, 0, 0)])
+def test_fused_rebuild_update_shrink_kernel(eng, torch_mod, M, N, r, nonneg):
+    """The sweep of large panels forms A = T Vs' in registers (never stored): against numpy's T @ Vs.T followed by
+    the reference statements (src/robustPCA.jl:205-213 product, :217-223, next :188-192).  A differs from the GEMM
+    by summation order only, so R/Y/E'/Z' are compared to 1e-12 of the panel scale."""
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    rng = np.random.default_rng(5 + r)
+    D, E, Y = (rng.standard_normal((M, N)) for _ in range(3))
+    Tm = rng.standard_normal((M, max(r, 1)))[:, :r]
+    Vs = rng.standard_normal((N, max(r, 1)))[:, :r] / max(np.sqrt(r), 1.0)
+    mu, inv_mu_n, thr_n = 0.27, 2.9, 0.4
+    A = Tm @ Vs.T if r else np.zeros((M, N))
+    if nonneg:
+        A = np.maximum(A, 0)
+    R = (D - A) - E
+    Y2 = Y + mu * R
+    t = inv_mu_n * Y2
+    En = O.soft_th((D - A) + t, thr_n)
+    if nonneg:
+        En = np.maximum(En, 0)
+    Zn = (D - En) + t
+    dD, dE, dY = (to_dev(torch, x) for x in (D, E, Y))
+    dT = to_dev(torch, Tm if r else np.zeros((M, 1)))
+    dV = to_dev(torch, Vs if r else np.zeros((N, 1)))
+    dR, dEn, dZn = (torch.empty_like(dD) for _ in range(3))
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_rebuild_update_shrink_f64(eng.h, dptr(dD), dptr(dT), dptr(dV), dptr(dE), dptr(dY), dptr(dR),
+                                                    dptr(dEn), dptr(dZn), M, N, r, mu, nonneg, inv_mu_n, thr_n,
+                                                    nonneg) == 0
+    eng.synchronize()
+    for got, ref in ((dR, R), (dY, Y2), (dEn, En), (dZn, Zn)):
+        np.testing.assert_allclose(to_host(got), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
+
+
+def test_rpca_large_panel_path_properties(eng):
+    """2^26 elements (131072 x 512): the loop takes the fused rebuild + sweep kernel (A is only materialised after the
+    loop).  Size-independent properties, as for the full C2 size."""
+    from oracle import rpca_oracle as O
+    M, N, r = 131072, 512, 12
+    D, A0, _ = O.synth_lowrank_sparse(M, N, r, seed=4)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False)
+    assert rep.converged and sv == r and rep.eig_full == 0
+    assert relerr(A + E, D) < 1.5e-8
+    assert relerr(A, A0) < 1e-6
+    assert np.linalg.matrix_rank(A[:2000], tol=1e-6 * s.S[0]) == r

@@ -51,7 +51,7 @@ EXPORTS = [
     "tlsq_lowrankfilter_f64", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
     "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_c64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
-    "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32",
+    "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
     "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
     "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64",
 ]
@@ -94,6 +94,8 @@ def load():
         getattr(lib, "tlsq_k_shrink_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, sc, i32]
         getattr(lib, "tlsq_k_update_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, i64, sc, i32]
         getattr(lib, "tlsq_k_update_shrink_" + suf).argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, sc, i32, sc, sc, i32]
+    lib.tlsq_k_rebuild_update_shrink_f64.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, dbl, i32, dbl, dbl,
+                                                     i32]
     lib.tlsq_lowrankfilter_f64.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, P(RpcaOpts), vp, i64,
                                            P(RpcaInfo)]
     lib.tlsq_tls_f64.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64, i32]

@@ -565,16 +565,16 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
     return TLSQ_OK;
 }
 
-// Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'   with r = sel.size() columns
+// Factors of the thresholded low-rank matrix A = Z * V[:,sel] * diag(g) * V[:,sel]' (r = sel.size() columns):
+// Tm (M x r, ld M, fp64, WS_T) = Z * V[:,sel] * diag(g) and Vs (N x r, ld N, WS_VS) = V[:,sel].  r = 0: both nullptr.
 template <typename T>
-static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
-                           const double* V, const std::vector<int32_t>& sel,
-                           const std::vector<double>& g, T* Aout, int64_t ldA) {
+static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,
+                           const std::vector<int32_t>& sel, const std::vector<double>& g, const double** Tm_out,
+                           const double** Vs_out) {
     const int64_t r = (int64_t)sel.size();
-    if (r == 0) {  // svp = 0  =>  A = 0 (mul! with inner dimension 0, src/robustPCA.jl:207-208)
-        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
-        return TLSQ_OK;
-    }
+    *Tm_out = nullptr;
+    *Vs_out = nullptr;
+    if (r == 0) return TLSQ_OK;
     void *Vg, *Vs, *T1, *aux;
     TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * r * 8, &Vg));
     TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
@@ -587,9 +587,31 @@ static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
-    // A (M x N) = T * Vs'
-    TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, T1, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
+    *Tm_out = (const double*)T1;
+    *Vs_out = (const double*)Vs;
     return TLSQ_OK;
+}
+
+// Aout (M x N, ldA) = Tm * Vs'   (r = 0  =>  A = 0: mul! with inner dimension 0, src/robustPCA.jl:207-208)
+template <typename T>
+static int rebuild_from_factors(Handle* h, const double* Tm, const double* Vs, int64_t M, int64_t N, int64_t r,
+                                T* Aout, int64_t ldA) {
+    if (r == 0) {
+        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
+        return TLSQ_OK;
+    }
+    TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, Tm, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
+    return TLSQ_OK;
+}
+
+// Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'
+template <typename T>
+static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
+                           const double* V, const std::vector<int32_t>& sel,
+                           const std::vector<double>& g, T* Aout, int64_t ldA) {
+    const double *Tm, *Vs;
+    TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, ldZ, V, sel, g, &Tm, &Vs));
+    return rebuild_from_factors<T>(h, Tm, Vs, M, N, (int64_t)sel.size(), Aout, ldA);
 }
 
 // Carry the dominant block (svp + pad Ritz/eigen vectors, sorted) to the next ALM iteration: WS_SX = V[:, top].
@@ -732,6 +754,10 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     int cur = 0;                 // index of the buffers holding E_k, Z_k
     bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
     static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
+    static const bool no_fuse_rebuild = [] { const char* e = getenv("TLSQ_NO_FUSED_REBUILD"); return e && e[0] == '1'; }();
+    const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
+    int64_t r_last = 0;
+    bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
     int64_t sweeps = 0;
     const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
     const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
@@ -880,12 +906,19 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             const double sg = s.sigma[sel[p]];
             g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
         }
-        TLSQ_TRY(rebuild_lowrank<T>(h, Z, M, N, M, V, sel, g, A, M));
-        if (use_subspace && !precise) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
-        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
-        pt.mark();
         const double mu_next = std::min(mu * ro.rho, mubar);       // :223
         const bool fuse = !no_fuse && k < ro.iters;
+        // large panels: A = T Vs' is not written at all, the fused sweep below forms it in registers from the factors
+        // (7 panel passes per iteration instead of 8 + the pass of the skinny GEMM that writes A)
+        const bool fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
+                                  rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
+        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
+        r_last = svp;
+        if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+        a_pending = fuse_rebuild;
+        if (use_subspace && !precise) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
+
         // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
         // side; while that lower bound of the cost is clearly above tol the iteration cannot be the last one and
         // the Gram + Lanczos evaluation of opnorm(R) is skipped altogether.
@@ -895,9 +928,15 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
             sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);   // 64 partial sums
-            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));
+            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));   // (before the mark: the sweep phase times the sweep)
         }
-        if (fuse) {
+        pt.mark();
+        if (fuse_rebuild) {
+            // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
+            TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
+                                                     svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev));
+        } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
@@ -961,6 +1000,10 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     }
     if (k > ro.iters) k = ro.iters;
     T* Z = Zbuf[cur];
+    if (a_pending) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
+        TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
+        if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+    }
     if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, E, M, N, M, (T)(lam / mu), (T*)meanws));  // :234-236
@@ -2016,6 +2059,14 @@ int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const floa
                              float thr_next, int nonnegE) {
     TLSQ_TRY(check_handle(h));
     return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr);
+}
+int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* E,
+                                     double* Y, double* R, double* En, double* Zn, int64_t M, int64_t N, int64_t r,
+                                     double mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    if (M % 2 != 0 || r > 32 || r < 0) return set_err(h, TLSQ_ERR_ARG, "k_rebuild_update_shrink: needs even M and r <= 32");
+    return launch_rebuild_update_shrink<double>(h, D, Tm, Vs, E, Y, R, En, Zn, M, N, r, mu, nonnegA, inv_mu_next,
+                                                thr_next, nonnegE, nullptr);
 }
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
                     int64_t ldG) {

@@ -101,6 +101,13 @@ template <typename T>
 int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
+// rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored
+template <typename T>
+bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r);
+template <typename T>
+int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
+                                 T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
+                                 int nonnegE, double* sumsq);
 // dst (N x M, ld ldd) = src' for src (M x N, ld lds)
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd);

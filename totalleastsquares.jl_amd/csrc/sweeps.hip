@@ -181,6 +181,87 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
     }
 }
 
+// Rebuild + update(k) + shrink(k+1) in one pass: A_k = T Vs' (T = Z V_svp diag(g), M x r; Vs = V_svp, N x r; the
+// singular-value-thresholded low-rank matrix of src/robustPCA.jl:205-213) is formed in registers and never stored,
+// so an ALM iteration reads D, E_k, Y and writes R_k, Y, E_{k+1}, Z_{k+1}: 7 panel passes, and the skinny GEMM that
+// used to write A (one more pass) disappears.  A thread owns two consecutive rows (16-byte accesses for fp64) and
+// walks over the 64 columns of its tile; the Vs tile sits in LDS as [column][i] and is read as broadcasts.  The
+// caller materialises A from the last T, Vs after the loop.
+constexpr int RUS_CT = 64;   // widest column tile
+// ROWS = 2: a thread owns two consecutive rows (16-byte accesses for fp64) - the streaming form for tall panels.
+// ROWS = 1: one row per thread and narrower column tiles, for panels too small to fill the chip otherwise.
+template <typename T, int RMAX, int ROWS>
+__global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restrict__ D, const double* __restrict__ Tm,
+                                                               const double* __restrict__ Vs,
+                                                               const T* __restrict__ E, T* __restrict__ Y,
+                                                               T* __restrict__ R, T* __restrict__ En,
+                                                               T* __restrict__ Zn, int64_t M, int N, int r, int ct,
+                                                               T mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
+                                                               double* __restrict__ sumsq) {
+    using VR = T __attribute__((ext_vector_type(ROWS)));
+    __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
+    const int c0 = blockIdx.y * ct;
+    const int nct = (N - c0 < ct) ? N - c0 : ct;
+    for (int e = threadIdx.x; e < ct * RMAX; e += 256) {
+        const int c = e / RMAX, i = e % RMAX;
+        sVs[e] = (c < nct && i < r) ? Vs[(size_t)(c0 + c) + (size_t)i * N] : 0.0;
+    }
+    __syncthreads();
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;   // ROWS = 2: M is even (launcher)
+    double ss = 0.0;
+    if (row < M) {
+        double t[ROWS][RMAX];
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) t[q][i] = i < r ? Tm[row + q + (size_t)i * M] : 0.0;
+#pragma unroll 4
+        for (int c = 0; c < nct; ++c) {
+            const int64_t idx = (row + (int64_t)(c0 + c) * M) / ROWS;
+            const VR d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
+            const VR e = __builtin_nontemporal_load(reinterpret_cast<const VR*>(E) + idx);
+            VR y = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Y) + idx);
+            const double* vs = sVs + c * RMAX;
+            double acc[ROWS];
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) acc[q] = __builtin_fma(t[q][i], vs[i], acc[q]);
+            VR rr, en, zn;
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                T a = (T)acc[q];
+                if (nonnegA) a = pos_part(a);                // A .= max.(A,0)            :217-219
+                const T z = (d[q] - a) - e[q];               // @. Z = D - A - E          :221
+                ss += (double)z * (double)z;
+                rr[q] = z;
+                y[q] = y[q] + mu * z;                        // @. Y = Y + mu*Z           :222
+                const T tt = inv_mu_n * y[q];                // next iteration, mu_{k+1}  :188
+                T ee = soft_th((d[q] - a) + tt, thr_n);
+                if (nonnegE) ee = pos_part(ee);              //                           :189-191
+                en[q] = ee;
+                zn[q] = (d[q] - ee) + tt;                    //                           :192
+            }
+            __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
+            __builtin_nontemporal_store(y, reinterpret_cast<VR*>(Y) + idx);
+            __builtin_nontemporal_store(en, reinterpret_cast<VR*>(En) + idx);
+            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Zn) + idx);
+        }
+    }
+    if (sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+        __shared__ double sw[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) sw[w] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicAdd(sumsq + ((blockIdx.x + blockIdx.y) & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_div_scalar(const T* __restrict__ D, T* __restrict__ Y,
                                                     int64_t n, T s) {
@@ -327,6 +408,55 @@ int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T*
     return TLSQ_OK;
 }
 
+// false: shape not served by the fused kernel (odd M, unaligned panels, r > 32) or too small to gain from it: the
+// caller uses the two-step path (skinny GEMM writes A, k_update_shrink streams it).  The column walk of the fused
+// kernel sustains 4.5-5 TB/s where the linear sweep reaches 5.5-5.7, so dropping A's write and read only pays
+// once the panels are large (measured: +16 % at 1e7 x 256, +9 % at 200000 x 512, +2 % at 20000 x 512).
+template <typename T>
+bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r) {
+    static const bool force = [] { const char* e = getenv("TLSQ_FUSED_REBUILD"); return e && e[0] == '1'; }();
+    if (!force && M * N < ((int64_t)1 << 26)) return false;
+    return (M % 2 == 0) && r <= 32 && aligned16(D) && aligned16(E) && aligned16(Y) && aligned16(R) && aligned16(En) &&
+           aligned16(Zn);
+}
+
+template <typename T>
+int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
+                                 T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
+                                 int nonnegE, double* sumsq) {
+    if (M <= 0 || N <= 0) return TLSQ_OK;
+    // tall panels: two rows per thread, 64-column tiles.  Otherwise one row per thread and tiles narrow enough to
+    // put ~16 waves on every CU (each tile re-reads its rows of T from L2, so not narrower than needed).
+    const int64_t want_waves = 4096;
+    const bool two = (M / 128) * ((N + 63) / 64) >= 2 * want_waves;
+    int ct = 64;
+    if (!two)
+        while (ct > 8 && ((M + 63) / 64) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
+    static const int env_rows = [] { const char* e = getenv("TLSQ_RUS_ROWS"); return e ? atoi(e) : 0; }();   // tuning knobs
+    static const int env_ct = [] { const char* e = getenv("TLSQ_RUS_CT"); return e ? atoi(e) : 0; }();
+    bool two2 = two;
+    if (env_rows == 1) two2 = false;
+    if (env_rows == 2) two2 = true;
+    if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
+    const int rows = two2 ? 2 : 1;
+    const dim3 grid((unsigned)((M / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
+#define RUS_LAUNCH(RM, RW)                                                                                           \
+    hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW>), grid, dim3(256), 0, h->stream, D, Tm, Vs, E, Y, R, En, Zn, \
+                       M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq)
+    if (two2) {
+        if (r <= 8) RUS_LAUNCH(8, 2);
+        else if (r <= 16) RUS_LAUNCH(16, 2);
+        else RUS_LAUNCH(32, 2);
+    } else {
+        if (r <= 8) RUS_LAUNCH(8, 1);
+        else if (r <= 16) RUS_LAUNCH(16, 1);
+        else RUS_LAUNCH(32, 1);
+    }
+#undef RUS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s) {
     if (n <= 0) return TLSQ_OK;
@@ -403,6 +533,9 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
     template int launch_update_shrink<T>(Handle*, const T*, T*, const T*, T*, T*, T*, T*, int64_t, T, int, T, T, \
                                          int, double*);                                                     \
+    template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
+    template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
+                                                 T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
