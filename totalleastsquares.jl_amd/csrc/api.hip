@@ -586,7 +586,12 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(upload_async(h, dg, g.data(), (size_t)r * 8));
     TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
-    TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
+    static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
+    if (r <= 32 && !no_tsmm) {
+        TLSQ_TRY(tsmm_mixed(h, Z, Prec<T>::f32, ldZ, (const double*)Vg, N, (double*)T1, M, M, N, r));
+    } else {
+        TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
+    }
     *Tm_out = (const double*)T1;
     *Vs_out = (const double*)Vs;
     return TLSQ_OK;
@@ -2078,6 +2083,7 @@ int tlsq_k_gemm_nn_f64(tlsq_handle h, const double* Z, int64_t M, int64_t K, int
                        int64_t Q, int64_t ldW, double* C, int64_t ldC) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !W || !C || ldZ < M || ldW < K || ldC < M) return set_err(h, TLSQ_ERR_ARG, "gemm_nn: bad argument");
+    if (Q <= 32) return tsmm_mixed(h, Z, 0, ldZ, W, ldW, C, ldC, M, K, Q);   // the rebuild's factor GEMM (tall-skinny kernel)
     return gemm_f64(h, true, false, W, ldW, Z, ldZ, C, ldC, Q, M, K, false);
 }
 int tlsq_k_gemm_nt_f64(tlsq_handle h, const double* T, int64_t M, int64_t K, int64_t ldT, const double* V,

@@ -131,6 +131,9 @@ int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, doub
 // instantiated operand type pairs (A,B): (f64,f64), (f32,f32), (f64,f32); layouts (KC,KC), (KC,MN), (MN,MN).
 int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
                int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
+// T (M x r, fp64) = Z (M x K, fp32 or fp64) * W (K x r), r <= 32: Z streamed once, MFMA fed from global memory
+int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
+               int64_t M, int64_t K, int64_t r);
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
 
 // ---------------- jacobi.hip ----------------

@@ -379,4 +379,114 @@ int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, doub
     return gram_any(h, Z, 0, M, N, ldZ, G, ldG);
 }
 
+// ---- tall-skinny product T (M x r) = Z (M x K) * W (K x r), r <= 32 -----------------------------------------
+// The factor GEMM of the rebuild (src/robustPCA.jl:205-213: U[:,1:svp] * S = Z * V_svp * diag(g)).  On the
+// 128 x 128-tile kernel above a 16-column output wastes 7/8 of the MFMA work and the panel streams at 2.3 TB/s.  Here
+// a workgroup owns 16*RT rows, its four waves split K, and every wave feeds v_mfma_f64_16x16x4_f64 straight from
+// global memory: the A fragment is 16 consecutive rows x 4 columns of Z (four full 128-byte lines per load), the B
+// fragment 4 consecutive rows of the row-major, zero-padded copy of W (512 contiguous bytes, L2 resident).  No LDS
+// and no barrier in the main loop; the four partial tiles meet in LDS at the end and are added in a fixed order.
+// Z is read exactly once.
+__global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, int64_t ldw, int K, int r, int lw,
+                                                double* __restrict__ Wt) {
+    const int total = K * lw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e % lw, k = e / lw;
+        Wt[e] = j < r ? W[(size_t)k + (size_t)j * ldw] : 0.0;
+    }
+}
+
+template <typename TA, int NCT, int RT>
+__global__ __launch_bounds__(256) void k_tsmm(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ Wt,
+                                              double* __restrict__ Tout, int64_t ldt, int64_t M, int K, int r) {
+    constexpr int LW = 16 * NCT;
+    __shared__ double sR[4 * RT * NCT * 256];   // [w][t][c][reg][lane]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * (16 * RT);
+    d4 acc[RT][NCT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[t][c] = d4{0.0, 0.0, 0.0, 0.0};
+    const TA* zrow[RT];
+    bool rok[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t row = r0 + 16 * t + fr;
+        rok[t] = row < M;
+        zrow[t] = Z + (rok[t] ? row : 0);
+    }
+    // this wave's share of K, in whole k-steps of 4
+    const int nks = (K + 3) / 4;
+    const int per = (nks + 3) / 4;
+    const int ks0 = w * per, ks1 = (ks0 + per < nks) ? ks0 + per : nks;
+    // four k-steps per trip: all 4*(RT+NCT) loads are issued before the first MFMA consumes one
+    for (int ksb = ks0; ksb < ks1; ksb += 4) {
+        double fa[4][RT], fb[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kg = (ksb + u) * 4 + fk;
+            const bool kok = (ksb + u < ks1) && kg < K;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) fa[u][t] = (rok[t] && kok) ? (double)zrow[t][(int64_t)kg * ldz] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) fb[u][c] = kok ? Wt[(size_t)kg * LW + c * 16 + fr] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u][t], fb[u][c], acc[t][c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sR[(((w * RT + t) * NCT + c) * 4 + q) * 64 + lane] = acc[t][c][q];
+    __syncthreads();
+    for (int o = tid; o < RT * NCT * 256; o += 256) {
+        const int l = o & 63, q = (o >> 6) & 3, tc = o >> 8;
+        const int t = tc / NCT, c = tc % NCT;
+        double sum = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) sum += sR[(((ww * RT + t) * NCT + c) * 4 + q) * 64 + l];
+        const int64_t row = r0 + 16 * t + (l >> 4) + 4 * q;   // lane holds column j = lane&15, rows (lane>>4) + 4*reg
+        const int col = c * 16 + (l & 15);
+        if (row < M && col < r) Tout[row + (int64_t)col * ldt] = sum;
+    }
+}
+
+// T (M x r, ldt, fp64) = Z (M x K, ldz; fp32 when z_f32) * W (K x r, ldw), r <= 32
+int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
+               int64_t M, int64_t K, int64_t r) {
+    if (M <= 0 || r <= 0) return TLSQ_OK;
+    if (r > 32) return set_err(h, TLSQ_ERR_ARG, "tsmm: r > 32");
+    const bool wide = r > 16;
+    const int lw = wide ? 32 : 16;
+    void* wt;
+    TLSQ_TRY(ws_get(h, WS_AUX4, (size_t)K * lw * 8, &wt));
+    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)std::min<int64_t>((K * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, W,
+                       ldw, (int)K, (int)r, lw, (double*)wt);
+    const bool tall = M >= 65536;   // fewer than ~1000 workgroups of 64 rows would leave CUs idle: 32-row workgroups
+    const int rt = tall ? 4 : 2;
+    const dim3 grid((unsigned)((M + 16 * rt - 1) / (16 * rt)));
+#define TS_LAUNCH(TA, NC, RTT)                                                                                      \
+    hipLaunchKernelGGL((k_tsmm<TA, NC, RTT>), grid, dim3(256), 0, h->stream, (const TA*)Z, ldz, (const double*)wt,    \
+                       Tout, ldt, M, (int)K, (int)r)
+    if (z_f32) {
+        if (wide) { if (tall) TS_LAUNCH(float, 2, 4); else TS_LAUNCH(float, 2, 2); }
+        else { if (tall) TS_LAUNCH(float, 1, 4); else TS_LAUNCH(float, 1, 2); }
+    } else {
+        if (wide) { if (tall) TS_LAUNCH(double, 2, 4); else TS_LAUNCH(double, 2, 2); }
+        else { if (tall) TS_LAUNCH(double, 1, 4); else TS_LAUNCH(double, 1, 2); }
+    }
+#undef TS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 }  // namespace tlsq
