@@ -371,6 +371,7 @@ static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<
 static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, SubspaceState& st,
                         double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
     *ok = false;
+    st.fail = SubspaceState::FAIL_NONE;
     const bool hook = st.hook_rank > 0;
     const bool cold = hook || !st.valid;
     if (hook) {
@@ -627,8 +628,12 @@ static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s,
     if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
     if (want > pmax || want < 3) {
         sub.valid = false;
+        // rank beyond the largest block: cold starts would only find that out again - the dense solver serves the
+        // next iterations until the rank fits (this function is called after every one of them)
+        sub.allow_cold = want < 3;
         return TLSQ_OK;
     }
+    sub.allow_cold = true;
     // the sorted vectors we have (a subspace result only carries p of them); any missing pad columns are
     // pseudo-random — the next iteration's CGS2 orthogonalises them against the rest
     const int64_t have = std::min<int64_t>(want, s.ncols);
@@ -853,10 +858,14 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         } else if (use_subspace) {
             TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
         }
-        if (!fast_ok && large && !(hook_svd && k >= 2)) {
-            // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry
-            for (int attempt = 0; !fast_ok && attempt < 10; ++attempt) {
+        if (!fast_ok && use_subspace && !(hook_svd && k >= 2) && sub.fail != SubspaceState::FAIL_NONE) {
+            // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
+            // Large mode has nothing else; below it a few cheap attempts come before the dense solver when the
+            // block was merely too small (rank above the cold block, rank jumps) - not when convergence stalled.
+            const int max_attempts = large ? 10 : 3;
+            for (int attempt = 0; !fast_ok && attempt < max_attempts; ++attempt) {
                 const int why = sub.fail;
+                if (!large && why != SubspaceState::FAIL_SMALL && why != SubspaceState::FAIL_CERT) break;
                 const bool grow = why == SubspaceState::FAIL_SMALL || why == SubspaceState::FAIL_CERT ||
                                   why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
                 const int64_t cap = std::min<int64_t>(pmax, N);
