@@ -197,9 +197,9 @@ struct Prec {
 // sigma_max of Z (device M x N, ld) = the default `opnorm`; uses WS_G.
 template <typename T>
 static int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double* out,
-                       int64_t* sweeps, double rel_tol = 1e-13, double stop_above_sigma = 0.0) {
+                       int64_t* sweeps, double rel_tol = 1e-13, double stop_above_sigma = 0.0, int gslot = WS_G) {
     void* G;
-    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(ws_get(h, gslot, (size_t)N * N * 8, &G));
     TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
     TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
     return sigma_max_of_gram(h, (const double*)G, N, rel_tol, out, sweeps, stop_above_sigma);
@@ -820,10 +820,13 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
 
     PhaseTimer pt(h, timing);
     double zero_sink = 0.0;
+    // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | next iteration's Gram queued
+    // behind the sweep (booked under gram) | cost evaluation
     double* acc[8] = {info ? &info->ms_shrink : &zero_sink, info ? &info->ms_gram : &zero_sink,
                       info ? &info->ms_eig : &zero_sink,    info ? &info->ms_rebuild : &zero_sink,
-                      info ? &info->ms_update : &zero_sink, info ? &info->ms_opnorm : &zero_sink,
-                      nullptr,                              nullptr};
+                      info ? &info->ms_update : &zero_sink, info ? &info->ms_gram : &zero_sink,
+                      info ? &info->ms_opnorm : &zero_sink, nullptr};
+    bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
     const double t_loop0 = now_ms();
     int64_t k = 0;
     for (k = 1; k <= ro.iters; ++k) {                              // :186
@@ -846,7 +849,9 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             ++sub.full;
             ++n_precise;
         } else {
-        TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+        if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
+        else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+        g_ready = false;
         pt.mark();
         if (hook_svd && k >= 2) {
             // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
@@ -966,6 +971,17 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             double fro2 = 0.0, part[64];
             TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
             TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
+            // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
+            // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
+            // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
+            const bool precise_next = !large && !hook_svd && sigma_top > 0.0 &&
+                                      1.0 / mu_next < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
+            if (!precise_next) {   // (the two-level decomposition forms its Gram matrices itself)
+                double* Gn = nullptr;
+                TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
+                g_ready = true;
+            }
+            pt.mark();
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
             memcpy(part, h->pinned, 512);
             for (double v : part) fro2 += v;
@@ -974,7 +990,10 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
                 cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
                 cost_skipped = true;
             }
+        } else {
+            pt.mark();   // (empty "next Gram" window)
         }
+        const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
         if (cost_skipped) {
             // nothing to evaluate
         } else if (hook_opnorm) {
@@ -985,10 +1004,10 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
             // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
             const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
-            TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma));  // :225
+            TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
-                TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N, 1e-13, &rn, &sweeps));
+                TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
                 cost = rn / d_norm;
             }
         }
