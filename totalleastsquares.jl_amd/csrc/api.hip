@@ -354,6 +354,21 @@ static int upload_async(Handle* h, void* dst, const void* src, size_t bytes) {
     return TLSQ_OK;
 }
 
+// one stream-ordered upload of an index list and a weight list of the same length r into `aux`
+// (layout: int32 sel[r], padding to 8 bytes, double w[r]); returns the two device pointers
+static int upload_sel_weights(Handle* h, void* aux, const std::vector<int32_t>& sel, const std::vector<double>& w,
+                              int32_t** dsel, double** dw) {
+    const size_t r = sel.size();
+    const size_t off = ((r * 4 + 7) / 8) * 8;
+    std::vector<char> buf(off + r * 8);
+    memcpy(buf.data(), sel.data(), r * 4);
+    memcpy(buf.data() + off, w.data(), r * 8);
+    TLSQ_TRY(upload_async(h, aux, buf.data(), buf.size()));
+    *dsel = (int32_t*)aux;
+    *dw = (double*)((char*)aux + off);
+    return TLSQ_OK;
+}
+
 // upload a column selection and gather X = V[:, sel]
 static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
     const int64_t r = (int64_t)sel.size();
@@ -544,10 +559,9 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
             sel[i] = s.order[i];
             th[i] = host[sel[i]];
         }
-        int32_t* dsel = (int32_t*)aux;
-        double* dth = (double*)((char*)aux + ((svp * 4 + 7) / 8) * 8);
-        TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)svp * 4));
-        TLSQ_TRY(upload_async(h, dth, th.data(), (size_t)svp * 8));
+        int32_t* dsel;
+        double* dth;
+        TLSQ_TRY(upload_sel_weights(h, aux, sel, th, &dsel, &dth));
         TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
         TLSQ_TRY(launch_deflate(h, G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
     } else {
@@ -581,10 +595,9 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
     TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T1));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
-    int32_t* dsel = (int32_t*)aux;
-    double* dg = (double*)((char*)aux + ((r * 4 + 7) / 8) * 8);
-    TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)r * 4));
-    TLSQ_TRY(upload_async(h, dg, g.data(), (size_t)r * 8));
+    int32_t* dsel;
+    double* dg;
+    TLSQ_TRY(upload_sel_weights(h, aux, sel, g, &dsel, &dg));
     TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
@@ -638,7 +651,21 @@ static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s,
     // pseudo-random — the next iteration's CGS2 orthogonalises them against the rest
     const int64_t have = std::min<int64_t>(want, s.ncols);
     std::vector<int32_t> keep((size_t)have);
-    for (int64_t p = 0; p < have; ++p) keep[p] = s.order[p];
+    bool identity = true;
+    for (int64_t p = 0; p < have; ++p) {
+        keep[p] = s.order[p];
+        identity = identity && keep[p] == (int32_t)p;
+    }
+    if (identity && h->ws[WS_SX].p && V == (const double*)h->ws[WS_SX].p) {
+        // the usual case: V is the sorted block the subspace solver left in WS_SX - its leading columns stay where
+        // they are, only missing pad columns are (re)filled
+        if (have < want)
+            TLSQ_TRY(launch_fill_hash(h, (double*)h->ws[WS_SX].p + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
+        sub.p = want;
+        sub.ntop = svp;
+        sub.valid = true;
+        return TLSQ_OK;
+    }
     void *tmp, *X;
     TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * want * 8, &tmp));
     TLSQ_TRY(gather_cols(h, V, N, keep, (double*)tmp));          // out of place (V may be WS_SX itself)
