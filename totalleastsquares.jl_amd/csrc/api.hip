@@ -457,10 +457,12 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
         if (sweeps) *sweeps += sw;
         // X' = Q S,  G X' = (G Q) S
-        TLSQ_TRY(launch_panel_rot2(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)XN, (double*)GX,
+        // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
+        // Ritz values did not come out in descending order)
+        TLSQ_TRY(launch_panel_rot2(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X, (double*)GX,
                                    N, p));
-        TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)XN, N, p, theta_dev));
-        TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)XN, theta_dev, N, p, res_dev));
+        TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)X, N, p, theta_dev));
+        TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)X, theta_dev, N, p, res_dev));
         TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
                                    h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -495,9 +497,14 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
                 th_sorted[i] = host[s.order[i]];
                 sg_sorted[i] = s.sigma[s.order[i]];
             }
-            TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
-            TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
-                                         (double*)X));
+            bool sorted = true;
+            for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[i] == (int32_t)i;
+            if (!sorted) {
+                TLSQ_HIP(h, hipMemcpyAsync(XN, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+                TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
+                TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
+                                             (double*)X));
+            }
             for (int64_t i = 0; i < p; ++i) {
                 host[i] = th_sorted[i];
                 host[p + i] = res_sorted[i];
