@@ -250,6 +250,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     __shared__ double red[16];
     __shared__ double sN[64];
     __shared__ unsigned int s_rot;
+    __shared__ unsigned long long s_max;
     const int LD = 65;
     const int tid = threadIdx.x;
     const int hw = tid >> 5, hl = tid & 31;   // half-wave index, lane within it
@@ -265,7 +266,10 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     }
     fro = wave_allsum(fro);
     if ((tid & 63) == 0) red[tid >> 6] = fro;
-    if (tid == 0) s_rot = 0;
+    if (tid == 0) {
+        s_rot = 0;
+        s_max = 0ull;
+    }
     __syncthreads();
     double fsum = 0.0;
     for (int k = 0; k < (nthr >> 6); ++k) fsum += red[k];
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         unsigned int my_rot = 0;
+        double my_max = 0.0;
         // squared column norms, refreshed once per sweep and updated by the rotation formulas in between
         for (int c = hw; c < N; c += nhw) {
             const double* x = sB + c * LD;
@@ -302,6 +307,8 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
                     const double c = half_allsum(x0 * y0 + x1 * y1);
                     const double mn = a < bb ? a : bb;
                     if (c * c > tol * tol * a * bb && mn > floor2) {
+                        const double ratio2 = c * c / (a * bb);   // cos^2 of the angle between the two columns
+                        my_max = ratio2 > my_max ? ratio2 : my_max;
                         // t = 2 c sgn(d) / (|d| + sqrt(d^2 + 4 c^2)), d = bb - a  (one sqrt, one division)
                         const double d = bb - a;
                         const double t = (d >= 0.0 ? 2.0 : -2.0) * c / (fabs(d) + sqrt(d * d + 4.0 * c * c));
@@ -340,12 +347,21 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
             }
             __syncthreads();
         }
-        if (hl == 0 && my_rot) atomicAdd(&s_rot, my_rot);
+        if (hl == 0 && my_rot) {
+            atomicAdd(&s_rot, my_rot);
+            atomicMax(&s_max, (unsigned long long)__double_as_longlong(my_max));   // non-negative doubles order like integers
+        }
         __syncthreads();
         const unsigned int r = s_rot;
+        const double swmax = __longlong_as_double((long long)s_max);
         __syncthreads();
-        if (tid == 0) s_rot = 0;
-        if (r == 0) {
+        if (tid == 0) {
+            s_rot = 0;
+            s_max = 0ull;
+        }
+        // converged: a sweep without rotations - or one whose largest rotation was so small (|cos| < 1e-8) that,
+        // Jacobi converging quadratically, what is left is below the rotation threshold anyway
+        if (r == 0 || swmax < 1e-16) {
             ++sweep;
             break;
         }
