@@ -644,7 +644,8 @@ static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
 // Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
 static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
                        SubspaceState& sub) {
-    int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(8, svp / 4));
+    static const int64_t pad_min = [] { const char* e = getenv("TLSQ_PAD"); return (int64_t)(e ? atoi(e) : 4); }();
+    int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(pad_min, svp / 4));
     if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
     if (want > pmax || want < 3) {
         sub.valid = false;
