@@ -14,10 +14,24 @@ namespace tlsq {
 constexpr int LZ_WGS = 64;       // workgroups per step-kernel
 constexpr int LZ_THREADS = 256;  // 4 waves
 
+// wave all-reduce without the LDS crossbar (see jacobi.hip): DPP inside each row of 16 lanes, then the four row totals
+template <int CTRL>
+__device__ __forceinline__ double lz_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lz_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += lz_dpp<0xB1>(v);
+    v += lz_dpp<0x4E>(v);
+    v += lz_dpp<0x141>(v);
+    v += lz_dpp<0x140>(v);
+    return (lz_lane(v, 0) + lz_lane(v, 16)) + (lz_lane(v, 32) + lz_lane(v, 48));
 }
 
 __device__ __forceinline__ double block_sum4(double v, double* red) {
