@@ -15,10 +15,24 @@ namespace tlsq {
 
 constexpr int SS_THREADS = 1024;
 
+// wave all-reduce without the LDS crossbar (see jacobi.hip): DPP inside each row of 16 lanes, then the four row totals
+template <int CTRL>
+__device__ __forceinline__ double ss_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ss_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double ss_wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += ss_dpp<0xB1>(v);
+    v += ss_dpp<0x4E>(v);
+    v += ss_dpp<0x141>(v);
+    v += ss_dpp<0x140>(v);
+    return (ss_lane(v, 0) + ss_lane(v, 16)) + (ss_lane(v, 32) + ss_lane(v, 48));
 }
 
 // In-place orthonormalisation of the p columns of Y (N x p, ld N) by classical Gram-Schmidt with one
