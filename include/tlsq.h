@@ -89,6 +89,9 @@ typedef struct tlsq_rpca_info {
     /* how the SVD step of each iteration was served: full Jacobi decompositions vs warm-started subspace
      * iterations (and the total number of subspace steps) */
     int64_t eig_full, eig_fast, subspace_steps;
+    /* sweeps that did not store the residual panel (its cost evaluation was predicted to be skipped): these moved
+     * one panel pass less */
+    int64_t residual_stores_skipped;
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);

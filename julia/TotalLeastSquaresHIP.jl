@@ -6,7 +6,7 @@
 # MI355X behind the C ABI.  NOTE: the build image has no `julia` binary, so this file is not executed by
 # the test-suite; it is mirrored line for line by the ctypes harness
 # `totalleastsquares.jl_amd/engine.py`, which is.  Struct layouts are checked there
-# (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts)=104, sizeof(info)=176).
+# (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts)=104, sizeof(info)=184).
 module TotalLeastSquaresHIP
 
 using LinearAlgebra, Libdl
@@ -36,6 +36,7 @@ mutable struct RpcaInfo
     ms_total::Cdouble; ms_loop::Cdouble; ms_h2d::Cdouble; ms_d2h::Cdouble
     ms_shrink::Cdouble; ms_update::Cdouble; ms_gram::Cdouble; ms_eig::Cdouble; ms_rebuild::Cdouble; ms_opnorm::Cdouble
     eig_full::Int64; eig_fast::Int64; subspace_steps::Int64
+    residual_stores_skipped::Int64
     RpcaInfo() = new()
 end
 

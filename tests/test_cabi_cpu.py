@@ -45,7 +45,7 @@ def test_version_and_default_opts():
 def test_struct_sizes_match_header():
     # natural alignment, no packing: these are the sizes the Julia shim's struct mirrors must have
     assert C.sizeof(L.RpcaOpts) == 104
-    assert C.sizeof(L.RpcaInfo) == 176
+    assert C.sizeof(L.RpcaInfo) == 184
 
 
 def test_tls_from_vt_is_host_only_math():

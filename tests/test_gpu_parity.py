@@ -807,3 +807,27 @@ def test_rpca_large_panel_path_properties(eng):
     assert relerr(A + E, D) < 1.5e-8
     assert relerr(A, A0) < 1e-6
     assert np.linalg.matrix_rank(A[:2000], tol=1e-6 * s.S[0]) == r
+
+
+def test_residual_store_misprediction_path():
+    """The fused sweep stops storing the residual panel while the Frobenius bound is far above tol; when that
+    prediction fails the residual is recomputed.  TLSQ_RSKIP_MARGIN=0 (read once per process, hence the subprocess)
+    makes every sweep skip the store, so every cost evaluation takes the recompute path: same result as the oracle."""
+    import os, subprocess, sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import tlsq_amd; from oracle import rpca_oracle as O\n"
+        "torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
+        "for (M, N, r, kw) in ((2000, 128, 8, {}), (600, 64, 5, dict(nonnegA=True, nonnegE=True))):\n"
+        "    D = O.synth_lowrank_sparse(M, N, r, seed=3)[0]; D = np.abs(D) if kw else D\n"
+        "    dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda(); dA = torch.empty_like(dD); dE = torch.empty_like(dD)\n"
+        "    sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False, **kw)\n"
+        "    Ao, Eo, so, svo, io = O.rpca(D, **kw)\n"
+        "    assert rep.residual_stores_skipped >= rep.iters_done - 2, rep.residual_stores_skipped\n"
+        "    assert (rep.iters_done, sv) == (io.iters_done, svo)\n"
+        "    assert np.linalg.norm(dA.cpu().numpy().T - Ao) <= 1e-8 * np.linalg.norm(Ao)\n"
+        "    assert np.linalg.norm(dE.cpu().numpy().T - Eo) <= 1e-8 * np.linalg.norm(Eo)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, TLSQ_RSKIP_MARGIN="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -38,7 +38,8 @@ class RpcaInfo(C.Structure):
                 ("ms_d2h", C.c_double), ("ms_shrink", C.c_double), ("ms_update", C.c_double),
                 ("ms_gram", C.c_double), ("ms_eig", C.c_double), ("ms_rebuild", C.c_double),
                 ("ms_opnorm", C.c_double),
-                ("eig_full", C.c_int64), ("eig_fast", C.c_int64), ("subspace_steps", C.c_int64)]
+                ("eig_full", C.c_int64), ("eig_fast", C.c_int64), ("subspace_steps", C.c_int64),
+                ("residual_stores_skipped", C.c_int64)]
 
 
 # every symbol include/tlsq.h declares (tests check that the .so exports all of them)

@@ -803,6 +803,9 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
     int64_t r_last = 0;
     bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
+    double prev_lower = 0.0;                               // Frobenius lower bound of the previous iteration's cost
+    int64_t n_rskip = 0;
+    static const double rskip_margin = [] { const char* e = getenv("TLSQ_RSKIP_MARGIN"); return e ? atof(e) : 8.0; }();
     int64_t sweeps = 0;
     const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
     const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
@@ -984,15 +987,21 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);   // 64 partial sums
             TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));   // (before the mark: the sweep phase times the sweep)
         }
+        // The residual panel R_k is only read by the cost evaluation.  While the Frobenius bound of the previous
+        // iteration was far above tol this one's will be too (the cost shrinks by ~rho per iteration): the sweep then
+        // does not store R_k at all (one panel pass less); should the bound disagree, R_k is recomputed below.
+        const bool store_R = !(sumsq_dev && prev_lower > rskip_margin * ro.tol);
+        T* Rst = store_R ? R : nullptr;
+        if (!store_R) ++n_rskip;
         pt.mark();
         if (fuse_rebuild) {
             // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
-            TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
+            TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
                                                      svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
                                                      (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev));
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
-            TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
+            TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
                                              ro.nonnegE ? 1 : 0, sumsq_dev));
         } else {
@@ -1021,9 +1030,18 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             memcpy(part, h->pinned, 512);
             for (double v : part) fro2 += v;
             const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
+            prev_lower = lower;
             if (lower > 2.0 * ro.tol) {
                 cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
                 cost_skipped = true;
+            } else if (!store_R) {
+                // mispredicted: the residual is needed after all.  R_k = D - A_k - E_k (A_k possibly still in factors)
+                if (a_pending) {
+                    TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
+                    if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+                    a_pending = false;
+                }
+                TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
             }
         } else {
             pt.mark();   // (empty "next Gram" window)
@@ -1086,6 +1104,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
         info->reserved = (int32_t)n_precise;   // iterations served by the two-level decomposition
+        info->residual_stores_skipped = n_rskip;
     }
     if (sv_out) *sv_out = sv;
 

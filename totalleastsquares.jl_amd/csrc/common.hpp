@@ -91,6 +91,7 @@ int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n
 // fused update(k) + shrink(k+1): R_k, Y_k, E_{k+1} (En), Z_{k+1} (Zn) in one pass
 template <typename T>
 // sumsq (optional, device, 64 doubles): their sum += ||R_k||_F^2 (atomic adds: a bound, never a result)
+// R may be nullptr (residual not stored; launch_residual recomputes it if it is needed after all)
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
                          int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq = nullptr);
 // Y = D / s  (src/robustPCA.jl:181), contiguous n
@@ -101,6 +102,8 @@ template <typename T>
 int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
+template <typename T>
+int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n);   // R = (D - A) - E
 // rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored
 template <typename T>
 bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r);

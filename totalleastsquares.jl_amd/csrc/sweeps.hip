@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
             zn[c] = (d[c] - ee) + t;                     //                           :192
         }
         if (nonnegA) SW_ST(A, i, a);
-        SW_ST(R, i, r);
+        if (R) SW_ST(R, i, r);   // R == nullptr: the caller predicted that this residual will not be looked at
         SW_ST(Y, i, y);
         SW_ST(En, i, en);
         SW_ST(Zn, i, zn);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
         }
         T z = (D[i] - a) - E[i];
         ss += (double)z * (double)z;
-        R[i] = z;
+        if (R) R[i] = z;
         T y = Y[i] + mu * z;
         Y[i] = y;
         T t = inv_mu_n * y;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
                 en[q] = ee;
                 zn[q] = (d[q] - ee) + tt;                    //                           :192
             }
-            __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
+            if (R) __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
             __builtin_nontemporal_store(y, reinterpret_cast<VR*>(Y) + idx);
             __builtin_nontemporal_store(en, reinterpret_cast<VR*>(En) + idx);
             __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Zn) + idx);
@@ -260,6 +260,15 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
         if (threadIdx.x == 0)
             atomicAdd(sumsq + ((blockIdx.x + blockIdx.y) & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
     }
+}
+
+// R = (D - A) - E  (the residual statement :221 alone, same expression order as in the sweeps): used when a sweep was
+// told not to store R and the residual turns out to be needed after all
+template <typename T>
+__global__ __launch_bounds__(256) void k_residual(const T* __restrict__ D, const T* __restrict__ A,
+                                                  const T* __restrict__ E, T* __restrict__ R, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) R[i] = (D[i] - A[i]) - E[i];
 }
 
 template <typename T, int VEC>
@@ -397,7 +406,7 @@ int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T*
                          int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq) {
     if (n <= 0) return TLSQ_OK;
     constexpr int VEC = 16 / sizeof(T);
-    if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R) && aligned16(En) && aligned16(Zn)) {
+    if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R) && aligned16(En) && aligned16(Zn)) {   // (a null R is aligned)
         hipLaunchKernelGGL((k_update_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, E,
                            Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq);
     } else {
@@ -453,6 +462,14 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
         else RUS_LAUNCH(32, 1);
     }
 #undef RUS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_residual<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, E, R, n);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -536,6 +553,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
                                                  T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*); \
+    template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \

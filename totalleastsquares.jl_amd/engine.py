@@ -57,6 +57,7 @@ class RpcaReport:
         self.jacobi_sweeps = int(info.jacobi_sweeps)
         self.eig_full, self.eig_fast = int(info.eig_full), int(info.eig_fast)
         self.subspace_steps = int(info.subspace_steps)
+        self.residual_stores_skipped = int(info.residual_stores_skipped)
         self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
 
 
