@@ -459,10 +459,8 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         // X' = Q S,  G X' = (G Q) S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
         // Ritz values did not come out in descending order)
-        TLSQ_TRY(launch_panel_rot2(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X, (double*)GX,
-                                   N, p));
-        TLSQ_TRY(launch_rayleigh(h, (const double*)GX, (const double*)X, N, p, theta_dev));
-        TLSQ_TRY(launch_ritz_resid(h, (const double*)GX, (const double*)X, theta_dev, N, p, res_dev));
+        TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X, (double*)GX,
+                                    theta_dev, res_dev, N, p));
         TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
                                    h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));

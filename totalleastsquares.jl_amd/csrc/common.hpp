@@ -199,7 +199,10 @@ int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t 
                       double* E, double* S, double* Vt, int64_t* sv, int32_t* it, int32_t* st, double* cost,
                       double* scratch);
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
-int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p);
+int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p,
+                    const double* skip_status = nullptr);
+int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
+                       double* theta, double* res, int64_t N, int64_t p);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
                       int64_t N, int64_t p);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);

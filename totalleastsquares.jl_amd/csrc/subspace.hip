@@ -222,6 +222,9 @@ int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed) {
 // ratio" CGS2 reports.
 constexpr int CQ_PMAX = 32;
 constexpr int CQ_LD = 33;
+// smallest pivot of the first factorisation above which one pass is enough: the columns are then so close to
+// orthogonal (kappa^2 <~ p / 0.25) that Q1'Q1 - I is O(100 eps) already; the second pass degenerates to a copy
+constexpr double CQ_ONEPASS = 0.25;
 
 // One wave: sL <- Cholesky factor (lower) of D^-1/2 W D^-1/2, sD <- D^-1/2.  Returns 0, or 1 when a pivot is
 // below `thresh` (or W is not finite / has a non-positive diagonal).  *minpiv_out = smallest pivot.
@@ -291,11 +294,20 @@ __global__ __launch_bounds__(64) void k_chol_trsm(const double* __restrict__ Yin
     double yv[CQ_PMAX];
 #pragma unroll
     for (int j = 0; j < CQ_PMAX; ++j) yv[j] = (j < p && r < N) ? Yin[r + (size_t)j * N] : 0.0;
+    if (pass == 2 && status[2] >= CQ_ONEPASS) {   // one pass was enough: hand the panel over as it is
+        if (r < N) {
+#pragma unroll
+            for (int j = 0; j < CQ_PMAX; ++j)
+                if (j < p) Qout[r + (size_t)j * N] = yv[j];
+        }
+        return;
+    }
     double minpiv;
     const int fail = chol_scaled_wave(W, p, sL, sD, pass == 1 ? 1.0e-5 : 1.0e-300, &minpiv);
     if (pass == 1 && blockIdx.x == 0 && lane == 0) {
         status[0] = fail ? 0.0 : sqrt(minpiv);
         status[1] = fail ? 1.0 : 0.0;
+        status[2] = fail ? 0.0 : minpiv;
     }
     if (fail) return;
     if (lane < p) sI[lane] = 1.0 / sL[lane + lane * CQ_LD];
@@ -408,7 +420,9 @@ __global__ __launch_bounds__(256) void k_deflate(const double* __restrict__ G, i
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
 __global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
-                                                  double* __restrict__ H, int N, int p) {
+                                                  double* __restrict__ H, int N, int p,
+                                                  const double* __restrict__ skip_status) {
+    if (skip_status && (skip_status[1] != 0.0 || skip_status[2] >= CQ_ONEPASS)) return;   // second CholeskyQR pass not needed
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= p * p) return;
@@ -493,8 +507,10 @@ int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, co
     return TLSQ_OK;
 }
 
-int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p) {
-    hipLaunchKernelGGL(k_panel_tn, dim3((int)((p * p + 3) / 4)), dim3(256), 0, h->stream, A, B, H, (int)N, (int)p);
+int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p,
+                    const double* skip_status) {
+    hipLaunchKernelGGL(k_panel_tn, dim3((int)((p * p + 3) / 4)), dim3(256), 0, h->stream, A, B, H, (int)N, (int)p,
+                       skip_status);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -531,7 +547,7 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
     return TLSQ_OK;
 }
 
-// Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, status: 2 doubles.
+// Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, status: 3 doubles.
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
@@ -541,7 +557,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
     for (int pass = 1; pass <= 2; ++pass) {
         const double* in = pass == 1 ? Y : tmp;
         double* out = pass == 1 ? tmp : Y;
-        TLSQ_TRY(launch_panel_tn(h, in, in, W, N, p));
+        TLSQ_TRY(launch_panel_tn(h, in, in, W, N, p, pass == 2 ? status_dev : nullptr));
         hipLaunchKernelGGL(k_chol_trsm, rows, dim3(64), 0, h->stream, in, (const double*)W, status_dev, out, (int)N,
                            (int)p, pass);
     }
@@ -562,6 +578,62 @@ int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int
                        theta);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
+}
+
+// Rayleigh-Ritz finish in one launch, one workgroup per Ritz vector c:  x = Q S[:,c],  gx = GQ S[:,c],
+// theta_c = x . gx,  res_c = ||gx - theta_c x||  (k_panel_rot2 + k_rayleigh + k_ritz_resid for small panels)
+__global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ Q, const double* __restrict__ GQ,
+                                                     const double* __restrict__ S, double* __restrict__ X,
+                                                     double* __restrict__ GX, double* __restrict__ theta,
+                                                     double* __restrict__ res, int N, int p) {
+    __shared__ double sS[CQ_PMAX * 8];   // p <= 256
+    __shared__ double red[4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = tid; k < p; k += 256) sS[k] = S[k + (size_t)c * p];
+    __syncthreads();
+    double dot = 0.0;
+    for (int r = tid; r < N; r += 256) {
+        double x = 0.0, g = 0.0;
+        for (int k = 0; k < p; ++k) {
+            x += Q[r + (size_t)k * N] * sS[k];
+            g += GQ[r + (size_t)k * N] * sS[k];
+        }
+        X[r + (size_t)c * N] = x;
+        GX[r + (size_t)c * N] = g;
+        dot += x * g;
+    }
+    dot = ss_wsum(dot);
+    if (lane == 0) red[w] = dot;
+    __syncthreads();
+    const double th = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    double rs = 0.0;
+    for (int r = tid; r < N; r += 256) {   // own writes, read back by the same thread
+        const double v = GX[r + (size_t)c * N] - th * X[r + (size_t)c * N];
+        rs += v * v;
+    }
+    rs = ss_wsum(rs);
+    if (lane == 0) red[w] = rs;
+    __syncthreads();
+    if (tid == 0) {
+        theta[c] = th;
+        res[c] = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// X = Q S, GX = GQ S, theta, res: fused for small panels, the three separate kernels otherwise (every workgroup of the
+// fused form reads both panels: 2 p^2 N doubles of L2 traffic)
+int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
+                       double* theta, double* res, int64_t N, int64_t p) {
+    if (p <= 256 && p * p * N * 16 <= (int64_t)64 << 20) {
+        hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
+                           (int)p);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    TLSQ_TRY(launch_panel_rot2(h, Q, GQ, S, X, GX, N, p));
+    TLSQ_TRY(launch_rayleigh(h, GX, X, N, p, theta));
+    return launch_ritz_resid(h, GX, X, theta, N, p, res);
 }
 
 }  // namespace tlsq
