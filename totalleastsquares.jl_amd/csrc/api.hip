@@ -130,25 +130,41 @@ static int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t ld
     return TLSQ_OK;
 }
 
+// Phase marks of one ALM iteration: HIP events on the handle's stream, two banks so that an iteration's marks can be
+// read back while the next iteration is already queued (no stream-wide synchronisation just for the timing).
 struct PhaseTimer {
     Handle* h;
     bool on;
-    int n = 0;
+    int bank = 0;
+    int n[2] = {0, 0};
     explicit PhaseTimer(Handle* hh, bool enable) : h(hh), on(enable) {}
     void mark() {
-        if (on && n < 16) (void)hipEventRecord(h->ev[n++], h->stream);
+        if (on && n[bank] < 16) (void)hipEventRecord(h->ev[bank * 16 + n[bank]++], h->stream);
     }
-    // call after a stream sync; adds elapsed(ev[i], ev[i+1]) to *acc[i]
-    void collect(double** acc) {
-        if (!on) {
-            n = 0;
-            return;
+    // adds elapsed(ev[i], ev[i+1]) of bank b to *acc[i]; the bank's last event must have completed
+    void collect_bank(int b, double** acc) {
+        if (on && n[b] > 0) {
+            (void)hipEventSynchronize(h->ev[b * 16 + n[b] - 1]);
+            for (int i = 0; i + 1 < n[b]; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->ev[b * 16 + i], h->ev[b * 16 + i + 1]) == hipSuccess && acc[i])
+                    *acc[i] += ms;
+            }
         }
-        for (int i = 0; i + 1 < n; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess && acc[i]) *acc[i] += ms;
-        }
-        n = 0;
+        n[b] = 0;
+    }
+    // read the PREVIOUS iteration's marks (long completed).  Best called while the GPU has plenty queued: the
+    // event queries cost host time
+    void collect_previous(double** acc) { collect_bank(bank ^ 1, acc); }
+    // end of an iteration: switch banks (collecting the other one first if nobody did)
+    void next_iteration(double** acc) {
+        collect_bank(bank ^ 1, acc);
+        bank ^= 1;
+    }
+    // after the loop: whatever is still pending
+    void finish(double** acc) {
+        collect_bank(bank ^ 1, acc);
+        collect_bank(bank, acc);
     }
 };
 
@@ -1013,6 +1029,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             double fro2 = 0.0, part[64];
             TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
             TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipEventRecord(h->ev[32], h->stream));
             // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
             // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
@@ -1024,7 +1041,8 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
                 g_ready = true;
             }
             pt.mark();
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            pt.collect_previous(acc);                      // (host work hidden behind the sweep + Gram just queued)
+            TLSQ_HIP(h, hipEventSynchronize(h->ev[32]));   // the copy only, not the Gram queued behind it
             memcpy(part, h->pinned, 512);
             for (double v : part) fro2 += v;
             const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
@@ -1063,8 +1081,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             }
         }
         pt.mark();
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        pt.collect(acc);
+        pt.next_iteration(acc);   // (no stream-wide synchronisation here: the next Gram may still be running)
         if (info) {
             info->iters_done = k;
             if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
@@ -1083,6 +1100,8 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         }
     }
     if (k > ro.iters) k = ro.iters;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    pt.finish(acc);
     T* Z = Zbuf[cur];
     if (a_pending) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
         TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));

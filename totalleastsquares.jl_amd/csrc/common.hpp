@@ -26,7 +26,7 @@ struct Comm;  // RCCL state (api.hip)
 struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[16] = {};
+    hipEvent_t ev[33] = {};   // two banks of 16 phase marks (PhaseTimer) + one for small readbacks
     std::string err;
     // grow-only device workspace, keyed by slot
     std::vector<DevBuf> ws;
