@@ -237,10 +237,10 @@ class Engine:
         return (A, E, s, int(sv.value), rep) if return_report else (A, E, s, int(sv.value))
 
     def rpca_device(self, dD, M, N, dA, dE, *, dU=None, dS=None, dVt=None, iters=1000, m_global=0,
-                    want_hist=True, **optkw):
+                    want_hist=True, dtype=np.float64, **optkw):
         """rpca on DEVICE-resident column-major panels (raw device addresses as ints): D (M x N, ld M) in,
-        A, E (M x N) out, optional U (M x d), S (d), Vt (d x N).  Nothing crosses PCIe except O(N) scalars.
-        Returns (sv, RpcaReport, status)."""
+        A, E (M x N) out, optional U (M x d), S (d), Vt (d x N); dtype float64 or float32 (all panels).  Nothing
+        crosses PCIe except O(N) scalars.  Returns (sv, RpcaReport, status)."""
         o = self.make_opts(iters=iters, memory=L.MEM_DEVICE, m_global=m_global, **optkw)
         info, cost, svp = self._info(int(iters))
         if not want_hist:   # no per-iteration cost requested: the library only settles cost < tol (see tlsq.h)
@@ -248,8 +248,9 @@ class Engine:
         sv = C.c_int64(0)
         d = min(max(m_global, M), N)
         vp = lambda x: C.c_void_p(int(x)) if x else None
-        st = self._check(self.lib.tlsq_rpca_f64(self.h, vp(dD), M, N, M, C.byref(o), vp(dA), M, vp(dE), M,
-                                                vp(dU), M, vp(dS), vp(dVt), d, C.byref(sv), C.byref(info)))
+        fn = self.lib.tlsq_rpca_f32 if np.dtype(dtype) == np.float32 else self.lib.tlsq_rpca_f64
+        st = self._check(fn(self.h, vp(dD), M, N, M, C.byref(o), vp(dA), M, vp(dE), M,
+                            vp(dU), M, vp(dS), vp(dVt), d, C.byref(sv), C.byref(info)))
         return int(sv.value), RpcaReport(info, cost, svp), st
 
     # -- hankel family ----------------------------------------------------------------------------
