@@ -344,6 +344,7 @@ struct SubspaceState {
     // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
     enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4 };
     int fail = FAIL_NONE;
+    bool skip_certificate = false;   // the caller certifies the count itself (late iterations, see svd_precise_fast)
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
 };
@@ -568,6 +569,11 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         if (st.fail == SubspaceState::FAIL_NONE) st.fail = SubspaceState::FAIL_NOCONV;
         return TLSQ_OK;
     }
+    if (st.skip_certificate) {
+        *V_out = (double*)X;
+        *ok = true;
+        return TLSQ_OK;
+    }
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
     TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
     if (svp > 0) {
@@ -787,6 +793,52 @@ static int svd_two_level(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch
     return TLSQ_OK;
 }
 
+// Late iterations, cheap case.  Most problems that reach the "precise" regime (1/mu within ~5x of the resolution of
+// the plain Gram route) are clean: nothing of Z lies between the block of sigma >= 1/mu and rounding noise.  Then
+// two dense decompositions are not needed.  The carried block is refined on G as usual (its pairs are accurate),
+// but the COUNT is certified on the explicitly deflated panel Z_perp = Z - (Z V_svp) V_svp' (written to
+// `scratch`), whose Gram matrix resolves singular values down to ~1e-9 sigma_max: Lanczos must put
+// lambda_max(Z_perp' Z_perp) clearly below (1/mu)^2.  Anything else (no block, no convergence, a value near the
+// threshold outside the block) -> *ok = false and svd_two_level decides.
+template <typename T>
+static int svd_precise_fast(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double inv_mu,
+                            SubspaceState& sub, const double* G, double** V_out, SmallSvd& s, int64_t* sweeps,
+                            bool* ok) {
+    *ok = false;
+    if (!sub.valid || sub.hook_rank > 0) return TLSQ_OK;
+    bool conv = false;
+    sub.skip_certificate = true;
+    const int st = svd_subspace(h, G, N, inv_mu, sub, V_out, s, sweeps, &conv);
+    sub.skip_certificate = false;
+    if (st < 0) return st;
+    if (!conv) return TLSQ_OK;
+    int64_t svp = 0;
+    for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
+    if (svp > s.ncols - 2) return TLSQ_OK;
+    const T* Zp = Z;
+    if (svp > 0) {
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> ones((size_t)svp, 1.0);
+        for (int64_t i = 0; i < svp; ++i) sel[i] = s.order[i];
+        const double *Tm, *Vs;
+        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, *V_out, sel, ones, &Tm, &Vs));
+        TLSQ_TRY(rebuild_from_factors<T>(h, Tm, Vs, M, N, svp, scratch, M));
+        TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
+        Zp = scratch;
+    }
+    void* G2;
+    TLSQ_TRY(ws_get(h, WS_G2, (size_t)N * N * 8, &G2));
+    TLSQ_TRY(gram_any(h, Zp, Prec<T>::f32, M, N, M, (double*)G2, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G2, (size_t)N * N, ncclSum));
+    double lmax = 0.0;
+    int steps = 0;
+    const int lst = lanczos_lmax_f64(h, (const double*)G2, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    if (lst < 0) return lst;
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;
+    *ok = true;
+    return TLSQ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the ALM loop on device-resident, contiguous (ld = M) panels D, A, E of element type T (fp64 or fp32).
 // The small N x N work (Gram matrices, eigenvectors, singular values) is always fp64.
@@ -895,12 +947,24 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
                              inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
-        if (precise) {
+        bool precise_fast = false;
+        if (precise && use_subspace && sub.valid) {
+            if (g_ready) G = (double*)h->ws[WS_G].p;
+            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+            g_ready = false;
+            TLSQ_TRY(svd_precise_fast<T>(h, Z, M, N, R, inv_mu, sub, G, &V, s, &sweeps, &precise_fast));
+            if (precise_fast) {
+                pt.mark();
+                ++sub.fast;
+                ++n_precise;
+            }
+        }
+        if (precise && !precise_fast) {
             TLSQ_TRY(svd_two_level<T>(h, Z, M, N, R, inv_mu, &V, s, &sweeps, &pt));
             sub.valid = false;
             ++sub.full;
             ++n_precise;
-        } else {
+        } else if (!precise) {
         if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
         else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
         g_ready = false;
@@ -987,7 +1051,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
         r_last = svp;
         if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
         a_pending = fuse_rebuild;
-        if (use_subspace && !precise) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (use_subspace && (!precise || precise_fast)) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
 
         // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
