@@ -665,7 +665,11 @@ static int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
 static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
                        SubspaceState& sub) {
     static const int64_t pad_min = [] { const char* e = getenv("TLSQ_PAD"); return (int64_t)(e ? atoi(e) : 4); }();
-    int64_t want = std::min<int64_t>(N, svp + std::max<int64_t>(pad_min, svp / 4));
+    int64_t pad = std::max<int64_t>(pad_min, svp / 4);
+    // up to 64 columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small); beyond that
+    // it costs ~1 ms per step: give up some padding to stay below when the rank allows
+    if (svp + pad > 64 && svp + pad_min <= 64) pad = 64 - svp;
+    int64_t want = std::min<int64_t>(N, svp + pad);
     if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
     if (want > pmax || want < 3) {
         sub.valid = false;

@@ -577,7 +577,9 @@ static bool cgs2_fits_lds(int64_t N, int64_t p) { return (size_t)(p * N + p + 16
 int subspace_max_block(int64_t N) {
     // CGS2 keeps the N x p panel in LDS when it fits and works out of L2 otherwise; the p x p Rayleigh-Ritz
     // problem goes to the single-launch Jacobi up to 64 and to the block solver above
-    return N > 2048 ? 192 : 96;   // large mode has no dense fallback: give the block more room
+    // blocked orthonormalisation and the block Jacobi solver keep a step at ~2 ms up to ~190 columns - still far
+    // below a dense N x N decomposition; small N: at most half of the columns
+    return N >= 384 ? 192 : 96;
 }
 
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) {
@@ -694,11 +696,11 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
     }
 }
 
-// X = Q S, GX = GQ S, theta, res: fused for small panels, the three separate kernels otherwise (every workgroup of the
-// fused form reads both panels: 2 p^2 N doubles of L2 traffic)
+// X = Q S, GX = GQ S, theta, res: one launch (every workgroup reads both panels); the three separate kernels remain
+// for blocks of more than 256 columns (k_panel_rot2 keeps S in LDS: p <= 90 there)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p) {
-    if (p <= 256 && p * p * N * 16 <= (int64_t)64 << 20) {
+    if (p <= 256) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
         hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
                            (int)p);
         TLSQ_HIP(h, hipGetLastError());
