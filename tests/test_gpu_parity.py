@@ -128,7 +128,8 @@ def test_gram(eng, torch_mod, M, N):
 
 
 @pytest.mark.parametrize("M,K,Q", [(500, 50, 7), (1000, 128, 16), (333, 37, 37), (20000, 512, 16), (4096, 512, 512),
-                                   (50, 4, 1), (300001, 130, 29), (1031, 777, 32), (262144, 64, 17)])
+                                   (50, 4, 1), (300001, 130, 29), (1031, 777, 32), (262144, 64, 17), (5000, 300, 33), (70001, 96, 80),
+                                   (4099, 257, 96)])
 def test_gemm_nn_nt(eng, torch_mod, M, K, Q):
     torch = torch_mod
     rng = np.random.default_rng(4)

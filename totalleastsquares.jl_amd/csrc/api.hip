@@ -330,6 +330,45 @@ static int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld,
     return eig_full(h, G, N, V_out, s, sweeps, false, WS_V, true);   // callers (tls!, SSA truncation) want every vector
 }
 
+// The N x N operator the small solvers work on: either the explicit Gram matrix G = Z'Z (summed over the row
+// shards), or - large mode, where forming G would cost far more than the few products the subspace solver needs
+// (2 M N^2 flops against 4 M N p per product) - the panel itself: G X = Z'(Z X), two streaming passes over Z.
+struct GramOp {
+    const double* G = nullptr;   // explicit (N x N, ld N)
+    const void* Z = nullptr;     // implicit: M x N panel (ld ldZ), fp32 when z_f32
+    int z_f32 = 0;
+    int64_t M = 0, ldZ = 0;
+    bool implicit() const { return G == nullptr; }
+};
+
+// Y (N x p, ld N) = G X
+static int op_apply(Handle* h, const GramOp& op, int64_t N, const double* X, double* Y, int64_t p) {
+    if (p <= 0) return TLSQ_OK;
+    if (!op.implicit()) return launch_symm_skinny(h, op.G, N, X, Y, N, p);
+    void* Tv;
+    TLSQ_TRY(ws_get(h, WS_OPT, (size_t)op.M * std::min<int64_t>(p, 96) * 8, &Tv));
+    for (int64_t c0 = 0; c0 < p; c0 += 96) {
+        const int64_t pc = std::min<int64_t>(96, p - c0);
+        TLSQ_TRY(tsmm_mixed(h, op.Z, op.z_f32, op.ldZ, X + (size_t)c0 * N, N, (double*)Tv, op.M, op.M, N, pc));
+        TLSQ_TRY(ztmm_mixed(h, op.Z, op.z_f32, op.ldZ, (const double*)Tv, op.M, Y + (size_t)c0 * N, N, op.M, N, pc));
+    }
+    TLSQ_TRY(comm_allreduce(h, Y, (size_t)N * p, ncclSum));
+    return TLSQ_OK;
+}
+
+// sigma_max of the panel behind an implicit operator (Lanczos on Z'Z through products); the same stopping rules
+// as sigma_max_of_gram
+static int sigma_max_of_op(Handle* h, const GramOp& op, int64_t N, double rel_tol, double* out,
+                           double stop_above_sigma = 0.0) {
+    double lmax = 0.0;
+    int steps = 0;
+    const LzApply apply = [&](const double* q, double* w) -> int { return op_apply(h, op, N, q, w, 1); };
+    const int st = lanczos_lmax_op(h, N, apply, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
+    if (st < 0) return st;
+    *out = std::sqrt(lmax);   // (no dense fallback in large mode: the value after 1000 steps stands)
+    return TLSQ_OK;
+}
+
 // ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
 struct SubspaceState {
     bool valid = false;
@@ -400,7 +439,7 @@ static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<
 // Try to get the sigma_i >= inv_mu pairs of G from the block carried in st.  *ok = false -> caller must run
 // the full solver.  On success V_out (N x p) / s describe the Ritz pairs (all p of them; the wanted ones are
 // converged, the rest only bound the count).
-static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, SubspaceState& st,
+static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, SubspaceState& st,
                         double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
     *ok = false;
     st.fail = SubspaceState::FAIL_NONE;
@@ -453,14 +492,14 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
         // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
         // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
-        TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)X, (double*)Q, N, p));
+        TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
         {
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
             const int q = cold ? 2 : 3;
             // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
             bool in_q = true;
             for (int t = 1; t < q && nt > 0; ++t) {
-                TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)(in_q ? Q : GQ), (double*)(in_q ? GQ : Q), N, nt));
+                TLSQ_TRY(op_apply(h, op, N, (const double*)(in_q ? Q : GQ), (double*)(in_q ? GQ : Q), nt));
                 in_q = !in_q;
             }
             if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -468,7 +507,7 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         bool used_cholqr = false;
         TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr));
         // Rayleigh-Ritz: H = Q' (G Q)
-        TLSQ_TRY(launch_symm_skinny(h, G, N, (const double*)Q, (double*)GQ, N, p));
+        TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
         int64_t sw = 0;
         TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
@@ -575,9 +614,8 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         return TLSQ_OK;
     }
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
-    TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+    void *Vg = nullptr, *Vs = nullptr;
     if (svp > 0) {
-        void *Vg, *Vs;
         TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
         TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
         std::vector<int32_t> sel((size_t)svp);
@@ -590,13 +628,26 @@ static int svd_subspace(Handle* h, const double* G, int64_t N, double inv_mu, Su
         double* dth;
         TLSQ_TRY(upload_sel_weights(h, aux, sel, th, &dsel, &dth));
         TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
-        TLSQ_TRY(launch_deflate(h, G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
-    } else {
-        TLSQ_HIP(h, hipMemcpyAsync(GD, G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
     }
     double lmax = 0.0;
     int steps = 0;
-    int lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    int lst;
+    if (!op.implicit()) {
+        TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+        if (svp > 0) TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
+        else TLSQ_HIP(h, hipMemcpyAsync(GD, op.G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    } else {
+        // the deflated operator as a product: w = G q - Vs (Vg' q)
+        void* cv;
+        TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(p * p, svp) * 8, &cv));
+        const LzApply apply = [&](const double* q, double* w) -> int {
+            TLSQ_TRY(op_apply(h, op, N, q, w, 1));
+            if (svp > 0) TLSQ_TRY(launch_deflate_vec(h, (const double*)Vs, (const double*)Vg, svp, q, (double*)cv, w, N));
+            return TLSQ_OK;
+        };
+        lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    }
     if (lst < 0) return lst;
     if (!(lmax * 1.5 < inv_mu * inv_mu)) {  // ambiguous: full solver decides (or a larger block)
         st.fail = SubspaceState::FAIL_CERT;
@@ -812,7 +863,9 @@ static int svd_precise_fast(Handle* h, const T* Z, int64_t M, int64_t N, T* scra
     if (!sub.valid || sub.hook_rank > 0) return TLSQ_OK;
     bool conv = false;
     sub.skip_certificate = true;
-    const int st = svd_subspace(h, G, N, inv_mu, sub, V_out, s, sweeps, &conv);
+    GramOp op;
+    op.G = G;
+    const int st = svd_subspace(h, op, N, inv_mu, sub, V_out, s, sweeps, &conv);
     sub.skip_certificate = false;
     if (st < 0) return st;
     if (!conv) return TLSQ_OK;
@@ -886,7 +939,22 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
     TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
     TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
     double norm2 = 0.0;
+    // Very wide problems: G = Z'Z is never formed (see GramOp).  The Gram costs M N^2 flops (lower triangle) per
+    // iteration, the ~8 products plus the Lanczos vectors of the implicit form ~130 M N p at the efficiency of the
+    // skinny kernels: measured break-even near N = 128 p (65536 x 4096, p = 80: 41 ms explicit, 58 ms implicit per
+    // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
+    static const int force_implicit = [] { const char* e = getenv("TLSQ_IMPLICIT_GRAM"); return e ? atoi(e) : -1; }();
+    const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
+    auto panel_op = [&](const T* P) {
+        GramOp o;
+        o.Z = P;
+        o.z_f32 = Prec<T>::f32;
+        o.M = M;
+        o.ldZ = M;
+        return o;
+    };
     if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
+    else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
     else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
     TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));                  // :178 norm(Y, Inf)
@@ -969,8 +1037,13 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             ++sub.full;
             ++n_precise;
         } else if (!precise) {
-        if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
-        else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+        GramOp op = panel_op(Z);
+        if (!implicit_gram) {
+            if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
+            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+            op = GramOp();
+            op.G = G;
+        }
         g_ready = false;
         pt.mark();
         if (hook_svd && k >= 2) {
@@ -978,10 +1051,10 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             SubspaceState rs;
             rs.hook_rank = sv;
             rs.hook_seed = seed + (uint64_t)k;
-            TLSQ_TRY(svd_subspace(h, G, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
+            TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
         } else if (use_subspace) {
-            TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+            TLSQ_TRY(svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
         }
         if (!fast_ok && use_subspace && !(hook_svd && k >= 2) && sub.fail != SubspaceState::FAIL_NONE) {
             // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
@@ -1007,7 +1080,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
                     }
                 }
                 sub.extra_steps = 10;
-                TLSQ_TRY(svd_subspace(h, G, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+                TLSQ_TRY(svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
                 sub.extra_steps = 0;
             }
         }
@@ -1103,7 +1176,7 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
             const bool precise_next = !large && !hook_svd && sigma_top > 0.0 &&
                                       1.0 / mu_next < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
-            if (!precise_next) {   // (the two-level decomposition forms its Gram matrices itself)
+            if (!precise_next && !implicit_gram) {   // (the two-level decomposition forms its Gram matrices itself)
                 double* Gn = nullptr;
                 TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
                 g_ready = true;
@@ -1141,10 +1214,12 @@ static int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const Resolved
             // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
             // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
             const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
-            TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
+            if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-8, &rn, stop_sigma));
+            else TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
-                TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
+                if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
+                else TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
                 cost = rn / d_norm;
             }
         }
@@ -2250,7 +2325,7 @@ int tlsq_k_gemm_nn_f64(tlsq_handle h, const double* Z, int64_t M, int64_t K, int
                        int64_t Q, int64_t ldW, double* C, int64_t ldC) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !W || !C || ldZ < M || ldW < K || ldC < M) return set_err(h, TLSQ_ERR_ARG, "gemm_nn: bad argument");
-    if (Q <= 32) return tsmm_mixed(h, Z, 0, ldZ, W, ldW, C, ldC, M, K, Q);   // the rebuild's factor GEMM (tall-skinny kernel)
+    if (Q <= 96) return tsmm_mixed(h, Z, 0, ldZ, W, ldW, C, ldC, M, K, Q);   // the rebuild's factor GEMM (tall-skinny kernel)
     return gemm_f64(h, true, false, W, ldW, Z, ldZ, C, ldC, Q, M, K, false);
 }
 int tlsq_k_gemm_nt_f64(tlsq_handle h, const double* T, int64_t M, int64_t K, int64_t ldT, const double* V,

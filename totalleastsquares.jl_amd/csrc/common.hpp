@@ -9,6 +9,7 @@
 #include <type_traits>
 #include <cmath>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -78,7 +79,7 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
+    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
 };
 
@@ -134,9 +135,12 @@ int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, doub
 // instantiated operand type pairs (A,B): (f64,f64), (f32,f32), (f64,f32); layouts (KC,KC), (KC,MN), (MN,MN).
 int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
                int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
-// T (M x r, fp64) = Z (M x K, fp32 or fp64) * W (K x r), r <= 32: Z streamed once, MFMA fed from global memory
+// T (M x r, fp64) = Z (M x K, fp32 or fp64) * W (K x r), r <= 96: Z streamed once, MFMA fed from global memory
 int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
                int64_t M, int64_t K, int64_t r);
+// Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
+int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
+               int64_t M, int64_t N, int64_t p);
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
 
 // ---------------- jacobi.hip ----------------
@@ -167,6 +171,10 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
 // estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.
 // accept_below > 0: also stop (status 0) as soon as 2.5 * estimate < accept_below after >= 16 steps.
 // stop_above > 0: also stop (status 0) as soon as the Ritz value (a lower bound of lambda_max) reaches stop_above.
+// the same for an operator given only as a product w = Op(q) on N-vectors (device pointers, handle's stream)
+using LzApply = std::function<int(const double* q, double* w)>;
+int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, int max_steps, double* lmax,
+                    int* steps_used, double accept_below = 0.0, double stop_above = 0.0);
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
                      double* lmax, int* steps_used, double accept_below = 0.0, double stop_above = 0.0);
 
@@ -201,6 +209,8 @@ int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t 
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
 int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p,
                     const double* skip_status = nullptr);
+int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r, const double* q, double* c, double* w,
+                       int64_t N);
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,

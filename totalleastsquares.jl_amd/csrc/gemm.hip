@@ -460,31 +460,86 @@ __global__ __launch_bounds__(256) void k_tsmm(const TA* __restrict__ Z, int64_t 
     }
 }
 
-// T (M x r, ldt, fp64) = Z (M x K, ldz; fp32 when z_f32) * W (K x r, ldw), r <= 32
+// T (M x r, ldt, fp64) = Z (M x K, ldz; fp32 when z_f32) * W (K x r, ldw), r <= 96
 int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
                int64_t M, int64_t K, int64_t r) {
     if (M <= 0 || r <= 0) return TLSQ_OK;
-    if (r > 32) return set_err(h, TLSQ_ERR_ARG, "tsmm: r > 32");
-    const bool wide = r > 16;
-    const int lw = wide ? 32 : 16;
+    if (r > 96) return set_err(h, TLSQ_ERR_ARG, "tsmm: r > 96");
+    const int nct = (int)((r + 15) / 16);
+    const int lw = 16 * nct;
     void* wt;
-    TLSQ_TRY(ws_get(h, WS_AUX4, (size_t)K * lw * 8, &wt));
+    TLSQ_TRY(ws_get(h, WS_OPW, (size_t)K * lw * 8, &wt));
     hipLaunchKernelGGL(k_pack_w, dim3((unsigned)std::min<int64_t>((K * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, W,
                        ldw, (int)K, (int)r, lw, (double*)wt);
-    const bool tall = M >= 65536;   // fewer than ~1000 workgroups of 64 rows would leave CUs idle: 32-row workgroups
-    const int rt = tall ? 4 : 2;
+    // rows per workgroup: 64 for tall panels, 32 otherwise (fewer than ~1000 workgroups would leave CUs idle); the
+    // wide forms (more than 32 columns) keep 16 rows so that the accumulators and the reduction buffer stay small
+    const bool tall = M >= 65536;
+    const int rt = nct > 2 ? 1 : (tall ? 4 : 2);
     const dim3 grid((unsigned)((M + 16 * rt - 1) / (16 * rt)));
 #define TS_LAUNCH(TA, NC, RTT)                                                                                      \
     hipLaunchKernelGGL((k_tsmm<TA, NC, RTT>), grid, dim3(256), 0, h->stream, (const TA*)Z, ldz, (const double*)wt,    \
                        Tout, ldt, M, (int)K, (int)r)
-    if (z_f32) {
-        if (wide) { if (tall) TS_LAUNCH(float, 2, 4); else TS_LAUNCH(float, 2, 2); }
-        else { if (tall) TS_LAUNCH(float, 1, 4); else TS_LAUNCH(float, 1, 2); }
-    } else {
-        if (wide) { if (tall) TS_LAUNCH(double, 2, 4); else TS_LAUNCH(double, 2, 2); }
-        else { if (tall) TS_LAUNCH(double, 1, 4); else TS_LAUNCH(double, 1, 2); }
+#define TS_TYPE(TA)                                                  \
+    switch (nct) {                                                   \
+        case 1: if (tall) TS_LAUNCH(TA, 1, 4); else TS_LAUNCH(TA, 1, 2); break; \
+        case 2: if (tall) TS_LAUNCH(TA, 2, 4); else TS_LAUNCH(TA, 2, 2); break; \
+        case 3: TS_LAUNCH(TA, 3, 1); break;                          \
+        case 4: TS_LAUNCH(TA, 4, 1); break;                          \
+        case 5: TS_LAUNCH(TA, 5, 1); break;                          \
+        default: TS_LAUNCH(TA, 6, 1); break;                         \
     }
+    if (z_f32) { TS_TYPE(float) } else { TS_TYPE(double) }
+#undef TS_TYPE
 #undef TS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// Y (N x pc, ld N) = Z' * T for a few columns (pc <= 8): one wave per column of Z (coalesced reads), T (M x pc) from L2.
+// The large-mode operator product G X = Z'(Z X) for Lanczos vectors and other narrow blocks (the 128 x 128-tile kernel
+// would spend 128/pc times the necessary MFMA work here).
+template <typename TA, int PC>
+__global__ __launch_bounds__(256) void k_zt_small(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ Tm,
+                                                  int64_t ldt, double* __restrict__ Y, int64_t ldy, int64_t M, int N,
+                                                  int pc) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const TA* z = Z + (int64_t)n * ldz;
+    double acc[PC];
+#pragma unroll
+    for (int c = 0; c < PC; ++c) acc[c] = 0.0;
+    for (int64_t m = lane; m < M; m += 64) {
+        const double zv = (double)z[m];
+#pragma unroll
+        for (int c = 0; c < PC; ++c)
+            if (c < pc) acc[c] += zv * Tm[m + (int64_t)c * ldt];
+    }
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+        if (c < pc) {
+            double v = acc[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) Y[n + (int64_t)c * ldy] = v;
+        }
+    }
+}
+
+// Y (N x p, ld N) = Z' * T,  Z: M x N (ldz, fp32 when z_f32), T: M x p (ldt, fp64)
+int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
+               int64_t M, int64_t N, int64_t p) {
+    if (p <= 0 || N <= 0) return TLSQ_OK;
+    if (p > 8)   // C[j + i*ldc] = sum_k A(i,k) B(j,k): A = T (P = p), B = Z (Q = N), K = M
+        return gemm_mixed(h, true, true, Tm, 0, ldt, Z, z_f32, ldz, Y, 0, ldy, p, N, M, false);
+    const dim3 grid((unsigned)((N + 3) / 4));
+    if (z_f32) {
+        if (p == 1) hipLaunchKernelGGL((k_zt_small<float, 1>), grid, dim3(256), 0, h->stream, (const float*)Z, ldz, Tm, ldt, Y, ldy, M, (int)N, (int)p);
+        else hipLaunchKernelGGL((k_zt_small<float, 8>), grid, dim3(256), 0, h->stream, (const float*)Z, ldz, Tm, ldt, Y, ldy, M, (int)N, (int)p);
+    } else {
+        if (p == 1) hipLaunchKernelGGL((k_zt_small<double, 1>), grid, dim3(256), 0, h->stream, (const double*)Z, ldz, Tm, ldt, Y, ldy, M, (int)N, (int)p);
+        else hipLaunchKernelGGL((k_zt_small<double, 8>), grid, dim3(256), 0, h->stream, (const double*)Z, ldz, Tm, ldt, Y, ldy, M, (int)N, (int)p);
+    }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

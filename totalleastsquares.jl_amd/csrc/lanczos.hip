@@ -273,4 +273,149 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
     return 1;
 }
 
+// ---- Lanczos on an operator that is only available as a product (large mode: G = Z'Z is never formed) ---------
+// One single-workgroup kernel per step does the vector part: alpha = q.w, w -= alpha q + beta_prev q_prev,
+// beta = ||w||, q_prev <- q, q <- w / beta; alpha/beta go to device arrays and are read back per chunk of steps.
+__global__ __launch_bounds__(1024) void k_lz_init(double* __restrict__ q, double* __restrict__ qprev, int N,
+                                                  double* __restrict__ st) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double nrm = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        unsigned int x = (unsigned int)i * 2654435761u + 12345u;
+        x ^= x >> 16;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        x *= 3266489917u;
+        x ^= x >> 16;
+        const double v = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+        q[i] = v;
+        qprev[i] = 0.0;
+        nrm += v * v;
+    }
+    nrm = wsum(nrm);
+    if (lane == 0) red[w] = nrm;
+    __syncthreads();
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const double inv = 1.0 / sqrt(tot);
+    for (int i = tid; i < N; i += 1024) q[i] *= inv;
+    if (tid == 0) {
+        st[0] = 0.0;   // beta_prev
+        st[1] = 0.0;   // breakdown
+        st[2] = 0.0;   // completed (alpha, beta) pairs
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_lz_vec(double* __restrict__ q, double* __restrict__ qprev,
+                                                 double* __restrict__ wv, int N, double* __restrict__ st,
+                                                 double* __restrict__ ab, int cap, int j) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (st[1] != 0.0) return;
+    double a = 0.0;
+    for (int i = tid; i < N; i += 1024) a += q[i] * wv[i];
+    a = wsum(a);
+    if (lane == 0) red[w] = a;
+    __syncthreads();
+    double alpha = 0.0;
+    for (int k = 0; k < 16; ++k) alpha += red[k];
+    __syncthreads();
+    const double beta_prev = st[0];
+    double nn = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const double v = wv[i] - alpha * q[i] - beta_prev * qprev[i];
+        wv[i] = v;
+        nn += v * v;
+    }
+    nn = wsum(nn);
+    if (lane == 0) red[w] = nn;
+    __syncthreads();
+    double b2 = 0.0;
+    for (int k = 0; k < 16; ++k) b2 += red[k];
+    const double beta = sqrt(b2);
+    __syncthreads();
+    if (tid == 0) {
+        ab[j] = alpha;
+        ab[cap + j] = beta;
+        st[2] = (double)(j + 1);
+        st[0] = beta;
+        if (!(beta > 1e-290)) st[1] = 1.0;
+    }
+    if (!(beta > 1e-290)) return;
+    const double inv = 1.0 / beta;
+    for (int i = tid; i < N; i += 1024) {
+        qprev[i] = q[i];
+        q[i] = wv[i] * inv;
+    }
+}
+
+int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, int max_steps, double* lmax,
+                    int* steps_used, double accept_below, double stop_above) {
+    if (N <= 0) {
+        *lmax = 0.0;
+        return TLSQ_OK;
+    }
+    if (max_steps > (int)N) max_steps = (int)N;
+    if (max_steps < 1) max_steps = 1;
+    const int cap = max_steps + 2;
+    if ((size_t)(2 * cap) * 8 + 64 > h->pinned_bytes) return 1;
+    void* stv;
+    TLSQ_TRY(ws_get(h, WS_LZOP, (8 + 3 * (size_t)N + 2 * (size_t)cap + 16) * 8, &stv));
+    double* st = (double*)stv;
+    double *q = st + 8, *qprev = q + N, *wv = qprev + N, *ab = wv + N;
+    hipLaunchKernelGGL(k_lz_init, dim3(1), dim3(1024), 0, h->stream, q, qprev, (int)N, st);
+    TLSQ_HIP(h, hipGetLastError());
+    std::vector<double> hab((size_t)2 * cap);
+    int done = 0;
+    double theta = 0.0;
+    int chunk = (accept_below > 0.0 || stop_above > 0.0) ? 4 : 16;
+    while (done < max_steps) {
+        const int n = std::min(chunk, max_steps - done);
+        for (int k = 0; k < n; ++k, ++done) {
+            TLSQ_TRY(apply(q, wv));
+            hipLaunchKernelGGL(k_lz_vec, dim3(1), dim3(1024), 0, h->stream, q, qprev, wv, (int)N, st, ab, cap, done);
+        }
+        TLSQ_HIP(h, hipGetLastError());
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, st, 64, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, ab, (size_t)2 * cap * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        double hs[8];
+        memcpy(hs, h->pinned, 64);
+        memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * cap * 8);
+        const int m = (int)hs[2];
+        const bool broke = hs[1] != 0.0;
+        if (m <= 0) {
+            if (broke) break;
+            continue;
+        }
+        const double* a = hab.data();
+        const double* b = hab.data() + cap;
+        double sm = 0.0;
+        theta = tridiag_lmax(a, b, m, &sm);
+        if (steps_used) *steps_used = m;
+        if (broke || m >= (int)N) {
+            *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        const double bound = fabs(b[m - 1]) * sm;
+        if (bound <= rel_tol * fabs(theta)) {
+            *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        if (stop_above > 0.0 && theta >= stop_above) {
+            *lmax = theta;
+            return TLSQ_OK;
+        }
+        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 8 && 5.0 * theta < accept_below) ||
+                                   (m >= 4 && 10.0 * theta < accept_below))) {
+            *lmax = theta > 0.0 ? theta : 0.0;
+            return TLSQ_OK;
+        }
+        if (chunk < 64) chunk *= 2;
+    }
+    *lmax = theta > 0.0 ? theta : 0.0;
+    return 1;
+}
+
 }  // namespace tlsq

@@ -711,4 +711,17 @@ int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const doubl
     return launch_ritz_resid(h, GX, X, theta, N, p, res);
 }
 
+// w -= Vs (Vg' q)  for N-vectors q, w and N x r panels Vs, Vg (the deflation term of the count certificate applied to
+// one Lanczos vector); c: r doubles of scratch
+int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r, const double* q, double* c, double* w,
+                       int64_t N) {
+    if (r <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((r + 3) / 4)), dim3(256), 0, h->stream, Vg, (int)r, q, 1, c, (int)N,
+                       (const double*)nullptr);
+    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)r * 8, h->stream, Vs, (int)r,
+                       (const double*)c, w, 1, (int)N, (const double*)nullptr);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 }  // namespace tlsq
