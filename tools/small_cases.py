@@ -1,0 +1,15 @@
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+import tlsq_amd
+from oracle import rpca_oracle as O
+eng = tlsq_amd.Engine(0)
+for (M, N, r) in ((500, 50, 5), (2000, 64, 6), (1000, 40, 4), (3000, 100, 8)):
+    D = O.synth_lowrank_sparse(M, N, r, seed=0)[0]
+    dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda(); dA = torch.empty_like(dD); dE = torch.empty_like(dD)
+    eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False)
+    dt = (time.perf_counter() - t0) / 5
+    print(f"{M}x{N}: iters={rep.iters_done} {dt*1e3:.2f} ms/solve {dt/rep.iters_done*1e6:.0f} us/iter full={rep.eig_full} fast={rep.eig_fast}")

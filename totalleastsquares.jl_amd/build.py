@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libtlsqhip.so")
-SOURCES = ["sweeps.hip", "gemm.hip", "jacobi.hip", "hankel.hip", "lanczos.hip", "subspace.hip", "cholesky.hip", "batched.hip", "complex.hip", "api.hip"]
+SOURCES = ["sweeps.hip", "gemm.hip", "jacobi.hip", "hankel.hip", "lanczos.hip", "subspace.hip", "cholesky.hip", "batched.hip", "complex.hip", "runtime.hip", "solver.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
 
@@ -29,7 +29,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "tlsq.h")]
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "internal.hpp"), os.path.join(ROOT, "include", "tlsq.h")]
     objs = []
     procs = []
     for s in SOURCES:

@@ -22,7 +22,7 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-struct Comm;  // RCCL state (api.hip)
+struct Comm;  // RCCL state (runtime.hip)
 
 struct Handle {
     int device = 0;
@@ -35,7 +35,7 @@ struct Handle {
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     // pinned staging ring for small host->device uploads (index lists, scale factors): the copy is asynchronous
-    // and the host may reuse its own buffer at once; see upload_async() in api.hip
+    // and the host may reuse its own buffer at once; see upload_async() in runtime.hip
     void* up_ring = nullptr;
     size_t up_bytes = 0, up_off = 0;
     Comm* comm = nullptr;

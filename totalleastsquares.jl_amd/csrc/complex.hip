@@ -6,7 +6,7 @@
 //        R(Z) = [ Re Z  -Im Z ]      (2M x 2N real)
 //               [ Im Z   Re Z ]
 // whose singular values are those of Z, each twice, and for which R(A B) = R(A) R(B), R(Z^H) = R(Z)^T: the Gram /
-// eigen / rebuild kernels of the real path apply unchanged (api.hip: rpca_core_complex groups the eigenvalue
+// eigen / rebuild kernels of the real path apply unchanged (solver.hip: rpca_core_complex groups the eigenvalue
 // pairs), and the left block column of R(A) is A.
 #include "common.hpp"
 

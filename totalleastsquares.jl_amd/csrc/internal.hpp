@@ -1,0 +1,156 @@
+// Declarations shared by runtime.hip, solver.hip and api.hip (the host side of libtlsqhip.so); the kernel launchers are
+// declared in common.hpp.
+#pragma once
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+#include "common.hpp"
+
+namespace tlsq {
+
+// ---- runtime.hip -------------------------------------------------------------------------------------------
+// in-place reduction over the row shards of a handle with a communicator (no-op otherwise)
+int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op);
+int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op);
+int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
+           hipMemcpyKind kind);
+double now_ms();
+// stream-ordered upload of a small host array through the pinned ring (src may be reused at once)
+int upload_async(Handle* h, void* dst, const void* src, size_t bytes);
+
+inline int check_handle(tlsq_handle h) { return h ? TLSQ_OK : TLSQ_ERR_ARG; }
+
+inline void reset_info(tlsq_rpca_info* info) {
+    if (!info) return;
+    double* ch = info->cost_hist;
+    int64_t* sh = info->svp_hist;
+    int64_t cap = info->hist_capacity;
+    memset(info, 0, sizeof(*info));
+    info->cost_hist = ch;
+    info->svp_hist = sh;
+    info->hist_capacity = cap;
+}
+
+// Phase marks of one ALM iteration: HIP events on the handle's stream, two banks so that an iteration's marks can be
+// read back while the next iteration is already queued (no stream-wide synchronisation just for the timing).
+struct PhaseTimer {
+    Handle* h;
+    bool on;
+    int bank = 0;
+    int n[2] = {0, 0};
+    explicit PhaseTimer(Handle* hh, bool enable) : h(hh), on(enable) {}
+    void mark() {
+        if (on && n[bank] < 16) (void)hipEventRecord(h->ev[bank * 16 + n[bank]++], h->stream);
+    }
+    // adds elapsed(ev[i], ev[i+1]) of bank b to *acc[i]; the bank's last event must have completed
+    void collect_bank(int b, double** acc) {
+        if (on && n[b] > 0) {
+            (void)hipEventSynchronize(h->ev[b * 16 + n[b] - 1]);
+            for (int i = 0; i + 1 < n[b]; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->ev[b * 16 + i], h->ev[b * 16 + i + 1]) == hipSuccess && acc[i])
+                    *acc[i] += ms;
+            }
+        }
+        n[b] = 0;
+    }
+    // read the PREVIOUS iteration's marks (long completed).  Best called while the GPU has plenty queued: the
+    // event queries cost host time
+    void collect_previous(double** acc) { collect_bank(bank ^ 1, acc); }
+    // end of an iteration: switch banks (collecting the other one first if nobody did)
+    void next_iteration(double** acc) {
+        collect_bank(bank ^ 1, acc);
+        bank ^= 1;
+    }
+    // after the loop: whatever is still pending
+    void finish(double** acc) {
+        collect_bank(bank ^ 1, acc);
+        collect_bank(bank, acc);
+    }
+};
+
+
+// ---- solver.hip --------------------------------------------------------------------------------------------
+// Largest Gram dimension the LDS-resident full Jacobi solvers handle.  Above it ("large mode") rpca relies on the
+// certified subspace iteration alone; see rpca_core.
+constexpr int64_t kFullEigMaxN = 2048;
+constexpr int64_t kGramMaxN = 16384;
+
+
+template <typename T>
+struct Prec {
+    static constexpr int f32 = std::is_same<T, float>::value ? 1 : 0;
+};
+
+
+// Decomposition of the Gram of Z: V (device, N x ncols, ld N), sigma (host, per column of V), order (descending)
+struct SmallSvd {
+    std::vector<double> sigma;   // per column of V
+    std::vector<int32_t> order;  // column indices sorted by sigma descending
+    int64_t ncols = 0;           // N for a full decomposition, p for a subspace one
+};
+
+inline void sort_desc(SmallSvd& s) {
+    s.order.resize(s.sigma.size());
+    std::iota(s.order.begin(), s.order.end(), 0);
+    std::stable_sort(s.order.begin(), s.order.end(),
+                     [&](int32_t a, int32_t b) { return s.sigma[a] > s.sigma[b]; });
+}
+
+
+struct ResolvedOpts {
+    double lambda, tol, rho;
+    int64_t maxrank, iters, m_global;
+    bool nonnegA, nonnegE, hankel, nukeA;
+};
+
+inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {
+    ResolvedOpts r;
+    r.m_global = (o && o->m_global > 0) ? o->m_global : M;
+    const int64_t mx = std::max(r.m_global, N);
+    r.lambda = (o && !std::isnan(o->lambda)) ? o->lambda : 1.0 / std::sqrt((double)mx);  // :157
+    r.maxrank = (o && o->maxrank > 0) ? o->maxrank : std::numeric_limits<int64_t>::max();  // :158
+    r.iters = (o && o->iters > 0) ? o->iters : 1000;                                     // :159
+    r.tol = (o && !std::isnan(o->tol)) ? o->tol : default_tol;                           // :160
+    r.rho = (o && !std::isnan(o->rho)) ? o->rho : 1.5;                                   // :161
+    r.nonnegA = o && o->nonnegA;
+    r.nonnegE = o && o->nonnegE;
+    r.hankel = o && o->hankel;
+    r.nukeA = o ? (o->nukeA != 0) : true;
+    return r;
+}
+
+
+// sigma_max of Z (device M x N, ld) through the Gram matrix in workspace slot gslot (the default `opnorm`)
+template <typename T>
+int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double* out, int64_t* sweeps,
+                double rel_tol = 1e-13, double stop_above_sigma = 0.0, int gslot = WS_G);
+// V (WS_V, all N vectors) / s of the Gram of Z: what tls! and the SSA truncation of lowrankfilter need
+template <typename T>
+int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s,
+                 int64_t* sweeps, PhaseTimer* pt);
+// Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'
+template <typename T>
+int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,
+                    const std::vector<int32_t>& sel, const std::vector<double>& g, T* Aout, int64_t ldA);
+// the ALM loop on device-resident contiguous panels (see solver.hip)
+template <typename T>
+int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& ro, const tlsq_rpca_opts* opts, T* A,
+              T* E, T* U_dev, double* S_host, double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info);
+int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                      const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
+                      tlsq_rpca_info* info);
+// staging of caller memory (host or device, any leading dimension) around rpca_core; wide problems are transposed
+template <typename T>
+int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts, T* A,
+               int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt, int64_t* sv,
+               tlsq_rpca_info* info);
+// x (n x q, ldx) from the right singular vectors: X V22 = -V21  (src/TotalLeastSquares.jl:65-69)
+int tls_partition_solve(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n, double* x, int64_t ldx);
+
+}  // namespace tlsq

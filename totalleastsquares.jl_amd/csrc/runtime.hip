@@ -1,0 +1,294 @@
+// Runtime of libtlsqhip.so: error reporting, the grow-only device workspace, the pinned upload ring, the RCCL
+// row-shard exchange (librccl is loaded with dlopen), and the handle / communicator entry points of include/tlsq.h.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "internal.hpp"
+
+namespace tlsq {
+
+// ------------------------------------------------------------------------------------------------
+// errors / workspace
+// ------------------------------------------------------------------------------------------------
+int set_err(Handle* h, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+int ws_get(Handle* h, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    DevBuf& b = h->ws[slot];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            TLSQ_HIP(h, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = (bytes + 255) & ~size_t(255);
+        TLSQ_HIP(h, hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL (loaded lazily; single-GPU use never touches it)
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static bool rccl_load() {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return false;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        dlclose(lib);
+        return false;
+    }
+    g_rccl.lib = lib;
+    return true;
+}
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+};
+
+#define TLSQ_NCCL(h, expr)                                                                     \
+    do {                                                                                       \
+        ncclResult_t _r = (expr);                                                              \
+        if (_r != ncclSuccess)                                                                 \
+            return set_err((h), TLSQ_ERR_COMM, "%s failed: %s", #expr,                         \
+                           g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error"); \
+    } while (0)
+
+// in-place sum of an N x N Gram over the row shards (the one real exchange of the path)
+int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
+    if (!h->comm) return TLSQ_OK;
+    TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
+    return TLSQ_OK;
+}
+
+int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op) {
+    if (!h->comm) return TLSQ_OK;
+    void* slot;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
+    double* d = reinterpret_cast<double*>(reinterpret_cast<char*>(slot) + 256);
+    TLSQ_HIP(h, hipMemcpyAsync(d, v, 8, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(comm_allreduce(h, d, 1, op));
+    TLSQ_HIP(h, hipMemcpyAsync(v, d, 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows,
+                  int64_t cols, size_t esz, hipMemcpyKind kind) {
+    if (rows <= 0 || cols <= 0) return TLSQ_OK;
+    if (ldd == rows && lds == rows) {
+        TLSQ_HIP(h, hipMemcpyAsync(dst, src, (size_t)rows * cols * esz, kind, h->stream));
+    } else {
+        TLSQ_HIP(h, hipMemcpy2DAsync(dst, (size_t)ldd * esz, src, (size_t)lds * esz, (size_t)rows * esz,
+                                     (size_t)cols, kind, h->stream));
+    }
+    return TLSQ_OK;
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+
+// Stream-ordered upload of a small host array through the pinned ring: no host synchronisation, and `src` may be
+// freed or overwritten as soon as this returns.  A slot is only reused after the ring has wrapped, and wrapping
+// synchronises the stream first.
+int upload_async(Handle* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return TLSQ_OK;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > h->up_bytes) {   // never the case for the index lists this is meant for
+        TLSQ_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
+    if (h->up_off + need > h->up_bytes) {
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        h->up_off = 0;
+    }
+    char* stage = reinterpret_cast<char*>(h->up_ring) + h->up_off;
+    memcpy(stage, src, bytes);
+    h->up_off += need;
+    TLSQ_HIP(h, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, h->stream));
+    return TLSQ_OK;
+}
+
+}  // namespace tlsq
+
+using namespace tlsq;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* tlsq_version(void) { return "tlsq-hip 0.1.0 (gfx950)"; }
+
+void tlsq_rpca_opts_default(tlsq_rpca_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->lambda = std::numeric_limits<double>::quiet_NaN();
+    o->tol = std::numeric_limits<double>::quiet_NaN();
+    o->rho = std::numeric_limits<double>::quiet_NaN();
+    o->maxrank = 0;
+    o->iters = 0;
+    o->nukeA = 1;
+    o->svd_mode = TLSQ_SVD_FULL;
+    o->opnorm_mode = TLSQ_OPNORM_EXACT;
+    o->opnorm_mvps = 10;
+    o->memory = TLSQ_MEM_HOST;
+}
+
+int tlsq_create(int device_id, tlsq_handle* out) {
+    if (!out) return TLSQ_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;  // no GPU: fail loudly
+    if (device_id < 0 || device_id >= ndev) return TLSQ_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return TLSQ_ERR_HIP;
+    tlsq_handle h = new (std::nothrow) tlsq_handle_s();
+    if (!h) return TLSQ_ERR_OOM;
+    h->device = device_id;
+    h->ws.resize(WS_COUNT);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return TLSQ_ERR_HIP;
+    }
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete h;
+            return TLSQ_ERR_HIP;
+        }
+    h->pinned_bytes = 1 << 16;
+    if (hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        return TLSQ_ERR_OOM;
+    }
+    h->up_bytes = 1 << 18;
+    if (hipHostMalloc(&h->up_ring, h->up_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipHostFree(h->pinned);
+        delete h;
+        return TLSQ_ERR_OOM;
+    }
+    *out = h;
+    return TLSQ_OK;
+}
+
+int tlsq_destroy(tlsq_handle h) {
+    if (!h) return TLSQ_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    tlsq_comm_destroy(h);
+    for (auto& b : h->ws)
+        if (b.p) (void)hipFree(b.p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->up_ring) (void)hipHostFree(h->up_ring);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return TLSQ_OK;
+}
+
+const char* tlsq_last_error(tlsq_handle h) { return h ? h->err.c_str() : "null handle"; }
+void* tlsq_stream(tlsq_handle h) { return h ? (void*)h->stream : nullptr; }
+int tlsq_synchronize(tlsq_handle h) {
+    TLSQ_TRY(check_handle(h));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+
+int tlsq_comm_unique_id(unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
+    if (!id) return TLSQ_ERR_ARG;
+    if (!rccl_load()) return TLSQ_ERR_COMM;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return TLSQ_ERR_COMM;
+    static_assert(sizeof(u) == TLSQ_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, TLSQ_UNIQUE_ID_BYTES);
+    return TLSQ_OK;
+}
+
+int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
+    TLSQ_TRY(check_handle(h));
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return set_err(h, TLSQ_ERR_ARG, "bad comm args");
+    tlsq_comm_destroy(h);
+    // a single rank needs no communicator (TLSQ_FORCE_COMM=1 creates one anyway: exercises the RCCL path on one GPU)
+    const char* force = getenv("TLSQ_FORCE_COMM");
+    if (nranks == 1 && !(force && force[0] == '1')) {
+        h->nranks = 1;
+        h->rank = 0;
+        return TLSQ_OK;
+    }
+    if (!rccl_load()) return set_err(h, TLSQ_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, TLSQ_UNIQUE_ID_BYTES);
+    h->comm = new Comm();
+    ncclResult_t r = g_rccl.CommInitRank(&h->comm->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        delete h->comm;
+        h->comm = nullptr;
+        return set_err(h, TLSQ_ERR_COMM, "ncclCommInitRank failed: %s",
+                       g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    h->nranks = nranks;
+    h->rank = rank;
+    return TLSQ_OK;
+}
+
+int tlsq_comm_destroy(tlsq_handle h) {
+    if (!h) return TLSQ_OK;
+    if (h->comm) {
+        if (h->comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm->comm);
+        delete h->comm;
+        h->comm = nullptr;
+    }
+    h->nranks = 1;
+    h->rank = 0;
+    return TLSQ_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,1446 @@
+// The inexact-ALM driver of rpca (src/robustPCA.jl:156-239 under /root/reference) and the small-matrix machinery
+// behind its SVD step: Gram / implicit operator, warm-started subspace iteration with a Lanczos count certificate,
+// dense Jacobi fall-backs, the two-level decomposition of late iterations, the low-rank rebuild, and the staging
+// of caller memory (rpca_entry).  All arithmetic on M x N data runs in the HIP kernels of sweeps.hip / gemm.hip /
+// jacobi.hip / subspace.hip; the host only does O(N) bookkeeping (rank count, sort, the q x q TLS partition solve).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "internal.hpp"
+
+namespace tlsq {
+
+// sqrt(lambda_max) of the Gram already sitting in G (N x N, ld N): Lanczos to the requested relative residual
+// bound, exact Jacobi eigenvalues as the fallback.  uses WS_B, WS_LAM.
+static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
+                             double stop_above_sigma = 0.0) {
+    double lmax = 0.0;
+    int steps = 0;
+    int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
+    if (st < 0) return st;
+    if (st == 0 || N > kFullEigMaxN) {   // large mode: no dense fallback; the Lanczos value after 1000 steps stands
+        *out = std::sqrt(lmax);
+        return TLSQ_OK;
+    }
+    void *B, *lam;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
+    int64_t sw = 0;
+    TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, nullptr, false, (double*)lam, &sw));
+    if (sweeps) *sweeps += sw;
+    std::vector<double> hl((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double mx = 0.0;
+    for (double v : hl) mx = v > mx ? v : mx;
+    *out = std::sqrt(mx);
+    return TLSQ_OK;
+}
+
+// sigma_max of Z (device M x N, ld) = the default `opnorm`; uses WS_G.
+template <typename T>
+int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double* out, int64_t* sweeps,
+                double rel_tol, double stop_above_sigma, int gslot) {
+    void* G;
+    TLSQ_TRY(ws_get(h, gslot, (size_t)N * N * 8, &G));
+    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    return sigma_max_of_gram(h, (const double*)G, N, rel_tol, out, sweeps, stop_above_sigma);
+}
+
+// The `opnorm = x -> rnorm(x, mvps)` hook of the reference's tests (test/runtests.jl:384-398,
+// RandomizedLinAlg.rnorm): probabilistic upper bound  alpha*sqrt(2/pi)*max_i ||Z w_i||,  w_i ~ N(0,I),
+// i = 1..mvps, alpha = 0.05^(-1/mvps)  (Halko, Martinsson, Tropp 2011, Lemma 4.1).  One skinny GEMM over Z.
+template <typename T>
+static int opnorm_power(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, int mvps, uint64_t seed,
+                        double* out) {
+    if (mvps < 1) mvps = 1;
+    if (mvps > 64) mvps = 64;
+    void *Om, *T1, *nn;
+    TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * mvps * 8, &Om));
+    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * mvps * 8, &T1));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 64) * 8, &nn));
+    TLSQ_TRY(launch_fill_gauss(h, (double*)Om, N * mvps, (unsigned int)(seed * 2654435761ull + 0x1234567u)));
+    TLSQ_TRY(gemm_mixed(h, true, false, Om, 0, N, Z, Prec<T>::f32, ld, T1, 0, M, mvps, M, N, false));
+    TLSQ_TRY(launch_colsumsq(h, (const double*)T1, M, M, mvps, (double*)nn));
+    TLSQ_TRY(comm_allreduce(h, (double*)nn, (size_t)mvps, ncclSum));
+    std::vector<double> hn((size_t)mvps);
+    TLSQ_HIP(h, hipMemcpyAsync(hn.data(), nn, (size_t)mvps * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double mx = 0.0;
+    for (double v : hn) mx = std::max(mx, v);
+    const double alpha = std::pow(0.05, -1.0 / (double)mvps);
+    *out = alpha * std::sqrt(2.0 / M_PI) * std::sqrt(mx);
+    return TLSQ_OK;
+}
+
+// G (WS_G) = Z'Z summed over the row shards
+template <typename T>
+static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out) {
+    void* G;
+    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    *G_out = (double*)G;
+    return TLSQ_OK;
+}
+
+// full eigen-decomposition of G by the block Jacobi solver: V in WS_V
+// does the full solver go through the Cholesky factor (zero columns for numerically-zero eigenvalues)?
+static bool chol_route(int64_t N) {
+    static const bool no_chol = [] { const char* e = getenv("TLSQ_NO_CHOL"); return e && e[0] == '1'; }();
+    return N > 64 && !no_chol;
+}
+
+static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps,
+                    bool allow_warm = false, int vslot = WS_V, bool need_all_vectors = false) {
+    void *B, *V, *lam;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
+    int64_t sw = 0;
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    s.sigma.resize((size_t)N);
+    if (chol_route(N) && !need_all_vectors) {
+        // Cholesky-preconditioned route: Jacobi on L = chol(G + delta I); far fewer sweeps on graded spectra and
+        // no eigenvector accumulation.  Vectors of numerically-zero eigenvalues come back as zero columns, which
+        // is fine for the ALM loop (only sigma_i >= 1/mu are used).
+        double delta = 0.0;
+        TLSQ_TRY(symeig_chol_f64(h, G, N, N, (double*)B, (double*)V, (double*)lam, &delta, &sw));
+        if (vslot == WS_V) h->warm_n = 0;
+        if (dbg) fprintf(stderr, "  full eig (chol) N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
+        if (sweeps) *sweeps += sw;
+        TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& v : s.sigma) v = std::sqrt(std::max(v * v - delta, 0.0));   // sigma(L)^2 = lambda + delta
+    } else {
+        // consecutive ALM iterations see nearly the same eigenvectors: reuse them (cold restart every 8th time so
+        // that rounding drift in the accumulated rotations cannot build up)
+        const bool warm = allow_warm && vslot == WS_V && h->warm_n == N && h->warm_uses < 8 && V == h->ws[WS_V].p;
+        TLSQ_TRY(symeig_f64(h, G, N, N, (double*)B, (double*)V, true, (double*)lam, &sw, false, warm));
+        if (vslot == WS_V) {
+            h->warm_n = N;
+            h->warm_uses = warm ? h->warm_uses + 1 : 0;
+        }
+        if (dbg) fprintf(stderr, "  full eig N=%lld warm=%d sweeps=%lld\n", (long long)N, (int)warm, (long long)sw);
+        if (sweeps) *sweeps += sw;
+        TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& v : s.sigma) v = std::sqrt(v);
+    }
+    s.ncols = N;
+    sort_desc(s);
+    *V_out = (double*)V;
+    return TLSQ_OK;
+}
+
+template <typename T>
+int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out,
+                        SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
+    double* G;
+    TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, ld, &G));
+    if (pt) pt->mark();
+    return eig_full(h, G, N, V_out, s, sweeps, false, WS_V, true);   // callers (tls!, SSA truncation) want every vector
+}
+
+// The N x N operator the small solvers work on: either the explicit Gram matrix G = Z'Z (summed over the row
+// shards), or - large mode, where forming G would cost far more than the few products the subspace solver needs
+// (2 M N^2 flops against 4 M N p per product) - the panel itself: G X = Z'(Z X), two streaming passes over Z.
+struct GramOp {
+    const double* G = nullptr;   // explicit (N x N, ld N)
+    const void* Z = nullptr;     // implicit: M x N panel (ld ldZ), fp32 when z_f32
+    int z_f32 = 0;
+    int64_t M = 0, ldZ = 0;
+    bool implicit() const { return G == nullptr; }
+};
+
+// Y (N x p, ld N) = G X
+static int op_apply(Handle* h, const GramOp& op, int64_t N, const double* X, double* Y, int64_t p) {
+    if (p <= 0) return TLSQ_OK;
+    if (!op.implicit()) return launch_symm_skinny(h, op.G, N, X, Y, N, p);
+    void* Tv;
+    TLSQ_TRY(ws_get(h, WS_OPT, (size_t)op.M * std::min<int64_t>(p, 96) * 8, &Tv));
+    for (int64_t c0 = 0; c0 < p; c0 += 96) {
+        const int64_t pc = std::min<int64_t>(96, p - c0);
+        TLSQ_TRY(tsmm_mixed(h, op.Z, op.z_f32, op.ldZ, X + (size_t)c0 * N, N, (double*)Tv, op.M, op.M, N, pc));
+        TLSQ_TRY(ztmm_mixed(h, op.Z, op.z_f32, op.ldZ, (const double*)Tv, op.M, Y + (size_t)c0 * N, N, op.M, N, pc));
+    }
+    TLSQ_TRY(comm_allreduce(h, Y, (size_t)N * p, ncclSum));
+    return TLSQ_OK;
+}
+
+// sigma_max of the panel behind an implicit operator (Lanczos on Z'Z through products); the same stopping rules
+// as sigma_max_of_gram
+static int sigma_max_of_op(Handle* h, const GramOp& op, int64_t N, double rel_tol, double* out,
+                           double stop_above_sigma = 0.0) {
+    double lmax = 0.0;
+    int steps = 0;
+    const LzApply apply = [&](const double* q, double* w) -> int { return op_apply(h, op, N, q, w, 1); };
+    const int st = lanczos_lmax_op(h, N, apply, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
+    if (st < 0) return st;
+    *out = std::sqrt(lmax);   // (no dense fallback in large mode: the value after 1000 steps stands)
+    return TLSQ_OK;
+}
+
+// ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
+struct SubspaceState {
+    bool valid = false;
+    bool allow_cold = true;
+    int64_t p = 0;       // columns of X (WS_SX, N x p)
+    int64_t ntop = 0;    // the first ntop columns of X were >= 1/mu in the iteration that produced them
+    // hook mode (`svd = rsvd`-style user hook, src/robustPCA.jl:195-197): rank-`hook_rank` randomized SVD from a
+    // fresh random block, fixed number of passes, no convergence test and no count certificate
+    int64_t hook_rank = 0;
+    uint64_t hook_seed = 0;
+    int64_t fast = 0, full = 0, steps = 0;
+    // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
+    enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4 };
+    int fail = FAIL_NONE;
+    bool skip_certificate = false;   // the caller certifies the count itself (late iterations, see svd_precise_fast)
+    int64_t cold_p = 18;   // block size of a cold start
+    int extra_steps = 0;   // added to the step budget (retries in large mode)
+};
+
+// one stream-ordered upload of an index list and a weight list of the same length r into `aux`
+// (layout: int32 sel[r], padding to 8 bytes, double w[r]); returns the two device pointers
+static int upload_sel_weights(Handle* h, void* aux, const std::vector<int32_t>& sel, const std::vector<double>& w,
+                              int32_t** dsel, double** dw) {
+    const size_t r = sel.size();
+    const size_t off = ((r * 4 + 7) / 8) * 8;
+    std::vector<char> buf(off + r * 8);
+    memcpy(buf.data(), sel.data(), r * 4);
+    memcpy(buf.data() + off, w.data(), r * 8);
+    TLSQ_TRY(upload_async(h, aux, buf.data(), buf.size()));
+    *dsel = (int32_t*)aux;
+    *dw = (double*)((char*)aux + off);
+    return TLSQ_OK;
+}
+
+// upload a column selection and gather X = V[:, sel]
+static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
+    const int64_t r = (int64_t)sel.size();
+    if (r == 0) return TLSQ_OK;
+    void* aux;
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16 + 64, &aux));
+    TLSQ_TRY(upload_async(h, aux, sel.data(), (size_t)r * 4));
+    TLSQ_TRY(launch_gather_scale(h, V, N, (const int32_t*)aux, nullptr, r, nullptr, X));
+    return TLSQ_OK;
+}
+
+// Try to get the sigma_i >= inv_mu pairs of G from the block carried in st.  *ok = false -> caller must run
+// the full solver.  On success V_out (N x p) / s describe the Ritz pairs (all p of them; the wanted ones are
+// converged, the rest only bound the count).
+static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, SubspaceState& st,
+                        double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
+    *ok = false;
+    st.fail = SubspaceState::FAIL_NONE;
+    const bool hook = st.hook_rank > 0;
+    const bool cold = hook || !st.valid;
+    if (hook) {
+        st.p = std::min<int64_t>(std::min<int64_t>(st.hook_rank + 10, subspace_max_block(N)), N);
+        if (st.p < st.hook_rank || st.p < 3) return TLSQ_OK;   // block too large for this path: full solver + truncation
+    } else if (cold) {
+        // no block yet (first ALM iteration): start from a pseudo-random block of 10 + 8 columns — 10 is the
+        // reference's initial rank guess `sv = 10` (src/robustPCA.jl:184)
+        if (!st.allow_cold) return TLSQ_OK;
+        st.p = std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(18, st.cold_p), subspace_max_block(N)), N);
+        if (st.p < 3) return TLSQ_OK;
+    }
+    if (st.p < 3) return TLSQ_OK;
+    st.fail = SubspaceState::FAIL_NONE;
+    const int64_t p = st.p;
+    void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
+    {   // the block lives in WS_SX across calls and may grow: reserve the largest block once (ws_get reallocates)
+        const int64_t pcap = std::max<int64_t>(p, std::min<int64_t>(subspace_max_block(N), N));
+        TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * pcap * 8, &X));
+        TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * pcap * 8, &XN));
+    }
+    if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, hook ? (unsigned int)(st.hook_seed * 2654435761ull + 77u) : 0x9E3779B9u));
+    TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
+    TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
+    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * p * 8, &XN));
+    TLSQ_TRY(ws_get(h, WS_SGX, (size_t)N * p * 8, &GX));
+    TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
+    TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
+    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
+    double* theta_dev = (double*)lam;
+    double* res_dev = theta_dev + p;
+    double* stat_dev = res_dev + p;
+    double* lamH_dev = stat_dev + 8;
+    std::vector<double> host((size_t)2 * p + 8);
+    const int max_steps = hook ? 2 : (cold ? 30 : 10) + st.extra_steps;
+    const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
+    int64_t svp = 0;
+    bool conv = false;
+    double prev_maxres = 0.0;
+    bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
+    for (int step = 0; step < max_steps; ++step) {
+        ++st.steps;
+        // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
+        // vectors; q-1 extra multiplications of those columns cost one skinny GEMM each and raise their
+        // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
+        // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
+        // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
+        TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
+        {
+            const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
+            const int q = cold ? 2 : 3;
+            // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
+            bool in_q = true;
+            for (int t = 1; t < q && nt > 0; ++t) {
+                TLSQ_TRY(op_apply(h, op, N, (const double*)(in_q ? Q : GQ), (double*)(in_q ? GQ : Q), nt));
+                in_q = !in_q;
+            }
+            if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
+        }
+        bool used_cholqr = false;
+        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr));
+        // Rayleigh-Ritz: H = Q' (G Q)
+        TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
+        TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
+        int64_t sw = 0;
+        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
+        if (sweeps) *sweeps += sw;
+        // X' = Q S,  G X' = (G Q) S
+        // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
+        // Ritz values did not come out in descending order)
+        TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X, (double*)GX,
+                                    theta_dev, res_dev, N, p));
+        TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
+                                   h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (used_cholqr && host[2 * p + 1] != 0.0) {
+            // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
+            force_cgs2 = true;
+            --step;
+            --st.steps;
+            continue;
+        }
+        s.sigma.resize((size_t)p);
+        double tmax = 0.0;
+        bool finite = true;
+        for (int64_t i = 0; i < p; ++i) {
+            const double t = host[i];
+            if (!std::isfinite(t) || !std::isfinite(host[p + i])) finite = false;
+            tmax = std::max(tmax, t);
+            s.sigma[i] = std::sqrt(std::max(t, 0.0));
+        }
+        if (!finite) {
+            st.valid = false;
+            st.fail = SubspaceState::FAIL_NUMERIC;
+            break;
+        }
+        s.ncols = p;
+        sort_desc(s);
+        // keep the block sorted by Ritz value: X = X'[:, order]
+        {
+            std::vector<double> res_sorted((size_t)p), th_sorted((size_t)p), sg_sorted((size_t)p);
+            for (int64_t i = 0; i < p; ++i) {
+                res_sorted[i] = host[p + s.order[i]];
+                th_sorted[i] = host[s.order[i]];
+                sg_sorted[i] = s.sigma[s.order[i]];
+            }
+            bool sorted = true;
+            for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[i] == (int32_t)i;
+            if (!sorted) {
+                TLSQ_HIP(h, hipMemcpyAsync(XN, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+                TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
+                TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
+                                             (double*)X));
+            }
+            for (int64_t i = 0; i < p; ++i) {
+                host[i] = th_sorted[i];
+                host[p + i] = res_sorted[i];
+                s.sigma[i] = sg_sorted[i];
+            }
+            std::iota(s.order.begin(), s.order.end(), 0);
+        }
+        svp = 0;
+        for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
+        if (hook) {
+            if (step + 1 < max_steps) continue;
+            s.ncols = std::min<int64_t>(st.hook_rank, p);   // rank-sv truncation, like `svd(Z, sv)`
+            *V_out = (double*)X;
+            *ok = true;
+            return TLSQ_OK;
+        }
+        if (svp > p - 2) {  // the block may not contain every sigma >= 1/mu: full solver, or a larger block
+            st.fail = SubspaceState::FAIL_SMALL;
+            break;
+        }
+        bool good = true;
+        double maxres = 0.0;
+        for (int64_t i = 0; i < svp; ++i) {
+            good = good && (host[p + i] <= 2e-13 * tmax);
+            maxres = std::max(maxres, host[p + i]);
+        }
+        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        if (dbg) {
+            int sd = -1;
+            void* scal = h->ws[WS_SCAL].p;
+            (void)hipMemcpy(&sd, (char*)scal + 136, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "  [small eig sweeps %d]", sd);
+        }
+        if (dbg)
+            fprintf(stderr, "  subspace step %d: p=%lld ntop=%lld svp=%lld maxres/tmax=%.3e tail/tau=%.3f cold=%d\n", step,
+                    (long long)p, (long long)ntop, (long long)svp, maxres / tmax,
+                    svp < p ? s.sigma[s.order[svp]] / inv_mu : 0.0, (int)cold);
+        if (good) {
+            conv = true;
+            break;
+        }
+        // hopeless (no spectral gap behind the block): stop early and let the full solver run
+        if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
+        prev_maxres = maxres;
+    }
+    if (!conv) {
+        if (st.fail == SubspaceState::FAIL_NONE) st.fail = SubspaceState::FAIL_NOCONV;
+        return TLSQ_OK;
+    }
+    if (st.skip_certificate) {
+        *V_out = (double*)X;
+        *ok = true;
+        return TLSQ_OK;
+    }
+    // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
+    void *Vg = nullptr, *Vs = nullptr;
+    if (svp > 0) {
+        TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
+        TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> th((size_t)svp);
+        for (int64_t i = 0; i < svp; ++i) {
+            sel[i] = s.order[i];
+            th[i] = host[sel[i]];
+        }
+        int32_t* dsel;
+        double* dth;
+        TLSQ_TRY(upload_sel_weights(h, aux, sel, th, &dsel, &dth));
+        TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
+    }
+    double lmax = 0.0;
+    int steps = 0;
+    int lst;
+    if (!op.implicit()) {
+        TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+        if (svp > 0) TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
+        else TLSQ_HIP(h, hipMemcpyAsync(GD, op.G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    } else {
+        // the deflated operator as a product: w = G q - Vs (Vg' q)
+        void* cv;
+        TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(p * p, svp) * 8, &cv));
+        const LzApply apply = [&](const double* q, double* w) -> int {
+            TLSQ_TRY(op_apply(h, op, N, q, w, 1));
+            if (svp > 0) TLSQ_TRY(launch_deflate_vec(h, (const double*)Vs, (const double*)Vg, svp, q, (double*)cv, w, N));
+            return TLSQ_OK;
+        };
+        lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    }
+    if (lst < 0) return lst;
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) {  // ambiguous: full solver decides (or a larger block)
+        st.fail = SubspaceState::FAIL_CERT;
+        return TLSQ_OK;
+    }
+    *V_out = (double*)X;
+    *ok = true;
+    return TLSQ_OK;
+}
+
+// Factors of the thresholded low-rank matrix A = Z * V[:,sel] * diag(g) * V[:,sel]' (r = sel.size() columns):
+// Tm (M x r, ld M, fp64, WS_T) = Z * V[:,sel] * diag(g) and Vs (N x r, ld N, WS_VS) = V[:,sel].  r = 0: both nullptr.
+template <typename T>
+static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,
+                           const std::vector<int32_t>& sel, const std::vector<double>& g, const double** Tm_out,
+                           const double** Vs_out) {
+    const int64_t r = (int64_t)sel.size();
+    *Tm_out = nullptr;
+    *Vs_out = nullptr;
+    if (r == 0) return TLSQ_OK;
+    void *Vg, *Vs, *T1, *aux;
+    TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * r * 8, &Vg));
+    TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
+    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T1));
+    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
+    int32_t* dsel;
+    double* dg;
+    TLSQ_TRY(upload_sel_weights(h, aux, sel, g, &dsel, &dg));
+    TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
+    // T (M x r, fp64) = Z * Vg
+    static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
+    if (r <= 32 && !no_tsmm) {
+        TLSQ_TRY(tsmm_mixed(h, Z, Prec<T>::f32, ldZ, (const double*)Vg, N, (double*)T1, M, M, N, r));
+    } else {
+        TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));
+    }
+    *Tm_out = (const double*)T1;
+    *Vs_out = (const double*)Vs;
+    return TLSQ_OK;
+}
+
+// Aout (M x N, ldA) = Tm * Vs'   (r = 0  =>  A = 0: mul! with inner dimension 0, src/robustPCA.jl:207-208)
+template <typename T>
+static int rebuild_from_factors(Handle* h, const double* Tm, const double* Vs, int64_t M, int64_t N, int64_t r,
+                                T* Aout, int64_t ldA) {
+    if (r == 0) {
+        TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
+        return TLSQ_OK;
+    }
+    TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, Tm, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
+    return TLSQ_OK;
+}
+
+// Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'
+template <typename T>
+int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
+                           const double* V, const std::vector<int32_t>& sel,
+                           const std::vector<double>& g, T* Aout, int64_t ldA) {
+    const double *Tm, *Vs;
+    TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, ldZ, V, sel, g, &Tm, &Vs));
+    return rebuild_from_factors<T>(h, Tm, Vs, M, N, (int64_t)sel.size(), Aout, ldA);
+}
+
+// Carry the dominant block (svp + pad Ritz/eigen vectors, sorted) to the next ALM iteration: WS_SX = V[:, top].
+// Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
+static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
+                       SubspaceState& sub) {
+    static const int64_t pad_min = [] { const char* e = getenv("TLSQ_PAD"); return (int64_t)(e ? atoi(e) : 4); }();
+    int64_t pad = std::max<int64_t>(pad_min, svp / 4);
+    // up to 64 columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small); beyond that
+    // it costs ~1 ms per step: give up some padding to stay below when the rank allows
+    if (svp + pad > 64 && svp + pad_min <= 64) pad = 64 - svp;
+    int64_t want = std::min<int64_t>(N, svp + pad);
+    if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
+    if (want > pmax || want < 3) {
+        sub.valid = false;
+        // rank beyond the largest block: cold starts would only find that out again - the dense solver serves the
+        // next iterations until the rank fits (this function is called after every one of them)
+        sub.allow_cold = want < 3;
+        return TLSQ_OK;
+    }
+    sub.allow_cold = true;
+    // the sorted vectors we have (a subspace result only carries p of them); any missing pad columns are
+    // pseudo-random — the next iteration's CGS2 orthogonalises them against the rest
+    const int64_t have = std::min<int64_t>(want, s.ncols);
+    std::vector<int32_t> keep((size_t)have);
+    bool identity = true;
+    for (int64_t p = 0; p < have; ++p) {
+        keep[p] = s.order[p];
+        identity = identity && keep[p] == (int32_t)p;
+    }
+    if (identity && h->ws[WS_SX].p && V == (const double*)h->ws[WS_SX].p) {
+        // the usual case: V is the sorted block the subspace solver left in WS_SX - its leading columns stay where
+        // they are, only missing pad columns are (re)filled
+        if (have < want)
+            TLSQ_TRY(launch_fill_hash(h, (double*)h->ws[WS_SX].p + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
+        sub.p = want;
+        sub.ntop = svp;
+        sub.valid = true;
+        return TLSQ_OK;
+    }
+    void *tmp, *X;
+    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * want * 8, &tmp));
+    TLSQ_TRY(gather_cols(h, V, N, keep, (double*)tmp));          // out of place (V may be WS_SX itself)
+    if (have < want) TLSQ_TRY(launch_fill_hash(h, (double*)tmp + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
+    TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * want * 8, &X));
+    TLSQ_HIP(h, hipMemcpyAsync(X, tmp, (size_t)N * want * 8, hipMemcpyDeviceToDevice, h->stream));
+    sub.p = want;
+    sub.ntop = svp;
+    sub.valid = true;
+    return TLSQ_OK;
+}
+
+// ---- two-level ("precise") decomposition for late ALM iterations ------------------------------------
+// The plain Gram route resolves singular values only down to ~sqrt(N eps) sigma_max.  When the threshold
+// 1/mu approaches that level (after ~33 iterations; mu is capped at 1e7 mu_0, src/robustPCA.jl:183) the
+// spectrum is split:  level 1 = eigenpairs of G = Z'Z with sigma >= 1e-3 sigma_max (accurate in the plain
+// route);  level 2 = eigenpairs of the Gram matrix of the explicitly deflated panel
+//     Z_perp = Z - (Z V_B) V_B'          (computed in the working precision, written to `scratch`)
+// whose own noise floor is sqrt(N eps) * 1e-3 sigma_max ~ 1e-9 sigma_max — below the smallest threshold the
+// reference can reach (0.8e-7 ||D||_2).  Both levels use the full Jacobi solver.  On return Vc (WS_VC, N x
+// s.ncols) holds [V_B, tail vectors] sorted by singular value; s.ncols counts only what may matter (all of
+// level 1, and the level-2 pairs above `keep_above`).
+template <typename T>
+static int svd_two_level(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double keep_above,
+                         double** V_out, SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
+    double* G = nullptr;
+    TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+    if (pt) pt->mark();
+    double* V1 = nullptr;
+    SmallSvd s1;
+    TLSQ_TRY(eig_full(h, G, N, &V1, s1, sweeps, false, WS_V));
+    const double top = s1.sigma[s1.order[0]];
+    std::vector<int32_t> big;
+    for (int64_t i = 0; i < N; ++i)
+        if (s1.sigma[s1.order[i]] >= 1e-3 * top && s1.sigma[s1.order[i]] > 0.0) big.push_back(s1.order[i]);
+    const int64_t nb = (int64_t)big.size();
+    void* Vc;
+    TLSQ_TRY(ws_get(h, WS_VC, (size_t)N * N * 8, &Vc));
+    s.sigma.clear();
+    if (nb > 0) TLSQ_TRY(gather_cols(h, V1, N, big, (double*)Vc));
+    for (int64_t i = 0; i < nb; ++i) s.sigma.push_back(s1.sigma[big[i]]);
+    if (nb < N) {
+        // Z_perp = Z - (Z V_B) V_B'
+        const T* Zp = Z;
+        if (nb > 0) {
+            void* T1;
+            TLSQ_TRY(ws_get(h, WS_T, (size_t)M * nb * 8, &T1));
+            TLSQ_TRY(gemm_mixed(h, true, false, Vc, 0, N, Z, Prec<T>::f32, M, T1, 0, M, nb, M, N, false));
+            TLSQ_TRY(gemm_mixed(h, false, false, Vc, 0, N, T1, 0, M, scratch, Prec<T>::f32, M, N, M, nb, false));
+            TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
+            Zp = scratch;
+        }
+        double* G2 = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, Zp, M, N, M, &G2));
+        double* V2 = nullptr;
+        SmallSvd s2;
+        TLSQ_TRY(eig_full(h, G2, N, &V2, s2, sweeps, false, WS_V2));
+        // level-2 pairs, largest first; the nb smallest ones are the deflated directions
+        std::vector<int32_t> tail;
+        const double top2 = s2.sigma[s2.order[0]];
+        const double res2 = std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * top2;
+        for (int64_t i = 0; i < N - nb; ++i) {
+            const double sg = s2.sigma[s2.order[i]];
+            if (sg >= keep_above && sg >= res2 && sg < 1e-3 * top * 1.01) tail.push_back(s2.order[i]);
+        }
+        if (!tail.empty()) {
+            TLSQ_TRY(gather_cols(h, V2, N, tail, (double*)Vc + (size_t)N * nb));
+            for (size_t i = 0; i < tail.size(); ++i) s.sigma.push_back(s2.sigma[tail[i]]);
+        }
+    }
+    s.ncols = (int64_t)s.sigma.size();
+    s.order.resize((size_t)s.ncols);
+    std::iota(s.order.begin(), s.order.end(), 0);   // already sorted: level 1 descending, then level 2 descending
+    *V_out = (double*)Vc;
+    return TLSQ_OK;
+}
+
+// Late iterations, cheap case.  Most problems that reach the "precise" regime (1/mu within ~5x of the resolution of
+// the plain Gram route) are clean: nothing of Z lies between the block of sigma >= 1/mu and rounding noise.  Then
+// two dense decompositions are not needed.  The carried block is refined on G as usual (its pairs are accurate),
+// but the COUNT is certified on the explicitly deflated panel Z_perp = Z - (Z V_svp) V_svp' (written to
+// `scratch`), whose Gram matrix resolves singular values down to ~1e-9 sigma_max: Lanczos must put
+// lambda_max(Z_perp' Z_perp) clearly below (1/mu)^2.  Anything else (no block, no convergence, a value near the
+// threshold outside the block) -> *ok = false and svd_two_level decides.
+template <typename T>
+static int svd_precise_fast(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double inv_mu,
+                            SubspaceState& sub, const double* G, double** V_out, SmallSvd& s, int64_t* sweeps,
+                            bool* ok) {
+    *ok = false;
+    if (!sub.valid || sub.hook_rank > 0) return TLSQ_OK;
+    bool conv = false;
+    sub.skip_certificate = true;
+    GramOp op;
+    op.G = G;
+    const int st = svd_subspace(h, op, N, inv_mu, sub, V_out, s, sweeps, &conv);
+    sub.skip_certificate = false;
+    if (st < 0) return st;
+    if (!conv) return TLSQ_OK;
+    int64_t svp = 0;
+    for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
+    if (svp > s.ncols - 2) return TLSQ_OK;
+    const T* Zp = Z;
+    if (svp > 0) {
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> ones((size_t)svp, 1.0);
+        for (int64_t i = 0; i < svp; ++i) sel[i] = s.order[i];
+        const double *Tm, *Vs;
+        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, *V_out, sel, ones, &Tm, &Vs));
+        TLSQ_TRY(rebuild_from_factors<T>(h, Tm, Vs, M, N, svp, scratch, M));
+        TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
+        Zp = scratch;
+    }
+    void* G2;
+    TLSQ_TRY(ws_get(h, WS_G2, (size_t)N * N * 8, &G2));
+    TLSQ_TRY(gram_any(h, Zp, Prec<T>::f32, M, N, M, (double*)G2, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G2, (size_t)N * N, ncclSum));
+    double lmax = 0.0;
+    int steps = 0;
+    const int lst = lanczos_lmax_f64(h, (const double*)G2, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+    if (lst < 0) return lst;
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;
+    *ok = true;
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the ALM loop on device-resident, contiguous (ld = M) panels D, A, E of element type T (fp64 or fp32).
+// The small N x N work (Gram matrices, eigenvectors, singular values) is always fp64.
+// Vt_host (d x N, ld ldVt, fp64) / S_host (d, fp64) / U_dev (M x d, ld M, T) optional.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                     const tlsq_rpca_opts* opts, T* A, T* E, T* U_dev, double* S_host,
+                     double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info) {
+    const int64_t n = M * N;
+    const bool timing = info != nullptr;
+    void *Yv, *Zv, *Rv;
+    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * sizeof(T), &Yv));
+    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
+    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
+    T *Y = (T*)Yv, *R = (T*)Rv;
+    // E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
+    // must survive in case iteration k is the last one
+    void *E2v, *Z2v;
+    TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
+    TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+    T* Ebuf[2] = {E, (T*)E2v};
+    T* Zbuf[2] = {(T*)Zv, (T*)Z2v};
+    int cur = 0;                 // index of the buffers holding E_k, Z_k
+    bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
+    static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
+    static const bool no_fuse_rebuild = [] { const char* e = getenv("TLSQ_NO_FUSED_REBUILD"); return e && e[0] == '1'; }();
+    const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
+    int64_t r_last = 0;
+    bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
+    double prev_lower = 0.0;                               // Frobenius lower bound of the previous iteration's cost
+    int64_t n_rskip = 0;
+    static const double rskip_margin = [] { const char* e = getenv("TLSQ_RSKIP_MARGIN"); return e ? atof(e) : 8.0; }();
+    int64_t sweeps = 0;
+    const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
+    const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
+    const int mvps = opts && opts->opnorm_mvps > 0 ? opts->opnorm_mvps : 10;
+    const uint64_t seed = opts ? opts->seed : 0;
+
+    // ---- setup, src/robustPCA.jl:171-184 ----
+    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
+    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
+    double norm2 = 0.0;
+    // Very wide problems: G = Z'Z is never formed (see GramOp).  The Gram costs M N^2 flops (lower triangle) per
+    // iteration, the ~8 products plus the Lanczos vectors of the implicit form ~130 M N p at the efficiency of the
+    // skinny kernels: measured break-even near N = 128 p (65536 x 4096, p = 80: 41 ms explicit, 58 ms implicit per
+    // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
+    static const int force_implicit = [] { const char* e = getenv("TLSQ_IMPLICIT_GRAM"); return e ? atoi(e) : -1; }();
+    const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
+    auto panel_op = [&](const T* P) {
+        GramOp o;
+        o.Z = P;
+        o.z_f32 = Prec<T>::f32;
+        o.M = M;
+        o.ldZ = M;
+        return o;
+    };
+    if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
+    else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
+    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps));                   // :177 opnorm(Y), Y = copy(D)
+    double maxabs = 0.0;
+    TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));                  // :178 norm(Y, Inf)
+    TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
+    const double lam = ro.lambda;
+    const double norminf = maxabs / lam;
+    const double dual_norm = std::max(norm2, norminf);             // :179
+    const double d_norm = norm2;                                   // :180
+    TLSQ_TRY(launch_div_scalar<T>(h, D, Y, n, (T)dual_norm));      // :181
+    double mu = 1.25 / norm2;                                      // :182
+    const double mubar = mu * 1.0e7;                               // :183
+    int64_t sv = 10, svp = 10;                                     // :184
+    if (info) {
+        info->d_norm = d_norm;
+        info->iters_done = 0;
+        info->converged = 0;
+    }
+    SmallSvd s;
+    double* V = nullptr;
+    // warm-started subspace iteration (falls back to the full Jacobi solver whenever it cannot certify the
+    // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
+    SubspaceState sub;
+    const int64_t pmax = subspace_max_block(N);
+    const char* force_full = getenv("TLSQ_FULL_EIG");
+    // Large mode (N > 2048): the full Jacobi solvers do not apply (their column blocks live in LDS); every SVD step
+    // has to be served by the certified subspace iteration, whose block is enlarged on demand.  Ranks beyond
+    // the largest block (subspace_max_block) are reported as TLSQ_ERR_UNSUPPORTED, and the two-level refinement
+    // of very late iterations is not available.
+    const bool large = N > kFullEigMaxN;
+    const bool use_subspace = large || (!hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24);
+    bool v_is_full = false, prev_full = false;
+    double sigma_top_prev = 0.0;
+    int64_t n_precise = 0;
+    h->warm_n = 0;   // nothing from an earlier call is reused
+    double cost = std::numeric_limits<double>::quiet_NaN();
+    bool converged = false;
+    void* meanws = nullptr;
+    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * sizeof(T), &meanws));
+
+    PhaseTimer pt(h, timing);
+    double zero_sink = 0.0;
+    // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | next iteration's Gram queued
+    // behind the sweep (booked under gram) | cost evaluation
+    double* acc[8] = {info ? &info->ms_shrink : &zero_sink, info ? &info->ms_gram : &zero_sink,
+                      info ? &info->ms_eig : &zero_sink,    info ? &info->ms_rebuild : &zero_sink,
+                      info ? &info->ms_update : &zero_sink, info ? &info->ms_gram : &zero_sink,
+                      info ? &info->ms_opnorm : &zero_sink, nullptr};
+    bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
+    const double t_loop0 = now_ms();
+    int64_t k = 0;
+    for (k = 1; k <= ro.iters; ++k) {                              // :186
+        const double inv_mu = 1.0 / mu;
+        const double thr = lam / mu;
+        T* E = Ebuf[cur];
+        T* Z = Zbuf[cur];
+        pt.mark();
+        if (!have_next)
+            TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
+        pt.mark();
+        // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
+        const bool precise = !large && !hook_svd && sigma_top_prev > 0.0 &&
+                             inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
+        double* G = nullptr;                                                                   // :193-194
+        bool fast_ok = false;
+        bool precise_fast = false;
+        if (precise && use_subspace && sub.valid) {
+            if (g_ready) G = (double*)h->ws[WS_G].p;
+            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+            g_ready = false;
+            TLSQ_TRY(svd_precise_fast<T>(h, Z, M, N, R, inv_mu, sub, G, &V, s, &sweeps, &precise_fast));
+            if (precise_fast) {
+                pt.mark();
+                ++sub.fast;
+                ++n_precise;
+            }
+        }
+        if (precise && !precise_fast) {
+            TLSQ_TRY(svd_two_level<T>(h, Z, M, N, R, inv_mu, &V, s, &sweeps, &pt));
+            sub.valid = false;
+            ++sub.full;
+            ++n_precise;
+        } else if (!precise) {
+        GramOp op = panel_op(Z);
+        if (!implicit_gram) {
+            if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
+            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+            op = GramOp();
+            op.G = G;
+        }
+        g_ready = false;
+        pt.mark();
+        if (hook_svd && k >= 2) {
+            // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
+            SubspaceState rs;
+            rs.hook_rank = sv;
+            rs.hook_seed = seed + (uint64_t)k;
+            TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
+            sub.steps += rs.steps;
+        } else if (use_subspace) {
+            TLSQ_TRY(svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+        }
+        if (!fast_ok && use_subspace && !(hook_svd && k >= 2) && sub.fail != SubspaceState::FAIL_NONE) {
+            // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
+            // Large mode has nothing else; below it a few cheap attempts come before the dense solver when the
+            // block was merely too small (rank above the cold block, rank jumps) - not when convergence stalled.
+            const int max_attempts = large ? 10 : 3;
+            for (int attempt = 0; !fast_ok && attempt < max_attempts; ++attempt) {
+                const int why = sub.fail;
+                if (!large && why != SubspaceState::FAIL_SMALL && why != SubspaceState::FAIL_CERT) break;
+                const bool grow = why == SubspaceState::FAIL_SMALL || why == SubspaceState::FAIL_CERT ||
+                                  why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
+                const int64_t cap = std::min<int64_t>(pmax, N);
+                if (grow) {
+                    const int64_t newp = std::min<int64_t>(cap, sub.p + std::max<int64_t>(16, sub.p / 2));
+                    if (newp == sub.p && why == SubspaceState::FAIL_SMALL) break;   // the rank exceeds the largest block
+                    if (sub.valid && newp > sub.p) {
+                        double* X = (double*)h->ws[WS_SX].p;
+                        TLSQ_TRY(launch_fill_hash(h, X + (size_t)N * sub.p, N * (newp - sub.p),
+                                                  0xC2B2AE35u + (unsigned int)(k * 131 + attempt)));
+                        sub.p = newp;
+                    } else {
+                        sub.cold_p = newp;
+                    }
+                }
+                sub.extra_steps = 10;
+                TLSQ_TRY(svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+                sub.extra_steps = 0;
+            }
+        }
+        if (!fast_ok && large)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED,
+                           "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
+                           "(block of %lld columns, reason %d): rank too large for this release",
+                           (long long)N, (long long)kFullEigMaxN, (long long)k, (long long)sub.p, sub.fail);
+        if (!fast_ok) {
+            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, prev_full));
+            if (hook_svd && k >= 2) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
+            ++sub.full;
+        } else {
+            ++sub.fast;
+        }
+        }   // !precise
+        v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2) && !chol_route(N);
+        prev_full = !precise && !fast_ok;
+        pt.mark();
+        // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
+        // singular values below sigma_res = sqrt(8 N eps) * sigma_max cannot be told from zero.
+        // The reference's threshold 1/mu only drops that low after ~36 iterations (mu_bar = 1e7 mu_0); from
+        // there on unresolved values are treated as zero instead of being counted at random.
+        const double sigma_top = s.ncols > 0 ? s.sigma[s.order[0]] : 0.0;
+        sigma_top_prev = sigma_top;
+        const double sigma_res = precise ? 0.0 : std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
+        const double count_thr = std::max(inv_mu, sigma_res);
+        svp = 0;                                                   // :198
+        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= count_thr) ? 1 : 0;
+        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+        std::vector<int32_t> sel((size_t)svp);
+        std::vector<double> g((size_t)svp);
+        for (int64_t p = 0; p < svp; ++p) {
+            sel[p] = s.order[p];
+            const double sg = s.sigma[sel[p]];
+            g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+        }
+        const double mu_next = std::min(mu * ro.rho, mubar);       // :223
+        const bool fuse = !no_fuse && k < ro.iters;
+        // large panels: A = T Vs' is not written at all, the fused sweep below forms it in registers from the factors
+        // (7 panel passes per iteration instead of 8 + the pass of the skinny GEMM that writes A)
+        const bool fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
+                                  rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
+        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
+        r_last = svp;
+        if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+        a_pending = fuse_rebuild;
+        if (use_subspace && (!precise || precise_fast)) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
+
+        // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
+        // side; while that lower bound of the cost is clearly above tol the iteration cannot be the last one and
+        // the Gram + Lanczos evaluation of opnorm(R) is skipped altogether.
+        const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
+        double* sumsq_dev = nullptr;
+        if (fuse && !want_exact_cost && !hook_opnorm) {
+            void* scal;
+            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+            sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);   // 64 partial sums
+            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));   // (before the mark: the sweep phase times the sweep)
+        }
+        // The residual panel R_k is only read by the cost evaluation.  While the Frobenius bound of the previous
+        // iteration was far above tol this one's will be too (the cost shrinks by ~rho per iteration): the sweep then
+        // does not store R_k at all (one panel pass less); should the bound disagree, R_k is recomputed below.
+        const bool store_R = !(sumsq_dev && prev_lower > rskip_margin * ro.tol);
+        T* Rst = store_R ? R : nullptr;
+        if (!store_R) ++n_rskip;
+        pt.mark();
+        if (fuse_rebuild) {
+            // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
+            TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
+                                                     svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev));
+        } else if (fuse) {
+            // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
+            TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
+                                             ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
+                                             ro.nonnegE ? 1 : 0, sumsq_dev));
+        } else {
+            TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
+        }
+        pt.mark();
+        mu = mu_next;
+        double rn = 0.0;
+        bool cost_skipped = false;
+        if (sumsq_dev) {
+            double fro2 = 0.0, part[64];
+            TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipEventRecord(h->ev[32], h->stream));
+            // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
+            // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
+            // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
+            const bool precise_next = !large && !hook_svd && sigma_top > 0.0 &&
+                                      1.0 / mu_next < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
+            if (!precise_next && !implicit_gram) {   // (the two-level decomposition forms its Gram matrices itself)
+                double* Gn = nullptr;
+                TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
+                g_ready = true;
+            }
+            pt.mark();
+            pt.collect_previous(acc);                      // (host work hidden behind the sweep + Gram just queued)
+            TLSQ_HIP(h, hipEventSynchronize(h->ev[32]));   // the copy only, not the Gram queued behind it
+            memcpy(part, h->pinned, 512);
+            for (double v : part) fro2 += v;
+            const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
+            prev_lower = lower;
+            if (lower > 2.0 * ro.tol) {
+                cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
+                cost_skipped = true;
+            } else if (!store_R) {
+                // mispredicted: the residual is needed after all.  R_k = D - A_k - E_k (A_k possibly still in factors)
+                if (a_pending) {
+                    TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
+                    if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+                    a_pending = false;
+                }
+                TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
+            }
+        } else {
+            pt.mark();   // (empty "next Gram" window)
+        }
+        const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
+        if (cost_skipped) {
+            // nothing to evaluate
+        } else if (hook_opnorm) {
+            TLSQ_TRY(opnorm_power<T>(h, R, M, N, M, mvps, seed + 7919ull * (uint64_t)k, &rn));   // :225 hook
+            cost = rn / d_norm;
+        } else {
+            // When nobody looks at the per-iteration cost (no cost_hist, no verbose hook) only the DECISION
+            // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
+            // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
+            const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
+            if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-8, &rn, stop_sigma));
+            else TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
+            cost = rn / d_norm;
+            if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
+                if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
+                else TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
+                cost = rn / d_norm;
+            }
+        }
+        pt.mark();
+        pt.next_iteration(acc);   // (no stream-wide synchronisation here: the next Gram may still be running)
+        if (info) {
+            info->iters_done = k;
+            if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
+            if (info->svp_hist && k <= info->hist_capacity) info->svp_hist[k - 1] = svp;
+        }
+        if (opts && opts->on_iter) opts->on_iter(k, cost, svp, opts->user);  // :226
+        if (cost < ro.tol) {                                       // :228
+            converged = true;
+            break;
+        }
+        if (fuse) {
+            cur ^= 1;
+            have_next = true;
+        } else {
+            have_next = false;
+        }
+    }
+    if (k > ro.iters) k = ro.iters;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    pt.finish(acc);
+    T* Z = Zbuf[cur];
+    if (a_pending) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
+        TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
+        if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+    }
+    if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
+        TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, E, M, N, M, (T)(lam / mu), (T*)meanws));  // :234-236
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_loop = now_ms() - t_loop0;
+        info->converged = converged ? 1 : 0;
+        info->final_cost = cost;
+        info->final_mu = mu;
+        info->jacobi_sweeps = sweeps;
+        info->eig_full = sub.full;
+        info->eig_fast = sub.fast;
+        info->subspace_steps = sub.steps;
+        info->reserved = (int32_t)n_precise;   // iterations served by the two-level decomposition
+        info->residual_stores_skipped = n_rskip;
+    }
+    if (sv_out) *sv_out = sv;
+
+    // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
+    const int64_t d = std::min(ro.m_global, N);
+    if ((S_host || Vt_host || U_dev) && V && large) {
+        // large mode: only the Ritz triplets of the last block are available; the rest of S is NaN and the
+        // corresponding vectors are zero (documented in include/tlsq.h)
+        const int64_t have = std::min<int64_t>(s.ncols, d);
+        if (S_host)
+            for (int64_t p = 0; p < d; ++p)
+                S_host[p] = p < have ? s.sigma[s.order[p]] : std::numeric_limits<double>::quiet_NaN();
+        if (Vt_host) {
+            std::vector<double> hv((size_t)N * have);
+            TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * have * 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            for (int64_t p = 0; p < d; ++p)
+                for (int64_t j = 0; j < N; ++j)
+                    Vt_host[p + j * ldVt] = p < have ? hv[(size_t)s.order[p] * N + j] : 0.0;
+        }
+        if (U_dev) {
+            TLSQ_HIP(h, hipMemsetAsync(U_dev, 0, (size_t)M * d * sizeof(T), h->stream));
+            std::vector<int32_t> sel((size_t)have);
+            std::vector<double> g((size_t)have);
+            for (int64_t p = 0; p < have; ++p) {
+                sel[p] = s.order[p];
+                const double sg = s.sigma[sel[p]];
+                g[p] = sg > 0.0 ? 1.0 / sg : 0.0;
+            }
+            void *Vg, *aux;
+            TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * have * 8, &Vg));
+            TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)have * 16 + 64, &aux));
+            int32_t* dsel = (int32_t*)aux;
+            double* dg = (double*)((char*)aux + ((have * 4 + 7) / 8) * 8);
+            TLSQ_TRY(upload_async(h, dsel, sel.data(), (size_t)have * 4));
+            TLSQ_TRY(upload_async(h, dg, g.data(), (size_t)have * 8));
+            TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, have, (double*)Vg, nullptr));
+            TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, M, U_dev, Prec<T>::f32, M, have, M, N, false));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        return converged ? TLSQ_OK : TLSQ_MAXITER;
+    }
+    if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
+        // the last iteration used a subspace path: the caller wants the complete SVD of the last Z
+        double* G = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+        TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, false, WS_V, true));
+        if (info) info->jacobi_sweeps = sweeps;
+    }
+    if (S_host && V)
+        for (int64_t p = 0; p < d; ++p) S_host[p] = s.sigma[s.order[p]];
+    if (Vt_host && V) {
+        std::vector<double> hv((size_t)N * N);
+        TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        for (int64_t p = 0; p < d; ++p) {
+            const double* col = hv.data() + (size_t)s.order[p] * N;
+            for (int64_t j = 0; j < N; ++j) Vt_host[p + j * ldVt] = col[j];
+        }
+    }
+    if (U_dev && V) {
+        // U = Z V diag(1/sigma); columns with sigma == 0 are returned as zeros
+        std::vector<int32_t> sel((size_t)d);
+        std::vector<double> g((size_t)d);
+        for (int64_t p = 0; p < d; ++p) {
+            sel[p] = s.order[p];
+            const double sg = s.sigma[sel[p]];
+            g[p] = sg > 0.0 ? 1.0 / sg : 0.0;
+        }
+        void *Vg, *aux;
+        TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * d * 8, &Vg));
+        TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)d * 16, &aux));
+        int32_t* dsel = (int32_t*)aux;
+        double* dg = (double*)((char*)aux + ((d * 4 + 7) / 8) * 8);
+        TLSQ_HIP(h, hipMemcpyAsync(dsel, sel.data(), (size_t)d * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(dg, g.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, d, (double*)Vg, nullptr));
+        TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, M, U_dev, Prec<T>::f32, M, d, M, N, false));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return converged ? TLSQ_OK : TLSQ_MAXITER;  // :232
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComplexF64 rpca (src/robustPCA.jl:156-239 with the complex soft_th of :3-7; test/runtests.jl:187-199).
+// D, A, E: device, interleaved complex, M x N, ld = M.  The sweeps are complex kernels (complex.hip); every
+// spectral step runs on the realified 2M x 2N panel with the real path's Gram / eigen / rebuild kernels.  The
+// eigenvalues of the realified Gram come in equal pairs: consecutive sorted values are grouped, the pair mean
+// decides sigma_i >= 1/mu, and both eigenvectors of a pair are selected together, so the rebuilt matrix keeps the
+// realified structure.  Full decompositions only (no subspace tier): a coverage path, not a tuned one.
+// ------------------------------------------------------------------------------------------------
+int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
+                             const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
+                             tlsq_rpca_info* info) {
+    const int64_t n = M * N, M2 = 2 * M, N2 = 2 * N;
+    const int64_t d = std::min(M, N);
+    void *Yv, *Zv, *Rv, *Wv, *ARv;
+    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * 16, &Yv));
+    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * 16, &Zv));
+    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * 16, &Rv));
+    TLSQ_TRY(ws_get(h, WS_DT, (size_t)n * 32, &Wv));    // realified panel
+    TLSQ_TRY(ws_get(h, WS_AT, (size_t)n * 32, &ARv));   // realified A
+    double *Y = (double*)Yv, *Z = (double*)Zv, *R = (double*)Rv, *W = (double*)Wv, *AR = (double*)ARv;
+    int64_t sweeps = 0;
+    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 16, h->stream));            // :174
+    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 16, h->stream));
+    double norm2 = 0.0, maxabs = 0.0;
+    TLSQ_TRY(launch_realify(h, D, M, N, W));
+    TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &norm2, &sweeps));         // :177
+    TLSQ_TRY(launch_cmaxabs(h, D, n, &maxabs));                               // :178
+    const double lam = ro.lambda;
+    const double dual_norm = std::max(norm2, maxabs / lam);                   // :179
+    const double d_norm = norm2;                                              // :180
+    TLSQ_TRY(launch_cdiv(h, D, Y, n, dual_norm));                             // :181
+    double mu = 1.25 / norm2;                                                 // :182
+    const double mubar = mu * 1.0e7;                                          // :183
+    int64_t sv = 10, svp = 10;                                                // :184
+    if (info) {
+        info->d_norm = d_norm;
+        info->iters_done = 0;
+        info->converged = 0;
+    }
+    h->warm_n = 0;
+    SmallSvd s;
+    double* V = nullptr;
+    std::vector<double> sig_pairs;
+    double cost = std::numeric_limits<double>::quiet_NaN();
+    bool converged = false;
+    int64_t n_full = 0;
+    const double t_loop0 = now_ms();
+    int64_t k = 0;
+    for (k = 1; k <= ro.iters; ++k) {                                         // :186
+        const double inv_mu = 1.0 / mu, thr = lam / mu;
+        TLSQ_TRY(launch_cshrink(h, D, A, Y, E, Z, n, inv_mu, thr));           // :188-192
+        TLSQ_TRY(launch_realify(h, Z, M, N, W));
+        double* G = nullptr;
+        TLSQ_TRY(gram_allreduce<double>(h, W, M2, N2, M2, &G));               // :194
+        TLSQ_TRY(eig_full(h, G, N2, &V, s, &sweeps, false));
+        ++n_full;
+        // pairs of equal eigenvalues -> singular values of the complex Z
+        sig_pairs.assign((size_t)d, 0.0);
+        for (int64_t i = 0; i < d; ++i) {
+            const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
+            sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
+        }
+        const double sigma_res = std::sqrt(8.0 * (double)N2 * 2.220446049250313e-16) * sig_pairs[0];
+        const double count_thr = std::max(inv_mu, sigma_res);
+        svp = 0;                                                              // :198
+        for (int64_t i = 0; i < d; ++i) svp += (sig_pairs[i] >= count_thr) ? 1 : 0;
+        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);                 // :199-204
+        std::vector<int32_t> sel((size_t)(2 * svp));
+        std::vector<double> g((size_t)(2 * svp));
+        for (int64_t i = 0; i < svp; ++i) {
+            const double sg = sig_pairs[i];
+            const double gi = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+            sel[2 * i] = s.order[2 * i];
+            sel[2 * i + 1] = s.order[2 * i + 1];
+            g[2 * i] = g[2 * i + 1] = gi;
+        }
+        TLSQ_TRY(rebuild_lowrank<double>(h, W, M2, N2, M2, V, sel, g, AR, M2));
+        TLSQ_TRY(launch_unrealify(h, AR, M, N, A));
+        TLSQ_TRY(launch_cupdate(h, D, A, E, Y, R, n, mu));                    // :221-222
+        mu = std::min(mu * ro.rho, mubar);                                    // :223
+        double rn = 0.0;
+        TLSQ_TRY(launch_realify(h, R, M, N, W));
+        TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &rn, &sweeps, 1e-8));  // :225
+        cost = rn / d_norm;
+        if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {
+            TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N2, 1e-13, &rn, &sweeps));
+            cost = rn / d_norm;
+        }
+        if (info) {
+            info->iters_done = k;
+            if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
+            if (info->svp_hist && k <= info->hist_capacity) info->svp_hist[k - 1] = svp;
+        }
+        if (opts && opts->on_iter) opts->on_iter(k, cost, svp, opts->user);   // :226
+        if (cost < ro.tol) {                                                  // :228
+            converged = true;
+            break;
+        }
+    }
+    if (k > ro.iters) k = ro.iters;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_loop = now_ms() - t_loop0;
+        info->converged = converged ? 1 : 0;
+        info->final_cost = cost;
+        info->final_mu = mu;
+        info->jacobi_sweeps = sweeps;
+        info->eig_full = n_full;
+    }
+    if (sv_out) *sv_out = sv;
+    if (S_host)
+        for (int64_t i = 0; i < d; ++i) S_host[i] = i < (int64_t)sig_pairs.size() ? sig_pairs[i] : 0.0;
+    return converged ? TLSQ_OK : TLSQ_MAXITER;                                // :232
+}
+
+
+// solve X * V22 = -V21 for X (n x q); V = Vt' where Vt is (ncols x ncols, ldVt) — TotalLeastSquares.jl:65-69
+int tls_partition_solve(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n, double* x,
+                               int64_t ldx) {
+    const int64_t q = ncols - n;
+    if (n <= 0 || q <= 0) return TLSQ_ERR_ARG;
+    // V[i][j] = Vt[j + i*ldVt].  V21 = V[0:n, n:], V22 = V[n:, n:]
+    // X V22 = -V21  <=>  V22' X' = -V21'.  Build M = V22' (q x q): M[a][b] = V22[b][a] = V[n+b][n+a] = Vt[(n+a) + (n+b)*ldVt]
+    std::vector<double> Mq((size_t)q * q), rhs((size_t)q * n);
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t b = 0; b < q; ++b) Mq[a * q + b] = Vt[(n + a) + (n + b) * ldVt];
+    // rhs[a][i] = -V21'[a][i] = -V21[i][a] = -V[i][n+a] = -Vt[(n+a) + i*ldVt]
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t i = 0; i < n; ++i) rhs[a * n + i] = -Vt[(n + a) + i * ldVt];
+    // LU with partial pivoting on Mq (row-major), applied to rhs
+    for (int64_t c = 0; c < q; ++c) {
+        int64_t piv = c;
+        double best = std::fabs(Mq[c * q + c]);
+        for (int64_t r2 = c + 1; r2 < q; ++r2)
+            if (std::fabs(Mq[r2 * q + c]) > best) best = std::fabs(Mq[r2 * q + c]), piv = r2;
+        if (piv != c) {
+            for (int64_t b = 0; b < q; ++b) std::swap(Mq[c * q + b], Mq[piv * q + b]);
+            for (int64_t i = 0; i < n; ++i) std::swap(rhs[c * n + i], rhs[piv * n + i]);
+        }
+        const double pv = Mq[c * q + c];
+        for (int64_t r2 = c + 1; r2 < q; ++r2) {
+            const double f = Mq[r2 * q + c] / pv;
+            if (f == 0.0) continue;
+            for (int64_t b = c; b < q; ++b) Mq[r2 * q + b] -= f * Mq[c * q + b];
+            for (int64_t i = 0; i < n; ++i) rhs[r2 * n + i] -= f * rhs[c * n + i];
+        }
+    }
+    for (int64_t c = q - 1; c >= 0; --c) {
+        for (int64_t i = 0; i < n; ++i) {
+            double v = rhs[c * n + i];
+            for (int64_t b = c + 1; b < q; ++b) v -= Mq[c * q + b] * rhs[b * n + i];
+            rhs[c * n + i] = v / Mq[c * q + c];
+        }
+    }
+    // rhs = X' (q x n)  ->  x[i + a*ldx] = X[i][a]
+    for (int64_t a = 0; a < q; ++a)
+        for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = rhs[a * n + i];
+    return TLSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rpca entry (both precisions): staging of caller memory, M < N handled on the transposed problem
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      T* A, int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt,
+                      int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
+        return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    reset_info(info);
+    const double eps_t = (double)std::numeric_limits<T>::epsilon();
+    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(eps_t));     // tol = sqrt(eps(real(T)))  (:160)
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const size_t es = sizeof(T);
+    const int64_t n = M * N;
+    const int64_t d = std::min(ro.m_global, N);
+    if (U && ldU < M) return set_err(h, TLSQ_ERR_ARG, "rpca: ldU < M");
+    if (Vt && ldVt < d) return set_err(h, TLSQ_ERR_ARG, "rpca: ldVt < min(M,N)");
+    // rpca is invariant under transposition (elementwise sweeps, singular-value thresholding, lambda =
+    // 1/sqrt(max(M,N))).  A wide unsharded D is solved as its tall transpose: the Gram matrix is then M x M
+    // and has no structurally-zero eigenvalues (accuracy of the Gram route).
+    const bool transposed = (M < N) && ro.m_global == M && !h->comm;
+    // the small-matrix solvers of this release keep their panels in LDS: the Gram dimension is limited
+    if ((transposed ? M : N) > kGramMaxN)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: min(M,N) = %lld exceeds %lld, the largest Gram dimension of this "
+                       "release", (long long)(transposed ? M : N), (long long)kGramMaxN);
+
+    // The panels the MFMA kernels stream (Z, R, ...) inherit the row count of the working problem as their leading
+    // dimension.  The Gram kernel reads 16-row (128-byte) segments of every column: when the leading dimension is
+    // not a multiple of 16 every segment straddles two cache lines (measured 3x slower at 9,999,745 rows), and an
+    // odd one also forces 8-byte loads.  So the row count is padded with zero rows to a multiple of 16 in private
+    // panels — zero rows change nothing in the algorithm (lambda and d use the true size through m_global).
+    const int64_t Mw = transposed ? N : M;          // rows of the working (tall) problem
+    const int64_t Nw = transposed ? M : N;
+    const bool pad = (Mw % 16 != 0) && !ro.hankel;  // soft_hankel! would see the extra rows: keep the exact shape there
+    const int64_t Mp = pad ? (Mw + 15) / 16 * 16 : Mw;
+    const size_t nw = (size_t)Mp * Nw;
+
+    const T* dD = D;
+    T *dA = A, *dE = E, *dU = U;
+    void* p;
+    double th = now_ms();
+    const bool priv = !dev || transposed || pad;    // work on private panels?
+    if (!dev || ldD != M) {
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * es, &p));
+        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        dD = (const T*)p;
+    }
+    if (!dev || ldA != M) {
+        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * es, &p));
+        dA = (T*)p;
+    }
+    if (!dev || ldE != M) {
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * es, &p));
+        dE = (T*)p;
+    }
+    if (U && !transposed && !pad && (!dev || ldU != M)) {
+        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * es, &p));
+        dU = (T*)p;
+    }
+    (void)priv;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_h2d = now_ms() - th;
+
+    // S / Vt are small: always produced on the host in fp64, then converted / copied to the caller's memory
+    std::vector<double> hS((size_t)(S ? d : 0)), hVt((size_t)(Vt ? d * N : 0));
+    int status;
+    if (!transposed && !pad) {
+        status = rpca_core<T>(h, dD, M, N, ro, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
+                              Vt ? hVt.data() : nullptr, d, sv, info);
+        if (status < 0) return status;
+    } else {
+        // working copies: Dw (Mp x Nw) = D or D', zero pad row; Aw, Ew results; Uw (Mp x d) left vectors of Zw
+        void *Dw, *Aw, *Ew, *Uw = nullptr;
+        TLSQ_TRY(ws_get(h, WS_DT, nw * es, &Dw));
+        TLSQ_TRY(ws_get(h, WS_AT, nw * es, &Aw));
+        TLSQ_TRY(ws_get(h, WS_ET, nw * es, &Ew));
+        const bool need_Uw = transposed ? (Vt != nullptr) : (U != nullptr);
+        if (need_Uw) TLSQ_TRY(ws_get(h, WS_UT, (size_t)Mp * d * es, &Uw));
+        if (pad) TLSQ_HIP(h, hipMemsetAsync(Dw, 0, nw * es, h->stream));
+        if (transposed) TLSQ_TRY(launch_transpose<T>(h, dD, M, M, N, (T*)Dw, Mp));
+        else TLSQ_TRY(copy2d(h, Dw, Mp, dD, M, M, N, es, hipMemcpyDeviceToDevice));
+        ResolvedOpts rw = ro;
+        rw.m_global = transposed ? N : ro.m_global;
+        std::vector<double> hVtW((size_t)d * Nw);                      // right vectors of the working problem
+        status = rpca_core<T>(h, (const T*)Dw, Mp, Nw, rw, opts, (T*)Aw, (T*)Ew, need_Uw ? (T*)Uw : nullptr,
+                              S ? hS.data() : nullptr, (transposed ? (U != nullptr) : (Vt != nullptr)) ? hVtW.data() : nullptr,
+                              d, sv, info);
+        if (status < 0) return status;
+        if (transposed) {
+            TLSQ_TRY(launch_transpose<T>(h, (const T*)Aw, Mp, N, M, dA, M));
+            TLSQ_TRY(launch_transpose<T>(h, (const T*)Ew, Mp, N, M, dE, M));
+            if (Vt) {   // Vt (d x N) = Uw^T  (Uw is N(+1) x d, ld Mp)
+                std::vector<T> hu((size_t)Mp * d);
+                TLSQ_HIP(h, hipMemcpyAsync(hu.data(), Uw, (size_t)Mp * d * es, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                for (int64_t pcol = 0; pcol < d; ++pcol)
+                    for (int64_t j = 0; j < N; ++j) hVt[pcol + j * d] = (double)hu[j + pcol * Mp];
+            }
+            if (U) {    // U (M x d) = VtW^T
+                std::vector<T> hu((size_t)M * d);
+                for (int64_t pcol = 0; pcol < d; ++pcol)
+                    for (int64_t i = 0; i < M; ++i) hu[i + pcol * M] = (T)hVtW[pcol + i * d];
+                TLSQ_TRY(copy2d(h, U, ldU, hu.data(), M, M, d, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
+        } else {
+            TLSQ_TRY(copy2d(h, dA, M, Aw, Mp, M, N, es, hipMemcpyDeviceToDevice));
+            TLSQ_TRY(copy2d(h, dE, M, Ew, Mp, M, N, es, hipMemcpyDeviceToDevice));
+            if (Vt) hVt = hVtW;
+            if (U) {
+                TLSQ_TRY(copy2d(h, U, ldU, Uw, Mp, M, d, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
+        }
+    }
+
+    th = now_ms();
+    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
+    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
+    if (U && !transposed && !pad && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
+    std::vector<T> tS, tVt;
+    if (S) {
+        tS.resize((size_t)d);
+        for (int64_t i = 0; i < d; ++i) tS[i] = (T)hS[i];
+        TLSQ_HIP(h, hipMemcpyAsync(S, tS.data(), (size_t)d * es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
+                                   h->stream));
+    }
+    if (Vt) {
+        tVt.resize((size_t)d * N);
+        for (size_t i = 0; i < tVt.size(); ++i) tVt[i] = (T)hVt[i];
+        TLSQ_TRY(copy2d(h, Vt, ldVt, tVt.data(), d, d, N, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_d2h = now_ms() - th;
+        info->ms_total = now_ms() - t0;
+    }
+    return status;
+}
+
+
+// explicit instantiations used by api.hip
+template int opnorm_gram<double>(Handle*, const double*, int64_t, int64_t, int64_t, double*, int64_t*, double, double, int);
+template int svd_via_gram<double>(Handle*, const double*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*,
+                                  PhaseTimer*);
+template int rebuild_lowrank<double>(Handle*, const double*, int64_t, int64_t, int64_t, const double*,
+                                     const std::vector<int32_t>&, const std::vector<double>&, double*, int64_t);
+template int rpca_core<double>(Handle*, const double*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*,
+                               double*, double*, double*, double*, double*, int64_t, int64_t*, tlsq_rpca_info*);
+template int rpca_entry<double>(tlsq_handle, const double*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, double*,
+                                int64_t, double*, int64_t, double*, int64_t, double*, double*, int64_t, int64_t*,
+                                tlsq_rpca_info*);
+template int rpca_entry<float>(tlsq_handle, const float*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, float*, int64_t,
+                               float*, int64_t, float*, int64_t, float*, float*, int64_t, int64_t*, tlsq_rpca_info*);
+}  // namespace tlsq
