@@ -832,3 +832,24 @@ def test_residual_store_misprediction_path():
     env = dict(os.environ, TLSQ_RSKIP_MARGIN="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_implicit_gram_operator_path():
+    """From N = 8192 on the Gram matrix is never formed: products G X = Z'(Z X), operator-form Lanczos with per-vector
+    deflation.  TLSQ_IMPLICIT_GRAM=1 (read once per process, hence the subprocess) forces that path at a size the
+    oracle can follow: same trajectory, A and E."""
+    import os, subprocess, sys
+    code = (
+        "import sys, warnings, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import tlsq_amd; from oracle import rpca_oracle as O\n"
+        "warnings.simplefilter('ignore'); torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
+        "D = O.synth_lowrank_sparse(2400, 2064, 5, seed=12)[0]\n"
+        "A, E, s, sv, rep = eng.rpca(D, iters=5, return_report=True, want_U=False)\n"
+        "Ao, Eo, so, svo, io = O.rpca(D, iters=5)\n"
+        "assert rep.svp_hist == io.svp_hist and sv == svo and rep.eig_full == 0, (rep.svp_hist, io.svp_hist)\n"
+        "assert np.linalg.norm(A - Ao) <= 1e-9 * np.linalg.norm(Ao) and np.linalg.norm(E - Eo) <= 1e-9 * np.linalg.norm(Eo)\n"
+        "assert np.allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, TLSQ_IMPLICIT_GRAM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
