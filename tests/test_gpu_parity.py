@@ -157,7 +157,7 @@ def test_gemm_nn_nt(eng, torch_mod, M, K, Q):
 # Jacobi eigensolver / opnorm
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,rank", [(5, 5), (4, 2), (37, 37), (50, 10), (128, 128), (512, 40), (512, 512), (1, 1),
-                                    (2, 2), (300, 300)])
+                                    (2, 2), (300, 300), (64, 64), (65, 65), (80, 30), (96, 96), (97, 97)])
 def test_symeig(eng, torch_mod, N, rank):
     torch = torch_mod
     rng = np.random.default_rng(5)

@@ -382,6 +382,163 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
 }
 
+// The same for 64 < N <= 96 (Rayleigh-Ritz problems of blocks of 65..96 columns): three rows per lane, up to 48
+// column pairs per round shared out over the 32 half-waves, B and V in dynamic LDS (2 N (N+1) doubles <= 149 KB).
+template <bool WANT_V>
+__global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ G, int64_t ldG,
+                                                       double* __restrict__ Bout, double* __restrict__ Vout,
+                                                       double* __restrict__ lam, int N, double tol, double nfloor,
+                                                       int max_sweeps, int* __restrict__ sweeps_done) {
+    extern __shared__ __attribute__((aligned(16))) double jm_sm[];   // sB[N*LD], sV[N*LD] (WANT_V), sN[N]
+    __shared__ double red[16];
+    __shared__ unsigned int s_rot;
+    __shared__ unsigned long long s_max;
+    const int LD = N + 1;
+    double* sB = jm_sm;
+    double* sV = jm_sm + (size_t)N * LD;
+    double* sN = jm_sm + (size_t)(WANT_V ? 2 : 1) * N * LD;
+    const int tid = threadIdx.x;
+    const int hw = tid >> 5, hl = tid & 31;   // half-wave index, lane within it
+    const int nthr = blockDim.x, nhw = nthr >> 5;   // the launcher sizes the block to the number of pairs
+    // init + ||G||_F^2
+    double fro = 0.0;
+    for (int e = tid; e < N * N; e += nthr) {
+        const int r = e % N, c = e / N;
+        const double v = G[r + (int64_t)c * ldG];
+        sB[c * LD + r] = v;
+        if (WANT_V) sV[c * LD + r] = (r == c) ? 1.0 : 0.0;
+        fro += v * v;
+    }
+    fro = wave_allsum(fro);
+    if ((tid & 63) == 0) red[tid >> 6] = fro;
+    if (tid == 0) {
+        s_rot = 0;
+        s_max = 0ull;
+    }
+    __syncthreads();
+    double fsum = 0.0;
+    for (int k = 0; k < (nthr >> 6); ++k) fsum += red[k];
+    const double floor2 = nfloor * nfloor * fsum;
+    const int nslot = (N + 1) & ~1;          // even number of tournament players
+    const int npair = nslot / 2;             // <= 32
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        unsigned int my_rot = 0;
+        double my_max = 0.0;
+        // squared column norms, refreshed once per sweep and updated by the rotation formulas in between
+        for (int c = hw; c < N; c += nhw) {
+            const double* x = sB + c * LD;
+            const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0,
+                         v2 = hl + 64 < N ? x[hl + 64] : 0.0;
+            const double ssum = half_allsum(v0 * v0 + v1 * v1 + v2 * v2);
+            if (hl == 0) sN[c] = ssum;
+        }
+        __syncthreads();
+        for (int ir = 0; ir < nslot - 1; ++ir) {
+            for (int ip = hw; ip < npair; ip += nhw) {   // up to 48 pairs per round on 32 half-waves
+                int s1, s2;
+                rr_pair(nslot, ir, ip, s1, s2);
+                if (s1 > s2) {
+                    const int t = s1;
+                    s1 = s2;
+                    s2 = t;
+                }
+                if (s2 < N) {
+                    double* x = sB + s1 * LD;
+                    double* y = sB + s2 * LD;
+                    const int r0 = hl, r1 = hl + 32, r2 = hl + 64;
+                    const double x0 = r0 < N ? x[r0] : 0.0, y0 = r0 < N ? y[r0] : 0.0;
+                    const double x1 = r1 < N ? x[r1] : 0.0, y1 = r1 < N ? y[r1] : 0.0;
+                    const double x2 = r2 < N ? x[r2] : 0.0, y2 = r2 < N ? y[r2] : 0.0;
+                    const double a = sN[s1], bb = sN[s2];
+                    const double c = half_allsum(x0 * y0 + x1 * y1 + x2 * y2);
+                    const double mn = a < bb ? a : bb;
+                    if (c * c > tol * tol * a * bb && mn > floor2) {
+                        const double ratio2 = c * c / (a * bb);   // cos^2 of the angle between the two columns
+                        my_max = ratio2 > my_max ? ratio2 : my_max;
+                        // t = 2 c sgn(d) / (|d| + sqrt(d^2 + 4 c^2)), d = bb - a  (one sqrt, one division)
+                        const double d = bb - a;
+                        const double t = (d >= 0.0 ? 2.0 : -2.0) * c / (fabs(d) + sqrt(d * d + 4.0 * c * c));
+                        const double cs = rsqrt(1.0 + t * t);
+                        const double sn = cs * t;
+                        if (hl == 0) {
+                            const double na = a - t * c, nb2 = bb + t * c;
+                            sN[s1] = na > 0.0 ? na : 0.0;
+                            sN[s2] = nb2 > 0.0 ? nb2 : 0.0;
+                        }
+                        if (r0 < N) {
+                            x[r0] = cs * x0 - sn * y0;
+                            y[r0] = sn * x0 + cs * y0;
+                        }
+                        if (r1 < N) {
+                            x[r1] = cs * x1 - sn * y1;
+                            y[r1] = sn * x1 + cs * y1;
+                        }
+                        if (r2 < N) {
+                            x[r2] = cs * x2 - sn * y2;
+                            y[r2] = sn * x2 + cs * y2;
+                        }
+                        if (WANT_V) {
+                            double* vx = sV + s1 * LD;
+                            double* vy = sV + s2 * LD;
+                            if (r0 < N) {
+                                const double u = vx[r0], w = vy[r0];
+                                vx[r0] = cs * u - sn * w;
+                                vy[r0] = sn * u + cs * w;
+                            }
+                            if (r1 < N) {
+                                const double u = vx[r1], w = vy[r1];
+                                vx[r1] = cs * u - sn * w;
+                                vy[r1] = sn * u + cs * w;
+                            }
+                            if (r2 < N) {
+                                const double u = vx[r2], w = vy[r2];
+                                vx[r2] = cs * u - sn * w;
+                                vy[r2] = sn * u + cs * w;
+                            }
+                        }
+                        ++my_rot;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (hl == 0 && my_rot) {
+            atomicAdd(&s_rot, my_rot);
+            atomicMax(&s_max, (unsigned long long)__double_as_longlong(my_max));   // non-negative doubles order like integers
+        }
+        __syncthreads();
+        const unsigned int r = s_rot;
+        const double swmax = __longlong_as_double((long long)s_max);
+        __syncthreads();
+        if (tid == 0) {
+            s_rot = 0;
+            s_max = 0ull;
+        }
+        // converged: a sweep without rotations - or one whose largest rotation was so small (|cos| < 1e-8) that,
+        // Jacobi converging quadratically, what is left is below the rotation threshold anyway
+        if (r == 0 || swmax < 1e-16) {
+            ++sweep;
+            break;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += nthr) {
+        const int r = e % N, c = e / N;
+        Bout[e] = sB[c * LD + r];
+        if (WANT_V) Vout[e] = sV[c * LD + r];
+    }
+    // lam[c] = ||B[:,c]||: half-wave per column
+    for (int c = hw; c < N; c += nhw) {
+        const double* x = sB + c * LD;
+        const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0,
+                     v2 = hl + 64 < N ? x[hl + 64] : 0.0;
+        const double ssum = half_allsum(v0 * v0 + v1 * v1 + v2 * v2);
+        if (hl == 0) lam[c] = sqrt(ssum);
+    }
+    if (tid == 0 && sweeps_done) *sweeps_done = sweep;
+}
+
 // B = G (ld -> N), V = I
 __global__ __launch_bounds__(256) void k_jacobi_init(const double* __restrict__ G, int64_t ldG,
                                                      double* __restrict__ B, double* __restrict__ V,
@@ -497,6 +654,35 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         if (sd >= max_sweeps0)
             return set_err(h, TLSQ_ERR_NOCONV, "Jacobi eigensolver did not converge in %d sweeps (N=%lld)",
                            max_sweeps0, (long long)N);
+        return TLSQ_OK;
+    }
+    if (N > 64 && N <= 96 && !(warm_v && want_v)) {
+        // one launch as well: init, noise floor, sweeps, column norms (k_jacobi_mid)
+        const double eps0 = 2.220446049250313e-16;
+        const double tol0 = 2.0 * eps0 * sqrt((double)N);
+        const int max_sweeps0 = 40;
+        const size_t lds = ((size_t)(want_v ? 2 : 1) * N * (N + 1) + N) * 8;
+        if (want_v) {
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_jacobi_mid<true>, dim3(1), dim3(1024), lds, h->stream, G, ldG, B, V, lam_dev, (int)N, tol0,
+                               (double)N * eps0, max_sweeps0, sweeps_dev);
+        } else {
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_jacobi_mid<false>, dim3(1), dim3(1024), lds, h->stream, G, ldG, B, V, lam_dev, (int)N,
+                               tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
+        }
+        TLSQ_HIP(h, hipGetLastError());
+        if (async_small) return TLSQ_OK;
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        int sd;
+        memcpy(&sd, h->pinned, 4);
+        if (sweeps_out) *sweeps_out = sd;
+        if (sd >= max_sweeps0)
+            return set_err(h, TLSQ_ERR_NOCONV, "Jacobi eigensolver did not converge in %d sweeps (N=%lld)", max_sweeps0,
+                           (long long)N);
         return TLSQ_OK;
     }
     int64_t g = (N * N + 255) / 256;

@@ -515,9 +515,10 @@ static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s,
                        SubspaceState& sub) {
     static const int64_t pad_min = [] { const char* e = getenv("TLSQ_PAD"); return (int64_t)(e ? atoi(e) : 4); }();
     int64_t pad = std::max<int64_t>(pad_min, svp / 4);
-    // up to 64 columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small); beyond that
-    // it costs ~1 ms per step: give up some padding to stay below when the rank allows
+    // up to 64 (96) columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small / _mid);
+    // beyond that it costs ~1 ms per step: give up some padding to stay below when the rank allows
     if (svp + pad > 64 && svp + pad_min <= 64) pad = 64 - svp;
+    else if (svp + pad > 96 && svp + pad_min <= 96) pad = 96 - svp;   // (k_jacobi_mid: one launch up to 96 as well)
     int64_t want = std::min<int64_t>(N, svp + pad);
     if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
     if (want > pmax || want < 3) {

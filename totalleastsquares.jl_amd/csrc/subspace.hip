@@ -456,30 +456,34 @@ __global__ __launch_bounds__(256) void k_panel_tn2(const double* __restrict__ A,
     if (lane == 0) Cm[i + (size_t)j * pa] = s;
 }
 
-// B (N x pb) -= A (N x pa) * C (pa x pb, ld pa): thread per row, C from LDS (pa * pb <= 192 * 32 doubles)
-__global__ __launch_bounds__(256) void k_panel_sub(const double* __restrict__ A, int pa, const double* __restrict__ Cm,
-                                                   double* __restrict__ B, int pb, int N,
-                                                   const double* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double sC[];
+// B (N x pb) -= A (N x pa) * C (pa x pb, ld pa): one wave per 64 rows x 8 columns (grid.y = column groups), its 8
+// columns of C in LDS
+__global__ __launch_bounds__(64) void k_panel_sub(const double* __restrict__ A, int pa, const double* __restrict__ Cm,
+                                                  double* __restrict__ B, int pb, int N,
+                                                  const double* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sC[];   // pa x 8, [i][q]
     if (status && status[1] != 0.0) return;
-    for (int e = threadIdx.x; e < pa * pb; e += 256) sC[e] = Cm[e];
-    __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
-    for (int j0 = 0; j0 < pb; j0 += 8) {
-        double acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        for (int i = 0; i < pa; ++i) {
-            const double a = A[r + (size_t)i * N];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (j0 + q < pb) acc[q] += a * sC[i + (size_t)(j0 + q) * pa];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (j0 + q < pb) B[r + (size_t)(j0 + q) * N] -= acc[q];
+    const int j0 = blockIdx.y * 8;
+    const int nq = (pb - j0 < 8) ? pb - j0 : 8;
+    for (int e = threadIdx.x; e < pa * 8; e += 64) {
+        const int i = e >> 3, q = e & 7;
+        sC[e] = q < nq ? Cm[i + (size_t)(j0 + q) * pa] : 0.0;
     }
+    __syncthreads();
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= N) return;
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < pa; ++i) {
+        const double a = A[r + (size_t)i * N];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += a * sC[i * 8 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < nq) B[r + (size_t)(j0 + q) * N] -= acc[q];
 }
 
 // X1 = Q * S and X2 = GQ * S  (N x p panels, S p x p, ld p): thread per output element, S from LDS
@@ -617,8 +621,9 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
             for (int rep = 0; rep < 2; ++rep) {   // project the block against the finished columns, twice
                 hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((c0 * pb + 3) / 4)), dim3(256), 0, h->stream,
                                    (const double*)Y, (int)c0, (const double*)Yb, (int)pb, W, (int)N, sticky);
-                hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)(c0 * pb) * 8,
-                                   h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb, (int)N, sticky);
+                hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64),
+                                   (size_t)c0 * 8 * 8, h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb,
+                                   (int)N, sticky);
             }
         }
         for (int pass = 1; pass <= 2; ++pass) {
@@ -718,7 +723,7 @@ int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r,
     if (r <= 0) return TLSQ_OK;
     hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((r + 3) / 4)), dim3(256), 0, h->stream, Vg, (int)r, q, 1, c, (int)N,
                        (const double*)nullptr);
-    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 255) / 256)), dim3(256), (size_t)r * 8, h->stream, Vs, (int)r,
+    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), 1), dim3(64), (size_t)r * 8 * 8, h->stream, Vs, (int)r,
                        (const double*)c, w, 1, (int)N, (const double*)nullptr);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
