@@ -773,12 +773,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
 
     PhaseTimer pt(h, timing);
     double zero_sink = 0.0;
-    // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | next iteration's Gram queued
-    // behind the sweep (booked under gram) | cost evaluation
+    // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | read-back of the Frobenius
+    // bound (booked under the cost evaluation) | next iteration's Gram queued behind the sweep (booked under gram) |
+    // cost evaluation
     double* acc[8] = {info ? &info->ms_shrink : &zero_sink, info ? &info->ms_gram : &zero_sink,
                       info ? &info->ms_eig : &zero_sink,    info ? &info->ms_rebuild : &zero_sink,
-                      info ? &info->ms_update : &zero_sink, info ? &info->ms_gram : &zero_sink,
-                      info ? &info->ms_opnorm : &zero_sink, nullptr};
+                      info ? &info->ms_update : &zero_sink, info ? &info->ms_opnorm : &zero_sink,
+                      info ? &info->ms_gram : &zero_sink,   info ? &info->ms_opnorm : &zero_sink};
     bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
     const double t_loop0 = now_ms();
     int64_t k = 0;
@@ -948,6 +949,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
             TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
             TLSQ_HIP(h, hipEventRecord(h->ev[32], h->stream));
+            pt.mark();
             // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
             // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
@@ -978,7 +980,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
             }
         } else {
-            pt.mark();   // (empty "next Gram" window)
+            pt.mark();   // (empty read-back and "next Gram" windows)
+            pt.mark();
         }
         const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
         if (cost_skipped) {
