@@ -334,10 +334,18 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
     // skinny outputs (P <= 32 rows of MFMA work per tile) are bandwidth/latency bound, not MFMA bound: they want
     // several workgroups per CU in flight, so split K further
     const int64_t want_wgs = (P <= 32 && !symmetric) ? 4 * target_wgs : target_wgs;
-    if (tiles < want_wgs) {
+    if (tiles < want_wgs && (tiles <= 64 || K < 64 * TK)) {
         nsplit = want_wgs / tiles;   // floor: never more workgroups than the target (no tail wave)
         if (nsplit < 1) nsplit = 1;
         const int64_t maxsplit = (K + 4 * TK - 1) / (4 * TK);
+        if (nsplit > maxsplit) nsplit = maxsplit;
+        if (nsplit < 1) nsplit = 1;
+    } else if (tiles < 8 * want_wgs && K >= 64 * TK) {
+        // 65 .. 2000 long tiles (136 for a 2048-column Gram, 528 for 4096 columns) quantise badly on 256 CUs x 2
+        // resident workgroups (528 -> two rounds, the second one almost empty; 136 -> half of the CUs idle): cut K
+        // until there are ~8 rounds worth of shorter work items
+        nsplit = (8 * want_wgs + tiles - 1) / tiles;
+        const int64_t maxsplit = (K + 32 * TK - 1) / (32 * TK);
         if (nsplit > maxsplit) nsplit = maxsplit;
         if (nsplit < 1) nsplit = 1;
     }
