@@ -19,6 +19,7 @@ ap.add_argument("r", type=int)
 ap.add_argument("--f32", action="store_true")
 ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--want-s", action="store_true")
+ap.add_argument("--randomized", action="store_true", help="svd = rsvd-style hook (TLSQ_SVD_RANDOMIZED)")
 ap.add_argument("--no-hist", action="store_true", help="device-resident call without cost history (what bench.py times)")
 a = ap.parse_args()
 D, A0, _ = O.synth_lowrank_sparse(a.M, a.N, a.r, seed=0)
@@ -27,13 +28,15 @@ if a.f32:
 eng = tlsq_amd.Engine(0)
 eng.rpca(np.asarray(D[:256, :64]), iters=2)   # warm up
 t0 = time.perf_counter()
+from tlsq_amd import _lib as L
+hook = dict(svd_mode=L.SVD_RANDOMIZED) if a.randomized else {}
 if a.no_hist:
     dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda()
     dA, dE = torch.empty_like(dD), torch.empty_like(dD)
-    eng.rpca_device(dD.data_ptr(), a.M, a.N, dA.data_ptr(), dE.data_ptr(), want_hist=False, dtype=D.dtype)   # warm-up
+    eng.rpca_device(dD.data_ptr(), a.M, a.N, dA.data_ptr(), dE.data_ptr(), want_hist=False, dtype=D.dtype, **hook)   # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sv, rep, st = eng.rpca_device(dD.data_ptr(), a.M, a.N, dA.data_ptr(), dE.data_ptr(), want_hist=False, dtype=D.dtype)
+    sv, rep, st = eng.rpca_device(dD.data_ptr(), a.M, a.N, dA.data_ptr(), dE.data_ptr(), want_hist=False, dtype=D.dtype, **hook)
     A, E = dA.cpu().numpy().T, dE.cpu().numpy().T
     s = tlsq_amd.SVD(None, np.full(1, np.nan), None) if hasattr(tlsq_amd, "SVD") else type("S", (), {"S": np.full(1, np.nan)})()
 else:
