@@ -27,7 +27,7 @@ struct Comm;  // RCCL state (runtime.hip)
 struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[33] = {};   // two banks of 16 phase marks (PhaseTimer) + one for small readbacks
+    hipEvent_t ev[34] = {};   // two banks of 16 phase marks (PhaseTimer) + [32] small readbacks + [33] Lanczos read-back
     std::string err;
     // grow-only device workspace, keyed by slot
     std::vector<DevBuf> ws;
@@ -171,6 +171,20 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
 // estimate) if not reached within max_steps so the caller can fall back to the Jacobi solver.
 // accept_below > 0: also stop (status 0) as soon as 2.5 * estimate < accept_below after >= 16 steps.
 // stop_above > 0: also stop (status 0) as soon as the Ritz value (a lower bound of lambda_max) reaches stop_above.
+// the two halves of lanczos_lmax_f64: begin queues the first steps and the read-back and records an event, finish
+// waits for that event only (kernels queued in between keep running) and decides / continues
+struct LanczosRun {
+    const double* G = nullptr;
+    int64_t N = 0, ldG = 0;
+    double rel_tol = 0.0, accept_below = 0.0, stop_above = 0.0;
+    int max_steps = 0, cap = 0, launched = 0, chunk = 0;
+    double *st = nullptr, *ab = nullptr;
+    size_t lds = 0;
+    bool event_pending = false, trivial = false, unsupported = false;
+};
+int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
+                  double accept_below, double stop_above);
+int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used);
 // the same for an operator given only as a product w = Op(q) on N-vectors (device pointers, handle's stream)
 using LzApply = std::function<int(const double* q, double* w)>;
 int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, int max_steps, double* lmax,

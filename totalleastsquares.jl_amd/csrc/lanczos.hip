@@ -195,82 +195,126 @@ static double tridiag_lmax(const double* a, const double* b, int m, double* last
     return theta;
 }
 
-// returns TLSQ_OK and *lmax, or 1 if the requested accuracy was not reached in max_steps (caller falls back)
-int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used, double accept_below, double stop_above) {
+// ---- explicit matrix: begin / finish ---------------------------------------------------------------------------
+// lanczos_begin queues the first chunk of steps and the read-back of (alpha, beta) and records an event;
+// lanczos_finish waits for that event only (work queued behind it keeps running), evaluates the Ritz value and the
+// residual bound, and - rarely - runs further chunks synchronously.  lanczos_lmax_f64 is begin + finish.
+static int lz_launch_chunk(Handle* h, LanczosRun& r) {
+    const int n = std::min(r.chunk, r.max_steps + 1 - r.launched);
+    for (int k = 0; k < n; ++k, ++r.launched)
+        hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
+                           r.ab, r.cap, r.launched);
+    TLSQ_HIP(h, hipGetLastError());
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, r.ab, (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
+    return TLSQ_OK;
+}
+
+int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
+                  double accept_below, double stop_above) {
+    r = LanczosRun();
+    r.G = G;
+    r.N = N;
+    r.ldG = ldG;
+    r.rel_tol = rel_tol;
+    r.accept_below = accept_below;
+    r.stop_above = stop_above;
     if (N <= 0) {
-        *lmax = 0.0;
+        r.trivial = true;
         return TLSQ_OK;
     }
     if (max_steps > (int)N) max_steps = (int)N;
     if (max_steps < 1) max_steps = 1;
-    const int cap = max_steps + 2;
+    r.max_steps = max_steps;
+    r.cap = max_steps + 2;
     void* stv;
-    const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS + 2 * (size_t)cap + 16;
+    const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS + 2 * (size_t)r.cap + 16;
     TLSQ_TRY(ws_get(h, WS_AUX4, st_doubles * 8, &stv));
-    double* st = (double*)stv;
-    double* ab = st + 8 + 5 * (size_t)N + 2 * LZ_WGS;
-    const size_t lds = (size_t)(N + 8) * 8;
-    if (lds > 150 * 1024 || (size_t)(2 * cap) * 8 + 64 > h->pinned_bytes) return 1;
-    if (lds > 48 * 1024)
+    r.st = (double*)stv;
+    r.ab = r.st + 8 + 5 * (size_t)N + 2 * LZ_WGS;
+    r.lds = (size_t)(N + 8) * 8;
+    if (r.lds > 150 * 1024 || (size_t)(2 * r.cap) * 8 + 64 > h->pinned_bytes) {
+        r.unsupported = true;
+        return TLSQ_OK;
+    }
+    if (r.lds > 48 * 1024)
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lanczos_step),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    TLSQ_HIP(h, hipMemsetAsync(st, 0, 64, h->stream));
-    std::vector<double> hab((size_t)2 * cap);
-    int launched = 0;  // launches issued; launch j completes the pair (alpha_{j-1}, beta_{j-1})
-    double theta = 0.0;
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.lds));
+    TLSQ_HIP(h, hipMemsetAsync(r.st, 0, 64, h->stream));
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
-    int chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;
-    while (launched < max_steps + 1) {
-        const int n = std::min(chunk, max_steps + 1 - launched);
-        for (int k = 0; k < n; ++k, ++launched)
-            hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), lds, h->stream, G, ldG, (int)N,
-                               st, ab, cap, launched);
-        TLSQ_HIP(h, hipGetLastError());
-        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, st, 64, hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, ab, (size_t)2 * cap * 8, hipMemcpyDeviceToHost,
-                                   h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    r.chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;
+    TLSQ_TRY(lz_launch_chunk(h, r));
+    TLSQ_HIP(h, hipEventRecord(h->ev[33], h->stream));
+    r.event_pending = true;
+    return TLSQ_OK;
+}
+
+// returns TLSQ_OK and *lmax, or 1 if the requested accuracy was not reached in max_steps (caller falls back)
+int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used) {
+    if (r.trivial) {
+        *lmax = 0.0;
+        return TLSQ_OK;
+    }
+    if (r.unsupported) return 1;
+    std::vector<double> hab((size_t)2 * r.cap);
+    double theta = 0.0;
+    for (;;) {
+        if (r.event_pending) {
+            TLSQ_HIP(h, hipEventSynchronize(h->ev[33]));
+            r.event_pending = false;
+        } else {
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
         double hs[8];
         memcpy(hs, h->pinned, 64);
-        memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * cap * 8);
+        memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * r.cap * 8);
         const int m = (int)hs[2];
         const bool broke = hs[1] != 0.0;
-        if (m <= 0) {
-            if (broke) break;
-            continue;
+        if (m > 0) {
+            const double* a = hab.data();
+            const double* b = hab.data() + r.cap;
+            double sm = 0.0;
+            theta = tridiag_lmax(a, b, m, &sm);
+            if (steps_used) *steps_used = m;
+            if (broke || m >= (int)r.N) {
+                *lmax = theta > 0.0 ? theta : 0.0;
+                return TLSQ_OK;
+            }
+            const double bound = fabs(b[m - 1]) * sm;  // ||G y - theta y|| for the Ritz pair
+            if (bound <= r.rel_tol * fabs(theta)) {
+                *lmax = theta > 0.0 ? theta : 0.0;
+                return TLSQ_OK;
+            }
+            // the Ritz value is a lower bound of lambda_max: "is lambda_max >= X?" is settled as soon as it passes X
+            if (r.stop_above > 0.0 && theta >= r.stop_above) {
+                *lmax = theta;
+                return TLSQ_OK;
+            }
+            // early accept for "is lambda_max clearly below X?" questions: the Ritz value is a lower bound that is
+            // already within ~15 % of lambda_max after 16 steps even on flat (noise-like) spectra
+            if (r.accept_below > 0.0 &&
+                ((m >= 16 && 2.5 * theta < r.accept_below) || (m >= 8 && 5.0 * theta < r.accept_below) ||
+                 (m >= 4 && 10.0 * theta < r.accept_below))) {
+                *lmax = theta > 0.0 ? theta : 0.0;
+                return TLSQ_OK;
+            }
+            if (r.chunk < 64) r.chunk *= 2;
+        } else if (broke) {
+            break;
         }
-        const double* a = hab.data();
-        const double* b = hab.data() + cap;
-        double sm = 0.0;
-        theta = tridiag_lmax(a, b, m, &sm);
-        if (steps_used) *steps_used = m;
-        if (broke || m >= (int)N) {
-            *lmax = theta > 0.0 ? theta : 0.0;
-            return TLSQ_OK;
-        }
-        const double bound = fabs(b[m - 1]) * sm;  // ||G y - theta y|| for the Ritz pair
-        if (bound <= rel_tol * fabs(theta)) {
-            *lmax = theta > 0.0 ? theta : 0.0;
-            return TLSQ_OK;
-        }
-        // the Ritz value is a lower bound of lambda_max: "is lambda_max >= X?" is settled as soon as it passes X
-        if (stop_above > 0.0 && theta >= stop_above) {
-            *lmax = theta;
-            return TLSQ_OK;
-        }
-        // early accept for "is lambda_max clearly below X?" questions: the Ritz value is a lower bound that is
-        // already within ~15 % of lambda_max after 16 steps even on flat (noise-like) spectra
-        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 8 && 5.0 * theta < accept_below) ||
-                                   (m >= 4 && 10.0 * theta < accept_below))) {
-            *lmax = theta > 0.0 ? theta : 0.0;
-            return TLSQ_OK;
-        }
-        if (chunk < 64) chunk *= 2;
+        if (r.launched >= r.max_steps + 1) break;
+        TLSQ_TRY(lz_launch_chunk(h, r));
     }
     *lmax = theta > 0.0 ? theta : 0.0;
     return 1;
+}
+
+int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
+                     double* lmax, int* steps_used, double accept_below, double stop_above) {
+    LanczosRun r;
+    TLSQ_TRY(lanczos_begin(h, r, G, N, ldG, rel_tol, max_steps, accept_below, stop_above));
+    return lanczos_finish(h, r, lmax, steps_used);
 }
 
 // ---- Lanczos on an operator that is only available as a product (large mode: G = Z'Z is never formed) ---------
