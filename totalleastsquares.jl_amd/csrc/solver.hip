@@ -204,6 +204,11 @@ struct SubspaceState {
     enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4 };
     int fail = FAIL_NONE;
     bool skip_certificate = false;   // the caller certifies the count itself (late iterations, see svd_precise_fast)
+    // deferred certificate: svd_subspace returns with *ok = true as soon as the Lanczos steps of the certificate are
+    // queued; the caller queues its own work (the rebuild) behind them and then asks svd_subspace_certify
+    bool defer_certificate = false;
+    bool cert_pending = false;
+    LanczosRun cert;
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
 };
@@ -241,6 +246,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                         double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
     *ok = false;
     st.fail = SubspaceState::FAIL_NONE;
+    st.cert_pending = false;
     const bool hook = st.hook_rank > 0;
     const bool cold = hook || !st.valid;
     if (hook) {
@@ -434,7 +440,14 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
         if (svp > 0) TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
         else TLSQ_HIP(h, hipMemcpyAsync(GD, op.G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-        lst = lanczos_lmax_f64(h, (const double*)GD, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
+        TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, inv_mu * inv_mu, 0.0));
+        if (st.defer_certificate) {
+            st.cert_pending = true;
+            *V_out = (double*)X;
+            *ok = true;   // tentatively: svd_subspace_certify has the last word
+            return TLSQ_OK;
+        }
+        lst = lanczos_finish(h, st.cert, &lmax, &steps);
     } else {
         // the deflated operator as a product: w = G q - Vs (Vg' q)
         void* cv;
@@ -452,6 +465,23 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         return TLSQ_OK;
     }
     *V_out = (double*)X;
+    *ok = true;
+    return TLSQ_OK;
+}
+
+// Second half of a deferred count certificate (SubspaceState::defer_certificate): waits for the read-back of the
+// Lanczos coefficients only - whatever the caller queued behind them keeps running.
+static int svd_subspace_certify(Handle* h, SubspaceState& st, double inv_mu, bool* ok) {
+    *ok = false;
+    st.cert_pending = false;
+    double lmax = 0.0;
+    int steps = 0;
+    const int lst = lanczos_finish(h, st.cert, &lmax, &steps);
+    if (lst < 0) return lst;
+    if (!(lmax * 1.5 < inv_mu * inv_mu)) {
+        st.fail = SubspaceState::FAIL_CERT;
+        return TLSQ_OK;
+    }
     *ok = true;
     return TLSQ_OK;
 }
@@ -700,6 +730,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
     static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
     static const bool no_fuse_rebuild = [] { const char* e = getenv("TLSQ_NO_FUSED_REBUILD"); return e && e[0] == '1'; }();
+    static const bool no_cert_overlap = [] { const char* e = getenv("TLSQ_NO_CERT_OVERLAP"); return e && e[0] == '1'; }();
     const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
     int64_t r_last = 0;
     bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
@@ -798,6 +829,48 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
         bool precise_fast = false;
+        // Rank count, singular-value thresholding and the factors of A for the decomposition currently in (s, V).
+        // Normally called once after the SVD step; with a deferred count certificate it is called right after the
+        // subspace solver (the rebuild kernels queue up behind the certificate's Lanczos steps) and, should the
+        // certificate fail, once more after the fall-back.
+        double sigma_top = 0.0, mu_next = mu;
+        bool fuse = false, fuse_rebuild = false, rebuilt = false, rebuild_marked = false;
+        auto count_and_rebuild = [&](bool mark) -> int {
+            if (mark) {
+                pt.mark();
+                rebuild_marked = true;
+            }
+            // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
+            // singular values below sigma_res = sqrt(8 N eps) * sigma_max cannot be told from zero.
+            // The reference's threshold 1/mu only drops that low after ~36 iterations (mu_bar = 1e7 mu_0); from
+            // there on unresolved values are treated as zero instead of being counted at random.
+            sigma_top = s.ncols > 0 ? s.sigma[s.order[0]] : 0.0;
+            sigma_top_prev = sigma_top;
+            const double sigma_res = precise ? 0.0 : std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
+            const double count_thr = std::max(inv_mu, sigma_res);
+            svp = 0;                                                   // :198
+            for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= count_thr) ? 1 : 0;
+            sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+            std::vector<int32_t> sel((size_t)svp);
+            std::vector<double> g((size_t)svp);
+            for (int64_t p = 0; p < svp; ++p) {
+                sel[p] = s.order[p];
+                const double sg = s.sigma[sel[p]];
+                g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+            }
+            mu_next = std::min(mu * ro.rho, mubar);                    // :223
+            fuse = !no_fuse && k < ro.iters;
+            // large panels: A = T Vs' is not written at all, the fused sweep below forms it in registers from the
+            // factors (7 panel passes per iteration instead of 8 + the pass of the skinny GEMM that writes A)
+            fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
+                           rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
+            TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
+            r_last = svp;
+            if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+            a_pending = fuse_rebuild;
+            rebuilt = true;
+            return TLSQ_OK;
+        };
         if (precise && use_subspace && sub.valid) {
             if (g_ready) G = (double*)h->ws[WS_G].p;
             else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
@@ -832,7 +905,22 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
         } else if (use_subspace) {
-            TLSQ_TRY(svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok));
+            sub.defer_certificate = !no_cert_overlap;
+            const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
+            sub.defer_certificate = false;
+            if (st_sub < 0) return st_sub;
+            if (fast_ok && sub.cert_pending) {
+                // the certificate's Lanczos steps are queued: put the rebuild right behind them, then wait for the
+                // certificate's read-back only - the host round trip is hidden behind the rebuild kernels.  (Z and G
+                // are not modified by the rebuild, so a failed certificate costs nothing but the redo below.)
+                TLSQ_TRY(count_and_rebuild(true));
+                bool cert_ok = false;
+                TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
+                if (!cert_ok) {
+                    fast_ok = false;
+                    rebuilt = false;
+                }
+            }
         }
         if (!fast_ok && use_subspace && !(hook_svd && k >= 2) && sub.fail != SubspaceState::FAIL_NONE) {
             // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
@@ -877,35 +965,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }   // !precise
         v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2) && !chol_route(N);
         prev_full = !precise && !fast_ok;
-        pt.mark();
-        // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
-        // singular values below sigma_res = sqrt(8 N eps) * sigma_max cannot be told from zero.
-        // The reference's threshold 1/mu only drops that low after ~36 iterations (mu_bar = 1e7 mu_0); from
-        // there on unresolved values are treated as zero instead of being counted at random.
-        const double sigma_top = s.ncols > 0 ? s.sigma[s.order[0]] : 0.0;
-        sigma_top_prev = sigma_top;
-        const double sigma_res = precise ? 0.0 : std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
-        const double count_thr = std::max(inv_mu, sigma_res);
-        svp = 0;                                                   // :198
-        for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= count_thr) ? 1 : 0;
-        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
-        std::vector<int32_t> sel((size_t)svp);
-        std::vector<double> g((size_t)svp);
-        for (int64_t p = 0; p < svp; ++p) {
-            sel[p] = s.order[p];
-            const double sg = s.sigma[sel[p]];
-            g[p] = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
-        }
-        const double mu_next = std::min(mu * ro.rho, mubar);       // :223
-        const bool fuse = !no_fuse && k < ro.iters;
-        // large panels: A = T Vs' is not written at all, the fused sweep below forms it in registers from the factors
-        // (7 panel passes per iteration instead of 8 + the pass of the skinny GEMM that writes A)
-        const bool fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
-                                  rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
-        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
-        r_last = svp;
-        if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
-        a_pending = fuse_rebuild;
+        if (!rebuilt) TLSQ_TRY(count_and_rebuild(!rebuild_marked));
         if (use_subspace && (!precise || precise_fast)) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
 
