@@ -43,17 +43,28 @@ struct PhaseTimer {
     bool on;
     int bank = 0;
     int n[2] = {0, 0};
+    int slot[2][16] = {};   // event behind each mark (an empty phase reuses the previous mark's event)
     explicit PhaseTimer(Handle* hh, bool enable) : h(hh), on(enable) {}
-    void mark() {
-        if (on && n[bank] < 16) (void)hipEventRecord(h->ev[bank * 16 + n[bank]++], h->stream);
+    // empty = nothing was queued since the previous mark: no event is recorded (every recorded event is a barrier
+    // packet the command processor has to work through between two kernels), the phase simply gets zero time
+    void mark(bool empty = false) {
+        if (!on || n[bank] >= 16) return;
+        const int i = n[bank]++;
+        if (empty && i > 0) {
+            slot[bank][i] = slot[bank][i - 1];
+            return;
+        }
+        slot[bank][i] = bank * 16 + i;
+        (void)hipEventRecord(h->ev[slot[bank][i]], h->stream);
     }
-    // adds elapsed(ev[i], ev[i+1]) of bank b to *acc[i]; the bank's last event must have completed
+    // adds elapsed(mark i, mark i+1) of bank b to *acc[i]; the bank's last event must have completed
     void collect_bank(int b, double** acc) {
         if (on && n[b] > 0) {
-            (void)hipEventSynchronize(h->ev[b * 16 + n[b] - 1]);
+            (void)hipEventSynchronize(h->ev[slot[b][n[b] - 1]]);
             for (int i = 0; i + 1 < n[b]; ++i) {
+                if (slot[b][i] == slot[b][i + 1]) continue;
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, h->ev[b * 16 + i], h->ev[b * 16 + i + 1]) == hipSuccess && acc[i])
+                if (hipEventElapsedTime(&ms, h->ev[slot[b][i]], h->ev[slot[b][i + 1]]) == hipSuccess && acc[i])
                     *acc[i] += ms;
             }
         }

@@ -822,7 +822,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         pt.mark();
         if (!have_next)
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
-        pt.mark();
+        pt.mark(have_next);
         // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
         const bool precise = !large && !hook_svd && sigma_top_prev > 0.0 &&
                              inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
@@ -889,6 +889,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             ++n_precise;
         } else if (!precise) {
         GramOp op = panel_op(Z);
+        const bool gram_queued_earlier = g_ready || implicit_gram;
         if (!implicit_gram) {
             if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
             else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
@@ -896,7 +897,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             op.G = G;
         }
         g_ready = false;
-        pt.mark();
+        pt.mark(gram_queued_earlier);
         if (hook_svd && k >= 2) {
             // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
             SubspaceState rs;
@@ -1063,7 +1064,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 cost = rn / d_norm;
             }
         }
-        pt.mark();
+        pt.mark(cost_skipped);
         pt.next_iteration(acc);   // (no stream-wide synchronisation here: the next Gram may still be running)
         if (info) {
             info->iters_done = k;
