@@ -517,13 +517,13 @@ int tlsq_k_update_shrink_f64(tlsq_handle h, const double* D, double* A, const do
                              double* En, double* Zn, int64_t n, double mu, int nonnegA, double inv_mu_next,
                              double thr_next, int nonnegE) {
     TLSQ_TRY(check_handle(h));
-    return launch_update_shrink<double>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr);
+    return launch_update_shrink<double>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr, nullptr);
 }
 int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const float* E, float* Y, float* R,
                              float* En, float* Zn, int64_t n, float mu, int nonnegA, float inv_mu_next,
                              float thr_next, int nonnegE) {
     TLSQ_TRY(check_handle(h));
-    return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr);
+    return launch_update_shrink<float>(h, D, A, E, Y, R, En, Zn, n, mu, nonnegA, inv_mu_next, thr_next, nonnegE, nullptr, nullptr);
 }
 int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* E,
                                      double* Y, double* R, double* En, double* Zn, int64_t M, int64_t N, int64_t r,
@@ -531,7 +531,7 @@ int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const doubl
     TLSQ_TRY(check_handle(h));
     if (M % 2 != 0 || r > 32 || r < 0) return set_err(h, TLSQ_ERR_ARG, "k_rebuild_update_shrink: needs even M and r <= 32");
     return launch_rebuild_update_shrink<double>(h, D, Tm, Vs, E, Y, R, En, Zn, M, N, r, mu, nonnegA, inv_mu_next,
-                                                thr_next, nonnegE, nullptr);
+                                                thr_next, nonnegE, nullptr, nullptr);
 }
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
                     int64_t ldG) {

@@ -94,7 +94,8 @@ template <typename T>
 // sumsq (optional, device, 64 doubles): their sum += ||R_k||_F^2 (atomic adds: a bound, never a result)
 // R may be nullptr (residual not stored; launch_residual recomputes it if it is needed after all)
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
-                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq = nullptr);
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq = nullptr,
+                         double* zero_slots = nullptr);   // zero_slots: 64 doubles cleared for the next sweep
 // Y = D / s  (src/robustPCA.jl:181), contiguous n
 template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s);
@@ -111,7 +112,7 @@ bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, 
 template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                 int nonnegE, double* sumsq);
+                                 int nonnegE, double* sumsq, double* zero_slots = nullptr);
 // dst (N x M, ld ldd) = src' for src (M x N, ld lds)
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd);
@@ -153,6 +154,13 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
                bool warm_v = false);
 // warm_v: V holds the previous decomposition's eigenvectors (orthogonal): start from B = G*V.
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
+// selection + weights small enough to travel as kernel arguments (r <= 32)
+struct SelWeights {
+    int32_t sel[32];
+    double w[32];
+};
+int launch_gather_scale_arg(Handle* h, const double* V, int64_t N, const SelWeights& sw, int64_t r, double* Vg,
+                            double* Vs);
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);
 

@@ -603,6 +603,19 @@ __global__ __launch_bounds__(256) void k_gather_scale(const double* __restrict__
     }
 }
 
+// the same with the (short) selection and weights passed as kernel arguments: no upload, no extra command
+__global__ __launch_bounds__(256) void k_gather_scale_arg(const double* __restrict__ V, int N, SelWeights sw, int r,
+                                                          double* __restrict__ Vg, double* __restrict__ Vs) {
+    const int64_t total = (int64_t)N * r;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t row = e % N, p = e / N;
+        const double v = V[(int64_t)sw.sel[p] * N + row];
+        if (Vs) Vs[e] = v;
+        if (Vg) Vg[e] = sw.w[p] * v;
+    }
+}
+
 static int pick_block(int64_t N, bool want_v, bool* single) {
     // 2b columns of B (and of V) resident in LDS; leave headroom below 160 KiB
     const int64_t budget = 150 * 1024;
@@ -860,6 +873,16 @@ int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* se
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_gather_scale, dim3((int)g), dim3(256), 0, h->stream, V, (int)N, sel_dev, g_dev,
                        (int)r, Vg, Vs);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_gather_scale_arg(Handle* h, const double* V, int64_t N, const SelWeights& sw, int64_t r, double* Vg,
+                            double* Vs) {
+    if (r <= 0) return TLSQ_OK;
+    int64_t g = (N * r + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_gather_scale_arg, dim3((int)g), dim3(256), 0, h->stream, V, (int)N, sw, (int)r, Vg, Vs);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

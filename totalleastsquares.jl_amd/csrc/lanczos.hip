@@ -51,7 +51,8 @@ __device__ __forceinline__ double block_sum4(double v, double* red) {
 //     partial of q_new . u_new.
 // Vectors rotate through 3 buffers, u and the partials through 2, so no launch overwrites what its own
 // (slower) workgroups still read.  Workgroup 0 records alpha_{j-1}, beta_{j-1}.
-// layout of `st` (doubles): [0..8) header {beta_prev, breakdown, ...}; vec[3][N]; u[2][N]; part[2][LZ_WGS]
+// layout of `st` (doubles): [0..8) header {-, breakdown, pairs done}; alpha[cap], beta[cap]; vec[3][N]; u[2][N];
+// part[2][LZ_WGS]
 __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __restrict__ G, int64_t ldG,
                                                              int N, double* __restrict__ st,
                                                              double* __restrict__ ab, int maxsteps, int j) {
@@ -59,11 +60,18 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
     double* q = sm;           // N  (q_new)
     double* red = sm + N;     // 4
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double* vec = st + 8;
+    double* vec = st + 8 + 2 * (size_t)maxsteps;   // (alpha, beta) sit right behind the header: one read-back
     double* ubuf = vec + 3 * (size_t)N;
     double* part = ubuf + 2 * (size_t)N;
     double* vnew = vec + (size_t)(j % 3) * N;
-    if (st[1] != 0.0) return;  // breakdown flagged by an earlier launch
+    if (j == 0) {
+        if (blockIdx.x == 0 && tid == 0) {   // the first launch of a run resets the header (no separate memset)
+            st[1] = 0.0;
+            st[2] = 0.0;
+        }
+    } else if (st[1] != 0.0) {
+        return;  // breakdown flagged by an earlier launch
+    }
     if (j == 0) {
         // deterministic pseudo-random start vector (integer hash), normalised
         double nrm = 0.0;
@@ -205,8 +213,7 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
         hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
                            r.ab, r.cap, r.launched);
     TLSQ_HIP(h, hipGetLastError());
-    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64, hipMemcpyDeviceToHost, h->stream));
-    TLSQ_HIP(h, hipMemcpyAsync((char*)h->pinned + 64, r.ab, (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64 + (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
     return TLSQ_OK;
 }
 
@@ -231,7 +238,7 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS + 2 * (size_t)r.cap + 16;
     TLSQ_TRY(ws_get(h, WS_AUX4, st_doubles * 8, &stv));
     r.st = (double*)stv;
-    r.ab = r.st + 8 + 5 * (size_t)N + 2 * LZ_WGS;
+    r.ab = r.st + 8;
     r.lds = (size_t)(N + 8) * 8;
     if (r.lds > 150 * 1024 || (size_t)(2 * r.cap) * 8 + 64 > h->pinned_bytes) {
         r.unsupported = true;
@@ -240,7 +247,6 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     if (r.lds > 48 * 1024)
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lanczos_step),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.lds));
-    TLSQ_HIP(h, hipMemsetAsync(r.st, 0, 64, h->stream));
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
     r.chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;

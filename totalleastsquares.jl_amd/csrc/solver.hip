@@ -228,6 +228,24 @@ static int upload_sel_weights(Handle* h, void* aux, const std::vector<int32_t>& 
     return TLSQ_OK;
 }
 
+// Vg = V[:, sel] * diag(w), Vs = V[:, sel] for host-side sel / w: as kernel arguments when short, through `aux` otherwise
+static int gather_scale_host(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel,
+                             const std::vector<double>& w, void* aux, double* Vg, double* Vs) {
+    const int64_t r = (int64_t)sel.size();
+    if (r <= 32) {
+        SelWeights sw;
+        for (int64_t i = 0; i < 32; ++i) {
+            sw.sel[i] = i < r ? sel[i] : 0;
+            sw.w[i] = i < r ? w[i] : 0.0;
+        }
+        return launch_gather_scale_arg(h, V, N, sw, r, Vg, Vs);
+    }
+    int32_t* dsel;
+    double* dw;
+    TLSQ_TRY(upload_sel_weights(h, aux, sel, w, &dsel, &dw));
+    return launch_gather_scale(h, V, N, dsel, dw, r, Vg, Vs);
+}
+
 // upload a column selection and gather X = V[:, sel]
 static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
     const int64_t r = (int64_t)sel.size();
@@ -428,10 +446,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             sel[i] = s.order[i];
             th[i] = host[sel[i]];
         }
-        int32_t* dsel;
-        double* dth;
-        TLSQ_TRY(upload_sel_weights(h, aux, sel, th, &dsel, &dth));
-        TLSQ_TRY(launch_gather_scale(h, (const double*)X, N, dsel, dth, svp, (double*)Vg, (double*)Vs));
+        TLSQ_TRY(gather_scale_host(h, (const double*)X, N, sel, th, aux, (double*)Vg, (double*)Vs));
     }
     double lmax = 0.0;
     int steps = 0;
@@ -501,10 +516,7 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
     TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T1));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
-    int32_t* dsel;
-    double* dg;
-    TLSQ_TRY(upload_sel_weights(h, aux, sel, g, &dsel, &dg));
-    TLSQ_TRY(launch_gather_scale(h, V, N, dsel, dg, r, (double*)Vg, (double*)Vs));
+    TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
     if (r <= 32 && !no_tsmm) {
@@ -736,6 +748,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
     double prev_lower = 0.0;                               // Frobenius lower bound of the previous iteration's cost
     int64_t n_rskip = 0;
+    bool sumsq_ready = false;   // the two accumulator sets of the Frobenius bound have been cleared
     static const double rskip_margin = [] { const char* e = getenv("TLSQ_RSKIP_MARGIN"); return e ? atof(e) : 8.0; }();
     int64_t sweeps = 0;
     const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
@@ -974,12 +987,19 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // side; while that lower bound of the cost is clearly above tol the iteration cannot be the last one and
         // the Gram + Lanczos evaluation of opnorm(R) is skipped altogether.
         const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
-        double* sumsq_dev = nullptr;
+        double *sumsq_dev = nullptr, *sumsq_next = nullptr;
         if (fuse && !want_exact_cost && !hook_opnorm) {
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-            sumsq_dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);   // 64 partial sums
-            TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 512, h->stream));   // (before the mark: the sweep phase times the sweep)
+            // two sets of 64 partial sums, used alternately: each sweep clears the set of the next one (no memset
+            // command between the kernels); both are cleared once on first use
+            double* set0 = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 512);
+            if (!sumsq_ready) {
+                TLSQ_HIP(h, hipMemsetAsync(set0, 0, 1024, h->stream));
+                sumsq_ready = true;
+            }
+            sumsq_dev = set0 + 64 * (k & 1);
+            sumsq_next = set0 + 64 * ((k + 1) & 1);
         }
         // The residual panel R_k is only read by the cost evaluation.  While the Frobenius bound of the previous
         // iteration was far above tol this one's will be too (the cost shrinks by ~rho per iteration): the sweep then
@@ -992,12 +1012,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
             TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
                                                      svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
-                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev));
+                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next));
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
-                                             ro.nonnegE ? 1 : 0, sumsq_dev));
+                                             ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next));
         } else {
             TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
         }

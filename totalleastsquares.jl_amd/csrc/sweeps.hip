@@ -105,8 +105,11 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
                                                        const T* __restrict__ E, T* __restrict__ Y,
                                                        T* __restrict__ R, T* __restrict__ En, T* __restrict__ Zn,
                                                        int64_t n, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                                       int nonnegE, double* __restrict__ sumsq) {
+                                                       int nonnegE, double* __restrict__ sumsq,
+                                                       double* __restrict__ zero_slots) {
     using V = T __attribute__((ext_vector_type(VEC)));
+    // the accumulator set of the NEXT sweep is cleared here (its previous contents were read back long ago): no memset
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
     const int64_t nv = n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,8 +200,10 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
                                                                T* __restrict__ R, T* __restrict__ En,
                                                                T* __restrict__ Zn, int64_t M, int N, int r, int ct,
                                                                T mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
-                                                               double* __restrict__ sumsq) {
+                                                               double* __restrict__ sumsq,
+                                                               double* __restrict__ zero_slots) {
     using VR = T __attribute__((ext_vector_type(ROWS)));
+    if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
     __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
     const int c0 = blockIdx.y * ct;
     const int nct = (N - c0 < ct) ? N - c0 : ct;
@@ -403,15 +408,15 @@ int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n
 
 template <typename T>
 int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T* En, T* Zn, int64_t n, T mu,
-                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq) {
+                         int nonnegA, T inv_mu_n, T thr_n, int nonnegE, double* sumsq, double* zero_slots) {
     if (n <= 0) return TLSQ_OK;
     constexpr int VEC = 16 / sizeof(T);
     if (aligned16(D) && aligned16(A) && aligned16(Y) && aligned16(E) && aligned16(R) && aligned16(En) && aligned16(Zn)) {   // (a null R is aligned)
         hipLaunchKernelGGL((k_update_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, E,
-                           Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq);
+                           Y, R, En, Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
     } else {
         hipLaunchKernelGGL((k_update_shrink<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, E, Y, R, En,
-                           Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq);
+                           Zn, n, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
@@ -432,7 +437,7 @@ bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, 
 template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                 int nonnegE, double* sumsq) {
+                                 int nonnegE, double* sumsq, double* zero_slots) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     // tall panels: two rows per thread, 64-column tiles.  Otherwise one row per thread and tiles narrow enough to
     // put ~16 waves on every CU (each tile re-reads its rows of T from L2, so not narrower than needed).
@@ -451,7 +456,7 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
     const dim3 grid((unsigned)((M / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
 #define RUS_LAUNCH(RM, RW)                                                                                           \
     hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW>), grid, dim3(256), 0, h->stream, D, Tm, Vs, E, Y, R, En, Zn, \
-                       M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq)
+                       M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots)
     if (two2) {
         if (r <= 8) RUS_LAUNCH(8, 2);
         else if (r <= 16) RUS_LAUNCH(16, 2);
@@ -549,10 +554,10 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
     template int launch_update_shrink<T>(Handle*, const T*, T*, const T*, T*, T*, T*, T*, int64_t, T, int, T, T, \
-                                         int, double*);                                                     \
+                                         int, double*, double*);                                                     \
     template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
-                                                 T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*); \
+                                                 T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*); \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
