@@ -38,6 +38,12 @@ struct Handle {
     // and the host may reuse its own buffer at once; see upload_async() in runtime.hip
     void* up_ring = nullptr;
     size_t up_bytes = 0, up_off = 0;
+    // host-visible mailbox (coherent pinned memory, 32 KB) kernels write small results to; the host polls mailbox[0]
+    double* mailbox = nullptr;       // host address
+    size_t mailbox_bytes = 0;
+    double* mailbox_dev = nullptr;   // device address of the same memory
+    double mail_seq = 0.0;
+    bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
     // warm start of the full Jacobi solver: WS_V holds the eigenvectors of the previous full decomposition
@@ -189,6 +195,8 @@ struct LanczosRun {
     double *st = nullptr, *ab = nullptr;
     size_t lds = 0;
     bool event_pending = false, trivial = false, unsupported = false;
+    bool mail_ok = false, use_mail = false;   // read-back through the handle's mailbox (polled) instead of copy + event
+    double seq = 0.0;
 };
 int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
                   double accept_below, double stop_above);
@@ -233,8 +241,11 @@ int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int6
                     const double* skip_status = nullptr);
 int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r, const double* q, double* c, double* w,
                        int64_t N);
+// mailbox_dev != nullptr (and p <= 256): theta, res and status[0..1] are also written to the host-visible mailbox
+// and published with sequence number seq (see k_ritz_finish)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
-                       double* theta, double* res, int64_t N, int64_t p);
+                       double* theta, double* res, int64_t N, int64_t p, const double* status = nullptr,
+                       double* mailbox_dev = nullptr, unsigned int* arrivals = nullptr, double seq = 0.0);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
                       int64_t N, int64_t p);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);

@@ -11,6 +11,8 @@
 
 namespace tlsq {
 
+double now_ms();   // runtime.hip
+
 constexpr int LZ_WGS = 64;       // workgroups per step-kernel
 constexpr int LZ_THREADS = 256;  // 4 waves
 
@@ -43,6 +45,22 @@ __device__ __forceinline__ double block_sum4(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Workgroup 0 copies the header and the completed (alpha, beta) pairs to the host-visible mailbox
+// ([0] flag, [8..16) header, [16..) alpha[cap], beta[cap]) and publishes them with the sequence number.
+__device__ __forceinline__ void lz_publish(const double* st, const double* ab, int cap, double* mailbox, double seq) {
+    volatile double* mb = mailbox;
+    __syncthreads();   // st[1], st[2], ab[j-1] were written by thread 0 just before
+    const int m = (int)st[2];
+    for (int i = threadIdx.x; i < m; i += LZ_THREADS) {
+        mb[16 + i] = ab[i];
+        mb[16 + cap + i] = ab[cap + i];
+    }
+    if (threadIdx.x < 8) mb[8 + threadIdx.x] = st[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) mb[0] = seq;
+}
+
 // One Lanczos step per launch (the kernel boundary is the grid-wide dependency; ~5 us per step).
 // Launch j:
 //   phase A (every workgroup, redundantly and identically): finish step j-1 from the partial dot products
@@ -55,7 +73,8 @@ __device__ __forceinline__ double block_sum4(double v, double* red) {
 // part[2][LZ_WGS]
 __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __restrict__ G, int64_t ldG,
                                                              int N, double* __restrict__ st,
-                                                             double* __restrict__ ab, int maxsteps, int j) {
+                                                             double* __restrict__ ab, int maxsteps, int j,
+                                                             double* mailbox, double seq) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* q = sm;           // N  (q_new)
     double* red = sm + N;     // 4
@@ -70,6 +89,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
             st[2] = 0.0;
         }
     } else if (st[1] != 0.0) {
+        if (mailbox && blockIdx.x == 0) lz_publish(st, ab, maxsteps, mailbox, seq);
         return;  // breakdown flagged by an earlier launch
     }
     if (j == 0) {
@@ -112,8 +132,12 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
         }
         if (!(beta > 1e-290)) {
             if (blockIdx.x == 0 && tid == 0) st[1] = 1.0;
+            if (mailbox && blockIdx.x == 0) lz_publish(st, ab, maxsteps, mailbox, seq);
             return;
         }
+        // the last launch of a chunk hands (alpha, beta) to the host as soon as workgroup 0 has them - the host
+        // polls the flag instead of paying a copy command and a stream synchronisation
+        if (mailbox && blockIdx.x == 0) lz_publish(st, ab, maxsteps, mailbox, seq);
         const double inv = 1.0 / beta;
         for (int i = tid; i < N; i += LZ_THREADS) q[i] *= inv;
     }
@@ -209,11 +233,16 @@ static double tridiag_lmax(const double* a, const double* b, int m, double* last
 // residual bound, and - rarely - runs further chunks synchronously.  lanczos_lmax_f64 is begin + finish.
 static int lz_launch_chunk(Handle* h, LanczosRun& r) {
     const int n = std::min(r.chunk, r.max_steps + 1 - r.launched);
-    for (int k = 0; k < n; ++k, ++r.launched)
+    r.use_mail = r.mail_ok && n >= 2;
+    if (r.use_mail) r.seq = (h->mail_seq += 1.0);
+    for (int k = 0; k < n; ++k, ++r.launched) {
+        const bool last = r.use_mail && k == n - 1;
         hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
-                           r.ab, r.cap, r.launched);
+                           r.ab, r.cap, r.launched, last ? h->mailbox_dev : (double*)nullptr, r.seq);
+    }
     TLSQ_HIP(h, hipGetLastError());
-    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64 + (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
+    if (!r.use_mail)
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64 + (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
     return TLSQ_OK;
 }
 
@@ -250,9 +279,13 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
     r.chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;
+    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    r.mail_ok = h->mailbox && !no_mailbox && (size_t)(16 + 2 * r.cap) * 8 <= h->mailbox_bytes;
     TLSQ_TRY(lz_launch_chunk(h, r));
-    TLSQ_HIP(h, hipEventRecord(h->ev[33], h->stream));
-    r.event_pending = true;
+    if (!r.use_mail) {
+        TLSQ_HIP(h, hipEventRecord(h->ev[33], h->stream));
+        r.event_pending = true;
+    }
     return TLSQ_OK;
 }
 
@@ -266,15 +299,37 @@ int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used) {
     std::vector<double> hab((size_t)2 * r.cap);
     double theta = 0.0;
     for (;;) {
-        if (r.event_pending) {
-            TLSQ_HIP(h, hipEventSynchronize(h->ev[33]));
-            r.event_pending = false;
-        } else {
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        }
         double hs[8];
-        memcpy(hs, h->pinned, 64);
-        memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * r.cap * 8);
+        bool from_mail = false;
+        if (r.use_mail) {
+            volatile double* mb = h->mailbox;
+            const double t_poll = now_ms();
+            while (mb[0] != r.seq && now_ms() - t_poll < 2000.0) {
+            }
+            from_mail = mb[0] == r.seq;
+            if (from_mail) {
+                for (int i = 0; i < 8; ++i) hs[i] = mb[8 + i];
+                const int mm = (int)hs[2];
+                for (int i = 0; i < mm && i < r.cap; ++i) {
+                    hab[(size_t)i] = mb[16 + i];
+                    hab[(size_t)r.cap + i] = mb[16 + r.cap + i];
+                }
+            } else {   // time-out (never seen in practice): classic read-back, and no mailbox on this handle any more
+                h->mailbox_bytes = 0;
+                r.mail_ok = false;
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64 + (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
+            }
+        }
+        if (!from_mail) {
+            if (r.event_pending) {
+                TLSQ_HIP(h, hipEventSynchronize(h->ev[33]));
+                r.event_pending = false;
+            } else {
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
+            memcpy(hs, h->pinned, 64);
+            memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * r.cap * 8);
+        }
         const int m = (int)hs[2];
         const bool broke = hs[1] != 0.0;
         if (m > 0) {

@@ -212,6 +212,21 @@ int tlsq_create(int device_id, tlsq_handle* out) {
         delete h;
         return TLSQ_ERR_OOM;
     }
+    // optional: without it the read-backs go through copy + synchronise as before
+    void* mb = nullptr;
+    const size_t mb_bytes = 32768;
+    if (hipHostMalloc(&mb, mb_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        void* mbd = nullptr;
+        if (hipHostGetDevicePointer(&mbd, mb, 0) == hipSuccess && mbd) {
+            memset(mb, 0, mb_bytes);
+            h->mailbox = (double*)mb;
+            h->mailbox_bytes = mb_bytes;
+            h->mailbox_dev = (double*)mbd;
+        } else {
+            (void)hipHostFree(mb);
+        }
+    }
+    (void)hipGetLastError();
     *out = h;
     return TLSQ_OK;
 }
@@ -225,6 +240,7 @@ int tlsq_destroy(tlsq_handle h) {
         if (b.p) (void)hipFree(b.p);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->up_ring) (void)hipHostFree(h->up_ring);
+    if (h->mailbox) (void)hipHostFree(h->mailbox);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);

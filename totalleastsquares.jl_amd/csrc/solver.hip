@@ -337,11 +337,47 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // X' = Q S,  G X' = (G Q) S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
         // Ritz values did not come out in descending order)
-        TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X, (double*)GX,
-                                    theta_dev, res_dev, N, p));
-        TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
-                                   h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+        const bool mail = h->mailbox && !no_mailbox && p <= 256 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
+        if (mail) {
+            void* scal;
+            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+            unsigned int* arrivals = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 320);   // self-resetting
+            if (!h->mail_counter_ready) {   // (fresh workspace memory is not zero)
+                TLSQ_HIP(h, hipMemsetAsync(arrivals, 0, 4, h->stream));
+                h->mail_counter_ready = true;
+            }
+            const double seq = (h->mail_seq += 1.0);
+            TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
+                                        (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq));
+            // poll the flag (the kernel publishes it once every workgroup has delivered); generous time-out, then the
+            // classic read-back
+            volatile double* mb = h->mailbox;
+            const double t_poll = now_ms();
+            bool got = false;
+            for (;;) {
+                if (mb[0] == seq) {
+                    got = true;
+                    break;
+                }
+                if (now_ms() - t_poll > 2000.0) break;
+            }
+            if (got) {
+                for (int64_t i = 0; i < 2 * p + 2; ++i) host[(size_t)i] = mb[8 + i];
+            } else {
+                // never seen in practice; do not pay the time-out again on this handle
+                h->mailbox_bytes = 0;
+                TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
+                                           h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            }
+        } else {
+            TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
+                                        (double*)GX, theta_dev, res_dev, N, p));
+            TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
+                                       h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
         if (used_cholqr && host[2 * p + 1] != 0.0) {
             // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
             force_cgs2 = true;

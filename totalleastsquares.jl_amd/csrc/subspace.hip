@@ -665,7 +665,9 @@ int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int
 __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ Q, const double* __restrict__ GQ,
                                                      const double* __restrict__ S, double* __restrict__ X,
                                                      double* __restrict__ GX, double* __restrict__ theta,
-                                                     double* __restrict__ res, int N, int p) {
+                                                     double* __restrict__ res, int N, int p,
+                                                     const double* __restrict__ status, double* mailbox,
+                                                     unsigned int* arrivals, double seq) {
     __shared__ double sS[CQ_PMAX * 8];   // p <= 256
     __shared__ double red[4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -696,18 +698,36 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
     if (lane == 0) red[w] = rs;
     __syncthreads();
     if (tid == 0) {
+        const double rr = sqrt((red[0] + red[1]) + (red[2] + red[3]));
         theta[c] = th;
-        res[c] = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        res[c] = rr;
+        if (mailbox) {
+            // Results go straight to host-visible (coherent, pinned) memory: [0] sequence flag, [8..) theta[p], res[p],
+            // status[2].  The workgroup that arrives last publishes the flag; the host polls it instead of paying a
+            // copy command plus a stream synchronisation (~40 us) for 2p+2 numbers.
+            volatile double* mb = mailbox;
+            mb[8 + c] = th;
+            mb[8 + p + c] = rr;
+            __threadfence_system();
+            if (atomicAdd(arrivals, 1u) == (unsigned int)(p - 1)) {
+                mb[8 + 2 * p] = status ? status[0] : 0.0;
+                mb[8 + 2 * p + 1] = status ? status[1] : 0.0;
+                *arrivals = 0u;
+                __threadfence_system();
+                mb[0] = seq;
+            }
+        }
     }
 }
 
 // X = Q S, GX = GQ S, theta, res: one launch (every workgroup reads both panels); the three separate kernels remain
 // for blocks of more than 256 columns (k_panel_rot2 keeps S in LDS: p <= 90 there)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
-                       double* theta, double* res, int64_t N, int64_t p) {
+                       double* theta, double* res, int64_t N, int64_t p, const double* status, double* mailbox_dev,
+                       unsigned int* arrivals, double seq) {
     if (p <= 256) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
         hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
-                           (int)p);
+                           (int)p, status, mailbox_dev, arrivals, seq);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
