@@ -112,6 +112,8 @@ template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 template <typename T>
 int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n);   // R = (D - A) - E
+// 64 doubles -> the handle's mailbox ([8..72)), published with sequence number seq
+int launch_publish_slots(Handle* h, const double* slots, double seq);
 // rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored
 template <typename T>
 bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r);

@@ -1064,8 +1064,16 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (sumsq_dev) {
             double fro2 = 0.0, part[64];
             TLSQ_TRY(comm_allreduce(h, sumsq_dev, 64, ncclSum));   // row shards: same bits on every rank afterwards
-            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
-            TLSQ_HIP(h, hipEventRecord(h->ev[32], h->stream));
+            static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+            const bool mail_sum = h->mailbox && h->mailbox_bytes >= 1024 && !no_mailbox;
+            double mail_seq = 0.0;
+            if (mail_sum) {
+                mail_seq = (h->mail_seq += 1.0);
+                TLSQ_TRY(launch_publish_slots(h, sumsq_dev, mail_seq));
+            } else {
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipEventRecord(h->ev[32], h->stream));
+            }
             pt.mark();
             // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
             // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
@@ -1079,8 +1087,24 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             }
             pt.mark();
             pt.collect_previous(acc);                      // (host work hidden behind the sweep + Gram just queued)
-            TLSQ_HIP(h, hipEventSynchronize(h->ev[32]));   // the copy only, not the Gram queued behind it
-            memcpy(part, h->pinned, 512);
+            bool got_mail = false;
+            if (mail_sum) {
+                volatile double* mb = h->mailbox;
+                const double t_poll = now_ms();
+                while (mb[0] != mail_seq && now_ms() - t_poll < 2000.0) {
+                }
+                got_mail = mb[0] == mail_seq;
+                if (got_mail) {
+                    for (int i = 0; i < 64; ++i) part[i] = mb[8 + i];
+                } else {
+                    h->mailbox_bytes = 0;   // never seen in practice; classic read-back from now on
+                    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sumsq_dev, 512, hipMemcpyDeviceToHost, h->stream));
+                    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                }
+            } else {
+                TLSQ_HIP(h, hipEventSynchronize(h->ev[32]));   // the copy only, not the Gram queued behind it
+            }
+            if (!got_mail) memcpy(part, h->pinned, 512);
             for (double v : part) fro2 += v;
             const double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
             prev_lower = lower;

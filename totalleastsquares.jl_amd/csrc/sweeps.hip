@@ -267,6 +267,16 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
     }
 }
 
+// The 64 partial sums of ||R||_F^2 go to the host-visible mailbox ([0] flag, [8..72) values) and are published with
+// the sequence number: the host polls the flag instead of paying a copy command and an event between two kernels.
+__global__ __launch_bounds__(64) void k_publish_slots(const double* __restrict__ slots, double* mailbox, double seq) {
+    volatile double* mb = mailbox;
+    mb[8 + threadIdx.x] = slots[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) mb[0] = seq;
+}
+
 // R = (D - A) - E  (the residual statement :221 alone, same expression order as in the sweeps): used when a sweep was
 // told not to store R and the residual turns out to be needed after all
 template <typename T>
@@ -467,6 +477,12 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
         else RUS_LAUNCH(32, 1);
     }
 #undef RUS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_publish_slots(Handle* h, const double* slots, double seq) {
+    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, h->stream, slots, h->mailbox_dev, seq);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
