@@ -209,6 +209,7 @@ struct SubspaceState {
     bool defer_certificate = false;
     bool cert_pending = false;
     LanczosRun cert;
+    int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
 };
@@ -317,7 +318,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
         {
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
-            const int q = cold ? 2 : 3;
+            const int q = cold ? 2 : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
             // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
             bool in_q = true;
             for (int t = 1; t < q && nt > 0; ++t) {
@@ -456,6 +457,12 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                     svp < p ? s.sigma[s.order[svp]] / inv_mu : 0.0, (int)cold);
         if (good) {
             conv = true;
+            if (!cold && !hook) {
+                // a warm block that needed a second step just missed the residual bound after the first one: two more
+                // multiplications of its top columns next time are far cheaper than another step; relax again later
+                if (step >= 1) st.q_warm = std::min(7, st.q_warm + 2);
+                else if (st.q_warm > 3) st.q_warm -= 1;
+            }
             break;
         }
         // hopeless (no spectral gap behind the block): stop early and let the full solver run
