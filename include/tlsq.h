@@ -194,6 +194,46 @@ int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64
 int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n,
                          double* x, int64_t ldx);
 
+/* ---- rpca_ga: Grassmann averages, src/robustPCA.jl:255-310 ---------------------------
+ * X is d x N (ldX), a COLUMN is one observation; Q (d x r, ldQ) receives the r components, found one at a time
+ * with deflation (:262-279).  The spherical average `μ` (:297) is chosen by opts->average:
+ *   TLSQ_GA_MEAN          μ!                      (:312-320)  the default
+ *   TLSQ_GA_TRIMMED_MEAN  entrywise_trimmed_mean  (:327-337)  with P = opts->trim
+ *   TLSQ_GA_MEDIAN        entrywise_median        (:354-362)
+ * q0 (d x r, ldq0; may be NULL) holds the start vector of each component — the reference draws `randn(d)` from
+ * Julia's global RNG (:289), which no other program can reproduce; with q0 == NULL the library draws seeded
+ * normals (opts->seed).  Returns TLSQ_MAXITER when a component used all `iters` iterations without dq < tol (the
+ * `@warn "Reached maximum number of iterations"` of :306).  The entrywise averages need d*N < 2^31.
+ * With a communicator (tlsq_comm_init) X holds this rank's COLUMNS; only TLSQ_GA_MEAN is available then. */
+enum { TLSQ_GA_MEAN = 0, TLSQ_GA_TRIMMED_MEAN = 1, TLSQ_GA_MEDIAN = 2 };
+typedef struct tlsq_ga_opts {
+    double  tol;       /* NaN -> 1e-7   (:286) */
+    int64_t iters;     /* <=0 -> 1000   (:286) */
+    int32_t average;   /* TLSQ_GA_* */
+    int32_t memory;    /* TLSQ_MEM_* for X, q0, Q */
+    double  trim;      /* NaN -> 0.1    (:327) */
+    uint64_t seed;
+} tlsq_ga_opts;
+/* optional per-component reports (arrays of r entries; dq_hist is hist_capacity x r, column i = the `dq` of every
+ * iteration of component i — what `verbose` prints at :300 — NaN padded) */
+typedef struct tlsq_ga_info {
+    int64_t* iters;
+    int32_t* status;   /* 0 converged, 1 iteration limit */
+    double*  dq;       /* last change */
+    double*  dq_hist;
+    int64_t  hist_capacity;
+    double   ms_total, ms_loop;
+    int64_t  passes;   /* total iterations = sweeps over U */
+} tlsq_ga_info;
+void tlsq_ga_opts_default(tlsq_ga_opts* o);
+int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64_t ldX, int64_t r,
+                     const tlsq_ga_opts* opts, const double* q0, int64_t ldq0, double* Q, int64_t ldQ,
+                     tlsq_ga_info* info);
+/* the averages on their own (exported by the reference, src/TotalLeastSquares.jl:3; tested at
+ * test/runtests.jl:466-490): s (d) = average of the columns of U (d x N, ldU) with weights w (N) */
+int tlsq_ga_average_f64(tlsq_handle h, int average, double trim, const double* w, const double* U, int64_t d,
+                        int64_t N, int64_t ldU, double* s, int memory);
+
 /* ---- kernel-level entry points (DEVICE pointers; used by the parity tests and bench.py) -------
  * shrink sweep  (src/robustPCA.jl:188-192):  E = soft_th((D-A)+inv_mu*Y, thr) [max(E,0)]; Z=(D-E)+inv_mu*Y
  * update sweep  (src/robustPCA.jl:217-222):  [A=max(A,0)]; R=(D-A)-E; Y=Y+mu*R

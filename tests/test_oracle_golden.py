@@ -159,3 +159,72 @@ def test_lowrankfilter_sine_spikes():             # test/runtests.jl:378-381, 40
     n = rng.standard_normal(T)
     yf = qn(O.lowrankfilter(y + n, sv=2))
     assert np.mean((y - yf) ** 2) / np.mean(n ** 2) < 0.05
+
+
+# ---- rpca_ga (oracle/ga_oracle.py): the reference's own tests of this path, test/runtests.jl:443-520 ----------
+from oracle import ga_oracle as G  # noqa: E402
+
+
+def _mu_blas(s, w, U):     # μ! with a BLAS summation order (the statistical tests below do not depend on it)
+    s[:] = (U @ w) / np.sum(w)
+    return s
+
+
+def _lowrank_case(rng, d, N, r, eps, sigma=None):
+    u, sv, vt = np.linalg.svd(rng.standard_normal((d, N)), full_matrices=False)
+    u, v = u[:, :r], vt[:r, :].T
+    sig = 10.0 * np.arange(1, r + 1) if sigma is None else sv[:r]
+    return u, (u * sig) @ v.T + eps * rng.standard_normal((d, N))
+
+
+@pytest.mark.parametrize("shape", [(10, 40), (40, 10)])
+def test_rpca_ga_orthonormal_components(shape):   # test/runtests.jl:446-464
+    rng = np.random.default_rng(1)
+    for r in range(1, 11):
+        for eps in 10.0 ** np.linspace(-8, 0, 5):
+            _, A = _lowrank_case(rng, *shape, r, eps)
+            Q = G.rpca_ga(A, r, seed=int(rng.integers(1 << 30)))
+            assert np.linalg.norm(Q.T @ Q - np.eye(r)) < math.sqrt(np.finfo(float).eps)
+
+
+def test_ga_averages_identities():                # test/runtests.jl:469-490
+    rng = np.random.default_rng(2)
+    U = rng.standard_normal((10, 10))
+    s = np.zeros(10)
+    w = np.ones(10)
+    assert np.allclose(G.mu_mean(s, w, U).copy(), U.mean(axis=1))
+    assert np.allclose(G.entrywise_trimmed_mean(s, w, U, 0).copy(), U.mean(axis=1))
+    w = rng.standard_normal(10)
+    ref = (U * w).sum(axis=1) / w.sum()
+    assert np.allclose(G.mu_mean(s, w, U).copy(), ref)
+    assert np.allclose(G.entrywise_trimmed_mean(s, w, U, 0).copy(), ref)
+    w = np.ones(10)
+    m2 = G.entrywise_trimmed_mean(s, w, U, 0.1).copy()
+    for i in range(10):                           # StatsBase.trim(x, prop=0.1): drop floor(0.1 n) from each end
+        assert np.isclose(m2[i], np.mean(np.sort(U[i, :])[1:-1]))
+    # the sequential and the BLAS summation of μ! agree to rounding
+    assert np.allclose(G.mu_mean(np.zeros(10), ref, U), _mu_blas(np.zeros(10), ref, U), rtol=1e-12)
+
+
+def test_ga_median_definition():                  # src/robustPCA.jl:354-362
+    U = np.array([[3.0, -1.0, 2.0, 5.0], [0.5, 0.25, -4.0, 1.0]])
+    w = np.array([1.0, -2.0, 1.0, 0.5])
+    s = G.entrywise_median(np.zeros(2), w, U)
+    # row 1: w.*U = [3, 2, 2, 2.5]; stable order -> columns 2,3,4,1; I[end÷2] = I[2] = column 3 -> sign(1)*2
+    # row 2: w.*U = [0.5, -0.5, -4, 0.5] -> columns 3,2,1,4; I[2] = column 2 -> sign(-2)*0.25
+    assert s.tolist() == [2.0, -0.25]
+
+
+@pytest.mark.parametrize("robust,thr", [(G.entrywise_trimmed_mean, 0.8), (G.entrywise_median, 0.9)])
+def test_ga_robust_average_beats_mean(robust, thr):   # test/runtests.jl:492-520
+    rng = np.random.default_rng(1)
+    wins = []
+    for r in range(1, 5):
+        for eps in 10.0 ** np.linspace(-8, -1, 3):
+            u, A = _lowrank_case(rng, 10, 1000, r, eps, sigma="svd")
+            A = A + 1000 * rng.standard_normal(A.shape) * (rng.random(A.shape) < 0.01)
+            q0 = rng.standard_normal((10, r))
+            Qr = G.rpca_ga(A, r, q0=q0, mu=robust, iters=120)
+            Qm = G.rpca_ga(A, r, q0=q0, mu=_mu_blas, iters=120)
+            wins.append(G.subspace_gap(Qr, u) < G.subspace_gap(Qm, u))
+    assert np.mean(wins) > thr

@@ -15,6 +15,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SVD_FULL, SVD_RANDOMIZED = 0, 1
 OPNORM_EXACT, OPNORM_POWER = 0, 1
 UNIQUE_ID_BYTES = 128
+GA_MEAN, GA_TRIMMED_MEAN, GA_MEDIAN = 0, 1, 2
 
 ON_ITER = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_int64, C.c_void_p)
 
@@ -42,6 +43,17 @@ class RpcaInfo(C.Structure):
                 ("residual_stores_skipped", C.c_int64)]
 
 
+class GaOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("iters", C.c_int64), ("average", C.c_int32), ("memory", C.c_int32),
+                ("trim", C.c_double), ("seed", C.c_uint64)]
+
+
+class GaInfo(C.Structure):
+    _fields_ = [("iters", C.POINTER(C.c_int64)), ("status", C.POINTER(C.c_int32)), ("dq", C.POINTER(C.c_double)),
+                ("dq_hist", C.POINTER(C.c_double)), ("hist_capacity", C.c_int64),
+                ("ms_total", C.c_double), ("ms_loop", C.c_double), ("passes", C.c_int64)]
+
+
 # every symbol include/tlsq.h declares (tests check that the .so exports all of them)
 EXPORTS = [
     "tlsq_version", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_destroy", "tlsq_last_error",
@@ -51,6 +63,7 @@ EXPORTS = [
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
     "tlsq_lowrankfilter_f64", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
     "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_c64",
+    "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
     "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
@@ -105,6 +118,10 @@ def load():
     lib.tlsq_rpca_c64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, P(i64), P(RpcaInfo)]
     lib.tlsq_rpca_batched_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tlsq_rtls_batched_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, P(RpcaOpts), vp, vp, vp]
+    lib.tlsq_ga_opts_default.argtypes = [P(GaOpts)]
+    lib.tlsq_ga_opts_default.restype = None
+    lib.tlsq_rpca_ga_f64.argtypes = [vp, vp, i64, i64, i64, i64, P(GaOpts), vp, i64, vp, i64, P(GaInfo)]
+    lib.tlsq_ga_average_f64.argtypes = [vp, C.c_int, dbl, vp, vp, i64, i64, i64, vp, C.c_int]
     lib.tlsq_k_gram_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]
     lib.tlsq_k_gemm_nn_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
     lib.tlsq_k_gemm_nt_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
@@ -114,7 +131,8 @@ def load():
     lib.tlsq_k_maxabs_f64.argtypes = [vp, vp, i64, P(dbl)]
     for name in EXPORTS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
-        if name not in ("tlsq_version", "tlsq_last_error", "tlsq_stream", "tlsq_rpca_opts_default"):
+        if name not in ("tlsq_version", "tlsq_last_error", "tlsq_stream", "tlsq_rpca_opts_default",
+                        "tlsq_ga_opts_default"):
             fn.restype = C.c_int
     _lib = lib
     return lib

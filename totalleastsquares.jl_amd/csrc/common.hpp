@@ -85,7 +85,9 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,                                                          // two-level (precise) decomposition                                            // transposed problem (M < N)
+    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
+    WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
+                                                             // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
 };
 

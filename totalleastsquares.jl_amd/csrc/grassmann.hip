@@ -1,0 +1,813 @@
+// rpca_ga — "Grassmann averages" robust PCA and its spherical averages.
+//
+// Reference (paths relative to /root/reference):
+//     rpca_ga                 src/robustPCA.jl:255-281     component loop: column norms, U = X ./ norms, deflation
+//     rpca_ga_1               src/robustPCA.jl:286-310     sign-weighted average iteration for one component
+//     μ!                      src/robustPCA.jl:312-320     weighted mean of the columns
+//     entrywise_trimmed_mean  src/robustPCA.jl:327-337
+//     entrywise_median        src/robustPCA.jl:354-362
+//
+// X is d x N, column-major: a column is one observation, so every step is a sweep over columns.  One iteration of
+// rpca_ga_1 is    w_n = sign(U[:,n]'q) * norm_n ;  s = sum_n w_n U[:,n] ;  q = normalised(s / sum_n w_n)
+// and needs each column exactly once: k_ga_pass holds a column in the registers of a lane group (G lanes, G = the
+// power of two >= d up to 64, then RPL rows per lane), forms the dot with a DPP/shuffle reduction inside the
+// group and accumulates w * column in registers.  HBM traffic is one read of U per iteration (the unfused reference
+// reads it twice: :294-296 and :315-318).  Sums are ordered: lane-group registers -> fixed-order LDS reduction per
+// block -> per-block partial rows -> fixed-order sum (k_ga_reduce), so results are reproducible run to run.
+//
+// The convergence test (:299-304) runs on the device: k_ga_reduce's last block normalises, forms dq and sets a
+// `converged` flag that turns the kernels of already queued iterations into no-ops; the host queues a few
+// iterations at a time and reads the 32-byte state block in between.
+//
+// The robust averages need order statistics of every row of U (trimmed mean: once per component, the ordering of
+// U[j,:] does not depend on w; median: every iteration, ordering of w .* U[j,:]).  Those go through a segmented
+// radix sort (hipcub::DeviceSegmentedRadixSort, stable, like sortperm) of the row-major transposed keys.
+#include <hipcub/hipcub.hpp>
+
+#include "internal.hpp"
+
+#pragma clang fp contract(off)
+
+namespace tlsq {
+
+namespace {
+
+struct GaState {
+    double dq, nrm, ws;
+    int32_t iters, converged;
+    uint32_t counter, pad;
+};
+
+__device__ __forceinline__ double ga_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }   // Julia sign()
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic sum over the 256 threads of a block (every thread returns the total)
+__device__ __forceinline__ double block_sum(double v, double* sh /* 4 doubles */) {
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// ---- component set-up: (deflate,) norms, normalise                                      (:263-266, :270-271) ----
+// src (d x N, lds) -> Xw (d x N, ld d) = src - q (q' src)  [only when q != nullptr],  norms[n] = ||Xw[:,n]||,
+// U[:,n] = Xw[:,n] / norms[n].  One lane group per column.
+template <int G>
+__global__ __launch_bounds__(256) void k_ga_prepare(const double* src /* may alias Xw */, int64_t lds, int d, int64_t N,
+                                                    const double* __restrict__ q, double* Xw,
+                                                    double* __restrict__ U, double* __restrict__ norms) {
+    constexpr int GPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / G, gl = lane % G;
+    const int64_t gpb = 4 * GPW, stride = (int64_t)gridDim.x * gpb;
+    for (int64_t n0 = (int64_t)blockIdx.x * gpb + wave * GPW; n0 < N; n0 += stride) {
+        const int64_t n = n0 + g;
+        const bool valid = n < N;
+        const double* c = src + (valid ? n : 0) * lds;
+        double t = 0.0;
+        if (q) {
+            for (int r = gl; r < d; r += G) t += (valid ? c[r] : 0.0) * q[r];
+            t = group_sum<G>(t);                                   // Xs1[n] = q' X[:,n]     (:270)
+        }
+        double ss = 0.0;
+        for (int r = gl; r < d; r += G) {
+            double v = valid ? c[r] : 0.0;
+            if (q) v = v - q[r] * t;                               // X .-= q * Xs1          (:271)
+            if (valid) Xw[n * d + r] = v;
+            ss += v * v;
+        }
+        ss = group_sum<G>(ss);
+        const double nrm = sqrt(ss);                               // :264
+        if (valid) {
+            if (gl == 0) norms[n] = nrm;
+            for (int r = gl; r < d; r += G) U[n * d + r] = Xw[n * d + r] / nrm;   // :265
+        }
+    }
+}
+
+// ---- the fused iteration sweep, d <= 64 * 32 ----------------------------------------------------------------
+// partial row of a block: [0,d) weighted column sum; mean: [d] sum of weights; TRIM: [d,2d) per-row weight sums
+template <int G, int RPL, bool TRIM>
+__global__ __launch_bounds__(256) void k_ga_pass(const double* __restrict__ U, int d, int64_t N,
+                                                 const double* __restrict__ norms, const double* __restrict__ w_in,
+                                                 const double* __restrict__ q, const uint8_t* __restrict__ mask,
+                                                 double* __restrict__ partial, int pstride,
+                                                 const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    constexpr int GPW = 64 / G, DP = G * RPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / G, gl = lane % G;
+    double qreg[RPL], acc[RPL], accw[TRIM ? RPL : 1];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const int row = gl + k * G;
+        qreg[k] = (!w_in && row < d) ? q[row] : 0.0;
+        acc[k] = 0.0;
+        if (TRIM) accw[k] = 0.0;
+    }
+    if (!TRIM) accw[0] = 0.0;
+    // UNR columns per lane group are in flight at once (the loads of all of them are issued before the first dot)
+    constexpr int UNR = RPL <= 2 ? 4 : (RPL <= 8 ? 2 : 1);
+    const int64_t gpb = 4 * GPW, stride = (int64_t)gridDim.x * gpb;
+    for (int64_t n0 = (int64_t)blockIdx.x * gpb + wave * GPW; n0 < N; n0 += stride * UNR) {
+        double col[UNR][RPL];
+#pragma unroll
+        for (int c = 0; c < UNR; ++c) {
+            const int64_t n = n0 + c * stride + g;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const int row = gl + k * G;
+                col[c][k] = (n < N && row < d) ? U[n * d + row] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < UNR; ++c) {
+            const int64_t n = n0 + c * stride + g;
+            const bool valid = n < N;
+            double w;
+            if (w_in) {
+                w = valid ? w_in[n] : 0.0;
+            } else {
+                double dot = 0.0;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) dot += col[c][k] * qreg[k];
+                dot = group_sum<G>(dot);
+                w = valid ? ga_sign(dot) * norms[n] : 0.0;            // :295
+            }
+            if (!TRIM) {
+                if (valid) {
+#pragma unroll
+                    for (int k = 0; k < RPL; ++k) acc[k] += w * col[c][k];   // :317
+                    accw[0] += w;                                             // :316
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    const int row = gl + k * G;
+                    if (valid && row < d && mask[n * d + row]) {          // :332-333 (rank of U[j,n] inside `range`)
+                        acc[k] += w * col[c][k];
+                        accw[k] += w;
+                    }
+                }
+            }
+        }
+    }
+    // block reduction in a fixed order over the 4*GPW lane groups
+    extern __shared__ double red[];   // [4*GPW][DP] (+ [4*GPW] weights)
+    const int gi = wave * GPW + g;
+    double* pb = partial + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) red[gi * DP + gl + k * G] = acc[k];
+    if (!TRIM && gl == 0) red[4 * GPW * DP + gi] = accw[0];
+    __syncthreads();
+    for (int row = threadIdx.x; row < d; row += 256) {
+        double s = 0.0;
+        for (int i = 0; i < 4 * GPW; ++i) s += red[i * DP + row];
+        pb[row] = s;
+    }
+    if (!TRIM) {
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 4 * GPW; ++i) s += red[4 * GPW * DP + i];
+            pb[d] = s;
+        }
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) red[gi * DP + gl + k * G] = accw[k];
+        __syncthreads();
+        for (int row = threadIdx.x; row < d; row += 256) {
+            double s = 0.0;
+            for (int i = 0; i < 4 * GPW; ++i) s += red[i * DP + row];
+            pb[d + row] = s;
+        }
+    }
+}
+
+// ---- two-kernel form for long columns (d > 2048) and for the median keys ---------------------------------------
+// w[n] = sign(U[:,n]'q) * norms[n]                                                               (:294-296)
+__global__ __launch_bounds__(256) void k_ga_dots(const double* __restrict__ U, int d, int64_t N,
+                                                 const double* __restrict__ norms, const double* __restrict__ q,
+                                                 double* __restrict__ w, const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), stride = (int64_t)gridDim.x * 4;
+    for (int64_t n = wid; n < N; n += stride) {
+        double dot = 0.0;
+        for (int r = lane; r < d; r += 64) dot += U[n * d + r] * q[r];
+        dot = group_sum<64>(dot);
+        if (lane == 0) w[n] = ga_sign(dot) * norms[n];
+    }
+}
+
+// thread per row, blockIdx.y = column chunk: partial[chunk] = sum over the chunk's columns
+template <bool TRIM>
+__global__ __launch_bounds__(256) void k_ga_wsum_rows(const double* __restrict__ U, int d, int64_t N,
+                                                      const double* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                      double* __restrict__ partial, int pstride,
+                                                      const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (N + gridDim.y - 1) / gridDim.y;
+    const int64_t c0 = (int64_t)blockIdx.y * per, c1 = (c0 + per < N) ? c0 + per : N;
+    double acc = 0.0, aw = 0.0;
+    if (row < d) {
+        for (int64_t n = c0; n < c1; ++n) {
+            const double wn = w[n];
+            if (!TRIM) {
+                acc += wn * U[n * d + row];
+                aw += wn;
+            } else if (mask[n * d + row]) {
+                acc += wn * U[n * d + row];
+                aw += wn;
+            }
+        }
+        double* pb = partial + (size_t)blockIdx.y * pstride;
+        pb[row] = acc;
+        if (TRIM) pb[d + row] = aw;
+        else if (row == 0) pb[d] = aw;
+    }
+}
+
+// ---- finish of an iteration: mu -> q, dq, convergence flag                                     (:297-304) ----
+// mode 0: mu = s / ws (:319);  1: mu[j] = s[j] / sw[j] (:333);  2: mu = s (:359)
+__device__ void ga_finalize(const double* __restrict__ sbuf, int d, int mode, double* __restrict__ q,
+                            double* __restrict__ qold, double tol, GaState* st, double* __restrict__ dq_hist,
+                            int hist_cap, double* sh) {
+    const double ws = (mode == 0) ? sbuf[d] : 1.0;
+    double n2 = 0.0;
+    for (int r = threadIdx.x; r < d; r += 256) {
+        const double m = (mode == 0) ? sbuf[r] / ws : (mode == 1 ? sbuf[r] / sbuf[d + r] : sbuf[r]);
+        n2 += m * m;
+    }
+    n2 = block_sum(n2, sh);
+    const double nrm = sqrt(n2);                                   // norm(μᵢ)   (:298)
+    double d2 = 0.0;
+    for (int r = threadIdx.x; r < d; r += 256) {
+        const double m = (mode == 0) ? sbuf[r] / ws : (mode == 1 ? sbuf[r] / sbuf[d + r] : sbuf[r]);
+        const double qn = m / nrm;
+        const double df = qn - qold[r];
+        d2 += df * df;
+        q[r] = qn;
+        qold[r] = qn;                                              // :305 (immaterial once converged)
+    }
+    d2 = block_sum(d2, sh);
+    if (threadIdx.x == 0) {
+        const double dq = sqrt(d2);                                // :299
+        st->dq = dq;
+        st->nrm = nrm;
+        st->ws = ws;
+        const int it = st->iters;
+        if (dq_hist && it < hist_cap) dq_hist[it] = dq;
+        st->iters = it + 1;
+        st->converged = (dq < tol) ? 1 : 0;                        // :301
+        st->counter = 0;
+    }
+}
+
+// sbuf[row] = sum over the per-block partial rows (fixed order); the last block to finish runs ga_finalize
+__global__ __launch_bounds__(256) void k_ga_reduce(const double* __restrict__ partial, int nblk, int pstride, int ne,
+                                                   int d, int mode, double* __restrict__ sbuf, int do_finalize,
+                                                   double* __restrict__ q, double* __restrict__ qold, double tol,
+                                                   GaState* st, double* __restrict__ dq_hist, int hist_cap) {
+    __shared__ double sh[4];
+    __shared__ int last;
+    if (st->converged) return;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row < ne) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * pstride + row];
+        sbuf[row] = s;
+    }
+    if (!do_finalize) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(&st->counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    ga_finalize(sbuf, d, mode, q, qold, tol, st, dq_hist, hist_cap, sh);
+}
+
+__global__ __launch_bounds__(256) void k_ga_finalize(const double* __restrict__ sbuf, int d, int mode,
+                                                     double* __restrict__ q, double* __restrict__ qold, double tol,
+                                                     GaState* st, double* __restrict__ dq_hist, int hist_cap) {
+    __shared__ double sh[4];
+    if (st->converged) return;
+    ga_finalize(sbuf, d, mode, q, qold, tol, st, dq_hist, hist_cap, sh);
+}
+
+// q = q0 / ||q0||, qold = q, state cleared                                                        (:289-291)
+__global__ __launch_bounds__(256) void k_ga_start(const double* __restrict__ q0, int d, double* __restrict__ q,
+                                                  double* __restrict__ qold, GaState* st) {
+    __shared__ double sh[4];
+    double n2 = 0.0;
+    for (int r = threadIdx.x; r < d; r += 256) n2 += q0[r] * q0[r];
+    n2 = block_sum(n2, sh);
+    const double nrm = sqrt(n2);
+    for (int r = threadIdx.x; r < d; r += 256) {
+        const double v = q0[r] / nrm;
+        q[r] = v;
+        qold[r] = v;
+    }
+    if (threadIdx.x == 0) {
+        st->dq = 0.0;
+        st->nrm = nrm;
+        st->ws = 0.0;
+        st->iters = 0;
+        st->converged = 0;
+        st->counter = 0;
+    }
+}
+
+// ---- order statistics of the rows ------------------------------------------------------------------------------
+// keys[j*N + n] = (w ? w[n] : 1) * U[j, n],  idx[j*N + n] = n     (row-major transposed: a row is one sort segment)
+__global__ __launch_bounds__(256) void k_ga_keys(const double* __restrict__ U, const double* __restrict__ w, int d,
+                                                 int64_t N, double* __restrict__ keys, int* __restrict__ idx,
+                                                 const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    const int64_t total = (int64_t)d * N, stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const int64_t j = e / N, n = e - j * N;
+        const double u = U[n * d + j];
+        keys[e] = w ? w[n] * u : u;                                // :356  (w) .* U[j,:]
+        idx[e] = (int)n;
+    }
+}
+// mask[j + n*d] = 1 for the columns whose rank within row j lies in [lo, hi)                      (:329,:332)
+__global__ __launch_bounds__(256) void k_ga_mask(const int* __restrict__ idx_sorted, int d, int64_t N, int64_t lo,
+                                                 int64_t hi, uint8_t* __restrict__ mask) {
+    const int64_t span = hi - lo, total = (int64_t)d * span, stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const int64_t j = e / span, p = lo + (e - j * span);
+        mask[(int64_t)idx_sorted[j * N + p] * d + j] = 1;
+    }
+}
+// s[j] = sign(w[m]) * U[j, m],  m = the column at sorted position N/2 (1-based) of row j            (:357-358)
+__global__ __launch_bounds__(256) void k_ga_pick(const int* __restrict__ idx_sorted, const double* __restrict__ w,
+                                                 const double* __restrict__ U, int d, int64_t N,
+                                                 double* __restrict__ sbuf, const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < d) {
+        const int64_t m = idx_sorted[(int64_t)j * N + (N / 2 - 1)];
+        sbuf[j] = ga_sign(w[m]) * U[m * d + j];
+    }
+}
+__global__ __launch_bounds__(256) void k_ga_offsets(int* __restrict__ offs, int d, int64_t N) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j <= d) offs[j] = (int)((int64_t)j * N);
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------------------
+constexpr int kGaFusedMaxD = 2048;
+
+inline int group_lanes(int64_t d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
+inline int rows_per_lane(int64_t d) {
+    const int64_t need = (d + 63) / 64;
+    int r = 1;
+    while (r < need) r *= 2;
+    return r;
+}
+inline int pass_blocks(int64_t N, int G) {
+    const int64_t gpb = 4 * (64 / G);
+    int64_t nb = (N + gpb * 8 - 1) / (gpb * 8);   // >= 8 columns per lane group
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    return (int)nb;
+}
+
+template <int G>
+int prepare_g(Handle* h, const double* src, int64_t lds, int64_t d, int64_t N, const double* q, double* Xw, double* U,
+              double* norms) {
+    const int64_t gpb = 4 * (64 / G);
+    int64_t nb = (N + gpb - 1) / gpb;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_ga_prepare<G>, dim3((int)nb), dim3(256), 0, h->stream, src, lds, (int)d, N, q, Xw, U, norms);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+int launch_prepare(Handle* h, const double* src, int64_t lds, int64_t d, int64_t N, const double* q, double* Xw,
+                   double* U, double* norms) {
+    switch (group_lanes(d)) {
+        case 4: return prepare_g<4>(h, src, lds, d, N, q, Xw, U, norms);
+        case 8: return prepare_g<8>(h, src, lds, d, N, q, Xw, U, norms);
+        case 16: return prepare_g<16>(h, src, lds, d, N, q, Xw, U, norms);
+        case 32: return prepare_g<32>(h, src, lds, d, N, q, Xw, U, norms);
+        default: return prepare_g<64>(h, src, lds, d, N, q, Xw, U, norms);
+    }
+}
+
+struct PassArgs {
+    const double* U;
+    int64_t d, N;
+    const double* norms;
+    const double* w_in;
+    const double* q;
+    const uint8_t* mask;   // non-null = trimmed mean
+    double* partial;
+    int pstride;
+    const GaState* st;
+};
+
+template <int G, int RPL>
+int pass_gr(Handle* h, const PassArgs& a, int nblk) {
+    const size_t lds = (size_t)(4 * (64 / G)) * (G * RPL + 1) * 8;
+    if (a.mask)
+        hipLaunchKernelGGL((k_ga_pass<G, RPL, true>), dim3(nblk), dim3(256), lds, h->stream, a.U, (int)a.d, a.N, a.norms,
+                           a.w_in, a.q, a.mask, a.partial, a.pstride, a.st);
+    else
+        hipLaunchKernelGGL((k_ga_pass<G, RPL, false>), dim3(nblk), dim3(256), lds, h->stream, a.U, (int)a.d, a.N,
+                           a.norms, a.w_in, a.q, a.mask, a.partial, a.pstride, a.st);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+int launch_pass(Handle* h, const PassArgs& a, int nblk) {
+    const int G = group_lanes(a.d);
+    if (G < 64) {
+        switch (G) {
+            case 4: return pass_gr<4, 1>(h, a, nblk);
+            case 8: return pass_gr<8, 1>(h, a, nblk);
+            case 16: return pass_gr<16, 1>(h, a, nblk);
+            default: return pass_gr<32, 1>(h, a, nblk);
+        }
+    }
+    switch (rows_per_lane(a.d)) {
+        case 1: return pass_gr<64, 1>(h, a, nblk);
+        case 2: return pass_gr<64, 2>(h, a, nblk);
+        case 4: return pass_gr<64, 4>(h, a, nblk);
+        case 8: return pass_gr<64, 8>(h, a, nblk);
+        case 16: return pass_gr<64, 16>(h, a, nblk);
+        default: return pass_gr<64, 32>(h, a, nblk);
+    }
+}
+
+// device buffers of one rpca_ga / average call
+struct GaBuffers {
+    double *Xw = nullptr, *U = nullptr;
+    double *norms = nullptr, *w = nullptr, *q = nullptr, *qold = nullptr, *sbuf = nullptr, *q0 = nullptr, *hist = nullptr;
+    GaState* st = nullptr;
+    double* partial = nullptr;
+    int pstride = 0, nblk = 0;
+    uint8_t* mask = nullptr;
+    double *keys_in = nullptr, *keys_out = nullptr;
+    int *idx_in = nullptr, *idx_out = nullptr, *offs = nullptr;
+    void* cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+};
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int ga_alloc(Handle* h, int64_t d, int64_t N, int mode, int64_t hist_cap, bool need_x, GaBuffers* b) {
+    void* p;
+    const size_t pn = (size_t)d * N * 8;
+    if (need_x) {
+        TLSQ_TRY(ws_get(h, WS_GA_X, pn, &p));
+        b->Xw = (double*)p;
+    }
+    TLSQ_TRY(ws_get(h, WS_GA_U, pn, &p));
+    b->U = (double*)p;
+    // small block: norms | w | q | qold | q0 | sbuf (2d+2) | state | hist
+    const size_t oN = 0, oW = oN + align256((size_t)N * 8), oQ = oW + align256((size_t)N * 8),
+                 oQo = oQ + align256((size_t)d * 8), oQ0 = oQo + align256((size_t)d * 8),
+                 oS = oQ0 + align256((size_t)d * 8), oSt = oS + align256((size_t)(2 * d + 2) * 8),
+                 oH = oSt + 256, oEnd = oH + align256((size_t)(hist_cap > 0 ? hist_cap : 1) * 8);
+    TLSQ_TRY(ws_get(h, WS_GA_AUX, oEnd, &p));
+    char* c = (char*)p;
+    b->norms = (double*)(c + oN);
+    b->w = (double*)(c + oW);
+    b->q = (double*)(c + oQ);
+    b->qold = (double*)(c + oQo);
+    b->q0 = (double*)(c + oQ0);
+    b->sbuf = (double*)(c + oS);
+    b->st = (GaState*)(c + oSt);
+    b->hist = (double*)(c + oH);
+    b->pstride = (int)(2 * d + 2);
+    if (d <= kGaFusedMaxD) {
+        b->nblk = pass_blocks(N, group_lanes(d));
+    } else {
+        int64_t nc = (N + 255) / 256;   // >= 256 columns per chunk
+        if (nc < 1) nc = 1;
+        if (nc > 256) nc = 256;
+        b->nblk = (int)nc;
+    }
+    TLSQ_TRY(ws_get(h, WS_GA_PART, (size_t)b->nblk * b->pstride * 8, &p));
+    b->partial = (double*)p;
+    if (mode != TLSQ_GA_MEAN) {
+        if ((int64_t)d * N >= (int64_t)1 << 31)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages need d*N < 2^31");
+        if (mode == TLSQ_GA_TRIMMED_MEAN) {
+            TLSQ_TRY(ws_get(h, WS_GA_MASK, (size_t)d * N, &p));
+            b->mask = (uint8_t*)p;
+        }
+        TLSQ_TRY(ws_get(h, WS_GA_KEYS, 2 * pn, &p));
+        b->keys_in = (double*)p;
+        b->keys_out = b->keys_in + (size_t)d * N;
+        const size_t ib = align256((size_t)d * N * 4);
+        TLSQ_TRY(ws_get(h, WS_GA_IDX, 2 * ib + align256((size_t)(d + 1) * 4), &p));
+        b->idx_in = (int*)p;
+        b->idx_out = (int*)((char*)p + ib);
+        b->offs = (int*)((char*)p + 2 * ib);
+        hipLaunchKernelGGL(k_ga_offsets, dim3((int)((d + 1 + 255) / 256)), dim3(256), 0, h->stream, b->offs, (int)d, N);
+        TLSQ_HIP(h, hipGetLastError());
+        size_t tb = 0;
+        TLSQ_HIP(h, hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, b->keys_in, b->keys_out, b->idx_in,
+                                                                 b->idx_out, (int)(d * N), (int)d, b->offs,
+                                                                 b->offs + 1, 0, 64, h->stream));
+        b->cub_bytes = tb;
+        TLSQ_TRY(ws_get(h, WS_GA_TMP, tb ? tb : 256, &p));
+        b->cub_tmp = p;
+    }
+    return TLSQ_OK;
+}
+
+// stable ascending sort of every row of the key matrix (keys_in/idx_in -> keys_out/idx_out): sortperm (:332,:356)
+int ga_sort_rows(Handle* h, GaBuffers* b, int64_t d, int64_t N) {
+    size_t tb = b->cub_bytes;
+    TLSQ_HIP(h, hipcub::DeviceSegmentedRadixSort::SortPairs(b->cub_tmp, tb, b->keys_in, b->keys_out, b->idx_in,
+                                                             b->idx_out, (int)(d * N), (int)d, b->offs, b->offs + 1,
+                                                             0, 64, h->stream));
+    return TLSQ_OK;
+}
+
+int ga_keys(Handle* h, GaBuffers* b, const double* w, int64_t d, int64_t N, const GaState* st) {
+    int64_t g = ((int64_t)d * N + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_ga_keys, dim3((int)g), dim3(256), 0, h->stream, b->U, w, (int)d, N, b->keys_in, b->idx_in, st);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// trimmed mean: mark the entries of U whose rank inside their row lies in `range` (:329); U is fixed per component
+int ga_build_mask(Handle* h, GaBuffers* b, int64_t d, int64_t N, double P) {
+    const int64_t lo = (int64_t)std::floor(P * (double)N), hi = (int64_t)std::floor((1.0 - P) * (double)N);
+    TLSQ_HIP(h, hipMemsetAsync(b->mask, 0, (size_t)d * N, h->stream));
+    if (hi <= lo) return TLSQ_OK;
+    TLSQ_TRY(ga_keys(h, b, nullptr, d, N, nullptr));
+    TLSQ_TRY(ga_sort_rows(h, b, d, N));
+    int64_t g = (d * (hi - lo) + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_ga_mask, dim3((int)g), dim3(256), 0, h->stream, b->idx_out, (int)d, N, lo, hi, b->mask);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// the weighted sums of one iteration into b->sbuf (no finish): w from q (w_in == nullptr) or given
+int ga_sums(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, const double* w_in, const GaState* st) {
+    if (mode == TLSQ_GA_MEDIAN) {
+        const double* w = w_in;
+        if (!w) {
+            int64_t g = (N + 3) / 4;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(k_ga_dots, dim3((int)g), dim3(256), 0, h->stream, b->U, (int)d, N, b->norms, b->q, b->w, st);
+            TLSQ_HIP(h, hipGetLastError());
+            w = b->w;
+        }
+        TLSQ_TRY(ga_keys(h, b, w, d, N, st));
+        TLSQ_TRY(ga_sort_rows(h, b, d, N));
+        hipLaunchKernelGGL(k_ga_pick, dim3((int)((d + 255) / 256)), dim3(256), 0, h->stream, b->idx_out, w, b->U, (int)d,
+                           N, b->sbuf, st);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    const uint8_t* mask = (mode == TLSQ_GA_TRIMMED_MEAN) ? b->mask : nullptr;
+    if (d <= kGaFusedMaxD) {
+        PassArgs a{b->U, d, N, b->norms, w_in, b->q, mask, b->partial, b->pstride, st};
+        TLSQ_TRY(launch_pass(h, a, b->nblk));
+    } else {
+        const double* w = w_in;
+        if (!w) {
+            int64_t g = (N + 3) / 4;
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(k_ga_dots, dim3((int)g), dim3(256), 0, h->stream, b->U, (int)d, N, b->norms, b->q, b->w, st);
+            TLSQ_HIP(h, hipGetLastError());
+            w = b->w;
+        }
+        const dim3 grid((unsigned)((d + 255) / 256), (unsigned)b->nblk);
+        if (mask)
+            hipLaunchKernelGGL(k_ga_wsum_rows<true>, grid, dim3(256), 0, h->stream, b->U, (int)d, N, w, mask, b->partial,
+                               b->pstride, st);
+        else
+            hipLaunchKernelGGL(k_ga_wsum_rows<false>, grid, dim3(256), 0, h->stream, b->U, (int)d, N, w, mask, b->partial,
+                               b->pstride, st);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    return TLSQ_OK;
+}
+
+inline int ga_entries(int64_t d, int mode) { return mode == TLSQ_GA_TRIMMED_MEAN ? (int)(2 * d) : (int)(d + 1); }
+
+// one queued iteration of rpca_ga_1: sums, (all-reduce,) finish
+int ga_iteration(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, double tol, int hist_cap) {
+    TLSQ_TRY(ga_sums(h, b, d, N, mode, nullptr, b->st));
+    const bool sharded = h->nranks > 1;
+    if (mode == TLSQ_GA_MEDIAN) {
+        hipLaunchKernelGGL(k_ga_finalize, dim3(1), dim3(256), 0, h->stream, b->sbuf, (int)d, 2, b->q, b->qold, tol, b->st,
+                           b->hist, hist_cap);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    const int ne = ga_entries(d, mode), fmode = (mode == TLSQ_GA_TRIMMED_MEAN) ? 1 : 0;
+    hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 255) / 256), dim3(256), 0, h->stream, b->partial, b->nblk, b->pstride, ne,
+                       (int)d, fmode, b->sbuf, sharded ? 0 : 1, b->q, b->qold, tol, b->st, b->hist, hist_cap);
+    TLSQ_HIP(h, hipGetLastError());
+    if (sharded) {
+        // column shards: the weighted sums add up over the ranks; q and the flag then evolve identically everywhere
+        TLSQ_TRY(comm_allreduce(h, b->sbuf, (size_t)ne, ncclSum));
+        hipLaunchKernelGGL(k_ga_finalize, dim3(1), dim3(256), 0, h->stream, b->sbuf, (int)d, fmode, b->q, b->qold, tol,
+                           b->st, b->hist, hist_cap);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    return TLSQ_OK;
+}
+
+int read_state(Handle* h, const GaState* dev, GaState* host) {
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, dev, sizeof(GaState), hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(host, h->pinned, sizeof(GaState));
+    return TLSQ_OK;
+}
+
+}  // namespace
+
+}  // namespace tlsq
+
+using namespace tlsq;
+
+extern "C" {
+
+void tlsq_ga_opts_default(tlsq_ga_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->tol = std::numeric_limits<double>::quiet_NaN();
+    o->iters = 0;
+    o->average = TLSQ_GA_MEAN;
+    o->memory = TLSQ_MEM_HOST;
+    o->trim = std::numeric_limits<double>::quiet_NaN();
+    o->seed = 0;
+}
+
+int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64_t ldX, int64_t r,
+                     const tlsq_ga_opts* opts, const double* q0, int64_t ldq0, double* Q, int64_t ldQ,
+                     tlsq_ga_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!X || !Q || d <= 0 || N <= 0 || ldX < d || ldQ < d || r < 0 || (q0 && ldq0 < d))
+        return set_err(h, TLSQ_ERR_ARG, "rpca_ga: bad argument");
+    if (d > (int64_t)1 << 30) return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: d too large");
+    const double tol = (opts && opts->tol == opts->tol) ? opts->tol : 1e-7;            // :286
+    const int64_t iters = (opts && opts->iters > 0) ? opts->iters : 1000;              // :286
+    const int mode = opts ? opts->average : TLSQ_GA_MEAN;
+    const double P = (opts && opts->trim == opts->trim) ? opts->trim : 0.1;           // :327
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const uint64_t seed = opts ? opts->seed : 0;
+    if (mode != TLSQ_GA_MEAN && mode != TLSQ_GA_TRIMMED_MEAN && mode != TLSQ_GA_MEDIAN)
+        return set_err(h, TLSQ_ERR_ARG, "rpca_ga: unknown average %d", mode);
+    if (mode == TLSQ_GA_MEDIAN && N < 2)
+        return set_err(h, TLSQ_ERR_ARG, "rpca_ga: entrywise_median needs at least 2 columns (I[end÷2])");
+    if (mode == TLSQ_GA_TRIMMED_MEAN && !(P >= 0.0 && P < 1.0))
+        return set_err(h, TLSQ_ERR_ARG, "rpca_ga: trim fraction outside [0,1)");
+    if (mode != TLSQ_GA_MEAN && h->nranks > 1)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages are not available on column shards");
+    if (info) {
+        info->ms_total = info->ms_loop = 0.0;
+        info->passes = 0;
+    }
+    if (r == 0) return TLSQ_OK;
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const double t_begin = now_ms();
+    const int hist_cap = (info && info->dq_hist && info->hist_capacity > 0)
+                             ? (int)std::min<int64_t>(info->hist_capacity, iters) : 0;
+    GaBuffers b;
+    TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
+    // inputs
+    const double* src = X;
+    int64_t lds = ldX;
+    void* p;
+    if (!dev) {
+        TLSQ_TRY(ws_get(h, WS_GA_IO, (size_t)d * N * 8, &p));
+        TLSQ_TRY(copy2d(h, p, d, X, ldX, d, N, 8, hipMemcpyHostToDevice));
+        src = (const double*)p;
+        lds = d;
+    }
+    double* dQ = Q;
+    int64_t ldq = ldQ;
+    double* dq0 = nullptr;
+    {
+        TLSQ_TRY(ws_get(h, WS_GA_Q, (size_t)d * r * 8 * 2, &p));
+        double* blk = (double*)p;
+        if (!dev) {
+            dQ = blk;
+            ldq = d;
+        }
+        dq0 = blk + (size_t)d * r;
+        if (q0) {
+            TLSQ_TRY(copy2d(h, dq0, d, q0, ldq0, d, r, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        } else {
+            // randn(d) of :289 — the library's own seeded normals (Julia's global RNG stream cannot be reproduced)
+            TLSQ_TRY(launch_fill_gauss(h, dq0, d * r, (unsigned int)(seed * 2654435761ull + 0x6a09e667u)));
+        }
+    }
+    std::vector<double> hist_host;
+    int rc = TLSQ_OK;
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // uploads done: ms_loop is the component loop alone
+    const double t_loop = now_ms();
+    int64_t passes = 0;
+    for (int64_t i = 0; i < r; ++i) {
+        // :263-266 (and the deflation :270-271 of the previous component, fused into the same sweep)
+        TLSQ_TRY(launch_prepare(h, i == 0 ? src : b.Xw, i == 0 ? lds : d, d, N, i == 0 ? nullptr : dQ + (i - 1) * ldq,
+                                b.Xw, b.U, b.norms));
+        if (mode == TLSQ_GA_TRIMMED_MEAN) TLSQ_TRY(ga_build_mask(h, &b, d, N, P));
+        hipLaunchKernelGGL(k_ga_start, dim3(1), dim3(256), 0, h->stream, dq0 + (size_t)i * d, (int)d, b.q, b.qold, b.st);
+        TLSQ_HIP(h, hipGetLastError());
+        if (hist_cap > 0) TLSQ_HIP(h, hipMemsetAsync(b.hist, 0xff, (size_t)hist_cap * 8, h->stream));   // NaN fill
+        GaState st{};
+        int64_t queued = 0;
+        const int64_t burst = (mode == TLSQ_GA_MEDIAN) ? 1 : ((double)d * (double)N > 3.0e7 ? 2 : 8);
+        while (queued < iters) {
+            const int64_t nq = std::min<int64_t>(burst, iters - queued);
+            for (int64_t k = 0; k < nq; ++k) TLSQ_TRY(ga_iteration(h, &b, d, N, mode, tol, hist_cap));
+            queued += nq;
+            TLSQ_TRY(read_state(h, b.st, &st));
+            if (st.converged) break;
+        }
+        passes += st.iters;
+        if (info) {
+            if (info->iters) info->iters[i] = st.iters;
+            if (info->status) info->status[i] = st.converged ? 0 : 1;      // 1 = the @warn of :306
+            if (info->dq) info->dq[i] = st.dq;
+            if (hist_cap > 0) {
+                hist_host.resize((size_t)hist_cap);
+                TLSQ_HIP(h, hipMemcpyAsync(hist_host.data(), b.hist, (size_t)hist_cap * 8, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                memcpy(info->dq_hist + (size_t)i * info->hist_capacity, hist_host.data(), (size_t)hist_cap * 8);
+                for (int64_t k = hist_cap; k < info->hist_capacity; ++k)
+                    info->dq_hist[(size_t)i * info->hist_capacity + k] = std::numeric_limits<double>::quiet_NaN();
+            }
+        }
+        if (!st.converged) rc = TLSQ_MAXITER;
+        TLSQ_HIP(h, hipMemcpyAsync(dQ + (size_t)i * ldq, b.q, (size_t)d * 8, hipMemcpyDeviceToDevice, h->stream));   // :268
+    }
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    const double t_loop_end = now_ms();
+    if (!dev) TLSQ_TRY(copy2d(h, Q, ldQ, dQ, d, d, r, 8, hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) {
+        info->ms_loop = t_loop_end - t_loop;
+        info->ms_total = now_ms() - t_begin;
+        info->passes = passes;
+    }
+    return rc;
+}
+
+int tlsq_ga_average_f64(tlsq_handle h, int average, double trim, const double* w, const double* U, int64_t d, int64_t N,
+                        int64_t ldU, double* s, int memory) {
+    TLSQ_TRY(check_handle(h));
+    if (!w || !U || !s || d <= 0 || N <= 0 || ldU < d) return set_err(h, TLSQ_ERR_ARG, "ga_average: bad argument");
+    if (average != TLSQ_GA_MEAN && average != TLSQ_GA_TRIMMED_MEAN && average != TLSQ_GA_MEDIAN)
+        return set_err(h, TLSQ_ERR_ARG, "ga_average: unknown average %d", average);
+    if (average == TLSQ_GA_MEDIAN && N < 2)
+        return set_err(h, TLSQ_ERR_ARG, "ga_average: entrywise_median needs at least 2 columns (I[end÷2])");
+    const double P = (trim == trim) ? trim : 0.1;
+    if (average == TLSQ_GA_TRIMMED_MEAN && !(P >= 0.0 && P < 1.0))
+        return set_err(h, TLSQ_ERR_ARG, "ga_average: trim fraction outside [0,1)");
+    if (h->nranks > 1) return set_err(h, TLSQ_ERR_UNSUPPORTED, "ga_average: single GPU only");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const bool dev = memory == TLSQ_MEM_DEVICE;
+    GaBuffers b;
+    TLSQ_TRY(ga_alloc(h, d, N, average, 0, false, &b));
+    TLSQ_TRY(copy2d(h, b.U, d, U, ldU, d, N, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    TLSQ_HIP(h, hipMemcpyAsync(b.w, w, (size_t)N * 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (average == TLSQ_GA_TRIMMED_MEAN) TLSQ_TRY(ga_build_mask(h, &b, d, N, P));
+    TLSQ_TRY(ga_sums(h, &b, d, N, average, b.w, nullptr));
+    const int ne = average == TLSQ_GA_MEDIAN ? (int)d : ga_entries(d, average);
+    if (average != TLSQ_GA_MEDIAN) {
+        // borrow the state block for the (unused) flag; k_ga_reduce reads st->converged
+        TLSQ_HIP(h, hipMemsetAsync(b.st, 0, sizeof(GaState), h->stream));
+        hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 255) / 256), dim3(256), 0, h->stream, b.partial, b.nblk, b.pstride, ne,
+                           (int)d, 0, b.sbuf, 0, b.q, b.qold, 0.0, b.st, (double*)nullptr, 0);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    std::vector<double> hs((size_t)ne);
+    TLSQ_HIP(h, hipMemcpyAsync(hs.data(), b.sbuf, (size_t)ne * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<double> out((size_t)d);
+    for (int64_t j = 0; j < d; ++j) {
+        if (average == TLSQ_GA_MEAN) out[(size_t)j] = hs[(size_t)j] / hs[(size_t)d];                 // :319
+        else if (average == TLSQ_GA_TRIMMED_MEAN) out[(size_t)j] = hs[(size_t)j] / hs[(size_t)(d + j)];   // :333
+        else out[(size_t)j] = hs[(size_t)j];                                                          // :359
+    }
+    if (dev) {
+        TLSQ_HIP(h, hipMemcpyAsync(s, out.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    } else {
+        memcpy(s, out.data(), (size_t)d * 8);
+    }
+    return TLSQ_OK;
+}
+
+}  // extern "C"

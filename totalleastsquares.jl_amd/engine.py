@@ -410,6 +410,86 @@ class Engine:
         out = out[:, :, 0].copy() if yv.ndim == 2 else out
         return (out, it, stt) if return_status else out
 
+    # ---- rpca_ga (src/robustPCA.jl:255-310) and the spherical averages (:312-362) -------------------------------
+    @staticmethod
+    def _average_code(mu):
+        """The reference's `μ` keyword is a function (`μ!`, `entrywise_trimmed_mean`, `entrywise_median`); here it is
+        named by one of those functions' Python counterparts below, their names, or None (= μ!)."""
+        name = getattr(mu, "__name__", mu)
+        table = {None: L.GA_MEAN, "mu_": L.GA_MEAN, "μ!": L.GA_MEAN, "mean": L.GA_MEAN,
+                 "entrywise_trimmed_mean": L.GA_TRIMMED_MEAN, "entrywise_median": L.GA_MEDIAN}
+        if name not in table:
+            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED,
+                            f"rpca_ga: average {name!r} has no device implementation (μ!, entrywise_trimmed_mean, "
+                            "entrywise_median do)")
+        return table[name]
+
+    def rpca_ga(self, X, r=None, *, tol=1e-7, iters=1000, mu=None, P=0.1, q0=None, seed=0, verbose=False,
+                return_report=False):
+        """Q = rpca_ga(X, r; tol, iters, μ): X is d x N with the observations in its columns; returns Q (d x r).
+        q0 (d x r) gives the start vector of every component (the reference draws randn(d), :289)."""
+        Xf = _f(X)
+        d, N = Xf.shape
+        r = min(d, N) if r is None else int(r)
+        Q = np.zeros((d, r), order="F")
+        o = L.GaOpts()
+        self.lib.tlsq_ga_opts_default(C.byref(o))
+        o.tol, o.iters, o.average, o.trim, o.seed = float(tol), int(iters), self._average_code(mu), float(P), int(seed)
+        it = np.zeros(max(r, 1), dtype=np.int64)
+        stt = np.zeros(max(r, 1), dtype=np.int32)
+        dq = np.zeros(max(r, 1))
+        cap = int(iters) if (verbose or return_report) else 0
+        hist = np.full((max(r, 1), max(cap, 1)), np.nan)
+        info = L.GaInfo()
+        info.iters = it.ctypes.data_as(C.POINTER(C.c_int64))
+        info.status = stt.ctypes.data_as(C.POINTER(C.c_int32))
+        info.dq = dq.ctypes.data_as(C.POINTER(C.c_double))
+        info.dq_hist = hist.ctypes.data_as(C.POINTER(C.c_double)) if cap else None
+        info.hist_capacity = cap
+        q0f = None if q0 is None else _f(np.asarray(q0, dtype=np.float64).reshape(d, -1))
+        if q0f is not None and q0f.shape[1] < r:
+            raise TlsqError(L.TLSQ_ERR_ARG, "rpca_ga: q0 needs one column per component")
+        st = self._check(self.lib.tlsq_rpca_ga_f64(self.h, _ptr(Xf), d, N, d, r, C.byref(o),
+                                                   _ptr(q0f) if q0f is not None else None, d, _ptr(Q), d,
+                                                   C.byref(info)))
+        if verbose:
+            for i in range(r):
+                for k in range(int(it[i])):
+                    print(f"Change at iteration {k + 1}: {hist[i, k]}")            # :300
+                if not stt[i]:
+                    print(f"Converged after {int(it[i])} iterations")               # :302
+        if st == L.TLSQ_MAXITER:
+            warnings.warn("Reached maximum number of iterations")                  # :306
+        if return_report:
+            return Q, {"iters": it[:r].tolist(), "status": stt[:r].tolist(), "dq": dq[:r].tolist(),
+                       "dq_hist": [hist[i, : int(it[i])].tolist() for i in range(r)] if cap else None,
+                       "ms_loop": float(info.ms_loop), "ms_total": float(info.ms_total), "passes": int(info.passes)}
+        return Q
+
+    def _average(self, code, s, w, U, P=float("nan")):
+        Uf = _f(U)
+        d, N = Uf.shape
+        wf = np.ascontiguousarray(np.asarray(w, dtype=np.float64).reshape(-1))
+        if wf.size != N:
+            raise TlsqError(L.TLSQ_ERR_ARG, "average: w needs one weight per column of U")
+        out = np.zeros(d)
+        self._check(self.lib.tlsq_ga_average_f64(self.h, code, float(P), _ptr(wf), _ptr(Uf), d, N, d, _ptr(out),
+                                                  L.MEM_HOST))
+        s[...] = out.reshape(np.shape(s))
+        return s
+
+    def mu_(self, s, w, U):
+        """μ!(s,w,U), src/robustPCA.jl:312-320 — writes into s and returns it."""
+        return self._average(L.GA_MEAN, s, w, U)
+
+    def entrywise_trimmed_mean(self, s, w, U, P=0.1):
+        """src/robustPCA.jl:327-337"""
+        return self._average(L.GA_TRIMMED_MEAN, s, w, U, P)
+
+    def entrywise_median(self, s, w, U):
+        """src/robustPCA.jl:354-362"""
+        return self._average(L.GA_MEDIAN, s, w, U)
+
 
 def ishankel(A):
     """src/robustPCA.jl:94-106 — exact test of constant anti-diagonals (host-side test helper)."""
@@ -455,6 +535,22 @@ def soft_hankel_(A, eps):
 
 def tls_(Ay, n):
     return default_engine().tls_(Ay, n)
+
+
+def rpca_ga(X, r=None, **kw):
+    return default_engine().rpca_ga(X, r, **kw)
+
+
+def mu_(s, w, U):
+    return default_engine().mu_(s, w, U)
+
+
+def entrywise_trimmed_mean(s, w, U, P=0.1):
+    return default_engine().entrywise_trimmed_mean(s, w, U, P)
+
+
+def entrywise_median(s, w, U):
+    return default_engine().entrywise_median(s, w, U)
 
 
 def rtls(A, y, **kw):
