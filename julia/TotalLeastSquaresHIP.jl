@@ -11,7 +11,7 @@ module TotalLeastSquaresHIP
 
 using LinearAlgebra, Libdl
 
-export rpca, lowrankfilter, hankel, unhankel, ishankel, tls!, rtls
+export rpca, lowrankfilter, hankel, unhankel, ishankel, tls!, rtls, rpca_ga, entrywise_median, entrywise_trimmed_mean, μ!
 
 const LIB = Ref{String}(get(ENV, "TLSQ_LIB", joinpath(@__DIR__, "..", "totalleastsquares.jl_amd", "libtlsqhip.so")))
 
@@ -205,6 +205,59 @@ function rtls(A::AbstractArray{Float64,3}, y::AbstractArray{Float64}; kwargs...)
          Ptr{Int32}, Ptr{Int32}), handle(), Array(A), Array(ym), M, n, q, B, o, x, iters, status))
     st == 1 && @warn "Maximum number of iterations reached in $(sum(status)) of $B problems"
     ndims(y) == 2 ? reshape(x, n, B) : x
+end
+
+# ---- rpca_ga (src/robustPCA.jl:255-310) and its spherical averages (:312-362) ----------------------------------------
+# mirrors `struct tlsq_ga_opts` (40 bytes) and `struct tlsq_ga_info` (64 bytes)
+mutable struct GaOpts
+    tol::Cdouble; iters::Int64; average::Int32; memory::Int32; trim::Cdouble; seed::UInt64
+    GaOpts() = new()
+end
+mutable struct GaInfo
+    iters::Ptr{Int64}; status::Ptr{Int32}; dq::Ptr{Cdouble}; dq_hist::Ptr{Cdouble}; hist_capacity::Int64
+    ms_total::Cdouble; ms_loop::Cdouble; passes::Int64
+    GaInfo() = new()
+end
+
+function _average(code::Integer, P, s, w, U)
+    Um = Matrix{Float64}(U); d, N = size(Um); wv = Vector{Float64}(w); out = Vector{Float64}(undef, d)
+    check(ccall((:tlsq_ga_average_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Cint, Cdouble, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Cint),
+        handle(), code, P, wv, Um, d, N, d, out, MEM_HOST))
+    s .= out
+end
+μ!(s, w, U) = _average(0, NaN, s, w, U)                                   # src/robustPCA.jl:312-320
+entrywise_trimmed_mean(s, w, U, P = 0.1) = _average(1, P, s, w, U)        # :327-337
+entrywise_median(s, w, U) = _average(2, NaN, s, w, U)                     # :354-362
+
+"""
+    Q = rpca_ga(X, r = minimum(size(X)); μ = μ!, tol = 1e-7, iters = 1000, verbose = false, q0 = randn(d, r))
+
+Same contract as the reference (src/robustPCA.jl:255-281).  `μ` must be one of the three averages above (the
+whole iteration runs on the device; an arbitrary Julia closure cannot).  The start vectors are drawn here with
+`randn`, exactly where the reference draws them (:289), and handed to the library as `q0`.
+"""
+function rpca_ga(X::AbstractMatrix{Float64}, r = minimum(size(X)), U = nothing; μ = μ!, tol = 1e-7, iters = 1000,
+                 verbose = false, P = 0.1, q0 = randn(size(X, 1), r))
+    code = μ === μ! ? 0 : μ === entrywise_trimmed_mean ? 1 : μ === entrywise_median ? 2 :
+           throw(ArgumentError("rpca_ga: μ must be μ!, entrywise_trimmed_mean or entrywise_median on the GPU path"))
+    Xm = Matrix(X); d, N = size(Xm); Q = zeros(d, r)
+    o = GaOpts(); ccall((:tlsq_ga_opts_default, LIB[]), Cvoid, (Ref{GaOpts},), o)
+    o.tol = tol; o.iters = iters; o.average = code; o.trim = P; o.memory = MEM_HOST
+    its = zeros(Int64, r); status = zeros(Int32, r); dq = zeros(r); hist = fill(NaN, verbose ? iters : 1, r)
+    info = GaInfo(); info.iters = pointer(its); info.status = pointer(status); info.dq = pointer(dq)
+    info.dq_hist = verbose ? pointer(hist) : C_NULL; info.hist_capacity = verbose ? iters : 0
+    st = GC.@preserve its status dq hist check(ccall((:tlsq_rpca_ga_f64, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ref{GaOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+         Ref{GaInfo}), handle(), Xm, d, N, d, r, o, Matrix{Float64}(q0), d, Q, d, info))
+    if verbose
+        for i in 1:r
+            for k in 1:its[i]; @info "Change at iteration $k: $(hist[k, i])"; end                  # :300
+            status[i] == 0 && @info "Converged after $(its[i]) iterations"                        # :302
+        end
+    end
+    st == 1 && @warn "Reached maximum number of iterations"                                      # :306
+    Q
 end
 
 end # module

@@ -59,3 +59,34 @@ def rpca_sharded(D_local, M_global, allreduce, lam=None, iters=1000, tol=None, r
             converged = True
             break
     return A, E, sv, dict(iters_done=k, svp_hist=svp_hist, cost_hist=cost_hist, converged=converged)
+
+
+def rpca_ga_sharded(X_local, r, q0, allreduce, tol=1e-7, iters=1000):
+    """Column-sharded rpca_ga with the default average μ! (src/robustPCA.jl:255-320) — the structure of the library's
+    multi-GPU path (grassmann.hip: ga_iteration): every rank owns a block of COLUMNS (observations); norms,
+    normalisation and the deflation are local; the only exchange is a sum-all-reduce of the d+1 numbers
+    [sum_n w_n U_n ; sum_n w_n] per iteration, after which q evolves identically on every rank."""
+    X = np.array(X_local, dtype=np.float64, copy=True, order="F")
+    d = X.shape[0]
+    Q = np.zeros((d, r))
+    used = []
+    for i in range(r):
+        norms = np.sqrt(np.sum(X * X, axis=0))
+        U = X / norms
+        q = np.array(q0[:, i], dtype=np.float64)
+        q /= np.sqrt(np.sum(q * q))
+        qold = q.copy()
+        it = 0
+        for it in range(1, iters + 1):
+            w = np.sign(U.T @ q) * norms
+            tot = allreduce(np.concatenate([U @ w, [np.sum(w)]]), "sum")
+            mu = tot[:d] / tot[d]
+            q = mu / np.sqrt(np.sum(mu * mu))
+            dq = math.sqrt(float(np.sum((q - qold) ** 2)))
+            if dq < tol:
+                break
+            qold = q.copy()
+        used.append(it)
+        Q[:, i] = q
+        X -= np.outer(q, q @ X)
+    return Q, used

@@ -48,6 +48,20 @@ def main():
     res["sv"] = (sv, svo)
     res["relA"] = float(np.linalg.norm(A - Ao[lo:hi]) / np.linalg.norm(Ao[lo:hi]))
     res["relE"] = float(np.linalg.norm(E - Eo[lo:hi]) / np.linalg.norm(Eo[lo:hi]))
+    # --- column-sharded rpca_ga (all-reduce of d+1 sums per iteration) == single-process oracle
+    from oracle import ga_oracle as G
+    from oracle.sharded import rpca_ga_sharded
+    rng = np.random.default_rng(5)
+    d, Ng, r = 12, 999, 3
+    u = np.linalg.qr(rng.standard_normal((d, r)))[0]
+    X = (u * np.array([30.0, 20.0, 10.0])) @ rng.standard_normal((r, Ng)) + 0.01 * rng.standard_normal((d, Ng))
+    q0 = rng.standard_normal((d, r))
+    clo, chi = tdist.row_partition(Ng, world, rank)          # the same contiguous split, over columns
+    Qs, used = rpca_ga_sharded(X[:, clo:chi], r, q0, allreduce)
+    ginfo = G.GaInfo()
+    Qo = G.rpca_ga(X, r, q0=q0, info=ginfo)
+    res["ga_iters"] = (used, ginfo.iters)
+    res["ga_err"] = float(np.abs(Qs - Qo).max())
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)
     dist.barrier()

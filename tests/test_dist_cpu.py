@@ -30,6 +30,7 @@ def test_two_rank_gloo_row_sharding(tmp_path):
         assert res["world"] == 2 and res["env_ok"] and res["partition_ok"] and res["uid_ok"]
         assert res["iters"][0] == res["iters"][1] and res["svp_same"] and res["sv"][0] == res["sv"][1]
         assert res["relA"] < 1e-8 and res["relE"] < 1e-8, res
+        assert res["ga_iters"][0] == res["ga_iters"][1] and res["ga_err"] < 1e-10, res
 
 
 def test_row_partition_edge_cases():

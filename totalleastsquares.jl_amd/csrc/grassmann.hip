@@ -32,6 +32,8 @@ namespace tlsq {
 
 namespace {
 
+constexpr int kGaFusedMaxD = 2048;   // longest column a lane group holds in registers (64 lanes x 32 rows)
+
 struct GaState {
     double dq, nrm, ws;
     int32_t iters, converged;
@@ -40,20 +42,45 @@ struct GaState {
 
 __device__ __forceinline__ double ga_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }   // Julia sign()
 
+// Sum over each aligned group of G lanes without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32, six
+// dependent LDS round trips per fp64 wave reduction): DPP steps inside a row of 16 lanes (quad_perm, quad_perm,
+// row_half_mirror, row_mirror), then v_readlane of the row totals.  Every lane of the wave must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_perm<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);                          // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_perm<0x141>(v);   // row_half_mirror
+    if constexpr (G >= 16) v += dpp_perm<0x140>(v);  // row_mirror
+    if constexpr (G == 32) {
+        const double a = read_lane(v, 0) + read_lane(v, 16), b = read_lane(v, 32) + read_lane(v, 48);
+        v = (threadIdx.x & 32) ? b : a;
+    }
+    if constexpr (G == 64) v = (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
     return v;
 }
 
-// deterministic sum over the 256 threads of a block (every thread returns the total)
-__device__ __forceinline__ double block_sum(double v, double* sh /* 4 doubles */) {
+// deterministic sum over the threads of a block (a multiple of 64, at most 1024; every thread returns the total)
+__device__ __forceinline__ double block_sum(double v, double* sh /* 16 doubles */) {
     v = group_sum<64>(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
 }
 
 // ---- component set-up: (deflate,) norms, normalise                                      (:263-266, :270-271) ----
@@ -72,12 +99,16 @@ __global__ __launch_bounds__(256) void k_ga_prepare(const double* src /* may ali
         const double* c = src + (valid ? n : 0) * lds;
         double t = 0.0;
         if (q) {
-            for (int r = gl; r < d; r += G) t += (valid ? c[r] : 0.0) * q[r];
+            for (int r = gl; r < d; r += G) {
+                const double x = c[r];                              // (column 0 when n is out of range)
+                t += (valid ? x : 0.0) * q[r];
+            }
             t = group_sum<G>(t);                                   // Xs1[n] = q' X[:,n]     (:270)
         }
         double ss = 0.0;
         for (int r = gl; r < d; r += G) {
-            double v = valid ? c[r] : 0.0;
+            const double x = c[r];
+            double v = valid ? x : 0.0;
             if (q) v = v - q[r] * t;                               // X .-= q * Xs1          (:271)
             if (valid) Xw[n * d + r] = v;
             ss += v * v;
@@ -87,6 +118,65 @@ __global__ __launch_bounds__(256) void k_ga_prepare(const double* src /* may ali
         if (valid) {
             if (gl == 0) norms[n] = nrm;
             for (int r = gl; r < d; r += G) U[n * d + r] = Xw[n * d + r] / nrm;   // :265
+        }
+    }
+}
+
+// the same with the column held in registers (d <= 64 * 32): one load, two stores per element
+template <int G, int RPL>
+__global__ __launch_bounds__(256) void k_ga_prepare_reg(const double* src /* may alias Xw */, int64_t lds, int d,
+                                                        int64_t N, const double* __restrict__ q, double* Xw,
+                                                        double* __restrict__ U, double* __restrict__ norms) {
+    constexpr int GPW = 64 / G;
+    constexpr int UNR = RPL <= 2 ? 4 : (RPL <= 8 ? 2 : 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / G, gl = lane % G;
+    double qreg[RPL];
+    int rowc[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const int row = gl + k * G;
+        rowc[k] = row < d ? row : d - 1;
+        qreg[k] = (q && row < d) ? q[row] : 0.0;
+    }
+    const int64_t gpb = 4 * GPW, stride = (int64_t)gridDim.x * gpb;
+    for (int64_t n0 = (int64_t)blockIdx.x * gpb + wave * GPW; n0 < N; n0 += stride * UNR) {
+        double col[UNR][RPL];
+#pragma unroll
+        for (int c = 0; c < UNR; ++c) {
+            const int64_t n = n0 + c * stride + g, nc = n < N ? n : N - 1;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) col[c][k] = src[nc * lds + rowc[k]];
+        }
+#pragma unroll
+        for (int c = 0; c < UNR; ++c) {
+            const int64_t n = n0 + c * stride + g;
+            const bool valid = n < N;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) col[c][k] = (valid && gl + k * G < d) ? col[c][k] : 0.0;
+            if (q) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) t += col[c][k] * qreg[k];
+                t = group_sum<G>(t);                                       // Xs1[n] = q' X[:,n]     (:270)
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) col[c][k] = col[c][k] - qreg[k] * t;   // X .-= q * Xs1  (:271)
+            }
+            double ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) ss += col[c][k] * col[c][k];
+            ss = group_sum<G>(ss);
+            const double nrm = sqrt(ss);                                   // :264
+            if (valid) {
+                if (gl == 0) norms[n] = nrm;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    const int row = gl + k * G;
+                    if (row < d) {
+                        Xw[n * d + row] = col[c][k];
+                        U[n * d + row] = col[c][k] / nrm;                  // :265
+                    }
+                }
+            }
         }
     }
 }
@@ -103,56 +193,59 @@ __global__ __launch_bounds__(256) void k_ga_pass(const double* __restrict__ U, i
     constexpr int GPW = 64 / G, DP = G * RPL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / G, gl = lane % G;
     double qreg[RPL], acc[RPL], accw[TRIM ? RPL : 1];
+    int rowc[RPL];   // row index clamped into the column: loads are unconditional, out-of-range values are zeroed
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int row = gl + k * G;
+        rowc[k] = row < d ? row : d - 1;
         qreg[k] = (!w_in && row < d) ? q[row] : 0.0;
         acc[k] = 0.0;
         if (TRIM) accw[k] = 0.0;
     }
     if (!TRIM) accw[0] = 0.0;
     // UNR columns per lane group are in flight at once (the loads of all of them are issued before the first dot)
-    constexpr int UNR = RPL <= 2 ? 4 : (RPL <= 8 ? 2 : 1);
+    constexpr int UNR = RPL == 1 ? 8 : (RPL == 2 ? 4 : (RPL <= 8 ? 2 : 1));
     const int64_t gpb = 4 * GPW, stride = (int64_t)gridDim.x * gpb;
     for (int64_t n0 = (int64_t)blockIdx.x * gpb + wave * GPW; n0 < N; n0 += stride * UNR) {
-        double col[UNR][RPL];
+        double col[UNR][RPL], wn[UNR];   // wn: the column's norm (or its given weight), loaded with the column
+        const double* __restrict__ wsrc = w_in ? w_in : norms;
 #pragma unroll
         for (int c = 0; c < UNR; ++c) {
-            const int64_t n = n0 + c * stride + g;
+            const int64_t n = n0 + c * stride + g, nc = n < N ? n : N - 1;
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
-                const int row = gl + k * G;
-                col[c][k] = (n < N && row < d) ? U[n * d + row] : 0.0;
-            }
+            for (int k = 0; k < RPL; ++k) col[c][k] = U[nc * d + rowc[k]];
+            wn[c] = wsrc[nc];
+        }
+#pragma unroll
+        for (int c = 0; c < UNR; ++c) {
+            const bool valid = n0 + c * stride + g < N;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) col[c][k] = (valid && gl + k * G < d) ? col[c][k] : 0.0;
         }
 #pragma unroll
         for (int c = 0; c < UNR; ++c) {
             const int64_t n = n0 + c * stride + g;
             const bool valid = n < N;
-            double w;
-            if (w_in) {
-                w = valid ? w_in[n] : 0.0;
-            } else {
+            const int64_t nc = valid ? n : N - 1;
+            double w = wn[c];
+            if (!w_in) {
                 double dot = 0.0;
 #pragma unroll
                 for (int k = 0; k < RPL; ++k) dot += col[c][k] * qreg[k];
                 dot = group_sum<G>(dot);
-                w = valid ? ga_sign(dot) * norms[n] : 0.0;            // :295
+                w = ga_sign(dot) * w;                                 // :295
             }
+            w = valid ? w : 0.0;                                      // (an out-of-range column adds +0)
             if (!TRIM) {
-                if (valid) {
 #pragma unroll
-                    for (int k = 0; k < RPL; ++k) acc[k] += w * col[c][k];   // :317
-                    accw[0] += w;                                             // :316
-                }
+                for (int k = 0; k < RPL; ++k) acc[k] += w * col[c][k];   // :317
+                accw[0] += w;                                             // :316
             } else {
 #pragma unroll
                 for (int k = 0; k < RPL; ++k) {
-                    const int row = gl + k * G;
-                    if (valid && row < d && mask[n * d + row]) {          // :332-333 (rank of U[j,n] inside `range`)
-                        acc[k] += w * col[c][k];
-                        accw[k] += w;
-                    }
+                    const bool in = mask[nc * d + rowc[k]] != 0 && valid && gl + k * G < d;   // :332-333
+                    acc[k] += in ? w * col[c][k] : 0.0;
+                    accw[k] += in ? w : 0.0;
                 }
             }
         }
@@ -241,14 +334,14 @@ __device__ void ga_finalize(const double* __restrict__ sbuf, int d, int mode, do
                             int hist_cap, double* sh) {
     const double ws = (mode == 0) ? sbuf[d] : 1.0;
     double n2 = 0.0;
-    for (int r = threadIdx.x; r < d; r += 256) {
+    for (int r = threadIdx.x; r < d; r += blockDim.x) {
         const double m = (mode == 0) ? sbuf[r] / ws : (mode == 1 ? sbuf[r] / sbuf[d + r] : sbuf[r]);
         n2 += m * m;
     }
     n2 = block_sum(n2, sh);
     const double nrm = sqrt(n2);                                   // norm(μᵢ)   (:298)
     double d2 = 0.0;
-    for (int r = threadIdx.x; r < d; r += 256) {
+    for (int r = threadIdx.x; r < d; r += blockDim.x) {
         const double m = (mode == 0) ? sbuf[r] / ws : (mode == 1 ? sbuf[r] / sbuf[d + r] : sbuf[r]);
         const double qn = m / nrm;
         const double df = qn - qold[r];
@@ -270,19 +363,35 @@ __device__ void ga_finalize(const double* __restrict__ sbuf, int d, int mode, do
     }
 }
 
-// sbuf[row] = sum over the per-block partial rows (fixed order); the last block to finish runs ga_finalize
-__global__ __launch_bounds__(256) void k_ga_reduce(const double* __restrict__ partial, int nblk, int pstride, int ne,
-                                                   int d, int mode, double* __restrict__ sbuf, int do_finalize,
-                                                   double* __restrict__ q, double* __restrict__ qold, double tol,
-                                                   GaState* st, double* __restrict__ dq_hist, int hist_cap) {
-    __shared__ double sh[4];
+// sbuf[row] = sum over the per-block partial rows in a fixed order: a block owns 64 rows, each of its 16 waves sums a
+// contiguous sixteenth of the partial rows (8 independent chains), LDS combines the waves.  The last block to finish
+// runs ga_finalize.
+__global__ __launch_bounds__(1024) void k_ga_reduce(const double* __restrict__ partial, int nblk, int pstride, int ne,
+                                                    int d, int mode, double* __restrict__ sbuf, int do_finalize,
+                                                    double* __restrict__ q, double* __restrict__ qold, double tol,
+                                                    GaState* st, double* __restrict__ dq_hist, int hist_cap) {
+    __shared__ double part[16][64];
+    __shared__ double sh[16];
     __shared__ int last;
     if (st->converged) return;
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    const int per = (nblk + 15) / 16, b0 = seg * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (row < ne) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * pstride + row];
-        sbuf[row] = s;
+        for (int b = b0; b < b1; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + u < b1) a[u] += partial[(size_t)(b + u) * pstride + row];
+        }
+    }
+    part[seg][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (seg == 0 && row < ne) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][lane];
+        sbuf[row] = t;
     }
     if (!do_finalize) return;
     __threadfence();
@@ -297,7 +406,7 @@ __global__ __launch_bounds__(256) void k_ga_reduce(const double* __restrict__ pa
 __global__ __launch_bounds__(256) void k_ga_finalize(const double* __restrict__ sbuf, int d, int mode,
                                                      double* __restrict__ q, double* __restrict__ qold, double tol,
                                                      GaState* st, double* __restrict__ dq_hist, int hist_cap) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     if (st->converged) return;
     ga_finalize(sbuf, d, mode, q, qold, tol, st, dq_hist, hist_cap, sh);
 }
@@ -305,7 +414,7 @@ __global__ __launch_bounds__(256) void k_ga_finalize(const double* __restrict__ 
 // q = q0 / ||q0||, qold = q, state cleared                                                        (:289-291)
 __global__ __launch_bounds__(256) void k_ga_start(const double* __restrict__ q0, int d, double* __restrict__ q,
                                                   double* __restrict__ qold, GaState* st) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double n2 = 0.0;
     for (int r = threadIdx.x; r < d; r += 256) n2 += q0[r] * q0[r];
     n2 = block_sum(n2, sh);
@@ -365,7 +474,6 @@ __global__ __launch_bounds__(256) void k_ga_offsets(int* __restrict__ offs, int 
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------------------
-constexpr int kGaFusedMaxD = 2048;
 
 inline int group_lanes(int64_t d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
 inline int rows_per_lane(int64_t d) {
@@ -374,11 +482,15 @@ inline int rows_per_lane(int64_t d) {
     while (r < need) r *= 2;
     return r;
 }
-inline int pass_blocks(int64_t N, int G) {
+inline int pass_blocks(int64_t N, int64_t d) {
+    const int G = group_lanes(d), rpl = G < 64 ? 1 : rows_per_lane(d);
     const int64_t gpb = 4 * (64 / G);
     int64_t nb = (N + gpb * 8 - 1) / (gpb * 8);   // >= 8 columns per lane group
+    // enough blocks for the occupancy the register footprint allows (8 / 4 / 2 blocks per CU); every block costs a
+    // partial row in k_ga_reduce
+    const int64_t cap = rpl <= 2 ? 2048 : (rpl <= 8 ? 1024 : 512);
     if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
+    if (nb > cap) nb = cap;
     return (int)nb;
 }
 
@@ -392,14 +504,36 @@ int prepare_g(Handle* h, const double* src, int64_t lds, int64_t d, int64_t N, c
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
+template <int G, int RPL>
+int prepare_reg(Handle* h, const double* src, int64_t lds, int64_t d, int64_t N, const double* q, double* Xw, double* U,
+                double* norms) {
+    const int64_t gpb = 4 * (64 / G);
+    int64_t nb = (N + gpb * 2 - 1) / (gpb * 2);
+    const int64_t cap = RPL <= 8 ? 2048 : 512;
+    if (nb < 1) nb = 1;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL((k_ga_prepare_reg<G, RPL>), dim3((int)nb), dim3(256), 0, h->stream, src, lds, (int)d, N, q, Xw, U,
+                       norms);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
 int launch_prepare(Handle* h, const double* src, int64_t lds, int64_t d, int64_t N, const double* q, double* Xw,
                    double* U, double* norms) {
+    if (d > kGaFusedMaxD) return prepare_g<64>(h, src, lds, d, N, q, Xw, U, norms);
     switch (group_lanes(d)) {
-        case 4: return prepare_g<4>(h, src, lds, d, N, q, Xw, U, norms);
-        case 8: return prepare_g<8>(h, src, lds, d, N, q, Xw, U, norms);
-        case 16: return prepare_g<16>(h, src, lds, d, N, q, Xw, U, norms);
-        case 32: return prepare_g<32>(h, src, lds, d, N, q, Xw, U, norms);
-        default: return prepare_g<64>(h, src, lds, d, N, q, Xw, U, norms);
+        case 4: return prepare_reg<4, 1>(h, src, lds, d, N, q, Xw, U, norms);
+        case 8: return prepare_reg<8, 1>(h, src, lds, d, N, q, Xw, U, norms);
+        case 16: return prepare_reg<16, 1>(h, src, lds, d, N, q, Xw, U, norms);
+        case 32: return prepare_reg<32, 1>(h, src, lds, d, N, q, Xw, U, norms);
+        default: break;
+    }
+    switch (rows_per_lane(d)) {
+        case 1: return prepare_reg<64, 1>(h, src, lds, d, N, q, Xw, U, norms);
+        case 2: return prepare_reg<64, 2>(h, src, lds, d, N, q, Xw, U, norms);
+        case 4: return prepare_reg<64, 4>(h, src, lds, d, N, q, Xw, U, norms);
+        case 8: return prepare_reg<64, 8>(h, src, lds, d, N, q, Xw, U, norms);
+        case 16: return prepare_reg<64, 16>(h, src, lds, d, N, q, Xw, U, norms);
+        default: return prepare_reg<64, 32>(h, src, lds, d, N, q, Xw, U, norms);
     }
 }
 
@@ -489,7 +623,7 @@ int ga_alloc(Handle* h, int64_t d, int64_t N, int mode, int64_t hist_cap, bool n
     b->hist = (double*)(c + oH);
     b->pstride = (int)(2 * d + 2);
     if (d <= kGaFusedMaxD) {
-        b->nblk = pass_blocks(N, group_lanes(d));
+        b->nblk = pass_blocks(N, d);
     } else {
         int64_t nc = (N + 255) / 256;   // >= 256 columns per chunk
         if (nc < 1) nc = 1;
@@ -613,7 +747,7 @@ int ga_iteration(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, double
         return TLSQ_OK;
     }
     const int ne = ga_entries(d, mode), fmode = (mode == TLSQ_GA_TRIMMED_MEAN) ? 1 : 0;
-    hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 255) / 256), dim3(256), 0, h->stream, b->partial, b->nblk, b->pstride, ne,
+    hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 63) / 64), dim3(1024), 0, h->stream, b->partial, b->nblk, b->pstride, ne,
                        (int)d, fmode, b->sbuf, sharded ? 0 : 1, b->q, b->qold, tol, b->st, b->hist, hist_cap);
     TLSQ_HIP(h, hipGetLastError());
     if (sharded) {
@@ -727,7 +861,9 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
         if (hist_cap > 0) TLSQ_HIP(h, hipMemsetAsync(b.hist, 0xff, (size_t)hist_cap * 8, h->stream));   // NaN fill
         GaState st{};
         int64_t queued = 0;
-        const int64_t burst = (mode == TLSQ_GA_MEDIAN) ? 1 : ((double)d * (double)N > 3.0e7 ? 2 : 8);
+        // kernels of iterations queued past the converged one return at once (a few microseconds each), a host round
+        // trip costs more: queue 8 at a time.  The median's sort cannot be gated by the flag.
+        const int64_t burst = (mode == TLSQ_GA_MEDIAN) ? 1 : 8;
         while (queued < iters) {
             const int64_t nq = std::min<int64_t>(burst, iters - queued);
             for (int64_t k = 0; k < nq; ++k) TLSQ_TRY(ga_iteration(h, &b, d, N, mode, tol, hist_cap));
@@ -788,7 +924,7 @@ int tlsq_ga_average_f64(tlsq_handle h, int average, double trim, const double* w
     if (average != TLSQ_GA_MEDIAN) {
         // borrow the state block for the (unused) flag; k_ga_reduce reads st->converged
         TLSQ_HIP(h, hipMemsetAsync(b.st, 0, sizeof(GaState), h->stream));
-        hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 255) / 256), dim3(256), 0, h->stream, b.partial, b.nblk, b.pstride, ne,
+        hipLaunchKernelGGL(k_ga_reduce, dim3((ne + 63) / 64), dim3(1024), 0, h->stream, b.partial, b.nblk, b.pstride, ne,
                            (int)d, 0, b.sbuf, 0, b.q, b.qold, 0.0, b.st, (double*)nullptr, 0);
         TLSQ_HIP(h, hipGetLastError());
     }
