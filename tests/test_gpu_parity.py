@@ -853,3 +853,27 @@ def test_implicit_gram_operator_path():
     env = dict(os.environ, TLSQ_IMPLICIT_GRAM="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_implicit_hankel_sweep_is_bit_identical(tmp_path):
+    """lowrankfilter on one channel with lag 1: the fused rebuild+sweep reads y instead of the Hankel panel
+    (D[i,j] = y[i+j], zero pad rows).  Same bits as with the panel (TLSQ_IMPLICIT_HANKEL=0), and the oracle's filter.
+    TLSQ_FUSED_REBUILD=1 selects that sweep at a size the oracle can follow (both read once per process)."""
+    import os, subprocess, sys
+    code = (
+        "import sys, warnings, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import tlsq_amd; from oracle import rpca_oracle as O\n"
+        "warnings.simplefilter('ignore'); torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
+        "y0, nz = O.synth_series(6001, seed=3); y = y0 + nz\n"
+        "yf, rep = eng.lowrankfilter(y, 40, return_report=True)\n"
+        "yo = O.lowrankfilter(y, 40)\n"
+        "assert np.linalg.norm(yf - yo) <= 1e-8 * np.linalg.norm(yo), np.linalg.norm(yf - yo)\n"
+        "np.save(sys.argv[1], yf); print('ok', rep.iters_done)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for tag, extra in (("implicit", {}), ("panel", {"TLSQ_IMPLICIT_HANKEL": "0"})):
+        f = str(tmp_path / (tag + ".npy"))
+        env = dict(os.environ, TLSQ_FUSED_REBUILD="1", **extra)
+        out = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1])

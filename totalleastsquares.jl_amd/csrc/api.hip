@@ -170,6 +170,12 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
         TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * 8, &E));
         ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
         ro.m_global = K;
+        // SURVEY §8f rank 2 (first step): the 7-pass sweep of large panels reads y instead of H (6 passes)
+        static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
+        if (implicit_ok && Dch == 1 && lag == 1) {
+            ro.hankel_y = dy;
+            ro.hankel_K = K;
+        }
         status = rpca_core<double>(h, (const double*)H, Kp, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
                            nullptr, 0, nullptr, info);
         if (status < 0) return status;

@@ -122,7 +122,8 @@ bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, 
 template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                 int nonnegE, double* sumsq, double* zero_slots = nullptr);
+                                 int nonnegE, double* sumsq, double* zero_slots = nullptr, const T* hankel_y = nullptr,
+                                 int64_t hankel_K = 0);
 // dst (N x M, ld ldd) = src' for src (M x N, ld lds)
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd);

@@ -118,6 +118,10 @@ struct ResolvedOpts {
     double lambda, tol, rho;
     int64_t maxrank, iters, m_global;
     bool nonnegA, nonnegE, hankel, nukeA;
+    // D is the (row-padded) Hankel matrix of this device vector, D[i, j] = hankel_y[i + j] for i < hankel_K: the big
+    // fused sweep reads the vector instead of the panel (set by lowrankfilter; fp64, one channel, lag 1)
+    const void* hankel_y = nullptr;
+    int64_t hankel_K = 0;
 };
 
 inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {

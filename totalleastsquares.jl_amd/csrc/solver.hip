@@ -1055,7 +1055,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
             TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
                                                      svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
-                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next));
+                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
+                                                     (const T*)ro.hankel_y, ro.hankel_K));
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,

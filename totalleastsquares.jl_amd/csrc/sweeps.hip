@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
 constexpr int RUS_CT = 64;   // widest column tile
 // ROWS = 2: a thread owns two consecutive rows (16-byte accesses for fp64) - the streaming form for tall panels.
 // ROWS = 1: one row per thread and narrower column tiles, for panels too small to fill the chip otherwise.
-template <typename T, int RMAX, int ROWS>
+// HK = true: D is a Hankel matrix that is not read at all — D[i, j] = y[i + j] for i < K, zero pad rows below
+// (lowrankfilter with one channel and lag 1, src/robustPCA.jl:76-92); `D` then points at y.  One panel pass less.
+template <typename T, int RMAX, int ROWS, bool HK>
 __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restrict__ D, const double* __restrict__ Tm,
                                                                const double* __restrict__ Vs,
                                                                const T* __restrict__ E, T* __restrict__ Y,
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
                                                                T* __restrict__ Zn, int64_t M, int N, int r, int ct,
                                                                T mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                                                                double* __restrict__ sumsq,
-                                                               double* __restrict__ zero_slots) {
+                                                               double* __restrict__ zero_slots, int64_t hankel_K) {
     using VR = T __attribute__((ext_vector_type(ROWS)));
     if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
     __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
@@ -223,7 +225,13 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
 #pragma unroll 4
         for (int c = 0; c < nct; ++c) {
             const int64_t idx = (row + (int64_t)(c0 + c) * M) / ROWS;
-            const VR d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
+            VR d;
+            if constexpr (HK) {
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+            } else {
+                d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
+            }
             const VR e = __builtin_nontemporal_load(reinterpret_cast<const VR*>(E) + idx);
             VR y = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Y) + idx);
             const double* vs = sVs + c * RMAX;
@@ -441,13 +449,13 @@ bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, 
     static const bool force = [] { const char* e = getenv("TLSQ_FUSED_REBUILD"); return e && e[0] == '1'; }();
     if (!force && M * N < ((int64_t)1 << 26)) return false;
     return (M % 2 == 0) && r <= 32 && aligned16(D) && aligned16(E) && aligned16(Y) && aligned16(R) && aligned16(En) &&
-           aligned16(Zn);
+           aligned16(Zn);   // (D is not read when the caller passes an implicit Hankel source instead)
 }
 
 template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                 int nonnegE, double* sumsq, double* zero_slots) {
+                                 int nonnegE, double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     // tall panels: two rows per thread, 64-column tiles.  Otherwise one row per thread and tiles narrow enough to
     // put ~16 waves on every CU (each tile re-reads its rows of T from L2, so not narrower than needed).
@@ -464,9 +472,17 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
     if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
     const int rows = two2 ? 2 : 1;
     const dim3 grid((unsigned)((M / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
-#define RUS_LAUNCH(RM, RW)                                                                                           \
-    hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW>), grid, dim3(256), 0, h->stream, D, Tm, Vs, E, Y, R, En, Zn, \
-                       M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots)
+#define RUS_LAUNCH(RM, RW)                                                                                            \
+    do {                                                                                                              \
+        if (hankel_y)                                                                                                 \
+            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, \
+                               Vs, E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE,      \
+                               sumsq, zero_slots, hankel_K);                                                          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, \
+                               E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq,   \
+                               zero_slots, (int64_t)0);                                                               \
+    } while (0)
     if (two2) {
         if (r <= 8) RUS_LAUNCH(8, 2);
         else if (r <= 16) RUS_LAUNCH(16, 2);
@@ -573,7 +589,8 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
                                          int, double*, double*);                                                     \
     template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
-                                                 T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*); \
+                                                 T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*, \
+                                                 const T*, int64_t);                                                  \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
