@@ -151,7 +151,10 @@ int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t 
 /* ---- lowrankfilter: src/robustPCA.jl:119-128 --------------------------------------------------
  * y (Nx x Dch, ldy) -> yf (Nx x Dch, ldyf).  n = embedding size (<=0 -> min(Nx/20,2000)),
  * sv>0 -> plain rank-sv truncation (:123-126).  opts->tol NaN -> 1e-3 (the lowrankfilter default).
- * The Hankel matrix is built, factored and averaged on the device; it never visits the host. */
+ * The Hankel matrix is built, factored and averaged on the device; it never visits the host.
+ * With a communicator (tlsq_comm_init) every rank passes the WHOLE series and receives the whole filtered series: a
+ * rank owns a contiguous block of the rows of H — a time window of y with an (n-1)-sample halo — rpca runs
+ * row-sharded, and the anti-diagonal averaging exchanges partial sums and counts with one all-reduce. */
 int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy,
                            int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
                            double* yf, int64_t ldyf, tlsq_rpca_info* info);

@@ -90,3 +90,29 @@ def rpca_ga_sharded(X_local, r, q0, allreduce, tol=1e-7, iters=1000):
         Q[:, i] = q
         X -= np.outer(q, q @ X)
     return Q, used
+
+
+def lowrankfilter_sharded(y, n, rank, world, allreduce, lag=1, tol=1e-3):
+    """Time-window sharded lowrankfilter (src/robustPCA.jl:119-128) — the structure of tlsq_lowrankfilter_f64 with a
+    communicator (SURVEY §8e "Hankel"): every rank owns a contiguous block of the rows of H = hankel(y, n, lag), i.e. a
+    window of y with an (n-1)-sample halo; rpca runs row-sharded; the anti-diagonal averaging exchanges partial sums
+    and counts with one sum all-reduce, then divides."""
+    y = np.asarray(y, dtype=np.float64)
+    Nx = y.shape[0]
+    Kg = (Nx - n) // lag + 1
+    base, rem = divmod(Kg, world)
+    r0 = rank * base + min(rank, rem)
+    r1 = r0 + base + (1 if rank < rem else 0)
+    s0, Nw = r0 * lag, (r1 - r0 - 1) * lag + n
+    H = O.hankel(y[s0:s0 + Nw], n, lag)                       # this rank's rows
+    A, E, sv, info = rpca_sharded(H, Kg, allreduce, tol=tol)
+    tot = np.zeros(Nx)
+    cnt = np.zeros(Nx)
+    K = r1 - r0
+    for k in range(K):
+        for l in range(n):
+            tot[s0 + k * lag + l] += A[k, l]
+            cnt[s0 + k * lag + l] += 1.0
+    both = allreduce(np.concatenate([tot, cnt]), "sum")
+    tot, cnt = both[:Nx], both[Nx:]
+    return np.where(cnt > 0, tot / np.maximum(cnt, 1.0), 0.0), info

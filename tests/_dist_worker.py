@@ -62,6 +62,12 @@ def main():
     Qo = G.rpca_ga(X, r, q0=q0, info=ginfo)
     res["ga_iters"] = (used, ginfo.iters)
     res["ga_err"] = float(np.abs(Qs - Qo).max())
+    # --- time-window sharded lowrankfilter (halo + all-reduce of anti-diagonal sums and counts) == oracle
+    from oracle.sharded import lowrankfilter_sharded
+    ys, nz = O.synth_series(700, seed=2)
+    yf_s, linfo = lowrankfilter_sharded(ys + nz, 20, rank, world, allreduce)
+    yf_o = O.lowrankfilter(ys + nz, 20)
+    res["lrf_err"] = float(np.linalg.norm(yf_s - yf_o) / np.linalg.norm(yf_o))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -667,6 +667,38 @@ def test_rccl_path_single_rank(torch_mod):
     assert np.array_equal(A, A2) and np.array_equal(E, E2)
 
 
+def test_sharded_lowrankfilter_and_rpca_ga_single_rank(torch_mod):
+    """The time-window shard path of lowrankfilter (local Hankel rows of the window, partial anti-diagonal sums and
+    counts, ncclAllReduce, division) and the column-shard path of rpca_ga (all-reduce of the d+1 sums per iteration,
+    separate finish kernel), exercised with a one-rank communicator: same results as the plain paths."""
+    import os
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    y0, nz = O.synth_series(3000, seed=5)
+    y2 = np.stack([y0 + nz, np.cos(0.05 * np.arange(3000)) + 0.1 * nz], axis=1)
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((20, 3)) @ rng.standard_normal((3, 900)) + 0.01 * rng.standard_normal((20, 900))
+    q0 = rng.standard_normal((20, 2))
+    os.environ["TLSQ_FORCE_COMM"] = "1"
+    try:
+        e = tlsq_amd.Engine(0)
+        e.comm_init(1, 0, e.unique_id())
+        f1 = e.lowrankfilter(y0 + nz, 40)
+        f2 = e.lowrankfilter(y2, 30, lag=2)
+        f3 = e.lowrankfilter(y0 + nz, 40, sv=2)
+        Q = e.rpca_ga(X, 2, q0=q0)
+        e.close()
+    finally:
+        os.environ.pop("TLSQ_FORCE_COMM", None)
+    e2 = tlsq_amd.Engine(0)
+    g1, g2, g3 = e2.lowrankfilter(y0 + nz, 40), e2.lowrankfilter(y2, 30, lag=2), e2.lowrankfilter(y0 + nz, 40, sv=2)
+    Q2 = e2.rpca_ga(X, 2, q0=q0)
+    e2.close()
+    assert np.array_equal(f1, g1) and np.array_equal(f2, g2) and np.array_equal(f3, g3)
+    assert np.array_equal(Q, Q2)
+    assert relerr(f1, O.lowrankfilter(y0 + nz, 40)) < 1e-8
+
+
 def test_fuzz_parity(eng):
     """Randomised shapes / ranks / noise levels / flags (tools/fuzz_parity.py), including runs of 40-120 ALM
     iterations where 1/mu reaches the resolution of the plain Gram route and the two-level decomposition takes

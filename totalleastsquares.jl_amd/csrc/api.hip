@@ -154,7 +154,20 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
     }
     const double t0 = now_ms();
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const int64_t K = (Nx - n) / lag + 1, LD = n * Dch;
+    const int64_t Kg = (Nx - n) / lag + 1, LD = n * Dch;   // rows of the whole Hankel matrix
+    // With a communicator every rank passes the WHOLE series and owns a contiguous block of the rows of H, i.e. a time
+    // window of y with an (n-1)-sample halo: rows [r0, r1) use the samples [r0*lag, (r1-1)*lag + n).
+    const bool sharded = h->comm != nullptr;
+    int64_t r0 = 0, r1 = Kg;
+    if (sharded) {
+        const int64_t base = Kg / h->nranks, rem = Kg % h->nranks;
+        r0 = h->rank * base + std::min<int64_t>(h->rank, rem);
+        r1 = r0 + base + (h->rank < rem ? 1 : 0);
+        if (r1 <= r0) return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: fewer Hankel rows (%lld) than ranks", (long long)Kg);
+        if (opts && opts->hankel)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the hankel option is not available on row shards");
+    }
+    const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
     // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
     // hankel option of rpca works on the exact shape
     const int64_t Kp = (opts && opts->hankel) ? K : (K + 15) / 16 * 16;
@@ -164,19 +177,23 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
     TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * 8, &A));
     if (Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * 8, h->stream));
     TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    TLSQ_TRY(launch_hankel<double>(h, (const double*)dy, Nx, Dch, Nx, n, lag, (double*)H, Kp));  // :120
+    const double* yw = (const double*)dy + s0;                                                // this rank's window
+    TLSQ_TRY(launch_hankel<double>(h, yw, Nw, Dch, Nx, n, lag, (double*)H, Kp));                // :120
     int status = TLSQ_OK;
     if (sv <= 0) {                                                                            // :121-122
         TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * 8, &E));
-        ResolvedOpts ro = resolve(opts, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
-        ro.m_global = K;
+        tlsq_rpca_opts oo;
+        if (opts) oo = *opts; else tlsq_rpca_opts_default(&oo);
+        oo.m_global = Kg;
+        ResolvedOpts ro = resolve(&oo, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
+        ro.m_global = Kg;
         // SURVEY §8f rank 2 (first step): the 7-pass sweep of large panels reads y instead of H (6 passes)
         static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
         if (implicit_ok && Dch == 1 && lag == 1) {
-            ro.hankel_y = dy;
+            ro.hankel_y = yw;
             ro.hankel_K = K;
         }
-        status = rpca_core<double>(h, (const double*)H, Kp, LD, ro, opts, (double*)A, (double*)E, nullptr, nullptr,
+        status = rpca_core<double>(h, (const double*)H, Kp, LD, ro, &oo, (double*)A, (double*)E, nullptr, nullptr,
                            nullptr, 0, nullptr, info);
         if (status < 0) return status;
     } else {                                                                                  // :123-126
@@ -184,7 +201,7 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
         double* V = nullptr;
         int64_t sweeps = 0;
         TLSQ_TRY(svd_via_gram<double>(h, (const double*)H, Kp, LD, Kp, &V, s, &sweeps, nullptr));
-        const int64_t r = std::min<int64_t>(sv, std::min(K, LD));
+        const int64_t r = std::min<int64_t>(sv, std::min(Kg, LD));
         std::vector<int32_t> sel((size_t)r);
         std::vector<double> g((size_t)r, 1.0);
         for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
@@ -192,7 +209,21 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
         if (info) info->jacobi_sweeps = sweeps;
     }
     // :127  (dy is reused for the filtered signal)
-    TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, Kp, lag, Nx, (double*)dy, Nx));
+    if (!sharded) {
+        TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, Kp, lag, Nx, (double*)dy, Nx));
+    } else {
+        // anti-diagonals that straddle a shard boundary get their partial sums and counts from both neighbours: one
+        // sum all-reduce over [sums | counts], then the division; every rank ends up with the whole filtered series
+        void* sc;
+        const size_t nn = (size_t)Nx * Dch;
+        TLSQ_TRY(ws_get(h, WS_AUX4, 2 * nn * 8, &sc));
+        double* sum = (double*)sc;
+        double* cnt = sum + nn;
+        TLSQ_HIP(h, hipMemsetAsync(sc, 0, 2 * nn * 8, h->stream));
+        TLSQ_TRY(launch_unhankel_partial(h, (const double*)A, K, n, Dch, Kp, lag, Nw, s0, sum, cnt, Nx));
+        TLSQ_TRY(comm_allreduce(h, sum, 2 * nn, ncclSum));
+        TLSQ_TRY(launch_unhankel_finish(h, sum, cnt, (int64_t)nn, (double*)dy));
+    }
     TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) info->ms_total = now_ms() - t0;
