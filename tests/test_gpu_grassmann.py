@@ -210,3 +210,16 @@ def test_rpca_ga_large_panel_properties(eng):
     assert np.linalg.norm(Q.T @ Q - np.eye(r)) < 1e-8
     s = np.linalg.svd(np.hstack([Q, u]), compute_uv=False)
     assert s[r:].max() < 0.05                         # same subspace
+
+
+def test_rpca_ga_fuzz(eng):
+    """Randomised shapes / ranks / noise / outlier rates / averages (tools/fuzz_ga.py): same iteration counts and
+    components (1e-9) as the oracle in every case."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_ga", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_ga.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run(cases=120, seed=3, eng=eng, verbose=False)
+    assert not bad, bad

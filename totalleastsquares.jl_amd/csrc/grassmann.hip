@@ -483,12 +483,13 @@ inline int rows_per_lane(int64_t d) {
     return r;
 }
 inline int pass_blocks(int64_t N, int64_t d) {
-    const int G = group_lanes(d), rpl = G < 64 ? 1 : rows_per_lane(d);
+    const int G = group_lanes(d);
     const int64_t gpb = 4 * (64 / G);
     int64_t nb = (N + gpb * 8 - 1) / (gpb * 8);   // >= 8 columns per lane group
-    // enough blocks for the occupancy the register footprint allows (8 / 4 / 2 blocks per CU); every block costs a
-    // partial row in k_ga_reduce
-    const int64_t cap = rpl <= 2 ? 2048 : (rpl <= 8 ? 1024 : 512);
+    // two blocks per CU: measured best for every column length (256 / 1024 / 2048 / 4096 blocks are slower) — each
+    // block costs a partial row in k_ga_reduce, and the columns in flight per lane group already cover the latency
+    static const int env_cap = [] { const char* e = getenv("TLSQ_GA_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int64_t cap = env_cap > 0 ? env_cap : 512;
     if (nb < 1) nb = 1;
     if (nb > cap) nb = cap;
     return (int)nb;
