@@ -11,7 +11,7 @@ module TotalLeastSquaresHIP
 
 using LinearAlgebra, Libdl
 
-export rpca, lowrankfilter, hankel, unhankel, ishankel, tls!, rtls, rpca_ga, entrywise_median, entrywise_trimmed_mean, μ!
+export rpca, lowrankfilter, hankel, unhankel, ishankel, tls, tls!, rtls, rpca_ga, entrywise_median, entrywise_trimmed_mean, μ!
 
 const LIB = Ref{String}(get(ENV, "TLSQ_LIB", joinpath(@__DIR__, "..", "totalleastsquares.jl_amd", "libtlsqhip.so")))
 
@@ -158,6 +158,8 @@ function tls!(Ay::AbstractMatrix{Float64}, n::Integer)                 # src/Tot
         handle(), Am, M, nc, M, n, x, n, MEM_HOST))
     x
 end
+
+tls(A::AbstractArray{Float64}, y::AbstractArray{Float64}) = tls!([A y], size(A, 2))   # src/TotalLeastSquares.jl:48-55
 
 function tls!(s::SVD, n::Integer)                                      # src/TotalLeastSquares.jl:65-69
     Vt = Matrix(s.Vt); nc = size(Vt, 2)

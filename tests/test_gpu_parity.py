@@ -909,3 +909,16 @@ def test_implicit_hankel_sweep_is_bit_identical(tmp_path):
         assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_tls_out_of_place(eng):                      # src/TotalLeastSquares.jl:48-55; test/runtests.jl:43
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((300, 5))
+    x = rng.standard_normal(5)
+    y = A @ x + 0.01 * rng.standard_normal(300)
+    got = eng.tls(A, y)
+    assert got.shape == (5,) and np.allclose(got, O.tls(A, y).reshape(-1), rtol=1e-9, atol=1e-11)
+    assert np.allclose(got, eng.tls_(np.hstack([A, y[:, None]]), 5)[:, 0], rtol=0, atol=0)     # tls == tls!
+    Y2 = np.stack([y, 2 * y + 0.01 * rng.standard_normal(300)], axis=1)
+    assert np.allclose(eng.tls(A, Y2), O.tls(A, Y2), rtol=1e-8, atol=1e-10)

@@ -5,8 +5,8 @@ The directory name contains a dot, so import it through the repo-root shim:  `im
 """
 from . import _lib  # noqa: F401
 from .engine import (SVD, Engine, TlsqError, default_engine, hankel, ishankel, lowrankfilter, rpca,  # noqa: F401
-                     rtls, soft_hankel_, tls_, unhankel, rpca_ga, mu_, entrywise_trimmed_mean,
+                     rtls, soft_hankel_, tls, tls_, unhankel, rpca_ga, mu_, entrywise_trimmed_mean,
                      entrywise_median)
 
 __all__ = ["SVD", "Engine", "TlsqError", "default_engine", "hankel", "ishankel", "lowrankfilter", "rpca",
-           "rtls", "soft_hankel_", "tls_", "unhankel", "rpca_ga", "mu_", "entrywise_trimmed_mean", "entrywise_median"]
+           "rtls", "soft_hankel_", "tls", "tls_", "unhankel", "rpca_ga", "mu_", "entrywise_trimmed_mean", "entrywise_median"]

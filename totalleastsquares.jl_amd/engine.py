@@ -342,6 +342,14 @@ class Engine:
         self._check(self.lib.tlsq_tls_f64(self.h, _ptr(Af), M, nc, M, n, _ptr(x), n, L.MEM_HOST))
         return x
 
+    def tls(self, A, y):
+        """tls(A, y) — src/TotalLeastSquares.jl:48-55: the out-of-place form, x = tls!([A y], size(A, 2)).
+        A vector y gives a vector x (Julia's `-V21/V22` with a 1 x 1 V22 is n x 1; the reference's tests use `vec`)."""
+        A = np.asarray(A, dtype=np.float64)
+        yv = np.asarray(y, dtype=np.float64)
+        x = self.tls_(np.hstack([A, yv.reshape(A.shape[0], -1)]), A.shape[1])
+        return x[:, 0].copy() if yv.ndim == 1 else x
+
     def rtls(self, A, y, *, return_report=False, **kw):
         """rtls(A, y; kwargs...) — src/TotalLeastSquares.jl:152-156."""
         A = _f(A)
@@ -535,6 +543,10 @@ def soft_hankel_(A, eps):
 
 def tls_(Ay, n):
     return default_engine().tls_(Ay, n)
+
+
+def tls(A, y):
+    return default_engine().tls(A, y)
 
 
 def rpca_ga(X, r=None, **kw):
