@@ -104,7 +104,9 @@ def test_median_stable_ties(eng, G):                  # sortperm is stable: ties
 
 
 # ---- rpca_ga against the oracle ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,N,r", [(10, 40, 3), (40, 10, 4), (4, 500, 2), (24, 3000, 3), (64, 5000, 3),
+# (N (d+1) <= 18000 and d <= 64: the single-workgroup kernel k_ga_solo; otherwise the grid path)
+@pytest.mark.parametrize("d,N,r", [(10, 40, 3), (40, 10, 4), (4, 500, 2), (3, 4400, 3), (64, 270, 3), (33, 500, 4),
+                                   (4, 6000, 2), (10, 3000, 2), (24, 3000, 3), (64, 5000, 3),
                                    (200, 4000, 2), (700, 1500, 2), (2048, 300, 1), (2300, 400, 2)])
 def test_rpca_ga_mean_matches_oracle(eng, G, d, N, r):
     rng = np.random.default_rng(7 * d + N)

@@ -473,6 +473,137 @@ __global__ __launch_bounds__(256) void k_ga_offsets(int* __restrict__ offs, int 
     if (j <= d) offs[j] = (int)((int64_t)j * N);
 }
 
+// ---- small problems: the whole of rpca_ga in ONE workgroup ------------------------------------------------------
+// The reference's own uses are small (10 x 40 ... 10 x 1000, test/runtests.jl:446-520): there a kernel launch and a
+// host round trip per iteration cost more than the arithmetic.  When U and the norms fit in LDS (N (d+1) <= 18000
+// doubles, d <= 64) one block of 512 threads runs every component and every iteration by itself: U lives in LDS,
+// X (only needed for the deflation) stays in global memory, nothing returns to the host until all r components are
+// done.  Same statements in the same order as the grid path (:263-271, :289-306, :312-320); the sums are again
+// ordered (lane-group registers -> fixed-order LDS reduction), but partitioned differently from the grid path.
+struct SoloOut {      // per component
+    double dq;
+    int32_t iters, status;
+};
+template <int G>
+__global__ __launch_bounds__(512) void k_ga_solo(double* __restrict__ X, int d, int N, int r,
+                                                 const double* __restrict__ q0, double tol, int iters,
+                                                 double* __restrict__ Q, int64_t ldq, SoloOut* __restrict__ out,
+                                                 double* __restrict__ hist, int hist_cap) {
+    constexpr int GPW = 64 / G, NG = 8 * GPW;
+    extern __shared__ double lds[];
+    double* U = lds;                       // [N][d]
+    double* nrm = U + (size_t)N * d;       // [N]
+    double* red = nrm + N;                 // [NG][G]
+    double* redw = red + NG * G;           // [NG]
+    double* q = redw + NG;                 // [64]
+    double* qold = q + 64;                 // [64]
+    double* qprev = qold + 64;             // [64]
+    double* sv = qprev + 64;               // [64] column sums
+    double* sh = sv + 64;                  // [16] + [0]=ws at sh[16], flag at sh[17]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane / G, gl = lane % G;
+    const int gi = wave * GPW + g;
+    const bool rowok = gl < d;
+    const int glc = rowok ? gl : d - 1;
+    const int ncol = (N + NG - 1) / NG;    // columns per lane group (the same trip count for every lane: DPP sums)
+    for (int i = 0; i < r; ++i) {
+        // ---- :263-266, and :270-271 of the previous component
+        for (int c = 0; c < ncol; ++c) {
+            const int n = gi + c * NG;
+            const bool valid = n < N;
+            const int nc = valid ? n : N - 1;
+            double x = X[(size_t)nc * d + glc];
+            x = (valid && rowok) ? x : 0.0;
+            if (i > 0) {
+                const double qp = rowok ? qprev[gl] : 0.0;
+                const double t = group_sum<G>(x * qp);
+                x = x - qp * t;
+                if (valid && rowok) X[(size_t)n * d + gl] = x;
+            }
+            const double nn = sqrt(group_sum<G>(x * x));
+            if (valid) {
+                if (gl == 0) nrm[n] = nn;
+                if (rowok) U[(size_t)n * d + gl] = x / nn;
+            }
+        }
+        // ---- :289-291
+        {
+            const double v = (threadIdx.x < d) ? q0[(size_t)i * d + threadIdx.x] : 0.0;
+            const double n2 = block_sum(v * v, sh);
+            if (threadIdx.x < d) {
+                const double qn = v / sqrt(n2);
+                q[threadIdx.x] = qn;
+                qold[threadIdx.x] = qn;
+            }
+        }
+        __syncthreads();
+        int it = 0, conv = 0;
+        double dq = 0.0;
+        while (it < iters) {
+            const double qr = rowok ? q[gl] : 0.0;
+            double acc = 0.0, wsum = 0.0;
+            for (int c = 0; c < ncol; ++c) {
+                const int n = gi + c * NG;
+                const bool valid = n < N;
+                const int nc = valid ? n : N - 1;
+                double u = U[(size_t)nc * d + glc];
+                u = (valid && rowok) ? u : 0.0;
+                const double dot = group_sum<G>(u * qr);
+                double w = ga_sign(dot) * nrm[nc];                 // :295
+                w = valid ? w : 0.0;
+                acc += w * u;                                      // :317
+                wsum += w;                                         // :316
+            }
+            red[gi * G + gl] = acc;
+            if (gl == 0) redw[gi] = wsum;
+            __syncthreads();
+            if (threadIdx.x < d) {
+                double t = 0.0;
+                for (int k = 0; k < NG; ++k) t += red[k * G + threadIdx.x];
+                sv[threadIdx.x] = t;
+            } else if (threadIdx.x == 64) {
+                double t = 0.0;
+                for (int k = 0; k < NG; ++k) t += redw[k];
+                sh[16] = t;
+            }
+            __syncthreads();
+            if (wave == 0) {                                       // :319, :298-301 on one wave
+                const double ws = sh[16];
+                const double m = (lane < d) ? sv[lane] / ws : 0.0;
+                const double n2 = group_sum<64>(m * m);
+                const double qn = (lane < d) ? m / sqrt(n2) : 0.0;
+                const double df = (lane < d) ? qn - qold[lane] : 0.0;
+                const double d2 = group_sum<64>(df * df);
+                if (lane < d) {
+                    q[lane] = qn;
+                    qold[lane] = qn;
+                }
+                if (lane == 0) {
+                    const double v = sqrt(d2);
+                    sh[17] = v;
+                    if (hist && it < hist_cap) hist[(size_t)i * hist_cap + it] = v;
+                }
+            }
+            __syncthreads();
+            dq = sh[17];
+            ++it;
+            if (dq < tol) {                                        // :301
+                conv = 1;
+                break;
+            }
+        }
+        if (threadIdx.x < d) {
+            Q[(size_t)i * ldq + threadIdx.x] = q[threadIdx.x];    // :268
+            qprev[threadIdx.x] = q[threadIdx.x];
+        }
+        if (threadIdx.x == 0) {
+            out[i].dq = dq;
+            out[i].iters = it;
+            out[i].status = conv ? 0 : 1;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- launch helpers --------------------------------------------------------------------------------------------
 
 inline int group_lanes(int64_t d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
@@ -772,7 +903,64 @@ int read_state(Handle* h, const GaState* dev, GaState* host) {
 
 }  // namespace tlsq
 
+
 using namespace tlsq;
+
+// the single-workgroup path for small problems (k_ga_solo)
+static size_t solo_lds_bytes(int64_t d, int64_t N, int G) {
+    const int NG = 8 * (64 / G);
+    return ((size_t)N * d + N + (size_t)NG * G + NG + 4 * 64 + 18) * 8;
+}
+static int run_solo(Handle* h, const double* X, int64_t d, int64_t N, int64_t ldX, int64_t r, bool dev, double tol,
+                    int64_t iters, const double* dq0, double* dQ, int64_t ldq, tlsq_ga_info* info, int hist_cap,
+                    int64_t* passes, int* rc) {
+    const int G = group_lanes(d);
+    const size_t lds = solo_lds_bytes(d, N, G);
+    void* p;
+    TLSQ_TRY(ws_get(h, WS_GA_X, (size_t)d * N * 8, &p));
+    double* Xw = (double*)p;
+    TLSQ_TRY(copy2d(h, Xw, d, X, ldX, d, N, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));   // :257
+    const size_t ob = (size_t)r * sizeof(SoloOut), hb = (size_t)r * (hist_cap > 0 ? hist_cap : 0) * 8;
+    TLSQ_TRY(ws_get(h, WS_GA_AUX, ob + hb + 256, &p));
+    SoloOut* out = (SoloOut*)p;
+    double* hist = hb ? (double*)((char*)p + ((ob + 255) & ~(size_t)255)) : nullptr;
+    if (hb) TLSQ_HIP(h, hipMemsetAsync(hist, 0xff, hb, h->stream));   // NaN fill
+#define SOLO_LAUNCH(GG)                                                                                              \
+    do {                                                                                                             \
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ga_solo<GG>),                                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+        hipLaunchKernelGGL(k_ga_solo<GG>, dim3(1), dim3(512), lds, h->stream, Xw, (int)d, (int)N, (int)r, dq0, tol,   \
+                           (int)std::min<int64_t>(iters, 1 << 30), dQ, ldq, out, hist, hist_cap);                    \
+    } while (0)
+    switch (G) {
+        case 4: SOLO_LAUNCH(4); break;
+        case 8: SOLO_LAUNCH(8); break;
+        case 16: SOLO_LAUNCH(16); break;
+        case 32: SOLO_LAUNCH(32); break;
+        default: SOLO_LAUNCH(64); break;
+    }
+#undef SOLO_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    std::vector<SoloOut> ho((size_t)r);
+    std::vector<double> hh(hb / 8);
+    TLSQ_HIP(h, hipMemcpyAsync(ho.data(), out, ob, hipMemcpyDeviceToHost, h->stream));
+    if (hb) TLSQ_HIP(h, hipMemcpyAsync(hh.data(), hist, hb, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < r; ++i) {
+        *passes += ho[(size_t)i].iters;
+        if (ho[(size_t)i].status) *rc = TLSQ_MAXITER;
+        if (!info) continue;
+        if (info->iters) info->iters[i] = ho[(size_t)i].iters;
+        if (info->status) info->status[i] = ho[(size_t)i].status;
+        if (info->dq) info->dq[i] = ho[(size_t)i].dq;
+        if (hist_cap > 0) {
+            memcpy(info->dq_hist + (size_t)i * info->hist_capacity, hh.data() + (size_t)i * hist_cap, (size_t)hist_cap * 8);
+            for (int64_t k = hist_cap; k < info->hist_capacity; ++k)
+                info->dq_hist[(size_t)i * info->hist_capacity + k] = std::numeric_limits<double>::quiet_NaN();
+        }
+    }
+    return TLSQ_OK;
+}
 
 extern "C" {
 
@@ -817,13 +1005,16 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     const double t_begin = now_ms();
     const int hist_cap = (info && info->dq_hist && info->hist_capacity > 0)
                              ? (int)std::min<int64_t>(info->hist_capacity, iters) : 0;
+    // small problems run in one workgroup (k_ga_solo); TLSQ_GA_SOLO=0 sends them through the grid path as well
+    static const bool solo_on = [] { const char* e = getenv("TLSQ_GA_SOLO"); return !(e && e[0] == '0'); }();
+    const bool solo = solo_on && mode == TLSQ_GA_MEAN && h->nranks == 1 && d <= 64 && N * (d + 1) <= 18000;
     GaBuffers b;
-    TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
+    if (!solo) TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
     // inputs
     const double* src = X;
     int64_t lds = ldX;
     void* p;
-    if (!dev) {
+    if (!dev && !solo) {
         TLSQ_TRY(ws_get(h, WS_GA_IO, (size_t)d * N * 8, &p));
         TLSQ_TRY(copy2d(h, p, d, X, ldX, d, N, 8, hipMemcpyHostToDevice));
         src = (const double*)p;
@@ -852,7 +1043,8 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // uploads done: ms_loop is the component loop alone
     const double t_loop = now_ms();
     int64_t passes = 0;
-    for (int64_t i = 0; i < r; ++i) {
+    if (solo) TLSQ_TRY(run_solo(h, X, d, N, ldX, r, dev, tol, iters, dq0, dQ, ldq, info, hist_cap, &passes, &rc));
+    for (int64_t i = 0; i < r && !solo; ++i) {
         // :263-266 (and the deflation :270-271 of the previous component, fused into the same sweep)
         TLSQ_TRY(launch_prepare(h, i == 0 ? src : b.Xw, i == 0 ? lds : d, d, N, i == 0 ? nullptr : dQ + (i - 1) * ldq,
                                 b.Xw, b.U, b.norms));
