@@ -39,3 +39,11 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle_golden():
+    """frozen oracle outputs at C1 and a shrunken C2 (tests/golden/make_oracle_vectors.py)"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")) as f:
+        return json.load(f)

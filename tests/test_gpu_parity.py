@@ -922,3 +922,21 @@ def test_tls_out_of_place(eng):                      # src/TotalLeastSquares.jl:
     assert np.allclose(got, eng.tls_(np.hstack([A, y[:, None]]), 5)[:, 0], rtol=0, atol=0)     # tls == tls!
     Y2 = np.stack([y, 2 * y + 0.01 * rng.standard_normal(300)], axis=1)
     assert np.allclose(eng.tls(A, Y2), O.tls(A, Y2), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["c1_500x50_r5", "c2s_2000x128_r8"])
+def test_frozen_oracle_vectors(eng, oracle_golden, name):
+    """The HIP path against the committed oracle outputs (tests/golden/oracle_vectors.json) — no oracle code runs
+    except the seeded input generator: iteration count, svp trajectory, per-iteration cost, the singular values of
+    the last Z, and a strided sample of A and E."""
+    from oracle import rpca_oracle as O
+    g = oracle_golden[name]
+    D, _, _ = O.synth_lowrank_sparse(g["M"], g["N"], g["rank"], seed=g["seed"])
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    assert rep.iters_done == g["iters_done"] and sv == g["sv"] and rep.svp_hist == g["svp_hist"]
+    assert np.allclose(rep.cost_hist, g["cost_hist"], rtol=1e-6, atol=1e-13)
+    assert np.allclose(s.S[:sv], g["S"][:sv], rtol=1e-9, atol=0)                   # the sigma >= 1/mu ones
+    assert np.allclose(s.S, g["S"], rtol=0, atol=1e-6 * g["S"][0])                # Gram route: sqrt(eps) sigma_max
+    k = g["sample_stride"]
+    assert np.abs(A.ravel(order="F")[::k] - np.array(g["A_sample"])).max() <= 1e-8 * g["normA"]
+    assert np.abs(E.ravel(order="F")[::k] - np.array(g["E_sample"])).max() <= 1e-8 * g["normE"]

@@ -228,3 +228,19 @@ def test_ga_robust_average_beats_mean(robust, thr):   # test/runtests.jl:492-520
             Qm = G.rpca_ga(A, r, q0=q0, mu=_mu_blas, iters=120)
             wins.append(G.subspace_gap(Qr, u) < G.subspace_gap(Qm, u))
     assert np.mean(wins) > thr
+
+
+# ---- frozen oracle outputs: guards the oracle itself against drift ---------------------------
+@pytest.mark.parametrize("name", ["c1_500x50_r5", "c2s_2000x128_r8"])
+def test_oracle_reproduces_frozen_vectors(oracle_golden, name):
+    import hashlib
+    g = oracle_golden[name]
+    D, _, _ = O.synth_lowrank_sparse(g["M"], g["N"], g["rank"], seed=g["seed"])
+    assert hashlib.sha256(np.asfortranarray(D).tobytes(order="F")).hexdigest() == g["D_sha256_of_float64_column_major"]
+    A, E, s, sv, info = O.rpca(D)
+    assert info.iters_done == g["iters_done"] and sv == g["sv"] and list(info.svp_hist) == g["svp_hist"]
+    assert np.allclose(info.cost_hist, g["cost_hist"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(s[1], g["S"], rtol=1e-10, atol=1e-12 * g["S"][0])
+    k = g["sample_stride"]
+    assert np.abs(A.ravel(order="F")[::k] - np.array(g["A_sample"])).max() <= 1e-10 * g["normA"]
+    assert np.abs(E.ravel(order="F")[::k] - np.array(g["E_sample"])).max() <= 1e-10 * g["normE"]
