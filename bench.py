@@ -152,6 +152,25 @@ def main():
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
             "svd_step": {"full_jacobi": rep.eig_full, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
         }
+        # on-box ceiling for a streaming kernel (SURVEY §8d asks for it beside the 8 TB/s vendor figure): a plain
+        # device-to-device copy of 1 GiB (read + write = 2 GiB moved), best of 5, on torch's stream
+        try:
+            src = torch.empty(1 << 27, dtype=torch.float64, device="cuda").fill_(1.0)
+            dst = torch.empty_like(src)
+            best = 0.0
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dst.copy_(src)
+                e1.record()
+                torch.cuda.synchronize()
+                best = max(best, 2.0 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            out["roofline"]["measured_copy_ceiling_GBps"] = best
+            out["roofline"]["frac_of_measured_copy"] = achieved / best
+            del src, dst
+        except Exception as e:  # the bench line must not depend on this extra
+            out["roofline"]["measured_copy_ceiling_GBps"] = None
+            print(f"# copy ceiling not measured: {e}", file=sys.stderr)
         # HBM bytes of the two sweep kernels from the committed PMC run (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_sweeps.json")) as f:
