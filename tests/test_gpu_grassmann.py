@@ -225,3 +225,37 @@ def test_rpca_ga_fuzz(eng):
     spec.loader.exec_module(mod)
     bad = mod.run(cases=120, seed=3, eng=eng, verbose=False)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("d,N,r", [(12, 300, 2), (48, 2500, 3)])     # single-workgroup path / grid path
+def test_rpca_ga_device_pointers_and_leading_dimensions(eng, G, d, N, r):
+    """TLSQ_MEM_DEVICE through the raw C ABI: X, q0 and Q live in HBM with leading dimensions larger than d."""
+    import ctypes as C
+    import torch
+    from tlsq_amd import _lib as L
+    rng = np.random.default_rng(d + N)
+    _, X = _data(rng, d, N, r, outliers=0.01)
+    q0 = rng.standard_normal((d, r))
+    ldX, ldq, ldQ = d + 3, d + 1, d + 5
+    def dev(a, ld):       # column-major with leading dimension ld, padded rows filled with NaN
+        buf = np.full((a.shape[1], ld), np.nan)
+        buf[:, : a.shape[0]] = a.T
+        return torch.from_numpy(buf).cuda()
+    dX, dq0 = dev(X, ldX), dev(q0, ldq)
+    dQ = torch.full((r, ldQ), float("nan"), dtype=torch.float64, device="cuda")
+    o = L.GaOpts()
+    eng.lib.tlsq_ga_opts_default(C.byref(o))
+    o.memory = L.MEM_DEVICE
+    it = np.zeros(r, dtype=np.int64)
+    info = L.GaInfo()
+    info.iters = it.ctypes.data_as(C.POINTER(C.c_int64))
+    st = eng.lib.tlsq_rpca_ga_f64(eng.h, C.c_void_p(dX.data_ptr()), d, N, ldX, r, C.byref(o),
+                                  C.c_void_p(dq0.data_ptr()), ldq, C.c_void_p(dQ.data_ptr()), ldQ, C.byref(info))
+    assert st == 0
+    got = dQ.cpu().numpy()
+    assert np.isnan(got[:, d:]).all()                                  # padding untouched
+    ginfo = G.GaInfo()
+    want = G.rpca_ga(X, r, q0=q0, info=ginfo)
+    assert it.tolist() == ginfo.iters
+    assert np.abs(got[:, :d].T - want).max() < 1e-9
+    assert np.array_equal(dX.cpu().numpy()[:, :d].T, X)                # the input is not modified (:257)
