@@ -159,6 +159,10 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
                            int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
                            double* yf, int64_t ldyf, tlsq_rpca_info* info);
 
+int tlsq_lowrankfilter_f32(tlsq_handle h, const float* y, int64_t Nx, int64_t Dch, int64_t ldy,
+                           int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
+                           float* yf, int64_t ldyf, tlsq_rpca_info* info);   /* single GPU */
+
 /* ---- tls! / rtls: src/TotalLeastSquares.jl:63-69, 152-156 -------------------------------------
  * tls:  Ay (M x ncols, ldAy; NOT destroyed, unlike svd!) , n = columns of A -> x (n x q), q=ncols-n
  * rtls: A (M x n), y (M x q) -> x (n x q) via rpca([A y]; nukeA=false) then tls!(s, n).

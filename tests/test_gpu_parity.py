@@ -940,3 +940,18 @@ def test_frozen_oracle_vectors(eng, oracle_golden, name):
     k = g["sample_stride"]
     assert np.abs(A.ravel(order="F")[::k] - np.array(g["A_sample"])).max() <= 1e-8 * g["normA"]
     assert np.abs(E.ravel(order="F")[::k] - np.array(g["E_sample"])).max() <= 1e-8 * g["normE"]
+
+
+def test_lowrankfilter_fp32(eng):                    # src/robustPCA.jl:119-128 with eltype Float32
+    from oracle import rpca_oracle as O
+    y0, nz = O.synth_series(4000, seed=6)
+    y32 = (y0 + nz).astype(np.float32)
+    yf, rep = eng.lowrankfilter(y32, 40, return_report=True)
+    assert yf.dtype == np.float32 and rep.converged
+    yo = O.lowrankfilter(y32.astype(np.float64), 40)
+    assert relerr(yf.astype(np.float64), yo) < 1e-3                       # fp32 <= 1e-3 relative
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+    assert np.mean((y0 - qn(yf.astype(np.float64))) ** 2) / np.mean(nz ** 2) < 0.001    # test/runtests.jl:381
+    y2 = np.stack([y32, np.cos(0.05 * np.arange(4000)).astype(np.float32)], axis=1)
+    f2 = eng.lowrankfilter(y2, 30, lag=2, sv=3)
+    assert f2.dtype == np.float32 and relerr(f2.astype(np.float64), O.lowrankfilter(y2.astype(np.float64), 30, lag=2, sv=3)) < 1e-3

@@ -91,6 +91,109 @@ static int soft_hankel_impl(tlsq_handle h, T* A, int64_t K, int64_t L, int64_t l
 }
 
 
+// ---- lowrankfilter: src/robustPCA.jl:119-128 (fp64 and fp32) ------------------------------------------------------
+template <typename T>
+static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch, int64_t ldy, int64_t n, int64_t lag,
+                              int64_t sv, const tlsq_rpca_opts* opts, T* yf, int64_t ldyf, tlsq_rpca_info* info) {
+    constexpr size_t ES = sizeof(T);
+    TLSQ_TRY(check_handle(h));
+    if (!y || !yf || Nx <= 0 || Dch <= 0 || ldy < Nx || ldyf < Nx)
+        return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: bad argument");
+    if (n <= 0) n = std::min<int64_t>(Nx / 20, 2000);  // :119
+    if (lag <= 0) lag = 1;
+    if (!(2 * n <= Nx)) return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
+    if (!(lag <= n)) return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    if (info) {
+        double* ch = info->cost_hist;
+        int64_t* sh = info->svp_hist;
+        int64_t cap = info->hist_capacity;
+        memset(info, 0, sizeof(*info));
+        info->cost_hist = ch;
+        info->svp_hist = sh;
+        info->hist_capacity = cap;
+    }
+    const double t0 = now_ms();
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    const int64_t Kg = (Nx - n) / lag + 1, LD = n * Dch;   // rows of the whole Hankel matrix
+    // With a communicator every rank passes the WHOLE series and owns a contiguous block of the rows of H, i.e. a time
+    // window of y with an (n-1)-sample halo (SURVEY §8e): rows [r0, r1) use the samples [r0*lag, (r1-1)*lag + n).
+    const bool sharded = h->comm != nullptr;
+    int64_t r0 = 0, r1 = Kg;
+    if (sharded) {
+        const int64_t base = Kg / h->nranks, rem = Kg % h->nranks;
+        r0 = h->rank * base + std::min<int64_t>(h->rank, rem);
+        r1 = r0 + base + (h->rank < rem ? 1 : 0);
+        if (r1 <= r0) return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: fewer Hankel rows (%lld) than ranks", (long long)Kg);
+        if (opts && opts->hankel)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the hankel option is not available on row shards");
+        if (!std::is_same<T, double>::value)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: row shards are fp64 only");
+    }
+    const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
+    // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
+    // hankel option of rpca works on the exact shape
+    const int64_t Kp = (opts && opts->hankel) ? K : (K + 15) / 16 * 16;
+    void *dy, *H, *A, *E;
+    TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
+    if (Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
+    TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    const T* yw = (const T*)dy + s0;                                                // this rank's window
+    TLSQ_TRY(launch_hankel<T>(h, yw, Nw, Dch, Nx, n, lag, (T*)H, Kp));                // :120
+    int status = TLSQ_OK;
+    if (sv <= 0) {                                                                            // :121-122
+        TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * ES, &E));
+        tlsq_rpca_opts oo;
+        if (opts) oo = *opts; else tlsq_rpca_opts_default(&oo);
+        oo.m_global = Kg;
+        ResolvedOpts ro = resolve(&oo, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
+        ro.m_global = Kg;
+        // SURVEY §8f rank 2 (first step): the 7-pass sweep of large panels reads y instead of H (6 passes)
+        static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
+        if (implicit_ok && Dch == 1 && lag == 1) {
+            ro.hankel_y = yw;
+            ro.hankel_K = K;
+        }
+        status = rpca_core<T>(h, (const T*)H, Kp, LD, ro, &oo, (T*)A, (T*)E, nullptr, nullptr, nullptr, 0, nullptr, info);
+        if (status < 0) return status;
+    } else {                                                                                  // :123-126
+        SmallSvd s;
+        double* V = nullptr;
+        int64_t sweeps = 0;
+        TLSQ_TRY(svd_via_gram<T>(h, (const T*)H, Kp, LD, Kp, &V, s, &sweeps, nullptr));
+        const int64_t r = std::min<int64_t>(sv, std::min(Kg, LD));
+        std::vector<int32_t> sel((size_t)r);
+        std::vector<double> g((size_t)r, 1.0);
+        for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
+        TLSQ_TRY(rebuild_lowrank<T>(h, (const T*)H, Kp, LD, Kp, V, sel, g, (T*)A, Kp));
+        if (info) info->jacobi_sweeps = sweeps;
+    }
+    // :127  (dy is reused for the filtered signal)
+    if (!sharded) {
+        TLSQ_TRY(launch_unhankel<T>(h, (const T*)A, K, n, Dch, Kp, lag, Nx, (T*)dy, Nx));
+    } else {
+        // anti-diagonals that straddle a shard boundary get their partial sums and counts from both neighbours: one
+        // sum all-reduce over [sums | counts], then the division; every rank ends up with the whole filtered series
+        void* sc;
+        const size_t nn = (size_t)Nx * Dch;
+        TLSQ_TRY(ws_get(h, WS_AUX4, 2 * nn * 8, &sc));
+        double* sum = (double*)sc;
+        double* cnt = sum + nn;
+        TLSQ_HIP(h, hipMemsetAsync(sc, 0, 2 * nn * 8, h->stream));
+        if constexpr (std::is_same<T, double>::value) {
+            TLSQ_TRY(launch_unhankel_partial(h, (const double*)A, K, n, Dch, Kp, lag, Nw, s0, sum, cnt, Nx));
+            TLSQ_TRY(comm_allreduce(h, sum, 2 * nn, ncclSum));
+            TLSQ_TRY(launch_unhankel_finish(h, sum, cnt, (int64_t)nn, (double*)dy));
+        }
+    }
+    TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (info) info->ms_total = now_ms() - t0;
+    return status;
+}
+
 extern "C" {
 
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
@@ -132,102 +235,13 @@ int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t 
 }
 
 // ---- lowrankfilter: src/robustPCA.jl:119-128 -----------------------------------------------------
-int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy,
-                           int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts, double* yf,
-                           int64_t ldyf, tlsq_rpca_info* info) {
-    TLSQ_TRY(check_handle(h));
-    if (!y || !yf || Nx <= 0 || Dch <= 0 || ldy < Nx || ldyf < Nx)
-        return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: bad argument");
-    if (n <= 0) n = std::min<int64_t>(Nx / 20, 2000);  // :119
-    if (lag <= 0) lag = 1;
-    if (!(2 * n <= Nx)) return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
-    if (!(lag <= n)) return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
-    TLSQ_HIP(h, hipSetDevice(h->device));
-    if (info) {
-        double* ch = info->cost_hist;
-        int64_t* sh = info->svp_hist;
-        int64_t cap = info->hist_capacity;
-        memset(info, 0, sizeof(*info));
-        info->cost_hist = ch;
-        info->svp_hist = sh;
-        info->hist_capacity = cap;
-    }
-    const double t0 = now_ms();
-    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const int64_t Kg = (Nx - n) / lag + 1, LD = n * Dch;   // rows of the whole Hankel matrix
-    // With a communicator every rank passes the WHOLE series and owns a contiguous block of the rows of H, i.e. a time
-    // window of y with an (n-1)-sample halo (SURVEY §8e): rows [r0, r1) use the samples [r0*lag, (r1-1)*lag + n).
-    const bool sharded = h->comm != nullptr;
-    int64_t r0 = 0, r1 = Kg;
-    if (sharded) {
-        const int64_t base = Kg / h->nranks, rem = Kg % h->nranks;
-        r0 = h->rank * base + std::min<int64_t>(h->rank, rem);
-        r1 = r0 + base + (h->rank < rem ? 1 : 0);
-        if (r1 <= r0) return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: fewer Hankel rows (%lld) than ranks", (long long)Kg);
-        if (opts && opts->hankel)
-            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the hankel option is not available on row shards");
-    }
-    const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
-    // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
-    // hankel option of rpca works on the exact shape
-    const int64_t Kp = (opts && opts->hankel) ? K : (K + 15) / 16 * 16;
-    void *dy, *H, *A, *E;
-    TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * 8, &dy));
-    TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * 8, &H));
-    TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * 8, &A));
-    if (Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * 8, h->stream));
-    TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    const double* yw = (const double*)dy + s0;                                                // this rank's window
-    TLSQ_TRY(launch_hankel<double>(h, yw, Nw, Dch, Nx, n, lag, (double*)H, Kp));                // :120
-    int status = TLSQ_OK;
-    if (sv <= 0) {                                                                            // :121-122
-        TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * 8, &E));
-        tlsq_rpca_opts oo;
-        if (opts) oo = *opts; else tlsq_rpca_opts_default(&oo);
-        oo.m_global = Kg;
-        ResolvedOpts ro = resolve(&oo, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
-        ro.m_global = Kg;
-        // SURVEY §8f rank 2 (first step): the 7-pass sweep of large panels reads y instead of H (6 passes)
-        static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
-        if (implicit_ok && Dch == 1 && lag == 1) {
-            ro.hankel_y = yw;
-            ro.hankel_K = K;
-        }
-        status = rpca_core<double>(h, (const double*)H, Kp, LD, ro, &oo, (double*)A, (double*)E, nullptr, nullptr,
-                           nullptr, 0, nullptr, info);
-        if (status < 0) return status;
-    } else {                                                                                  // :123-126
-        SmallSvd s;
-        double* V = nullptr;
-        int64_t sweeps = 0;
-        TLSQ_TRY(svd_via_gram<double>(h, (const double*)H, Kp, LD, Kp, &V, s, &sweeps, nullptr));
-        const int64_t r = std::min<int64_t>(sv, std::min(Kg, LD));
-        std::vector<int32_t> sel((size_t)r);
-        std::vector<double> g((size_t)r, 1.0);
-        for (int64_t p2 = 0; p2 < r; ++p2) sel[p2] = s.order[p2];
-        TLSQ_TRY(rebuild_lowrank<double>(h, (const double*)H, Kp, LD, Kp, V, sel, g, (double*)A, Kp));
-        if (info) info->jacobi_sweeps = sweeps;
-    }
-    // :127  (dy is reused for the filtered signal)
-    if (!sharded) {
-        TLSQ_TRY(launch_unhankel<double>(h, (const double*)A, K, n, Dch, Kp, lag, Nx, (double*)dy, Nx));
-    } else {
-        // anti-diagonals that straddle a shard boundary get their partial sums and counts from both neighbours: one
-        // sum all-reduce over [sums | counts], then the division; every rank ends up with the whole filtered series
-        void* sc;
-        const size_t nn = (size_t)Nx * Dch;
-        TLSQ_TRY(ws_get(h, WS_AUX4, 2 * nn * 8, &sc));
-        double* sum = (double*)sc;
-        double* cnt = sum + nn;
-        TLSQ_HIP(h, hipMemsetAsync(sc, 0, 2 * nn * 8, h->stream));
-        TLSQ_TRY(launch_unhankel_partial(h, (const double*)A, K, n, Dch, Kp, lag, Nw, s0, sum, cnt, Nx));
-        TLSQ_TRY(comm_allreduce(h, sum, 2 * nn, ncclSum));
-        TLSQ_TRY(launch_unhankel_finish(h, sum, cnt, (int64_t)nn, (double*)dy));
-    }
-    TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) info->ms_total = now_ms() - t0;
-    return status;
+int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy, int64_t n, int64_t lag,
+                           int64_t sv, const tlsq_rpca_opts* opts, double* yf, int64_t ldyf, tlsq_rpca_info* info) {
+    return lowrankfilter_impl<double>(h, y, Nx, Dch, ldy, n, lag, sv, opts, yf, ldyf, info);
+}
+int tlsq_lowrankfilter_f32(tlsq_handle h, const float* y, int64_t Nx, int64_t Dch, int64_t ldy, int64_t n, int64_t lag,
+                           int64_t sv, const tlsq_rpca_opts* opts, float* yf, int64_t ldyf, tlsq_rpca_info* info) {
+    return lowrankfilter_impl<float>(h, y, Nx, Dch, ldy, n, lag, sv, opts, yf, ldyf, info);
 }
 
 // ---- tls! / rtls ---------------------------------------------------------------------------------

@@ -1591,6 +1591,11 @@ template int rebuild_lowrank<double>(Handle*, const double*, int64_t, int64_t, i
                                      const std::vector<int32_t>&, const std::vector<double>&, double*, int64_t);
 template int rpca_core<double>(Handle*, const double*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*,
                                double*, double*, double*, double*, double*, int64_t, int64_t*, tlsq_rpca_info*);
+template int svd_via_gram<float>(Handle*, const float*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*, PhaseTimer*);
+template int rebuild_lowrank<float>(Handle*, const float*, int64_t, int64_t, int64_t, const double*,
+                                    const std::vector<int32_t>&, const std::vector<double>&, float*, int64_t);
+template int rpca_core<float>(Handle*, const float*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*, float*,
+                              float*, float*, double*, double*, int64_t, int64_t*, tlsq_rpca_info*);
 template int rpca_entry<double>(tlsq_handle, const double*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, double*,
                                 int64_t, double*, int64_t, double*, int64_t, double*, double*, int64_t, int64_t*,
                                 tlsq_rpca_info*);

@@ -298,8 +298,10 @@ class Engine:
         """src/robustPCA.jl:119-128.  cost_history=False: like a plain Julia call, nobody looks at the
         per-iteration cost, so the library only settles `cost < tol` (same result, less work)."""
         svd_mode, opn_mode, mvps = self._hook_modes(svd, kw.pop("opnorm", None))
-        y = np.asarray(y, dtype=np.float64)
-        y2 = _f(y.reshape(y.shape[0], -1))
+        y = np.asarray(y)
+        dt = np.float32 if y.dtype == np.float32 else np.float64      # eltype(y) as in the reference (generic T)
+        y = np.asarray(y, dtype=dt)
+        y2 = _f(y.reshape(y.shape[0], -1), dt)
         Nx, Dch = y2.shape
         if n is None:
             n = min(Nx // 20, 2000)
@@ -314,9 +316,10 @@ class Engine:
         o = self.make_opts(iters=iters, tol=tol, on_iter=cb, svd_mode=svd_mode, opnorm_mode=opn_mode,
                            opnorm_mvps=mvps, seed=kw.pop("seed", 0), **allowed)
         info, cost, svp = self._info(iters, cost_history)
-        yf = np.empty((Nx, Dch), dtype=np.float64, order="F")
-        st = self._check(self.lib.tlsq_lowrankfilter_f64(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag),
-                                                         int(sv), C.byref(o), _ptr(yf), Nx, C.byref(info)))
+        yf = np.empty((Nx, Dch), dtype=dt, order="F")
+        fn = self.lib.tlsq_lowrankfilter_f32 if dt == np.float32 else self.lib.tlsq_lowrankfilter_f64
+        st = self._check(fn(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag), int(sv), C.byref(o), _ptr(yf), Nx,
+                            C.byref(info)))
         rep = RpcaReport(info, cost, svp)
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: {tol}")
