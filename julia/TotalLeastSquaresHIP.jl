@@ -128,8 +128,8 @@ function ishankel(A)                                                   # src/rob
     true
 end
 
-function lowrankfilter(y::AbstractVecOrMat{Float64}, n = min(size(y, 1) ÷ 20, 2000);
-                       sv = 0, lag = 1, tol = 1e-3, svd = LinearAlgebra.svd!, kwargs...)   # :119-128
+function lowrankfilter(y::AbstractVecOrMat{T}, n = min(size(y, 1) ÷ 20, 2000);
+                       sv = 0, lag = 1, tol = 1e-3, svd = LinearAlgebra.svd!, kwargs...) where {T<:Union{Float64,Float32}}   # :119-128
     svd ∈ (LinearAlgebra.svd, LinearAlgebra.svd!) || error("custom svd hooks cannot run on the GPU path")
     ym = Matrix(reshape(y, size(y, 1), :)); N, D = size(ym)
     @assert n <= N / 2 "L has to be less than N/2 = $(N/2)"
@@ -142,10 +142,14 @@ function lowrankfilter(y::AbstractVecOrMat{Float64}, n = min(size(y, 1) ÷ 20, 2
         k === :hankel && (o.hankel = v); k === :nukeA && (o.nukeA = v ? 1 : 0)
     end
     info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
-    yf = Matrix{Float64}(undef, N, D)
-    st = check(ccall((:tlsq_lowrankfilter_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64,
-         Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info))
+    yf = Matrix{T}(undef, N, D)
+    st = T === Float64 ?
+        check(ccall((:tlsq_lowrankfilter_f64, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64,
+             Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info)) :
+        check(ccall((:tlsq_lowrankfilter_f32, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float32}, Int64,
+             Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info))
     st == TLSQ_MAXITER && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
     y isa AbstractVector ? vec(yf) : yf
 end
