@@ -10,14 +10,15 @@
 // X is d x N, column-major: a column is one observation, so every step is a sweep over columns.  One iteration of
 // rpca_ga_1 is    w_n = sign(U[:,n]'q) * norm_n ;  s = sum_n w_n U[:,n] ;  q = normalised(s / sum_n w_n)
 // and needs each column exactly once: k_ga_pass holds a column in the registers of a lane group (G lanes, G = the
-// power of two >= d up to 64, then RPL rows per lane), forms the dot with a DPP/shuffle reduction inside the
+// power of two >= d up to 64, then RPL rows per lane), forms the dot with a DPP reduction inside the
 // group and accumulates w * column in registers.  HBM traffic is one read of U per iteration (the unfused reference
 // reads it twice: :294-296 and :315-318).  Sums are ordered: lane-group registers -> fixed-order LDS reduction per
 // block -> per-block partial rows -> fixed-order sum (k_ga_reduce), so results are reproducible run to run.
 //
 // The convergence test (:299-304) runs on the device: k_ga_reduce's last block normalises, forms dq and sets a
-// `converged` flag that turns the kernels of already queued iterations into no-ops; the host queues a few
-// iterations at a time and reads the 32-byte state block in between.
+// `converged` flag that turns the kernels of already queued iterations into no-ops; the host queues eight
+// iterations at a time and reads the 40-byte state block in between.  Small problems (U fits in LDS) run whole in
+// one workgroup, k_ga_solo, with no host round trip at all.
 //
 // The robust averages need order statistics of every row of U (trimmed mean: once per component, the ordering of
 // U[j,:] does not depend on w; median: every iteration, ordering of w .* U[j,:]).  Those go through a segmented
