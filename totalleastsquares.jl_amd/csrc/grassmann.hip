@@ -33,6 +33,9 @@ namespace tlsq {
 
 namespace {
 
+#ifndef TLSQ_GA_UNR1
+#define TLSQ_GA_UNR1 8
+#endif
 constexpr int kGaFusedMaxD = 2048;   // longest column a lane group holds in registers (64 lanes x 32 rows)
 
 struct GaState {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void k_ga_pass(const double* __restrict__ U, i
     }
     if (!TRIM) accw[0] = 0.0;
     // UNR columns per lane group are in flight at once (the loads of all of them are issued before the first dot)
-    constexpr int UNR = RPL == 1 ? 8 : (RPL == 2 ? 4 : (RPL <= 8 ? 2 : 1));
+    constexpr int UNR = RPL == 1 ? TLSQ_GA_UNR1 : (RPL == 2 ? 4 : (RPL <= 8 ? 2 : 1));
     const int64_t gpb = 4 * GPW, stride = (int64_t)gridDim.x * gpb;
     for (int64_t n0 = (int64_t)blockIdx.x * gpb + wave * GPW; n0 < N; n0 += stride * UNR) {
         double col[UNR][RPL], wn[UNR];   // wn: the column's norm (or its given weight), loaded with the column
