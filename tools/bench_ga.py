@@ -30,7 +30,7 @@ def main():
         X = (u * np.array([30.0, 20.0, 10.0])) @ rng.standard_normal((r, N)) + 0.01 * rng.standard_normal((d, N))
         X += 100 * rng.standard_normal((d, N)) * (rng.random((d, N)) < 0.001)
         q0 = rng.standard_normal((d, r))
-        eng.rpca_ga(X, r, q0=q0)
+        eng.rpca_ga(X, r, q0=q0, return_report=True)     # warm-up with the same workspace (the dq history included)
         Q, rep = eng.rpca_ga(X, r, q0=q0, return_report=True)
         gb = rep["passes"] * d * N * 8 / 1e9
         line = (f"d={d:5d} N={N:8d}  iters={rep['iters']}  loop {rep['ms_loop']:8.2f} ms  "
