@@ -875,7 +875,7 @@ inline int ga_entries(int64_t d, int mode) { return mode == TLSQ_GA_TRIMMED_MEAN
 // one queued iteration of rpca_ga_1: sums, (all-reduce,) finish
 int ga_iteration(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, double tol, int hist_cap) {
     TLSQ_TRY(ga_sums(h, b, d, N, mode, nullptr, b->st));
-    const bool sharded = h->nranks > 1;
+    const bool sharded = h->comm != nullptr;
     if (mode == TLSQ_GA_MEDIAN) {
         hipLaunchKernelGGL(k_ga_finalize, dim3(1), dim3(256), 0, h->stream, b->sbuf, (int)d, 2, b->q, b->qold, tol, b->st,
                            b->hist, hist_cap);
@@ -998,7 +998,7 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: entrywise_median needs at least 2 columns (I[end÷2])");
     if (mode == TLSQ_GA_TRIMMED_MEAN && !(P >= 0.0 && P < 1.0))
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: trim fraction outside [0,1)");
-    if (mode != TLSQ_GA_MEAN && h->nranks > 1)
+    if (mode != TLSQ_GA_MEAN && h->comm != nullptr)
         return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages are not available on column shards");
     if (info) {
         info->ms_total = info->ms_loop = 0.0;
@@ -1011,7 +1011,7 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
                              ? (int)std::min<int64_t>(info->hist_capacity, iters) : 0;
     // small problems run in one workgroup (k_ga_solo); TLSQ_GA_SOLO=0 sends them through the grid path as well
     static const bool solo_on = [] { const char* e = getenv("TLSQ_GA_SOLO"); return !(e && e[0] == '0'); }();
-    const bool solo = solo_on && mode == TLSQ_GA_MEAN && h->nranks == 1 && d <= 64 && N * (d + 1) <= 18000;
+    const bool solo = solo_on && mode == TLSQ_GA_MEAN && !h->comm && d <= 64 && N * (d + 1) <= 18000;
     GaBuffers b;
     if (!solo) TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
     // inputs
