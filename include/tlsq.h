@@ -282,6 +282,15 @@ int tlsq_k_symeig_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, do
  * eigenvector accumulation): eigenvectors of numerically-zero eigenvalues are returned as zero columns */
 int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ldG, double* lam, double* V,
                            int64_t ldV, int64_t* sweeps);
+/* R (N x N upper triangular, ldR) of the Householder TSQR factorisation Z = Q R of a tall panel Z (M x N, ldZ, M >= N):
+ * LDS-staged Householder panel reduction over 256-row blocks, tree over the block factors, MFMA trailing updates.
+ * R'R = Z'Z, and the singular values of R are those of Z to a few eps * sigma_max (what LAPACK's gesdd delivers at
+ * src/robustPCA.jl:194) — unlike the Gram route, which squares the condition number. */
+int tlsq_k_tsqr_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* R, int64_t ldR);
+/* thin SVD factors of Z through that route: S (N, descending), V (N x N, ldV; column i = right singular vector i):
+ * TSQR, then one-sided Jacobi on R'.  Every singular value is accurate to a few eps * sigma_max. */
+int tlsq_k_svd_r_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* S, double* V,
+                     int64_t ldV, int64_t* sweeps);
 /* sigma_max of Z (M x N, ldZ) — the default `opnorm` */
 int tlsq_k_opnorm_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                       double* sigma_max);

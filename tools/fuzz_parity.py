@@ -25,6 +25,8 @@ def make_case(rng):
               iters=int(rng.choice([120, 60])))
     if rng.random() < 0.2:
         kw["lam"] = float(rng.uniform(0.02, 0.5))
+    if rng.random() < 0.12:
+        kw["hankel"] = True   # soft_hankel!(A, lambda/mu) inside the loop and soft_hankel!(E, .) after it (:214-216, :234-236)
     return D, kw, f"{M}x{N} r={r} noise={noise} frac={frac} scale={scale}"
 
 

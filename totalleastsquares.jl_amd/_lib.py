@@ -67,7 +67,7 @@ EXPORTS = [
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
     "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
-    "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64",
+    "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64", "tlsq_k_tsqr_f64", "tlsq_k_svd_r_f64",
 ]
 
 _lib = None
@@ -129,6 +129,8 @@ def load():
     lib.tlsq_k_gemm_nt_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
     lib.tlsq_k_symeig_f64.argtypes = [vp, vp, i64, i64, vp, vp, i64, P(i64)]
     lib.tlsq_k_symeig_chol_f64.argtypes = [vp, vp, i64, i64, vp, vp, i64, P(i64)]
+    lib.tlsq_k_tsqr_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]
+    lib.tlsq_k_svd_r_f64.argtypes = [vp, vp, i64, i64, i64, vp, vp, i64, P(i64)]
     lib.tlsq_k_opnorm_f64.argtypes = [vp, vp, i64, i64, i64, P(dbl)]
     lib.tlsq_k_maxabs_f64.argtypes = [vp, vp, i64, P(dbl)]
     for name in EXPORTS:

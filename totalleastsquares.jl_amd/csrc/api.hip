@@ -257,7 +257,10 @@ static int vt_of(tlsq_handle h, const double* dAy, int64_t M, int64_t nc, int64_
     SmallSvd s;
     double* V = nullptr;
     int64_t sweeps = 0;
-    TLSQ_TRY(svd_via_gram<double>(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
+    // TSQR route: tls! takes the right singular vectors of the SMALLEST singular values (V[:, n+1:end],
+    // src/TotalLeastSquares.jl:66-68), which the Gram route only resolves to eps * cond(Ay)^2
+    if (M >= nc && nc <= kFullEigMaxN && !h->comm) TLSQ_TRY(svd_via_r<double>(h, dAy, M, nc, ld, &V, s, &sweeps));
+    else TLSQ_TRY(svd_via_gram<double>(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
     std::vector<double> hv((size_t)nc * nc);
     TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)nc * nc * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -664,6 +667,39 @@ int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ld
     TLSQ_HIP(h, hipMemcpyAsync(aux, order.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
     TLSQ_TRY(launch_gather_scale(h, (const double*)Vw, N, (const int32_t*)aux, nullptr, N, nullptr, (double*)Vs));
     TLSQ_TRY(copy2d(h, V, ldV, Vs, N, N, N, 8, hipMemcpyDeviceToDevice));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+int tlsq_k_tsqr_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* R, int64_t ldR) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !R || N <= 0 || M < N || ldZ < M || ldR < N) return set_err(h, TLSQ_ERR_ARG, "tsqr: bad argument (needs M >= N)");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    TLSQ_TRY(tsqr_r(h, Z, M, N, ldZ, R, ldR));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    return TLSQ_OK;
+}
+int tlsq_k_svd_r_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* S, double* V,
+                     int64_t ldV, int64_t* sweeps) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !S || N <= 0 || M < N || ldZ < M || (V && ldV < N) || N > kFullEigMaxN)
+        return set_err(h, TLSQ_ERR_ARG, "svd_r: bad argument (needs M >= N, N <= %lld)", (long long)kFullEigMaxN);
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    SmallSvd s;
+    double* Vw = nullptr;
+    int64_t sw = 0;
+    TLSQ_TRY(svd_via_r<double>(h, Z, M, N, ldZ, &Vw, s, &sw));
+    if (sweeps) *sweeps = sw;
+    std::vector<double> sorted((size_t)N);
+    for (int64_t i = 0; i < N; ++i) sorted[i] = s.sigma[s.order[i]];
+    TLSQ_HIP(h, hipMemcpyAsync(S, sorted.data(), (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    if (V) {
+        void *aux, *Vs;
+        TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)N * 16, &aux));
+        TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * N * 8, &Vs));
+        TLSQ_HIP(h, hipMemcpyAsync(aux, s.order.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(launch_gather_scale(h, (const double*)Vw, N, (const int32_t*)aux, nullptr, N, nullptr, (double*)Vs));
+        TLSQ_TRY(copy2d(h, V, ldV, Vs, N, N, N, 8, hipMemcpyDeviceToDevice));
+    }
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }

@@ -86,6 +86,7 @@ enum WsSlot {
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
     WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
+    WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_COUNT
@@ -184,6 +185,17 @@ int launch_normalize_cols(Handle* h, const double* B, int64_t N, double* V, doub
 // Columns belonging to numerically-zero eigenvalues come back as zero vectors.
 int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev,
                     double* delta_host, int64_t* sweeps_out);
+// One-sided Jacobi on the columns of a square factor B (N x N, ld N, in place): V = normalised orthogonal columns,
+// sig_dev = their norms (unsorted).  floor_rel * ||B||_F = norm below which a column takes no part (0: none).
+int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_dev, double floor_rel,
+                      int64_t* sweeps_out);
+
+// ---------------- tsqr.hip ----------------
+// B (N x N, ld N) = R' (lower triangular) of the Householder TSQR factorisation Z = Q R; Z (M x N, ld ldz, fp32 when
+// z_f32) is not modified.  On a handle with a communicator Z is the local row shard and R belongs to the whole matrix.
+int tsqr_lt(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldz, double* B);
+// R (N x N, upper triangular, ld ldR)
+int tsqr_r(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldz, double* R, int64_t ldR);
 
 // ---------------- lanczos.hip ----------------
 // lambda_max(G) to relative accuracy rel_tol (residual bound of the Ritz pair); returns 1 (and the best

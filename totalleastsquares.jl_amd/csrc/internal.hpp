@@ -17,6 +17,8 @@ namespace tlsq {
 // in-place reduction over the row shards of a handle with a communicator (no-op otherwise)
 int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op);
 int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op);
+// recv (nranks * count doubles, rank-major) <- every rank's send (count doubles)
+int comm_allgather(Handle* h, const double* send, double* recv, size_t count);
 int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
            hipMemcpyKind kind);
 double now_ms();
@@ -149,6 +151,9 @@ int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double*
 template <typename T>
 int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s,
                  int64_t* sweeps, PhaseTimer* pt);
+// the same through the TSQR route (tsqr.hip + one-sided Jacobi on R'): full accuracy for every singular value; M >= N
+template <typename T>
+int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s, int64_t* sweeps);
 // Aout (M x N, ldA) = Z * V[:,sel] * diag(g) * V[:,sel]'
 template <typename T>
 int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,

@@ -798,29 +798,31 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     return TLSQ_OK;
 }
 
-// Eigen-decomposition of the PSD matrix G through its Cholesky factor (cholesky.hip): one-sided Jacobi on the
-// columns of L = chol(G + delta I) with no eigenvector accumulation; the eigenvectors of G are the normalised
-// columns of the rotated L and sig = column norms = sqrt(lambda + delta).
-int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev,
-                    double* delta_host, int64_t* sweeps_out) {
+// One-sided Jacobi on the columns of a square factor B (N x N, ld N, rotated in place): on return the columns of B are
+// mutually orthogonal, V (N x N, ld N) holds them normalised and sig_dev[i] their norms (unsorted).  For B = L with
+// G = L L' (Cholesky factor, or R' of a QR factorisation Z = Q R) these are the eigenvectors of G / right singular
+// vectors of Z and sqrt(lambda_i) / sigma_i — no eigenvector accumulation.  floor_rel: columns whose norm is below
+// floor_rel * ||B||_F take no part in rotations (0: every non-zero column does).  Matrices that fit one block pair
+// in LDS (N <= ~130) run all sweeps in a single launch.
+int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_dev, double floor_rel,
+                      int64_t* sweeps_out) {
     if (sweeps_out) *sweeps_out = 0;
     if (N <= 0) return TLSQ_OK;
     void* scal;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
     double* params = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 64);
     unsigned int* rot = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 128);
-    double* stats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 192);
-    TLSQ_TRY(cholesky_shifted(h, G, ldG, N, B, V /* scratch */, stats));
+    int* sweeps_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 136);
     const double eps = 2.220446049250313e-16;
     int sweep = 0;
     bool converged = true;
     if (N >= 2) {
-        const double nf = (double)N * eps;
-        hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params, nf * nf);
+        hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params,
+                           floor_rel * floor_rel);
         TLSQ_HIP(h, hipGetLastError());
         bool single = false;
         int b = pick_block(N, false, &single);
-        if (b > 16) b = 16;
+        if (!single && b > 16) b = 16;
         if (b < 1)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "N=%lld too large for the LDS-resident Jacobi eigensolver",
                            (long long)N);
@@ -835,35 +837,62 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
         if (tol < 4.0 * eps) tol = 4.0 * eps;
         const int max_sweeps = 40;
         converged = false;
-        for (; sweep < max_sweeps; ++sweep) {
-            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
-            for (int r = 0; r < nblk - 1; ++r)
-                hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * nwaves), lds, h->stream, B,
-                                   (double*)nullptr, (int)N, b, nblk, r, tol, (const double*)params, rot, 1,
-                                   (int*)nullptr);
+        if (single && nblk == 2) {
+            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 16, h->stream));
+            hipLaunchKernelGGL(k_jacobi_round<false>, dim3(1), dim3(64 * nwaves), lds, h->stream, B, (double*)nullptr,
+                               (int)N, b, nblk, 0, tol, (const double*)params, rot, max_sweeps, sweeps_dev);
             TLSQ_HIP(h, hipGetLastError());
-            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            unsigned int nrot;
-            memcpy(&nrot, h->pinned, 4);
-            if (nrot == 0) {
-                ++sweep;
-                converged = true;
-                break;
+            int sd;
+            memcpy(&sd, h->pinned, 4);
+            sweep = sd;
+            converged = sd < max_sweeps;
+        } else {
+            for (; sweep < max_sweeps; ++sweep) {
+                TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+                for (int r = 0; r < nblk - 1; ++r)
+                    hipLaunchKernelGGL(k_jacobi_round<false>, dim3(nblk / 2), dim3(64 * nwaves), lds, h->stream, B,
+                                       (double*)nullptr, (int)N, b, nblk, r, tol, (const double*)params, rot, 1,
+                                       (int*)nullptr);
+                TLSQ_HIP(h, hipGetLastError());
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                unsigned int nrot;
+                memcpy(&nrot, h->pinned, 4);
+                if (nrot == 0) {
+                    ++sweep;
+                    converged = true;
+                    break;
+                }
             }
         }
     }
     if (sweeps_out) *sweeps_out = sweep;
     TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
+    if (!converged)
+        return set_err(h, TLSQ_ERR_NOCONV, "one-sided Jacobi did not converge in 40 sweeps (N=%lld)", (long long)N);
+    return TLSQ_OK;
+}
+
+// Eigen-decomposition of the PSD matrix G through its Cholesky factor (cholesky.hip): one-sided Jacobi on the
+// columns of L = chol(G + delta I) with no eigenvector accumulation; the eigenvectors of G are the normalised
+// columns of the rotated L and sig = column norms = sqrt(lambda + delta).
+int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev,
+                    double* delta_host, int64_t* sweeps_out) {
+    if (sweeps_out) *sweeps_out = 0;
+    if (N <= 0) return TLSQ_OK;
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* stats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 192);
+    TLSQ_TRY(cholesky_shifted(h, G, ldG, N, B, V /* scratch */, stats));
+    const int st = jacobi_factor_f64(h, B, N, V, sig_dev, (double)N * 2.220446049250313e-16, sweeps_out);
     TLSQ_HIP(h, hipMemcpyAsync(h->pinned, stats, 16, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    double st[2];
-    memcpy(st, h->pinned, 16);
-    if (delta_host) *delta_host = st[1];
-    if (!converged)
-        return set_err(h, TLSQ_ERR_NOCONV, "Jacobi (Cholesky route) did not converge in 40 sweeps (N=%lld)",
-                       (long long)N);
-    return TLSQ_OK;
+    double sv[2];
+    memcpy(sv, h->pinned, 16);
+    if (delta_host) *delta_host = sv[1];
+    return st;
 }
 
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,

@@ -54,6 +54,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -71,9 +72,10 @@ static bool rccl_load() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         dlclose(lib);
         return false;
     }
@@ -97,6 +99,16 @@ struct Comm {
 int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
     if (!h->comm) return TLSQ_OK;
     TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
+    return TLSQ_OK;
+}
+
+// the TSQR exchange: every rank's N x N triangular factor to every rank
+int comm_allgather(Handle* h, const double* send, double* recv, size_t count) {
+    if (!h->comm) {
+        TLSQ_HIP(h, hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, h->stream));
+        return TLSQ_OK;
+    }
+    TLSQ_NCCL(h, g_rccl.AllGather(send, recv, count, ncclDouble, h->comm->comm, h->stream));
     return TLSQ_OK;
 }
 

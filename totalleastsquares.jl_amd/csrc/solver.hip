@@ -150,6 +150,32 @@ int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double
     return eig_full(h, G, N, V_out, s, sweeps, false, WS_V, true);   // callers (tls!, SSA truncation) want every vector
 }
 
+// The accurate route (the fp64 default of the north star): Householder TSQR of the panel (tsqr.hip),
+// then one-sided Jacobi on R' (jacobi.hip).  Both steps are orthogonal transformations, so every singular value
+// carries an absolute error of a few eps * sigma_max like LAPACK's gesdd (src/robustPCA.jl:194) — the Gram route only
+// reaches eps * sigma_max^2 / sigma.  V in WS_V (all N right singular vectors), s = all N singular values.
+template <typename T>
+int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s, int64_t* sweeps) {
+    void *B, *V, *lam;
+    TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
+    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
+    TLSQ_TRY(tsqr_lt(h, Z, Prec<T>::f32, M, N, ld, (double*)B));
+    int64_t sw = 0;
+    TLSQ_TRY(jacobi_factor_f64(h, (double*)B, N, (double*)V, (double*)lam, 0.0, &sw));
+    if (sweeps) *sweeps += sw;
+    h->warm_n = 0;
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "  svd via R: N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
+    s.sigma.resize((size_t)N);
+    TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    s.ncols = N;
+    sort_desc(s);
+    *V_out = (double*)V;
+    return TLSQ_OK;
+}
+
 // The N x N operator the small solvers work on: either the explicit Gram matrix G = Z'Z (summed over the row
 // shards), or - large mode, where forming G would cost far more than the few products the subspace solver needs
 // (2 M N^2 flops against 4 M N p per product) - the panel itself: G X = Z'(Z X), two streaming passes over Z.
@@ -201,7 +227,7 @@ struct SubspaceState {
     uint64_t hook_seed = 0;
     int64_t fast = 0, full = 0, steps = 0;
     // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
-    enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4 };
+    enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4, FAIL_WINDOW = 5 };
     int fail = FAIL_NONE;
     bool skip_certificate = false;   // the caller certifies the count itself (late iterations, see svd_precise_fast)
     // deferred certificate: svd_subspace returns with *ok = true as soon as the Lanczos steps of the certificate are
@@ -212,6 +238,12 @@ struct SubspaceState {
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
+    // Uncertainty of an eigenvalue of the computed Gram matrix relative to lambda_max (rounding of G = Z'Z, Ritz
+    // residuals).  An eigenvalue within dlam = noise_rel * lambda_max of the threshold (1/mu)^2 cannot be counted
+    // reliably on this route (FAIL_WINDOW: the caller decides on the TSQR route), and the tail certificate has to
+    // clear the threshold by the same margin.  0: no window (large mode, where no other solver exists).
+    double noise_rel = 0.0;
+    double dlam = 0.0;     // noise_rel * lambda_max of the last call
 };
 
 // one stream-ordered upload of an index list and a weight list of the same length r into `aux`
@@ -473,6 +505,16 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         if (st.fail == SubspaceState::FAIL_NONE) st.fail = SubspaceState::FAIL_NOCONV;
         return TLSQ_OK;
     }
+    {   // count window: a Ritz value this close to the threshold cannot be trusted to fall on the right side
+        const double tau2 = inv_mu * inv_mu;
+        st.dlam = st.noise_rel * host[0];   // (sorted: host[0] is the largest Ritz value)
+        bool in_window = !(tau2 > 2.0 * st.dlam);
+        for (int64_t i = 0; i < p && !in_window; ++i) in_window = std::fabs(host[i] - tau2) <= st.dlam;
+        if (in_window) {
+            st.fail = SubspaceState::FAIL_WINDOW;
+            return TLSQ_OK;
+        }
+    }
     if (st.skip_certificate) {
         *V_out = (double*)X;
         *ok = true;
@@ -518,7 +560,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
     }
     if (lst < 0) return lst;
-    if (!(lmax * 1.5 < inv_mu * inv_mu)) {  // ambiguous: full solver decides (or a larger block)
+    if (!(lmax * 1.5 + st.dlam < inv_mu * inv_mu)) {  // ambiguous: the accurate route decides (or a larger block)
         st.fail = SubspaceState::FAIL_CERT;
         return TLSQ_OK;
     }
@@ -536,7 +578,7 @@ static int svd_subspace_certify(Handle* h, SubspaceState& st, double inv_mu, boo
     int steps = 0;
     const int lst = lanczos_finish(h, st.cert, &lmax, &steps);
     if (lst < 0) return lst;
-    if (!(lmax * 1.5 < inv_mu * inv_mu)) {
+    if (!(lmax * 1.5 + st.dlam < inv_mu * inv_mu)) {
         st.fail = SubspaceState::FAIL_CERT;
         return TLSQ_OK;
     }
@@ -645,117 +687,10 @@ static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s,
     return TLSQ_OK;
 }
 
-// ---- two-level ("precise") decomposition for late ALM iterations ------------------------------------
-// The plain Gram route resolves singular values only down to ~sqrt(N eps) sigma_max.  When the threshold
-// 1/mu approaches that level (after ~33 iterations; mu is capped at 1e7 mu_0, src/robustPCA.jl:183) the
-// spectrum is split:  level 1 = eigenpairs of G = Z'Z with sigma >= 1e-3 sigma_max (accurate in the plain
-// route);  level 2 = eigenpairs of the Gram matrix of the explicitly deflated panel
-//     Z_perp = Z - (Z V_B) V_B'          (computed in the working precision, written to `scratch`)
-// whose own noise floor is sqrt(N eps) * 1e-3 sigma_max ~ 1e-9 sigma_max — below the smallest threshold the
-// reference can reach (0.8e-7 ||D||_2).  Both levels use the full Jacobi solver.  On return Vc (WS_VC, N x
-// s.ncols) holds [V_B, tail vectors] sorted by singular value; s.ncols counts only what may matter (all of
-// level 1, and the level-2 pairs above `keep_above`).
-template <typename T>
-static int svd_two_level(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double keep_above,
-                         double** V_out, SmallSvd& s, int64_t* sweeps, PhaseTimer* pt) {
-    double* G = nullptr;
-    TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
-    if (pt) pt->mark();
-    double* V1 = nullptr;
-    SmallSvd s1;
-    TLSQ_TRY(eig_full(h, G, N, &V1, s1, sweeps, false, WS_V));
-    const double top = s1.sigma[s1.order[0]];
-    std::vector<int32_t> big;
-    for (int64_t i = 0; i < N; ++i)
-        if (s1.sigma[s1.order[i]] >= 1e-3 * top && s1.sigma[s1.order[i]] > 0.0) big.push_back(s1.order[i]);
-    const int64_t nb = (int64_t)big.size();
-    void* Vc;
-    TLSQ_TRY(ws_get(h, WS_VC, (size_t)N * N * 8, &Vc));
-    s.sigma.clear();
-    if (nb > 0) TLSQ_TRY(gather_cols(h, V1, N, big, (double*)Vc));
-    for (int64_t i = 0; i < nb; ++i) s.sigma.push_back(s1.sigma[big[i]]);
-    if (nb < N) {
-        // Z_perp = Z - (Z V_B) V_B'
-        const T* Zp = Z;
-        if (nb > 0) {
-            void* T1;
-            TLSQ_TRY(ws_get(h, WS_T, (size_t)M * nb * 8, &T1));
-            TLSQ_TRY(gemm_mixed(h, true, false, Vc, 0, N, Z, Prec<T>::f32, M, T1, 0, M, nb, M, N, false));
-            TLSQ_TRY(gemm_mixed(h, false, false, Vc, 0, N, T1, 0, M, scratch, Prec<T>::f32, M, N, M, nb, false));
-            TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
-            Zp = scratch;
-        }
-        double* G2 = nullptr;
-        TLSQ_TRY(gram_allreduce<T>(h, Zp, M, N, M, &G2));
-        double* V2 = nullptr;
-        SmallSvd s2;
-        TLSQ_TRY(eig_full(h, G2, N, &V2, s2, sweeps, false, WS_V2));
-        // level-2 pairs, largest first; the nb smallest ones are the deflated directions
-        std::vector<int32_t> tail;
-        const double top2 = s2.sigma[s2.order[0]];
-        const double res2 = std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * top2;
-        for (int64_t i = 0; i < N - nb; ++i) {
-            const double sg = s2.sigma[s2.order[i]];
-            if (sg >= keep_above && sg >= res2 && sg < 1e-3 * top * 1.01) tail.push_back(s2.order[i]);
-        }
-        if (!tail.empty()) {
-            TLSQ_TRY(gather_cols(h, V2, N, tail, (double*)Vc + (size_t)N * nb));
-            for (size_t i = 0; i < tail.size(); ++i) s.sigma.push_back(s2.sigma[tail[i]]);
-        }
-    }
-    s.ncols = (int64_t)s.sigma.size();
-    s.order.resize((size_t)s.ncols);
-    std::iota(s.order.begin(), s.order.end(), 0);   // already sorted: level 1 descending, then level 2 descending
-    *V_out = (double*)Vc;
-    return TLSQ_OK;
-}
-
-// Late iterations, cheap case.  Most problems that reach the "precise" regime (1/mu within ~5x of the resolution of
-// the plain Gram route) are clean: nothing of Z lies between the block of sigma >= 1/mu and rounding noise.  Then
-// two dense decompositions are not needed.  The carried block is refined on G as usual (its pairs are accurate),
-// but the COUNT is certified on the explicitly deflated panel Z_perp = Z - (Z V_svp) V_svp' (written to
-// `scratch`), whose Gram matrix resolves singular values down to ~1e-9 sigma_max: Lanczos must put
-// lambda_max(Z_perp' Z_perp) clearly below (1/mu)^2.  Anything else (no block, no convergence, a value near the
-// threshold outside the block) -> *ok = false and svd_two_level decides.
-template <typename T>
-static int svd_precise_fast(Handle* h, const T* Z, int64_t M, int64_t N, T* scratch, double inv_mu,
-                            SubspaceState& sub, const double* G, double** V_out, SmallSvd& s, int64_t* sweeps,
-                            bool* ok) {
-    *ok = false;
-    if (!sub.valid || sub.hook_rank > 0) return TLSQ_OK;
-    bool conv = false;
-    sub.skip_certificate = true;
-    GramOp op;
-    op.G = G;
-    const int st = svd_subspace(h, op, N, inv_mu, sub, V_out, s, sweeps, &conv);
-    sub.skip_certificate = false;
-    if (st < 0) return st;
-    if (!conv) return TLSQ_OK;
-    int64_t svp = 0;
-    for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
-    if (svp > s.ncols - 2) return TLSQ_OK;
-    const T* Zp = Z;
-    if (svp > 0) {
-        std::vector<int32_t> sel((size_t)svp);
-        std::vector<double> ones((size_t)svp, 1.0);
-        for (int64_t i = 0; i < svp; ++i) sel[i] = s.order[i];
-        const double *Tm, *Vs;
-        TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, *V_out, sel, ones, &Tm, &Vs));
-        TLSQ_TRY(rebuild_from_factors<T>(h, Tm, Vs, M, N, svp, scratch, M));
-        TLSQ_TRY(launch_diff<T>(h, Z, scratch, scratch, M * N));
-        Zp = scratch;
-    }
-    void* G2;
-    TLSQ_TRY(ws_get(h, WS_G2, (size_t)N * N * 8, &G2));
-    TLSQ_TRY(gram_any(h, Zp, Prec<T>::f32, M, N, M, (double*)G2, N));
-    TLSQ_TRY(comm_allreduce(h, (double*)G2, (size_t)N * N, ncclSum));
-    double lmax = 0.0;
-    int steps = 0;
-    const int lst = lanczos_lmax_f64(h, (const double*)G2, N, N, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
-    if (lst < 0) return lst;
-    if (!(lmax * 1.5 < inv_mu * inv_mu)) return TLSQ_OK;
-    *ok = true;
-    return TLSQ_OK;
+static double large_mode_noise(int64_t N, int64_t m_global) {
+    if (N > kFullEigMaxN) return 0.0;
+    const double eps = 2.220446049250313e-16;
+    return 16.0 * std::max((double)N, std::sqrt((double)m_global)) * eps + 2e-12;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -849,9 +784,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // of very late iterations is not available.
     const bool large = N > kFullEigMaxN;
     const bool use_subspace = large || (!hook_svd && !(force_full && force_full[0] == '1') && pmax >= 11 && N >= 24);
-    bool v_is_full = false, prev_full = false;
+    bool v_is_full = false;
     double sigma_top_prev = 0.0;
-    int64_t n_precise = 0;
+    int64_t n_rroute = 0;   // iterations whose SVD step was served by the TSQR route
+    // Relative uncertainty of an eigenvalue of the computed Gram matrix (rounding of Z'Z accumulated over M rows, the
+    // small solvers' own eps N lambda_max, Ritz residuals <= 2e-13 lambda_max per pair): see SubspaceState::noise_rel.
+    // Large mode has no other solver, so no window there.
+    const double noise_rel = large_mode_noise(N, ro.m_global);
     h->warm_n = 0;   // nothing from an earlier call is reused
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
@@ -879,12 +818,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (!have_next)
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
         pt.mark(have_next);
-        // late iterations: 1/mu close to the resolution of the plain Gram route -> two-level decomposition
-        const bool precise = !large && !hook_svd && sigma_top_prev > 0.0 &&
-                             inv_mu < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top_prev;
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
-        bool precise_fast = false;
         // Rank count, singular-value thresholding and the factors of A for the decomposition currently in (s, V).
         // Normally called once after the SVD step; with a deferred count certificate it is called right after the
         // subspace solver (the rebuild kernels queue up behind the certificate's Lanczos steps) and, should the
@@ -896,16 +831,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 pt.mark();
                 rebuild_marked = true;
             }
-            // Resolution of the Gram route: eigenvalues of G below ~8*N*eps*lambda_max are rounding noise, i.e.
-            // singular values below sigma_res = sqrt(8 N eps) * sigma_max cannot be told from zero.
-            // The reference's threshold 1/mu only drops that low after ~36 iterations (mu_bar = 1e7 mu_0); from
-            // there on unresolved values are treated as zero instead of being counted at random.
             sigma_top = s.ncols > 0 ? s.sigma[s.order[0]] : 0.0;
             sigma_top_prev = sigma_top;
-            const double sigma_res = precise ? 0.0 : std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
-            const double count_thr = std::max(inv_mu, sigma_res);
             svp = 0;                                                   // :198
-            for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= count_thr) ? 1 : 0;
+            for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
             sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
             std::vector<int32_t> sel((size_t)svp);
             std::vector<double> g((size_t)svp);
@@ -927,23 +856,18 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             rebuilt = true;
             return TLSQ_OK;
         };
-        if (precise && use_subspace && sub.valid) {
-            if (g_ready) G = (double*)h->ws[WS_G].p;
-            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
-            g_ready = false;
-            TLSQ_TRY(svd_precise_fast<T>(h, Z, M, N, R, inv_mu, sub, G, &V, s, &sweeps, &precise_fast));
-            if (precise_fast) {
-                pt.mark();
-                ++sub.fast;
-                ++n_precise;
-            }
-        }
-        if (precise && !precise_fast) {
-            TLSQ_TRY(svd_two_level<T>(h, Z, M, N, R, inv_mu, &V, s, &sweeps, &pt));
-            sub.valid = false;
-            ++sub.full;
-            ++n_precise;
-        } else if (!precise) {
+        // How the SVD step is served.  The fast route works on the Gram matrix (warm-started subspace iteration +
+        // count certificate); it is only believed when no eigenvalue lies within the Gram route's own uncertainty
+        // of the threshold (1/mu)^2.  Everything else — no warm block, no spectral gap, a value inside the window,
+        // a threshold at the noise level of G, tiny matrices — goes through the TSQR route (svd_via_r), whose
+        // singular values are as accurate as LAPACK's.  Large mode (N > 2048) and the randomized hook keep to the
+        // subspace solver.
+        const bool hook_now = hook_svd && k >= 2;
+        bool r_route = !large && !hook_now && (!use_subspace || hook_svd);
+        if (!r_route && !large && !hook_now && sigma_top_prev > 0.0 &&
+            !(inv_mu * inv_mu > 2.0 * noise_rel * sigma_top_prev * sigma_top_prev))
+            r_route = true;   // the threshold has reached the noise level of the Gram matrix
+        if (!r_route) {
         GramOp op = panel_op(Z);
         const bool gram_queued_earlier = g_ready || implicit_gram;
         if (!implicit_gram) {
@@ -954,14 +878,15 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         g_ready = false;
         pt.mark(gram_queued_earlier);
-        if (hook_svd && k >= 2) {
+        if (hook_now) {
             // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
             SubspaceState rs;
             rs.hook_rank = sv;
             rs.hook_seed = seed + (uint64_t)k;
             TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
-        } else if (use_subspace) {
+        } else {
+            sub.noise_rel = noise_rel;
             sub.defer_certificate = !no_cert_overlap;
             const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
             sub.defer_certificate = false;
@@ -979,13 +904,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 }
             }
         }
-        if (!fast_ok && use_subspace && !(hook_svd && k >= 2) && sub.fail != SubspaceState::FAIL_NONE) {
+        if (!fast_ok && !hook_now && sub.fail != SubspaceState::FAIL_NONE && sub.fail != SubspaceState::FAIL_WINDOW) {
             // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
-            // Large mode has nothing else; below it a few cheap attempts come before the dense solver when the
+            // Large mode has nothing else; below it a few cheap attempts come before the TSQR route when the
             // block was merely too small (rank above the cold block, rank jumps) - not when convergence stalled.
             const int max_attempts = large ? 10 : 3;
             for (int attempt = 0; !fast_ok && attempt < max_attempts; ++attempt) {
                 const int why = sub.fail;
+                if (why == SubspaceState::FAIL_WINDOW) break;
                 if (!large && why != SubspaceState::FAIL_SMALL && why != SubspaceState::FAIL_CERT) break;
                 const bool grow = why == SubspaceState::FAIL_SMALL || why == SubspaceState::FAIL_CERT ||
                                   why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
@@ -1012,18 +938,22 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                            "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
                            "(block of %lld columns, reason %d): rank too large for this release",
                            (long long)N, (long long)kFullEigMaxN, (long long)k, (long long)sub.p, sub.fail);
-        if (!fast_ok) {
-            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, prev_full));
-            if (hook_svd && k >= 2) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
-            ++sub.full;
+        if (fast_ok) ++sub.fast;
+        else r_route = true;
         } else {
-            ++sub.fast;
+            g_ready = false;
+            pt.mark(true);
         }
-        }   // !precise
-        v_is_full = !precise && !fast_ok && !(hook_svd && k >= 2) && !chol_route(N);
-        prev_full = !precise && !fast_ok;
+        if (r_route) {
+            TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V, s, &sweeps));
+            if (hook_now) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
+            rebuilt = false;
+            ++sub.full;
+            ++n_rroute;
+        }
+        v_is_full = r_route && !hook_now;
         if (!rebuilt) TLSQ_TRY(count_and_rebuild(!rebuild_marked));
-        if (use_subspace && (!precise || precise_fast)) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
 
         // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
@@ -1086,9 +1016,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
             // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
-            const bool precise_next = !large && !hook_svd && sigma_top > 0.0 &&
-                                      1.0 / mu_next < 5.0 * std::sqrt(8.0 * (double)N * 2.220446049250313e-16) * sigma_top;
-            if (!precise_next && !implicit_gram) {   // (the two-level decomposition forms its Gram matrices itself)
+            const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 &&
+                                !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
+            if (!r_next && !implicit_gram) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
                 TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
                 g_ready = true;
@@ -1192,7 +1122,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->eig_full = sub.full;
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
-        info->reserved = (int32_t)n_precise;   // iterations served by the two-level decomposition
+        info->reserved = (int32_t)n_rroute;   // iterations served by the TSQR route
         info->residual_stores_skipped = n_rskip;
     }
     if (sv_out) *sv_out = sv;
@@ -1237,10 +1167,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         return converged ? TLSQ_OK : TLSQ_MAXITER;
     }
     if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
-        // the last iteration used a subspace path: the caller wants the complete SVD of the last Z
-        double* G = nullptr;
-        TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
-        TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps, false, WS_V, true));
+        // the last iteration used a subspace path: the caller wants the complete SVD of the last Z (:194, :238) -
+        // through the TSQR route, so that the small singular values and their vectors are as accurate as LAPACK's
+        TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V, s, &sweeps));
         if (info) info->jacobi_sweeps = sweeps;
     }
     if (S_host && V)
@@ -1592,6 +1521,8 @@ template int rebuild_lowrank<double>(Handle*, const double*, int64_t, int64_t, i
 template int rpca_core<double>(Handle*, const double*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*,
                                double*, double*, double*, double*, double*, int64_t, int64_t*, tlsq_rpca_info*);
 template int svd_via_gram<float>(Handle*, const float*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*, PhaseTimer*);
+template int svd_via_r<double>(Handle*, const double*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*);
+template int svd_via_r<float>(Handle*, const float*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*);
 template int rebuild_lowrank<float>(Handle*, const float*, int64_t, int64_t, int64_t, const double*,
                                     const std::vector<int32_t>&, const std::vector<double>&, float*, int64_t);
 template int rpca_core<float>(Handle*, const float*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*, float*,
