@@ -168,9 +168,12 @@ class Engine:
     # -- rpca -------------------------------------------------------------------------------------
     def rpca(self, D, *, lam=None, maxrank=None, iters=1000, tol=None, rho=None, verbose=False,
              nonnegA=False, nonnegE=False, hankel=False, nukeA=True, svd=None, opnorm=None,
-             want_U=True, return_report=False, m_global=0, **kwargs):
+             want_U=True, want_s=True, cost_history=True, return_report=False, m_global=0, **kwargs):
         """A, E, s, sv = rpca(D; ...) — src/robustPCA.jl:156-239.  Unknown kwargs are swallowed like the
-        reference's `kwargs...` (:170).  `svd`/`opnorm` hooks: only the defaults run on the GPU."""
+        reference's `kwargs...` (:170).  `svd`/`opnorm` hooks: only the defaults run on the GPU.
+        want_U / want_s = False skip the left vectors / the whole returned SVD (s is None then: no extra
+        decomposition after the loop); cost_history=False lets the library settle only `cost < tol` per iteration
+        (what a plain, non-verbose Julia call observes)."""
         svd_mode, opn_mode, mvps = self._hook_modes(svd, opnorm)
         D = np.asarray(D)
         if np.iscomplexobj(D):
@@ -185,9 +188,9 @@ class Engine:
         d = min(max(m_global, M), N)
         A = np.empty((M, N), dtype=dt, order="F")
         E = np.empty((M, N), dtype=dt, order="F")
-        U = np.empty((M, d), dtype=dt, order="F") if want_U else None
-        S = np.empty(d, dtype=dt)
-        Vt = np.empty((d, N), dtype=dt, order="F")
+        U = np.empty((M, d), dtype=dt, order="F") if (want_U and want_s) else None
+        S = np.empty(d, dtype=dt) if want_s else None
+        Vt = np.empty((d, N), dtype=dt, order="F") if want_s else None
         cb = None
         if verbose:
             def _print(k, cost, svp, user):
@@ -196,19 +199,20 @@ class Engine:
         o = self.make_opts(lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, nonnegA=nonnegA,
                            nonnegE=nonnegE, hankel=hankel, nukeA=nukeA, m_global=m_global, on_iter=cb,
                            svd_mode=svd_mode, opnorm_mode=opn_mode, opnorm_mvps=mvps, seed=kwargs.get("seed", 0))
-        info, cost, svp = self._info(int(iters))
+        info, cost, svp = self._info(int(iters), cost_history)
         sv = C.c_int64(0)
         fn = self.lib.tlsq_rpca_f32 if dt == np.float32 else self.lib.tlsq_rpca_f64
         st = self._check(fn(
             self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
-            _ptr(U) if U is not None else None, M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
+            _ptr(U) if U is not None else None, M, _ptr(S) if want_s else None, _ptr(Vt) if want_s else None, d,
+            C.byref(sv), C.byref(info)))
         rep = RpcaReport(info, cost, svp)
         if verbose and rep.converged:
             print("converged")                                             # :229
         if st == L.TLSQ_MAXITER:                                           # :232
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: "
                           f"{tol if tol is not None else math.sqrt(np.finfo(dt).eps)}")
-        s = SVD(U, S, Vt)
+        s = SVD(U, S, Vt) if want_s else None
         if return_report:
             return A, E, s, int(sv.value), rep
         return A, E, s, int(sv.value)
