@@ -86,6 +86,7 @@ enum WsSlot {
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
     WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
+    WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
@@ -146,8 +147,11 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
 int gram_f64(Handle* h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
 // mixed-precision storage: operands / result may be fp32 in memory (x_f32 != 0), arithmetic is fp64 MFMA.
 // instantiated operand type pairs (A,B): (f64,f64), (f32,f32), (f64,f32); layouts (KC,KC), (KC,MN), (MN,MN).
+// skip (device, optional): a non-zero skip[0] turns the launches into no-ops.  normpart / normblocks (symmetric only):
+// the reduction also leaves *normblocks partial sums of ||C||_F^2 in normpart (at most 2048; add them in order).
 int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
-               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric);
+               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric,
+               const double* skip = nullptr, double* normpart = nullptr, int* normblocks = nullptr);
 // T (M x r, fp64) = Z (M x K, fp32 or fp64) * W (K x r), r <= 96: Z streamed once, MFMA fed from global memory
 int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
                int64_t M, int64_t K, int64_t r);
@@ -236,8 +240,12 @@ int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int
 template <typename TA>
 int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64_t ldx, double* Y, int64_t ldy,
                      int64_t R, int64_t K, int64_t p);
+// GD = scale * (G - Vs Vg')
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
-                   int64_t r);
+                   int64_t r, double scale = 1.0);
+// power certificate (subspace.hip, k_cert_decide)
+int launch_cert_decide(Handle* h, const double* part, int nblk, int level, double thresh, double* state, double* mailbox_dev,
+                       double seq);
 // complex.hip: ComplexF64 sweeps + realification (panels are interleaved re/im, n counts complex elements)
 int launch_cshrink(Handle* h, const double* D, const double* A, const double* Y, double* E, double* Z, int64_t n,
                    double inv_mu, double thr);

@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const TA* __restrict__ A, i
                                                      void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
                                                      int64_t Q, int64_t K, int64_t kchunk,
                                                      int64_t slab_stride, int nti, int ntj, int nsplit,
-                                                     int symmetric, int vec_ok) {
+                                                     int symmetric, int vec_ok, const double* __restrict__ skip) {
     __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
+    if (skip && skip[0] != 0.0) return;   // (conditional launches of the count certificate, see power_certificate)
     // Work items = (K split z, active tile t), z-major.  Blocks b and b+8 share an XCD (and its L2), so every
     // XCD gets a contiguous run of work items: neighbours share z (the same rows of the operands) and the
     // eight XCDs carry equal loads — also for symmetric launches, where only tiles with tj <= ti exist.
@@ -263,17 +264,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const TA* __restrict__ A, i
 
 // C[j + i*ldc] = sum_z slab[z][j + i*lds]   (fixed order -> deterministic);
 // symmetric: only tiles ti>=tj were computed, mirror into both triangles.  C may be fp32.
+// normpart (optional): normpart[block] = this block's share of ||C||_F^2 (mirrored entries counted twice), summed in
+// a fixed order - the caller adds the gridDim.x partials in order, so the norm is reproducible bit for bit
 __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ slab, int64_t lds_,
                                                      int64_t slab_stride, int nsplit,
                                                      void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
-                                                     int64_t Q, int symmetric) {
+                                                     int64_t Q, int symmetric, const double* __restrict__ skip,
+                                                     double* __restrict__ normpart) {
+    __shared__ double nred[4];
+    if (skip && skip[0] != 0.0) return;
     const int64_t total = P * Q;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double nacc = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t j = e % Q, i = e / Q;
         if (symmetric && (j / TJ) > (i / TI)) continue;
         double s = 0.0;
         for (int zz = 0; zz < nsplit; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
+        nacc += ((symmetric && (j / TJ) < (i / TI)) ? 2.0 : 1.0) * s * s;
         if (c_f32) {
             reinterpret_cast<float*>(C)[j + i * ldc] = (float)s;
             if (symmetric) reinterpret_cast<float*>(C)[i + j * ldc] = (float)s;
@@ -282,11 +290,19 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
             if (symmetric) reinterpret_cast<double*>(C)[i + j * ldc] = s;
         }
     }
+    if (normpart) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nacc += __shfl_xor(nacc, off, 64);
+        if ((threadIdx.x & 63) == 0) nred[threadIdx.x >> 6] = nacc;
+        __syncthreads();
+        if (threadIdx.x == 0) normpart[blockIdx.x] = (nred[0] + nred[1]) + (nred[2] + nred[3]);
+    }
 }
 
 static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda,
                        const void* B, int b_f32, int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P,
-                       int64_t Q, int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric) {
+                       int64_t Q, int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric,
+                       const double* skip = nullptr) {
     const int nti = (int)((P + TI - 1) / TI), ntj = (int)((Q + TJ - 1) / TJ);
     const int64_t ntiles = symmetric ? (int64_t)nti * (nti + 1) / 2 : (int64_t)nti * ntj;
     const int64_t nwork = ntiles * nsplit;
@@ -301,7 +317,7 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
 #define GO2(AK, BK, TA, TB)                                                                              \
     hipLaunchKernelGGL((k_gemm_f64<AK, BK, TA, TB>), grid, block, 0, h->stream, (const TA*)A, lda,       \
                        (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj, nsplit, \
-                       symmetric ? 1 : 0, vec_ok)
+                       symmetric ? 1 : 0, vec_ok, skip)
 #define GO(TA, TB)                                         \
     do {                                                   \
         if (A_KC && B_KC) GO2(true, true, TA, TB);         \
@@ -320,8 +336,10 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
 }
 
 int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda, const void* B, int b_f32,
-               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric) {
+               int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P, int64_t Q, int64_t K, bool symmetric,
+               const double* skip, double* normpart, int* normblocks) {
     if (P <= 0 || Q <= 0) return TLSQ_OK;
+    if (normpart && !symmetric) return set_err(h, TLSQ_ERR_ARG, "gemm: the norm by-product needs the symmetric (slab) path");
     const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
     const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
     // split K so that the launch has ~256 workgroups (one per CU), each with >= 4 K stages
@@ -354,17 +372,18 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
     if (kchunk < TK) kchunk = TK;
     nsplit = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     if (nsplit == 1 && !symmetric)
-        return launch_gemm(h, A_KC, B_KC, A, a_f32, lda, B, b_f32, ldb, C, c_f32, ldc, P, Q, K, 1, kchunk, 0, false);
+        return launch_gemm(h, A_KC, B_KC, A, a_f32, lda, B, b_f32, ldb, C, c_f32, ldc, P, Q, K, 1, kchunk, 0, false, skip);
     // slabs (always fp64): nsplit x (P rows of Q contiguous)
     const int64_t slab_stride = P * Q;
     void* slab;
     TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * sizeof(double), &slab));
     TLSQ_TRY(launch_gemm(h, A_KC, B_KC, A, a_f32, lda, B, b_f32, ldb, slab, 0, Q, P, Q, K, (int)nsplit, kchunk,
-                         slab_stride, symmetric));
+                         slab_stride, symmetric, skip));
     int64_t g = (P * Q + 255) / 256;
     if (g > 2048) g = 2048;
+    if (normblocks) *normblocks = (int)g;
     hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, Q,
-                       slab_stride, (int)nsplit, C, c_f32, ldc, P, Q, symmetric ? 1 : 0);
+                       slab_stride, (int)nsplit, C, c_f32, ldc, P, Q, symmetric ? 1 : 0, skip, normpart);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

@@ -278,7 +278,7 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.lds));
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
-    r.chunk = (accept_below > 0.0 || stop_above > 0.0) ? 5 : 16;
+    r.chunk = stop_above > 0.0 ? 5 : (accept_below > 0.0 ? 11 : 16);
     static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
     r.mail_ok = h->mailbox && !no_mailbox && (size_t)(16 + 2 * r.cap) * 8 <= h->mailbox_bytes;
     TLSQ_TRY(lz_launch_chunk(h, r));
@@ -354,9 +354,11 @@ int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used) {
             }
             // early accept for "is lambda_max clearly below X?" questions: the Ritz value is a lower bound that is
             // already within ~15 % of lambda_max after 16 steps even on flat (noise-like) spectra
+            // (Kuczynski-Wozniakowski: with a random start vector the Ritz value misses lambda_max by a factor f after m
+            // steps with probability <= 1.65 sqrt(N) exp(-sqrt(1 - 1/f) (2m - 1)): 1e-9 for f = 2.5, m = 16 and 1e-6
+            // for f = 6, m = 10 at N = 512; anything earlier is not accepted)
             if (r.accept_below > 0.0 &&
-                ((m >= 16 && 2.5 * theta < r.accept_below) || (m >= 8 && 5.0 * theta < r.accept_below) ||
-                 (m >= 4 && 10.0 * theta < r.accept_below))) {
+                ((m >= 16 && 2.5 * theta < r.accept_below) || (m >= 10 && 6.0 * theta < r.accept_below))) {
                 *lmax = theta > 0.0 ? theta : 0.0;
                 return TLSQ_OK;
             }
@@ -474,7 +476,7 @@ int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, 
     std::vector<double> hab((size_t)2 * cap);
     int done = 0;
     double theta = 0.0;
-    int chunk = (accept_below > 0.0 || stop_above > 0.0) ? 4 : 16;
+    int chunk = stop_above > 0.0 ? 4 : (accept_below > 0.0 ? 10 : 16);
     while (done < max_steps) {
         const int n = std::min(chunk, max_steps - done);
         for (int k = 0; k < n; ++k, ++done) {
@@ -512,8 +514,7 @@ int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, 
             *lmax = theta;
             return TLSQ_OK;
         }
-        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 8 && 5.0 * theta < accept_below) ||
-                                   (m >= 4 && 10.0 * theta < accept_below))) {
+        if (accept_below > 0.0 && ((m >= 16 && 2.5 * theta < accept_below) || (m >= 10 && 6.0 * theta < accept_below))) {
             *lmax = theta > 0.0 ? theta : 0.0;
             return TLSQ_OK;
         }

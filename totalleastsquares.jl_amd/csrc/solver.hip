@@ -244,7 +244,96 @@ struct SubspaceState {
     // clear the threshold by the same margin.  0: no window (large mode, where no other solver exists).
     double noise_rel = 0.0;
     double dlam = 0.0;     // noise_rel * lambda_max of the last call
+    // count certificate in flight (scaled by 1 / tau^2): deflated matrix, pass mark, which bound was queued
+    const double* cert_GD = nullptr;
+    int64_t cert_N = 0;
+    double cert_margin = 0.0, cert_seq = 0.0;
+    bool cert_power = false;
+    int64_t n_power = 0, n_power_l2 = 0, n_lanczos_cert = 0;   // statistics: served by S^2 / S^4 / Lanczos
 };
+
+// ---- count certificate: lambda_max(GD) < margin for the deflated, scaled Gram matrix GD ---------------------------
+// Matrix powers first (k_cert_decide in subspace.hip: ||GD^2||_F^(1/2), then ||GD^4||_F^(1/4) - rigorous upper bounds,
+// two MFMA contractions, one read-back); only when both are too coarse (an eigenvalue within ~1.5x of the mark, or a
+// very flat tail) does a Lanczos run decide, with the usual 1.5x safety factor on its (lower-bound) Ritz value.
+static int power_cert_begin(Handle* h, SubspaceState& st) {
+    const int64_t N = st.cert_N;
+    void *P1, *P2, *part, *scal;
+    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
+    TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
+    TLSQ_TRY(ws_get(h, WS_CPART, 2 * 2048 * 8, &part));
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* state = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 1600);
+    double* part1 = (double*)part;
+    double* part2 = part1 + 2048;
+    int nb1 = 0, nb2 = 0;
+    const double m2 = st.cert_margin * st.cert_margin;
+    TLSQ_TRY(gemm_mixed(h, true, true, st.cert_GD, 0, N, st.cert_GD, 0, N, P1, 0, N, N, N, N, true, nullptr, part1, &nb1));
+    TLSQ_TRY(launch_cert_decide(h, part1, nb1, 1, m2 * m2, state, nullptr, 0.0));
+    TLSQ_TRY(gemm_mixed(h, true, true, P1, 0, N, P1, 0, N, P2, 0, N, N, N, N, true, state, part2, &nb2));
+    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    const bool mail = h->mailbox && h->mailbox_bytes >= 1024 && !no_mailbox;
+    st.cert_seq = mail ? (h->mail_seq += 1.0) : 0.0;
+    TLSQ_TRY(launch_cert_decide(h, part2, nb2, 2, 0.0, state, mail ? h->mailbox_dev : nullptr, st.cert_seq));
+    return TLSQ_OK;
+}
+
+static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
+    *pass = false;
+    double lmax = 0.0;
+    int steps = 0;
+    if (!st.cert_power) {
+        const int lst = lanczos_finish(h, st.cert, &lmax, &steps);
+        if (lst < 0) return lst;
+        ++st.n_lanczos_cert;
+        *pass = lmax * 1.5 < st.cert_margin;
+        return TLSQ_OK;
+    }
+    double ab[2] = {0.0, -1.0};
+    bool got = false;
+    if (st.cert_seq != 0.0) {
+        volatile double* mb = h->mailbox;
+        const double t_poll = now_ms();
+        while (mb[0] != st.cert_seq && now_ms() - t_poll < 2000.0) {
+        }
+        got = mb[0] == st.cert_seq;
+        if (got) {
+            ab[0] = mb[8];
+            ab[1] = mb[9];
+        } else {
+            h->mailbox_bytes = 0;   // never seen in practice; classic read-back from now on
+        }
+    }
+    if (!got) {
+        void* scal;
+        TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, reinterpret_cast<char*>(scal) + 1608, 16, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        memcpy(ab, h->pinned, 16);
+    }
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    const double b1 = ab[0] >= 0.0 ? std::pow(ab[0], 0.25) : std::numeric_limits<double>::infinity();
+    const double b2 = ab[1] >= 0.0 ? std::pow(ab[1], 0.125) : std::numeric_limits<double>::infinity();
+    if (dbg) fprintf(stderr, "  power certificate: bound1=%.4f bound2=%.4f margin=%.6f\n", b1, b2, st.cert_margin);
+    if (std::isfinite(b1) && b1 < st.cert_margin) {
+        ++st.n_power;
+        *pass = true;
+        return TLSQ_OK;
+    }
+    if (std::isfinite(b2) && b2 < st.cert_margin) {
+        ++st.n_power_l2;
+        *pass = true;
+        return TLSQ_OK;
+    }
+    if (!std::isfinite(ab[0])) return TLSQ_OK;   // NaN / inf in the deflated matrix: not certified
+    // the power bounds are up to rank^(1/8) above lambda_max: a Lanczos run has the last word
+    const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
+    if (lst < 0) return lst;
+    ++st.n_lanczos_cert;
+    *pass = lmax * 1.5 < st.cert_margin;
+    return TLSQ_OK;
+}
+
 
 // one stream-ordered upload of an index list and a weight list of the same length r into `aux`
 // (layout: int32 sel[r], padding to 8 bytes, double w[r]); returns the two device pointers
@@ -533,23 +622,33 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         }
         TLSQ_TRY(gather_scale_host(h, (const double*)X, N, sel, th, aux, (double*)Vg, (double*)Vs));
     }
-    double lmax = 0.0;
-    int steps = 0;
-    int lst;
+    const double tau2 = inv_mu * inv_mu;
+    // everything below is scaled by 1 / tau^2: the question is lambda_max(GD) < margin = 1 - dlam / tau^2
+    st.cert_margin = (1.0 - st.dlam / tau2) * (1.0 - 1e-9);
     if (!op.implicit()) {
         TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
-        if (svp > 0) TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp));
-        else TLSQ_HIP(h, hipMemcpyAsync(GD, op.G, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-        TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, inv_mu * inv_mu, 0.0));
+        TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
+        st.cert_GD = (const double*)GD;
+        st.cert_N = N;
+        static const bool no_power = [] { const char* e = getenv("TLSQ_NO_POWER_CERT"); return e && e[0] == '1'; }();
+        // the two dense squarings cost N^3 flops against ~16 N^2 loads for a Lanczos run: matrix powers up to N = 1024
+        st.cert_power = N <= 1024 && !no_power;
+        if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
+        else TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, st.cert_margin, 0.0));
         if (st.defer_certificate) {
             st.cert_pending = true;
             *V_out = (double*)X;
             *ok = true;   // tentatively: svd_subspace_certify has the last word
             return TLSQ_OK;
         }
-        lst = lanczos_finish(h, st.cert, &lmax, &steps);
+        bool pass = false;
+        TLSQ_TRY(cert_finish(h, st, &pass));
+        if (!pass) {
+            st.fail = SubspaceState::FAIL_CERT;   // ambiguous: the accurate route decides (or a larger block)
+            return TLSQ_OK;
+        }
     } else {
-        // the deflated operator as a product: w = G q - Vs (Vg' q)
+        // the deflated operator as a product: w = (G q - Vs (Vg' q)); Lanczos bound, unscaled
         void* cv;
         TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(p * p, svp) * 8, &cv));
         const LzApply apply = [&](const double* q, double* w) -> int {
@@ -557,28 +656,29 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             if (svp > 0) TLSQ_TRY(launch_deflate_vec(h, (const double*)Vs, (const double*)Vg, svp, q, (double*)cv, w, N));
             return TLSQ_OK;
         };
-        lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, inv_mu * inv_mu);
-    }
-    if (lst < 0) return lst;
-    if (!(lmax * 1.5 + st.dlam < inv_mu * inv_mu)) {  // ambiguous: the accurate route decides (or a larger block)
-        st.fail = SubspaceState::FAIL_CERT;
-        return TLSQ_OK;
+        double lmax = 0.0;
+        int steps = 0;
+        const int lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, tau2);
+        if (lst < 0) return lst;
+        if (!(lmax * 1.5 + st.dlam < tau2)) {
+            st.fail = SubspaceState::FAIL_CERT;
+            return TLSQ_OK;
+        }
     }
     *V_out = (double*)X;
     *ok = true;
     return TLSQ_OK;
 }
 
-// Second half of a deferred count certificate (SubspaceState::defer_certificate): waits for the read-back of the
-// Lanczos coefficients only - whatever the caller queued behind them keeps running.
+// Second half of a deferred count certificate (SubspaceState::defer_certificate): waits for the certificate's numbers
+// only - whatever the caller queued behind them keeps running.
 static int svd_subspace_certify(Handle* h, SubspaceState& st, double inv_mu, bool* ok) {
+    (void)inv_mu;
     *ok = false;
     st.cert_pending = false;
-    double lmax = 0.0;
-    int steps = 0;
-    const int lst = lanczos_finish(h, st.cert, &lmax, &steps);
-    if (lst < 0) return lst;
-    if (!(lmax * 1.5 + st.dlam < inv_mu * inv_mu)) {
+    bool pass = false;
+    TLSQ_TRY(cert_finish(h, st, &pass));
+    if (!pass) {
         st.fail = SubspaceState::FAIL_CERT;
         return TLSQ_OK;
     }

@@ -408,17 +408,61 @@ __global__ __launch_bounds__(SK_WAVES * 64) void k_skinny_mm(const TA* __restric
     }
 }
 
-// GD = G - Vs * Vg'  (N x N, rank-r deflation for the count certificate; Vs, Vg: N x r, ld N)
+// GD = scale * (G - Vs * Vg')  (N x N, rank-r deflation for the count certificate; Vs, Vg: N x r, ld N)
 __global__ __launch_bounds__(256) void k_deflate(const double* __restrict__ G, int64_t ldG,
                                                  const double* __restrict__ Vs, const double* __restrict__ Vg,
-                                                 double* __restrict__ GD, int N, int r) {
+                                                 double* __restrict__ GD, int N, int r, double scale) {
     const int64_t total = (int64_t)N * N;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e % N), j = (int)(e / N);
         double sv = G[i + (int64_t)j * ldG];
         for (int k = 0; k < r; ++k) sv -= Vs[i + (size_t)k * N] * Vg[j + (size_t)k * N];
-        GD[e] = sv;
+        GD[e] = sv * scale;
     }
+}
+
+// Count certificate by matrix powers: for a symmetric S,  lambda_max(S) <= ||S^(2^k)||_F^(1/2^k)  (the Frobenius norm
+// of a power bounds its largest eigenvalue; the bound tightens to rank^(1/2^(k+1)) lambda_max).  S^2 and S^4 are plain
+// dense contractions (MFMA), so the certificate is deterministic and rigorous - a Lanczos Ritz value is only a lower
+// bound of lambda_max.  This kernel adds the partial sums of ||S^(2^level)||_F^2 left by the slab reduction, in order:
+//   level 1: state[1] = ||S^2||_F^2;  state[0] = 1 when that already proves lambda_max < margin (the level-2 launches
+//            then return at once), 0 otherwise
+//   level 2: state[2] = ||S^4||_F^2 (or -1 when skipped); both numbers go to the host-visible mailbox
+__global__ __launch_bounds__(256) void k_cert_decide(const double* __restrict__ part, int nblk, int level, double thresh,
+                                                     double* __restrict__ state, double* mailbox, double seq) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const bool skipped = level == 2 && state[0] != 0.0;
+    double v = 0.0;
+    if (!skipped)
+        for (int i = tid; i < nblk; i += 256) v += part[i];
+    v = ss_wsum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (level == 1) {
+            state[1] = tot;
+            state[2] = -1.0;
+            state[0] = (tot < thresh) ? 1.0 : 0.0;
+        } else {
+            if (!skipped) state[2] = tot;
+            if (mailbox) {
+                volatile double* mb = mailbox;
+                mb[8] = state[1];
+                mb[9] = skipped ? -1.0 : tot;
+                __threadfence_system();
+                mb[0] = seq;
+            }
+        }
+    }
+}
+
+int launch_cert_decide(Handle* h, const double* part, int nblk, int level, double thresh, double* state, double* mailbox_dev,
+                       double seq) {
+    hipLaunchKernelGGL(k_cert_decide, dim3(1), dim3(256), 0, h->stream, part, nblk, level, thresh, state, mailbox_dev, seq);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
@@ -537,10 +581,76 @@ template int launch_skinny_mm<double>(Handle*, const double*, int64_t, const dou
 template int launch_skinny_mm<float>(Handle*, const float*, int64_t, const double*, int64_t, double*, int64_t, int64_t,
                                      int64_t, int64_t);
 
+// Y (N x p, ld N) = G X for the SYMMETRIC N x N Gram matrix (ld ldG) and a narrow panel X (N x p, ld N): the product
+// of the subspace iteration, a few MFLOP that sit in L2 - latency is everything.  One workgroup per 16 x 16 output
+// tile; its four waves split the inner dimension in chunks of 128 and feed v_mfma_f64_16x16x4_f64 straight from
+// global memory: the A fragment is G[i, k] = G[k, i] (16 consecutive rows of column k: one 128-byte line), and the
+// inner index is permuted (k = chunk + 32 fk + u for k-step u) so that every lane reads 32 CONSECUTIVE entries of its
+// column of X with 16-byte loads.  All loads of a chunk are issued before the first MFMA; the four partial tiles meet
+// in LDS and are added in a fixed order.
+typedef double sm_d4 __attribute__((ext_vector_type(4)));
+typedef double sm_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ G, int64_t ldG, const double* __restrict__ X,
+                                                   double* __restrict__ Y, int N, int p) {
+    __shared__ double sR[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int gi = i0 + fr, gj = j0 + fr;
+    const bool iok = gi < N, jok = gj < p;
+    const double* Gr = G + (iok ? gi : 0);
+    const double* Xc = X + (size_t)(jok ? gj : 0) * N;
+    sm_d4 acc = sm_d4{0.0, 0.0, 0.0, 0.0};
+    const bool vec = (N % 2 == 0);
+    for (int c0 = w * 128; c0 < N; c0 += 512) {
+        const int kb = c0 + fk * 32;
+        double a[32], b[32];
+        if (kb + 32 <= N) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a[u] = iok ? Gr[(int64_t)(kb + u) * ldG] : 0.0;
+            if (vec) {
+#pragma unroll
+                for (int u = 0; u < 32; u += 2) {
+                    const sm_d2 v = jok ? *reinterpret_cast<const sm_d2*>(Xc + kb + u) : sm_d2{0.0, 0.0};
+                    b[u] = v[0];
+                    b[u + 1] = v[1];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) b[u] = jok ? Xc[kb + u] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const bool kok = kb + u < N;
+                a[u] = (iok && kok) ? Gr[(int64_t)(kb + u) * ldG] : 0.0;
+                b[u] = (jok && kok) ? Xc[kb + u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q];
+    __syncthreads();
+    // lane holds column j = lane & 15, rows (lane >> 4) + 4 q of the tile
+    const int q = tid >> 6, l = tid & 63;
+    const double sum = ((sR[q * 64 + l] + sR[256 + q * 64 + l]) + sR[512 + q * 64 + l]) + sR[768 + q * 64 + l];
+    const int row = i0 + (l >> 4) + 4 * q, col = j0 + (l & 15);
+    if (row < N && col < p) Y[row + (size_t)col * N] = sum;
+}
+
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p) {
+    if (p <= 0) return TLSQ_OK;
+    static const bool no_mfma = [] { const char* e = getenv("TLSQ_NO_SYMM_MFMA"); return e && e[0] == '1'; }();
+    if (!no_mfma && (reinterpret_cast<uintptr_t>(X) % 16) == 0) {
+        hipLaunchKernelGGL(k_symm_mfma, dim3((unsigned)((N + 15) / 16), (unsigned)((p + 15) / 16)), dim3(256), 0, h->stream, G,
+                           ldG, X, Y, (int)N, (int)p);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
     // symmetric G: column c of G doubles as row c, so the generic kernel's coalesced A[r, c] reads apply as is.
     // 8 columns per workgroup keeps the grid wide for these latency-bound N x N products.
-    if (p <= 0) return TLSQ_OK;
     if (N >= 1024 && p > 8)   // G no longer sits in L2: re-reading it per 8 columns costs more than the narrower grid
         return launch_skinny_mm<double>(h, G, ldG, X, N, Y, N, N, N, p);
     hipLaunchKernelGGL((k_skinny_mm<double, 8>), dim3((unsigned)((N + 63) / 64), (unsigned)((p + 7) / 8)),
@@ -550,10 +660,10 @@ int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X,
 }
 
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
-                   int64_t r) {
+                   int64_t r, double scale) {
     int64_t g = (N * N + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_deflate, dim3((int)g), dim3(256), 0, h->stream, G, ldG, Vs, Vg, GD, (int)N, (int)r);
+    hipLaunchKernelGGL(k_deflate, dim3((int)g), dim3(256), 0, h->stream, G, ldG, Vs, Vg, GD, (int)N, (int)r, scale);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
