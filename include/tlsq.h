@@ -14,9 +14,10 @@
  *  - Every entry point returns an int status: 0 OK, >0 non-fatal (TLSQ_MAXITER = the reference's
  *    `@warn "Maximum number of iterations reached"`, src/robustPCA.jl:232), <0 fatal.  No C++
  *    exception or exit() crosses the ABI.  tlsq_last_error(h) gives the text of the last failure.
- *  - A handle is bound to ONE GPU and is used by one host thread at a time.  All calls block until
- *    the device work has completed.  Multi-GPU = one process (or one handle) per GPU, row-sharded,
- *    joined by tlsq_comm_init (RCCL over xGMI): the only exchanged data are N x N Gram matrices.
+ *  - A handle is used by one host thread at a time.  All calls block until the device work has completed.
+ *    Multi-GPU, row-sharded, two ways: tlsq_create_multi (one process, one handle, host matrices - the drop-in for
+ *    the Julia package), or one handle per GPU / process joined by tlsq_comm_init for device-resident shards.  The
+ *    only exchanged data are N x N matrices (Gram all-reduce, TSQR factor all-gather) over RCCL / xGMI.
  *  - There is NO CPU fallback: without a GPU (or for complex element types) calls fail with
  *    TLSQ_ERR_HIP / TLSQ_ERR_UNSUPPORTED.
  */
@@ -98,6 +99,16 @@ const char* tlsq_version(void);
 void        tlsq_rpca_opts_default(tlsq_rpca_opts* o);
 
 int  tlsq_create(int device_id, tlsq_handle* out);
+/* Single-process multi-GPU handle: one host process (e.g. a Julia session) drives `ngpus` GPUs of
+ * the node.  device_ids == NULL means 0 .. ngpus-1.  The library creates one stream + workspace per GPU and one RCCL
+ * communicator over them (ncclCommInitAll), and serves tlsq_rpca_f64/_f32 and tlsq_lowrankfilter_f64 on HOST matrices
+ * by scattering contiguous row blocks (strided 2-D copies straight from the caller's column-major arrays), running
+ * one worker thread per GPU, and gathering A, E (U) back; S, Vt, sv, the report and the on_iter hook come from rank
+ * 0 on the calling thread - worker threads never call back into the host language.  Every other entry point (and
+ * problems that do not shard: wide matrices, tiny row counts) runs on the first GPU alone.  ngpus = 1 is valid
+ * (same code path, one-rank communicator). */
+int  tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out);
+int  tlsq_ngpus(tlsq_handle h);   /* GPUs behind the handle (1 for tlsq_create) */
 int  tlsq_destroy(tlsq_handle h);
 const char* tlsq_last_error(tlsq_handle h);
 /* hipStream_t the handle launches on (as void*), so a caller can time it with HIP events */

@@ -56,7 +56,7 @@ class GaInfo(C.Structure):
 
 # every symbol include/tlsq.h declares (tests check that the .so exports all of them)
 EXPORTS = [
-    "tlsq_version", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_destroy", "tlsq_last_error",
+    "tlsq_version", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_create_multi", "tlsq_ngpus", "tlsq_destroy", "tlsq_last_error",
     "tlsq_stream", "tlsq_synchronize", "tlsq_comm_unique_id", "tlsq_comm_init", "tlsq_comm_destroy",
     "tlsq_rpca_f64", "tlsq_rpca_f32",
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
@@ -89,6 +89,8 @@ def load():
     lib.tlsq_rpca_opts_default.argtypes = [P(RpcaOpts)]
     lib.tlsq_rpca_opts_default.restype = None
     lib.tlsq_create.argtypes = [i32, P(vp)]
+    lib.tlsq_create_multi.argtypes = [i32, P(i32), P(vp)]
+    lib.tlsq_ngpus.argtypes = [vp]
     lib.tlsq_destroy.argtypes = [vp]
     lib.tlsq_last_error.argtypes = [vp]
     lib.tlsq_last_error.restype = C.c_char_p

@@ -103,6 +103,48 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     if (lag <= 0) lag = 1;
     if (!(2 * n <= Nx)) return set_err(h, TLSQ_ERR_ARG, "L has to be less than N/2 = %g", Nx / 2.0);
     if (!(lag <= n)) return set_err(h, TLSQ_ERR_ARG, "lag must be <= L");
+    if (is_multi_call(h)) {
+        // single-process multi-GPU group: every rank receives the whole series (host memory) and owns a block of the
+        // Hankel rows; ranks > 0 write their (identical) filtered series to scratch.  What the sharded form does not
+        // cover (fp32, the hankel option, plain SSA truncation, short series) runs on the first GPU alone.
+        const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
+        if (dev_mem) return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: a multi-GPU handle takes host vectors");
+        const int64_t Kall = (Nx - n) / lag + 1;
+        if (std::is_same<T, double>::value && !(opts && opts->hankel) && sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
+            const int nr = h->multi_n;
+            std::vector<std::vector<T>> scratch((size_t)nr);
+            std::vector<tlsq_rpca_info> ri((size_t)nr);
+            std::vector<tlsq_rpca_opts> ro((size_t)nr);
+            std::vector<std::vector<double>> chv((size_t)nr);
+            std::vector<std::vector<int64_t>> shv((size_t)nr);
+            for (int r = 0; r < nr; ++r) {
+                if (opts) ro[(size_t)r] = *opts; else tlsq_rpca_opts_default(&ro[(size_t)r]);
+                ro[(size_t)r].memory = TLSQ_MEM_HOST;
+                memset(&ri[(size_t)r], 0, sizeof(tlsq_rpca_info));
+                if (r == 0) {
+                    if (info) ri[0] = *info;
+                    continue;
+                }
+                scratch[(size_t)r].resize((size_t)Nx * Dch);
+                if (ro[(size_t)r].on_iter) ro[(size_t)r].on_iter = [](int64_t, double, int64_t, void*) {};
+                if (info && info->cost_hist) {
+                    chv[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
+                    ri[(size_t)r].cost_hist = chv[(size_t)r].data();
+                }
+                if (info && info->svp_hist) {
+                    shv[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
+                    ri[(size_t)r].svp_hist = shv[(size_t)r].data();
+                }
+                ri[(size_t)r].hist_capacity = info ? info->hist_capacity : 0;
+            }
+            const int st = multi_run(h, [&](Handle* hr, int r, int) -> int {
+                return lowrankfilter_impl<T>(static_cast<tlsq_handle>(hr), y, Nx, Dch, ldy, n, lag, sv, &ro[(size_t)r],
+                                             r == 0 ? yf : scratch[(size_t)r].data(), r == 0 ? ldyf : Nx, &ri[(size_t)r]);
+            });
+            if (info) *info = ri[0];
+            return st;
+        }
+    }
     TLSQ_HIP(h, hipSetDevice(h->device));
     if (info) {
         double* ch = info->cost_hist;

@@ -46,6 +46,13 @@ struct Handle {
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
+    // single-process multi-GPU group (tlsq_create_multi): the caller holds rank 0, subs[r - 1] is rank r.  multi_comm
+    // is this rank's communicator of the group; it is attached as `comm` only while a group call runs (in_multi), so
+    // that every other entry point uses the handle as a plain single-GPU one.
+    std::vector<Handle*> subs;
+    Comm* multi_comm = nullptr;
+    int multi_n = 1, multi_rank = 0;
+    bool in_multi = false;
     // warm start of the full Jacobi solver: WS_V holds the eigenvectors of the previous full decomposition
     int64_t warm_n = 0;      // its size (0 = nothing to reuse)
     int warm_uses = 0;       // consecutive warm starts (reset to a cold start now and then: drift control)

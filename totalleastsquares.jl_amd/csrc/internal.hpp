@@ -22,6 +22,12 @@ int comm_allgather(Handle* h, const double* send, double* recv, size_t count);
 int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
            hipMemcpyKind kind);
 double now_ms();
+// Single-process multi-GPU group: runs fn(rank handle, rank, nranks) on every GPU of the group concurrently - rank 0 on
+// the calling thread, the others on worker threads that never call back into the host language - with each rank's
+// communicator attached for the duration.  Returns the first fatal status (its message is copied to h), else the
+// largest non-fatal one.
+int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn);
+inline bool is_multi_call(const Handle* h) { return h->multi_comm != nullptr && !h->in_multi; }
 // stream-ordered upload of a small host array through the pinned ring (src may be reused at once)
 int upload_async(Handle* h, void* dst, const void* src, size_t bytes);
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "internal.hpp"
 
@@ -52,6 +53,7 @@ struct RcclApi {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +73,7 @@ static bool rccl_load() {
     if (!lib) return false;
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(lib, "ncclCommInitAll");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
@@ -137,6 +140,45 @@ int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int6
                                      (size_t)cols, kind, h->stream));
     }
     return TLSQ_OK;
+}
+
+int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn) {
+    const int n = h->multi_n;
+    std::vector<Handle*> hs((size_t)n);
+    hs[0] = h;
+    for (int r = 1; r < n; ++r) hs[(size_t)r] = h->subs[(size_t)r - 1];
+    std::vector<int> st((size_t)n, TLSQ_OK);
+    auto body = [&](int r) {
+        Handle* hr = hs[(size_t)r];
+        if (hipSetDevice(hr->device) != hipSuccess) {
+            st[(size_t)r] = set_err(hr, TLSQ_ERR_HIP, "hipSetDevice(%d) failed", hr->device);
+            return;
+        }
+        hr->comm = hr->multi_comm;
+        hr->nranks = n;
+        hr->rank = r;
+        hr->in_multi = true;
+        st[(size_t)r] = fn(hr, r, n);
+        (void)hipStreamSynchronize(hr->stream);
+        hr->in_multi = false;
+        hr->comm = nullptr;
+        hr->nranks = 1;
+        hr->rank = 0;
+    };
+    std::vector<std::thread> workers;
+    for (int r = 1; r < n; ++r) workers.emplace_back(body, r);
+    body(0);
+    for (auto& t : workers) t.join();
+    (void)hipSetDevice(h->device);
+    int worst = TLSQ_OK;
+    for (int r = 0; r < n; ++r) {
+        if (st[(size_t)r] < 0) {
+            if (r > 0) h->err = "rank " + std::to_string(r) + ": " + hs[(size_t)r]->err;
+            return st[(size_t)r];
+        }
+        worst = std::max(worst, st[(size_t)r]);
+    }
+    return worst;
 }
 
 double now_ms() {
@@ -243,10 +285,63 @@ int tlsq_create(int device_id, tlsq_handle* out) {
     return TLSQ_OK;
 }
 
+int tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out) {
+    if (!out || ngpus < 1) return TLSQ_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;   // no GPU: fail loudly
+    if (ngpus > ndev) return TLSQ_ERR_ARG;
+    std::vector<int> devs((size_t)ngpus);
+    for (int r = 0; r < ngpus; ++r) {
+        devs[(size_t)r] = device_ids ? device_ids[r] : r;
+        if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) return TLSQ_ERR_ARG;
+        for (int q = 0; q < r; ++q)
+            if (devs[(size_t)q] == devs[(size_t)r]) return TLSQ_ERR_ARG;
+    }
+    if (!rccl_load() || !g_rccl.CommInitAll) return TLSQ_ERR_COMM;
+    std::vector<tlsq_handle> hs((size_t)ngpus, nullptr);
+    auto undo = [&]() {
+        for (auto x : hs)
+            if (x) tlsq_destroy(x);
+    };
+    for (int r = 0; r < ngpus; ++r) {
+        const int st = tlsq_create(devs[(size_t)r], &hs[(size_t)r]);
+        if (st != TLSQ_OK) {
+            undo();
+            return st;
+        }
+    }
+    std::vector<ncclComm_t> comms((size_t)ngpus, nullptr);
+    if (g_rccl.CommInitAll(comms.data(), ngpus, devs.data()) != ncclSuccess) {
+        undo();
+        return TLSQ_ERR_COMM;
+    }
+    for (int r = 0; r < ngpus; ++r) {
+        hs[(size_t)r]->multi_comm = new Comm();
+        hs[(size_t)r]->multi_comm->comm = comms[(size_t)r];
+        hs[(size_t)r]->multi_n = ngpus;
+        hs[(size_t)r]->multi_rank = r;
+    }
+    for (int r = 1; r < ngpus; ++r) hs[0]->subs.push_back(hs[(size_t)r]);
+    (void)hipSetDevice(devs[0]);
+    *out = hs[0];
+    return TLSQ_OK;
+}
+
+int tlsq_ngpus(tlsq_handle h) { return h ? h->multi_n : 0; }
+
 int tlsq_destroy(tlsq_handle h) {
     if (!h) return TLSQ_OK;
+    for (Handle* sub : h->subs) tlsq_destroy(static_cast<tlsq_handle>(sub));
+    h->subs.clear();
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->multi_comm) {
+        if (h->multi_comm->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->multi_comm->comm);
+        delete h->multi_comm;
+        h->multi_comm = nullptr;
+    }
+    h->comm = nullptr == h->comm ? nullptr : h->comm;
     tlsq_comm_destroy(h);
     for (auto& b : h->ws)
         if (b.p) (void)hipFree(b.p);

@@ -1469,6 +1469,61 @@ int tls_partition_solve(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n
 // ------------------------------------------------------------------------------------------------
 // rpca entry (both precisions): staging of caller memory, M < N handled on the transposed problem
 // ------------------------------------------------------------------------------------------------
+// rpca on a single-process multi-GPU group (tlsq_create_multi): host matrices, contiguous row blocks, one worker per
+// GPU.  Every rank runs the ordinary row-sharded entry on its block of the caller's arrays (column-major with the
+// caller's leading dimensions, so a row block is just an offset pointer: the strided 2-D copies of rpca_entry do the
+// scatter and the gather).  All ranks get structurally identical requests - history arrays, an on_iter hook, S / Vt
+// buffers - because those requests steer which collectives a rank enters.
+static void noop_on_iter(int64_t, double, int64_t, void*) {}
+
+template <typename T>
+static int rpca_multi(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts, T* A,
+                      int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt, int64_t* sv,
+                      tlsq_rpca_info* info) {
+    const int n = h->multi_n;
+    const int64_t d = std::min(M, N);
+    tlsq_rpca_opts base;
+    if (opts) base = *opts; else tlsq_rpca_opts_default(&base);
+    base.m_global = M;
+    base.memory = TLSQ_MEM_HOST;
+    std::vector<tlsq_rpca_opts> ro((size_t)n, base);
+    std::vector<tlsq_rpca_info> ri((size_t)n);
+    std::vector<std::vector<double>> ch((size_t)n);
+    std::vector<std::vector<int64_t>> sh((size_t)n);
+    std::vector<std::vector<T>> Sr((size_t)n), Vr((size_t)n);
+    std::vector<int64_t> svr((size_t)n, 0);
+    for (int r = 0; r < n; ++r) {
+        memset(&ri[(size_t)r], 0, sizeof(tlsq_rpca_info));
+        if (r == 0) {
+            if (info) ri[0] = *info;
+        } else {
+            if (base.on_iter) ro[(size_t)r].on_iter = noop_on_iter;   // the caller's hook runs on the calling thread only
+            if (info && info->cost_hist) {
+                ch[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
+                ri[(size_t)r].cost_hist = ch[(size_t)r].data();
+            }
+            if (info && info->svp_hist) {
+                sh[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
+                ri[(size_t)r].svp_hist = sh[(size_t)r].data();
+            }
+            ri[(size_t)r].hist_capacity = info ? info->hist_capacity : 0;
+            if (S) Sr[(size_t)r].resize((size_t)d);
+            if (Vt) Vr[(size_t)r].resize((size_t)d * N);
+        }
+    }
+    const int st = multi_run(h, [&](Handle* hr, int r, int nr) -> int {
+        const int64_t bs = M / nr, rem = M % nr;
+        const int64_t lo = r * bs + std::min<int64_t>(r, rem), rows = bs + (r < rem ? 1 : 0);
+        return rpca_entry<T>(static_cast<tlsq_handle>(hr), D + lo, rows, N, ldD, &ro[(size_t)r], A + lo, ldA, E + lo, ldE,
+                             U ? U + lo : nullptr, ldU, S ? (r == 0 ? S : Sr[(size_t)r].data()) : nullptr,
+                             Vt ? (r == 0 ? Vt : Vr[(size_t)r].data()) : nullptr, r == 0 ? ldVt : d, &svr[(size_t)r],
+                             &ri[(size_t)r]);
+    });
+    if (info) *info = ri[0];
+    if (sv) *sv = svr[0];
+    return st;
+}
+
 template <typename T>
 int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
                       T* A, int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt,
@@ -1476,6 +1531,15 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     TLSQ_TRY(check_handle(h));
     if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
         return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    if (is_multi_call(h)) {
+        const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
+        if (dev_mem)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: a multi-GPU handle takes host matrices (device pointers belong "
+                           "to one GPU; use one handle per GPU with tlsq_comm_init for device-resident shards)");
+        // tall problems with enough rows per GPU are row-sharded; anything else runs on the first GPU alone
+        if (M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
+            return rpca_multi<T>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
+    }
     TLSQ_HIP(h, hipSetDevice(h->device));
     const double t0 = now_ms();
     reset_info(info);

@@ -562,14 +562,9 @@ int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64
                            ldx, Y, ldy, R, (int)K, (int)p);
     } else {
         const size_t lds = (size_t)SK_KB * 16 * 8;
-        static bool attr_done = false;
-        if (!attr_done) {
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_mm<double, 16>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_mm<float, 16>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
+        // (per device: a multi-GPU group launches this on every GPU of the process)
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_mm<TA, 16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_skinny_mm<TA, 16>), dim3((unsigned)gx, (unsigned)((p + 15) / 16)), dim3(SK_WAVES * 64), lds,
                            h->stream, A, lda, X, ldx, Y, ldy, R, (int)K, (int)p);
     }

@@ -64,14 +64,23 @@ class RpcaReport:
 class Engine:
     """One handle = one GPU (tlsq_create)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, *, ngpus: int | None = None, devices=None):
+        """Engine(device) = tlsq_create: one GPU.  Engine(ngpus=n) / Engine(devices=[...]) = tlsq_create_multi: one
+        handle over n GPUs of this process; rpca / lowrankfilter on host arrays are row-sharded over them."""
         self.lib = L.load()
         h = C.c_void_p()
-        st = self.lib.tlsq_create(int(device), C.byref(h))
+        if ngpus is not None or devices is not None:
+            devs = list(devices) if devices is not None else list(range(int(ngpus)))
+            arr = (C.c_int * len(devs))(*devs)
+            st = self.lib.tlsq_create_multi(len(devs), arr, C.byref(h))
+            device = devs[0]
+        else:
+            st = self.lib.tlsq_create(int(device), C.byref(h))
         if st != 0:
             raise TlsqError(st, "tlsq_create failed (no MI355X visible? there is no CPU fallback)")
         self.h = h
         self.device = device
+        self.ngpus = int(self.lib.tlsq_ngpus(h))
         self.nranks, self.rank = 1, 0
 
     def close(self):
