@@ -44,8 +44,22 @@ enum {
 };
 
 enum { TLSQ_MEM_HOST = 0, TLSQ_MEM_DEVICE = 1 };
-enum { TLSQ_SVD_FULL = 0, TLSQ_SVD_RANDOMIZED = 1 };       /* the `svd` hook, src/robustPCA.jl:168,193-197 */
-enum { TLSQ_OPNORM_EXACT = 0, TLSQ_OPNORM_POWER = 1 };     /* the `opnorm` hook, src/robustPCA.jl:169,177,225 */
+enum { TLSQ_SVD_FULL = 0, TLSQ_SVD_RANDOMIZED = 1, TLSQ_SVD_CALLBACK = 2 };       /* the `svd` hook, src/robustPCA.jl:168,193-197 */
+enum { TLSQ_OPNORM_EXACT = 0, TLSQ_OPNORM_POWER = 1, TLSQ_OPNORM_CALLBACK = 2 };  /* the `opnorm` hook, :169,177,225 */
+
+/* Arbitrary user hooks (TLSQ_SVD_CALLBACK / TLSQ_OPNORM_CALLBACK): the reference accepts any `svd(Z, sv)` returning
+ * .U, .S, .Vt and any `opnorm(X)::real(T)` (src/robustPCA.jl:168-169; test/runtests.jl:384-398).  A closure of the host
+ * language cannot run on the GPU, so in these modes the working panel is copied to HOST memory and the callback is
+ * invoked there, on the calling thread, once per use (iterations k >= 2 for svd, exactly like :193-197; set-up and every
+ * iteration for opnorm).  Element type = that of the entry point (double for _f64, float for _f32), column-major.
+ *   svd_cb:    Z (M x N, ldZ) in; fill U (M x k, ldU), S (k, descending), Vt (k x N, ldVt) and *k_out = k <= min(M,N)
+ *              (buffers hold min(M,N) triplets); return 0, anything else aborts the call with TLSQ_ERR_ARG.
+ *   opnorm_cb: returns the norm estimate of X (M x N, ldX).
+ * For a wide input (M < N, unsharded) the library works on the transposed problem and the hooks receive that panel
+ * (N x M): singular values and norms are the same, U and V swap roles consistently.  Not available on row shards. */
+typedef int (*tlsq_svd_cb)(const void* Z, int64_t M, int64_t N, int64_t ldZ, int64_t sv, void* U, int64_t ldU, void* S,
+                           void* Vt, int64_t ldVt, int64_t* k_out, void* user);
+typedef double (*tlsq_opnorm_cb)(const void* X, int64_t M, int64_t N, int64_t ldX, void* user);
 
 /* Keyword arguments of rpca (src/robustPCA.jl:156-170).  Fill with tlsq_rpca_opts_default() first;
  * NaN / <=0 sentinels resolve to the reference's defaults at call time (they depend on T, M, N). */
@@ -68,6 +82,8 @@ typedef struct tlsq_rpca_opts {
     /* live `verbose` hook (src/robustPCA.jl:226): called on the calling thread after each iteration */
     void (*on_iter)(int64_t k, double cost, int64_t svp, void* user);
     void* user;
+    tlsq_svd_cb svd_cb;         /* svd_mode == TLSQ_SVD_CALLBACK */
+    tlsq_opnorm_cb opnorm_cb;   /* opnorm_mode == TLSQ_OPNORM_CALLBACK */
 } tlsq_rpca_opts;
 
 /* Per-call report.  cost_hist / svp_hist are optional caller-provided arrays of hist_capacity entries.
@@ -76,7 +92,7 @@ typedef struct tlsq_rpca_opts {
 typedef struct tlsq_rpca_info {
     int64_t iters_done;
     int32_t converged;
-    int32_t reserved;
+    int32_t reserved;        /* iterations whose SVD step went through the TSQR route */
     double  final_cost;
     double  final_mu;
     double  d_norm;          /* opnorm(D), src/robustPCA.jl:177 */
@@ -93,6 +109,10 @@ typedef struct tlsq_rpca_info {
     /* sweeps that did not store the residual panel (its cost evaluation was predicted to be skipped): these moved
      * one panel pass less */
     int64_t residual_stores_skipped;
+    /* HBM bytes the panel-sized kernels of the ALM loop had to move (algorithmic bytes of what was launched: passes over
+     * M x N x sizeof(T) panels): the sweep kernels alone, and everything (sweeps + Gram reads + the
+     * rebuild's read of Z and write of A + residual Gram).  Per GPU when row-sharded. */
+    double hbm_bytes_sweeps, hbm_bytes;
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);
@@ -183,6 +203,13 @@ int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int6
 int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA,
                   const double* y, int64_t q, int64_t ldy, const tlsq_rpca_opts* opts,
                   double* x, int64_t ldx, tlsq_rpca_info* info);
+/* Float32 methods (the reference functions are generic in the element type, src/TotalLeastSquares.jl:63,152): fp32
+ * panels, fp64 small-matrix work, x returned in fp32 */
+int tlsq_tls_f32(tlsq_handle h, const float* Ay, int64_t M, int64_t ncols, int64_t ldAy,
+                 int64_t n, float* x, int64_t ldx, int memory);
+int tlsq_rtls_f32(tlsq_handle h, const float* A, int64_t M, int64_t n, int64_t ldA,
+                  const float* y, int64_t q, int64_t ldy, const tlsq_rpca_opts* opts,
+                  float* x, int64_t ldx, tlsq_rpca_info* info);
 
 /* ---- ComplexF64 rpca: the complex soft_th method (src/robustPCA.jl:3-7; test/runtests.jl:187-199) -------------
  * D, A, E are interleaved (re, im) complex M x N matrices, column-major, leading dimensions in complex elements;

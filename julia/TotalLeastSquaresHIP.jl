@@ -1,34 +1,44 @@
 # TotalLeastSquaresHIP.jl — thin `ccall` shim over libtlsqhip.so (include/tlsq.h).
 #
-# Drop-in for the rpca / lowrankfilter / hankel / unhankel / tls! / rtls entry points of
-# baggepinnen/TotalLeastSquares.jl (reference signatures: src/robustPCA.jl:76,28,53,119,156;
-# src/TotalLeastSquares.jl:63,65,152).  Host code stays in Julia; every M x N operation runs on the
-# MI355X behind the C ABI.  NOTE: the build image has no `julia` binary, so this file is not executed by
-# the test-suite; it is mirrored line for line by the ctypes harness
-# `totalleastsquares.jl_amd/engine.py`, which is.  Struct layouts are checked there
-# (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts)=104, sizeof(info)=184).
+# Drop-in for the rpca / lowrankfilter / hankel / unhankel / tls! / rtls / rpca_ga entry points of
+# baggepinnen/TotalLeastSquares.jl (reference signatures: src/robustPCA.jl:76,28,53,119,156,255;
+# src/TotalLeastSquares.jl:48,63,65,152).  Host code stays in Julia; every M x N operation runs on the MI355X behind
+# the C ABI.  `ishankel` (src/robustPCA.jl:94-106) is a host-side test helper and is NOT redefined here: when the shim
+# is included into the reference module (INTEGRATION.md) the reference's own definition stays in place.
+#
+# NOTE: the build image has no `julia` binary, so this file is not executed by the test-suite; every call below is
+# mirrored one to one by the ctypes harness `totalleastsquares.jl_amd/engine.py`, which is.  Struct layouts are
+# checked there (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts) = 120, sizeof(info) = 200).
+#
+# Multi-GPU: ENV["TLSQ_NGPUS"] = "8" makes the one process-wide handle a tlsq_create_multi handle; rpca / lowrankfilter
+# on host arrays are then row-sharded over the GPUs inside the library (worker threads never call back into Julia; the
+# `verbose` hook runs on the calling thread).
 module TotalLeastSquaresHIP
 
 using LinearAlgebra, Libdl
 
-export rpca, lowrankfilter, hankel, unhankel, ishankel, tls, tls!, rtls, rpca_ga, entrywise_median, entrywise_trimmed_mean, μ!
+export rpca, lowrankfilter, hankel, unhankel, tls, tls!, rtls, rpca_ga, entrywise_median, entrywise_trimmed_mean, μ!
 
 const LIB = Ref{String}(get(ENV, "TLSQ_LIB", joinpath(@__DIR__, "..", "totalleastsquares.jl_amd", "libtlsqhip.so")))
 
 const TLSQ_OK, TLSQ_MAXITER = Cint(0), Cint(1)
 const MEM_HOST = Cint(0)
+const SVD_FULL, SVD_RANDOMIZED, SVD_CALLBACK = Int32(0), Int32(1), Int32(2)
+const OPNORM_EXACT, OPNORM_POWER, OPNORM_CALLBACK = Int32(0), Int32(1), Int32(2)
+const HipFloat = Union{Float64,Float32}
 
-# mirrors `struct tlsq_rpca_opts` (include/tlsq.h)
+# mirrors `struct tlsq_rpca_opts` (include/tlsq.h), 120 bytes
 mutable struct RpcaOpts
     lambda::Cdouble; maxrank::Int64; iters::Int64; tol::Cdouble; rho::Cdouble
     nonnegA::Int32; nonnegE::Int32; hankel::Int32; nukeA::Int32
     svd_mode::Int32; opnorm_mode::Int32; opnorm_mvps::Int32; memory::Int32
     m_global::Int64; seed::UInt64
     on_iter::Ptr{Cvoid}; user::Ptr{Cvoid}
+    svd_cb::Ptr{Cvoid}; opnorm_cb::Ptr{Cvoid}
     RpcaOpts() = new()
 end
 
-# mirrors `struct tlsq_rpca_info`
+# mirrors `struct tlsq_rpca_info`, 200 bytes
 mutable struct RpcaInfo
     iters_done::Int64; converged::Int32; reserved::Int32
     final_cost::Cdouble; final_mu::Cdouble; d_norm::Cdouble
@@ -37,7 +47,13 @@ mutable struct RpcaInfo
     ms_shrink::Cdouble; ms_update::Cdouble; ms_gram::Cdouble; ms_eig::Cdouble; ms_rebuild::Cdouble; ms_opnorm::Cdouble
     eig_full::Int64; eig_fast::Int64; subspace_steps::Int64
     residual_stores_skipped::Int64
+    hbm_bytes_sweeps::Cdouble; hbm_bytes::Cdouble
     RpcaInfo() = new()
+end
+
+function _info()
+    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    info
 end
 
 const HANDLE = Ref{Ptr{Cvoid}}(C_NULL)
@@ -45,7 +61,10 @@ const HANDLE = Ref{Ptr{Cvoid}}(C_NULL)
 function handle()
     if HANDLE[] == C_NULL
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        st = ccall((:tlsq_create, LIB[]), Cint, (Cint, Ref{Ptr{Cvoid}}), 0, h)
+        ngpus = parse(Int, get(ENV, "TLSQ_NGPUS", "1"))
+        st = ngpus > 1 ?
+            ccall((:tlsq_create_multi, LIB[]), Cint, (Cint, Ptr{Cint}, Ref{Ptr{Cvoid}}), ngpus, C_NULL, h) :
+            ccall((:tlsq_create, LIB[]), Cint, (Cint, Ref{Ptr{Cvoid}}), parse(Int, get(ENV, "TLSQ_DEVICE", "0")), h)
         st == 0 || error("tlsq_create failed ($st): no MI355X visible; there is no CPU fallback")
         HANDLE[] = h[]
     end
@@ -58,115 +77,199 @@ check(st) = st < 0 ? (st == -1 ? throw(AssertionError(lasterr())) : error("tlsq 
 _print_iter(k::Int64, cost::Cdouble, svp::Int64, ::Ptr{Cvoid}) =
     (println("$(k) cost: $(round(cost, sigdigits=4))"); nothing)      # src/robustPCA.jl:226
 
-"""
-    A, E, s, sv = rpca(D; λ, maxrank, iters, tol, ρ, verbose, nonnegA, nonnegE, hankel, nukeA)
+# ---- the `svd` / `opnorm` keyword hooks (src/robustPCA.jl:168-169) -----------------------------------------------
+# Defaults -> the library's own solvers.  Functions called rsvd / rsvd_fnkz / tsvd (RandomizedLinAlg, TSVD: what the
+# reference's tests pass, test/runtests.jl:384-398) -> the built-in rank-sv randomized SVD on the GPU, unless
+# `gpu_hooks = false`.  ANY other function runs as it is, in Julia, through the C callbacks: the library copies the
+# working panel to the host and calls back on this thread (tlsq_svd_cb / tlsq_opnorm_cb in include/tlsq.h).
+mutable struct HookBox
+    svd::Any
+    opnorm::Any
+    err::Any
+end
 
-Same contract as the reference (src/robustPCA.jl:156-239).  `svd`/`opnorm` hooks other than the defaults
-are not supported on the GPU path (TLSQ_ERR_UNSUPPORTED); complex element types are rejected.
-"""
-function rpca(D::AbstractMatrix{Float64};
-              λ = 1.0 / sqrt(maximum(size(D))), maxrank = typemax(Int), iters::Int = 1000,
-              tol = sqrt(eps(Float64)), ρ = 1.5, verbose::Bool = false, nonnegA::Bool = false,
-              nonnegE::Bool = false, hankel::Bool = false, nukeA = true,
-              svd = LinearAlgebra.svd!, opnorm = LinearAlgebra.opnorm, kwargs...)
-    (svd ∈ (LinearAlgebra.svd, LinearAlgebra.svd!) && opnorm === LinearAlgebra.opnorm) ||
-        error("custom svd/opnorm hooks cannot run on the GPU path")
-    Dm = Matrix(D)
-    M, N = size(Dm); d = min(M, N)
-    A = Matrix{Float64}(undef, M, N); E = similar(A)
-    U = Matrix{Float64}(undef, M, d); S = Vector{Float64}(undef, d); Vt = Matrix{Float64}(undef, d, N)
+function _svd_tramp(::Type{T}, Zp::Ptr{Cvoid}, M::Int64, N::Int64, ldZ::Int64, sv::Int64, Up::Ptr{Cvoid}, ldU::Int64,
+                    Sp::Ptr{Cvoid}, Vtp::Ptr{Cvoid}, ldVt::Int64, kout::Ptr{Int64}, user::Ptr{Cvoid})::Cint where {T}
+    box = unsafe_pointer_to_objref(user)::HookBox
+    try
+        Z = copy(view(unsafe_wrap(Array, Ptr{T}(Zp), (ldZ, N)), 1:M, :))
+        s = box.svd(Z, Int(sv))                                          # :196  svd(Z, sv)
+        k = min(length(s.S), min(M, N))
+        U = unsafe_wrap(Array, Ptr{T}(Up), (ldU, min(M, N)))
+        S = unsafe_wrap(Array, Ptr{T}(Sp), (min(M, N),))
+        Vt = unsafe_wrap(Array, Ptr{T}(Vtp), (ldVt, N))
+        U[1:M, 1:k] .= view(s.U, :, 1:k)
+        S[1:k] .= view(s.S, 1:k)
+        Vt[1:k, :] .= view(s.Vt, 1:k, :)
+        unsafe_store!(kout, k)
+        return Cint(0)
+    catch e
+        box.err = e
+        return Cint(1)
+    end
+end
+_svd_tramp64(a...) = _svd_tramp(Float64, a...)
+_svd_tramp32(a...) = _svd_tramp(Float32, a...)
+
+function _opnorm_tramp(::Type{T}, Xp::Ptr{Cvoid}, M::Int64, N::Int64, ldX::Int64, user::Ptr{Cvoid})::Cdouble where {T}
+    box = unsafe_pointer_to_objref(user)::HookBox
+    try
+        X = copy(view(unsafe_wrap(Array, Ptr{T}(Xp), (ldX, N)), 1:M, :))
+        return Cdouble(box.opnorm(X))                                    # :177, :225
+    catch e
+        box.err = e
+        return Cdouble(NaN)
+    end
+end
+_opnorm_tramp64(a...) = _opnorm_tramp(Float64, a...)
+_opnorm_tramp32(a...) = _opnorm_tramp(Float32, a...)
+
+_is_default_svd(f) = f === LinearAlgebra.svd || f === LinearAlgebra.svd!
+_is_randomized_svd(f) = nameof(f) in (:rsvd, :rsvd_fnkz, :tsvd)
+
+# options from the keyword arguments of rpca (src/robustPCA.jl:156-170); unknown keywords are swallowed like the
+# reference's `kwargs...`.  Returns the options and the hook box that has to stay rooted during the ccall.
+function _opts(::Type{T}, M, N; λ = nothing, maxrank = typemax(Int), iters::Integer = 1000, tol = nothing, ρ = 1.5,
+               verbose::Bool = false, nonnegA::Bool = false, nonnegE::Bool = false, hankel::Bool = false,
+               nukeA::Bool = true, svd = LinearAlgebra.svd!, opnorm = LinearAlgebra.opnorm, gpu_hooks::Bool = true,
+               opnorm_mvps::Integer = 10, seed::Integer = 0, kwargs...) where {T<:HipFloat}
+    iters >= 1 || throw(ArgumentError("iters must be >= 1 (the reference leaves `s` undefined for iters = 0, src/robustPCA.jl:185,238)"))
     o = RpcaOpts()
     ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
-    o.lambda = λ; o.maxrank = min(maxrank, typemax(Int64) ÷ 2); o.iters = iters; o.tol = tol; o.rho = ρ
+    λ === nothing || (o.lambda = λ)
+    tol === nothing || (o.tol = tol)
+    o.maxrank = min(maxrank, typemax(Int64) ÷ 2); o.iters = iters; o.rho = ρ
     o.nonnegA = nonnegA; o.nonnegE = nonnegE; o.hankel = hankel; o.nukeA = nukeA ? 1 : 0
-    o.memory = MEM_HOST
+    o.memory = MEM_HOST; o.opnorm_mvps = opnorm_mvps; o.seed = seed
     verbose && (o.on_iter = @cfunction(_print_iter, Cvoid, (Int64, Cdouble, Int64, Ptr{Cvoid})))
-    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    box = HookBox(svd, opnorm, nothing)
+    if !_is_default_svd(svd)
+        if gpu_hooks && _is_randomized_svd(svd)
+            o.svd_mode = SVD_RANDOMIZED
+        else
+            o.svd_mode = SVD_CALLBACK
+            o.svd_cb = T === Float64 ? @cfunction(_svd_tramp64, Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Cvoid})) :
+                                       @cfunction(_svd_tramp32, Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Cvoid}))
+        end
+    end
+    if opnorm !== LinearAlgebra.opnorm
+        o.opnorm_mode = OPNORM_CALLBACK
+        o.opnorm_cb = T === Float64 ? @cfunction(_opnorm_tramp64, Cdouble, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid})) :
+                                      @cfunction(_opnorm_tramp32, Cdouble, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}))
+    end
+    o.user = pointer_from_objref(box)
+    o, box
+end
+
+_rethrow(box::HookBox) = box.err === nothing ? nothing : throw(box.err)
+
+"""
+    A, E, s, sv = rpca(D; λ, maxrank, iters, tol, ρ, verbose, nonnegA, nonnegE, hankel, nukeA, svd, opnorm)
+
+Same contract as the reference (src/robustPCA.jl:156-239) for Float64 and Float32 matrices (ComplexF64 below).
+"""
+function rpca(D::AbstractMatrix{T}; tol = sqrt(eps(T)), kwargs...) where {T<:HipFloat}
+    Dm = Matrix(D)
+    M, N = size(Dm); d = min(M, N)
+    A = Matrix{T}(undef, M, N); E = similar(A)
+    U = Matrix{T}(undef, M, d); S = Vector{T}(undef, d); Vt = Matrix{T}(undef, d, N)
+    o, box = _opts(T, M, N; tol = tol, kwargs...)
+    info = _info()
     sv = Ref{Int64}(0)
-    st = check(ccall((:tlsq_rpca_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
-         Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}, Ref{RpcaInfo}),
-        handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info))
-    verbose && info.converged != 0 && println("converged")            # src/robustPCA.jl:229
+    st = GC.@preserve box begin
+        T === Float64 ?
+            ccall((:tlsq_rpca_f64, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+                 Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}, Ref{RpcaInfo}),
+                handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info) :
+            ccall((:tlsq_rpca_f32, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float32}, Int64, Ptr{Float32}, Int64,
+                 Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float32}, Int64, Ref{Int64}, Ref{RpcaInfo}),
+                handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info)
+    end
+    _rethrow(box)
+    check(st)
+    get(kwargs, :verbose, false) && info.converged != 0 && println("converged")   # src/robustPCA.jl:229
     st == TLSQ_MAXITER &&
         @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"   # :232
     A, E, SVD(U, S, Vt), sv[]
 end
 
-function hankel(x::AbstractVecOrMat{Float64}, L, lag = 1)             # src/robustPCA.jl:76-92
-    xm = Matrix(reshape(x, size(x, 1), :)); N, D = size(xm)
+function hankel(x::AbstractVecOrMat{T}, L, lag = 1) where {T}           # src/robustPCA.jl:76-92
+    # Float64 / Float32 run on the GPU as they are; any other eltype (the reference allows integers, test/runtests.jl:293)
+    # is embedded in Float64 on the device and converted back - the embedding is a pure copy, so the result is exact
+    W = T === Float32 ? Float32 : Float64
+    xm = Matrix{W}(reshape(x, size(x, 1), :)); N, D = size(xm)
     @assert L <= N / 2 "L has to be less than N/2 = $(N/2)"
     @assert lag <= L "lag must be <= L"
     K = (N - L) ÷ lag + 1
-    X = Matrix{Float64}(undef, K, L * D)
-    check(ccall((:tlsq_hankel_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
-        handle(), xm, N, D, N, L, lag, X, K, MEM_HOST))
-    X
+    X = Matrix{W}(undef, K, L * D)
+    W === Float64 ?
+        check(ccall((:tlsq_hankel_f64, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+            handle(), xm, N, D, N, L, lag, X, K, MEM_HOST)) :
+        check(ccall((:tlsq_hankel_f32, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Int64, Ptr{Float32}, Int64, Cint),
+            handle(), xm, N, D, N, L, lag, X, K, MEM_HOST))
+    T <: HipFloat ? X : convert(Matrix{T}, X)
 end
 
-unhankel(A::AbstractMatrix{Float64}) = unhankel(A, 1, size(A, 1) + size(A, 2) - 1, 1)   # :28-39
-function unhankel(A::AbstractMatrix{Float64}, lag, N, D = 1)          # src/robustPCA.jl:53-68
+unhankel(A::AbstractMatrix{<:HipFloat}) = unhankel(A, 1, size(A, 1) + size(A, 2) - 1, 1)   # :28-39
+function unhankel(A::AbstractMatrix{T}, lag, N, D = 1) where {T<:HipFloat}   # src/robustPCA.jl:53-68
     Am = Matrix(A); K, LD = size(Am)
     lag == 1 && D == 1 && (N = K + LD - 1)
-    y = Matrix{Float64}(undef, N, D)
-    check(ccall((:tlsq_unhankel_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
-        handle(), Am, K, LD, K, lag, N, D, y, N, MEM_HOST))
+    y = Matrix{T}(undef, N, D)
+    T === Float64 ?
+        check(ccall((:tlsq_unhankel_f64, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+            handle(), Am, K, LD, K, lag, N, D, y, N, MEM_HOST)) :
+        check(ccall((:tlsq_unhankel_f32, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Float32}, Int64, Cint),
+            handle(), Am, K, LD, K, lag, N, D, y, N, MEM_HOST))
     D == 1 ? vec(y) : y
 end
 
-function ishankel(A)                                                   # src/robustPCA.jl:94-106 (host)
-    K, L = size(A)
-    for k = 1:K+L-1
-        ri = min(K, k):-1:max(k - L, 1); ci = max(1, k - K + 1):L
-        val = A[ri[1], ci[1]]
-        for (r, c) in zip(ri, ci)
-            A[r, c] != val && return false
-        end
-    end
-    true
-end
-
 function lowrankfilter(y::AbstractVecOrMat{T}, n = min(size(y, 1) ÷ 20, 2000);
-                       sv = 0, lag = 1, tol = 1e-3, svd = LinearAlgebra.svd!, kwargs...) where {T<:Union{Float64,Float32}}   # :119-128
-    svd ∈ (LinearAlgebra.svd, LinearAlgebra.svd!) || error("custom svd hooks cannot run on the GPU path")
+                       sv = 0, lag = 1, tol = 1e-3, kwargs...) where {T<:HipFloat}   # :119-128
     ym = Matrix(reshape(y, size(y, 1), :)); N, D = size(ym)
     @assert n <= N / 2 "L has to be less than N/2 = $(N/2)"
     @assert lag <= n "lag must be <= L"
-    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
-    o.tol = tol; o.memory = MEM_HOST
-    for (k, v) in kwargs
-        k === :λ && (o.lambda = v); k === :ρ && (o.rho = v); k === :iters && (o.iters = v)
-        k === :maxrank && (o.maxrank = v); k === :nonnegA && (o.nonnegA = v); k === :nonnegE && (o.nonnegE = v)
-        k === :hankel && (o.hankel = v); k === :nukeA && (o.nukeA = v ? 1 : 0)
-    end
-    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    K = (N - n) ÷ lag + 1
+    o, box = _opts(T, K, n * D; tol = tol, kwargs...)    # every rpca keyword is forwarded, as `kwargs...` at :122
+    info = _info()
     yf = Matrix{T}(undef, N, D)
-    st = T === Float64 ?
-        check(ccall((:tlsq_lowrankfilter_f64, LIB[]), Cint,
-            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64,
-             Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info)) :
-        check(ccall((:tlsq_lowrankfilter_f32, LIB[]), Cint,
-            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float32}, Int64,
-             Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info))
+    st = GC.@preserve box begin
+        T === Float64 ?
+            ccall((:tlsq_lowrankfilter_f64, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64}, Int64,
+                 Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info) :
+            ccall((:tlsq_lowrankfilter_f32, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float32}, Int64,
+                 Ref{RpcaInfo}), handle(), ym, N, D, N, n, lag, sv, o, yf, N, info)
+    end
+    _rethrow(box)
+    check(st)
     st == TLSQ_MAXITER && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
     y isa AbstractVector ? vec(yf) : yf
 end
 
-function tls!(Ay::AbstractMatrix{Float64}, n::Integer)                 # src/TotalLeastSquares.jl:63
+function tls!(Ay::AbstractMatrix{T}, n::Integer) where {T<:HipFloat}   # src/TotalLeastSquares.jl:63
     Am = Matrix(Ay); M, nc = size(Am)
-    x = Matrix{Float64}(undef, n, nc - n)
-    check(ccall((:tlsq_tls_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
-        handle(), Am, M, nc, M, n, x, n, MEM_HOST))
+    x = Matrix{T}(undef, n, nc - n)
+    T === Float64 ?
+        check(ccall((:tlsq_tls_f64, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Cint),
+            handle(), Am, M, nc, M, n, x, n, MEM_HOST)) :
+        check(ccall((:tlsq_tls_f32, LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Ptr{Float32}, Int64, Cint),
+            handle(), Am, M, nc, M, n, x, n, MEM_HOST))
     x
 end
 
-tls(A::AbstractArray{Float64}, y::AbstractArray{Float64}) = tls!([A y], size(A, 2))   # src/TotalLeastSquares.jl:48-55
+tls(A::AbstractArray{<:HipFloat}, y::AbstractArray{<:HipFloat}) = tls!([A y], size(A, 2))   # src/TotalLeastSquares.jl:48-55
 
 function tls!(s::SVD, n::Integer)                                      # src/TotalLeastSquares.jl:65-69
-    Vt = Matrix(s.Vt); nc = size(Vt, 2)
+    Vt = Matrix{Float64}(s.Vt); nc = size(Vt, 2)
     x = Matrix{Float64}(undef, n, nc - n)
     st = ccall((:tlsq_tls_from_vt_f64, LIB[]), Cint, (Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64),
                Vt, nc, nc, n, x, n)
@@ -174,14 +277,24 @@ function tls!(s::SVD, n::Integer)                                      # src/Tot
     x
 end
 
-function rtls(A::AbstractArray{Float64}, y::AbstractArray{Float64}; kwargs...)   # :152-156
+function rtls(A::AbstractMatrix{T}, y::AbstractVecOrMat{T}; kwargs...) where {T<:HipFloat}   # :152-156
     Am = Matrix(A); ym = Matrix(reshape(y, size(y, 1), :)); M, n = size(Am); q = size(ym, 2)
-    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o); o.memory = MEM_HOST
-    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
-    x = Matrix{Float64}(undef, n, q)
-    check(ccall((:tlsq_rtls_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},
-         Int64, Ref{RpcaInfo}), handle(), Am, M, n, M, ym, q, M, o, x, n, info))
+    o, box = _opts(T, M, n + q; tol = sqrt(eps(T)), kwargs...)          # kwargs go to rpca, as in the reference (:154)
+    o.nukeA = 0                                                        # rpca([A y]; nukeA = false, kwargs...)
+    info = _info()
+    x = Matrix{T}(undef, n, q)
+    st = GC.@preserve box begin
+        T === Float64 ?
+            ccall((:tlsq_rtls_f64, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},
+                 Int64, Ref{RpcaInfo}), handle(), Am, M, n, M, ym, q, M, o, x, n, info) :
+            ccall((:tlsq_rtls_f32, LIB[]), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Ptr{Float32}, Int64, Int64, Ref{RpcaOpts}, Ptr{Float32},
+                 Int64, Ref{RpcaInfo}), handle(), Am, M, n, M, ym, q, M, o, x, n, info)
+    end
+    _rethrow(box)
+    check(st)
+    st == TLSQ_MAXITER && @warn "Maximum number of iterations reached, cost: $(info.final_cost)"
     y isa AbstractVector ? vec(x) : x
 end
 
@@ -191,7 +304,7 @@ function rpca(D::AbstractMatrix{ComplexF64}; λ = 1 / sqrt(maximum(size(D))), it
     Dm = Matrix(D); M, N = size(Dm)
     o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
     o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA ? 1 : 0; o.memory = MEM_HOST
-    info = RpcaInfo(); info.cost_hist = C_NULL; info.svp_hist = C_NULL; info.hist_capacity = 0
+    info = _info()
     A = similar(Dm); E = similar(Dm); S = Vector{Float64}(undef, min(M, N)); sv = Ref{Int64}(0)
     st = check(ccall((:tlsq_rpca_c64, LIB[]), Cint,
         (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{ComplexF64}, Int64, Ptr{ComplexF64},
@@ -204,7 +317,7 @@ end
 # (or M x q x B); returns x as n x B (n x q x B).  One workgroup per problem, everything in LDS.
 function rtls(A::AbstractArray{Float64,3}, y::AbstractArray{Float64}; kwargs...)
     M, n, B = size(A); ym = reshape(y, M, :, B); q = size(ym, 2)
-    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o); o.memory = MEM_HOST
+    o, box = _opts(Float64, M, n + q; tol = sqrt(eps()), kwargs...)
     x = Array{Float64}(undef, n, q, B); iters = Vector{Int32}(undef, B); status = Vector{Int32}(undef, B)
     st = check(ccall((:tlsq_rtls_batched_f64, LIB[]), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},

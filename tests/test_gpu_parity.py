@@ -420,9 +420,79 @@ def test_rpca_unsupported_paths_fail_loudly(eng):
     with pytest.raises(tlsq_amd.TlsqError):
         eng.rpca(np.ones((4, 4)) * (1 + 1j), nonnegA=True)           # max.(A, 0) has no complex method
     with pytest.raises(tlsq_amd.TlsqError):
-        eng.rpca(np.ones((4, 4)), svd=lambda Z, k: None)           # arbitrary closures cannot run on the GPU
+        eng.rpca(np.ones((4, 4)), svd="no such mode")
     with pytest.raises(tlsq_amd.TlsqError):
-        eng.rpca(np.ones((4, 4)), opnorm=lambda X: 1.0)
+        eng.rpca(np.ones((4, 4)), opnorm=3.0)
+
+
+def test_rpca_user_hooks_through_the_c_callbacks(eng):
+    """src/robustPCA.jl:168-169, test/runtests.jl:384-398: ANY `svd(Z, sv)` / `opnorm(X)` function of the host language.
+    The library copies the panel to the host and calls back (tlsq_svd_cb / tlsq_opnorm_cb).  With LAPACK behind both
+    hooks the run has to reproduce the default path: same iterations, same svp trajectory, A and E to 1e-8."""
+    from oracle import rpca_oracle as O
+    D, _, _ = O.synth_lowrank_sparse(700, 60, 5, seed=9)
+    calls = {"svd": 0, "opnorm": 0, "shapes": set()}
+
+    def my_svd(Z, sv):
+        calls["svd"] += 1
+        calls["shapes"].add(Z.shape)
+        return sla.svd(Z, full_matrices=False, lapack_driver="gesdd")
+
+    def my_opnorm(X):
+        calls["opnorm"] += 1
+        return sla.svdvals(X)[0]
+
+    A0, E0, s0, sv0, rep0 = eng.rpca(D, return_report=True)
+    A1, E1, s1, sv1, rep1 = eng.rpca(D, svd=my_svd, opnorm=my_opnorm, return_report=True)
+    assert rep1.iters_done == rep0.iters_done and rep1.svp_hist == rep0.svp_hist and sv1 == sv0
+    assert relerr(A1, A0) < 1e-8 and relerr(E1, E0) < 1e-8
+    assert calls["svd"] == rep0.iters_done - 1            # iteration 1 is the library's own full SVD (:193)
+    assert calls["opnorm"] == rep0.iters_done + 1         # set-up (:177) + one per iteration (:225)
+    assert calls["shapes"] == {(700, 60)}                 # the exact panel, no padding rows
+    # only one of the two hooks; a truncating svd hook (rank sv, like rsvd) behaves like the oracle with the same hook
+    trunc = lambda Z, sv: tuple(x[..., :sv] if i == 0 else (x[:sv] if i == 1 else x[:sv, :])
+                                for i, x in enumerate(sla.svd(Z, full_matrices=False)))
+    A2, E2, s2, sv2, rep2 = eng.rpca(D, svd=trunc, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D, svd=trunc)
+    assert rep2.iters_done == io.iters_done and rep2.svp_hist == io.svp_hist and sv2 == svo
+    assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8
+    # fp32 entry point: the hook receives float32 panels
+    seen = []
+    eng.rpca(D.astype(np.float32), opnorm=lambda X: (seen.append(X.dtype), float(sla.svdvals(X)[0]))[1], iters=3)
+    assert seen and all(dt == np.float32 for dt in seen)
+    # an exception inside a hook comes back as that exception, not as a crash across the C frames
+    class Boom(Exception):
+        pass
+
+    def bad(Z, sv):
+        raise Boom("hook failed")
+    with pytest.raises(Boom):
+        eng.rpca(D, svd=bad)
+
+
+def test_lowrankfilter_user_hooks_reference_thresholds(eng):         # test/runtests.jl:383-398 with real closures
+    rng = np.random.default_rng(1)
+    T = 1000
+    y = np.sin(0.1 * np.arange(1, T + 1))
+    y = y / np.quantile(np.abs(y), 0.9)
+    n = 20 * rng.standard_normal(T) * (rng.random(T) < 0.01) + 0.1 * rng.standard_normal(T)
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+
+    def rsvd(Z, sv, over=10, power=2):             # Halko-Martinsson-Tropp randomized SVD, like RandomizedLinAlg.rsvd
+        g = np.random.default_rng(sv).standard_normal((Z.shape[1], sv + over))
+        Q, _ = np.linalg.qr(Z @ g)
+        for _ in range(power):
+            Q, _ = np.linalg.qr(Z @ (Z.T @ Q))
+        Ub, S, Vt = np.linalg.svd(Q.T @ Z, full_matrices=False)
+        return (Q @ Ub)[:, :sv], S[:sv], Vt[:sv]
+
+    def rnorm(X, mvps=10):                         # RandomizedLinAlg.rnorm
+        g = np.random.default_rng(0).standard_normal((X.shape[1], mvps))
+        return 0.05 ** (-1.0 / mvps) * math.sqrt(2 / math.pi) * np.max(np.linalg.norm(X @ g, axis=0))
+
+    assert np.mean((y - qn(eng.lowrankfilter(y + n, opnorm=rnorm))) ** 2) / np.mean(n ** 2) < 0.001
+    assert np.mean((y - qn(eng.lowrankfilter(y + n, svd=rsvd))) ** 2) / np.mean(n ** 2) < 0.05
+    assert np.mean((y - qn(eng.lowrankfilter(y + n, svd=rsvd, opnorm=rnorm))) ** 2) / np.mean(n ** 2) < 0.05
 
 
 # --------------------------------------------------------------------------------------------
@@ -973,3 +1043,34 @@ def test_lowrankfilter_fp32(eng):                    # src/robustPCA.jl:119-128 
     y2 = np.stack([y32, np.cos(0.05 * np.arange(4000)).astype(np.float32)], axis=1)
     f2 = eng.lowrankfilter(y2, 30, lag=2, sv=3)
     assert f2.dtype == np.float32 and relerr(f2.astype(np.float64), O.lowrankfilter(y2.astype(np.float64), 30, lag=2, sv=3)) < 1e-3
+
+
+def test_tls_rtls_float32_methods(eng):
+    """The reference functions are generic in the element type (src/TotalLeastSquares.jl:63,152): Float32 in, Float32
+    out, through tlsq_tls_f32 / tlsq_rtls_f32 (fp32 panels, fp64 small-matrix work)."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((400, 5)).astype(np.float32)
+    x0 = rng.standard_normal(5).astype(np.float32)
+    y = (A @ x0 + 0.01 * rng.standard_normal(400)).astype(np.float32)
+    x = eng.tls(A, y)
+    assert x.dtype == np.float32
+    assert relerr(x.astype(np.float64), O.tls(A.astype(np.float64), y.astype(np.float64))) < 1e-4
+    ys = y.copy()
+    ys[rng.random(400) < 0.05] += 10.0
+    xr = eng.rtls(A, ys)
+    assert xr.dtype == np.float32
+    assert relerr(xr.astype(np.float64), O.rtls(A.astype(np.float64), ys.astype(np.float64))) < 5e-3
+    assert np.linalg.norm(xr - x0) < 0.1 * np.linalg.norm(eng.tls(A, ys) - x0) + 1e-2   # robust beats plain on outliers
+
+
+def test_lowrankfilter_wide_hankel_matrix(eng):
+    """two channels with a long window give a Hankel matrix with fewer rows than columns (K < n*D); the
+    library solves the transposed problem instead of forming a rank-deficient Gram."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(4)
+    T = 130
+    yy = np.column_stack([np.sin(0.2 * np.arange(T)), np.cos(0.31 * np.arange(T))]) + 0.05 * rng.standard_normal((T, 2))
+    n = 60                                               # K = 71 rows, n*D = 120 columns
+    assert (T - n + 1) < 2 * n
+    assert relerr(eng.lowrankfilter(yy, n), O.lowrankfilter(yy, n)) < 1e-8

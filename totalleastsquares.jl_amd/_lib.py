@@ -12,12 +12,15 @@ LIB_PATH = os.environ.get("TLSQ_LIB") or os.path.join(_HERE, "libtlsqhip.so")  #
 TLSQ_OK, TLSQ_MAXITER = 0, 1
 TLSQ_ERR_ARG, TLSQ_ERR_HIP, TLSQ_ERR_OOM, TLSQ_ERR_COMM, TLSQ_ERR_UNSUPPORTED, TLSQ_ERR_NOCONV = -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
-SVD_FULL, SVD_RANDOMIZED = 0, 1
-OPNORM_EXACT, OPNORM_POWER = 0, 1
+SVD_FULL, SVD_RANDOMIZED, SVD_CALLBACK = 0, 1, 2
+OPNORM_EXACT, OPNORM_POWER, OPNORM_CALLBACK = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 GA_MEAN, GA_TRIMMED_MEAN, GA_MEDIAN = 0, 1, 2
 
 ON_ITER = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_int64, C.c_void_p)
+SVD_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                     C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p)
+OPNORM_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
 
 
 class RpcaOpts(C.Structure):
@@ -27,7 +30,7 @@ class RpcaOpts(C.Structure):
                 ("nukeA", C.c_int32), ("svd_mode", C.c_int32), ("opnorm_mode", C.c_int32),
                 ("opnorm_mvps", C.c_int32), ("memory", C.c_int32),
                 ("m_global", C.c_int64), ("seed", C.c_uint64),
-                ("on_iter", ON_ITER), ("user", C.c_void_p)]
+                ("on_iter", ON_ITER), ("user", C.c_void_p), ("svd_cb", SVD_CB), ("opnorm_cb", OPNORM_CB)]
 
 
 class RpcaInfo(C.Structure):
@@ -40,7 +43,8 @@ class RpcaInfo(C.Structure):
                 ("ms_gram", C.c_double), ("ms_eig", C.c_double), ("ms_rebuild", C.c_double),
                 ("ms_opnorm", C.c_double),
                 ("eig_full", C.c_int64), ("eig_fast", C.c_int64), ("subspace_steps", C.c_int64),
-                ("residual_stores_skipped", C.c_int64)]
+                ("residual_stores_skipped", C.c_int64),
+                ("hbm_bytes_sweeps", C.c_double), ("hbm_bytes", C.c_double)]
 
 
 class GaOpts(C.Structure):
@@ -61,7 +65,7 @@ EXPORTS = [
     "tlsq_rpca_f64", "tlsq_rpca_f32",
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
-    "tlsq_lowrankfilter_f64", "tlsq_lowrankfilter_f32", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_from_vt_f64",
+    "tlsq_lowrankfilter_f64", "tlsq_lowrankfilter_f32", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_f32", "tlsq_rtls_f32", "tlsq_tls_from_vt_f64",
     "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_c64",
     "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
@@ -118,6 +122,8 @@ def load():
                                            P(RpcaInfo)]
     lib.tlsq_tls_f64.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64, i32]
     lib.tlsq_rtls_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, P(RpcaOpts), vp, i64, P(RpcaInfo)]
+    lib.tlsq_tls_f32.argtypes = lib.tlsq_tls_f64.argtypes
+    lib.tlsq_rtls_f32.argtypes = lib.tlsq_rtls_f64.argtypes
     lib.tlsq_tls_from_vt_f64.argtypes = [vp, i64, i64, i64, vp, i64]
     lib.tlsq_rpca_c64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, P(i64), P(RpcaInfo)]
     lib.tlsq_rpca_batched_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, vp, vp, vp, vp, vp, vp, vp]

@@ -175,7 +175,10 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
     // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
     // hankel option of rpca works on the exact shape
-    const int64_t Kp = (opts && opts->hankel) ? K : (K + 15) / 16 * 16;
+    // (a caller's hook sees the panel; a wide Hankel matrix goes through rpca_entry in place: same workspace slots)
+    const bool exact_shape = (opts && (opts->hankel || opts->svd_mode == TLSQ_SVD_CALLBACK ||
+                                       opts->opnorm_mode == TLSQ_OPNORM_CALLBACK)) || (K < LD && !sharded);
+    const int64_t Kp = exact_shape ? K : (K + 15) / 16 * 16;
     void *dy, *H, *A, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
     TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
@@ -198,7 +201,23 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
             ro.hankel_y = yw;
             ro.hankel_K = K;
         }
-        status = rpca_core<T>(h, (const T*)H, Kp, LD, ro, &oo, (T*)A, (T*)E, nullptr, nullptr, nullptr, 0, nullptr, info);
+        if (std::min(Kg, LD) > kGramMaxN)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: min(K, n*D) = %lld exceeds %lld, the largest Gram "
+                           "dimension of this release", (long long)std::min(Kg, LD), (long long)kGramMaxN);
+        if (K < LD && !sharded) {
+            // a wide Hankel matrix (several channels / lag > 1 with a long window): the Gram of the panel would be
+            // structurally rank deficient - go through the general entry, which solves the transposed problem
+            oo.memory = TLSQ_MEM_DEVICE;
+            tlsq_rpca_info inner;
+            memset(&inner, 0, sizeof(inner));
+            if (info) inner = *info;
+            if (std::isnan(oo.tol)) oo.tol = 1e-3;   // the lowrankfilter default (:119)
+            status = rpca_entry<T>(h, (const T*)H, K, LD, Kp, &oo, (T*)A, Kp, (T*)E, Kp, nullptr, K, nullptr, nullptr,
+                                   std::min(K, LD), nullptr, info ? &inner : nullptr);
+            if (info) *info = inner;
+        } else {
+            status = rpca_core<T>(h, (const T*)H, Kp, LD, ro, &oo, (T*)A, (T*)E, nullptr, nullptr, nullptr, 0, nullptr, info);
+        }
         if (status < 0) return status;
     } else {                                                                                  // :123-126
         SmallSvd s;
@@ -293,16 +312,18 @@ int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t 
     return tls_partition_solve(Vt, ncols, ldVt, n, x, ldx);
 }
 
-// full right-singular basis of a device matrix (M x nc, ld) as Vt on the host (nc x nc)
-static int vt_of(tlsq_handle h, const double* dAy, int64_t M, int64_t nc, int64_t ld,
-                 std::vector<double>& Vt) {
+}  // extern "C"
+
+// full right-singular basis of a device matrix (M x nc, ld; fp64 or fp32) as Vt on the host (nc x nc, fp64)
+template <typename T>
+static int vt_of(tlsq_handle h, const T* dAy, int64_t M, int64_t nc, int64_t ld, std::vector<double>& Vt) {
     SmallSvd s;
     double* V = nullptr;
     int64_t sweeps = 0;
     // TSQR route: tls! takes the right singular vectors of the SMALLEST singular values (V[:, n+1:end],
     // src/TotalLeastSquares.jl:66-68), which the Gram route only resolves to eps * cond(Ay)^2
-    if (M >= nc && nc <= kFullEigMaxN && !h->comm) TLSQ_TRY(svd_via_r<double>(h, dAy, M, nc, ld, &V, s, &sweeps));
-    else TLSQ_TRY(svd_via_gram<double>(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
+    if (M >= nc && nc <= kFullEigMaxN && !h->comm) TLSQ_TRY(svd_via_r<T>(h, dAy, M, nc, ld, &V, s, &sweeps));
+    else TLSQ_TRY(svd_via_gram<T>(h, dAy, M, nc, ld, &V, s, &sweeps, nullptr));
     std::vector<double> hv((size_t)nc * nc);
     TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)nc * nc * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -312,81 +333,97 @@ static int vt_of(tlsq_handle h, const double* dAy, int64_t M, int64_t nc, int64_
     return TLSQ_OK;
 }
 
-int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
-                 double* x, int64_t ldx, int memory) {
+// x (n x q, ldx, type T) <- the fp64 solution hx (n x q, ld n), to host or device memory
+template <typename T>
+static int put_x(tlsq_handle h, const std::vector<double>& hx, int64_t n, int64_t q, T* x, int64_t ldx, bool dev) {
+    std::vector<T> tx((size_t)n * q);
+    for (size_t i = 0; i < tx.size(); ++i) tx[i] = (T)hx[i];
+    if (dev) {
+        TLSQ_TRY(copy2d(h, x, ldx, tx.data(), n, n, q, sizeof(T), hipMemcpyHostToDevice));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    } else {
+        for (int64_t a = 0; a < q; ++a)
+            for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = tx[(size_t)(i + a * n)];
+    }
+    return TLSQ_OK;
+}
+
+template <typename T>
+static int tls_impl(tlsq_handle h, const T* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n, T* x, int64_t ldx,
+                    int memory) {
     TLSQ_TRY(check_handle(h));
     if (!Ay || !x || M <= 0 || ncols <= 1 || n <= 0 || n >= ncols || ldAy < M || ldx < n)
         return set_err(h, TLSQ_ERR_ARG, "tls: bad argument");
     TLSQ_HIP(h, hipSetDevice(h->device));
-    const double* dAy = Ay;
+    const T* dAy = Ay;
     int64_t ld = ldAy;
     if (memory != TLSQ_MEM_DEVICE) {
         void* p;
-        TLSQ_TRY(ws_get(h, WS_D, (size_t)M * ncols * 8, &p));
-        TLSQ_TRY(copy2d(h, p, M, Ay, ldAy, M, ncols, 8, hipMemcpyHostToDevice));
-        dAy = (const double*)p;
+        TLSQ_TRY(ws_get(h, WS_D, (size_t)M * ncols * sizeof(T), &p));
+        TLSQ_TRY(copy2d(h, p, M, Ay, ldAy, M, ncols, sizeof(T), hipMemcpyHostToDevice));
+        dAy = (const T*)p;
         ld = M;
     }
     std::vector<double> Vt;
-    TLSQ_TRY(vt_of(h, dAy, M, ncols, ld, Vt));
+    TLSQ_TRY(vt_of<T>(h, dAy, M, ncols, ld, Vt));
     const int64_t q = ncols - n;
-    if (memory == TLSQ_MEM_DEVICE) {
-        std::vector<double> hx((size_t)n * q);
-        int st = tls_partition_solve(Vt.data(), ncols, ncols, n, hx.data(), n);
-        if (st < 0) return set_err(h, st, "tls: partition solve failed");
-        TLSQ_TRY(copy2d(h, x, ldx, hx.data(), n, n, q, 8, hipMemcpyHostToDevice));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        return TLSQ_OK;
-    }
-    int st = tls_partition_solve(Vt.data(), ncols, ncols, n, x, ldx);
+    std::vector<double> hx((size_t)n * q);
+    const int st = tls_partition_solve(Vt.data(), ncols, ncols, n, hx.data(), n);   // :65-69
     if (st < 0) return set_err(h, st, "tls: partition solve failed");
-    return TLSQ_OK;
+    return put_x<T>(h, hx, n, q, x, ldx, memory == TLSQ_MEM_DEVICE);
 }
 
-int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA, const double* y,
-                  int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, double* x, int64_t ldx,
-                  tlsq_rpca_info* info) {
+template <typename T>
+static int rtls_impl(tlsq_handle h, const T* A, int64_t M, int64_t n, int64_t ldA, const T* y, int64_t q, int64_t ldy,
+                     const tlsq_rpca_opts* opts, T* x, int64_t ldx, tlsq_rpca_info* info) {
     TLSQ_TRY(check_handle(h));
     if (!A || !y || !x || M <= 0 || n <= 0 || q <= 0 || ldA < M || ldy < M || ldx < n)
         return set_err(h, TLSQ_ERR_ARG, "rtls: bad argument");
     TLSQ_HIP(h, hipSetDevice(h->device));
-    if (info) {
-        double* ch = info->cost_hist;
-        int64_t* sh = info->svp_hist;
-        int64_t cap = info->hist_capacity;
-        memset(info, 0, sizeof(*info));
-        info->cost_hist = ch;
-        info->svp_hist = sh;
-        info->hist_capacity = cap;
-    }
+    reset_info(info);
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
     const int64_t nc = n + q;
     void *AA, *Ah, *Eh;
-    TLSQ_TRY(ws_get(h, WS_D, (size_t)M * nc * 8, &AA));
-    TLSQ_TRY(ws_get(h, WS_A, (size_t)M * nc * 8, &Ah));
-    TLSQ_TRY(ws_get(h, WS_E, (size_t)M * nc * 8, &Eh));
+    TLSQ_TRY(ws_get(h, WS_D, (size_t)M * nc * sizeof(T), &AA));
+    TLSQ_TRY(ws_get(h, WS_A, (size_t)M * nc * sizeof(T), &Ah));
+    TLSQ_TRY(ws_get(h, WS_E, (size_t)M * nc * sizeof(T), &Eh));
     const hipMemcpyKind kin = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    TLSQ_TRY(copy2d(h, AA, M, A, ldA, M, n, 8, kin));                                  // AA = [A y]  :153
-    TLSQ_TRY(copy2d(h, (double*)AA + (size_t)M * n, M, y, ldy, M, q, 8, kin));
-    ResolvedOpts ro = resolve(opts, M, nc, std::sqrt(std::numeric_limits<double>::epsilon()));
+    TLSQ_TRY(copy2d(h, AA, M, A, ldA, M, n, sizeof(T), kin));                          // AA = [A y]  :153
+    TLSQ_TRY(copy2d(h, (T*)AA + (size_t)M * n, M, y, ldy, M, q, sizeof(T), kin));
+    ResolvedOpts ro = resolve(opts, M, nc, std::sqrt((double)std::numeric_limits<T>::epsilon()));
     ro.nukeA = false;                                                                 // :154
     std::vector<double> Vt((size_t)nc * nc, 0.0);
     const int64_t d = std::min(ro.m_global, nc);
     if (d < nc) return set_err(h, TLSQ_ERR_ARG, "rtls: needs M >= n+q");
-    int status = rpca_core<double>(h, (const double*)AA, M, nc, ro, opts, (double*)Ah, (double*)Eh, nullptr,
-                           nullptr, Vt.data(), nc, nullptr, info);
+    const int status = rpca_core<T>(h, (const T*)AA, M, nc, ro, opts, (T*)Ah, (T*)Eh, nullptr, nullptr, Vt.data(), nc,
+                                    nullptr, info);
     if (status < 0) return status;
     std::vector<double> hx((size_t)n * q);
-    int st = tls_partition_solve(Vt.data(), nc, nc, n, hx.data(), n);                 // :155
+    const int st = tls_partition_solve(Vt.data(), nc, nc, n, hx.data(), n);           // :155
     if (st < 0) return set_err(h, st, "rtls: partition solve failed");
-    if (dev) {
-        TLSQ_TRY(copy2d(h, x, ldx, hx.data(), n, n, q, 8, hipMemcpyHostToDevice));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    } else {
-        for (int64_t a = 0; a < q; ++a)
-            for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = hx[i + a * n];
-    }
+    TLSQ_TRY(put_x<T>(h, hx, n, q, x, ldx, dev));
     return status;
+}
+
+extern "C" {
+
+int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
+                 double* x, int64_t ldx, int memory) {
+    return tls_impl<double>(h, Ay, M, ncols, ldAy, n, x, ldx, memory);
+}
+int tlsq_tls_f32(tlsq_handle h, const float* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
+                 float* x, int64_t ldx, int memory) {
+    return tls_impl<float>(h, Ay, M, ncols, ldAy, n, x, ldx, memory);
+}
+int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA, const double* y,
+                  int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, double* x, int64_t ldx,
+                  tlsq_rpca_info* info) {
+    return rtls_impl<double>(h, A, M, n, ldA, y, q, ldy, opts, x, ldx, info);
+}
+int tlsq_rtls_f32(tlsq_handle h, const float* A, int64_t M, int64_t n, int64_t ldA, const float* y,
+                  int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, float* x, int64_t ldx,
+                  tlsq_rpca_info* info) {
+    return rtls_impl<float>(h, A, M, n, ldA, y, q, ldy, opts, x, ldx, info);
 }
 
 // ---- ComplexF64 rpca ---------------------------------------------------------------------------------------

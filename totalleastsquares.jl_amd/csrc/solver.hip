@@ -829,8 +829,26 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool sumsq_ready = false;   // the two accumulator sets of the Frobenius bound have been cleared
     static const double rskip_margin = [] { const char* e = getenv("TLSQ_RSKIP_MARGIN"); return e ? atof(e) : 8.0; }();
     int64_t sweeps = 0;
-    const bool hook_svd = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED;       // `svd = rsvd`-style hook
-    const bool hook_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_POWER;   // `opnorm = x->rnorm(x,mvps)`
+    // arbitrary hooks of the host language (src/robustPCA.jl:168-169): the panel visits the host and the caller's
+    // own function runs there, on the calling thread ("the CPU path with the user's closure")
+    const bool cb_svd = opts && opts->svd_mode == TLSQ_SVD_CALLBACK && opts->svd_cb;
+    const bool cb_opnorm = opts && opts->opnorm_mode == TLSQ_OPNORM_CALLBACK && opts->opnorm_cb;
+    if (opts && ((opts->svd_mode == TLSQ_SVD_CALLBACK && !opts->svd_cb) ||
+                 (opts->opnorm_mode == TLSQ_OPNORM_CALLBACK && !opts->opnorm_cb)))
+        return set_err(h, TLSQ_ERR_ARG, "rpca: callback mode without a callback");
+    if ((cb_svd || cb_opnorm) && h->comm)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: svd / opnorm callbacks need the whole matrix on one GPU (not row shards)");
+    std::vector<T> cbZ, cbU, cbS, cbVt;
+    auto opnorm_callback = [&](const T* P, double* out) -> int {
+        cbZ.resize((size_t)n);
+        TLSQ_HIP(h, hipMemcpyAsync(cbZ.data(), P, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        *out = opts->opnorm_cb(cbZ.data(), M, N, M, opts->user);
+        if (!std::isfinite(*out) || *out < 0.0) return set_err(h, TLSQ_ERR_ARG, "rpca: the opnorm callback returned %g", *out);
+        return TLSQ_OK;
+    };
+    const bool hook_svd = (opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED) || cb_svd;   // `svd = rsvd`-style hook
+    const bool hook_opnorm = (opts && opts->opnorm_mode == TLSQ_OPNORM_POWER) || cb_opnorm;   // `opnorm = x->rnorm(x,mvps)`
     const int mvps = opts && opts->opnorm_mvps > 0 ? opts->opnorm_mvps : 10;
     const uint64_t seed = opts ? opts->seed : 0;
 
@@ -852,7 +870,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         o.ldZ = M;
         return o;
     };
-    if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
+    if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
+    else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
     else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
@@ -887,6 +906,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool v_is_full = false;
     double sigma_top_prev = 0.0;
     int64_t n_rroute = 0;   // iterations whose SVD step was served by the TSQR route
+    // HBM traffic the panel-sized kernels of this call have to move (algorithmic bytes of what was launched: panel
+    // passes x M x N x sizeof(T)); reported in tlsq_rpca_info
+    const double panel_bytes = (double)n * sizeof(T);
+    double hbm_sweeps = 0.0, hbm_other = 0.0;
     // Relative uncertainty of an eigenvalue of the computed Gram matrix (rounding of Z'Z accumulated over M rows, the
     // small solvers' own eps N lambda_max, Ritz residuals <= 2e-13 lambda_max per pair): see SubspaceState::noise_rel.
     // Large mode has no other solver, so no window there.
@@ -916,7 +939,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         T* Z = Zbuf[cur];
         pt.mark();
         if (!have_next)
+        {
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
+            hbm_sweeps += 5.0 * panel_bytes;
+        }
         pt.mark(have_next);
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
@@ -951,7 +977,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                            rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
             TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
             r_last = svp;
-            if (!fuse_rebuild) TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+            if (svp > 0) hbm_other += panel_bytes;                      // T = Z Vg reads Z once
+            if (!fuse_rebuild) {
+                TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+                hbm_other += panel_bytes;                               // A = T Vs' written once
+            }
             a_pending = fuse_rebuild;
             rebuilt = true;
             return TLSQ_OK;
@@ -962,6 +992,59 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // a threshold at the noise level of G, tiny matrices — goes through the TSQR route (svd_via_r), whose
         // singular values are as accurate as LAPACK's.  Large mode (N > 2048) and the randomized hook keep to the
         // subspace solver.
+        if (cb_svd && k >= 2) {
+            // The caller's own `svd(Z, sv)` (:195-197): Z goes to the host, the hook fills U, S, Vt there (on the calling
+            // thread), and A = U[:,1:svp] diag(S - 1/mu) Vt[1:svp,:] is rebuilt from the returned factors exactly as the
+            // reference does (:205-213) - the hook may be approximate, so Z V V' is not a substitute.
+            pt.mark(true);
+            const int64_t dd = std::min(M, N);
+            cbZ.resize((size_t)n);
+            cbU.resize((size_t)M * dd);
+            cbS.resize((size_t)dd);
+            cbVt.resize((size_t)dd * N);
+            TLSQ_HIP(h, hipMemcpyAsync(cbZ.data(), Z, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            int64_t kout = 0;
+            const int cst = opts->svd_cb(cbZ.data(), M, N, M, sv, cbU.data(), M, cbS.data(), cbVt.data(), dd, &kout,
+                                         opts->user);
+            if (cst != 0 || kout < 0 || kout > dd)
+                return set_err(h, TLSQ_ERR_ARG, "rpca: the svd callback failed (status %d, %lld triplets)", cst, (long long)kout);
+            svp = 0;                                                   // :198
+            for (int64_t i = 0; i < kout; ++i) svp += ((double)cbS[(size_t)i] >= inv_mu) ? 1 : 0;
+            sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+            sigma_top = kout > 0 ? (double)cbS[0] : 0.0;
+            sigma_top_prev = sigma_top;
+            mu_next = std::min(mu * ro.rho, mubar);                    // :223
+            fuse = !no_fuse && k < ro.iters;
+            fuse_rebuild = false;
+            Tm_last = Vs_last = nullptr;
+            r_last = svp;
+            if (svp > 0) {
+                // the first svp triplets in the hook's order (the reference indexes 1:svp as well)
+                std::vector<double> hT((size_t)M * svp), hV((size_t)N * svp);
+                for (int64_t p = 0; p < svp; ++p) {
+                    const double sg = (double)cbS[(size_t)p];
+                    const double gp = ro.nukeA ? sg - inv_mu : sg;     // :205-213
+                    for (int64_t i = 0; i < M; ++i) hT[(size_t)(i + p * M)] = (double)cbU[(size_t)(i + p * M)] * gp;
+                    for (int64_t j = 0; j < N; ++j) hV[(size_t)(j + p * N)] = (double)cbVt[(size_t)(p + j * dd)];
+                }
+                void *T1, *Vsb;
+                TLSQ_TRY(ws_get(h, WS_T, (size_t)M * svp * 8, &T1));
+                TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vsb));
+                TLSQ_HIP(h, hipMemcpyAsync(T1, hT.data(), hT.size() * 8, hipMemcpyHostToDevice, h->stream));
+                TLSQ_HIP(h, hipMemcpyAsync(Vsb, hV.data(), hV.size() * 8, hipMemcpyHostToDevice, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                Tm_last = (const double*)T1;
+                Vs_last = (const double*)Vsb;
+            }
+            pt.mark(true);
+            TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
+            a_pending = false;
+            rebuilt = true;
+            V = nullptr;
+            v_is_full = false;
+            ++sub.fast;
+        } else {
         const bool hook_now = hook_svd && k >= 2;
         bool r_route = !large && !hook_now && (!use_subspace || hook_svd);
         if (!r_route && !large && !hook_now && sigma_top_prev > 0.0 &&
@@ -972,7 +1055,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const bool gram_queued_earlier = g_ready || implicit_gram;
         if (!implicit_gram) {
             if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
-            else TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+            else {
+                TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+                hbm_other += panel_bytes;
+            }
             op = GramOp();
             op.G = G;
         }
@@ -1054,6 +1140,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         v_is_full = r_route && !hook_now;
         if (!rebuilt) TLSQ_TRY(count_and_rebuild(!rebuild_marked));
         if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        }   // !(cb_svd && k >= 2)
         if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
 
         // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
@@ -1087,13 +1174,16 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                                                      svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
                                                      (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
                                                      (const T*)ro.hankel_y, ro.hankel_K));
+            hbm_sweeps += ((Rst ? 7.0 : 6.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
                                              ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next));
+            hbm_sweeps += (Rst ? 8.0 : 7.0) * panel_bytes;
         } else {
             TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
+            hbm_sweeps += 6.0 * panel_bytes;
         }
         pt.mark();
         mu = mu_next;
@@ -1121,6 +1211,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             if (!r_next && !implicit_gram) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
                 TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
+                hbm_other += panel_bytes;
                 g_ready = true;
             }
             pt.mark();
@@ -1157,6 +1248,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     a_pending = false;
                 }
                 TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
+                hbm_sweeps += 4.0 * panel_bytes;
             }
         } else {
             pt.mark();   // (empty read-back and "next Gram" windows)
@@ -1165,6 +1257,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
         if (cost_skipped) {
             // nothing to evaluate
+        } else if (cb_opnorm) {
+            TLSQ_TRY(opnorm_callback(R, &rn));                                                    // :225 caller's hook
+            cost = rn / d_norm;
         } else if (hook_opnorm) {
             TLSQ_TRY(opnorm_power<T>(h, R, M, N, M, mvps, seed + 7919ull * (uint64_t)k, &rn));   // :225 hook
             cost = rn / d_norm;
@@ -1175,6 +1270,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
             if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-8, &rn, stop_sigma));
             else TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
+            hbm_other += panel_bytes;
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
                 if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
@@ -1223,6 +1319,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
         info->reserved = (int32_t)n_rroute;   // iterations served by the TSQR route
+        info->hbm_bytes_sweeps = hbm_sweeps;
+        info->hbm_bytes = hbm_sweeps + hbm_other;
         info->residual_stores_skipped = n_rskip;
     }
     if (sv_out) *sv_out = sv;
@@ -1266,7 +1364,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         return converged ? TLSQ_OK : TLSQ_MAXITER;
     }
-    if ((S_host || Vt_host || U_dev) && V && !v_is_full) {
+    if ((S_host || Vt_host || U_dev) && !large && !v_is_full) {
         // the last iteration used a subspace path: the caller wants the complete SVD of the last Z (:194, :238) -
         // through the TSQR route, so that the small singular values and their vectors are as accurate as LAPACK's
         TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V, s, &sweeps));
@@ -1567,7 +1665,9 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     // panels — zero rows change nothing in the algorithm (lambda and d use the true size through m_global).
     const int64_t Mw = transposed ? N : M;          // rows of the working (tall) problem
     const int64_t Nw = transposed ? M : N;
-    const bool pad = (Mw % 16 != 0) && !ro.hankel;  // soft_hankel! would see the extra rows: keep the exact shape there
+    const bool has_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
+    // soft_hankel! would see the extra rows, and so would a caller's svd / opnorm hook: keep the exact shape there
+    const bool pad = (Mw % 16 != 0) && !ro.hankel && !has_cb;
     const int64_t Mp = pad ? (Mw + 15) / 16 * 16 : Mw;
     const size_t nw = (size_t)Mp * Nw;
 

@@ -58,6 +58,8 @@ class RpcaReport:
         self.eig_full, self.eig_fast = int(info.eig_full), int(info.eig_fast)
         self.subspace_steps = int(info.subspace_steps)
         self.residual_stores_skipped = int(info.residual_stores_skipped)
+        self.tsqr_iterations = int(info.reserved)
+        self.hbm_bytes_sweeps, self.hbm_bytes = float(info.hbm_bytes_sweeps), float(info.hbm_bytes)
         self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
 
 
@@ -108,28 +110,68 @@ class Engine:
 
     @staticmethod
     def _hook_modes(svd, opnorm):
-        """Map the reference's `svd` / `opnorm` keyword hooks (src/robustPCA.jl:168-169) onto the built-in
-        modes.  None = LinearAlgebra.svd! / opnorm.  "randomized" (or "rsvd", "rsvd_fnkz", "tsvd") = rank-sv
-        randomized SVD for k >= 2;  "power" / ("power", mvps) = the rnorm(x, mvps) estimator.  Arbitrary
-        callables cannot run on the GPU."""
+        """Map the reference's `svd` / `opnorm` keyword hooks (src/robustPCA.jl:168-169) onto the library's modes.
+        None = LinearAlgebra.svd! / opnorm.  "randomized" (or "rsvd", "rsvd_fnkz", "tsvd") = rank-sv randomized SVD
+        for k >= 2 on the GPU;  "power" / ("power", mvps) = the rnorm(x, mvps) estimator on the GPU.  Any other
+        CALLABLE is the user's own function: svd(Z, sv) -> (U, S, Vt) (or an object with .U, .S, .Vt), opnorm(X) ->
+        float; it runs on the host through the C callback (the panel is copied out for every call)."""
         svd_mode, opn_mode, mvps = L.SVD_FULL, L.OPNORM_EXACT, 10
         if svd is not None:
             if isinstance(svd, str) and svd.lower() in ("randomized", "rsvd", "rsvd_fnkz", "tsvd"):
                 svd_mode = L.SVD_RANDOMIZED
+            elif callable(svd):
+                svd_mode = L.SVD_CALLBACK
             else:
-                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom svd hooks cannot run on the GPU path; use svd='randomized'")
+                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "svd hook: a callable, or svd='randomized'")
         if opnorm is not None:
             if isinstance(opnorm, tuple) and len(opnorm) == 2 and str(opnorm[0]).lower() in ("power", "rnorm"):
                 opn_mode, mvps = L.OPNORM_POWER, int(opnorm[1])
             elif isinstance(opnorm, str) and opnorm.lower() in ("power", "rnorm"):
                 opn_mode = L.OPNORM_POWER
+            elif callable(opnorm):
+                opn_mode = L.OPNORM_CALLBACK
             else:
-                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "custom opnorm hooks cannot run on the GPU path; use opnorm=('power', mvps)")
+                raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, "opnorm hook: a callable, or opnorm=('power', mvps)")
         return svd_mode, opn_mode, mvps
+
+    @staticmethod
+    def _wrap_hooks(svd, opnorm, dt, errbox):
+        """ctypes callbacks around Python callables (kept alive by the caller for the duration of the call)"""
+        ct = C.c_float if dt == np.float32 else C.c_double
+
+        def view(p, rows, cols, ld):   # column-major (rows x cols, ld) host matrix behind a raw pointer
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(cols, ld)).T[:rows]
+
+        svd_cb = opn_cb = None
+        if callable(svd):
+            def _svd(Zp, M, N, ldZ, sv, Up, ldU, Sp, Vtp, ldVt, kout, user):
+                try:
+                    r = svd(np.array(view(Zp, M, N, ldZ)), int(sv))
+                    U, S, Vt = (r.U, r.S, r.Vt) if hasattr(r, "Vt") else r
+                    k = min(len(S), min(M, N))
+                    view(Up, M, min(M, N), ldU)[:, :k] = np.asarray(U)[:, :k]
+                    np.ctypeslib.as_array(C.cast(Sp, C.POINTER(ct)), shape=(min(M, N),))[:k] = np.asarray(S)[:k]
+                    view(Vtp, min(M, N), N, ldVt)[:k, :] = np.asarray(Vt)[:k, :]
+                    kout[0] = k
+                    return 0
+                except Exception as e:   # noqa: BLE001  (must not propagate through the C frames)
+                    errbox.append(e)
+                    return 1
+            svd_cb = L.SVD_CB(_svd)
+        if callable(opnorm):
+            def _opn(Xp, M, N, ldX, user):
+                try:
+                    return float(opnorm(np.array(view(Xp, M, N, ldX))))
+                except Exception as e:   # noqa: BLE001
+                    errbox.append(e)
+                    return float("nan")
+            opn_cb = L.OPNORM_CB(_opn)
+        return svd_cb, opn_cb
 
     def make_opts(self, *, lam=None, maxrank=None, iters=None, tol=None, rho=None, nonnegA=False,
                   nonnegE=False, hankel=False, nukeA=True, memory=L.MEM_HOST, m_global=0,
-                  svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, opnorm_mvps=10, seed=0, on_iter=None):
+                  svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, opnorm_mvps=10, seed=0, on_iter=None,
+                  svd_cb=None, opnorm_cb=None):
         o = L.RpcaOpts()
         self.lib.tlsq_rpca_opts_default(C.byref(o))
         if lam is not None:
@@ -149,6 +191,10 @@ class Engine:
         o.opnorm_mvps, o.seed = int(opnorm_mvps), int(seed)
         if on_iter is not None:
             o.on_iter = on_iter
+        if svd_cb is not None:
+            o.svd_cb = svd_cb
+        if opnorm_cb is not None:
+            o.opnorm_cb = opnorm_cb
         return o
 
     @staticmethod
@@ -184,6 +230,8 @@ class Engine:
         decomposition after the loop); cost_history=False lets the library settle only `cost < tol` per iteration
         (what a plain, non-verbose Julia call observes)."""
         svd_mode, opn_mode, mvps = self._hook_modes(svd, opnorm)
+        if int(iters) < 1:   # (the reference leaves `s` undefined and throws for iters = 0, src/robustPCA.jl:185,238)
+            raise ValueError("iters must be >= 1")
         D = np.asarray(D)
         if np.iscomplexobj(D):
             if svd_mode != L.SVD_FULL or opn_mode != L.OPNORM_EXACT:
@@ -205,16 +253,22 @@ class Engine:
             def _print(k, cost, svp, user):
                 print(f"{k} cost: {float(f'{cost:.4g}')}")                 # :226
             cb = L.ON_ITER(_print)
+        errbox = []
+        svd_cb, opn_cb = self._wrap_hooks(svd, opnorm, dt, errbox)
         o = self.make_opts(lam=lam, maxrank=maxrank, iters=iters, tol=tol, rho=rho, nonnegA=nonnegA,
                            nonnegE=nonnegE, hankel=hankel, nukeA=nukeA, m_global=m_global, on_iter=cb,
-                           svd_mode=svd_mode, opnorm_mode=opn_mode, opnorm_mvps=mvps, seed=kwargs.get("seed", 0))
+                           svd_mode=svd_mode, opnorm_mode=opn_mode, opnorm_mvps=mvps, seed=kwargs.get("seed", 0),
+                           svd_cb=svd_cb, opnorm_cb=opn_cb)
         info, cost, svp = self._info(int(iters), cost_history)
         sv = C.c_int64(0)
         fn = self.lib.tlsq_rpca_f32 if dt == np.float32 else self.lib.tlsq_rpca_f64
-        st = self._check(fn(
+        st = fn(
             self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
             _ptr(U) if U is not None else None, M, _ptr(S) if want_s else None, _ptr(Vt) if want_s else None, d,
-            C.byref(sv), C.byref(info)))
+            C.byref(sv), C.byref(info))
+        if errbox:
+            raise errbox[0]          # the user's hook raised: surface its own exception
+        st = self._check(st)
         rep = RpcaReport(info, cost, svp)
         if verbose and rep.converged:
             print("converged")                                             # :229
@@ -310,7 +364,8 @@ class Engine:
                       cost_history=True, **kw):
         """src/robustPCA.jl:119-128.  cost_history=False: like a plain Julia call, nobody looks at the
         per-iteration cost, so the library only settles `cost < tol` (same result, less work)."""
-        svd_mode, opn_mode, mvps = self._hook_modes(svd, kw.pop("opnorm", None))
+        opnorm = kw.pop("opnorm", None)
+        svd_mode, opn_mode, mvps = self._hook_modes(svd, opnorm)
         y = np.asarray(y)
         dt = np.float32 if y.dtype == np.float32 else np.float64      # eltype(y) as in the reference (generic T)
         y = np.asarray(y, dtype=dt)
@@ -326,13 +381,17 @@ class Engine:
         cb = None
         if verbose:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
+        errbox = []
+        svd_cb, opn_cb = self._wrap_hooks(svd, opnorm, dt, errbox)
         o = self.make_opts(iters=iters, tol=tol, on_iter=cb, svd_mode=svd_mode, opnorm_mode=opn_mode,
-                           opnorm_mvps=mvps, seed=kw.pop("seed", 0), **allowed)
+                           opnorm_mvps=mvps, seed=kw.pop("seed", 0), svd_cb=svd_cb, opnorm_cb=opn_cb, **allowed)
         info, cost, svp = self._info(iters, cost_history)
         yf = np.empty((Nx, Dch), dtype=dt, order="F")
         fn = self.lib.tlsq_lowrankfilter_f32 if dt == np.float32 else self.lib.tlsq_lowrankfilter_f64
-        st = self._check(fn(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag), int(sv), C.byref(o), _ptr(yf), Nx,
-                            C.byref(info)))
+        st = fn(self.h, _ptr(y2), Nx, Dch, Nx, int(n), int(lag), int(sv), C.byref(o), _ptr(yf), Nx, C.byref(info))
+        if errbox:
+            raise errbox[0]
+        st = self._check(st)
         rep = RpcaReport(info, cost, svp)
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}, tol: {tol}")
@@ -352,25 +411,32 @@ class Engine:
             if st < 0:
                 raise TlsqError(st, "tls_from_vt failed")
             return x
-        Af = _f(Ay)
+        Ay = np.asarray(Ay)
+        dt = np.float32 if Ay.dtype == np.float32 else np.float64     # generic element type like the reference (:63)
+        Af = _f(Ay, dt)
         M, nc = Af.shape
-        x = np.empty((n, nc - n), dtype=np.float64, order="F")
-        self._check(self.lib.tlsq_tls_f64(self.h, _ptr(Af), M, nc, M, n, _ptr(x), n, L.MEM_HOST))
+        x = np.empty((n, nc - n), dtype=dt, order="F")
+        fn = self.lib.tlsq_tls_f32 if dt == np.float32 else self.lib.tlsq_tls_f64
+        self._check(fn(self.h, _ptr(Af), M, nc, M, n, _ptr(x), n, L.MEM_HOST))
         return x
 
     def tls(self, A, y):
         """tls(A, y) — src/TotalLeastSquares.jl:48-55: the out-of-place form, x = tls!([A y], size(A, 2)).
         A vector y gives a vector x (Julia's `-V21/V22` with a 1 x 1 V22 is n x 1; the reference's tests use `vec`)."""
-        A = np.asarray(A, dtype=np.float64)
-        yv = np.asarray(y, dtype=np.float64)
+        A = np.asarray(A)
+        dt = np.float32 if A.dtype == np.float32 else np.float64
+        A = np.asarray(A, dtype=dt)
+        yv = np.asarray(y, dtype=dt)
         x = self.tls_(np.hstack([A, yv.reshape(A.shape[0], -1)]), A.shape[1])
         return x[:, 0].copy() if yv.ndim == 1 else x
 
     def rtls(self, A, y, *, return_report=False, **kw):
-        """rtls(A, y; kwargs...) — src/TotalLeastSquares.jl:152-156."""
-        A = _f(A)
-        yv = np.asarray(y, dtype=np.float64)
-        y2 = _f(yv.reshape(yv.shape[0], -1))
+        """rtls(A, y; kwargs...) — src/TotalLeastSquares.jl:152-156; the kwargs go to rpca as in the reference."""
+        A = np.asarray(A)
+        dt = np.float32 if A.dtype == np.float32 else np.float64
+        A = _f(A, dt)
+        yv = np.asarray(y, dtype=dt)
+        y2 = _f(yv.reshape(yv.shape[0], -1), dt)
         M, n = A.shape
         q = y2.shape[1]
         iters = int(kw.pop("iters", 1000))
@@ -379,9 +445,9 @@ class Engine:
         o = self.make_opts(iters=iters, **{k: v for k, v in kw.items()
                                            if k in ("lam", "maxrank", "tol", "rho", "nonnegA", "nonnegE", "hankel")})
         info, cost, svp = self._info(iters)
-        x = np.empty((n, q), dtype=np.float64, order="F")
-        st = self._check(self.lib.tlsq_rtls_f64(self.h, _ptr(A), M, n, M, _ptr(y2), q, M, C.byref(o),
-                                                _ptr(x), n, C.byref(info)))
+        x = np.empty((n, q), dtype=dt, order="F")
+        fn = self.lib.tlsq_rtls_f32 if dt == np.float32 else self.lib.tlsq_rtls_f64
+        st = self._check(fn(self.h, _ptr(A), M, n, M, _ptr(y2), q, M, C.byref(o), _ptr(x), n, C.byref(info)))
         rep = RpcaReport(info, cost, svp)
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}")
