@@ -25,7 +25,11 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+LAST_COMPILE_COUNT = 0   # hipcc -c commands of the last build() call
+
+
 def build(force=False, verbose=True):
+    global LAST_COMPILE_COUNT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -45,6 +49,7 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
+    LAST_COMPILE_COUNT = len(procs)
     if force or procs or not _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
