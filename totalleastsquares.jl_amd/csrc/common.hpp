@@ -44,6 +44,7 @@ struct Handle {
     double* mailbox_dev = nullptr;   // device address of the same memory
     double mail_seq = 0.0;
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
+    bool cert_ticket_ready = false;    // ... and the one of k_sq_norm
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
     // single-process multi-GPU group (tlsq_create_multi): the caller holds rank 0, subs[r - 1] is rank r.  multi_comm
@@ -133,6 +134,11 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
                                  int nonnegE, double* sumsq, double* zero_slots = nullptr, const T* hankel_y = nullptr,
                                  int64_t hankel_K = 0);
+// A (M x N, ld M) = Tm Vs' (Tm M x r fp64, Vs N x r): the streaming-store form of the rebuild (r <= 32, even M)
+template <typename T>
+bool rebuild_store_ok(const T* A, int64_t M, int64_t N, int64_t ldA, int64_t r);
+template <typename T>
+int launch_rebuild_store(Handle* h, const double* Tm, const double* Vs, T* A, int64_t M, int64_t N, int64_t r);
 // dst (N x M, ld ldd) = src' for src (M x N, ld lds)
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd);
@@ -250,9 +256,10 @@ int launch_skinny_mm(Handle* h, const TA* A, int64_t lda, const double* X, int64
 // GD = scale * (G - Vs Vg')
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
                    int64_t r, double scale = 1.0);
-// power certificate (subspace.hip, k_cert_decide)
-int launch_cert_decide(Handle* h, const double* part, int nblk, int level, double thresh, double* state, double* mailbox_dev,
-                       double seq);
+// ||S^2||_F^2 of a symmetric S (N x N, ld N) as per-tile partial sums in the host-visible mailbox ([16 .. 16 + ntile)),
+// published with sequence number seq
+int launch_sq_norm(Handle* h, const double* S, int64_t N, double* mailbox_dev, unsigned int* ticket, double seq, int* ntile_out);
+
 // complex.hip: ComplexF64 sweeps + realification (panels are interleaved re/im, n counts complex elements)
 int launch_cshrink(Handle* h, const double* D, const double* A, const double* Y, double* E, double* Z, int64_t n,
                    double inv_mu, double thr);

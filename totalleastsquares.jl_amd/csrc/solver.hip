@@ -236,6 +236,7 @@ struct SubspaceState {
     bool cert_pending = false;
     LanczosRun cert;
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
+    int q_floor = 1;       // smallest count that may be tried again (raised when a count needed a second step)
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
     // Uncertainty of an eigenvalue of the computed Gram matrix relative to lambda_max (rounding of G = Z'Z, Ritz
@@ -248,33 +249,53 @@ struct SubspaceState {
     const double* cert_GD = nullptr;
     int64_t cert_N = 0;
     double cert_margin = 0.0, cert_seq = 0.0;
+    int cert_ntile = 0;
     bool cert_power = false;
     int64_t n_power = 0, n_power_l2 = 0, n_lanczos_cert = 0;   // statistics: served by S^2 / S^4 / Lanczos
 };
 
 // ---- count certificate: lambda_max(GD) < margin for the deflated, scaled Gram matrix GD ---------------------------
-// Matrix powers first (k_cert_decide in subspace.hip: ||GD^2||_F^(1/2), then ||GD^4||_F^(1/4) - rigorous upper bounds,
-// two MFMA contractions, one read-back); only when both are too coarse (an eigenvalue within ~1.5x of the mark, or a
-// very flat tail) does a Lanczos run decide, with the usual 1.5x safety factor on its (lower-bound) Ritz value.
-static int power_cert_begin(Handle* h, SubspaceState& st) {
+// Matrix powers first: lambda_max(S) <= ||S^(2^k)||_F^(1/2^k) for symmetric S - rigorous, deterministic upper bounds
+// from plain MFMA contractions (a Lanczos Ritz value is only a LOWER bound of lambda_max).  ||GD^2||_F comes from one
+// fused kernel whose per-tile sums land in the host-visible mailbox (k_sq_norm in subspace.hip); ||GD^4||_F and, when
+// that is still too coarse, a Lanczos run with the usual 1.5x safety factor follow synchronously - rarely.
+// ||S^(2^levels)||_F^2 of the symmetric S = GD through the general MFMA GEMM (slab reduction with the norm by-product),
+// partial sums read back and added on the host in order: the slow but general form (no mailbox, second squaring)
+static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out) {
     const int64_t N = st.cert_N;
-    void *P1, *P2, *part, *scal;
+    void *P1, *P2, *part;
     TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
-    TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
-    TLSQ_TRY(ws_get(h, WS_CPART, 2 * 2048 * 8, &part));
-    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-    double* state = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 1600);
-    double* part1 = (double*)part;
-    double* part2 = part1 + 2048;
-    int nb1 = 0, nb2 = 0;
-    const double m2 = st.cert_margin * st.cert_margin;
-    TLSQ_TRY(gemm_mixed(h, true, true, st.cert_GD, 0, N, st.cert_GD, 0, N, P1, 0, N, N, N, N, true, nullptr, part1, &nb1));
-    TLSQ_TRY(launch_cert_decide(h, part1, nb1, 1, m2 * m2, state, nullptr, 0.0));
-    TLSQ_TRY(gemm_mixed(h, true, true, P1, 0, N, P1, 0, N, P2, 0, N, N, N, N, true, state, part2, &nb2));
+    TLSQ_TRY(ws_get(h, WS_CPART, 2048 * 8, &part));
+    int nb = 0;
+    TLSQ_TRY(gemm_mixed(h, true, true, st.cert_GD, 0, N, st.cert_GD, 0, N, P1, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
+    if (levels >= 2) {
+        TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
+        TLSQ_TRY(gemm_mixed(h, true, true, P1, 0, N, P1, 0, N, P2, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
+    }
+    std::vector<double> hp((size_t)nb);
+    TLSQ_HIP(h, hipMemcpyAsync(hp.data(), part, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    double a = 0.0;
+    for (double v : hp) a += v;
+    *out = a;
+    return TLSQ_OK;
+}
+
+static int power_cert_begin(Handle* h, SubspaceState& st) {
     static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
-    const bool mail = h->mailbox && h->mailbox_bytes >= 1024 && !no_mailbox;
-    st.cert_seq = mail ? (h->mail_seq += 1.0) : 0.0;
-    TLSQ_TRY(launch_cert_decide(h, part2, nb2, 2, 0.0, state, mail ? h->mailbox_dev : nullptr, st.cert_seq));
+    const int64_t N = st.cert_N;
+    const int64_t nt = (N + 31) / 32;
+    st.cert_seq = 0.0;
+    if (!(h->mailbox && !no_mailbox && (size_t)(16 + nt * (nt + 1) / 2) * 8 <= h->mailbox_bytes)) return TLSQ_OK;
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 336);   // self-resetting
+    if (!h->cert_ticket_ready) {   // (fresh workspace memory is not zero)
+        TLSQ_HIP(h, hipMemsetAsync(ticket, 0, 4, h->stream));
+        h->cert_ticket_ready = true;
+    }
+    st.cert_seq = (h->mail_seq += 1.0);
+    TLSQ_TRY(launch_sq_norm(h, st.cert_GD, N, h->mailbox_dev, ticket, st.cert_seq, &st.cert_ntile));
     return TLSQ_OK;
 }
 
@@ -289,51 +310,46 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
         *pass = lmax * 1.5 < st.cert_margin;
         return TLSQ_OK;
     }
-    double ab[2] = {0.0, -1.0};
-    bool got = false;
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    double a = -1.0;
     if (st.cert_seq != 0.0) {
         volatile double* mb = h->mailbox;
         const double t_poll = now_ms();
         while (mb[0] != st.cert_seq && now_ms() - t_poll < 2000.0) {
         }
-        got = mb[0] == st.cert_seq;
-        if (got) {
-            ab[0] = mb[8];
-            ab[1] = mb[9];
+        if (mb[0] == st.cert_seq) {
+            a = 0.0;
+            for (int t = 0; t < st.cert_ntile; ++t) a += mb[16 + t];   // tile order: reproducible
         } else {
-            h->mailbox_bytes = 0;   // never seen in practice; classic read-back from now on
+            h->mailbox_bytes = 0;   // never seen in practice; classic read-backs from now on
         }
     }
-    if (!got) {
-        void* scal;
-        TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, reinterpret_cast<char*>(scal) + 1608, 16, hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        memcpy(ab, h->pinned, 16);
-    }
-    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
-    const double b1 = ab[0] >= 0.0 ? std::pow(ab[0], 0.25) : std::numeric_limits<double>::infinity();
-    const double b2 = ab[1] >= 0.0 ? std::pow(ab[1], 0.125) : std::numeric_limits<double>::infinity();
-    if (dbg) fprintf(stderr, "  power certificate: bound1=%.4f bound2=%.4f margin=%.6f\n", b1, b2, st.cert_margin);
-    if (std::isfinite(b1) && b1 < st.cert_margin) {
+    if (a < 0.0) TLSQ_TRY(power_norm_sync(h, st, 1, &a));
+    const double b1 = std::isfinite(a) ? std::pow(a, 0.25) : std::numeric_limits<double>::infinity();
+    if (dbg) fprintf(stderr, "  power certificate: bound1=%.4f margin=%.6f\n", b1, st.cert_margin);
+    if (b1 < st.cert_margin) {
         ++st.n_power;
         *pass = true;
         return TLSQ_OK;
     }
-    if (std::isfinite(b2) && b2 < st.cert_margin) {
+    if (!std::isfinite(a)) return TLSQ_OK;   // NaN / inf in the deflated matrix: not certified
+    // one more squaring tightens the bound from rank^(1/4) to rank^(1/8) above lambda_max
+    double b = 0.0;
+    TLSQ_TRY(power_norm_sync(h, st, 2, &b));
+    const double b2 = std::isfinite(b) ? std::pow(b, 0.125) : std::numeric_limits<double>::infinity();
+    if (dbg) fprintf(stderr, "  power certificate: bound2=%.4f\n", b2);
+    if (b2 < st.cert_margin) {
         ++st.n_power_l2;
         *pass = true;
         return TLSQ_OK;
     }
-    if (!std::isfinite(ab[0])) return TLSQ_OK;   // NaN / inf in the deflated matrix: not certified
-    // the power bounds are up to rank^(1/8) above lambda_max: a Lanczos run has the last word
+    // still too coarse (an eigenvalue within ~1.5x of the mark, or a very flat tail): a Lanczos run has the last word
     const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
     if (lst < 0) return lst;
     ++st.n_lanczos_cert;
     *pass = lmax * 1.5 < st.cert_margin;
     return TLSQ_OK;
 }
-
 
 // one stream-ordered upload of an index list and a weight list of the same length r into `aux`
 // (layout: int32 sel[r], padding to 8 bytes, double w[r]); returns the two device pointers
@@ -581,8 +597,14 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             if (!cold && !hook) {
                 // a warm block that needed a second step just missed the residual bound after the first one: two more
                 // multiplications of its top columns next time are far cheaper than another step; relax again later
-                if (step >= 1) st.q_warm = std::min(7, st.q_warm + 2);
-                else if (st.q_warm > 3) st.q_warm -= 1;
+                // ... and when a single step landed far below the bound (the spectral gap behind the block grows by
+                // rho^2 per ALM iteration) give a multiplication back - but never return to a count that has failed
+                if (step >= 1) {
+                    st.q_floor = std::max(st.q_floor, std::min(st.q_warm + 1, 3));
+                    st.q_warm = std::min(7, st.q_warm + 2);
+                } else if (st.q_warm > st.q_floor && maxres <= 0.02 * 2e-13 * tmax) {
+                    st.q_warm -= 1;
+                }
             }
             break;
         }
@@ -722,6 +744,8 @@ static int rebuild_from_factors(Handle* h, const double* Tm, const double* Vs, i
         TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
         return TLSQ_OK;
     }
+    static const bool no_store = [] { const char* e = getenv("TLSQ_NO_REBUILD_STORE"); return e && e[0] == '1'; }();
+    if (!no_store && rebuild_store_ok<T>(Aout, M, N, ldA, r)) return launch_rebuild_store<T>(h, Tm, Vs, Aout, M, N, r);
     TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, Tm, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
     return TLSQ_OK;
 }

@@ -421,49 +421,6 @@ __global__ __launch_bounds__(256) void k_deflate(const double* __restrict__ G, i
     }
 }
 
-// Count certificate by matrix powers: for a symmetric S,  lambda_max(S) <= ||S^(2^k)||_F^(1/2^k)  (the Frobenius norm
-// of a power bounds its largest eigenvalue; the bound tightens to rank^(1/2^(k+1)) lambda_max).  S^2 and S^4 are plain
-// dense contractions (MFMA), so the certificate is deterministic and rigorous - a Lanczos Ritz value is only a lower
-// bound of lambda_max.  This kernel adds the partial sums of ||S^(2^level)||_F^2 left by the slab reduction, in order:
-//   level 1: state[1] = ||S^2||_F^2;  state[0] = 1 when that already proves lambda_max < margin (the level-2 launches
-//            then return at once), 0 otherwise
-//   level 2: state[2] = ||S^4||_F^2 (or -1 when skipped); both numbers go to the host-visible mailbox
-__global__ __launch_bounds__(256) void k_cert_decide(const double* __restrict__ part, int nblk, int level, double thresh,
-                                                     double* __restrict__ state, double* mailbox, double seq) {
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const bool skipped = level == 2 && state[0] != 0.0;
-    double v = 0.0;
-    if (!skipped)
-        for (int i = tid; i < nblk; i += 256) v += part[i];
-    v = ss_wsum(v);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    if (tid == 0) {
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-        if (level == 1) {
-            state[1] = tot;
-            state[2] = -1.0;
-            state[0] = (tot < thresh) ? 1.0 : 0.0;
-        } else {
-            if (!skipped) state[2] = tot;
-            if (mailbox) {
-                volatile double* mb = mailbox;
-                mb[8] = state[1];
-                mb[9] = skipped ? -1.0 : tot;
-                __threadfence_system();
-                mb[0] = seq;
-            }
-        }
-    }
-}
-
-int launch_cert_decide(Handle* h, const double* part, int nblk, int level, double thresh, double* state, double* mailbox_dev,
-                       double seq) {
-    hipLaunchKernelGGL(k_cert_decide, dim3(1), dim3(256), 0, h->stream, part, nblk, level, thresh, state, mailbox_dev, seq);
-    TLSQ_HIP(h, hipGetLastError());
-    return TLSQ_OK;
-}
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
 __global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
@@ -650,6 +607,80 @@ int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X,
         return launch_skinny_mm<double>(h, G, ldG, X, N, Y, N, N, N, p);
     hipLaunchKernelGGL((k_skinny_mm<double, 8>), dim3((unsigned)((N + 63) / 64), (unsigned)((p + 7) / 8)),
                        dim3(SK_WAVES * 64), (size_t)SK_KB * 8 * 8, h->stream, G, ldG, X, N, Y, N, N, (int)N, (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+
+// ---- fused level-1 power certificate (N <= 1024): ||S^2||_F^2 for the symmetric S = GD, straight to the host ------
+// One workgroup (16 waves) per 32 x 32 tile of the lower triangle of S^2: wave w owns MFMA tile (w & 3) and the
+// K-quarter (w >> 2); both fragments are "16 consecutive rows of column k" of the symmetric S (one 128-byte line per
+// 16 lanes), fed to v_mfma_f64_16x16x4_f64 from global memory (S is 2 MB: L2).  The squares of the tile are summed in a
+// fixed order; the partial sum goes to the host-visible mailbox slot of the tile (off-diagonal tiles count twice), and
+// the workgroup that arrives last publishes the sequence number - the host adds the partials in tile order, so the
+// bound is reproducible bit for bit.
+__global__ __launch_bounds__(1024) void k_sq_norm(const double* __restrict__ S, int N, int ntile, double* mailbox,
+                                                  unsigned int* ticket, double seq) {
+    __shared__ double sR[16 * 256];
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    // tile index -> (ti, tj), tj <= ti
+    int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int sub = w & 3, kq = w >> 2;
+    const int i0 = ti * 32 + (sub & 1) * 16, j0 = tj * 32 + (sub >> 1) * 16;
+    const int gi = i0 + fr, gj = j0 + fr;
+    const bool iok = gi < N, jok = gj < N;
+    const double* Si = S + (iok ? gi : 0);
+    const double* Sj = S + (jok ? gj : 0);
+    sm_d4 acc = sm_d4{0.0, 0.0, 0.0, 0.0};
+    const int kper = ((N + 3) / 4 + 3) / 4 * 4;   // inner indices per K-quarter, a multiple of 4
+    const int kbeg = kq * kper, kend = (kbeg + kper < N) ? kbeg + kper : N;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + fk;
+            const bool kok = k < kend;
+            a[u] = (iok && kok) ? Si[(int64_t)k * N] : 0.0;
+            b[u] = (jok && kok) ? Sj[(int64_t)k * N] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q];
+    __syncthreads();
+    // 4 sub-tiles x 256 entries; thread (sub2, e): sum of the four K-quarters, squared
+    const int sub2 = tid >> 8, e = tid & 255;
+    const double v = ((sR[(sub2) * 256 + e] + sR[(4 + sub2) * 256 + e]) + sR[(8 + sub2) * 256 + e]) + sR[(12 + sub2) * 256 + e];
+    double sq = v * v;
+    sq = ss_wsum(sq);
+    if (lane == 0) red[w] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int q = 0; q < 16; ++q) tot += red[q];
+        volatile double* mb = mailbox;
+        mb[16 + blockIdx.x] = (ti == tj ? 1.0 : 2.0) * tot;
+        __threadfence_system();
+        if (atomicAdd(ticket, 1u) == (unsigned int)(ntile - 1)) {
+            *ticket = 0u;
+            __threadfence_system();
+            mb[0] = seq;
+        }
+    }
+}
+
+int launch_sq_norm(Handle* h, const double* S, int64_t N, double* mailbox_dev, unsigned int* ticket, double seq, int* ntile_out) {
+    const int nt = (int)((N + 31) / 32);
+    const int ntile = nt * (nt + 1) / 2;
+    if (ntile_out) *ntile_out = ntile;
+    hipLaunchKernelGGL(k_sq_norm, dim3((unsigned)ntile), dim3(1024), 0, h->stream, S, (int)N, ntile, mailbox_dev, ticket, seq);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

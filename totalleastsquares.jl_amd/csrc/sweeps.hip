@@ -275,6 +275,66 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
     }
 }
 
+// A (M x N, ld M) = Tm Vs' alone: the store-bound form of the rebuild (src/robustPCA.jl:207-208 / 211-212) for the
+// panels that keep A in memory (C2 size).  Same walk as above: a thread owns two consecutive rows of T in registers,
+// the Vs tile is broadcast from LDS, every store is 16 bytes per lane and 1 KB contiguous per wave.  The 128 x 128
+// tile GEMM needs 24 us for this 82 MB store at 20000 x 512; here the store stream is all there is.
+template <typename T, int RMAX>
+__global__ __launch_bounds__(256) void k_rebuild_store(const double* __restrict__ Tm, const double* __restrict__ Vs,
+                                                       T* __restrict__ A, int64_t M, int N, int r, int ct) {
+    using VR = T __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
+    const int c0 = blockIdx.y * ct;
+    const int nct = (N - c0 < ct) ? N - c0 : ct;
+    for (int e = threadIdx.x; e < ct * RMAX; e += 256) {
+        const int c = e / RMAX, i = e % RMAX;
+        sVs[e] = (c < nct && i < r) ? Vs[(size_t)(c0 + c) + (size_t)i * N] : 0.0;
+    }
+    __syncthreads();
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (row >= M) return;
+    double t[2][RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) t[q][i] = i < r ? Tm[row + q + (size_t)i * M] : 0.0;
+#pragma unroll 4
+    for (int c = 0; c < nct; ++c) {
+        const double* vs = sVs + c * RMAX;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) {
+            a0 = __builtin_fma(t[0][i], vs[i], a0);
+            a1 = __builtin_fma(t[1][i], vs[i], a1);
+        }
+        VR out;
+        out[0] = (T)a0;
+        out[1] = (T)a1;
+        *(reinterpret_cast<VR*>(A) + (row + (int64_t)(c0 + c) * M) / 2) = out;
+    }
+}
+
+template <typename T>
+bool rebuild_store_ok(const T* A, int64_t M, int64_t N, int64_t ldA, int64_t r) {
+    return r >= 1 && r <= 32 && (M % 2) == 0 && ldA == M && (reinterpret_cast<uintptr_t>(A) % (2 * sizeof(T))) == 0 &&
+           N <= 2147483647LL;
+}
+
+template <typename T>
+int launch_rebuild_store(Handle* h, const double* Tm, const double* Vs, T* A, int64_t M, int64_t N, int64_t r) {
+    const int ct = 32;
+    const dim3 grid((unsigned)((M / 2 + 255) / 256), (unsigned)((N + ct - 1) / ct));
+    if (r <= 8) hipLaunchKernelGGL((k_rebuild_store<T, 8>), grid, dim3(256), 0, h->stream, Tm, Vs, A, M, (int)N, (int)r, ct);
+    else if (r <= 16) hipLaunchKernelGGL((k_rebuild_store<T, 16>), grid, dim3(256), 0, h->stream, Tm, Vs, A, M, (int)N, (int)r, ct);
+    else hipLaunchKernelGGL((k_rebuild_store<T, 32>), grid, dim3(256), 0, h->stream, Tm, Vs, A, M, (int)N, (int)r, ct);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template bool rebuild_store_ok<double>(const double*, int64_t, int64_t, int64_t, int64_t);
+template bool rebuild_store_ok<float>(const float*, int64_t, int64_t, int64_t, int64_t);
+template int launch_rebuild_store<double>(Handle*, const double*, const double*, double*, int64_t, int64_t, int64_t);
+template int launch_rebuild_store<float>(Handle*, const double*, const double*, float*, int64_t, int64_t, int64_t);
+
 // The 64 partial sums of ||R||_F^2 go to the host-visible mailbox ([0] flag, [8..72) values) and are published with
 // the sequence number: the host polls the flag instead of paying a copy command and an event between two kernels.
 __global__ __launch_bounds__(64) void k_publish_slots(const double* __restrict__ slots, double* mailbox, double seq) {
