@@ -147,11 +147,12 @@ int tlsq_comm_destroy(tlsq_handle h);
  * D  M x N (ldD)  in;  A, E  M x N out;  optional (may be NULL): U M x d (ldU), S d, Vt d x N (ldVt),
  * d = min(M_global,N) — the SVD of the last Z = D-E+Y/mu (the reference's returned `s`, :194,:238).
  * *sv = estimated rank (:204,:238).  When row-sharded, M/D/A/E/U are the local shard.
- * Large mode, min(M,N) in (2048, 16384]: every SVD step is served by the certified subspace solver (there is no
- * dense eigensolver of that size); A, E, sv, the iteration count and the costs are the same as always, but of
- * U/S/Vt only the leading triplets (the sigma >= 1/mu ones plus the solver's padding) are returned - the rest
- * of S is NaN and the corresponding vectors are zero - and a rank beyond the largest block (190 columns) is
- * reported as TLSQ_ERR_UNSUPPORTED.  min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED. */
+ * Large mode, min(M,N) in (2048, 16384]: every SVD step of the loop is served by the certified subspace solver (there
+ * is no dense eigensolver of that size in the loop); A, E, sv, the iteration count and the costs are the same as
+ * always.  The returned U/S/Vt are complete up to min(M,N) = 4608 (TSQR + one-sided Jacobi once after the loop, a
+ * few seconds, only when asked for); beyond that only the leading triplets (the sigma >= 1/mu ones plus the solver's
+ * padding) are returned - the rest of S is NaN and the corresponding vectors are zero.  A rank beyond the largest
+ * block (190 columns) is reported as TLSQ_ERR_UNSUPPORTED.  min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED. */
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE,
                   double* U, int64_t ldU, double* S, double* Vt, int64_t ldVt,

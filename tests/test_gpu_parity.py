@@ -374,10 +374,12 @@ def test_rpca_large_mode_vs_oracle_and_planted(eng):
     assert rep.eig_full == 0                                   # nothing fell back to a dense solver
     assert relerr(A, Ao) < 1e-9 and relerr(E, Eo) < 1e-9
     np.testing.assert_allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
-    # leading singular values of the last Z are returned, the unresolved rest is NaN
-    k = int(np.isfinite(s.S).sum())
-    assert sv <= k < N
-    np.testing.assert_allclose(s.S[:sv], so[1][:sv], rtol=1e-9)
+    # the returned `s` is the complete SVD of the last Z in large mode too (TSQR + Jacobi once after the loop, N <= 4608):
+    # every singular value, no NaN tail
+    assert np.all(np.isfinite(s.S)) and np.all(np.diff(s.S) <= 0)
+    np.testing.assert_allclose(s.S, so[1], rtol=1e-10, atol=64 * 2.2e-16 * math.sqrt(N) * so[1][0])
+    Vt = np.asarray(s.Vt)
+    assert np.max(np.abs(Vt @ Vt.T - np.eye(N))) < 1e-11
     with warnings.catch_warnings():
         warnings.simplefilter("error")                         # must converge: no max-iteration warning
         A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False)

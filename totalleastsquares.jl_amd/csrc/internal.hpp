@@ -99,6 +99,9 @@ struct PhaseTimer {
 // certified subspace iteration alone; see rpca_core.
 constexpr int64_t kFullEigMaxN = 2048;
 constexpr int64_t kGramMaxN = 16384;
+// largest N for which the complete returned SVD is computed after a large-mode loop (one-sided Jacobi on R' with at
+// least two resident columns per workgroup: 2 * 2 * N * 8 bytes of LDS)
+constexpr int64_t kReturnedSvdMaxN = 4608;
 
 
 template <typename T>

@@ -1351,7 +1351,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
 
     // ---- the returned `s` (SVD of the last Z), src/robustPCA.jl:194,238 ----
     const int64_t d = std::min(ro.m_global, N);
-    if ((S_host || Vt_host || U_dev) && V && large) {
+    // Large mode (N > 2048): the loop never needs a dense decomposition, but the returned `s` is the complete SVD of the
+    // last Z (:194, :238).  Up to kReturnedSvdMaxN columns it is computed once after the loop by the TSQR route (the
+    // block Jacobi then keeps 2-4 columns of R' per workgroup in LDS: seconds, not milliseconds - only when the caller
+    // asks for S / Vt / U); beyond that only the Ritz triplets of the last block exist.
+    const bool slow_full_s = large && N <= kReturnedSvdMaxN && !h->comm;
+    if ((S_host || Vt_host || U_dev) && V && large && !slow_full_s) {
         // large mode: only the Ritz triplets of the last block are available; the rest of S is NaN and the
         // corresponding vectors are zero (documented in include/tlsq.h)
         const int64_t have = std::min<int64_t>(s.ncols, d);
@@ -1388,7 +1393,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         return converged ? TLSQ_OK : TLSQ_MAXITER;
     }
-    if ((S_host || Vt_host || U_dev) && !large && !v_is_full) {
+    if ((S_host || Vt_host || U_dev) && (!large || slow_full_s) && !v_is_full) {
         // the last iteration used a subspace path: the caller wants the complete SVD of the last Z (:194, :238) -
         // through the TSQR route, so that the small singular values and their vectors are as accurate as LAPACK's
         TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V, s, &sweeps));
