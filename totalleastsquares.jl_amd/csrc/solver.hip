@@ -252,6 +252,7 @@ struct SubspaceState {
     int cert_ntile = 0;
     bool cert_power = false;
     int64_t n_power = 0, n_power_l2 = 0, n_lanczos_cert = 0;   // statistics: served by S^2 / S^4 / Lanczos
+    double cert_tail = 0.0;   // Lanczos estimate of lambda_max(GD) / tau^2 of the last failed certificate (0: unknown)
 };
 
 // ---- count certificate: lambda_max(GD) < margin for the deflated, scaled Gram matrix GD ---------------------------
@@ -348,6 +349,7 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
     if (lst < 0) return lst;
     ++st.n_lanczos_cert;
     *pass = lmax * 1.5 < st.cert_margin;
+    st.cert_tail = *pass ? 0.0 : lmax;
     return TLSQ_OK;
 }
 
@@ -403,6 +405,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     *ok = false;
     st.fail = SubspaceState::FAIL_NONE;
     st.cert_pending = false;
+    st.cert_tail = 0.0;
     const bool hook = st.hook_rank > 0;
     const bool cold = hook || !st.valid;
     if (hook) {
@@ -930,6 +933,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool v_is_full = false;
     double sigma_top_prev = 0.0;
     int64_t n_rroute = 0;   // iterations whose SVD step was served by the TSQR route
+    int64_t n_gram_dense = 0;   // ... by the dense decomposition of the Gram matrix (very tall panels)
+    // the tail of the spectrum is a noise bulk whose top sits right below 1/mu (noisy data: every iteration): the
+    // subspace solver cannot certify a count there, so it is not even tried until a dense result shows a gap again
+    bool bulk_tail = false;
+    static const bool no_gram_dense = [] { const char* e = getenv("TLSQ_NO_GRAM_DENSE"); return e && e[0] == '1'; }();
     // HBM traffic the panel-sized kernels of this call have to move (algorithmic bytes of what was launched: panel
     // passes x M x N x sizeof(T)); reported in tlsq_rpca_info
     const double panel_bytes = (double)n * sizeof(T);
@@ -986,6 +994,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             svp = 0;                                                   // :198
             for (int64_t i = 0; i < s.ncols; ++i) svp += (s.sigma[s.order[i]] >= inv_mu) ? 1 : 0;
             sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+            if (s.ncols == N && svp < N) {   // a complete decomposition shows where the tail stands
+                const double tr = s.sigma[s.order[svp]] / inv_mu;
+                bulk_tail = tr * tr > 0.4;
+            }
             std::vector<int32_t> sel((size_t)svp);
             std::vector<double> g((size_t)svp);
             for (int64_t p = 0; p < svp; ++p) {
@@ -1095,6 +1107,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             rs.hook_seed = seed + (uint64_t)k;
             TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
+        } else if (bulk_tail && !large) {
+            sub.fail = SubspaceState::FAIL_NONE;   // straight to the dense tier below
         } else {
             sub.noise_rel = noise_rel;
             sub.defer_certificate = !no_cert_overlap;
@@ -1123,6 +1137,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 const int why = sub.fail;
                 if (why == SubspaceState::FAIL_WINDOW) break;
                 if (!large && why != SubspaceState::FAIL_SMALL && why != SubspaceState::FAIL_CERT) break;
+                // a tail whose top sits within a factor two of the threshold is a noise bulk, not a stray value: no
+                // block of this solver will ever put a 1.5x gap behind it - the dense route decides
+                if (!large && why == SubspaceState::FAIL_CERT && sub.cert_tail > 0.5) {
+                    bulk_tail = true;
+                    break;
+                }
                 const bool grow = why == SubspaceState::FAIL_SMALL || why == SubspaceState::FAIL_CERT ||
                                   why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
                 const int64_t cap = std::min<int64_t>(pmax, N);
@@ -1148,8 +1168,24 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                            "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
                            "(block of %lld columns, reason %d): rank too large for this release",
                            (long long)N, (long long)kFullEigMaxN, (long long)k, (long long)sub.p, sub.fail);
-        if (fast_ok) ++sub.fast;
-        else r_route = true;
+        if (fast_ok) {
+            ++sub.fast;
+        } else if (!hook_now && G && !no_gram_dense && (double)ro.m_global > 400.0 * (double)N) {
+            // Very tall panels: the TSQR route would stream the whole panel ~N/16 times, the Gram matrix is already
+            // there.  Dense decomposition of G (Jacobi on its Cholesky factor), believed under the same rule as the
+            // subspace result: no eigenvalue within the Gram route's uncertainty of the threshold.
+            TLSQ_TRY(eig_full(h, G, N, &V, s, &sweeps));
+            const double ltop = s.sigma[s.order[0]] * s.sigma[s.order[0]], dl = noise_rel * ltop, tau2 = inv_mu * inv_mu;
+            bool uncertain = !(tau2 > 2.0 * dl);
+            for (int64_t i = 0; i < N && !uncertain; ++i) uncertain = std::fabs(s.sigma[i] * s.sigma[i] - tau2) <= dl;
+            if (uncertain) r_route = true;
+            else {
+                rebuilt = false;
+                ++n_gram_dense;
+            }
+        } else {
+            r_route = true;
+        }
         } else {
             g_ready = false;
             pt.mark(true);
@@ -1339,7 +1375,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->final_cost = cost;
         info->final_mu = mu;
         info->jacobi_sweeps = sweeps;
-        info->eig_full = sub.full;
+        info->eig_full = sub.full + n_gram_dense;
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
         info->reserved = (int32_t)n_rroute;   // iterations served by the TSQR route
