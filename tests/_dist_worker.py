@@ -68,6 +68,22 @@ def main():
     yf_s, linfo = lowrankfilter_sharded(ys + nz, 20, rank, world, allreduce)
     yf_o = O.lowrankfilter(ys + nz, 20)
     res["lrf_err"] = float(np.linalg.norm(yf_s - yf_o) / np.linalg.norm(yf_o))
+    # --- TSQR on row shards (tsqr.hip with a communicator): local R_r, all-gather of the N x N factors, redundant
+    #     reduction of the stack -> the singular values of the whole panel to eps * sigma_max, identical on all ranks
+    Zt = (np.random.default_rng(9).standard_normal((M, N)) * np.geomspace(1.0, 1e-9, N)[None, :])
+    Rl = np.linalg.qr(Zt[lo:hi], mode="r")
+    gathered = [torch.zeros((N, N), dtype=torch.float64) for _ in range(world)]
+    pad = np.zeros((N, N))
+    pad[: Rl.shape[0]] = Rl
+    dist.all_gather(gathered, torch.from_numpy(pad))
+    Rs = np.linalg.qr(np.vstack([g.numpy() for g in gathered]), mode="r")
+    sv_stack = np.linalg.svd(Rs, compute_uv=False)
+    sv_full = np.linalg.svd(Zt, compute_uv=False)
+    res["tsqr_err"] = float(np.max(np.abs(sv_stack - sv_full)) / sv_full[0])
+    chk = torch.from_numpy(np.ascontiguousarray(np.abs(Rs)))
+    ref = chk.clone()
+    dist.broadcast(ref, src=0)
+    res["tsqr_same_on_all_ranks"] = bool(torch.equal(chk, ref))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)
     dist.barrier()

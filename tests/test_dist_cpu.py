@@ -32,6 +32,7 @@ def test_two_rank_gloo_row_sharding(tmp_path):
         assert res["relA"] < 1e-8 and res["relE"] < 1e-8, res
         assert res["ga_iters"][0] == res["ga_iters"][1] and res["ga_err"] < 1e-10, res
         assert res["lrf_err"] < 1e-8, res
+        assert res["tsqr_err"] < 1e-14 and res["tsqr_same_on_all_ranks"], res
 
 
 def test_row_partition_edge_cases():
