@@ -94,6 +94,7 @@ enum WsSlot {
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
     WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
+    WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
@@ -231,16 +232,25 @@ struct LanczosRun {
     bool event_pending = false, trivial = false, unsupported = false;
     bool mail_ok = false, use_mail = false;   // read-back through the handle's mailbox (polled) instead of copy + event
     double seq = 0.0;
+    const double* v0 = nullptr;   // start vector (device, N; need not be normalised); nullptr: fixed pseudo-random vector
 };
 int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                  double accept_below, double stop_above);
+                  double accept_below, double stop_above, const double* v0 = nullptr);
 int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used);
 // the same for an operator given only as a product w = Op(q) on N-vectors (device pointers, handle's stream)
 using LzApply = std::function<int(const double* q, double* w)>;
 int lanczos_lmax_op(Handle* h, int64_t N, const LzApply& apply, double rel_tol, int max_steps, double* lmax,
                     int* steps_used, double accept_below = 0.0, double stop_above = 0.0);
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used, double accept_below = 0.0, double stop_above = 0.0);
+                     double* lmax, int* steps_used, double accept_below = 0.0, double stop_above = 0.0,
+                     const double* v0 = nullptr);
+// v (N) = the column of largest diagonal entry of the symmetric S (N x N, ld N); S /= sqrt(sum of the nb partial sums)
+int launch_dominant_column(Handle* h, const double* S, int64_t N, double* v);
+int launch_scale_by_norm(Handle* h, double* S, int64_t N, const double* part, int nb);
+
+// best of nsteps lower bounds ||G v|| of lambda_max(G) along power steps on a vector that persists between calls
+// (init: restart it); returns 1 when not applicable (the caller runs Lanczos)
+int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool init, int nsteps, double* lb_out);
 
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);

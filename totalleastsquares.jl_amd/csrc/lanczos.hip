@@ -74,7 +74,8 @@ __device__ __forceinline__ void lz_publish(const double* st, const double* ab, i
 __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __restrict__ G, int64_t ldG,
                                                              int N, double* __restrict__ st,
                                                              double* __restrict__ ab, int maxsteps, int j,
-                                                             double* mailbox, double seq) {
+                                                             double* mailbox, double seq,
+                                                             const double* __restrict__ v0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* q = sm;           // N  (q_new)
     double* red = sm + N;     // 4
@@ -96,13 +97,18 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
         // deterministic pseudo-random start vector (integer hash), normalised
         double nrm = 0.0;
         for (int i = tid; i < N; i += LZ_THREADS) {
-            unsigned int x = (unsigned int)i * 2654435761u + 12345u;
-            x ^= x >> 16;
-            x *= 2246822519u;
-            x ^= x >> 13;
-            x *= 3266489917u;
-            x ^= x >> 16;
-            const double v = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+            double v;
+            if (v0) {   // caller's start vector (e.g. the dominant column of a high power of G)
+                v = v0[i];
+            } else {
+                unsigned int x = (unsigned int)i * 2654435761u + 12345u;
+                x ^= x >> 16;
+                x *= 2246822519u;
+                x ^= x >> 13;
+                x *= 3266489917u;
+                x ^= x >> 16;
+                v = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+            }
             q[i] = v;
             nrm += v * v;
         }
@@ -238,7 +244,7 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
     for (int k = 0; k < n; ++k, ++r.launched) {
         const bool last = r.use_mail && k == n - 1;
         hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
-                           r.ab, r.cap, r.launched, last ? h->mailbox_dev : (double*)nullptr, r.seq);
+                           r.ab, r.cap, r.launched, last ? h->mailbox_dev : (double*)nullptr, r.seq, r.v0);
     }
     TLSQ_HIP(h, hipGetLastError());
     if (!r.use_mail)
@@ -247,8 +253,9 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
 }
 
 int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                  double accept_below, double stop_above) {
+                  double accept_below, double stop_above, const double* v0) {
     r = LanczosRun();
+    r.v0 = v0;
     r.G = G;
     r.N = N;
     r.ldG = ldG;
@@ -374,10 +381,132 @@ int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used) {
 }
 
 int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
-                     double* lmax, int* steps_used, double accept_below, double stop_above) {
+                     double* lmax, int* steps_used, double accept_below, double stop_above, const double* v0) {
     LanczosRun r;
-    TLSQ_TRY(lanczos_begin(h, r, G, N, ldG, rel_tol, max_steps, accept_below, stop_above));
+    TLSQ_TRY(lanczos_begin(h, r, G, N, ldG, rel_tol, max_steps, accept_below, stop_above, v0));
     return lanczos_finish(h, r, lmax, steps_used);
+}
+
+
+// ---- power steps on a persistent vector: cheap LOWER bounds of lambda_max ----------------------------------------
+// The convergence test of rpca (src/robustPCA.jl:225-228) asks "opnorm(R) / opnorm(D) < tol?" once per iteration, and in
+// all but the last iteration the answer is no.  For unit v, ||G v|| <= lambda_max(G): a lower bound that costs one
+// product.  The vector is kept from one ALM iteration to the next (the dominant direction of the residual moves
+// slowly), so three products usually put the bound within a few per cent of lambda_max - enough to say "not converged"
+// without a Lanczos run (~25 dependent launches).  Launch j finishes product j - 1 (norm, bound, normalised vector:
+// every workgroup redundantly, like k_lanczos_step) and computes its rows of product j; the last launch only finishes
+// and hands the bounds to the host through the mailbox.
+// layout of `pw` (doubles): [0..8) bounds; v[N] (persistent); u[2][N]; part[2][LZ_WGS]
+__global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restrict__ G, int64_t ldG, int N,
+                                                           double* __restrict__ pw, int j, int nsteps, int init,
+                                                           double* mailbox, double seq) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* q = sm;          // N
+    double* red = sm + N;    // 4
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* v = pw + 8;
+    double* ubuf = v + N;
+    double* part = ubuf + 2 * (size_t)N;
+    if (j == 0) {
+        if (init) {   // deterministic pseudo-random start, normalised
+            double nrm = 0.0;
+            for (int i = tid; i < N; i += LZ_THREADS) {
+                unsigned int x = (unsigned int)i * 2654435761u + 777u;
+                x ^= x >> 16;
+                x *= 2246822519u;
+                x ^= x >> 13;
+                x *= 3266489917u;
+                x ^= x >> 16;
+                const double val = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+                q[i] = val;
+                nrm += val * val;
+            }
+            nrm = block_sum4(nrm, red);
+            const double inv = 1.0 / sqrt(nrm);
+            for (int i = tid; i < N; i += LZ_THREADS) q[i] *= inv;
+        } else {
+            for (int i = tid; i < N; i += LZ_THREADS) q[i] = v[i];
+        }
+    } else {
+        const double* u = ubuf + (size_t)((j + 1) % 2) * N;
+        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS;
+        double nn = 0.0;
+        for (int k = 0; k < LZ_WGS; ++k) nn += pp[k];
+        const double beta = sqrt(nn);                 // ||G v_{j-1}||, v_{j-1} a unit vector
+        const double inv = beta > 1e-290 ? 1.0 / beta : 0.0;
+        for (int i = tid; i < N; i += LZ_THREADS) q[i] = u[i] * inv;
+        if (blockIdx.x == 0 && tid == 0) pw[j - 1] = beta;
+    }
+    __syncthreads();
+    if (j == nsteps) {   // the finishing launch: persist the vector, publish the bounds
+        if (blockIdx.x == 0) {
+            for (int i = tid; i < N; i += LZ_THREADS) v[i] = q[i];
+            if (mailbox) {
+                volatile double* mb = mailbox;
+                __syncthreads();
+                if (tid < nsteps) mb[8 + tid] = pw[tid];
+                __threadfence_system();
+                __syncthreads();
+                if (tid == 0) mb[0] = seq;
+            }
+        }
+        return;
+    }
+    double* unew = ubuf + (size_t)(j % 2) * N;
+    const int rows_per = (N + LZ_WGS - 1) / LZ_WGS;
+    const int r0 = blockIdx.x * rows_per;
+    const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
+    double pacc = 0.0;
+    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
+        const double* __restrict__ col = G + (int64_t)r * ldG;   // symmetric: row r == column r
+        double acc = 0.0;
+        for (int c = lane; c < N; c += 64) acc += col[c] * q[c];
+        acc = wsum(acc);
+        if (lane == 0) {
+            unew[r] = acc;
+            pacc += acc * acc;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) red[w] = pacc;
+    __syncthreads();
+    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// *lb_out = the best of `nsteps` lower bounds ||G v|| <= lambda_max(G) along power steps on the handle's persistent
+// vector (init: start from a fixed pseudo-random vector).  One mailbox read-back.  Returns 1 when this form does not
+// apply (N too large for the LDS copy of the vector, no mailbox): the caller runs Lanczos.
+int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool init, int nsteps, double* lb_out) {
+    *lb_out = 0.0;
+    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    const size_t lds = (size_t)(N + 8) * 8;
+    if (N <= 0 || nsteps < 1 || nsteps > 8 || lds > 150 * 1024 || !h->mailbox || no_mailbox || h->mailbox_bytes < 1024) return 1;
+    void* pwv;
+    TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * LZ_WGS) * 8, &pwv));
+    if (lds > 48 * 1024)
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_power_step), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    const double seq = (h->mail_seq += 1.0);
+    for (int j = 0; j <= nsteps; ++j)
+        hipLaunchKernelGGL(k_power_step, dim3(j == nsteps ? 1 : LZ_WGS), dim3(LZ_THREADS), lds, h->stream, G, ldG, (int)N,
+                           (double*)pwv, j, nsteps, init ? 1 : 0, j == nsteps ? h->mailbox_dev : (double*)nullptr, seq);
+    TLSQ_HIP(h, hipGetLastError());
+    volatile double* mb = h->mailbox;
+    const double t_poll = now_ms();
+    while (mb[0] != seq && now_ms() - t_poll < 2000.0) {
+    }
+    if (mb[0] != seq) {
+        h->mailbox_bytes = 0;   // never seen in practice
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return 1;
+    }
+    double best = 0.0;
+    for (int j = 0; j < nsteps; ++j) {
+        const double b = mb[8 + j];
+        if (std::isfinite(b) && b > best) best = b;
+    }
+    *lb_out = best;
+    return TLSQ_OK;
 }
 
 // ---- Lanczos on an operator that is only available as a product (large mode: G = Z'Z is never formed) ---------

@@ -23,8 +23,34 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
                              double stop_above_sigma = 0.0) {
     double lmax = 0.0;
     int steps = 0;
-    int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
+    // A tight answer with no yes/no shortcut (the set-up norm ||D||_2, src/robustPCA.jl:177): plain Lanczos needs hundreds
+    // of dependent launches when the top of the spectrum is a cluster (a rank-16 D: 239 steps = 1.7 ms at N = 512).
+    // Five squarings G -> G^32 (MFMA, each rescaled to unit Frobenius norm) concentrate any column on the dominant
+    // cluster; started from the dominant column, the Krylov space is that of a ~16-dimensional problem.
+    const double* v0 = nullptr;
+    static const bool no_pow_start = [] { const char* e = getenv("TLSQ_NO_POWER_START"); return e && e[0] == '1'; }();
+    if (stop_above_sigma == 0.0 && rel_tol <= 1e-9 && N >= 64 && N <= 1024 && !no_pow_start) {
+        void *P1, *P2, *part, *vst;
+        TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
+        TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
+        TLSQ_TRY(ws_get(h, WS_CPART, 2 * 2048 * 8, &part));
+        TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * 64) * 8, &vst));
+        const double* src = G;
+        double* dst = (double*)P1;
+        for (int k = 0; k < 5; ++k) {
+            int nb = 0;
+            TLSQ_TRY(gemm_mixed(h, true, true, src, 0, N, src, 0, N, dst, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
+            TLSQ_TRY(launch_scale_by_norm(h, dst, N, (const double*)part, nb));
+            src = dst;
+            dst = (dst == (double*)P1) ? (double*)P2 : (double*)P1;
+        }
+        TLSQ_TRY(launch_dominant_column(h, src, N, (double*)vst + 8));
+        v0 = (const double*)vst + 8;
+    }
+    int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma, v0);
     if (st < 0) return st;
+    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "  opnorm Lanczos: %d steps (rel_tol %.0e, stop %.3e) -> sigma %.6e\n", steps, rel_tol, stop_above_sigma, std::sqrt(lmax));
     if (st == 0 || N > kFullEigMaxN) {   // large mode: no dense fallback; the Lanczos value after 1000 steps stands
         *out = std::sqrt(lmax);
         return TLSQ_OK;
@@ -900,7 +926,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
     else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
-    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps));                   // :177 opnorm(Y), Y = copy(D)
+    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
     TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));                  // :178 norm(Y, Inf)
     TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
@@ -937,6 +963,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // the tail of the spectrum is a noise bulk whose top sits right below 1/mu (noisy data: every iteration): the
     // subspace solver cannot certify a count there, so it is not even tried until a dense result shows a gap again
     bool bulk_tail = false;
+    bool power_vec_valid = false;   // the power-iteration vector of the cost evaluation has been started in this call
+    static const bool no_power_lb = [] { const char* e = getenv("TLSQ_NO_POWER_LB"); return e && e[0] == '1'; }();
     static const bool no_gram_dense = [] { const char* e = getenv("TLSQ_NO_GRAM_DENSE"); return e && e[0] == '1'; }();
     // HBM traffic the panel-sized kernels of this call have to move (algorithmic bytes of what was launched: panel
     // passes x M x N x sizeof(T)); reported in tlsq_rpca_info
@@ -1328,8 +1356,30 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // cost < tol matters: the Lanczos Ritz value is a lower bound of sigma_max^2, so the test is
             // settled ("not converged") as soon as it passes (tol*d_norm)^2.  The last iteration is exact.
             const double stop_sigma = want_exact_cost ? 0.0 : ro.tol * d_norm * (1.0 + 1e-9);
-            if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-8, &rn, stop_sigma));
-            else TLSQ_TRY(opnorm_gram<T>(h, R, M, N, M, &rn, &sweeps, 1e-8, stop_sigma, cost_gslot));  // :225
+            if (implicit_gram) {
+                TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-8, &rn, stop_sigma));
+            } else {                                                                               // :225
+                void* Gc;
+                TLSQ_TRY(ws_get(h, cost_gslot, (size_t)N * N * 8, &Gc));
+                TLSQ_TRY(gram_any(h, R, Prec<T>::f32, M, N, M, (double*)Gc, N));
+                TLSQ_TRY(comm_allreduce(h, (double*)Gc, (size_t)N * N, ncclSum));
+                bool settled = false;
+                if (stop_sigma > 0.0 && !no_power_lb) {
+                    // "not converged" from three power steps on the vector carried over from the previous evaluation
+                    // (||G v|| <= lambda_max for unit v): no Lanczos run unless the bound falls short of the mark
+                    double lb = 0.0;
+                    const int pst = power_lower_bound(h, (const double*)Gc, N, N, !power_vec_valid, 3, &lb);
+                    if (pst < 0) return pst;
+                    if (pst == 0) {
+                        power_vec_valid = true;
+                        if (lb >= stop_sigma * stop_sigma) {
+                            rn = std::sqrt(lb);
+                            settled = true;
+                        }
+                    }
+                }
+                if (!settled) TLSQ_TRY(sigma_max_of_gram(h, (const double*)Gc, N, 1e-8, &rn, &sweeps, stop_sigma));
+            }
             hbm_other += panel_bytes;
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy

@@ -676,6 +676,72 @@ __global__ __launch_bounds__(1024) void k_sq_norm(const double* __restrict__ S, 
     }
 }
 
+// S (N x N) <- S / ||S||_F, the squared norm given as nb partial sums (the by-product of the slab reduction that
+// produced S): keeps a chain of squarings S <- S^2 away from overflow and underflow
+__global__ __launch_bounds__(256) void k_scale_by_norm(double* __restrict__ S, int64_t n, const double* __restrict__ part,
+                                                       int nb) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) v += part[i];
+    v = ss_wsum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const double sc = tot > 0.0 ? 1.0 / sqrt(tot) : 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) S[e] *= sc;
+}
+
+// v = S[:, j*] with j* = argmax_j S[j, j] (one workgroup): for S ~ (G / c)^(2^k) this is the dominant eigenvector of G
+// up to (lambda_2 / lambda_1)^(2^k)
+__global__ __launch_bounds__(1024) void k_dominant_column(const double* __restrict__ S, int N, double* __restrict__ v) {
+    __shared__ double sval[16];
+    __shared__ int sidx[16];
+    double best = -1.0;
+    int bi = 0;
+    for (int j = threadIdx.x; j < N; j += 1024) {
+        const double d = S[(size_t)j * N + j];
+        if (d > best) {
+            best = d;
+            bi = j;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sval[threadIdx.x >> 6] = best;
+        sidx[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    double b = sval[0];
+    int jb = sidx[0];
+    for (int k = 1; k < 16; ++k)
+        if (sval[k] > b || (sval[k] == b && sidx[k] < jb)) {
+            b = sval[k];
+            jb = sidx[k];
+        }
+    for (int i = threadIdx.x; i < N; i += 1024) v[i] = S[(size_t)jb * N + i];
+}
+
+int launch_scale_by_norm(Handle* h, double* S, int64_t N, const double* part, int nb) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_scale_by_norm, dim3((int)g), dim3(256), 0, h->stream, S, N * N, part, nb);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_dominant_column(Handle* h, const double* S, int64_t N, double* v) {
+    hipLaunchKernelGGL(k_dominant_column, dim3(1), dim3(1024), 0, h->stream, S, (int)N, v);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int launch_sq_norm(Handle* h, const double* S, int64_t N, double* mailbox_dev, unsigned int* ticket, double seq, int* ntile_out) {
     const int nt = (int)((N + 31) / 32);
     const int ntile = nt * (nt + 1) / 2;
