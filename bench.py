@@ -147,8 +147,16 @@ def main():
               "value": n4 / t4, "unit": "iters/s", "n_gpus": world, "rows_per_gpu": M4l, "solves": 2,
               "ms_per_solve": t4 / 2 * 1e3, "iters_per_solve": rep4.iters_done, "sv": sv4, "converged": rep4.converged,
               "phases_ms_per_iter": {k: v / rep4.iters_done for k, v in rep4.ms.items()
-                                     if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")}}
+                                     if k in ("shrink", "update")}}
         del d4, a4, e4, D4
+
+    # one more solve, outside the timed region, with every phase of the iteration bracketed by HIP events: the source of
+    # phases_ms_per_iter and of the Gram roofline (the timed solves only bracket the sweep kernels - each recorded
+    # event costs ~6 us between two kernels, tlsq_rpca_opts.phase_timing)
+    _, rep_ph, _ = eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False,
+                                   phase_timing=True)
+    barrier()
+    ms_ph = dict(rep_ph.ms)
 
     sv, rep, st = last
     # sanity of the timed work (not part of the timing): residual and recovery on this rank's shard
@@ -194,8 +202,10 @@ def main():
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
                          "passes_per_iter": alg_bytes / array_bytes, "sweeps_without_residual_store": rskip_total,
                          "survey_11_pass_equivalent_GBps": 11.0 * array_bytes / (sweep_ms_per_iter * 1e-3) / 1e9},
-            "phases_ms_per_iter": {k: v / iters_total for k, v in ms.items()
+            "phases_ms_per_iter": {k: v / rep_ph.iters_done for k, v in ms_ph.items()
                                    if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")},
+            "phases_source": "one extra solve with tlsq_rpca_opts.phase_timing = 1 (events at all nine phase boundaries: "
+                             "that solve runs ~6 % slower than the timed ones)",
             "roofline_mfma": None,
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
             "svd_step": {"tsqr_route": rep.eig_full, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
@@ -249,10 +259,11 @@ def main():
         # (only the lower-triangular 128x128 tiles of Z'Z are computed)
         nt = (N + 127) // 128
         gram_flops = 2.0 * Ml * 128 * 128 * (nt * (nt + 1) // 2)
-        if ms.get("gram"):
-            # Gram launches in the timed solves: one per iteration, plus the one queued behind the last sweep of each
-            # solve before its convergence is known (the library hides the host round trip behind it)
-            n_gram = iters_total + args.steps
+        if ms_ph.get("gram"):
+            # Gram launches of the profiled solve: one per iteration, plus the one queued behind the last sweep
+            # before its convergence is known (the library hides the host round trip behind it)
+            n_gram = rep_ph.iters_done + 1
+            ms = dict(ms, gram=ms_ph["gram"])
             tf = gram_flops / (ms["gram"] / n_gram * 1e-3) / 1e12
             out["roofline_mfma"] = {"kernel": "k_gemm_f64<KC,KC> Gram(Z) + slab reduce", "bound": "mfma",
                                     "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,

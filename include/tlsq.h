@@ -84,6 +84,11 @@ typedef struct tlsq_rpca_opts {
     void* user;
     tlsq_svd_cb svd_cb;         /* svd_mode == TLSQ_SVD_CALLBACK */
     tlsq_opnorm_cb opnorm_cb;   /* opnorm_mode == TLSQ_OPNORM_CALLBACK */
+    /* 1: bracket every phase of an iteration with HIP events (ms_gram, ms_eig, ms_rebuild, ms_opnorm of the report).  0:
+     * only the sweep kernels are bracketed (ms_shrink, ms_update) - each recorded event is a packet the command processor
+     * works through between two kernels, ~6 us, and an iteration has nine phase boundaries. */
+    int32_t phase_timing;
+    int32_t reserved0;
 } tlsq_rpca_opts;
 
 /* Per-call report.  cost_hist / svp_hist are optional caller-provided arrays of hist_capacity entries.
@@ -100,7 +105,8 @@ typedef struct tlsq_rpca_info {
     int64_t* svp_hist;
     int64_t hist_capacity;
     int64_t jacobi_sweeps;   /* total sweeps of the small eigensolver */
-    /* wall/device time in ms */
+    /* wall/device time in ms.  ms_shrink / ms_update (the sweep kernels, HIP events on the handle's stream) are always
+     * measured; the other phases only with opts->phase_timing (zero otherwise) */
     double ms_total, ms_loop, ms_h2d, ms_d2h;
     double ms_shrink, ms_update, ms_gram, ms_eig, ms_rebuild, ms_opnorm;
     /* how the SVD step of each iteration was served: full Jacobi decompositions vs warm-started subspace

@@ -8,7 +8,7 @@
 #
 # NOTE: the build image has no `julia` binary, so this file is not executed by the test-suite; every call below is
 # mirrored one to one by the ctypes harness `totalleastsquares.jl_amd/engine.py`, which is.  Struct layouts are
-# checked there (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts) = 120, sizeof(info) = 200).
+# checked there (tests/test_cabi_cpu.py::test_struct_sizes_match_header: sizeof(opts) = 128, sizeof(info) = 200).
 #
 # Multi-GPU: ENV["TLSQ_NGPUS"] = "8" makes the one process-wide handle a tlsq_create_multi handle; rpca / lowrankfilter
 # on host arrays are then row-sharded over the GPUs inside the library (worker threads never call back into Julia; the
@@ -27,7 +27,7 @@ const SVD_FULL, SVD_RANDOMIZED, SVD_CALLBACK = Int32(0), Int32(1), Int32(2)
 const OPNORM_EXACT, OPNORM_POWER, OPNORM_CALLBACK = Int32(0), Int32(1), Int32(2)
 const HipFloat = Union{Float64,Float32}
 
-# mirrors `struct tlsq_rpca_opts` (include/tlsq.h), 120 bytes
+# mirrors `struct tlsq_rpca_opts` (include/tlsq.h), 128 bytes
 mutable struct RpcaOpts
     lambda::Cdouble; maxrank::Int64; iters::Int64; tol::Cdouble; rho::Cdouble
     nonnegA::Int32; nonnegE::Int32; hankel::Int32; nukeA::Int32
@@ -35,6 +35,7 @@ mutable struct RpcaOpts
     m_global::Int64; seed::UInt64
     on_iter::Ptr{Cvoid}; user::Ptr{Cvoid}
     svd_cb::Ptr{Cvoid}; opnorm_cb::Ptr{Cvoid}
+    phase_timing::Int32; reserved0::Int32
     RpcaOpts() = new()
 end
 

@@ -14,9 +14,10 @@ eng = tlsq_amd.Engine(0)
 dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda()
 dA, dE = torch.empty_like(dD), torch.empty_like(dD)
 torch.cuda.synchronize()
-for rep_i in range(2):
+for rep_i in range(4):
     t0 = time.perf_counter()
-    sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False)
+    sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False,
+                                  phase_timing=(rep_i == 3))
     dt = time.perf_counter() - t0
     print(f"run {rep_i}: iters={rep.iters_done} sv={sv} full={rep.eig_full} fast={rep.eig_fast} steps={rep.subspace_steps} "
           f"wall={dt*1e3:.1f} ms loop={rep.ms['loop']:.1f} ms", {k: round(v / rep.iters_done, 4) for k, v in rep.ms.items()}, flush=True)

@@ -30,7 +30,8 @@ class RpcaOpts(C.Structure):
                 ("nukeA", C.c_int32), ("svd_mode", C.c_int32), ("opnorm_mode", C.c_int32),
                 ("opnorm_mvps", C.c_int32), ("memory", C.c_int32),
                 ("m_global", C.c_int64), ("seed", C.c_uint64),
-                ("on_iter", ON_ITER), ("user", C.c_void_p), ("svd_cb", SVD_CB), ("opnorm_cb", OPNORM_CB)]
+                ("on_iter", ON_ITER), ("user", C.c_void_p), ("svd_cb", SVD_CB), ("opnorm_cb", OPNORM_CB),
+                ("phase_timing", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class RpcaInfo(C.Structure):

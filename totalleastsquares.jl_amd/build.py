@@ -34,6 +34,8 @@ def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "internal.hpp"), os.path.join(ROOT, "include", "tlsq.h")]
+    extra = os.environ.get("TLSQ_EXTRA_FLAGS", "").split()   # development builds (tools/kbench.py ablations)
+    force = force or bool(extra)
     objs = []
     procs = []
     for s in SOURCES:
@@ -42,7 +44,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if not force and _newer(obj, [src] + headers):
             continue
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -256,7 +256,7 @@ int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool i
 int subspace_max_block(int64_t N);
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
-                bool allow_cholqr, bool* used_cholqr);
+                bool allow_cholqr, bool* used_cholqr, bool one_pass = false);
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);

@@ -49,17 +49,22 @@ inline void reset_info(tlsq_rpca_info* info) {
 struct PhaseTimer {
     Handle* h;
     bool on;
+    // full: every phase boundary records an event.  Otherwise only the sweep kernels are bracketed (windows 0 and 4:
+    // what the HBM roofline needs) - every recorded event is a barrier packet the command processor works through
+    // between two kernels (~5.7 us each at C2 size: six of them were 7 % of an iteration).
+    bool full;
     int bank = 0;
     int n[2] = {0, 0};
-    int slot[2][16] = {};   // event behind each mark (an empty phase reuses the previous mark's event)
-    explicit PhaseTimer(Handle* hh, bool enable) : h(hh), on(enable) {}
-    // empty = nothing was queued since the previous mark: no event is recorded (every recorded event is a barrier
-    // packet the command processor has to work through between two kernels), the phase simply gets zero time
-    void mark(bool empty = false) {
+    int slot[2][16] = {};   // event behind each mark (an empty phase reuses the previous mark's event; -1: none)
+    PhaseTimer(Handle* hh, bool enable, bool all_phases) : h(hh), on(enable), full(all_phases) {}
+    // empty = nothing was queued since the previous mark: no event is recorded, the phase simply gets zero time.
+    // essential = one of the marks around a sweep kernel (recorded in the light mode too)
+    void mark(bool empty = false, bool essential = false) {
         if (!on || n[bank] >= 16) return;
         const int i = n[bank]++;
-        if (empty && i > 0) {
-            slot[bank][i] = slot[bank][i - 1];
+        if (!full && !essential) empty = true;
+        if (empty) {
+            slot[bank][i] = i > 0 ? slot[bank][i - 1] : -1;
             return;
         }
         slot[bank][i] = bank * 16 + i;
@@ -68,9 +73,13 @@ struct PhaseTimer {
     // adds elapsed(mark i, mark i+1) of bank b to *acc[i]; the bank's last event must have completed
     void collect_bank(int b, double** acc) {
         if (on && n[b] > 0) {
-            (void)hipEventSynchronize(h->ev[slot[b][n[b] - 1]]);
+            int last = -1;
+            for (int i = 0; i < n[b]; ++i)
+                if (slot[b][i] >= 0) last = slot[b][i];
+            if (last >= 0) (void)hipEventSynchronize(h->ev[last]);
             for (int i = 0; i + 1 < n[b]; ++i) {
-                if (slot[b][i] == slot[b][i + 1]) continue;
+                if (slot[b][i] < 0 || slot[b][i + 1] < 0 || slot[b][i] == slot[b][i + 1]) continue;
+                if (!full && i != 0 && i != 4) continue;   // light mode: only the sweep windows are bracketed properly
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, h->ev[slot[b][i]], h->ev[slot[b][i + 1]]) == hipSuccess && acc[i])
                     *acc[i] += ms;

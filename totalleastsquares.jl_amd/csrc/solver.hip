@@ -263,6 +263,8 @@ struct SubspaceState {
     LanczosRun cert;
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
     int q_floor = 1;       // smallest count that may be tried again (raised when a count needed a second step)
+    double chol_piv = 0.0; // smallest CholeskyQR pivot of the previous step on this warm block (one-pass guess, launch_orth)
+    int64_t chol_p = 0;    //   ... and the block width it was measured at
     int64_t cold_p = 18;   // block size of a cold start
     int extra_steps = 0;   // added to the step budget (retries in large mode)
     // Uncertainty of an eigenvalue of the computed Gram matrix relative to lambda_max (rounding of G = Z'Z, Ritz
@@ -474,6 +476,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     bool conv = false;
     double prev_maxres = 0.0;
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
+    static const bool no_onepass = [] { const char* e = getenv("TLSQ_NO_ONEPASS"); return e && e[0] == '1'; }();
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
         // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
@@ -494,7 +497,9 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
         }
         bool used_cholqr = false;
-        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr));
+        // one CholeskyQR pass when the previous step on this block cleared the one-pass pivot bound with room to spare
+        const bool one_pass = !cold && !force_cgs2 && !no_onepass && p <= 32 && st.chol_p == p && st.chol_piv >= 0.5;   // (32 = CQ_PMAX: single-block panels)
+        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr, one_pass));
         // Rayleigh-Ritz: H = Q' (G Q)
         TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
@@ -530,20 +535,29 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                 if (now_ms() - t_poll > 2000.0) break;
             }
             if (got) {
-                for (int64_t i = 0; i < 2 * p + 2; ++i) host[(size_t)i] = mb[8 + i];
+                for (int64_t i = 0; i < 2 * p + 3; ++i) host[(size_t)i] = mb[8 + i];
             } else {
                 // never seen in practice; do not pay the time-out again on this handle
                 h->mailbox_bytes = 0;
-                TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
+                TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
                                            h->stream));
                 TLSQ_HIP(h, hipStreamSynchronize(h->stream));
             }
         } else {
             TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
                                         (double*)GX, theta_dev, res_dev, N, p));
-            TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 2) * 8, hipMemcpyDeviceToHost,
+            TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
                                        h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        st.chol_piv = used_cholqr && host[2 * p + 1] == 0.0 ? host[2 * p + 2] : 0.0;
+        st.chol_p = p;
+        if (used_cholqr && one_pass && host[2 * p + 1] == 0.0 && host[2 * p + 2] < 0.25) {
+            // the one-pass guess was wrong (the columns have moved closer together since the last step): Q is only
+            // orthonormal to ~1e-10; same step again with both passes
+            --step;
+            --st.steps;
+            continue;
         }
         if (used_cholqr && host[2 * p + 1] != 0.0) {
             // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
@@ -980,7 +994,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     void* meanws = nullptr;
     if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * sizeof(T), &meanws));
 
-    PhaseTimer pt(h, timing);
+    // (all phase marks only on request: tlsq_rpca_opts.phase_timing or TLSQ_PHASE_TIMING=1)
+    static const bool env_phases = [] { const char* e = getenv("TLSQ_PHASE_TIMING"); return e && e[0] == '1'; }();
+    PhaseTimer pt(h, timing, env_phases || (opts && opts->phase_timing != 0));
     double zero_sink = 0.0;
     // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | read-back of the Frobenius
     // bound (booked under the cost evaluation) | next iteration's Gram queued behind the sweep (booked under gram) |
@@ -997,13 +1013,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const double thr = lam / mu;
         T* E = Ebuf[cur];
         T* Z = Zbuf[cur];
-        pt.mark();
+        pt.mark(false, !have_next);
         if (!have_next)
         {
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
             hbm_sweeps += 5.0 * panel_bytes;
         }
-        pt.mark(have_next);
+        pt.mark(have_next, !have_next);
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
         // Rank count, singular-value thresholding and the factors of A for the decomposition currently in (s, V).
@@ -1255,7 +1271,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const bool store_R = !(sumsq_dev && prev_lower > rskip_margin * ro.tol);
         T* Rst = store_R ? R : nullptr;
         if (!store_R) ++n_rskip;
-        pt.mark();
+        pt.mark(false, true);
         if (fuse_rebuild) {
             // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
             TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
@@ -1273,7 +1289,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
             hbm_sweeps += 6.0 * panel_bytes;
         }
-        pt.mark();
+        pt.mark(false, true);
         mu = mu_next;
         double rn = 0.0;
         bool cost_skipped = false;

@@ -807,8 +807,12 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 // (BCGS2) over blocks of 32 columns - each block is projected twice against the finished ones (two small products
 // per projection) and then orthonormalised by CholeskyQR2 - a handful of launches per block instead of the
 // column-by-column CGS2 (4 us per column at N = 512, 90 us per column at N = 4096).
+// `one_pass` (single-block panels only): the caller expects the smallest pivot of the first factorisation to clear
+// CQ_ONEPASS again (it did in the previous step of the same warm block), so only the first pass is queued - in place -
+// and the two launches of a second pass that would find nothing to do are not.  The caller checks status[2] of THIS
+// step (it arrives with the Ritz values) and repeats the step with both passes when the guess was wrong.
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
-                bool allow_cholqr, bool* used_cholqr) {
+                bool allow_cholqr, bool* used_cholqr, bool one_pass) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
     *used_cholqr = allow_cholqr && p <= 256 && !no_cholqr;
     if (!*used_cholqr) return launch_cgs2(h, Y, N, p, status_dev);
@@ -827,6 +831,12 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
                                    (size_t)c0 * 8 * 8, h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb,
                                    (int)N, sticky);
             }
+        }
+        if (one_pass && p <= CQ_PMAX) {   // (k_chol_trsm keeps its rows in registers: in == out is fine)
+            TLSQ_TRY(launch_panel_tn(h, Yb, Yb, W, N, pb, nullptr));
+            hipLaunchKernelGGL(k_chol_trsm, rows, dim3(64), 0, h->stream, (const double*)Yb, (const double*)W, status_dev, Yb,
+                               (int)N, (int)pb, 1, first);
+            break;
         }
         for (int pass = 1; pass <= 2; ++pass) {
             const double* in = pass == 1 ? Yb : Tb;
@@ -905,7 +915,7 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
         res[c] = rr;
         if (mailbox) {
             // Results go straight to host-visible (coherent, pinned) memory: [0] sequence flag, [8..) theta[p], res[p],
-            // status[2].  The workgroup that arrives last publishes the flag; the host polls it instead of paying a
+            // status[3].  The workgroup that arrives last publishes the flag; the host polls it instead of paying a
             // copy command plus a stream synchronisation (~40 us) for 2p+2 numbers.
             volatile double* mb = mailbox;
             mb[8 + c] = th;
@@ -914,6 +924,7 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
             if (atomicAdd(arrivals, 1u) == (unsigned int)(p - 1)) {
                 mb[8 + 2 * p] = status ? status[0] : 0.0;
                 mb[8 + 2 * p + 1] = status ? status[1] : 0.0;
+                mb[8 + 2 * p + 2] = status ? status[2] : 0.0;
                 *arrivals = 0u;
                 __threadfence_system();
                 mb[0] = seq;

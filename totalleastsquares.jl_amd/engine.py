@@ -171,7 +171,7 @@ class Engine:
     def make_opts(self, *, lam=None, maxrank=None, iters=None, tol=None, rho=None, nonnegA=False,
                   nonnegE=False, hankel=False, nukeA=True, memory=L.MEM_HOST, m_global=0,
                   svd_mode=L.SVD_FULL, opnorm_mode=L.OPNORM_EXACT, opnorm_mvps=10, seed=0, on_iter=None,
-                  svd_cb=None, opnorm_cb=None):
+                  svd_cb=None, opnorm_cb=None, phase_timing=False):
         o = L.RpcaOpts()
         self.lib.tlsq_rpca_opts_default(C.byref(o))
         if lam is not None:
@@ -191,6 +191,7 @@ class Engine:
         o.opnorm_mvps, o.seed = int(opnorm_mvps), int(seed)
         if on_iter is not None:
             o.on_iter = on_iter
+        o.phase_timing = int(bool(phase_timing))
         if svd_cb is not None:
             o.svd_cb = svd_cb
         if opnorm_cb is not None:
