@@ -110,7 +110,7 @@ def test_maxabs(eng, torch_mod):
 # MFMA contractions
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N", [(500, 50), (5, 5), (50, 4), (1000, 37), (777, 130), (2000, 128), (20000, 512),
-                                 (3, 40)])
+                                 (3, 40), (20001, 512), (16, 128), (17, 256), (4099, 384), (100000, 256), (8192, 640)])
 def test_gram(eng, torch_mod, M, N):
     torch = torch_mod
     rng = np.random.default_rng(3)
@@ -123,6 +123,26 @@ def test_gram(eng, torch_mod, M, N):
     G = to_host(dG)
     ref = Z.T @ Z
     assert np.array_equal(G, G.T)                                   # mirrored exactly
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert np.max(np.abs(G - ref) / scale) < 1e-13
+
+
+@pytest.mark.parametrize("M,N,ld,off", [(1000, 128, 1003, 1), (4096, 256, 4100, 0), (4096, 256, 4100, 2), (999, 200, 1024, 3)])
+def test_gram_strided(eng, torch_mod, M, N, ld, off):
+    """Z as a window of a larger column-major buffer: odd leading dimensions and bases that are not 16-byte aligned take
+    the guarded (element-wise) loads of the Gram kernel."""
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    buf = rng.standard_normal(ld * N + off + 8)
+    Z = buf[off: off + ld * N].reshape(N, ld).T[:M, :]
+    dbuf = torch.from_numpy(buf).cuda()
+    dG = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_gram_f64(eng.h, C.c_void_p(dbuf.data_ptr() + 8 * off), M, N, ld, dptr(dG), N) == 0
+    eng.synchronize()
+    G = to_host(dG)
+    ref = Z.T @ Z
+    assert np.array_equal(G, G.T)
     scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
     assert np.max(np.abs(G - ref) / scale) < 1e-13
 

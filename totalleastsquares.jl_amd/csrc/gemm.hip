@@ -299,6 +299,179 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
     }
 }
 
+
+// ---- the Gram kernel proper: slab[z] (lower 128 x 128 tiles) = Z[kbeg:kend, :]' Z[kbeg:kend, :], Z column-major --------
+// Same tile, panel layout and work-item map as k_gemm_f64<true, true>, but shaped for the way a CDNA wave issues - in
+// order, one MFMA every 64 cycles, nothing queued behind it (tools/ubench/syrk_f64.hip holds the measurements, C2 size:
+// 4 waves / classic loop 125.7 us, this form 102.5 us, MFMAs alone 95 us):
+//  * 8 waves (two per SIMD), wave tile 64 x 32: while one wave waits at the barrier or on LDS the other one issues;
+//  * fragments are read 16 bytes at a time: lane (r, g) holds k = 8q + 2g + {0, 1} of its column and feeds element m to
+//    MFMA m of the pair - the same permutation of k on both operands, so the product is unchanged;
+//  * software pipeline over the two LDS buffers: the next panel is stored during the first half of a stage, the barrier
+//    sits between the halves, and the second half already fetches the first fragments of the next stage - no LDS
+//    latency is exposed behind the barrier;
+//  * every LDS / global access is pinned between two MFMAs of its half-stage (sched_barrier): a burst of ds_write or
+//    global_load instructions ahead of the MFMAs would idle the matrix pipe under both waves of the SIMD at once.
+// FULL: tile inside the matrix, whole stages, aligned 2-element loads; otherwise every element is loaded under a guard.
+template <typename TZ, bool FULL>
+__device__ __forceinline__ void gram_body(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ Cz, int64_t ldc,
+                                          int64_t N, int64_t kbeg, int64_t kend, int64_t i0, int64_t j0,
+                                          double* __restrict__ smem) {
+    typedef TZ x2 __attribute__((ext_vector_type(2)));
+    constexpr int SL = 2;   // 2-element slots per thread and panel (128 columns x 8 pairs / 512 threads)
+    const int nstage = (kend > kbeg) ? (int)((kend - kbeg + TK - 1) / TK) : 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wj = w & 3, wi = w >> 2;
+    const int fr = lane & 15, fk = lane >> 4;
+    d4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    const TZ* pa[SL];
+    const TZ* pb[SL];
+    int so[SL], sr[SL], sk[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int e = tid + 512 * s;
+        sr[s] = e >> 3;
+        sk[s] = (e & 7) * 2;
+        pa[s] = Z + kbeg + sk[s] + (i0 + sr[s]) * ld;
+        pb[s] = Z + kbeg + sk[s] + (j0 + sr[s]) * ld;
+        so[s] = sr[s] * LDK + sk[s];
+    }
+    const int oa = (wi * 64 + fr) * LDK + 2 * fk, ob = (wj * 32 + fr) * LDK + 2 * fk;
+    x2 ra[SL], rb[SL];
+    d2 ga[2][4], gb[2][2];
+
+#define G_FR(buf, q, slot, i)                                                                                        \
+    do {                                                                                                             \
+        if ((i) < 4) ga[slot][(i) & 3] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + oa + ((i) & 3) * 16 * LDK + 8 * (q)); \
+        else gb[slot][(i) & 1] = *reinterpret_cast<const d2*>(smem + (2 + (buf)) * PANEL + ob + ((i) & 1) * 16 * LDK + 8 * (q)); \
+    } while (0)
+#define G_SW(buf, i)                                                                                                  \
+    do {                                                                                                              \
+        if ((i) < SL) *reinterpret_cast<d2*>(smem + (buf) * PANEL + so[(i) % SL]) = d2{(double)ra[(i) % SL][0], (double)ra[(i) % SL][1]}; \
+        else *reinterpret_cast<d2*>(smem + (2 + (buf)) * PANEL + so[(i) % SL]) = d2{(double)rb[(i) % SL][0], (double)rb[(i) % SL][1]}; \
+    } while (0)
+#define G_GL(i, koff)                                                                                  \
+    do {                                                                                               \
+        const int u_ = (i) % SL;                                                                       \
+        if (FULL) {                                                                                    \
+            if ((i) < SL) ra[u_] = *reinterpret_cast<const x2*>(pa[u_] + (koff));                      \
+            else rb[u_] = *reinterpret_cast<const x2*>(pb[u_] + (koff));                               \
+        } else {                                                                                       \
+            const int64_t k_ = kbeg + (koff) + sk[u_];                                                 \
+            const int64_t c_ = ((i) < SL ? i0 : j0) + sr[u_];                                          \
+            const TZ* p_ = ((i) < SL ? pa[u_] : pb[u_]) + (koff);                                      \
+            const bool o0_ = c_ < N && k_ < kend, o1_ = c_ < N && k_ + 1 < kend;                       \
+            const TZ v0_ = o0_ ? p_[0] : (TZ)0, v1_ = o1_ ? p_[1] : (TZ)0;                             \
+            if ((i) < SL) ra[u_] = x2{v0_, v1_};                                                       \
+            else rb[u_] = x2{v0_, v1_};                                                                \
+        }                                                                                              \
+    } while (0)
+#define G_MF(slot, t)                                                                                           \
+    acc[((t) >> 1) & 3][(t) & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[slot][((t) >> 1) & 3][(t) >> 3],     \
+                                                                        gb[slot][(t) & 1][(t) >> 3], acc[((t) >> 1) & 3][(t) & 1], 0, 0, 0)
+    // one half-stage: 16 MFMAs on fragment slot q, each followed by at most one memory instruction.
+    // KIND 0: fragments q = 1 of the same buffer; 1: those + the panel store into the other buffer; 2: fragments q = 0 of
+    // the other buffer + the global loads of the stage after the next; 3: MFMAs only
+    auto half = [&](auto kind, int cur, int q, int64_t koff) {
+        constexpr int KIND = decltype(kind)::value;
+        const int slot = q & 1, nslot = slot ^ 1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            G_MF(slot, t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (KIND != 3 && t < 6) {
+                if (KIND == 2) G_FR(cur ^ 1, 0, nslot, t);
+                else G_FR(cur, 1, nslot, t);
+            } else if (KIND == 1 && t - 6 < 2 * SL) {
+                G_SW(cur ^ 1, t - 6);
+            } else if (KIND == 2 && t - 6 < 2 * SL) {
+                G_GL(t - 6, koff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    std::integral_constant<int, 0> K0;
+    std::integral_constant<int, 1> K1;
+    std::integral_constant<int, 2> K2;
+    std::integral_constant<int, 3> K3;
+
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) G_GL(i, (int64_t)0);
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) G_SW(0, i);
+    }
+    __syncthreads();
+    if (nstage > 1) {
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) G_GL(i, (int64_t)TK);
+    }
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) G_FR(0, 0, 0, i);
+    }
+    for (int s = 0; s + 1 < nstage; ++s) {
+        const int cur = s & 1;
+        // (the last two stages load the final stage again instead of branching: those values are never stored)
+        const int64_t koff = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * TK;
+        half(K1, cur, 0, (int64_t)0);
+        __syncthreads();
+        half(K2, cur, 1, koff);
+    }
+    if (nstage > 0) {
+        const int cur = (nstage - 1) & 1;
+        half(K0, cur, 0, (int64_t)0);
+        half(K3, cur, 1, (int64_t)0);
+    }
+#undef G_FR
+#undef G_SW
+#undef G_GL
+#undef G_MF
+    // epilogue: lane holds column j = lane & 15, rows i = (lane >> 4) + 4 reg of each 16 x 16 tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = j0 + wj * 32 + b * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wi * 64 + a * 16 + fk + 4 * r;
+                if (FULL || (i < N && j < N)) Cz[j + i * ldc] = acc[a][b][r];
+            }
+        }
+}
+
+template <typename TZ>
+__global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ slab,
+                                                 int64_t ldc, int64_t N, int64_t K, int64_t kchunk, int64_t slab_stride,
+                                                 int nti, int nsplit, int vec_ok, const double* __restrict__ skip) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
+    if (skip && skip[0] != 0.0) return;
+    // work items as in k_gemm_f64: (K split z, lower-triangle tile t), z-major, dealt to the XCDs in contiguous runs
+    const int ntiles = nti * (nti + 1) / 2;
+    const int64_t nwork = (int64_t)ntiles * nsplit;
+    const int64_t cpx = (nwork + 7) / 8;
+    const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
+    if (item >= nwork) return;
+    const int z = (int)(item / ntiles);
+    const int t = (int)(item % ntiles);
+    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int64_t kbeg = (int64_t)z * kchunk;
+    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
+    double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+    const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);   // (j0 <= i0)
+    if (full) gram_body<TZ, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+    else gram_body<TZ, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+}
+
 static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda,
                        const void* B, int b_f32, int64_t ldb, void* C, int c_f32, int64_t ldc, int64_t P,
                        int64_t Q, int64_t K, int nsplit, int64_t kchunk, int64_t slab_stride, bool symmetric,
@@ -314,6 +487,18 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
     const int vec_ok = ((lda % 2) == 0 && (ldb % 2) == 0 && (kchunk % 2) == 0 &&
                         (reinterpret_cast<uintptr_t>(A) % am) == 0 && (reinterpret_cast<uintptr_t>(B) % bm) == 0)
                            ? 1 : 0;
+    static const bool old_gram = [] { const char* e = getenv("TLSQ_GRAM_OLD"); return e && e[0] == '1'; }();
+    if (symmetric && A_KC && B_KC && A == B && lda == ldb && a_f32 == b_f32 && !c_f32 && P == Q && !old_gram) {
+        // the Gram matrix of one K-contiguous operand (the only symmetric use of this layout): its own kernel
+        if (a_f32)
+            hipLaunchKernelGGL((k_gram_kc<float>), grid, dim3(512), 0, h->stream, (const float*)A, lda, (double*)C, ldc, P, K,
+                               kchunk, slab_stride, nti, nsplit, vec_ok, skip);
+        else
+            hipLaunchKernelGGL((k_gram_kc<double>), grid, dim3(512), 0, h->stream, (const double*)A, lda, (double*)C, ldc, P, K,
+                               kchunk, slab_stride, nti, nsplit, vec_ok, skip);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
 #define GO2(AK, BK, TA, TB)                                                                              \
     hipLaunchKernelGGL((k_gemm_f64<AK, BK, TA, TB>), grid, block, 0, h->stream, (const TA*)A, lda,       \
                        (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj, nsplit, \
