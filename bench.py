@@ -256,19 +256,22 @@ def main():
             except (OSError, KeyError):
                 continue
         # second roofline: the Gram kernel (fp64 MFMA, v_mfma_f64_16x16x4_f64), flops actually executed
-        # (only the lower-triangular 128x128 tiles of Z'Z are computed)
+        # ALGORITHMIC flops of G = Z'Z: the N (N + 1) / 2 distinct entries, 2 M flop each.  The kernel issues more: the
+        # strictly lower 128 x 128 tiles in full, of the diagonal tiles the 36 of 64 MFMA tiles on and below the diagonal
         nt = (N + 127) // 128
-        gram_flops = 2.0 * Ml * 128 * 128 * (nt * (nt + 1) // 2)
+        gram_flops = 1.0 * Ml * N * (N + 1)
+        issued_flops = 2.0 * Ml * 128 * 128 * (nt * (nt - 1) // 2 + nt * 36.0 / 64.0)
         if ms_ph.get("gram"):
             # Gram launches of the profiled solve: one per iteration, plus the one queued behind the last sweep
             # before its convergence is known (the library hides the host round trip behind it)
             n_gram = rep_ph.iters_done + 1
             ms = dict(ms, gram=ms_ph["gram"])
             tf = gram_flops / (ms["gram"] / n_gram * 1e-3) / 1e12
-            out["roofline_mfma"] = {"kernel": "k_gemm_f64<KC,KC> Gram(Z) + slab reduce", "bound": "mfma",
+            out["roofline_mfma"] = {"kernel": "k_gram_kc Gram(Z) + k_slab_reduce", "bound": "mfma",
                                     "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                    "flops_per_launch": gram_flops, "ms_per_launch": ms["gram"] / n_gram,
-                                    "launches": n_gram}
+                                    "flops_per_launch": gram_flops, "issued_flops_per_launch": issued_flops,
+                                    "issued_TFLOPs": issued_flops / (ms["gram"] / n_gram * 1e-3) / 1e12,
+                                    "ms_per_launch": ms["gram"] / n_gram, "launches": n_gram}
         if world == 1 and args.cpu_iters > 0:
             ncores = os.cpu_count() or 1
             # LAPACK gesdd on a 20000x512 panel does not scale to hundreds of threads: pick the best of a few

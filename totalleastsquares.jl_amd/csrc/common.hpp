@@ -44,6 +44,7 @@ struct Handle {
     double* mailbox_dev = nullptr;   // device address of the same memory
     double mail_seq = 0.0;
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
+    int64_t gram_tab_nti = 0;          // tile-order table in WS_GRAMTAB is the one for this many tile rows
     bool cert_ticket_ready = false;    // ... and the one of k_sq_norm
     Comm* comm = nullptr;
     int nranks = 1, rank = 0;
@@ -95,6 +96,7 @@ enum WsSlot {
     WS_DT, WS_AT, WS_ET, WS_UT,
     WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
     WS_PW,   // persistent power-iteration vector of the cost evaluation
+    WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)

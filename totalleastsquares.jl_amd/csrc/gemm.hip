@@ -8,6 +8,7 @@
 //     A_KC: Aop(i,k) = A[k + i*lda]   else  A[i + k*lda]
 //     B_KC: Bop(k,j) = B[k + j*ldb]   else  B[j + k*ldb]
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
                                                      int64_t slab_stride, int nsplit,
                                                      void* __restrict__ C, int c_f32, int64_t ldc, int64_t P,
                                                      int64_t Q, int symmetric, const double* __restrict__ skip,
-                                                     double* __restrict__ normpart) {
+                                                     double* __restrict__ normpart, int nsplit_d, int tri) {
     __shared__ double nred[4];
     if (skip && skip[0] != 0.0) return;
     const int64_t total = P * Q;
@@ -279,9 +280,14 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t j = e % Q, i = e / Q;
         if (symmetric && (j / TJ) > (i / TI)) continue;
+        // tri (k_gram_kc): diagonal tiles hold only their 16 x 16 MFMA tiles on and below the diagonal, in nsplit_d slabs
+        const bool dtile = tri && (j / TJ) == (i / TI);
+        if (dtile && (j / 16) > (i / 16)) continue;
+        const int ns = dtile ? nsplit_d : nsplit;
         double s = 0.0;
-        for (int zz = 0; zz < nsplit; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
-        nacc += ((symmetric && (j / TJ) < (i / TI)) ? 2.0 : 1.0) * s * s;
+        for (int zz = 0; zz < ns; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
+        const bool twice = symmetric && ((j / TJ) < (i / TI) || (dtile && (j / 16) < (i / 16)));
+        nacc += (twice ? 2.0 : 1.0) * s * s;
         if (c_f32) {
             reinterpret_cast<float*>(C)[j + i * ldc] = (float)s;
             if (symmetric) reinterpret_cast<float*>(C)[i + j * ldc] = (float)s;
@@ -445,31 +451,321 @@ __device__ __forceinline__ void gram_body(const TZ* __restrict__ Z, int64_t ld, 
         }
 }
 
+// ---- diagonal 128 x 128 tiles of the Gram matrix: only the 36 MFMA tiles (16 x 16) on and below the diagonal ----------
+// Tile rows a, columns b of the 8 x 8 grid, b <= a.  Rows a and 7 - a hold nine tiles together; every pair is split
+// 5 + 4 over two waves, the five-tile waves (0..3) and the four-tile waves (4..7) of a pair sit on the same SIMD:
+//   wave u     (u = 0..3): row 7 - u, columns 0..4
+//   wave 4 + u           : row 7 - u, columns 5..7 - u   and   row u, columns 0..u
+// 9 tiles per SIMD and k-step instead of 16: a diagonal work item costs 0.56 of an off-diagonal one per row of Z (the
+// host gives it a longer K chunk).  One operand panel (A == B), fragments: two A rows + one B per tile.
+template <typename TZ, bool FULL, bool FIVE>
+__device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ Cz,
+                                               int64_t ldc, int64_t N, int64_t kbeg, int64_t kend, int64_t i0,
+                                               double* __restrict__ smem) {
+    typedef TZ x2 __attribute__((ext_vector_type(2)));
+    constexpr int SL = 2;
+    constexpr int NTL = FIVE ? 5 : 4;
+    const int nstage = (kend > kbeg) ? (int)((kend - kbeg + TK - 1) / TK) : 0;
+    const int tid = threadIdx.x, lane = tid & 63, u = (tid >> 6) & 3;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ar0 = 7 - u, ar1 = u;
+    const int c1 = FIVE ? 5 : 3 - u;   // tiles t < c1 lie in row ar0 (columns b0 + t), the others in row ar1 (columns t - c1)
+    const int b0 = FIVE ? 0 : 5;
+    d4 acc[NTL];
+    int ob[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        const int b = t < c1 ? b0 + t : t - c1;
+        ob[t] = (16 * b + fr) * LDK + 2 * fk;
+    }
+    const int oa0 = (16 * ar0 + fr) * LDK + 2 * fk, oa1 = (16 * ar1 + fr) * LDK + 2 * fk;
+    const TZ* pa[SL];
+    int so[SL], sr[SL], sk[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int e = tid + 512 * s;
+        sr[s] = e >> 3;
+        sk[s] = (e & 7) * 2;
+        pa[s] = Z + kbeg + sk[s] + (i0 + sr[s]) * ld;
+        so[s] = sr[s] * LDK + sk[s];
+    }
+    x2 ra[SL];
+    d2 ga[2][2], gb[2][NTL];
+
+#define D_FR(buf, q, slot, i)                                                                                    \
+    do {                                                                                                         \
+        if ((i) == 0) ga[slot][0] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + oa0 + 8 * (q));           \
+        else if ((i) == 1) ga[slot][1] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + oa1 + 8 * (q));      \
+        else gb[slot][((i) - 2) % NTL] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + ob[((i) - 2) % NTL] + 8 * (q)); \
+    } while (0)
+#define D_SW(buf, i) \
+    *reinterpret_cast<d2*>(smem + (buf) * PANEL + so[(i) % SL]) = d2{(double)ra[(i) % SL][0], (double)ra[(i) % SL][1]}
+#define D_GL(i, koff)                                                                     \
+    do {                                                                                  \
+        const int u_ = (i) % SL;                                                          \
+        if (FULL) {                                                                       \
+            ra[u_] = *reinterpret_cast<const x2*>(pa[u_] + (koff));                       \
+        } else {                                                                          \
+            const int64_t k_ = kbeg + (koff) + sk[u_];                                    \
+            const int64_t c_ = i0 + sr[u_];                                               \
+            const TZ* p_ = pa[u_] + (koff);                                               \
+            const bool o0_ = c_ < N && k_ < kend, o1_ = c_ < N && k_ + 1 < kend;          \
+            ra[u_] = x2{o0_ ? p_[0] : (TZ)0, o1_ ? p_[1] : (TZ)0};                        \
+        }                                                                                 \
+    } while (0)
+    // KIND as in gram_body
+    auto half = [&](auto kind, int cur, int q, int64_t koff) {
+        constexpr int KIND = decltype(kind)::value;
+        const int slot = q & 1, nslot = slot ^ 1;
+#pragma unroll
+        for (int n = 0; n < 2 * NTL; ++n) {
+            const int t = n % NTL, m = n / NTL;
+            const double av = (t < c1) ? ga[slot][0][m] : ga[slot][1][m];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gb[slot][t][m], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (KIND != 3 && n < 2 + NTL) {
+                if (KIND == 2) D_FR(cur ^ 1, 0, nslot, n);
+                else D_FR(cur, 1, nslot, n);
+            } else if (KIND == 1 && n - (2 + NTL) < SL) {
+                D_SW(cur ^ 1, n - (2 + NTL));
+            } else if (KIND == 2 && n - (2 + NTL) < SL) {
+                D_GL(n - (2 + NTL), koff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    std::integral_constant<int, 0> K0;
+    std::integral_constant<int, 1> K1;
+    std::integral_constant<int, 2> K2;
+    std::integral_constant<int, 3> K3;
+
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < SL; ++i) D_GL(i, (int64_t)0);
+#pragma unroll
+        for (int i = 0; i < SL; ++i) D_SW(0, i);
+    }
+    __syncthreads();
+    if (nstage > 1) {
+#pragma unroll
+        for (int i = 0; i < SL; ++i) D_GL(i, (int64_t)TK);
+    }
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < 2 + NTL; ++i) D_FR(0, 0, 0, i);
+    }
+    for (int s = 0; s + 1 < nstage; ++s) {
+        const int cur = s & 1;
+        const int64_t koff = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * TK;
+        half(K1, cur, 0, (int64_t)0);
+        __syncthreads();
+        half(K2, cur, 1, koff);
+    }
+    if (nstage > 0) {
+        const int cur = (nstage - 1) & 1;
+        half(K0, cur, 0, (int64_t)0);
+        half(K3, cur, 1, (int64_t)0);
+    }
+#undef D_FR
+#undef D_SW
+#undef D_GL
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int a = t < c1 ? ar0 : ar1, b = t < c1 ? b0 + t : t - c1;
+        const int64_t j = i0 + 16 * b + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + 16 * a + fk + 4 * r;
+            if (FULL || (i < N && j < N)) Cz[j + i * ldc] = acc[t][r];
+        }
+    }
+}
+
+// Work items: the strictly lower 128 x 128 tiles, nsplit_o K chunks each (z-major), then the diagonal tiles, nsplit_d
+// (longer) chunks each; both kinds cost about the same, and the XCDs get contiguous runs of the list (blocks b and b + 8
+// share an XCD and its L2: neighbours share z, i.e. the same rows of Z).
 template <typename TZ>
 __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ slab,
-                                                 int64_t ldc, int64_t N, int64_t K, int64_t kchunk, int64_t slab_stride,
-                                                 int nti, int nsplit, int vec_ok, const double* __restrict__ skip) {
+                                                 int64_t ldc, int64_t N, int64_t K, int64_t kchunk_o, int64_t kchunk_d,
+                                                 int64_t slab_stride, int nti, int nsplit_o, int nsplit_d, int vec_ok,
+                                                 const double* __restrict__ skip, const int32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
     if (skip && skip[0] != 0.0) return;
-    // work items as in k_gemm_f64: (K split z, lower-triangle tile t), z-major, dealt to the XCDs in contiguous runs
-    const int ntiles = nti * (nti + 1) / 2;
-    const int64_t nwork = (int64_t)ntiles * nsplit;
+    const int noff = nti * (nti - 1) / 2;
+    const int64_t n_o = (int64_t)noff * nsplit_o;
+    const int64_t nwork = n_o + (int64_t)nti * nsplit_d;
     const int64_t cpx = (nwork + 7) / 8;
     const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
     if (item >= nwork) return;
-    const int z = (int)(item / ntiles);
-    const int t = (int)(item % ntiles);
-    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int64_t kbeg = (int64_t)z * kchunk;
-    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
-    double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
-    const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);   // (j0 <= i0)
-    if (full) gram_body<TZ, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
-    else gram_body<TZ, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+    if (item < n_o) {
+        const int z = (int)(item / noff);
+        const int t = (int)(item % noff);
+        // t -> (ti, tj), tj < ti: from the host's blocked order (large N), else row-wise through the strictly lower triangle
+        int ti, tj;
+        if (order) {
+            ti = order[2 * t];
+            tj = order[2 * t + 1];
+        } else {
+            ti = (int)((sqrtf(8.0f * (float)t + 1.0f) + 1.0f) * 0.5f);
+            while (ti * (ti + 1) / 2 <= t) ++ti;
+            while (ti * (ti - 1) / 2 > t) --ti;
+            tj = t - ti * (ti - 1) / 2;
+        }
+        const int64_t kbeg = (int64_t)z * kchunk_o;
+        const int64_t kend = (kbeg + kchunk_o < K) ? kbeg + kchunk_o : K;
+        const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
+        double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+        const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);   // (j0 < i0)
+        if (full) gram_body<TZ, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+        else gram_body<TZ, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+    } else {
+        const int64_t d = item - n_o;
+        const int z = (int)(d / nti);
+        const int ti = (int)(d % nti);
+        const int64_t kbeg = (int64_t)z * kchunk_d;
+        const int64_t kend = (kbeg + kchunk_d < K) ? kbeg + kchunk_d : K;
+        const int64_t i0 = (int64_t)ti * TI;
+        double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+        const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);
+        const bool five = threadIdx.x < 256;   // waves 0..3 (wave-uniform: both sides meet the same barriers)
+        if (full) {
+            if (five) gram_diag_body<TZ, true, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, smem);
+            else gram_diag_body<TZ, true, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, smem);
+        } else {
+            if (five) gram_diag_body<TZ, false, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, smem);
+            else gram_diag_body<TZ, false, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, smem);
+        }
+    }
+}
+
+// G = Z'Z through k_gram_kc: split-K slabs + the fixed-order reduction (k_slab_reduce, tri = 1)
+static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K,
+                   const double* skip, double* normpart, int* normblocks) {
+    const int64_t nti = (N + TI - 1) / TI, noff = nti * (nti - 1) / 2;
+    // relative cost of a diagonal work item per row of Z (9 of 16 MFMA tiles per SIMD + the shared per-stage overhead)
+    static const double rho = [] { const char* e = getenv("TLSQ_GRAM_RHO"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.72; }();
+    static const int64_t target_wgs = [] { const char* e = getenv("TLSQ_GEMM_WGS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 256); }();
+    // K splits (nsplit_o for the off-diagonal tiles, nsplit_d for the diagonal ones) by a small cost model, in us:
+    // an item of kc rows takes kc * c_row (a CU at ~92 % of its MFMA peak: 2 * 128 * 128 flop per row) + c_item
+    // (dispatch, first loads, slab store: fitted), items run in rounds of one per CU, and every slab entry is written and read once more
+    // (~4 TB/s).  Small N: one round, ~252 items.  Large N: enough items that the last round is nearly full without
+    // the slabs growing past what that is worth.
+    constexpr double c_row = 0.116, c_item = 18.0, slab_us_per_byte = 2.0 / 4.0e6;
+    const int64_t maxsplit = std::max<int64_t>(1, (K + 4 * TK - 1) / (4 * TK));                       // >= four K stages per item
+    const int64_t memsplit = std::max<int64_t>(1, (int64_t)(((size_t)2 << 30) / ((size_t)N * N * 8)));   // slabs <= 2 GB
+    auto chunk = [&](int64_t& ns) {
+        int64_t kc = (K + ns - 1) / ns;
+        kc = (kc + TK - 1) / TK * TK;
+        if (kc < TK) kc = TK;
+        ns = K > 0 ? (K + kc - 1) / kc : 1;
+        return kc;
+    };
+    int64_t nsplit_o = 1, nsplit_d = 1;
+    double best = 1e300;
+    const int64_t hi = std::min<int64_t>(std::min<int64_t>(maxsplit, memsplit), 4 * target_wgs);
+    for (int64_t so = 1; so <= hi; ++so) {
+        for (int pass = 0; pass < 2; ++pass) {
+            int64_t o = noff > 0 ? so : 1;
+            int64_t d = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::floor(so * rho) + pass), std::min(maxsplit, memsplit));
+            const int64_t kco = chunk(o), kcd = chunk(d);
+            const double t_o = kco * c_row + c_item, t_d = rho * kcd * c_row + c_item;
+            // list schedule on target_wgs CUs, off-diagonal items first (the launch order): r_o full rounds, then m CUs
+            // take the rest of them while the others start on the diagonal items
+            const int64_t n_o = noff * o, n_d = nti * d, W = target_wgs;
+            const int64_t r_o = n_o / W, m = n_o % W;
+            const double s0 = (double)r_o * t_o, s1 = m > 0 ? s0 + t_o : s0;   // when the two groups of CUs become free
+            double t_end = s1;
+            for (int64_t k = 0;; ++k) {   // smallest finishing time with room for all diagonal items
+                const double c0 = s0 + (double)k * t_d, c1 = s1 + (double)k * t_d;
+                bool done = false;
+                for (const double T : {std::min(c0, c1), std::max(c0, c1)}) {
+                    const double cap = (double)(W - m) * std::floor((T - s0) / t_d + 1e-9) +
+                                       (m > 0 ? (double)m * std::max(0.0, std::floor((T - s1) / t_d + 1e-9)) : 0.0);
+                    if (cap >= (double)n_d && T >= s1 - 1e-9) {
+                        t_end = std::max(T, s1);
+                        done = true;
+                        break;
+                    }
+                }
+                if (done) break;
+            }
+            const double slab_bytes = ((double)n_o + 0.5625 * (double)n_d) * (double)(TI * TJ * 8);
+            // (several rounds: + a quarter item - the CUs drift out of step, and long items lose more to that than the
+            // schedule says: 65536 x 4096 measured 18.0 ms with 4 chunks, 16.6 ms with 16)
+            const double t = t_end + (n_o + n_d > W ? 0.25 * std::max(t_o, t_d) : 0.0) + slab_bytes * slab_us_per_byte;
+            if (t < best) {
+                best = t;
+                nsplit_o = o;
+                nsplit_d = d;
+            }
+        }
+        if (noff == 0 && so >= hi) break;
+    }
+    if (const char* e = getenv("TLSQ_GRAM_SPLIT")) {   // development: "o,d"
+        long o = 0, d = 0;
+        if (sscanf(e, "%ld,%ld", &o, &d) == 2 && o > 0 && d > 0) {
+            nsplit_o = noff > 0 ? std::min<int64_t>(o, maxsplit) : 1;
+            nsplit_d = std::min<int64_t>(d, maxsplit);
+        }
+    }
+    const int64_t kchunk_o = chunk(nsplit_o), kchunk_d = chunk(nsplit_d);
+    {
+        static const bool dbg = [] { const char* e = getenv("TLSQ_DEBUG"); return e && e[0] == '2'; }();
+        if (dbg) fprintf(stderr, "[tlsq] gram %lld x %lld: nsplit %lld / %lld, model %.0f us\n", (long long)K, (long long)N,
+                         (long long)nsplit_o, (long long)nsplit_d, best);
+    }
+    const int64_t nslab = std::max(nsplit_o, nsplit_d);
+    const int64_t slab_stride = N * N;
+    void* slab;
+    TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nslab * slab_stride) * sizeof(double), &slab));
+    const int64_t nwork = noff * nsplit_o + nti * nsplit_d;
+    const int64_t cpx = (nwork + 7) / 8;
+    if (8 * cpx > 2147483647LL) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: grid too large");
+    // Tile order.  The ~32 work items an XCD runs at a time are neighbours in the list and march through the same rows
+    // of Z: row-wise order makes them share one column block of Z and differ in the other (33 blocks through the L2 for
+    // 32 tiles); blocks of 8 x 4 tiles share 12.  From N = 2048 on the kernel is otherwise bound by that traffic
+    // (65536 x 4096: 70 GB per Gram).
+    const int32_t* order = nullptr;
+    static const bool no_order = [] { const char* e = getenv("TLSQ_GRAM_ROWWISE"); return e && e[0] == '1'; }();
+    if (nti > 8 && !no_order) {
+        void* tab;
+        TLSQ_TRY(ws_get(h, WS_GRAMTAB, (size_t)noff * 8, &tab));
+        if (h->gram_tab_nti != nti) {
+            std::vector<int32_t> o;
+            o.reserve((size_t)noff * 2);
+            for (int64_t I = 0; I < nti; I += 8)
+                for (int64_t J = 0; J < std::min(I + 8, nti); J += 4)
+                    for (int64_t ti = I; ti < std::min(I + 8, nti); ++ti)
+                        for (int64_t tj = J; tj < std::min(J + 4, ti); ++tj) {
+                            o.push_back((int32_t)ti);
+                            o.push_back((int32_t)tj);
+                        }
+            if ((int64_t)o.size() != 2 * noff) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: tile order table");
+            TLSQ_HIP(h, hipMemcpyAsync(tab, o.data(), o.size() * 4, hipMemcpyHostToDevice, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (pageable source; once per N)
+            h->gram_tab_nti = nti;
+        }
+        order = (const int32_t*)tab;
+    }
+    const uintptr_t am = z_f32 ? 8 : 16;
+    const int vec_ok = ((ld % 2) == 0 && (kchunk_o % 2) == 0 && (kchunk_d % 2) == 0 && (reinterpret_cast<uintptr_t>(Z) % am) == 0) ? 1 : 0;
+    if (z_f32)
+        hipLaunchKernelGGL((k_gram_kc<float>), dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, (const float*)Z, ld,
+                           (double*)slab, N, N, K, kchunk_o, kchunk_d, slab_stride, (int)nti, (int)nsplit_o, (int)nsplit_d,
+                           vec_ok, skip, order);
+    else
+        hipLaunchKernelGGL((k_gram_kc<double>), dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, (const double*)Z, ld,
+                           (double*)slab, N, N, K, kchunk_o, kchunk_d, slab_stride, (int)nti, (int)nsplit_o, (int)nsplit_d,
+                           vec_ok, skip, order);
+    TLSQ_HIP(h, hipGetLastError());
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (normblocks) *normblocks = (int)g;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, N, slab_stride,
+                       (int)nsplit_o, (void*)G, 0, ldg, N, N, 1, skip, normpart, (int)nsplit_d, 1);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda,
@@ -487,18 +783,6 @@ static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32
     const int vec_ok = ((lda % 2) == 0 && (ldb % 2) == 0 && (kchunk % 2) == 0 &&
                         (reinterpret_cast<uintptr_t>(A) % am) == 0 && (reinterpret_cast<uintptr_t>(B) % bm) == 0)
                            ? 1 : 0;
-    static const bool old_gram = [] { const char* e = getenv("TLSQ_GRAM_OLD"); return e && e[0] == '1'; }();
-    if (symmetric && A_KC && B_KC && A == B && lda == ldb && a_f32 == b_f32 && !c_f32 && P == Q && !old_gram) {
-        // the Gram matrix of one K-contiguous operand (the only symmetric use of this layout): its own kernel
-        if (a_f32)
-            hipLaunchKernelGGL((k_gram_kc<float>), grid, dim3(512), 0, h->stream, (const float*)A, lda, (double*)C, ldc, P, K,
-                               kchunk, slab_stride, nti, nsplit, vec_ok, skip);
-        else
-            hipLaunchKernelGGL((k_gram_kc<double>), grid, dim3(512), 0, h->stream, (const double*)A, lda, (double*)C, ldc, P, K,
-                               kchunk, slab_stride, nti, nsplit, vec_ok, skip);
-        TLSQ_HIP(h, hipGetLastError());
-        return TLSQ_OK;
-    }
 #define GO2(AK, BK, TA, TB)                                                                              \
     hipLaunchKernelGGL((k_gemm_f64<AK, BK, TA, TB>), grid, block, 0, h->stream, (const TA*)A, lda,       \
                        (const TB*)B, ldb, C, c_f32, ldc, P, Q, K, kchunk, slab_stride, nti, ntj, nsplit, \
@@ -525,6 +809,9 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
                const double* skip, double* normpart, int* normblocks) {
     if (P <= 0 || Q <= 0) return TLSQ_OK;
     if (normpart && !symmetric) return set_err(h, TLSQ_ERR_ARG, "gemm: the norm by-product needs the symmetric (slab) path");
+    static const bool old_gram = [] { const char* e = getenv("TLSQ_GRAM_OLD"); return e && e[0] == '1'; }();
+    if (symmetric && A_KC && B_KC && A == B && lda == ldb && a_f32 == b_f32 && !c_f32 && P == Q && !old_gram)
+        return gram_kc(h, A, a_f32, lda, (double*)C, ldc, P, K, skip, normpart, normblocks);   // the Gram matrix of one operand
     const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
     const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
     // split K so that the launch has ~256 workgroups (one per CU), each with >= 4 K stages
@@ -568,7 +855,7 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
     if (g > 2048) g = 2048;
     if (normblocks) *normblocks = (int)g;
     hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, Q,
-                       slab_stride, (int)nsplit, C, c_f32, ldc, P, Q, symmetric ? 1 : 0, skip, normpart);
+                       slab_stride, (int)nsplit, C, c_f32, ldc, P, Q, symmetric ? 1 : 0, skip, normpart, (int)nsplit, 0);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
