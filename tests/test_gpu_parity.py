@@ -8,6 +8,7 @@ iteration count and per-iteration svp;  the reference's 5x5 tab
 """
 import ctypes as C
 import math
+import os
 import warnings
 
 import numpy as np
@@ -15,6 +16,7 @@ import pytest
 import scipy.linalg as sla
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -539,6 +541,40 @@ def test_lowrankfilter_vs_oracle_and_thresholds(eng):                # test/runt
     # multi-channel, lag 2
     yy = np.column_stack([np.sin(0.1 * np.arange(T)), np.sin(0.3 * np.arange(T))]) + 0.1 * rng.standard_normal((T, 2))
     assert relerr(eng.lowrankfilter(yy, 20, lag=2), O.lowrankfilter(yy, 20, lag=2)) < 1e-8
+
+
+def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
+    """with one channel and lag 1 the solver reads H[i, j] = y[i + j] from the series - set-up on a
+    transient copy, sweeps and residual from y - so a fresh handle ends up holding seven panels, not eight, and the
+    result is bit-identical to the run that builds and keeps H (TLSQ_LAZY_HANKEL=0 TLSQ_IMPLICIT_HANKEL=0, separate
+    process: the switches are read once)."""
+    import subprocess
+    import sys
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    Ns, n = 300_000, 256                       # K x n = 7.7e7 entries: the large-panel (fused, implicit) sweep
+    y, noise = O.synth_series(Ns, seed=3)
+    np.save(tmp_path / "y.npy", y + noise)
+    free0, _ = torch_mod.cuda.mem_get_info(0)
+    e2 = tlsq_amd.Engine(0)
+    try:
+        yf, rep = e2.lowrankfilter(y + noise, n, return_report=True, cost_history=False)
+        free1, _ = torch_mod.cuda.mem_get_info(0)
+    finally:
+        e2.close()
+    K = Ns - n + 1
+    panel = (K + 15) // 16 * 16 * n * 8
+    assert rep.converged
+    assert (free0 - free1) < 7.35 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import torch; torch.zeros(1, device='cuda'); import tlsq_amd;"
+            "e = tlsq_amd.Engine(0); y = np.load(%r);"
+            "yf, rep = e.lowrankfilter(y, %d, return_report=True, cost_history=False);"
+            "np.save(%r, yf); open(%r, 'w').write(str(rep.iters_done))"
+            % (ROOT, str(tmp_path / "y.npy"), n, str(tmp_path / "yf.npy"), str(tmp_path / "iters.txt")))
+    env = dict(os.environ, TLSQ_LAZY_HANKEL="0", TLSQ_IMPLICIT_HANKEL="0")
+    subprocess.run([sys.executable, "-c", code], env=env, check=True, timeout=600)
+    assert int(open(tmp_path / "iters.txt").read()) == rep.iters_done
+    assert np.array_equal(np.load(tmp_path / "yf.npy"), yf)
 
 
 def test_missing_values(eng):                                        # test/runtests.jl:172-185

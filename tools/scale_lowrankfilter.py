@@ -13,13 +13,17 @@ ap.add_argument("--N", type=int, default=10_000_000)
 ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--check", action="store_true", help="compare with the CPU oracle (small N only)")
 ap.add_argument("--no-hist", action="store_true", help="do not ask for the per-iteration cost (what a plain Julia call does)")
+ap.add_argument("--phases", action="store_true", help="bracket every phase with events (tlsq_rpca_opts.phase_timing)")
 a = ap.parse_args()
 y, noise = O.synth_series(a.N, seed=0)
 yn = y + noise
+import torch
+free0, total = torch.cuda.mem_get_info(0)
 eng = tlsq_amd.Engine(0)
 t0 = time.perf_counter()
-yf, rep = eng.lowrankfilter(yn, a.n, return_report=True, cost_history=not a.no_hist)
+yf, rep = eng.lowrankfilter(yn, a.n, return_report=True, cost_history=not a.no_hist, phase_timing=a.phases)
 dt = time.perf_counter() - t0
+free1, _ = torch.cuda.mem_get_info(0)   # the handle keeps its workspace: what is missing now is the peak of the call
 qn = lambda x: x / np.quantile(np.abs(x), 0.9)
 ratio = np.mean((y - qn(yf)) ** 2) / np.mean(noise ** 2)
 K = a.N - a.n + 1
@@ -28,6 +32,9 @@ print(f"N={a.N} n={a.n}: H is {K}x{a.n} ({K*a.n*8/1e9:.2f} GB/array); {rep.iters
       f"{rep.iters_done/(rep.ms['loop']/1e3):.2f} iters/s; MSE ratio {ratio:.2e} (< 1e-3 required); "
       f"phases ms/iter: " + ", ".join(f"{k}={v/rep.iters_done:.1f}" for k, v in rep.ms.items() if k in
                                      ("shrink", "gram", "eig", "rebuild", "update", "opnorm")))
+Kp = (K + 15) // 16 * 16
+print(f"device memory held by the handle after the call: {(free0 - free1)/1e9:.2f} GB = {(free0 - free1)/(Kp*a.n*8):.2f} panels "
+      f"of {Kp*a.n*8/1e9:.2f} GB")
 if a.check:
     yo = O.lowrankfilter(yn, a.n)
     print("rel diff vs oracle:", np.linalg.norm(yf - yo) / np.linalg.norm(yo))

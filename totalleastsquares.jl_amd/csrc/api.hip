@@ -179,14 +179,21 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     const bool exact_shape = (opts && (opts->hankel || opts->svd_mode == TLSQ_SVD_CALLBACK ||
                                        opts->opnorm_mode == TLSQ_OPNORM_CALLBACK)) || (K < LD && !sharded);
     const int64_t Kp = exact_shape ? K : (K + 15) / 16 * 16;
-    void *dy, *H, *A, *E;
+    // one channel, lag 1, robust mode - the Hankel matrix is never stored.  The big fused sweep, the
+    // residual and the set-up of rpca_core read H[i, j] = y[i + j] from the series (ResolvedOpts::hankel_lazy): seven
+    // resident panels instead of eight, six panel passes per iteration instead of seven.
+    static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
+    static const bool lazy_ok = [] { const char* e = getenv("TLSQ_LAZY_HANKEL"); return !(e && e[0] == '0'); }();
+    const bool implicit = implicit_ok && Dch == 1 && lag == 1;
+    const bool lazy = implicit && lazy_ok && sv <= 0 && !exact_shape;
+    void *dy, *H = nullptr, *A, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
-    TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
+    if (!lazy) TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
     TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
-    if (Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
+    if (!lazy && Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
     TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     const T* yw = (const T*)dy + s0;                                                // this rank's window
-    TLSQ_TRY(launch_hankel<T>(h, yw, Nw, Dch, Nx, n, lag, (T*)H, Kp));                // :120
+    if (!lazy) TLSQ_TRY(launch_hankel<T>(h, yw, Nw, Dch, Nx, n, lag, (T*)H, Kp));     // :120
     int status = TLSQ_OK;
     if (sv <= 0) {                                                                            // :121-122
         TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * ES, &E));
@@ -195,11 +202,10 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         oo.m_global = Kg;
         ResolvedOpts ro = resolve(&oo, K, LD, 1e-3);  // tol defaults to 1e-3 here (:119)
         ro.m_global = Kg;
-        // SURVEY §8f rank 2 (first step): the 7-pass sweep of large panels reads y instead of H (6 passes)
-        static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
-        if (implicit_ok && Dch == 1 && lag == 1) {
+        if (implicit) {
             ro.hankel_y = yw;
             ro.hankel_K = K;
+            ro.hankel_lazy = lazy;
         }
         if (std::min(Kg, LD) > kGramMaxN)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: min(K, n*D) = %lld exceeds %lld, the largest Gram "

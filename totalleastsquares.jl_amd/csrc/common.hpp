@@ -126,7 +126,9 @@ int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 template <typename T>
-int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n);   // R = (D - A) - E
+int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n);
+template <typename T>
+int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N);   // R = (D - A) - E
 // 64 doubles -> the handle's mailbox ([8..72)), published with sequence number seq
 int launch_publish_slots(Handle* h, const double* slots, double seq);
 // rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored

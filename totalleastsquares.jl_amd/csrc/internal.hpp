@@ -142,6 +142,10 @@ struct ResolvedOpts {
     // fused sweep reads the vector instead of the panel (set by lowrankfilter; fp64, one channel, lag 1)
     const void* hankel_y = nullptr;
     int64_t hankel_K = 0;
+    // ... and the caller has not built that panel at all (rpca_core is called with D == nullptr): the set-up works on a
+    // transient copy in a buffer the loop only needs later, and the rare kernels without an implicit form build one on
+    // demand (seven resident panels instead of eight)
+    bool hankel_lazy = false;
 };
 
 inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {

@@ -919,6 +919,36 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const int mvps = opts && opts->opnorm_mvps > 0 ? opts->opnorm_mvps : 10;
     const uint64_t seed = opts ? opts->seed : 0;
 
+    // The data panel.  Normally the caller's; for an implicit Hankel source (ro.hankel_lazy) a transient copy in Z's
+    // second buffer serves the set-up and the first shrink - the loop writes that buffer for the first time in the sweep
+    // that follows, which reads y itself - and the kernels without an implicit form (non-fused sweeps: ranks above 32,
+    // hooks) get a real panel built on demand.
+    const T* Dm = D;
+    bool d_transient = false;
+    auto build_hankel = [&](T* dst) -> int {
+        const int64_t Kh = ro.hankel_K, Nw = Kh - 1 + N;
+        if (Kh != M) TLSQ_HIP(h, hipMemsetAsync(dst, 0, (size_t)n * sizeof(T), h->stream));
+        return launch_hankel<T>(h, (const T*)ro.hankel_y, Nw, 1, Nw, N, 1, dst, M);
+    };
+    auto panel_D = [&](const T** out) -> int {
+        if (!Dm || d_transient) {
+            void* p;
+            TLSQ_TRY(ws_get(h, WS_D, (size_t)n * sizeof(T), &p));
+            TLSQ_TRY(build_hankel((T*)p));
+            Dm = (const T*)p;
+            d_transient = false;
+        }
+        *out = Dm;
+        return TLSQ_OK;
+    };
+    if (!D) {
+        if (!ro.hankel_lazy || !ro.hankel_y) return set_err(h, TLSQ_ERR_ARG, "rpca: no data panel");
+        TLSQ_TRY(build_hankel(Zbuf[1]));
+        Dm = Zbuf[1];
+        d_transient = true;
+    }
+    D = Dm;   // (set-up below; every later use goes through panel_D or the implicit kernels)
+
     // ---- setup, src/robustPCA.jl:171-184 ----
     TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
     TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
@@ -1016,9 +1046,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         pt.mark(false, !have_next);
         if (!have_next)
         {
+            if (!(d_transient && k == 1)) TLSQ_TRY(panel_D(&D));   // (iteration 1 may still read the transient copy)
             TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
             hbm_sweeps += 5.0 * panel_bytes;
         }
+        if (d_transient) D = nullptr;   // the copy in Zbuf[1] is not to be read any more
         pt.mark(have_next, !have_next);
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
@@ -1281,11 +1313,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             hbm_sweeps += ((Rst ? 7.0 : 6.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
+            TLSQ_TRY(panel_D(&D));
             TLSQ_TRY(launch_update_shrink<T>(h, D, A, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], n, (T)mu,
                                              ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
                                              ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next));
             hbm_sweeps += (Rst ? 8.0 : 7.0) * panel_bytes;
         } else {
+            TLSQ_TRY(panel_D(&D));
             TLSQ_TRY(launch_update<T>(h, D, A, E, Y, R, n, (T)mu, ro.nonnegA ? 1 : 0));     // :217-222
             hbm_sweeps += 6.0 * panel_bytes;
         }
@@ -1351,8 +1385,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
                     a_pending = false;
                 }
-                TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
-                hbm_sweeps += 4.0 * panel_bytes;
+                if (ro.hankel_y && (!Dm || d_transient)) {
+                    TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, E, R, M, N));
+                    hbm_sweeps += 3.0 * panel_bytes;
+                } else {
+                    TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));
+                    hbm_sweeps += 4.0 * panel_bytes;
+                }
             }
         } else {
             pt.mark();   // (empty read-back and "next Gram" windows)

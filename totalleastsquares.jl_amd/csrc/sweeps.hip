@@ -354,6 +354,21 @@ __global__ __launch_bounds__(256) void k_residual(const T* __restrict__ D, const
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) R[i] = (D[i] - A[i]) - E[i];
 }
 
+// R = D - A - E with D[i, j] = y[i + j] for i < K (zero pad rows below): the Hankel panel is not read (nor kept)
+template <typename T>
+__global__ __launch_bounds__(256) void k_residual_hankel(const T* __restrict__ y, int64_t K, const T* __restrict__ A,
+                                                         const T* __restrict__ E, T* __restrict__ R, int64_t M,
+                                                         int64_t N) {
+    const int64_t j = blockIdx.y;
+    const T* __restrict__ yj = y + j;
+    const int64_t off = j * M;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+        const T d = i < K ? yj[i] : (T)0;
+        R[off + i] = (d - A[off + i]) - E[off + i];
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_div_scalar(const T* __restrict__ D, T* __restrict__ Y,
                                                     int64_t n, T s) {
@@ -572,6 +587,16 @@ int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t
 }
 
 template <typename T>
+int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return TLSQ_OK;
+    if (N > 65535) return set_err(h, TLSQ_ERR_UNSUPPORTED, "residual: more than 65535 Hankel columns");
+    const int64_t gx = std::min<int64_t>((M + 1023) / 1024, 4096);
+    hipLaunchKernelGGL((k_residual_hankel<T>), dim3((unsigned)gx, (unsigned)N), dim3(256), 0, h->stream, y, K, A, E, R, M, N);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
 int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s) {
     if (n <= 0) return TLSQ_OK;
     constexpr int VEC = 16 / sizeof(T);
@@ -652,6 +677,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
                                                  T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*, \
                                                  const T*, int64_t);                                                  \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
+    template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \

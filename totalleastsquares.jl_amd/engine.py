@@ -378,7 +378,8 @@ class Engine:
         assert lag <= n, "lag must be <= L"
         iters = int(kw.pop("iters", 1000))
         verbose = kw.pop("verbose", False)
-        allowed = {k: kw[k] for k in ("lam", "maxrank", "rho", "nonnegA", "nonnegE", "hankel", "nukeA") if k in kw}
+        allowed = {k: kw[k] for k in ("lam", "maxrank", "rho", "nonnegA", "nonnegE", "hankel", "nukeA", "phase_timing")
+                   if k in kw}
         cb = None
         if verbose:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
