@@ -458,14 +458,17 @@ __device__ __forceinline__ void gram_body(const TZ* __restrict__ Z, int64_t ld, 
 //   wave 4 + u           : row 7 - u, columns 5..7 - u   and   row u, columns 0..u
 // 9 tiles per SIMD and k-step instead of 16: a diagonal work item costs 0.56 of an off-diagonal one per row of Z (the
 // host gives it a longer K chunk).  One operand panel (A == B), fragments: two A rows + one B per tile.
+constexpr int DTK = 32;            // K rows per stage of a diagonal work item: one panel (A == B) leaves room for twice the
+constexpr int DLDK = DTK + 2;      // rows of the off-diagonal stage in the same LDS, and halves the barriers per row
+constexpr int DPANEL = 128 * DLDK; // doubles per buffer (2 * DPANEL <= 4 * PANEL)
 template <typename TZ, bool FULL, bool FIVE>
 __device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ Cz,
                                                int64_t ldc, int64_t N, int64_t kbeg, int64_t kend, int64_t i0,
                                                double* __restrict__ smem) {
     typedef TZ x2 __attribute__((ext_vector_type(2)));
-    constexpr int SL = 2;
+    constexpr int SL = 4;   // 2-element slots per thread and stage (128 columns x 16 pairs / 512 threads)
     constexpr int NTL = FIVE ? 5 : 4;
-    const int nstage = (kend > kbeg) ? (int)((kend - kbeg + TK - 1) / TK) : 0;
+    const int nstage = (kend > kbeg) ? (int)((kend - kbeg + DTK - 1) / DTK) : 0;
     const int tid = threadIdx.x, lane = tid & 63, u = (tid >> 6) & 3;
     const int fr = lane & 15, fk = lane >> 4;
     const int ar0 = 7 - u, ar1 = u;
@@ -477,30 +480,30 @@ __device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t
     for (int t = 0; t < NTL; ++t) {
         acc[t] = d4{0.0, 0.0, 0.0, 0.0};
         const int b = t < c1 ? b0 + t : t - c1;
-        ob[t] = (16 * b + fr) * LDK + 2 * fk;
+        ob[t] = (16 * b + fr) * DLDK + 2 * fk;
     }
-    const int oa0 = (16 * ar0 + fr) * LDK + 2 * fk, oa1 = (16 * ar1 + fr) * LDK + 2 * fk;
+    const int oa0 = (16 * ar0 + fr) * DLDK + 2 * fk, oa1 = (16 * ar1 + fr) * DLDK + 2 * fk;
     const TZ* pa[SL];
     int so[SL], sr[SL], sk[SL];
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
         const int e = tid + 512 * s;
-        sr[s] = e >> 3;
-        sk[s] = (e & 7) * 2;
+        sr[s] = e >> 4;
+        sk[s] = (e & 15) * 2;
         pa[s] = Z + kbeg + sk[s] + (i0 + sr[s]) * ld;
-        so[s] = sr[s] * LDK + sk[s];
+        so[s] = sr[s] * DLDK + sk[s];
     }
     x2 ra[SL];
     d2 ga[2][2], gb[2][NTL];
 
 #define D_FR(buf, q, slot, i)                                                                                    \
     do {                                                                                                         \
-        if ((i) == 0) ga[slot][0] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + oa0 + 8 * (q));           \
-        else if ((i) == 1) ga[slot][1] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + oa1 + 8 * (q));      \
-        else gb[slot][((i) - 2) % NTL] = *reinterpret_cast<const d2*>(smem + (buf) * PANEL + ob[((i) - 2) % NTL] + 8 * (q)); \
+        if ((i) == 0) ga[slot][0] = *reinterpret_cast<const d2*>(smem + (buf) * DPANEL + oa0 + 8 * (q));          \
+        else if ((i) == 1) ga[slot][1] = *reinterpret_cast<const d2*>(smem + (buf) * DPANEL + oa1 + 8 * (q));     \
+        else gb[slot][((i) - 2) % NTL] = *reinterpret_cast<const d2*>(smem + (buf) * DPANEL + ob[((i) - 2) % NTL] + 8 * (q)); \
     } while (0)
 #define D_SW(buf, i) \
-    *reinterpret_cast<d2*>(smem + (buf) * PANEL + so[(i) % SL]) = d2{(double)ra[(i) % SL][0], (double)ra[(i) % SL][1]}
+    *reinterpret_cast<d2*>(smem + (buf) * DPANEL + so[(i) % SL]) = d2{(double)ra[(i) % SL][0], (double)ra[(i) % SL][1]}
 #define D_GL(i, koff)                                                                     \
     do {                                                                                  \
         const int u_ = (i) % SL;                                                          \
@@ -514,9 +517,12 @@ __device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t
             ra[u_] = x2{o0_ ? p_[0] : (TZ)0, o1_ ? p_[1] : (TZ)0};                        \
         }                                                                                 \
     } while (0)
-    // KIND as in gram_body
-    auto half = [&](auto kind, int cur, int q, int64_t koff) {
-        constexpr int KIND = decltype(kind)::value;
+    // one quarter of a stage (8 rows of Z): 2 NTL MFMAs on fragment slot q & 1, each followed by at most one memory
+    // instruction - first the fragments of the next quarter (fbuf, fq), then the two extra items of this quarter:
+    //   EXTRA 0 none | 1 global loads of slots x0, x0 + 1 at row offset koff | 2 LDS stores of slots x0, x0 + 1 into sbuf
+    auto quarter = [&](auto extra, auto frags, int q, int fbuf, int fq, int x0, int sbuf, int64_t koff) {
+        constexpr int EXTRA = decltype(extra)::value;
+        constexpr bool FRAGS = decltype(frags)::value;
         const int slot = q & 1, nslot = slot ^ 1;
 #pragma unroll
         for (int n = 0; n < 2 * NTL; ++n) {
@@ -524,21 +530,21 @@ __device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t
             const double av = (t < c1) ? ga[slot][0][m] : ga[slot][1][m];
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gb[slot][t][m], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (KIND != 3 && n < 2 + NTL) {
-                if (KIND == 2) D_FR(cur ^ 1, 0, nslot, n);
-                else D_FR(cur, 1, nslot, n);
-            } else if (KIND == 1 && n - (2 + NTL) < SL) {
-                D_SW(cur ^ 1, n - (2 + NTL));
-            } else if (KIND == 2 && n - (2 + NTL) < SL) {
-                D_GL(n - (2 + NTL), koff);
+            if (FRAGS && n < 2 + NTL) {
+                D_FR(fbuf, fq, nslot, n);
+            } else if (EXTRA == 1 && n - (2 + NTL) < 2 && n >= 2 + NTL) {
+                D_GL(x0 + n - (2 + NTL), koff);
+            } else if (EXTRA == 2 && n - (2 + NTL) < 2 && n >= 2 + NTL) {
+                D_SW(sbuf, x0 + n - (2 + NTL));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    std::integral_constant<int, 0> K0;
-    std::integral_constant<int, 1> K1;
-    std::integral_constant<int, 2> K2;
-    std::integral_constant<int, 3> K3;
+    std::integral_constant<int, 0> X0;
+    std::integral_constant<int, 1> XL;
+    std::integral_constant<int, 2> XS;
+    std::true_type FR1;
+    std::false_type FR0;
 
     if (nstage > 0) {
 #pragma unroll
@@ -547,25 +553,31 @@ __device__ __forceinline__ void gram_diag_body(const TZ* __restrict__ Z, int64_t
         for (int i = 0; i < SL; ++i) D_SW(0, i);
     }
     __syncthreads();
-    if (nstage > 1) {
-#pragma unroll
-        for (int i = 0; i < SL; ++i) D_GL(i, (int64_t)TK);
+    if (nstage > 1) {   // (slots 0, 1 of the next stage: what the last quarter of a stage does for the one after it)
+        D_GL(0, (int64_t)DTK);
+        D_GL(1, (int64_t)DTK);
     }
     if (nstage > 0) {
 #pragma unroll
         for (int i = 0; i < 2 + NTL; ++i) D_FR(0, 0, 0, i);
     }
     for (int s = 0; s + 1 < nstage; ++s) {
-        const int cur = s & 1;
-        const int64_t koff = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * TK;
-        half(K1, cur, 0, (int64_t)0);
+        const int cur = s & 1, nxt = cur ^ 1;
+        const int64_t k1 = (int64_t)(s + 1) * DTK;
+        // (the last two stages load the final stage again instead of branching: those values are never stored)
+        const int64_t k2 = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * DTK;
+        quarter(XL, FR1, 0, cur, 1, 2, 0, k1);      // + loads of slots 2, 3 of stage s + 1
+        quarter(XS, FR1, 1, cur, 2, 0, nxt, 0);     // + stores of slots 0, 1 (loaded a stage ago)
+        quarter(XS, FR1, 2, cur, 3, 2, nxt, 0);     // + stores of slots 2, 3
         __syncthreads();
-        half(K2, cur, 1, koff);
+        quarter(XL, FR1, 3, nxt, 0, 0, 0, k2);      // fragments of the next stage, loads of slots 0, 1 of stage s + 2
     }
     if (nstage > 0) {
         const int cur = (nstage - 1) & 1;
-        half(K0, cur, 0, (int64_t)0);
-        half(K3, cur, 1, (int64_t)0);
+        quarter(X0, FR1, 0, cur, 1, 0, 0, 0);
+        quarter(X0, FR1, 1, cur, 2, 0, 0, 0);
+        quarter(X0, FR1, 2, cur, 3, 0, 0, 0);
+        quarter(X0, FR0, 3, cur, 0, 0, 0, 0);
     }
 #undef D_FR
 #undef D_SW
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
         const int64_t kend = (kbeg + kchunk_d < K) ? kbeg + kchunk_d : K;
         const int64_t i0 = (int64_t)ti * TI;
         double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
-        const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);
+        const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % DTK == 0);
         const bool five = threadIdx.x < 256;   // waves 0..3 (wave-uniform: both sides meet the same barriers)
         if (full) {
             if (five) gram_diag_body<TZ, true, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, smem);
@@ -644,7 +656,7 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
                    const double* skip, double* normpart, int* normblocks) {
     const int64_t nti = (N + TI - 1) / TI, noff = nti * (nti - 1) / 2;
     // relative cost of a diagonal work item per row of Z (9 of 16 MFMA tiles per SIMD + the shared per-stage overhead)
-    static const double rho = [] { const char* e = getenv("TLSQ_GRAM_RHO"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.72; }();
+    static const double rho = [] { const char* e = getenv("TLSQ_GRAM_RHO"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.62; }();
     static const int64_t target_wgs = [] { const char* e = getenv("TLSQ_GEMM_WGS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 256); }();
     // K splits (nsplit_o for the off-diagonal tiles, nsplit_d for the diagonal ones) by a small cost model, in us:
     // an item of kc rows takes kc * c_row (a CU at ~92 % of its MFMA peak: 2 * 128 * 128 flop per row) + c_item
@@ -654,10 +666,10 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
     constexpr double c_row = 0.116, c_item = 18.0, slab_us_per_byte = 2.0 / 4.0e6;
     const int64_t maxsplit = std::max<int64_t>(1, (K + 4 * TK - 1) / (4 * TK));                       // >= four K stages per item
     const int64_t memsplit = std::max<int64_t>(1, (int64_t)(((size_t)2 << 30) / ((size_t)N * N * 8)));   // slabs <= 2 GB
-    auto chunk = [&](int64_t& ns) {
+    auto chunk_of = [&](int64_t& ns, int64_t tk) {
         int64_t kc = (K + ns - 1) / ns;
-        kc = (kc + TK - 1) / TK * TK;
-        if (kc < TK) kc = TK;
+        kc = (kc + tk - 1) / tk * tk;
+        if (kc < tk) kc = tk;
         ns = K > 0 ? (K + kc - 1) / kc : 1;
         return kc;
     };
@@ -668,7 +680,7 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
         for (int pass = 0; pass < 2; ++pass) {
             int64_t o = noff > 0 ? so : 1;
             int64_t d = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::floor(so * rho) + pass), std::min(maxsplit, memsplit));
-            const int64_t kco = chunk(o), kcd = chunk(d);
+            const int64_t kco = chunk_of(o, TK), kcd = chunk_of(d, DTK);
             const double t_o = kco * c_row + c_item, t_d = rho * kcd * c_row + c_item;
             // list schedule on target_wgs CUs, off-diagonal items first (the launch order): r_o full rounds, then m CUs
             // take the rest of them while the others start on the diagonal items
@@ -709,7 +721,7 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
             nsplit_d = std::min<int64_t>(d, maxsplit);
         }
     }
-    const int64_t kchunk_o = chunk(nsplit_o), kchunk_d = chunk(nsplit_d);
+    const int64_t kchunk_o = chunk_of(nsplit_o, TK), kchunk_d = chunk_of(nsplit_d, DTK);
     {
         static const bool dbg = [] { const char* e = getenv("TLSQ_DEBUG"); return e && e[0] == '2'; }();
         if (dbg) fprintf(stderr, "[tlsq] gram %lld x %lld: nsplit %lld / %lld, model %.0f us\n", (long long)K, (long long)N,
