@@ -21,6 +21,7 @@ ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--want-s", action="store_true")
 ap.add_argument("--randomized", action="store_true", help="svd = rsvd-style hook (TLSQ_SVD_RANDOMIZED)")
 ap.add_argument("--no-hist", action="store_true", help="device-resident call without cost history (what bench.py times)")
+ap.add_argument("--phases", action="store_true", help="bracket every phase with events (tlsq_rpca_opts.phase_timing)")
 a = ap.parse_args()
 D, A0, _ = O.synth_lowrank_sparse(a.M, a.N, a.r, seed=0)
 if a.f32:
@@ -30,6 +31,8 @@ eng.rpca(np.asarray(D[:256, :64]), iters=2)   # warm up
 t0 = time.perf_counter()
 from tlsq_amd import _lib as L
 hook = dict(svd_mode=L.SVD_RANDOMIZED) if a.randomized else {}
+if a.phases:
+    hook["phase_timing"] = True
 if a.no_hist:
     dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda()
     dA, dE = torch.empty_like(dD), torch.empty_like(dD)

@@ -13,7 +13,8 @@ namespace tlsq {
 
 double now_ms();   // runtime.hip
 
-constexpr int LZ_WGS = 64;       // workgroups per step-kernel
+constexpr int LZ_WGS = 64;       // workgroups per step-kernel up to N = 1024 ...
+constexpr int LZ_WGS_MAX = 1024; // ... N / 8 beyond (lz_wgs): a 4096 x 4096 matrix is 134 MB, 64 workgroups stream it at 0.6 TB/s
 constexpr int LZ_THREADS = 256;  // 4 waves
 
 // wave all-reduce without the LDS crossbar (see jacobi.hip): DPP inside each row of 16 lanes, then the four row totals
@@ -45,6 +46,41 @@ __device__ __forceinline__ double block_sum4(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+static inline int lz_wgs(int64_t N) {
+    if (N <= 1024) return LZ_WGS;
+    return (int)std::min<int64_t>(LZ_WGS_MAX, (N + 7) / 8);
+}
+
+// rows [r0, r1) of u = G q for this workgroup (G symmetric: row r == column r, contiguous; q: N doubles in LDS), one row
+// per wave at a time, 16-byte loads when the rows are aligned.  Returns this wave's lane-0 share of sum_r u_r * (SQ ? u_r
+// : q_r); u_r is stored by lane 0.
+typedef double lz_d2 __attribute__((ext_vector_type(2)));
+template <bool SQ>
+__device__ __forceinline__ double lz_rows(const double* __restrict__ G, int64_t ldG, int N, const double* q,
+                                          double* __restrict__ unew, int r0, int r1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool vec = ((ldG & 1) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
+    const int n2 = vec ? (N & ~1) : 0;
+    double pacc = 0.0;
+    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
+        const double* __restrict__ col = G + (int64_t)r * ldG;
+        double a0 = 0.0, a1 = 0.0;
+        for (int c = 2 * lane; c < n2; c += 128) {
+            const lz_d2 g = *reinterpret_cast<const lz_d2*>(col + c);
+            const lz_d2 x = *reinterpret_cast<const lz_d2*>(q + c);
+            a0 += g[0] * x[0];
+            a1 += g[1] * x[1];
+        }
+        for (int c = n2 + lane; c < N; c += 64) a0 += col[c] * q[c];
+        const double acc = wsum(a0 + a1);
+        if (lane == 0) {
+            unew[r] = acc;
+            pacc += acc * (SQ ? acc : q[r]);
+        }
+    }
+    return pacc;
+}
+
 // Workgroup 0 copies the header and the completed (alpha, beta) pairs to the host-visible mailbox
 // ([0] flag, [8..16) header, [16..) alpha[cap], beta[cap]) and publishes them with the sequence number.
 __device__ __forceinline__ void lz_publish(const double* st, const double* ab, int cap, double* mailbox, double seq) {
@@ -70,12 +106,12 @@ __device__ __forceinline__ void lz_publish(const double* st, const double* ab, i
 // Vectors rotate through 3 buffers, u and the partials through 2, so no launch overwrites what its own
 // (slower) workgroups still read.  Workgroup 0 records alpha_{j-1}, beta_{j-1}.
 // layout of `st` (doubles): [0..8) header {-, breakdown, pairs done}; alpha[cap], beta[cap]; vec[3][N]; u[2][N];
-// part[2][LZ_WGS]
+// part[2][LZ_WGS_MAX]
 __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __restrict__ G, int64_t ldG,
                                                              int N, double* __restrict__ st,
                                                              double* __restrict__ ab, int maxsteps, int j,
                                                              double* mailbox, double seq,
-                                                             const double* __restrict__ v0) {
+                                                             const double* __restrict__ v0, int nwg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* q = sm;           // N  (q_new)
     double* red = sm + N;     // 4
@@ -119,9 +155,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
         const double* qc = vec + (size_t)((j + 2) % 3) * N;   // q_{j-1}  (buffer (j-1)%3)
         const double* qp = vec + (size_t)((j + 1) % 3) * N;   // q_{j-2}  (buffer (j-2)%3)
         const double* u = ubuf + (size_t)((j + 1) % 2) * N;   // u of launch j-1
-        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS;
+        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS_MAX;
         double alpha = 0.0;
-        for (int k = 0; k < LZ_WGS; ++k) alpha += pp[k];
+        for (int k = 0; k < nwg; ++k) alpha += pp[k];
         const double beta_prev = (j >= 2) ? ab[maxsteps + (j - 2)] : 0.0;
         double nn = 0.0;
         for (int i = tid; i < N; i += LZ_THREADS) {
@@ -152,25 +188,15 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
         for (int i = tid; i < N; i += LZ_THREADS) vnew[i] = q[i];
     // phase B: rows [r0, r1) of u_new = G q_new
     double* unew = ubuf + (size_t)(j % 2) * N;
-    const int rows_per = (N + LZ_WGS - 1) / LZ_WGS;
+    const int rows_per = (N + nwg - 1) / nwg;
     const int r0 = blockIdx.x * rows_per;
     const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
-    double pacc = 0.0;
-    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
-        const double* __restrict__ col = G + (int64_t)r * ldG;
-        double acc = 0.0;
-        for (int c = lane; c < N; c += 64) acc += col[c] * q[c];
-        acc = wsum(acc);
-        if (lane == 0) {
-            unew[r] = acc;
-            pacc += acc * q[r];
-        }
-    }
+    const double pacc = lz_rows<false>(G, ldG, N, q, unew, r0, r1);
     // partial of q_new . u_new over this workgroup's rows (lane 0 of each wave holds a piece)
     __syncthreads();
     if (lane == 0) red[w] = pacc;
     __syncthreads();
-    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS_MAX + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- host: largest eigenvalue of the symmetric tridiagonal (alpha[0..m), beta[0..m-1)) + residual bound
@@ -243,8 +269,8 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
     if (r.use_mail) r.seq = (h->mail_seq += 1.0);
     for (int k = 0; k < n; ++k, ++r.launched) {
         const bool last = r.use_mail && k == n - 1;
-        hipLaunchKernelGGL(k_lanczos_step, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
-                           r.ab, r.cap, r.launched, last ? h->mailbox_dev : (double*)nullptr, r.seq, r.v0);
+        hipLaunchKernelGGL(k_lanczos_step, dim3(lz_wgs(r.N)), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
+                           r.ab, r.cap, r.launched, last ? h->mailbox_dev : (double*)nullptr, r.seq, r.v0, lz_wgs(r.N));
     }
     TLSQ_HIP(h, hipGetLastError());
     if (!r.use_mail)
@@ -271,7 +297,7 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     r.max_steps = max_steps;
     r.cap = max_steps + 2;
     void* stv;
-    const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS + 2 * (size_t)r.cap + 16;
+    const size_t st_doubles = 8 + 5 * (size_t)N + 2 * LZ_WGS_MAX + 2 * (size_t)r.cap + 16;
     TLSQ_TRY(ws_get(h, WS_AUX4, st_doubles * 8, &stv));
     r.st = (double*)stv;
     r.ab = r.st + 8;
@@ -396,10 +422,10 @@ int lanczos_lmax_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double 
 // without a Lanczos run (~25 dependent launches).  Launch j finishes product j - 1 (norm, bound, normalised vector:
 // every workgroup redundantly, like k_lanczos_step) and computes its rows of product j; the last launch only finishes
 // and hands the bounds to the host through the mailbox.
-// layout of `pw` (doubles): [0..8) bounds; v[N] (persistent); u[2][N]; part[2][LZ_WGS]
+// layout of `pw` (doubles): [0..8) bounds; v[N] (persistent); u[2][N]; part[2][LZ_WGS_MAX]
 __global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restrict__ G, int64_t ldG, int N,
                                                            double* __restrict__ pw, int j, int nsteps, int init,
-                                                           double* mailbox, double seq) {
+                                                           double* mailbox, double seq, int nwg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* q = sm;          // N
     double* red = sm + N;    // 4
@@ -429,9 +455,9 @@ __global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restr
         }
     } else {
         const double* u = ubuf + (size_t)((j + 1) % 2) * N;
-        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS;
+        const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS_MAX;
         double nn = 0.0;
-        for (int k = 0; k < LZ_WGS; ++k) nn += pp[k];
+        for (int k = 0; k < nwg; ++k) nn += pp[k];
         const double beta = sqrt(nn);                 // ||G v_{j-1}||, v_{j-1} a unit vector
         const double inv = beta > 1e-290 ? 1.0 / beta : 0.0;
         for (int i = tid; i < N; i += LZ_THREADS) q[i] = u[i] * inv;
@@ -453,24 +479,14 @@ __global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restr
         return;
     }
     double* unew = ubuf + (size_t)(j % 2) * N;
-    const int rows_per = (N + LZ_WGS - 1) / LZ_WGS;
+    const int rows_per = (N + nwg - 1) / nwg;
     const int r0 = blockIdx.x * rows_per;
     const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
-    double pacc = 0.0;
-    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
-        const double* __restrict__ col = G + (int64_t)r * ldG;   // symmetric: row r == column r
-        double acc = 0.0;
-        for (int c = lane; c < N; c += 64) acc += col[c] * q[c];
-        acc = wsum(acc);
-        if (lane == 0) {
-            unew[r] = acc;
-            pacc += acc * acc;
-        }
-    }
+    const double pacc = lz_rows<true>(G, ldG, N, q, unew, r0, r1);   // symmetric: row r == column r
     __syncthreads();
     if (lane == 0) red[w] = pacc;
     __syncthreads();
-    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) part[(size_t)(j % 2) * LZ_WGS_MAX + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // *lb_out = the best of `nsteps` lower bounds ||G v|| <= lambda_max(G) along power steps on the handle's persistent
@@ -482,14 +498,14 @@ int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool i
     const size_t lds = (size_t)(N + 8) * 8;
     if (N <= 0 || nsteps < 1 || nsteps > 8 || lds > 150 * 1024 || !h->mailbox || no_mailbox || h->mailbox_bytes < 1024) return 1;
     void* pwv;
-    TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * LZ_WGS) * 8, &pwv));
+    TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * LZ_WGS_MAX) * 8, &pwv));
     if (lds > 48 * 1024)
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_power_step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
     const double seq = (h->mail_seq += 1.0);
     for (int j = 0; j <= nsteps; ++j)
-        hipLaunchKernelGGL(k_power_step, dim3(j == nsteps ? 1 : LZ_WGS), dim3(LZ_THREADS), lds, h->stream, G, ldG, (int)N,
-                           (double*)pwv, j, nsteps, init ? 1 : 0, j == nsteps ? h->mailbox_dev : (double*)nullptr, seq);
+        hipLaunchKernelGGL(k_power_step, dim3(j == nsteps ? 1 : lz_wgs(N)), dim3(LZ_THREADS), lds, h->stream, G, ldG, (int)N,
+                           (double*)pwv, j, nsteps, init ? 1 : 0, j == nsteps ? h->mailbox_dev : (double*)nullptr, seq, lz_wgs(N));
     TLSQ_HIP(h, hipGetLastError());
     volatile double* mb = h->mailbox;
     const double t_poll = now_ms();

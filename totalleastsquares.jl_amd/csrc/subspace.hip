@@ -751,10 +751,28 @@ int launch_sq_norm(Handle* h, const double* S, int64_t N, double* mailbox_dev, u
     return TLSQ_OK;
 }
 
+// GD = scale * (G - GD)  (second half of the deflation when the rank-r product came from the MFMA GEMM)
+__global__ __launch_bounds__(256) void k_sub_scale(const double* __restrict__ G, int64_t ldG, double* __restrict__ GD, int N,
+                                                   double scale) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        GD[e] = (G[i + (int64_t)j * ldG] - GD[e]) * scale;
+    }
+}
+
 int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, const double* Vg, double* GD, int64_t N,
                    int64_t r, double scale) {
     int64_t g = (N * N + 255) / 256;
     if (g > 2048) g = 2048;
+    if (N >= 1024 && r >= 16) {
+        // large mode: 2 N^2 r flop (2.1 GFLOP at N = 4096, r = 64) do not belong on one-FMA-per-two-loads code (1.05 ms):
+        // the product on the MFMA GEMM, then one pass  GD = scale (G - GD)
+        TLSQ_TRY(gemm_f64(h, false, false, Vg, N, Vs, N, GD, N, N, N, r, false));
+        hipLaunchKernelGGL(k_sub_scale, dim3((int)g), dim3(256), 0, h->stream, G, ldG, GD, (int)N, scale);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
     hipLaunchKernelGGL(k_deflate, dim3((int)g), dim3(256), 0, h->stream, G, ldG, Vs, Vg, GD, (int)N, (int)r, scale);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
