@@ -314,6 +314,10 @@ int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const doubl
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);
+/* the same for an fp32 panel, G in fp64.  mfma32 = 0: the panel is widened while staged, fp64 MFMA (what rpca uses up to
+ * N = 2048); 1: fp32 MFMA, the 32-row partial sums folded into fp64 accumulators (large mode); -1: the library's choice */
+int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ,
+                    double* G, int64_t ldG, int mfma32);
 /* C (M x Q, ldC) = Z (M x K, ldZ) * W (K x Q, ldW) */
 int tlsq_k_gemm_nn_f64(tlsq_handle h, const double* Z, int64_t M, int64_t K, int64_t ldZ,
                        const double* W, int64_t Q, int64_t ldW, double* C, int64_t ldC);

@@ -129,6 +129,33 @@ def test_gram(eng, torch_mod, M, N):
     assert np.max(np.abs(G - ref) / scale) < 1e-13
 
 
+@pytest.mark.parametrize("mfma32", [0, 1])
+@pytest.mark.parametrize("M,N", [(4096, 256), (6000, 2304), (1000, 130), (33, 128), (65536, 512), (5, 5), (20001, 384)])
+def test_gram_fp32_panel(eng, torch_mod, M, N, mfma32):
+    """Gram matrix (fp64) of an fp32 panel: widened operands on the fp64 MFMA (exact products, 1e-13), and the fp32 MFMA
+    whose 32-row partial sums are folded into fp64 accumulators (large mode): its error is the rounding of the fp32
+    products and 32-term sums (worst case 33 eps32 = 2e-6 of sqrt(G_ii G_jj) per entry, typically sqrt(32) eps32 / 2) -
+    and the fp64 fold-in keeps it from growing with M: far below the plain fp32 sum for tall panels."""
+    torch = torch_mod
+    rng = np.random.default_rng(7)
+    Z = (rng.standard_normal((M, N)) * np.exp(0.5 * rng.standard_normal(N))[None, :] + 0.5).astype(np.float32)
+    dZ = to_dev(torch, Z)
+    dG = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_gram_f32(eng.h, dptr(dZ), M, N, M, dptr(dG), N, mfma32) == 0
+    eng.synchronize()
+    G = to_host(dG)
+    Zd = Z.astype(np.float64)
+    ref = Zd.T @ Zd
+    assert np.array_equal(G, G.T)
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    err = np.max(np.abs(G - ref) / scale)
+    assert err < (1e-6 if mfma32 else 1e-13)
+    if mfma32 and M >= 4096:
+        plain = (Z.T @ Z).astype(np.float64)          # fp32 accumulation over all M rows (BLAS)
+        assert err < 0.5 * np.max(np.abs(plain - ref) / scale) or err < 3e-8
+
+
 @pytest.mark.parametrize("M,N,ld,off", [(1000, 128, 1003, 1), (4096, 256, 4100, 0), (4096, 256, 4100, 2), (999, 200, 1024, 3)])
 def test_gram_strided(eng, torch_mod, M, N, ld, off):
     """Z as a window of a larger column-major buffer: odd leading dimensions and bases that are not 16-byte aligned take

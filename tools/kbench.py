@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--N", type=int, default=512)
     ap.add_argument("--r", type=int, default=16)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--f32", type=int, default=None, help="gram of an fp32 panel: 0 widened to the fp64 MFMA, 1 fp32 MFMA + fp64 fold-in")
     a = ap.parse_args()
     M, N, r = a.M, a.N, a.r
     torch.zeros(1, device="cuda")
@@ -38,7 +39,15 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     Z = torch.randn((N, M), dtype=torch.float64, device="cuda", generator=g)      # column-major M x N
     p = lambda t: C.c_void_p(t.data_ptr())
-    if a.what in ("gram", "all"):
+    if a.what == "gram" and a.f32 is not None:
+        Zf = Z.float()
+        G = torch.empty((N, N), dtype=torch.float64, device="cuda")
+        us = timeit(eng, lambda: lib.tlsq_k_gram_f32(h, p(Zf), M, N, M, p(G), N, a.f32), a.reps)
+        ref = Zf.double() @ Zf.double().T
+        err = (G - ref).abs().max().item() / ref.abs().max().item()
+        print(f"gram f32 (mfma32={a.f32}) {M}x{N}: {us:.1f} us  sym-flop {2*M*N*(N+128)/2/us/1e6:.1f} TF  algorithmic {M*N*(N+1)/us/1e6:.1f} TF  "
+              f"max |dG| / max |G| = {err:.2e}")
+    elif a.what in ("gram", "all"):
         G = torch.empty((N, N), dtype=torch.float64, device="cuda")
         us = timeit(eng, lambda: lib.tlsq_k_gram_f64(h, p(Z), M, N, M, p(G), N), a.reps)
         print(f"gram {M}x{N}: {us:.1f} us  full-flop {2*M*N*N/us/1e6:.1f} TF  sym-flop {2*M*N*(N+128)/2/us/1e6:.1f} TF")

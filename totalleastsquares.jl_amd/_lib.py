@@ -71,7 +71,7 @@ EXPORTS = [
     "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
-    "tlsq_k_gram_f64", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
+    "tlsq_k_gram_f64", "tlsq_k_gram_f32", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
     "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64", "tlsq_k_tsqr_f64", "tlsq_k_svd_r_f64",
 ]
 
@@ -134,6 +134,7 @@ def load():
     lib.tlsq_rpca_ga_f64.argtypes = [vp, vp, i64, i64, i64, i64, P(GaOpts), vp, i64, vp, i64, P(GaInfo)]
     lib.tlsq_ga_average_f64.argtypes = [vp, C.c_int, dbl, vp, vp, i64, i64, i64, vp, C.c_int]
     lib.tlsq_k_gram_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]
+    lib.tlsq_k_gram_f32.argtypes = [vp, vp, i64, i64, i64, vp, i64, C.c_int]
     lib.tlsq_k_gemm_nn_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
     lib.tlsq_k_gemm_nt_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64, i64, vp, i64]
     lib.tlsq_k_symeig_f64.argtypes = [vp, vp, i64, i64, vp, vp, i64, P(i64)]

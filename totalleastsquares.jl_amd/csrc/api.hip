@@ -672,6 +672,11 @@ int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const doubl
     return launch_rebuild_update_shrink<double>(h, D, Tm, Vs, E, Y, R, En, Zn, M, N, r, mu, nonnegA, inv_mu_next,
                                                 thr_next, nonnegE, nullptr, nullptr);
 }
+int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !G || M < 0 || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "k_gram_f32: bad arguments");
+    return gram_any(h, Z, 1, M, N, ldZ, G, ldG, mfma32);
+}
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ, double* G,
                     int64_t ldG) {
     TLSQ_TRY(check_handle(h));

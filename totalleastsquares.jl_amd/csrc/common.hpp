@@ -44,6 +44,7 @@ struct Handle {
     double* mailbox_dev = nullptr;   // device address of the same memory
     double mail_seq = 0.0;
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
+    int64_t gram_tab2_nti = 0;
     int64_t gram_tab_nti = 0;          // tile-order table in WS_GRAMTAB is the one for this many tile rows
     bool cert_ticket_ready = false;    // ... and the one of k_sq_norm
     Comm* comm = nullptr;
@@ -97,6 +98,7 @@ enum WsSlot {
     WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
     WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
+    WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
@@ -176,7 +178,8 @@ int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W
 // Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
 int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t p);
-int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG);
+int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG,
+             int mfma32 = -1);   // fp32 panels: -1 library's choice, 0 fp64 MFMA on widened operands, 1 fp32 MFMA + fp64 fold-in
 
 // ---------------- jacobi.hip ----------------
 // One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal

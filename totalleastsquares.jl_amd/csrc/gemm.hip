@@ -877,12 +877,262 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
     return gemm_mixed(h, A_KC, B_KC, A, 0, lda, B, 0, ldb, C, 0, ldc, P, Q, K, symmetric);
 }
 
+// ---- Gram matrix of an fp32 panel on the fp32 MFMA, folded into fp64 every 32 rows (large mode, C5) -----------------
+// v_mfma_f32_16x16x4_f32 runs at twice the rate of the fp64 form (32 cycles per 2048 flop).  A plain fp32 accumulation
+// over M ~ 1e5 rows would lose every eigenvalue below ~4e-3 sigma_max^2 - the count sigma >= 1/mu is taken at
+// ~5e-4 sigma_max late in a solve - so the fp32 accumulators only ever hold the sum over one 32-row stage: at the start
+// of the next stage every tile's sum is converted and added to the fp64 accumulators (VALU, between the MFMAs) and the
+// tile's first MFMA restarts from zero.  What is left is the rounding of the 32-term sums, ~1e-8 sigma_max^2 in
+// norm at 65536 x 4096, i.e. singular values are resolved down to ~1e-4 sigma_max.
+// Same tile / wave grid / software pipeline as gram_body (8 waves, wave tile 64 x 32, panels of 128 columns x 32 rows of
+// fp32 in LDS, 16-byte fragment reads: lane (r, g) holds k = 16 q + 4 g + {0..3} of its column, element m feeds MFMA m).
+// Diagonal tiles are computed in full (large N: 32 of 528 tiles at N = 4096).
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int FTK = 32;             // rows of Z per stage
+constexpr int FLDK = FTK + 4;       // floats per panel column: (36 r + 4 g) distinct multiples of 4 mod 64 over a quarter wave
+constexpr int FPANEL = 128 * FLDK;  // floats per panel (4 panels = 73.7 KB)
+
+template <bool FULL>
+__device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t ld, double* __restrict__ Cz, int64_t ldc,
+                                            int64_t N, int64_t kbeg, int64_t kend, int64_t i0, int64_t j0,
+                                            float* __restrict__ smem) {
+    constexpr int SL = 2;   // 4-element slots per thread and panel (128 columns x 8 quads / 512 threads)
+    const int nstage = (kend > kbeg) ? (int)((kend - kbeg + FTK - 1) / FTK) : 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wj = w & 3, wi = w >> 2;
+    const int fr = lane & 15, fk = lane >> 4;
+    d4 acc[4][2];
+    f4 a32[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+            a32[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float* pa[SL];
+    const float* pb[SL];
+    int so[SL], sr[SL], sk[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int e = tid + 512 * s;
+        sr[s] = e >> 3;
+        sk[s] = (e & 7) * 4;
+        pa[s] = Z + kbeg + sk[s] + (i0 + sr[s]) * ld;
+        pb[s] = Z + kbeg + sk[s] + (j0 + sr[s]) * ld;
+        so[s] = sr[s] * FLDK + sk[s];
+    }
+    const int oa = (wi * 64 + fr) * FLDK + 4 * fk, ob = (wj * 32 + fr) * FLDK + 4 * fk;
+    f4 ra[SL], rb[SL], ga[2][4], gb[2][2];
+
+#define F_FR(buf, q, slot, i)                                                                                         \
+    do {                                                                                                              \
+        if ((i) < 4) ga[slot][(i) & 3] = *reinterpret_cast<const f4*>(smem + (buf) * FPANEL + oa + ((i) & 3) * 16 * FLDK + 16 * (q)); \
+        else gb[slot][(i) & 1] = *reinterpret_cast<const f4*>(smem + (2 + (buf)) * FPANEL + ob + ((i) & 1) * 16 * FLDK + 16 * (q)); \
+    } while (0)
+#define F_SW(buf, i)                                                                              \
+    do {                                                                                          \
+        if ((i) < SL) *reinterpret_cast<f4*>(smem + (buf) * FPANEL + so[(i) % SL]) = ra[(i) % SL]; \
+        else *reinterpret_cast<f4*>(smem + (2 + (buf)) * FPANEL + so[(i) % SL]) = rb[(i) % SL];    \
+    } while (0)
+#define F_GL(i, koff)                                                                                  \
+    do {                                                                                               \
+        const int u_ = (i) % SL;                                                                       \
+        if (FULL) {                                                                                    \
+            if ((i) < SL) ra[u_] = *reinterpret_cast<const f4*>(pa[u_] + (koff));                      \
+            else rb[u_] = *reinterpret_cast<const f4*>(pb[u_] + (koff));                               \
+        } else {                                                                                       \
+            const int64_t k_ = kbeg + (koff) + sk[u_];                                                 \
+            const int64_t c_ = ((i) < SL ? i0 : j0) + sr[u_];                                          \
+            const float* p_ = ((i) < SL ? pa[u_] : pb[u_]) + (koff);                                   \
+            f4 v_;                                                                                     \
+            for (int x_ = 0; x_ < 4; ++x_) v_[x_] = (c_ < N && k_ + x_ < kend) ? p_[x_] : 0.f;         \
+            if ((i) < SL) ra[u_] = v_;                                                                 \
+            else rb[u_] = v_;                                                                          \
+        }                                                                                              \
+    } while (0)
+    // fold the fp32 sums of tile i (0..7) into the fp64 accumulators (the MFMA that follows restarts the tile from zero)
+#define F_FOLD(i)                                                                          \
+    do {                                                                                   \
+        const int a_ = ((i) >> 1) & 3, b_ = (i) & 1;                                       \
+        for (int x_ = 0; x_ < 4; ++x_) acc[a_][b_][x_] += (double)a32[a_][b_][x_];         \
+    } while (0)
+    // one half-stage (16 rows of Z): 32 MFMAs on fragment slot q, each followed by at most one memory instruction.
+    // NEW: first half of a stage - every tile's first MFMA starts from zero, right after the tile's sums of the previous
+    // stage have been folded (its last MFMA there is eight MFMAs back: no wait).
+    // KIND 0: fragments q = 1 of the same buffer | 1: those + the panel store into the other buffer | 2: fragments q = 0
+    // of the other buffer + global loads | 3: nothing
+    auto half = [&](auto kind, auto fresh, int cur, int q, int64_t koff) {
+        constexpr int KIND = decltype(kind)::value;
+        constexpr bool NEW = decltype(fresh)::value;
+        const int slot = q & 1, nslot = slot ^ 1;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int m = t >> 3, a = (t >> 1) & 3, b = t & 1;
+            if (NEW && m == 0) F_FOLD(t);
+            const f4 c0 = (NEW && m == 0) ? f4{0.f, 0.f, 0.f, 0.f} : a32[a][b];
+            a32[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[slot][a][m], gb[slot][b][m], c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (KIND != 3 && t < 6) {
+                if (KIND == 2) F_FR(cur ^ 1, 0, nslot, t);
+                else F_FR(cur, 1, nslot, t);
+            } else if (KIND == 1 && t - 6 < 2 * SL) {
+                F_SW(cur ^ 1, t - 6);
+            } else if (KIND == 2 && t - 6 < 2 * SL) {
+                F_GL(t - 6, koff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    std::integral_constant<int, 0> K0;
+    std::integral_constant<int, 1> K1;
+    std::integral_constant<int, 2> K2;
+    std::integral_constant<int, 3> K3;
+    std::true_type ZY;
+    std::false_type ZN;
+
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) F_GL(i, (int64_t)0);
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) F_SW(0, i);
+    }
+    __syncthreads();
+    if (nstage > 1) {
+#pragma unroll
+        for (int i = 0; i < 2 * SL; ++i) F_GL(i, (int64_t)FTK);
+    }
+    if (nstage > 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) F_FR(0, 0, 0, i);
+    }
+    for (int s = 0; s + 1 < nstage; ++s) {
+        const int cur = s & 1;
+        // (the last two stages load the final stage again instead of branching: those values are never stored)
+        const int64_t koff = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * FTK;
+        half(K1, ZY, cur, 0, (int64_t)0);
+        __syncthreads();
+        half(K2, ZN, cur, 1, koff);
+    }
+    if (nstage > 0) {
+        const int cur = (nstage - 1) & 1;
+        half(K0, ZY, cur, 0, (int64_t)0);
+        half(K3, ZN, cur, 1, (int64_t)0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) F_FOLD(i);
+    }
+#undef F_FR
+#undef F_SW
+#undef F_GL
+#undef F_FOLD
+    // epilogue: v_mfma_f32_16x16x4_f32 leaves column j = lane & 15, rows i = 4 (lane >> 4) + reg in a lane
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = j0 + wj * 32 + b * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = i0 + wi * 64 + a * 16 + 4 * fk + r;
+                if (FULL || (i < N && j < N)) Cz[j + i * ldc] = acc[a][b][r];
+            }
+        }
+}
+
+// work items: (K split z, lower-triangle tile incl. the diagonal, in the host's blocked order), z-major, XCD runs
+template <bool ALLFULL>
+__global__ __launch_bounds__(512) void k_gram_f32mfma(const float* __restrict__ Z, int64_t ld, double* __restrict__ slab,
+                                                      int64_t ldc, int64_t N, int64_t K, int64_t kchunk, int64_t slab_stride,
+                                                      int ntiles, int nsplit, int vec_ok, const int32_t* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FPANEL];
+    const int64_t nwork = (int64_t)ntiles * nsplit;
+    const int64_t cpx = (nwork + 7) / 8;
+    const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
+    if (item >= nwork) return;
+    const int z = (int)(item / ntiles), t = (int)(item % ntiles);
+    const int ti = order[2 * t], tj = order[2 * t + 1];
+    const int64_t kbeg = (int64_t)z * kchunk;
+    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
+    double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+    // (two kernels rather than one branch: register pressure)
+    if (ALLFULL) gram32_body<true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+    else gram32_body<false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+}
+
+static int gram_f32mfma(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K) {
+    const int64_t nti = (N + TI - 1) / TI, ntiles = nti * (nti + 1) / 2;
+    static const int64_t target_wgs = 256;
+    // uniform K split: rounds of one item per CU, + a quarter item for the drift, + the slab traffic (see gram_kc)
+    constexpr double c_row = 0.060, c_item = 18.0, slab_us_per_byte = 2.0 / 4.0e6;
+    const int64_t maxsplit = std::max<int64_t>(1, (K + 4 * FTK - 1) / (4 * FTK));
+    const int64_t memsplit = std::max<int64_t>(1, (int64_t)(((size_t)2 << 30) / ((size_t)N * N * 8)));
+    int64_t nsplit = 1, kchunk = 0;
+    double best = 1e300;
+    for (int64_t ns0 = 1; ns0 <= std::min<int64_t>(std::min(maxsplit, memsplit), 1024); ++ns0) {
+        int64_t kc = (K + ns0 - 1) / ns0;
+        kc = (kc + FTK - 1) / FTK * FTK;
+        const int64_t ns = (K + kc - 1) / kc;
+        const double t_item = kc * c_row + c_item;
+        const double rounds = std::ceil((double)(ntiles * ns) / (double)target_wgs);
+        const double t = rounds * t_item + (ntiles * ns > target_wgs ? 0.25 * t_item : 0.0) +
+                         (double)(ntiles * ns) * (double)(TI * TJ * 8) * slab_us_per_byte;
+        if (t < best) {
+            best = t;
+            nsplit = ns;
+            kchunk = kc;
+        }
+    }
+    const int64_t slab_stride = N * N;
+    void *slab, *tab;
+    TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * sizeof(double), &slab));
+    TLSQ_TRY(ws_get(h, WS_GRAMTAB2, (size_t)ntiles * 8, &tab));
+    if (h->gram_tab2_nti != nti) {   // blocked tile order, diagonal tiles included (see gram_kc)
+        std::vector<int32_t> o;
+        o.reserve((size_t)ntiles * 2);
+        for (int64_t I = 0; I < nti; I += 8)
+            for (int64_t J = 0; J < std::min(I + 8, nti); J += 4)
+                for (int64_t ti = I; ti < std::min(I + 8, nti); ++ti)
+                    for (int64_t tj = J; tj < std::min(J + 4, ti + 1); ++tj) {
+                        o.push_back((int32_t)ti);
+                        o.push_back((int32_t)tj);
+                    }
+        if ((int64_t)o.size() != 2 * ntiles) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: tile order table");
+        TLSQ_HIP(h, hipMemcpyAsync(tab, o.data(), o.size() * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        h->gram_tab2_nti = nti;
+    }
+    const int64_t nwork = ntiles * nsplit, cpx = (nwork + 7) / 8;
+    if (8 * cpx > 2147483647LL) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: grid too large");
+    const int vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(Z) % 16) == 0) ? 1 : 0;
+    // every tile inside the matrix, every chunk whole stages, aligned 16-byte loads: the unguarded kernel
+    const bool allfull = vec_ok && (N % TI) == 0 && (K % FTK) == 0;
+    if (allfull)
+        hipLaunchKernelGGL(k_gram_f32mfma<true>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ld, (double*)slab, N, N, K,
+                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, (const int32_t*)tab);
+    else
+        hipLaunchKernelGGL(k_gram_f32mfma<false>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ld, (double*)slab, N, N, K,
+                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, (const int32_t*)tab);
+    TLSQ_HIP(h, hipGetLastError());
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, N, slab_stride, (int)nsplit,
+                       (void*)G, 0, ldg, N, N, 1, (const double*)nullptr, (double*)nullptr, (int)nsplit, 0);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 // G (fp64, N x N) = Z'Z for Z of either precision
-int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG) {
+int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
     if (M <= 0) {
         TLSQ_HIP(h, hipMemset2DAsync(G, ldG * sizeof(double), 0, N * sizeof(double), N, h->stream));
         return TLSQ_OK;
     }
+    // fp32 panels in large mode (no dense eigen-solver behind the count anyway): the fp32 MFMA with fp64 fold-in
+    static const bool no_f32mfma = [] { const char* e = getenv("TLSQ_GRAM_F32MFMA"); return e && e[0] == '0'; }();
+    static const bool all_f32mfma = [] { const char* e = getenv("TLSQ_GRAM_F32MFMA"); return e && e[0] == '2'; }();
+    if (z_f32 && (mfma32 == 1 || (mfma32 < 0 && !no_f32mfma && (N > 2048 || all_f32mfma))))
+        return gram_f32mfma(h, (const float*)Z, ldZ, G, ldG, N, M);
     return gemm_mixed(h, true, true, Z, z_f32, ldZ, Z, z_f32, ldZ, G, 0, ldG, N, N, M, true);
 }
 
