@@ -27,6 +27,8 @@ struct Comm;  // RCCL state (runtime.hip)
 struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_b = nullptr;    // second stream: the Gram of the row chunks a fused sweep has finished (created on first use)
+    hipEvent_t ev_b[9] = {};           // chunk c swept (0..7), Gram reduced (8); timing disabled
     hipEvent_t ev[34] = {};   // two banks of 16 phase marks (PhaseTimer) + [32] small readbacks + [33] Lanczos read-back
     std::string err;
     // grow-only device workspace, keyed by slot
@@ -140,7 +142,8 @@ template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
                                  int nonnegE, double* sumsq, double* zero_slots = nullptr, const T* hankel_y = nullptr,
-                                 int64_t hankel_K = 0);
+                                 int64_t hankel_K = 0, int64_t row0 = 0, int64_t row1 = 0,   // rows [row0, row1), default all
+                                 size_t pad_lds = 0);   // unused dynamic LDS per workgroup (caps the residency per CU)
 // A (M x N, ld M) = Tm Vs' (Tm M x r fp64, Vs N x r): the streaming-store form of the rebuild (r <= 32, even M)
 template <typename T>
 bool rebuild_store_ok(const T* A, int64_t M, int64_t N, int64_t ldA, int64_t r);
@@ -178,6 +181,18 @@ int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W
 // Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
 int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t p);
+// the Gram of a K-contiguous operand as plan / per-chunk launch / reduction (gemm.hip)
+struct GramPlan {
+    int64_t N = 0, K = 0, nti = 0, nsplit_o = 1, nsplit_d = 1, kchunk_o = 0, kchunk_d = 0;
+    int nchunks = 1, z_f32 = 0;
+    double* slab = nullptr;
+    const int32_t* order = nullptr;
+};
+int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan* pl);
+int gram_launch_chunk(Handle* h, hipStream_t st, const GramPlan& pl, const void* Z, int64_t ld, int64_t rows, int c,
+                      const double* skip = nullptr);
+int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_t ldg, const double* skip = nullptr,
+                double* normpart = nullptr, int* normblocks = nullptr);
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG,
              int mfma32 = -1);   // fp32 panels: -1 library's choice, 0 fp64 MFMA on widened operands, 1 fp32 MFMA + fp64 fold-in
 

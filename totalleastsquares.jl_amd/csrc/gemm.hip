@@ -601,7 +601,8 @@ template <typename TZ>
 __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64_t ld, double* __restrict__ slab,
                                                  int64_t ldc, int64_t N, int64_t K, int64_t kchunk_o, int64_t kchunk_d,
                                                  int64_t slab_stride, int nti, int nsplit_o, int nsplit_d, int vec_ok,
-                                                 const double* __restrict__ skip, const int32_t* __restrict__ order) {
+                                                 const double* __restrict__ skip, const int32_t* __restrict__ order,
+                                                 int zbase_o, int zbase_d) {
     __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
     if (skip && skip[0] != 0.0) return;
     const int noff = nti * (nti - 1) / 2;
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
         const int64_t kbeg = (int64_t)z * kchunk_o;
         const int64_t kend = (kbeg + kchunk_o < K) ? kbeg + kchunk_o : K;
         const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
-        double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+        double* __restrict__ Cz = slab + (int64_t)(zbase_o + z) * slab_stride;   // (row chunks of a panel stack their slabs)
         const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % TK == 0);   // (j0 < i0)
         if (full) gram_body<TZ, true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
         else gram_body<TZ, false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
         const int64_t kbeg = (int64_t)z * kchunk_d;
         const int64_t kend = (kbeg + kchunk_d < K) ? kbeg + kchunk_d : K;
         const int64_t i0 = (int64_t)ti * TI;
-        double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+        double* __restrict__ Cz = slab + (int64_t)(zbase_d + z) * slab_stride;
         const bool full = vec_ok && (i0 + TI <= N) && ((kend - kbeg) % DTK == 0);
         const bool five = threadIdx.x < 256;   // waves 0..3 (wave-uniform: both sides meet the same barriers)
         if (full) {
@@ -652,8 +653,10 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
 }
 
 // G = Z'Z through k_gram_kc: split-K slabs + the fixed-order reduction (k_slab_reduce, tri = 1)
-static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K,
-                   const double* skip, double* normpart, int* normblocks) {
+// The Gram matrix of one K-contiguous operand in three steps, so that the row chunks of a panel can be queued one by
+// one (behind the chunks of the sweep that produces it, on a second stream: solver.hip): plan (K splits for chunks of K
+// rows, slabs for `nchunks` of them, tile order), launch of one chunk, fixed-order reduction of all slabs.
+int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan* pl) {
     const int64_t nti = (N + TI - 1) / TI, noff = nti * (nti - 1) / 2;
     // relative cost of a diagonal work item per row of Z (9 of 16 MFMA tiles per SIMD + the shared per-stage overhead)
     static const double rho = [] { const char* e = getenv("TLSQ_GRAM_RHO"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.62; }();
@@ -727,7 +730,7 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
         if (dbg) fprintf(stderr, "[tlsq] gram %lld x %lld: nsplit %lld / %lld, model %.0f us\n", (long long)K, (long long)N,
                          (long long)nsplit_o, (long long)nsplit_d, best);
     }
-    const int64_t nslab = std::max(nsplit_o, nsplit_d);
+    const int64_t nslab = std::max(nsplit_o, nsplit_d) * nchunks;
     const int64_t slab_stride = N * N;
     void* slab;
     TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nslab * slab_stride) * sizeof(double), &slab));
@@ -760,24 +763,57 @@ static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, i
         }
         order = (const int32_t*)tab;
     }
-    const uintptr_t am = z_f32 ? 8 : 16;
-    const int vec_ok = ((ld % 2) == 0 && (kchunk_o % 2) == 0 && (kchunk_d % 2) == 0 && (reinterpret_cast<uintptr_t>(Z) % am) == 0) ? 1 : 0;
-    if (z_f32)
-        hipLaunchKernelGGL((k_gram_kc<float>), dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, (const float*)Z, ld,
-                           (double*)slab, N, N, K, kchunk_o, kchunk_d, slab_stride, (int)nti, (int)nsplit_o, (int)nsplit_d,
-                           vec_ok, skip, order);
+    pl->N = N;
+    pl->K = K;
+    pl->nti = nti;
+    pl->nsplit_o = nsplit_o;
+    pl->nsplit_d = nsplit_d;
+    pl->kchunk_o = kchunk_o;
+    pl->kchunk_d = kchunk_d;
+    pl->nchunks = nchunks;
+    pl->z_f32 = z_f32;
+    pl->slab = (double*)slab;
+    pl->order = order;
+    return TLSQ_OK;
+}
+
+// chunk `c` of the plan: rows [0, rows) of Z (rows <= pl.K), slabs c * nsplit .. of each kind
+int gram_launch_chunk(Handle* h, hipStream_t st, const GramPlan& pl, const void* Z, int64_t ld, int64_t rows, int c,
+                      const double* skip) {
+    const int64_t N = pl.N, noff = pl.nti * (pl.nti - 1) / 2;
+    const int64_t nwork = noff * pl.nsplit_o + pl.nti * pl.nsplit_d, cpx = (nwork + 7) / 8;
+    const uintptr_t am = pl.z_f32 ? 8 : 16;
+    const int vec_ok = ((ld % 2) == 0 && (pl.kchunk_o % 2) == 0 && (pl.kchunk_d % 2) == 0 && (reinterpret_cast<uintptr_t>(Z) % am) == 0) ? 1 : 0;
+    if (pl.z_f32)
+        hipLaunchKernelGGL((k_gram_kc<float>), dim3((unsigned)(8 * cpx)), dim3(512), 0, st, (const float*)Z, ld, pl.slab, N, N, rows,
+                           pl.kchunk_o, pl.kchunk_d, N * N, (int)pl.nti, (int)pl.nsplit_o, (int)pl.nsplit_d, vec_ok, skip, pl.order,
+                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d));
     else
-        hipLaunchKernelGGL((k_gram_kc<double>), dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, (const double*)Z, ld,
-                           (double*)slab, N, N, K, kchunk_o, kchunk_d, slab_stride, (int)nti, (int)nsplit_o, (int)nsplit_d,
-                           vec_ok, skip, order);
+        hipLaunchKernelGGL((k_gram_kc<double>), dim3((unsigned)(8 * cpx)), dim3(512), 0, st, (const double*)Z, ld, pl.slab, N, N, rows,
+                           pl.kchunk_o, pl.kchunk_d, N * N, (int)pl.nti, (int)pl.nsplit_o, (int)pl.nsplit_d, vec_ok, skip, pl.order,
+                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d));
     TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_t ldg, const double* skip, double* normpart,
+                int* normblocks) {
+    const int64_t N = pl.N;
     int64_t g = (N * N + 255) / 256;
     if (g > 2048) g = 2048;
     if (normblocks) *normblocks = (int)g;
-    hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, h->stream, (const double*)slab, N, slab_stride,
-                       (int)nsplit_o, (void*)G, 0, ldg, N, N, 1, skip, normpart, (int)nsplit_d, 1);
+    hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, st, (const double*)pl.slab, N, N * N,
+                       (int)(pl.nsplit_o * pl.nchunks), (void*)G, 0, ldg, N, N, 1, skip, normpart, (int)(pl.nsplit_d * pl.nchunks), 1);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
+}
+
+static int gram_kc(Handle* h, const void* Z, int z_f32, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K,
+                   const double* skip, double* normpart, int* normblocks) {
+    GramPlan pl;
+    TLSQ_TRY(gram_plan(h, z_f32, N, K, 1, &pl));
+    TLSQ_TRY(gram_launch_chunk(h, h->stream, pl, Z, ld, K, 0, skip));
+    return gram_reduce(h, h->stream, pl, G, ldg, skip, normpart, normblocks);
 }
 
 static int launch_gemm(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_t lda,

@@ -30,6 +30,7 @@ int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn);
 inline bool is_multi_call(const Handle* h) { return h->multi_comm != nullptr && !h->in_multi; }
 // stream-ordered upload of a small host array through the pinned ring (src may be reused at once)
 int upload_async(Handle* h, void* dst, const void* src, size_t bytes);
+int second_stream(Handle* h);   // creates Handle::stream_b / ev_b on first use
 
 inline int check_handle(tlsq_handle h) { return h ? TLSQ_OK : TLSQ_ERR_ARG; }
 

@@ -190,6 +190,19 @@ double now_ms() {
 // Stream-ordered upload of a small host array through the pinned ring: no host synchronisation, and `src` may be
 // freed or overwritten as soon as this returns.  A slot is only reused after the ring has wrapped, and wrapping
 // synchronises the stream first.
+int second_stream(Handle* h) {
+    if (h->stream_b) return TLSQ_OK;
+    // (highest priority: its workgroups are few and large - they should get a CU as soon as one has room)
+    int least = 0, greatest = 0;
+    static const bool no_prio = [] { const char* e = getenv("TLSQ_OVERLAP_NOPRIO"); return e && e[0] == '1'; }();
+    if (!no_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        TLSQ_HIP(h, hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, greatest));
+    else
+        TLSQ_HIP(h, hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    for (auto& e : h->ev_b) TLSQ_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return TLSQ_OK;
+}
+
 int upload_async(Handle* h, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return TLSQ_OK;
     const size_t need = (bytes + 63) & ~(size_t)63;
@@ -350,6 +363,9 @@ int tlsq_destroy(tlsq_handle h) {
     if (h->mailbox) (void)hipHostFree(h->mailbox);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_b)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TLSQ_OK;

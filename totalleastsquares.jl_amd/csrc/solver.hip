@@ -1304,12 +1304,55 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         T* Rst = store_R ? R : nullptr;
         if (!store_R) ++n_rskip;
         pt.mark(false, true);
+        // Will the next iteration want the Gram of Z_{k+1}?  (Not on the TSQR route, not with the implicit operator.)  It is
+        // queued before the host looks at this iteration's cost - the GPU works through that round trip, and a Gram is
+        // wasted only at convergence.
+        const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 &&
+                            !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
+        const bool gram_next = sumsq_dev && !r_next && !implicit_gram;
+        bool gram_queued = false;
         if (fuse_rebuild) {
-            // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels
-            TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
-                                                     svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
-                                                     (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
-                                                     (const T*)ro.hankel_y, ro.hankel_K));
+            // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels.
+            // Very large panels: the sweep is HBM-bound, the Gram of what it writes MFMA-bound, and each takes many
+            // milliseconds - the sweep goes row chunk by row chunk and the Gram of a finished chunk runs beside the sweep
+            // of the next one, on the handle's second stream.  The two kernels do share the CUs, but each runs at about
+            // half speed meanwhile (kernel trace at 1e7 x 256, 8 chunks: sweep chunk 2.6 ms alone / 3.7 beside a Gram
+            // chunk, Gram chunk 1.5 / 3.6): 30.9 ms for the pair instead of 35.0, nothing at 200000 x 512 (TLSQ_OVERLAP_CHUNKS
+            // forces a chunk count, 1 = off).
+            static const int env_chunks = [] { const char* e = getenv("TLSQ_OVERLAP_CHUNKS"); return e ? atoi(e) : -1; }();
+            const bool f32mfma_gram = Prec<T>::f32 && N > 2048;   // (gram_any's choice: that kernel is not chunked)
+            int nchunks = (gram_next && !f32mfma_gram && M * N >= ((int64_t)1 << 30)) ? 8 : 1;
+            if (env_chunks >= 1 && env_chunks <= 8 && gram_next && !f32mfma_gram) nchunks = env_chunks;
+            if (nchunks > 1) {
+                TLSQ_TRY(second_stream(h));
+                // (TLSQ_OVERLAP_LDS: unused dynamic LDS per sweep workgroup, caps its residency per CU - measured: 40 KB
+                // no change, 80 KB, i.e. one sweep workgroup per CU, slower)
+                static const size_t pad_lds = [] { const char* e = getenv("TLSQ_OVERLAP_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+                const int64_t rows_c = ((M + nchunks - 1) / nchunks + 511) / 512 * 512;
+                GramPlan pl;
+                TLSQ_TRY(gram_plan(h, Prec<T>::f32, N, rows_c, nchunks, &pl));
+                void* Gv;
+                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                for (int c = 0; c < nchunks; ++c) {
+                    const int64_t r0 = std::min<int64_t>((int64_t)c * rows_c, M), r1 = std::min<int64_t>(r0 + rows_c, M);
+                    if (r1 > r0)
+                        TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M,
+                                                                 N, svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                                                 (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
+                                                                 (const T*)ro.hankel_y, ro.hankel_K, r0, r1, pad_lds));
+                    TLSQ_HIP(h, hipEventRecord(h->ev_b[c], h->stream));
+                    TLSQ_HIP(h, hipStreamWaitEvent(h->stream_b, h->ev_b[c], 0));
+                    TLSQ_TRY(gram_launch_chunk(h, h->stream_b, pl, Zbuf[cur ^ 1] + r0, M, r1 - r0, c));
+                }
+                TLSQ_TRY(gram_reduce(h, h->stream_b, pl, (double*)Gv, N));
+                TLSQ_HIP(h, hipEventRecord(h->ev_b[8], h->stream_b));
+                gram_queued = true;   // (h->stream waits for ev_b[8] below, behind the publication of the Frobenius sums)
+            } else {
+                TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
+                                                         svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                                         (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
+                                                         (const T*)ro.hankel_y, ro.hankel_K));
+            }
             hbm_sweeps += ((Rst ? 7.0 : 6.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
@@ -1344,9 +1387,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // The bound almost always says "not the last iteration": queue the next iteration's Gram of Z_{k+1}
             // right away so that the GPU works through the host round trip below (the opnorm evaluation, when it
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
-            const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 &&
-                                !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
-            if (!r_next && !implicit_gram) {   // (the TSQR route does not use the Gram matrix)
+            if (gram_queued) {   // the chunks' Gram sits on the second stream: join it (+ the all-reduce of row shards)
+                void* Gv;
+                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                TLSQ_HIP(h, hipStreamWaitEvent(h->stream, h->ev_b[8], 0));
+                TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
+                hbm_other += panel_bytes;
+                g_ready = true;
+            } else if (gram_next) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
                 TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
                 hbm_other += panel_bytes;

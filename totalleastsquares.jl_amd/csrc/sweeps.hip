@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
                                                                T* __restrict__ Zn, int64_t M, int N, int r, int ct,
                                                                T mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                                                                double* __restrict__ sumsq,
-                                                               double* __restrict__ zero_slots, int64_t hankel_K) {
+                                                               double* __restrict__ zero_slots, int64_t hankel_K,
+                                                               int64_t row0, int64_t row1) {
+    // rows [row0, row1) of the panels (row0 a multiple of ROWS): the whole panel, or one row chunk of it when the caller
+    // interleaves the chunks with the Gram kernel of the rows already swept (solver.hip)
     using VR = T __attribute__((ext_vector_type(ROWS)));
     if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
     __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
         sVs[e] = (c < nct && i < r) ? Vs[(size_t)(c0 + c) + (size_t)i * N] : 0.0;
     }
     __syncthreads();
-    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;   // ROWS = 2: M is even (launcher)
+    const int64_t row = row0 + ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;   // ROWS = 2: M, row0, row1 are even (launcher)
     double ss = 0.0;
-    if (row < M) {
+    if (row < row1) {
         double t[ROWS][RMAX];
 #pragma unroll
         for (int i = 0; i < RMAX; ++i)
@@ -530,8 +533,12 @@ bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, 
 template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
-                                 int nonnegE, double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K) {
+                                 int nonnegE, double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K,
+                                 int64_t row0, int64_t row1, size_t pad_lds) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
+    if (row1 <= 0) row1 = M;   // (default: the whole panel)
+    if (row0 < 0 || row0 >= row1 || row1 > M || (row0 % 2) != 0 || (row1 % 2) != 0)
+        return set_err(h, TLSQ_ERR_ARG, "rebuild_update_shrink: bad row range");
     // tall panels: two rows per thread, 64-column tiles.  Otherwise one row per thread and tiles narrow enough to
     // put ~16 waves on every CU (each tile re-reads its rows of T from L2, so not narrower than needed).
     const int64_t want_waves = 4096;
@@ -546,17 +553,23 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
     if (env_rows == 2) two2 = true;
     if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
     const int rows = two2 ? 2 : 1;
-    const dim3 grid((unsigned)((M / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
+    const dim3 grid((unsigned)(((row1 - row0) / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
 #define RUS_LAUNCH(RM, RW)                                                                                            \
     do {                                                                                                              \
+        if (pad_lds > 32768) {   /* (unused dynamic LDS: caps the resident workgroups per CU, see solver.hip) */      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rebuild_update_shrink<T, RM, RW, true>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rebuild_update_shrink<T, RM, RW, false>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds);                      \
+        }                                                                                                             \
         if (hankel_y)                                                                                                 \
-            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, \
+            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, true>), grid, dim3(256), pad_lds, h->stream, hankel_y, Tm, \
                                Vs, E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE,      \
-                               sumsq, zero_slots, hankel_K);                                                          \
+                               sumsq, zero_slots, hankel_K, row0, row1);                                              \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, \
+            hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, false>), grid, dim3(256), pad_lds, h->stream, D, Tm, Vs, \
                                E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq,   \
-                               zero_slots, (int64_t)0);                                                               \
+                               zero_slots, (int64_t)0, row0, row1);                                                   \
     } while (0)
     if (two2) {
         if (r <= 8) RUS_LAUNCH(8, 2);
@@ -675,7 +688,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
                                                  T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*, \
-                                                 const T*, int64_t);                                                  \
+                                                 const T*, int64_t, int64_t, int64_t, size_t);                        \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
