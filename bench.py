@@ -170,7 +170,8 @@ def main():
         sweep_ms_per_iter = (ms["shrink"] + ms["update"]) / iters_total
         # Bytes the sweeps have to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11
         # passes per iteration); the shipped path fuses K2(k) with K1(k+1) (R4/W4 = 8 passes) and runs one plain
-        # K1 (5 passes) at k = 1, so the roofline is priced against the bytes of THAT form - the smaller figure.
+        # K1 at k = 1 - folded together with the set-up's Y = D / dual_norm: R D / W Y,E,Z = 4 passes (k_first_shrink) - so
+        # the roofline is priced against the bytes of THAT form - the smaller figure.
         fused = os.environ.get("TLSQ_NO_FUSED_SWEEP", "0") != "1"
         # large panels (>= 2^26 elements): the rebuild A = T Vs' is folded in as well (A stays in registers):
         # R D,E,Y / W R,Y,E',Z' = 7 passes
@@ -180,7 +181,8 @@ def main():
         sweep_passes = 7.0 if fused_rebuild else 8.0
         if fused:
             # sweeps that were told not to store the residual panel moved one pass less
-            alg_bytes = (5.0 * args.steps + sweep_passes * iters_total - rskip_total) / iters_total * array_bytes
+            first_passes = 5.0 if os.environ.get("TLSQ_NO_FIRST_SHRINK", "0") == "1" else 4.0
+            alg_bytes = (first_passes * args.steps + sweep_passes * iters_total - rskip_total) / iters_total * array_bytes
         else:
             alg_bytes = 11.0 * array_bytes
         achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
@@ -197,7 +199,7 @@ def main():
                        "call": "plain (non-verbose) call: no per-iteration cost history is requested, so opnorm(residual) is "
                                "only resolved far enough to settle cost < tol; identical iterations and outputs "
                                "(tests/test_gpu_parity.py::test_rpca_device_mode_and_decision_only_cost)"},
-            "roofline": {"kernel": ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_first_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_first_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
                          "passes_per_iter": alg_bytes / array_bytes, "sweeps_without_residual_store": rskip_total,
@@ -244,7 +246,8 @@ def main():
                     sk = pmc["sweep_kernels"]
                     kname = "k_rebuild_update_shrink" if fused_rebuild else "k_update_shrink"
                     if fused and kname in sk:   # PMC average over the launches of one solve (with and without the R store)
-                        tr = (sk["k_shrink"]["hbm_bytes_per_launch"] +
+                        first = sk.get("k_first_shrink", sk.get("k_shrink"))
+                        tr = (first["hbm_bytes_per_launch"] +
                               rep.iters_done * sk[kname]["hbm_bytes_per_launch"]) / rep.iters_done
                     elif not fused and "k_update" in sk:
                         tr = sk["k_shrink"]["hbm_bytes_per_launch"] + sk["k_update"]["hbm_bytes_per_launch"]

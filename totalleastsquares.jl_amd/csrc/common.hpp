@@ -113,6 +113,8 @@ template <typename T>
 int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int64_t n, T inv_mu,
                   T thr, int nonnegE);
 template <typename T>
+int launch_first_shrink(Handle* h, const T* D, T* Y, T* E, T* Z, int64_t n, T s, T inv_mu, T thr, int nonnegE);
+template <typename T>
 int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu, int nonnegA);
 // fused update(k) + shrink(k+1): R_k, Y_k, E_{k+1} (En), Z_{k+1} (Zn) in one pass
 template <typename T>

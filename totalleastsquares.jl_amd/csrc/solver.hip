@@ -978,7 +978,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const double norminf = maxabs / lam;
     const double dual_norm = std::max(norm2, norminf);             // :179
     const double d_norm = norm2;                                   // :180
-    TLSQ_TRY(launch_div_scalar<T>(h, D, Y, n, (T)dual_norm));      // :181
+    // :181 Y = D / dual_norm is folded into the first shrink (launch_first_shrink, one pass over D instead of three)
+    bool y_pending = true;
+    static const bool no_first = [] { const char* e = getenv("TLSQ_NO_FIRST_SHRINK"); return e && e[0] == '1'; }();
+    if (no_first) {
+        TLSQ_TRY(launch_div_scalar<T>(h, D, Y, n, (T)dual_norm));      // :181
+        y_pending = false;
+    }
     double mu = 1.25 / norm2;                                      // :182
     const double mubar = mu * 1.0e7;                               // :183
     int64_t sv = 10, svp = 10;                                     // :184
@@ -1047,8 +1053,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (!have_next)
         {
             if (!(d_transient && k == 1)) TLSQ_TRY(panel_D(&D));   // (iteration 1 may still read the transient copy)
-            TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
-            hbm_sweeps += 5.0 * panel_bytes;
+            if (y_pending) {   // k = 1: A is zero and Y not formed yet
+                TLSQ_TRY(launch_first_shrink<T>(h, D, Y, E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));
+                y_pending = false;
+                hbm_sweeps += 4.0 * panel_bytes;
+            } else {
+                TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
+                hbm_sweeps += 5.0 * panel_bytes;
+            }
         }
         if (d_transient) D = nullptr;   // the copy in Zbuf[1] is not to be read any more
         pt.mark(have_next, !have_next);

@@ -486,6 +486,58 @@ int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int
     return TLSQ_OK;
 }
 
+// Set-up + first shrink in one pass (src/robustPCA.jl:181 and :188-192 at k = 1, where A is still zero):
+//   Y = D / s,  E = soft_th(D - 0 + (1/mu) Y, thr),  Z = D - E + (1/mu) Y
+// - the same operations in the same order as k_div_scalar followed by k_shrink (bit-identical; D - 0 is D), reading D once
+// instead of D twice, A and Y: 4 panel passes instead of 7.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_first_shrink(const T* __restrict__ D, T* __restrict__ Y, T* __restrict__ E,
+                                                      T* __restrict__ Z, int64_t n, T s, T inv_mu, T thr, int nonnegE) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = tid; i < nv; i += stride) {
+        const V d = reinterpret_cast<const V*>(D)[i];
+        V y, e, z;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            y[c] = d[c] / s;                          // Y ./= dual_norm                        :181
+            const T t = inv_mu * y[c];
+            T ee = soft_th(d[c] + t, thr);            // A = 0                                  :188
+            if (nonnegE) ee = pos_part(ee);
+            e[c] = ee;
+            z[c] = (d[c] - ee) + t;                   //                                        :192
+        }
+        reinterpret_cast<V*>(Y)[i] = y;
+        reinterpret_cast<V*>(E)[i] = e;
+        reinterpret_cast<V*>(Z)[i] = z;
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) {
+        const T y = D[i] / s;
+        const T t = inv_mu * y;
+        T ee = soft_th(D[i] + t, thr);
+        if (nonnegE) ee = pos_part(ee);
+        Y[i] = y;
+        E[i] = ee;
+        Z[i] = (D[i] - ee) + t;
+    }
+}
+
+template <typename T>
+int launch_first_shrink(Handle* h, const T* D, T* Y, T* E, T* Z, int64_t n, T s, T inv_mu, T thr, int nonnegE) {
+    if (n <= 0) return TLSQ_OK;
+    constexpr int VEC = 16 / sizeof(T);
+    if (aligned16(D) && aligned16(Y) && aligned16(E) && aligned16(Z))
+        hipLaunchKernelGGL((k_first_shrink<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, Y, E, Z, n, s,
+                           inv_mu, thr, nonnegE);
+    else
+        hipLaunchKernelGGL((k_first_shrink<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, Y, E, Z, n, s, inv_mu, thr,
+                           nonnegE);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 template <typename T>
 int launch_update(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, int64_t n, T mu,
                   int nonnegA) {
@@ -682,6 +734,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
 
 #define INST(T)                                                                                   \
     template int launch_shrink<T>(Handle*, const T*, const T*, const T*, T*, T*, int64_t, T, T, int); \
+    template int launch_first_shrink<T>(Handle*, const T*, T*, T*, T*, int64_t, T, T, T, int);    \
     template int launch_update<T>(Handle*, const T*, T*, const T*, T*, T*, int64_t, T, int);      \
     template int launch_update_shrink<T>(Handle*, const T*, T*, const T*, T*, T*, T*, T*, int64_t, T, int, T, T, \
                                          int, double*, double*);                                                     \
