@@ -195,10 +195,12 @@ int second_stream(Handle* h) {
     // (highest priority: its workgroups are few and large - they should get a CU as soon as one has room)
     int least = 0, greatest = 0;
     static const bool no_prio = [] { const char* e = getenv("TLSQ_OVERLAP_NOPRIO"); return e && e[0] == '1'; }();
-    if (!no_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-        TLSQ_HIP(h, hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, greatest));
-    else
-        TLSQ_HIP(h, hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    if (!no_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+        hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        h->stream_b = nullptr;
+    }
+    if (!h->stream_b) TLSQ_HIP(h, hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
     for (auto& e : h->ev_b) TLSQ_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return TLSQ_OK;
 }
