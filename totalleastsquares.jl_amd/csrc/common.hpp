@@ -205,7 +205,7 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
 // async_small: when the matrix fits the single-workgroup path, do not read the sweep count back (no host sync).
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
                bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false,
-               bool warm_v = false);
+               bool warm_v = false, bool two_sided = false);   // two_sided (N <= 64): rotate G itself (absolute accuracy)
 // warm_v: V holds the previous decomposition's eigenvectors (orthogonal): start from B = G*V.
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 // selection + weights small enough to travel as kernel arguments (r <= 32)

@@ -382,6 +382,137 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
 }
 
+// ---- two-sided Jacobi for the Rayleigh-Ritz problems of the subspace iteration (N <= 64, one launch) ----------------------
+// H = Q'GQ is symmetric and, on a warm block, nearly diagonal.  The one-sided form above needs a dot product over the
+// rows - a DPP reduction in the middle of every rotation's dependent chain - and carries B = H V beside V; rotating H
+// itself takes the rotation from three entries (h_pp, h_qq, h_pq), then updates the two columns (lane = row) and, after
+// a barrier, the two rows (lane = column) of every pair of the round: ~0.3 us per round instead of ~0.8.  Its accuracy is
+// absolute (eps ||H||), which is what the Gram matrix behind H has anyway (SubspaceState::noise_rel); the solvers that
+// need relative accuracy (dense Jacobi on a triangular factor) keep the one-sided form.
+// Outputs as k_jacobi_small: V = eigenvectors, lam = |eigenvalues| (unsorted), B = H V = V diag(lambda).
+template <bool WANT_V>
+__global__ __launch_bounds__(1024) void k_jacobi2_small(const double* __restrict__ G, int64_t ldG,
+                                                        double* __restrict__ Bout, double* __restrict__ Vout,
+                                                        double* __restrict__ lam, int N, double tol, double nfloor,
+                                                        int max_sweeps, int* __restrict__ sweeps_done) {
+    __shared__ double sH[64 * 65];
+    __shared__ double sV[WANT_V ? 64 * 65 : 1];
+    __shared__ double red[16];
+    __shared__ unsigned int s_rot;
+    __shared__ unsigned long long s_max;
+    const int LD = 65;
+    const int tid = threadIdx.x;
+    const int hw = tid >> 5, hl = tid & 31;   // half-wave = one pair of the round
+    const int nthr = blockDim.x;
+    double fro = 0.0;
+    for (int e = tid; e < N * N; e += nthr) {
+        const int r = e % N, c = e / N;
+        // (symmetrised: H comes from a product Q'(GQ) whose two triangles agree to rounding only)
+        const double v = 0.5 * (G[r + (int64_t)c * ldG] + G[c + (int64_t)r * ldG]);
+        sH[c * LD + r] = v;
+        if (WANT_V) sV[c * LD + r] = (r == c) ? 1.0 : 0.0;
+        fro += v * v;
+    }
+    fro = wave_allsum(fro);
+    if ((tid & 63) == 0) red[tid >> 6] = fro;
+    if (tid == 0) {
+        s_rot = 0;
+        s_max = 0ull;
+    }
+    __syncthreads();
+    double fsum = 0.0;
+    for (int k = 0; k < (nthr >> 6); ++k) fsum += red[k];
+    const double floor2 = nfloor * nfloor * fsum;   // off-diagonal entries below nfloor ||H||_F are rounding noise
+    const int nslot = (N + 1) & ~1;
+    const int npair = nslot / 2;
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        unsigned int my_rot = 0;
+        double my_max = 0.0;
+        for (int ir = 0; ir < nslot - 1; ++ir) {
+            int p = 0, q = 0;
+            bool rotate = false;
+            double cs = 1.0, sn = 0.0;
+            if (hw < npair) {
+                rr_pair(nslot, ir, hw, p, q);
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
+                if (q < N) {
+                    const double hpp = sH[p * LD + p], hqq = sH[q * LD + q], hpq = sH[q * LD + p];
+                    const double prod = fabs(hpp * hqq);
+                    if (hpq * hpq > tol * tol * prod && hpq * hpq > floor2) {
+                        rotate = true;
+                        const double ratio2 = prod > 0.0 ? hpq * hpq / prod : 1.0;
+                        my_max = ratio2 > my_max ? ratio2 : my_max;
+                        // t = 2 h_pq sgn(d) / (|d| + sqrt(d^2 + 4 h_pq^2)), d = h_qq - h_pp
+                        const double d = hqq - hpp;
+                        const double t = (d >= 0.0 ? 2.0 : -2.0) * hpq / (fabs(d) + sqrt(d * d + 4.0 * hpq * hpq));
+                        cs = rsqrt(1.0 + t * t);
+                        sn = cs * t;
+                        ++my_rot;
+                        // columns p, q of H (and of V): lane = row
+                        for (int r = hl; r < N; r += 32) {
+                            const double x = sH[p * LD + r], y = sH[q * LD + r];
+                            sH[p * LD + r] = cs * x - sn * y;
+                            sH[q * LD + r] = sn * x + cs * y;
+                            if (WANT_V) {
+                                const double u = sV[p * LD + r], w2 = sV[q * LD + r];
+                                sV[p * LD + r] = cs * u - sn * w2;
+                                sV[q * LD + r] = sn * u + cs * w2;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (rotate) {
+                // rows p, q of H: lane = column
+                for (int c = hl; c < N; c += 32) {
+                    const double x = sH[c * LD + p], y = sH[c * LD + q];
+                    sH[c * LD + p] = cs * x - sn * y;
+                    sH[c * LD + q] = sn * x + cs * y;
+                }
+                // (same half-wave, program order: the rotated pair is exactly decoupled)
+                if (hl == 0) {
+                    sH[q * LD + p] = 0.0;
+                    sH[p * LD + q] = 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        if (hl == 0 && my_rot) {
+            atomicAdd(&s_rot, my_rot);
+            atomicMax(&s_max, (unsigned long long)__double_as_longlong(my_max));
+        }
+        __syncthreads();
+        const unsigned int r = s_rot;
+        const double swmax = __longlong_as_double((long long)s_max);
+        __syncthreads();
+        if (tid == 0) {
+            s_rot = 0;
+            s_max = 0ull;
+        }
+        // converged: a sweep without rotations - or one whose largest rotation was so small (h_pq^2 < 1e-16 h_pp h_qq)
+        // that, Jacobi converging quadratically, what is left is below the rotation threshold anyway
+        if (r == 0 || swmax < 1e-16) {
+            ++sweep;
+            break;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += nthr) {
+        const int r = e % N, c = e / N;
+        const double v = WANT_V ? sV[c * LD + r] : 0.0;
+        if (WANT_V) Vout[e] = v;
+        Bout[e] = v * sH[c * LD + c];
+    }
+    for (int c = tid; c < N; c += nthr) lam[c] = fabs(sH[c * LD + c]);
+    if (tid == 0 && sweeps_done) *sweeps_done = sweep;
+}
+
 // The same for 64 < N <= 96 (Rayleigh-Ritz problems of blocks of 65..96 columns): three rows per lane, up to 48
 // column pairs per round shared out over the 32 half-waves, B and V in dynamic LDS (2 N (N+1) doubles <= 149 KB).
 template <bool WANT_V>
@@ -633,7 +764,7 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
 }
 
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,
-               double* lam_dev, int64_t* sweeps_out, bool async_small, bool warm_v) {
+               double* lam_dev, int64_t* sweeps_out, bool async_small, bool warm_v, bool two_sided) {
     if (sweeps_out) *sweeps_out = 0;
     if (N <= 0) return TLSQ_OK;
     void* scal;
@@ -651,7 +782,11 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         // one half-wave per column pair; whole waves only
         const int npair0 = (int)((N + 1) / 2);
         const int nthr0 = ((npair0 * 32 + 63) / 64) * 64;
-        if (want_v)
+        static const bool no_two = [] { const char* e = getenv("TLSQ_JACOBI2"); return e && e[0] == '0'; }();
+        if (want_v && two_sided && !no_two)
+            hipLaunchKernelGGL(k_jacobi2_small<true>, dim3(1), dim3(nthr0), 0, h->stream, G, ldG, B, V, lam_dev,
+                               (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
+        else if (want_v)
             hipLaunchKernelGGL(k_jacobi_small<true>, dim3(1), dim3(nthr0), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
         else

@@ -504,7 +504,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
         int64_t sw = 0;
-        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true));
+        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
         if (sweeps) *sweeps += sw;
         // X' = Q S,  G X' = (G Q) S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
