@@ -132,7 +132,8 @@ int  tlsq_create(int device_id, tlsq_handle* out);
  * one worker thread per GPU, and gathering A, E (U) back; S, Vt, sv, the report and the on_iter hook come from rank
  * 0 on the calling thread - worker threads never call back into the host language.  Every other entry point (and
  * problems that do not shard: wide matrices, tiny row counts) runs on the first GPU alone.  ngpus = 1 is valid
- * (same code path, one-rank communicator). */
+ * (same code path, one-rank communicator).  A device id may be repeated (testing the rank > 1 paths on a box with
+ * fewer GPUs): such a group gets a host-staged loop-back communicator instead of RCCL - correct, not fast. */
 int  tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out);
 int  tlsq_ngpus(tlsq_handle h);   /* GPUs behind the handle (1 for tlsq_create) */
 int  tlsq_destroy(tlsq_handle h);

@@ -98,3 +98,91 @@ def test_multi_handle_rejects_device_pointers(engines):
     with pytest.raises(tlsq_amd.TlsqError) as ei:
         multi.rpca_device(d.data_ptr(), 1500, 96, a.data_ptr(), e.data_ptr())
     assert ei.value.code == tlsq_amd._lib.TLSQ_ERR_UNSUPPORTED
+
+
+# ---- rank > 1 on a one-GPU box: a loop-back group (the same device named several times) -------------------------
+# RCCL refuses duplicate devices, so tlsq_create_multi gives such a group a host-staged communicator (runtime.hip,
+# LocalGroup): every rank is a handle with its own stream and worker thread, all-reduce / all-gather reduce the ranks'
+# buffers in rank order.  What this exercises is everything ABOVE the collective: the row-sharded solver's control flow
+# with nranks > 1 (every decision has to come out the same on all ranks or the group dead-locks - the loop-back barrier
+# then times out and the call fails), uneven row blocks, the TSQR gather + stacked factorisation, time-window shards.
+@pytest.fixture(scope="module", params=[2, 3, 8])
+def loopback(request):
+    import torch  # noqa: F401
+    import tlsq_amd
+    plain = tlsq_amd.Engine(0)
+    multi = tlsq_amd.Engine(devices=[0] * request.param)
+    assert multi.ngpus == request.param
+    yield plain, multi, request.param
+    multi.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("M,N,r,kw", [(1500, 96, 6, {}), (1237, 50, 4, {"nonnegE": True}), (3001, 130, 30, {"nukeA": False}),
+                                      (20000, 128, 8, {})])
+def test_loopback_rpca_rank_gt_1_vs_plain_and_oracle(loopback, M, N, r, kw):
+    from oracle import rpca_oracle as O
+    plain, multi, n = loopback
+    D, _, _ = O.synth_lowrank_sparse(M, N, r, seed=M)
+    A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, **kw)
+    A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, **kw)
+    assert rep2.iters_done == rep1.iters_done and rep2.svp_hist == rep1.svp_hist and sv2 == sv1
+    assert relerr(A2, A1) < 1e-9 and relerr(E2, E1) < 1e-9
+    assert np.allclose(rep2.cost_hist, rep1.cost_hist, rtol=1e-6, atol=1e-12)
+    if M <= 3001:
+        Ao, Eo, so, svo, io = O.rpca(D, **kw)
+        assert rep2.iters_done == io.iters_done and rep2.svp_hist == io.svp_hist
+        assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8
+        assert np.allclose(s2.S, so[1], rtol=1e-10, atol=64 * 2.2e-16 * np.sqrt(N) * so[1][0])
+
+
+def test_loopback_noisy_problem_takes_the_tsqr_route(loopback):
+    """Dense noise on top of the low-rank part: late iterations count singular values inside the noise of the Gram
+    matrix and go through the TSQR route - on shards: per-rank factorisation, all-gather of the triangular factors,
+    stacked factorisation, redundantly on every rank."""
+    from oracle import rpca_oracle as O
+    plain, multi, n = loopback
+    rng = np.random.default_rng(11)
+    M, N = 1200, 48
+    D = rng.standard_normal((M, 3)) @ rng.standard_normal((3, N)) + 1e-3 * rng.standard_normal((M, N))
+    A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True)
+    A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert rep2.iters_done == rep1.iters_done == io.iters_done
+    assert rep2.svp_hist == rep1.svp_hist == io.svp_hist
+    assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8
+    assert rep2.tsqr_iterations > 0
+
+
+def test_loopback_lowrankfilter_time_windows(loopback):
+    from oracle import rpca_oracle as O
+    plain, multi, n = loopback
+    y, noise = O.synth_series(6000, seed=3)
+    f1 = plain.lowrankfilter(y + noise, 40)
+    f2 = multi.lowrankfilter(y + noise, 40)
+    assert relerr(f2, f1) < 1e-9
+
+
+def test_loopback_large_panel_shards_fused_rebuild_sweep():
+    """Two ranks whose shards are large panels (>= 2^26 entries each): the fused rebuild + update + shrink sweep, the
+    Frobenius shortcut with its all-reduced partial sums and the next iteration's Gram queued behind the sweep - with
+    nranks = 2.  Same trajectory as the one-GPU solve of the whole matrix."""
+    import torch  # noqa: F401
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    M, N, r = 270_000, 512, 8
+    D, A0, _ = O.synth_lowrank_sparse(M, N, r, seed=5)
+    plain = tlsq_amd.Engine(0)
+    try:
+        A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+    finally:
+        plain.close()
+    multi = tlsq_amd.Engine(devices=[0, 0])
+    try:
+        A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+    finally:
+        multi.close()
+    assert rep1.converged and rep2.converged and sv2 == sv1 == r
+    assert rep2.iters_done == rep1.iters_done and rep2.svp_hist == rep1.svp_hist
+    assert relerr(A2, A1) < 1e-9 and relerr(E2, E1) < 1e-9
+    assert relerr(A2, A0) < 1e-6

@@ -10,6 +10,9 @@
 #include <limits>
 #include <numeric>
 #include <thread>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 
 #include "internal.hpp"
 
@@ -86,8 +89,36 @@ static bool rccl_load() {
     return true;
 }
 
+// Loop-back group: the "ranks" of a tlsq_create_multi handle that names the same device more than once (tests: the
+// rank > 1 control flow of the sharded solvers on a one-GPU box; RCCL refuses duplicate devices).  Collectives go
+// through host memory: every rank stages its buffer, a barrier, every rank reduces all slots in rank order (identical
+// bits everywhere, like RCCL's all-reduce), a second barrier before the slots are reused.  Slow, and only meant to be.
+struct LocalGroup {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    std::vector<std::vector<double>> slot;
+    bool barrier() {   // false: the other ranks did not arrive within a minute (one of them left the call with an error)
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        if (++arrived == n) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+            return true;
+        }
+        if (cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g; })) return true;
+        --arrived;
+        return false;
+    }
+};
+
 struct Comm {
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LocalGroup> local;   // set instead of `comm` for a loop-back group
+    int local_rank = 0;
 };
 
 #define TLSQ_NCCL(h, expr)                                                                     \
@@ -101,6 +132,34 @@ struct Comm {
 // in-place sum of an N x N Gram over the row shards (the one real exchange of the path)
 int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
     if (!h->comm) return TLSQ_OK;
+    if (h->comm->local) {
+        LocalGroup& g = *h->comm->local;
+        std::vector<double>& mine = g.slot[(size_t)h->comm->local_rank];
+        mine.resize(count);
+        TLSQ_HIP(h, hipMemcpyAsync(mine.data(), dev, count * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (!g.barrier()) return set_err(h, TLSQ_ERR_COMM, "loop-back all-reduce: a rank is missing (diverged control flow?)");
+        std::vector<double> acc(g.slot[0]);
+        bool ok = acc.size() == count;
+        for (int r = 1; r < g.n && ok; ++r) {
+            const std::vector<double>& o = g.slot[(size_t)r];
+            if (o.size() != count) {
+                ok = false;
+                break;
+            }
+            for (size_t i = 0; i < count; ++i) {
+                if (op == ncclSum) acc[i] += o[i];
+                else if (op == ncclMax) acc[i] = o[i] > acc[i] ? o[i] : acc[i];
+                else if (op == ncclMin) acc[i] = o[i] < acc[i] ? o[i] : acc[i];
+                else acc[i] *= o[i];
+            }
+        }
+        if (!g.barrier()) return set_err(h, TLSQ_ERR_COMM, "loop-back all-reduce: a rank is missing (diverged control flow?)");
+        if (!ok) return set_err(h, TLSQ_ERR_COMM, "loop-back all-reduce: the ranks disagree on the element count");
+        TLSQ_HIP(h, hipMemcpyAsync(dev, acc.data(), count * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    }
     TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
     return TLSQ_OK;
 }
@@ -109,6 +168,28 @@ int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
 int comm_allgather(Handle* h, const double* send, double* recv, size_t count) {
     if (!h->comm) {
         TLSQ_HIP(h, hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, h->stream));
+        return TLSQ_OK;
+    }
+    if (h->comm->local) {
+        LocalGroup& g = *h->comm->local;
+        std::vector<double>& mine = g.slot[(size_t)h->comm->local_rank];
+        mine.resize(count);
+        TLSQ_HIP(h, hipMemcpyAsync(mine.data(), send, count * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (!g.barrier()) return set_err(h, TLSQ_ERR_COMM, "loop-back all-gather: a rank is missing (diverged control flow?)");
+        std::vector<double> all((size_t)g.n * count);
+        bool ok = true;
+        for (int r = 0; r < g.n; ++r) {
+            if (g.slot[(size_t)r].size() != count) {
+                ok = false;
+                break;
+            }
+            memcpy(all.data() + (size_t)r * count, g.slot[(size_t)r].data(), count * 8);
+        }
+        if (!g.barrier()) return set_err(h, TLSQ_ERR_COMM, "loop-back all-gather: a rank is missing (diverged control flow?)");
+        if (!ok) return set_err(h, TLSQ_ERR_COMM, "loop-back all-gather: the ranks disagree on the element count");
+        TLSQ_HIP(h, hipMemcpyAsync(recv, all.data(), all.size() * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         return TLSQ_OK;
     }
     TLSQ_NCCL(h, g_rccl.AllGather(send, recv, count, ncclDouble, h->comm->comm, h->stream));
@@ -305,15 +386,16 @@ int tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;   // no GPU: fail loudly
-    if (ngpus > ndev) return TLSQ_ERR_ARG;
+    if (ngpus > 64) return TLSQ_ERR_ARG;
     std::vector<int> devs((size_t)ngpus);
+    bool repeats = false;   // the same device twice: a loop-back group (see LocalGroup), device ids must then be given
     for (int r = 0; r < ngpus; ++r) {
         devs[(size_t)r] = device_ids ? device_ids[r] : r;
         if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) return TLSQ_ERR_ARG;
         for (int q = 0; q < r; ++q)
-            if (devs[(size_t)q] == devs[(size_t)r]) return TLSQ_ERR_ARG;
+            if (devs[(size_t)q] == devs[(size_t)r]) repeats = true;
     }
-    if (!rccl_load() || !g_rccl.CommInitAll) return TLSQ_ERR_COMM;
+    if (!repeats && (!rccl_load() || !g_rccl.CommInitAll)) return TLSQ_ERR_COMM;
     std::vector<tlsq_handle> hs((size_t)ngpus, nullptr);
     auto undo = [&]() {
         for (auto x : hs)
@@ -327,13 +409,20 @@ int tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out) {
         }
     }
     std::vector<ncclComm_t> comms((size_t)ngpus, nullptr);
-    if (g_rccl.CommInitAll(comms.data(), ngpus, devs.data()) != ncclSuccess) {
+    std::shared_ptr<LocalGroup> lg;
+    if (repeats) {
+        lg = std::make_shared<LocalGroup>();
+        lg->n = ngpus;
+        lg->slot.resize((size_t)ngpus);
+    } else if (g_rccl.CommInitAll(comms.data(), ngpus, devs.data()) != ncclSuccess) {
         undo();
         return TLSQ_ERR_COMM;
     }
     for (int r = 0; r < ngpus; ++r) {
         hs[(size_t)r]->multi_comm = new Comm();
         hs[(size_t)r]->multi_comm->comm = comms[(size_t)r];
+        hs[(size_t)r]->multi_comm->local = lg;
+        hs[(size_t)r]->multi_comm->local_rank = r;
         hs[(size_t)r]->multi_n = ngpus;
         hs[(size_t)r]->multi_rank = r;
     }
