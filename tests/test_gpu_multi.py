@@ -186,3 +186,27 @@ def test_loopback_large_panel_shards_fused_rebuild_sweep():
     assert rep2.iters_done == rep1.iters_done and rep2.svp_hist == rep1.svp_hist
     assert relerr(A2, A1) < 1e-9 and relerr(E2, E1) < 1e-9
     assert relerr(A2, A0) < 1e-6
+
+
+def test_loopback_large_mode_fp32_shards():
+    """BASELINE config 5's shape class on row shards: fp32, min(M, N) > 2048 (large mode: subspace solver only, the Gram
+    of every shard on the fp32 MFMA with fp64 fold-in, all-reduced), two ranks; against the one-GPU solve."""
+    import torch  # noqa: F401
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    M, N, r = 6000, 2304, 12
+    D, A0, _ = O.synth_lowrank_sparse(M, N, r, seed=0, dtype=np.float32)
+    plain = tlsq_amd.Engine(0)
+    try:
+        A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, want_U=False)
+    finally:
+        plain.close()
+    multi = tlsq_amd.Engine(devices=[0, 0])
+    try:
+        A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, want_U=False)
+    finally:
+        multi.close()
+    assert A2.dtype == np.float32 and rep1.converged and rep2.converged and sv2 == sv1 == r
+    assert abs(rep2.iters_done - rep1.iters_done) <= 1
+    assert relerr(A2.astype(np.float64), A1.astype(np.float64)) < 1e-3
+    assert relerr(A2.astype(np.float64), A0.astype(np.float64)) < 1e-3
