@@ -161,6 +161,11 @@ def test_loopback_lowrankfilter_time_windows(loopback):
     f1 = plain.lowrankfilter(y + noise, 40)
     f2 = multi.lowrankfilter(y + noise, 40)
     assert relerr(f2, f1) < 1e-9
+    # fp32 series: the shards sum their anti-diagonals in fp32 (like the one-GPU kernel), fp64 across shards
+    y32 = (y + noise).astype(np.float32)
+    g1 = plain.lowrankfilter(y32, 40)
+    g2 = multi.lowrankfilter(y32, 40)
+    assert g2.dtype == np.float32 and relerr(g2.astype(np.float64), g1.astype(np.float64)) < 1e-4
 
 
 def test_loopback_large_panel_shards_fused_rebuild_sweep():

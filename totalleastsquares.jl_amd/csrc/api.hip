@@ -106,11 +106,11 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     if (is_multi_call(h)) {
         // single-process multi-GPU group: every rank receives the whole series (host memory) and owns a block of the
         // Hankel rows; ranks > 0 write their (identical) filtered series to scratch.  What the sharded form does not
-        // cover (fp32, the hankel option, plain SSA truncation, short series) runs on the first GPU alone.
+        // cover (the hankel option, plain SSA truncation, short series) runs on the first GPU alone.
         const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
         if (dev_mem) return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: a multi-GPU handle takes host vectors");
         const int64_t Kall = (Nx - n) / lag + 1;
-        if (std::is_same<T, double>::value && !(opts && opts->hankel) && sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
+        if (!(opts && opts->hankel) && sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
             const int nr = h->multi_n;
             std::vector<std::vector<T>> scratch((size_t)nr);
             std::vector<tlsq_rpca_info> ri((size_t)nr);
@@ -169,8 +169,6 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         if (r1 <= r0) return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: fewer Hankel rows (%lld) than ranks", (long long)Kg);
         if (opts && opts->hankel)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the hankel option is not available on row shards");
-        if (!std::is_same<T, double>::value)
-            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: row shards are fp64 only");
     }
     const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
     // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the
@@ -249,11 +247,9 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         double* sum = (double*)sc;
         double* cnt = sum + nn;
         TLSQ_HIP(h, hipMemsetAsync(sc, 0, 2 * nn * 8, h->stream));
-        if constexpr (std::is_same<T, double>::value) {
-            TLSQ_TRY(launch_unhankel_partial(h, (const double*)A, K, n, Dch, Kp, lag, Nw, s0, sum, cnt, Nx));
-            TLSQ_TRY(comm_allreduce(h, sum, 2 * nn, ncclSum));
-            TLSQ_TRY(launch_unhankel_finish(h, sum, cnt, (int64_t)nn, (double*)dy));
-        }
+        TLSQ_TRY(launch_unhankel_partial<T>(h, (const T*)A, K, n, Dch, Kp, lag, Nw, s0, sum, cnt, Nx));
+        TLSQ_TRY(comm_allreduce(h, sum, 2 * nn, ncclSum));
+        TLSQ_TRY(launch_unhankel_finish<T>(h, sum, cnt, (int64_t)nn, (T*)dy));
     }
     TLSQ_TRY(copy2d(h, yf, ldyf, dy, Nx, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));

@@ -333,9 +333,11 @@ template <typename T>
 int launch_unhankel(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA,
                     int64_t lag, int64_t Nx, T* y, int64_t ldy);
 // multi-GPU lowrankfilter: per-shard anti-diagonal sums / counts at a window offset, and the division after the all-reduce
-int launch_unhankel_partial(Handle* h, const double* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA, int64_t lag,
+template <typename T>
+int launch_unhankel_partial(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA, int64_t lag,
                             int64_t Nw, int64_t off, double* sum, double* cnt, int64_t ldy);
-int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, double* y);
+template <typename T>
+int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, T* y);
 template <typename T>
 int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, T* mean_ws);
 

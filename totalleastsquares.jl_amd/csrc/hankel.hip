@@ -62,33 +62,35 @@ __global__ __launch_bounds__(256) void k_unhankel(const T* __restrict__ A, int64
 // Time-window shards (multi-GPU lowrankfilter): the anti-diagonal sums and counts of this rank's rows, written at
 // the window's offset `off` into full-length arrays sum / cnt (Nx_glob x Dch, zero-filled by the caller); after the
 // all-reduce k_unhankel_finish divides (y ./= max.(counts,1), :66).  Same summation order inside a shard as above.
-__global__ __launch_bounds__(256) void k_unhankel_partial(const double* __restrict__ A, int64_t K, int64_t L, int64_t Dch,
+template <typename T>
+__global__ __launch_bounds__(256) void k_unhankel_partial(const T* __restrict__ A, int64_t K, int64_t L, int64_t Dch,
                                                           int64_t ldA, int64_t lag, int64_t Nw, int64_t off,
                                                           double* __restrict__ sum, double* __restrict__ cnt,
                                                           int64_t ldy) {
     const int64_t d = blockIdx.y;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < Nw; n += stride) {
-        double tot = 0.0;
+        T tot = (T)0;   // (summed in the element type, like the one-GPU kernel and the reference; fp64 across shards)
         int64_t c = 0;
         const int64_t lmax = n < L - 1 ? n : L - 1;
         for (int64_t l = n % lag; l <= lmax; l += lag) {
             const int64_t k = (n - l) / lag;
             if (k < K) {
-                const double v = A[k + (d + Dch * l) * ldA];
+                const T v = A[k + (d + Dch * l) * ldA];
                 tot = (c == 0) ? v : tot + v;
                 ++c;
             }
         }
-        sum[off + n + d * ldy] = tot;
+        sum[off + n + d * ldy] = (double)tot;
         cnt[off + n + d * ldy] = (double)c;
     }
 }
+template <typename T>
 __global__ __launch_bounds__(256) void k_unhankel_finish(const double* __restrict__ sum, const double* __restrict__ cnt,
-                                                         int64_t n, double* __restrict__ y) {
+                                                         int64_t n, T* __restrict__ y) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        y[i] = cnt[i] > 0.0 ? sum[i] / cnt[i] : 0.0;
+        y[i] = (T)(cnt[i] > 0.0 ? sum[i] / cnt[i] : 0.0);
 }
 
 // A[k + l*ldA] = soft_th(A[k + l*ldA], eps, m[k+l]),  soft_th(x,e,m) = max(x-e,m) + min(x+e,m) - m
@@ -151,17 +153,19 @@ int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps
     return TLSQ_OK;
 }
 
-int launch_unhankel_partial(Handle* h, const double* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA, int64_t lag,
+template <typename T>
+int launch_unhankel_partial(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA, int64_t lag,
                             int64_t Nw, int64_t off, double* sum, double* cnt, int64_t ldy) {
     if (Nw <= 0 || Dch <= 0) return TLSQ_OK;
-    hipLaunchKernelGGL(k_unhankel_partial, dim3(gx(Nw), (unsigned)Dch), dim3(256), 0, h->stream, A, K, L, Dch, ldA, lag,
+    hipLaunchKernelGGL((k_unhankel_partial<T>), dim3(gx(Nw), (unsigned)Dch), dim3(256), 0, h->stream, A, K, L, Dch, ldA, lag,
                        Nw, off, sum, cnt, ldy);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
-int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, double* y) {
+template <typename T>
+int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, T* y) {
     if (n <= 0) return TLSQ_OK;
-    hipLaunchKernelGGL(k_unhankel_finish, dim3(gx(n)), dim3(256), 0, h->stream, sum, cnt, n, y);
+    hipLaunchKernelGGL((k_unhankel_finish<T>), dim3(gx(n)), dim3(256), 0, h->stream, sum, cnt, n, y);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -171,7 +175,10 @@ int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int6
                                   int64_t);                                                           \
     template int launch_unhankel<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t,   \
                                     int64_t, T*, int64_t);                                            \
-    template int launch_soft_hankel<T>(Handle*, T*, int64_t, int64_t, int64_t, T, T*);
+    template int launch_soft_hankel<T>(Handle*, T*, int64_t, int64_t, int64_t, T, T*);                \
+    template int launch_unhankel_partial<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, \
+                                            int64_t, double*, double*, int64_t);                      \
+    template int launch_unhankel_finish<T>(Handle*, const double*, const double*, int64_t, T*);
 INST(double)
 INST(float)
 #undef INST
