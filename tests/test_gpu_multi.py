@@ -215,3 +215,24 @@ def test_loopback_large_mode_fp32_shards():
     assert abs(rep2.iters_done - rep1.iters_done) <= 1
     assert relerr(A2.astype(np.float64), A1.astype(np.float64)) < 1e-3
     assert relerr(A2.astype(np.float64), A0.astype(np.float64)) < 1e-3
+
+
+def test_loopback_hankel_flag_on_row_shards(loopback):
+    """rpca(H; hankel=true) and lowrankfilter(...; hankel=true) on row shards: the anti-diagonal means of soft_hankel!
+    (src/robustPCA.jl:214-216, 234-236) run through several ranks' row blocks - block sums and counts at the block's
+    row offset, one all-reduce, shrink towards the global means.  Same trajectory and matrices as the one-GPU solve."""
+    from oracle import rpca_oracle as O
+    plain, multi, n = loopback
+    y, noise = O.synth_series(1500, seed=7)
+    H = plain.hankel(y + noise, 30)
+    for kw in ({"hankel": True}, {"hankel": True, "nukeA": False}):
+        A1, E1, s1, sv1, rep1 = plain.rpca(H, return_report=True, **kw)
+        A2, E2, s2, sv2, rep2 = multi.rpca(H, return_report=True, **kw)
+        assert rep2.iters_done == rep1.iters_done and rep2.svp_hist == rep1.svp_hist and sv2 == sv1
+        assert relerr(A2, A1) < 1e-9 and relerr(E2, E1) < 1e-9
+    Ao, Eo, so, svo, io = O.rpca(H, hankel=True)
+    A2, E2, s2, sv2, rep2 = multi.rpca(H, return_report=True, hankel=True)
+    assert rep2.iters_done == io.iters_done and relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8
+    f1 = plain.lowrankfilter(y + noise, 30, hankel=True)
+    f2 = multi.lowrankfilter(y + noise, 30, hankel=True)
+    assert relerr(f2, f1) < 1e-9

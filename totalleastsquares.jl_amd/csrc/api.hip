@@ -106,11 +106,11 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     if (is_multi_call(h)) {
         // single-process multi-GPU group: every rank receives the whole series (host memory) and owns a block of the
         // Hankel rows; ranks > 0 write their (identical) filtered series to scratch.  What the sharded form does not
-        // cover (the hankel option, plain SSA truncation, short series) runs on the first GPU alone.
+        // cover (plain SSA truncation, short series) runs on the first GPU alone.
         const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
         if (dev_mem) return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: a multi-GPU handle takes host vectors");
         const int64_t Kall = (Nx - n) / lag + 1;
-        if (!(opts && opts->hankel) && sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
+        if (sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
             const int nr = h->multi_n;
             std::vector<std::vector<T>> scratch((size_t)nr);
             std::vector<tlsq_rpca_info> ri((size_t)nr);
@@ -167,8 +167,6 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         r0 = h->rank * base + std::min<int64_t>(h->rank, rem);
         r1 = r0 + base + (h->rank < rem ? 1 : 0);
         if (r1 <= r0) return set_err(h, TLSQ_ERR_ARG, "lowrankfilter: fewer Hankel rows (%lld) than ranks", (long long)Kg);
-        if (opts && opts->hankel)
-            return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the hankel option is not available on row shards");
     }
     const int64_t K = r1 - r0, s0 = r0 * lag, Nw = (K - 1) * lag + n;   // local rows, window start and length
     // zero pad rows up to a multiple of 16 so that every panel column is 128-byte aligned (see rpca_entry); the

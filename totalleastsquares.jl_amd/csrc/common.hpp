@@ -101,6 +101,7 @@ enum WsSlot {
     WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
+    WS_HKSUM,     // soft_hankel! on row shards: anti-diagonal sums and counts of the whole matrix (solver.hip)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
@@ -340,5 +341,7 @@ template <typename T>
 int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, T* y);
 template <typename T>
 int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, T* mean_ws);
+template <typename T>
+int launch_soft_toward(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, const T* m, T eps);
 
 }  // namespace tlsq

@@ -153,6 +153,16 @@ int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps
     return TLSQ_OK;
 }
 
+// the second half of soft_hankel! alone: A[k, l] = soft_th(A[k, l], eps, m[k + l]) for given anti-diagonal means m
+template <typename T>
+int launch_soft_toward(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, const T* m, T eps) {
+    if (K <= 0 || L <= 0) return TLSQ_OK;
+    if (L > 65535) return set_err(h, TLSQ_ERR_UNSUPPORTED, "soft_hankel: L=%lld exceeds 65535", (long long)L);
+    hipLaunchKernelGGL((k_soft_toward<T>), dim3(gx(K), (unsigned)L), dim3(256), 0, h->stream, A, K, ldA, m, eps);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 template <typename T>
 int launch_unhankel_partial(Handle* h, const T* A, int64_t K, int64_t L, int64_t Dch, int64_t ldA, int64_t lag,
                             int64_t Nw, int64_t off, double* sum, double* cnt, int64_t ldy) {
@@ -178,7 +188,8 @@ int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int6
     template int launch_soft_hankel<T>(Handle*, T*, int64_t, int64_t, int64_t, T, T*);                \
     template int launch_unhankel_partial<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, \
                                             int64_t, double*, double*, int64_t);                      \
-    template int launch_unhankel_finish<T>(Handle*, const double*, const double*, int64_t, T*);
+    template int launch_unhankel_finish<T>(Handle*, const double*, const double*, int64_t, T*);        \
+    template int launch_soft_toward<T>(Handle*, T*, int64_t, int64_t, int64_t, const T*, T);
 INST(double)
 INST(float)
 #undef INST

@@ -1028,7 +1028,42 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     double cost = std::numeric_limits<double>::quiet_NaN();
     bool converged = false;
     void* meanws = nullptr;
-    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(M + N) * sizeof(T), &meanws));
+    // soft_hankel! (:214-216, :234-236).  On row shards the anti-diagonals run through several ranks' blocks (contiguous
+    // row blocks in rank order): every rank adds its block's sums and counts into full-length arrays at its row offset,
+    // one all-reduce, then the shrink towards the global means.
+    int64_t hk_row0 = 0;
+    const int64_t hk_len = ro.m_global + N - 1;
+    if (ro.hankel) TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)(hk_len + 1) * sizeof(T), &meanws));
+    if (ro.hankel && h->comm) {
+        void* sc;
+        TLSQ_TRY(ws_get(h, WS_HKSUM, (size_t)std::max<int64_t>(2 * hk_len, h->nranks) * 8, &sc));
+        double mine = (double)M;
+        std::vector<double> all((size_t)h->nranks);
+        TLSQ_HIP(h, hipMemcpyAsync(sc, &mine, 8, hipMemcpyHostToDevice, h->stream));
+        void* gat;
+        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)h->nranks * 8, &gat));
+        TLSQ_TRY(comm_allgather(h, (const double*)sc, (double*)gat, 1));
+        TLSQ_HIP(h, hipMemcpyAsync(all.data(), gat, (size_t)h->nranks * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        int64_t tot = 0;
+        for (int q = 0; q < h->nranks; ++q) {
+            if (q < h->rank) hk_row0 += (int64_t)all[(size_t)q];
+            tot += (int64_t)all[(size_t)q];
+        }
+        if (tot != ro.m_global)
+            return set_err(h, TLSQ_ERR_ARG, "rpca: the row blocks of the ranks add up to %lld rows, m_global says %lld",
+                           (long long)tot, (long long)ro.m_global);
+    }
+    auto soft_hankel = [&](T* P, T eps) -> int {
+        if (!h->comm) return launch_soft_hankel<T>(h, P, M, N, M, eps, (T*)meanws);
+        double* sum = (double*)h->ws[WS_HKSUM].p;
+        double* cnt = sum + hk_len;
+        TLSQ_HIP(h, hipMemsetAsync(sum, 0, (size_t)2 * hk_len * 8, h->stream));
+        TLSQ_TRY(launch_unhankel_partial<T>(h, P, M, N, 1, M, 1, M + N - 1, hk_row0, sum, cnt, hk_len));
+        TLSQ_TRY(comm_allreduce(h, sum, (size_t)2 * hk_len, ncclSum));
+        TLSQ_TRY(launch_unhankel_finish<T>(h, sum, cnt, hk_len, (T*)meanws));
+        return launch_soft_toward<T>(h, P, M, N, M, (const T*)meanws + hk_row0, eps);
+    };
 
     // (all phase marks only on request: tlsq_rpca_opts.phase_timing or TLSQ_PHASE_TIMING=1)
     static const bool env_phases = [] { const char* e = getenv("TLSQ_PHASE_TIMING"); return e && e[0] == '1'; }();
@@ -1289,7 +1324,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (!rebuilt) TLSQ_TRY(count_and_rebuild(!rebuild_marked));
         if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         }   // !(cb_svd && k >= 2)
-        if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, A, M, N, M, (T)thr, (T*)meanws));  // :214-216
+        if (ro.hankel) TLSQ_TRY(soft_hankel(A, (T)thr));  // :214-216
 
         // decision-only mode: ||R||_2 >= ||R||_F / sqrt(min(M,N)).  The fused sweep accumulates ||R||_F^2 on the
         // side; while that lower bound of the cost is clearly above tol the iteration cannot be the last one and
@@ -1532,7 +1567,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     }
     if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-    if (ro.hankel) TLSQ_TRY(launch_soft_hankel<T>(h, E, M, N, M, (T)(lam / mu), (T*)meanws));  // :234-236
+    if (ro.hankel) TLSQ_TRY(soft_hankel(E, (T)(lam / mu)));  // :234-236
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (info) {
         info->ms_loop = now_ms() - t_loop0;
