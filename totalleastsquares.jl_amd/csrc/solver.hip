@@ -769,7 +769,8 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
-    if (r <= 32 && !no_tsmm) {
+    static const int64_t tsmm_max = [] { const char* e = getenv("TLSQ_TSMM_MAXR"); return (int64_t)(e ? atoi(e) : 96); }();
+    if (r <= tsmm_max && r <= 96 && !no_tsmm) {
         TLSQ_TRY(tsmm_mixed(h, Z, Prec<T>::f32, ldZ, (const double*)Vg, N, (double*)T1, M, M, N, r));
     } else {
         TLSQ_TRY(gemm_mixed(h, true, false, Vg, 0, N, Z, Prec<T>::f32, ldZ, T1, 0, M, r, M, N, false));

@@ -40,7 +40,7 @@ __device__ __forceinline__ double ss_wsum(double v) {
 // ||y_j after projection|| / ||y_j before|| (tiny => numerically dependent column).
 template <bool IN_LDS>
 __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int N, int p,
-                                                     double* __restrict__ status) {
+                                                     double* __restrict__ status, int combine) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // IN_LDS: the whole panel lives in LDS.  Otherwise it stays in global memory (L2-resident, a single
     // workgroup reads back its own stores after a barrier) and LDS only holds the dot products.
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(SS_THREADS) void k_cgs2(double* __restrict__ Y, int
     if (IN_LDS) {
         for (int e = tid; e < N * p; e += SS_THREADS) Y[e] = sY[e];
     }
-    if (tid == 0) status[0] = minratio;
+    // (combine: a later block of a blocked orthonormalisation - keep the smallest ratio of all blocks)
+    if (tid == 0) status[0] = (combine && status[0] < minratio) ? status[0] : minratio;
 }
 
 // res[i] = || GX[:,i] - theta[i] * X[:,i] ||_2   (one wave per column)
@@ -811,10 +812,10 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
         const size_t lds = (size_t)(p * N + p + 16) * 8;
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_cgs2<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+        hipLaunchKernelGGL(k_cgs2<true>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev, 0);
     } else {
         const size_t lds = (size_t)(p + 16) * 8;
-        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev);
+        hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Y, (int)N, (int)p, status_dev, 0);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
@@ -833,7 +834,33 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
                 bool allow_cholqr, bool* used_cholqr, bool one_pass) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
     *used_cholqr = allow_cholqr && p <= 256 && !no_cholqr;
-    if (!*used_cholqr) return launch_cgs2(h, Y, N, p, status_dev);
+    if (!*used_cholqr) {
+        // Column-sequential CGS2 is one workgroup: 3.4 ms for a 4096 x 76 block (large-mode cold start).  Wide blocks of
+        // long vectors go block by block: 16 columns are projected twice against the finished ones (two multi-workgroup
+        // products per projection) and orthonormalised among themselves by the one-workgroup kernel, whose cost falls
+        // with the square of the block width.
+        static const bool no_blocked = [] { const char* e = getenv("TLSQ_NO_BLOCKED_CGS2"); return e && e[0] == '1'; }();
+        if (no_blocked || N < 2048 || p <= 32) return launch_cgs2(h, Y, N, p, status_dev);
+        constexpr int64_t GB = 16;
+        for (int64_t c0 = 0; c0 < p; c0 += GB) {
+            const int64_t pb = std::min<int64_t>(GB, p - c0);
+            double* Yb = Y + (size_t)c0 * N;
+            if (c0 > 0) {
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((c0 * pb + 3) / 4)), dim3(256), 0, h->stream,
+                                       (const double*)Y, (int)c0, (const double*)Yb, (int)pb, W, (int)N, (const double*)nullptr);
+                    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64),
+                                       (size_t)c0 * 8 * 8, h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb,
+                                       (int)N, (const double*)nullptr);
+                }
+            }
+            const size_t lds = (size_t)(pb + 16) * 8;
+            hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Yb, (int)N, (int)pb, status_dev,
+                               c0 > 0 ? 1 : 0);
+        }
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
     const dim3 rows((int)((N + 63) / 64));
     for (int64_t c0 = 0; c0 < p; c0 += CQ_PMAX) {
         const int64_t pb = std::min<int64_t>(CQ_PMAX, p - c0);
