@@ -33,8 +33,8 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
         void *P1, *P2, *part, *vst;
         TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
         TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
-        TLSQ_TRY(ws_get(h, WS_CPART, 2 * 2048 * 8, &part));
-        TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * 64) * 8, &vst));
+        TLSQ_TRY(ws_get(h, WS_CPART, (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * 8, &part));   // (norm partials: one per 32 x 32 block of the lower triangle)
+        TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * 1024) * 8, &vst));   // (same size as power_lower_bound asks for)
         const double* src = G;
         double* dst = (double*)P1;
         for (int k = 0; k < 5; ++k) {
@@ -294,7 +294,7 @@ static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out
     const int64_t N = st.cert_N;
     void *P1, *P2, *part;
     TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
-    TLSQ_TRY(ws_get(h, WS_CPART, 2048 * 8, &part));
+    TLSQ_TRY(ws_get(h, WS_CPART, (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * 8, &part));
     int nb = 0;
     TLSQ_TRY(gemm_mixed(h, true, true, st.cert_GD, 0, N, st.cert_GD, 0, N, P1, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
     if (levels >= 2) {
