@@ -97,6 +97,15 @@ def test_shrink_update_sweeps_bitexact(eng, torch_mod, dt, n, nonneg):
     assert np.array_equal(to_host(dA), A2)
 
 
+def test_hankel_keeps_integer_eltype(eng):
+    """test/runtests.jl:293-294: hankel(1:10, 3) of an integer range is an integer matrix in the reference."""
+    X = eng.hankel(np.arange(1, 11), 3)
+    assert X.dtype.kind == "i" and X.shape == (8, 3)
+    assert np.array_equal(X, np.array([[i + j for j in range(3)] for i in range(1, 9)]))
+    X2 = eng.hankel(np.arange(1, 21).reshape(10, 2, order="F").astype(np.int32), 2, 2)
+    assert X2.dtype == np.int32 and np.array_equal(X2, eng.hankel(np.arange(1, 21).reshape(10, 2, order="F").astype(float), 2, 2))
+
+
 def test_maxabs(eng, torch_mod):
     rng = np.random.default_rng(2)
     x = rng.standard_normal(1_000_003)

@@ -323,8 +323,14 @@ class Engine:
 
     # -- hankel family ----------------------------------------------------------------------------
     def hankel(self, x, L_, lag=1):
-        """src/robustPCA.jl:76-92 (float64/float32 on the GPU; other eltypes are converted to float64)."""
+        """src/robustPCA.jl:76-92.  float64 / float32 run on the GPU as they are; integer (and bool) series - the
+        reference's own test uses `hankel(1:10, 3)`, test/runtests.jl:293 - are embedded in float64 on the device and
+        converted back: the kernel only copies, so the result is exact for |x| < 2^53."""
         x = np.asarray(x)
+        if x.dtype.kind in "iub":
+            if x.size and np.abs(x.astype(np.float64)).max() >= 2.0 ** 53:
+                raise ValueError("hankel: integers beyond 2^53 do not survive the float64 embedding")
+            return np.rint(self.hankel(x.astype(np.float64), L_, lag)).astype(x.dtype)
         dt = np.float32 if x.dtype == np.float32 else np.float64
         x2 = _f(x.reshape(x.shape[0], -1), dt)
         Nx, Dch = x2.shape
