@@ -158,8 +158,10 @@ int tlsq_comm_destroy(tlsq_handle h);
  * is no dense eigensolver of that size in the loop); A, E, sv, the iteration count and the costs are the same as
  * always.  The returned U/S/Vt are complete up to min(M,N) = 4608 (TSQR + one-sided Jacobi once after the loop, a
  * few seconds, only when asked for); beyond that only the leading triplets (the sigma >= 1/mu ones plus the solver's
- * padding) are returned - the rest of S is NaN and the corresponding vectors are zero.  A rank beyond the largest
- * block (190 columns) is reported as TLSQ_ERR_UNSUPPORTED.  min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED. */
+ * padding) are returned - the rest of S is NaN and the corresponding vectors are zero.  The subspace block grows to
+ * 512 columns; an iteration it cannot serve (a rank beyond ~480, or a cold start on a high-rank problem) goes through
+ * the TSQR route up to min(M,N) = 4608 (about a second per decomposition) and is TLSQ_ERR_UNSUPPORTED beyond.
+ * min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED. */
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE,
                   double* U, int64_t ldU, double* S, double* Vt, int64_t ldVt,

@@ -128,3 +128,17 @@ def test_c5_full_size_properties(eng):
     assert np.linalg.norm((D[::3] - (A[::3] + E[::3])).astype(np.float64)) < math.sqrt(N) * tol * rep.d_norm
     assert relerr(A[::5].astype(np.float64), A0[::5].astype(np.float64)) < 1e-3
     assert np.mean((E[::11] != 0) == (S0[::11] != 0)) > 0.99
+
+
+def test_large_mode_rank_beyond_the_old_block_limit(eng):
+    """min(M, N) > 2048 with rank 250: the subspace block grows to 512 columns in large mode, and an iteration it cannot
+    serve (here the cold first one) goes through the TSQR route (up to 4608 columns) instead of failing."""
+    from oracle import rpca_oracle as O
+    M, N, r = 6000, 2304, 250
+    D, A0, S0 = O.synth_lowrank_sparse(M, N, r, seed=1)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+    assert rep.converged and sv == r
+    assert all(v == r for v in rep.svp_hist[3:])
+    assert rep.eig_fast >= rep.iters_done - 2            # the subspace solver serves the loop once the block fits
+    assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
+    assert relerr(A, A0) < 1e-6

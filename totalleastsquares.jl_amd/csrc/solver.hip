@@ -510,7 +510,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
         // Ritz values did not come out in descending order)
         static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
-        const bool mail = h->mailbox && !no_mailbox && p <= 256 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
+        const bool mail = h->mailbox && !no_mailbox && p <= 512 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
         if (mail) {
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
@@ -1287,7 +1287,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 sub.extra_steps = 0;
             }
         }
-        if (!fast_ok && large)
+        // Large mode has no cheap second solver.  Up to kReturnedSvdMaxN columns the TSQR route still applies (its block
+        // Jacobi then keeps 2-4 columns of R' per workgroup in LDS: seconds per decomposition - the price of a rank beyond
+        // the largest subspace block, but a result instead of an error); beyond that the call fails.
+        const bool large_dense_ok = large && N <= kReturnedSvdMaxN && !hook_now;
+        if (!fast_ok && large && !large_dense_ok)
             return set_err(h, TLSQ_ERR_UNSUPPORTED,
                            "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
                            "(block of %lld columns, reason %d): rank too large for this release",

@@ -804,6 +804,10 @@ int subspace_max_block(int64_t N) {
     // problem goes to the single-launch Jacobi up to 64 and to the block solver above
     // blocked orthonormalisation and the block Jacobi solver keep a step at ~2 ms up to ~190 columns - still far
     // below a dense N x N decomposition; small N: at most half of the columns
+    // large mode (N > 2048) has no dense solver to hand a high rank to (the TSQR route takes ~1 s per decomposition
+    // there): blocks of up to 512 columns - a step then costs tens of milliseconds (512 x 512 block Jacobi for the
+    // Rayleigh-Ritz problem), still two orders of magnitude below the alternative
+    if (N > 2048) return 512;
     return N >= 384 ? 192 : 96;
 }
 
@@ -822,7 +826,7 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 }
 
 // Y <- orth(Y) (N x p).  tmp: N x p panel, W: p x p, status: 3 doubles.
-// p <= 32: CholeskyQR2 on the whole panel.  32 < p <= 256: block classical Gram-Schmidt with re-orthogonalisation
+// p <= 32: CholeskyQR2 on the whole panel.  32 < p <= 512: block classical Gram-Schmidt with re-orthogonalisation
 // (BCGS2) over blocks of 32 columns - each block is projected twice against the finished ones (two small products
 // per projection) and then orthonormalised by CholeskyQR2 - a handful of launches per block instead of the
 // column-by-column CGS2 (4 us per column at N = 512, 90 us per column at N = 4096).
@@ -833,7 +837,7 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr, bool one_pass) {
     static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
-    *used_cholqr = allow_cholqr && p <= 256 && !no_cholqr;
+    *used_cholqr = allow_cholqr && p <= 512 && !no_cholqr;
     if (!*used_cholqr) {
         // Column-sequential CGS2 is one workgroup: 3.4 ms for a 4096 x 76 block (large-mode cold start).  Wide blocks of
         // long vectors go block by block: 16 columns are projected twice against the finished ones (two multi-workgroup
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
                                                      double* __restrict__ res, int N, int p,
                                                      const double* __restrict__ status, double* mailbox,
                                                      unsigned int* arrivals, double seq) {
-    __shared__ double sS[CQ_PMAX * 8];   // p <= 256
+    __shared__ double sS[CQ_PMAX * 16];   // p <= 512
     __shared__ double red[4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int k = tid; k < p; k += 256) sS[k] = S[k + (size_t)c * p];
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p, const double* status, double* mailbox_dev,
                        unsigned int* arrivals, double seq) {
-    if (p <= 256) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
+    if (p <= 512) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
         hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
                            (int)p, status, mailbox_dev, arrivals, seq);
         TLSQ_HIP(h, hipGetLastError());
