@@ -808,6 +808,8 @@ int subspace_max_block(int64_t N) {
     // there): blocks of up to 512 columns - a step then costs tens of milliseconds (512 x 512 block Jacobi for the
     // Rayleigh-Ritz problem), still two orders of magnitude below the alternative
     if (N > 2048) return 512;
+    // 1024..2048 columns: a dense decomposition costs 0.1-0.3 s there, a 512-column step ~30 ms
+    if (N >= 1024) return (int)std::min<int64_t>(512, N / 3);
     return N >= 384 ? 192 : 96;
 }
 
