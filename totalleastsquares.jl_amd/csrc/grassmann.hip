@@ -21,9 +21,11 @@
 // one workgroup, k_ga_solo, with no host round trip at all.
 //
 // The robust averages need order statistics of every row of U (trimmed mean: once per component, the ordering of
-// U[j,:] does not depend on w; median: every iteration, ordering of w .* U[j,:]).  Those go through a segmented
-// radix sort (hipcub::DeviceSegmentedRadixSort, stable, like sortperm) of the row-major transposed keys.
-#include <hipcub/hipcub.hpp>
+// U[j,:] does not depend on w; median: every iteration, ordering of w .* U[j,:]).  Not a sort: what the reference takes
+// from `sortperm` is the element at one rank (median, :357) or the set of elements between two ranks (trimmed mean,
+// :329-332), so every row runs a most-significant-digit radix SELECT on the composite key (value in `isless` order,
+// column index) - distinct for every element, hence the ranks of a stable sort exactly: twelve histogram passes over
+// the row-major transposed keys (eight value bytes, four index bytes), both ranks of a trimmed mean in the same passes.
 
 #include "internal.hpp"
 
@@ -439,42 +441,138 @@ __global__ __launch_bounds__(256) void k_ga_start(const double* __restrict__ q0,
 }
 
 // ---- order statistics of the rows ------------------------------------------------------------------------------
-// keys[j*N + n] = (w ? w[n] : 1) * U[j, n],  idx[j*N + n] = n     (row-major transposed: a row is one sort segment)
+// keys[j*N + n] = (w ? w[n] : 1) * U[j, n]     (row-major transposed: a row is one selection segment)
 __global__ __launch_bounds__(256) void k_ga_keys(const double* __restrict__ U, const double* __restrict__ w, int d,
-                                                 int64_t N, double* __restrict__ keys, int* __restrict__ idx,
-                                                 const GaState* __restrict__ st) {
+                                                 int64_t N, double* __restrict__ keys, const GaState* __restrict__ st) {
     if (st && st->converged) return;
     const int64_t total = (int64_t)d * N, stride = (int64_t)gridDim.x * 256;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
         const int64_t j = e / N, n = e - j * N;
         const double u = U[n * d + j];
         keys[e] = w ? w[n] * u : u;                                // :356  (w) .* U[j,:]
-        idx[e] = (int)n;
     }
 }
-// mask[j + n*d] = 1 for the columns whose rank within row j lies in [lo, hi)                      (:329,:332)
-__global__ __launch_bounds__(256) void k_ga_mask(const int* __restrict__ idx_sorted, int d, int64_t N, int64_t lo,
-                                                 int64_t hi, uint8_t* __restrict__ mask) {
-    const int64_t span = hi - lo, total = (int64_t)d * span, stride = (int64_t)gridDim.x * 256;
+
+// value -> unsigned integer with the order of Julia's isless (-0.0 < 0.0, every NaN after +Inf and equal to each other)
+__device__ __forceinline__ unsigned long long ga_sortable(double x) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    if (x != x) u = 0x7FF8000000000000ull;
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// selection state of one (row, target): the bytes of the composite key fixed so far and the rank still to be found among
+// the elements that match them
+struct GaSel {
+    unsigned long long pkey;   // value bytes fixed so far (high bytes; the rest zero)
+    unsigned long long k;      // rank among the candidates
+    unsigned int pidx;         // index bytes fixed so far
+    unsigned int pad;
+};
+
+// pass p = 0..7: byte 7 - p of the value; pass 8..11: byte 11 - p of the column index among the elements whose value
+// equals the selected one.  hist[(row * NT + t) * 256 + digit] += 1 for every candidate of target t.
+template <int NT>
+__global__ __launch_bounds__(256) void k_ga_sel_hist(const double* __restrict__ keys, int64_t N, const GaSel* __restrict__ sel,
+                                                     unsigned int* __restrict__ hist, int pass,
+                                                     const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    __shared__ unsigned int sh[NT * 256];
+    const int row = blockIdx.y;
+    for (int i = threadIdx.x; i < NT * 256; i += 256) sh[i] = 0;
+    __syncthreads();
+    GaSel my[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) my[t] = sel[row * NT + t];
+    const double* __restrict__ kr = keys + (int64_t)row * N;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += stride) {
+        const unsigned long long u = ga_sortable(kr[n]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (pass < 8) {
+                const int sh_hi = 8 * (8 - pass);   // bits above the current byte
+                const bool cand = pass == 0 || (u >> sh_hi) == (my[t].pkey >> sh_hi);
+                if (cand) atomicAdd(&sh[t * 256 + (int)((u >> (8 * (7 - pass))) & 255ull)], 1u);
+            } else if (u == my[t].pkey) {
+                const unsigned int i32 = (unsigned int)n;
+                const int q = pass - 8, sh_hi = 8 * (4 - q);
+                const bool cand = q == 0 || (i32 >> sh_hi) == (my[t].pidx >> sh_hi);
+                if (cand) atomicAdd(&sh[t * 256 + (int)((i32 >> (8 * (3 - q))) & 255u)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * 256; i += 256)
+        if (sh[i]) atomicAdd(&hist[(size_t)row * NT * 256 + i], sh[i]);
+}
+
+// one workgroup per (row, target): the bin that holds rank k, fixed into the state; the histogram is cleared for the
+// next pass
+__global__ __launch_bounds__(256) void k_ga_sel_pick(unsigned int* __restrict__ hist, GaSel* __restrict__ sel, int pass,
+                                                     const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    __shared__ unsigned long long cum[256];
+    const int rt = blockIdx.x, t = threadIdx.x;
+    unsigned int* hh = hist + (size_t)rt * 256;
+    const unsigned int mine = hh[t];
+    cum[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // inclusive scan
+        const unsigned long long v = t >= off ? cum[t - off] : 0ull;
+        __syncthreads();
+        cum[t] += v;
+        __syncthreads();
+    }
+    const unsigned long long k = sel[rt].k;
+    const unsigned long long before = cum[t] - mine;
+    if (mine > 0 && before <= k && k < cum[t]) {   // exactly one thread
+        GaSel sn = sel[rt];
+        sn.k = k - before;
+        if (pass < 8) sn.pkey |= (unsigned long long)t << (8 * (7 - pass));
+        else sn.pidx |= (unsigned int)t << (8 * (11 - pass));
+        sel[rt] = sn;
+    }
+    hh[t] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ga_sel_init(GaSel* __restrict__ sel, int n, int nt, unsigned long long k0,
+                                                     unsigned long long k1, const GaState* __restrict__ st) {
+    if (st && st->converged) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        GaSel s0;
+        s0.pkey = 0ull;
+        s0.pidx = 0u;
+        s0.pad = 0u;
+        s0.k = (i % nt) == 0 ? k0 : k1;
+        sel[i] = s0;
+    }
+}
+
+// mask[j + n*d] = 1 for the columns whose stable rank within row j lies in [lo, hi): composite (value, column) at or
+// after the element of rank lo (sel[2j]) and before the element of rank hi (sel[2j+1]; no upper limit when hi == N)
+__global__ __launch_bounds__(256) void k_ga_mask(const double* __restrict__ keys, const GaSel* __restrict__ sel, int d,
+                                                 int64_t N, int has_hi, uint8_t* __restrict__ mask) {
+    const int64_t total = (int64_t)d * N, stride = (int64_t)gridDim.x * 256;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
-        const int64_t j = e / span, p = lo + (e - j * span);
-        mask[(int64_t)idx_sorted[j * N + p] * d + j] = 1;
+        const int64_t j = e / N, n = e - j * N;
+        const unsigned long long u = ga_sortable(keys[e]);
+        const GaSel a = sel[2 * j], b = sel[2 * j + 1];
+        const bool ge_lo = u > a.pkey || (u == a.pkey && (unsigned int)n >= a.pidx);
+        const bool lt_hi = !has_hi || u < b.pkey || (u == b.pkey && (unsigned int)n < b.pidx);
+        mask[n * d + j] = (ge_lo && lt_hi) ? 1 : 0;
     }
 }
 // s[j] = sign(w[m]) * U[j, m],  m = the column at sorted position N/2 (1-based) of row j            (:357-358)
-__global__ __launch_bounds__(256) void k_ga_pick(const int* __restrict__ idx_sorted, const double* __restrict__ w,
+__global__ __launch_bounds__(256) void k_ga_pick(const GaSel* __restrict__ sel, const double* __restrict__ w,
                                                  const double* __restrict__ U, int d, int64_t N,
                                                  double* __restrict__ sbuf, const GaState* __restrict__ st) {
     if (st && st->converged) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < d) {
-        const int64_t m = idx_sorted[(int64_t)j * N + (N / 2 - 1)];
+        const int64_t m = (int64_t)sel[j].pidx;
         sbuf[j] = ga_sign(w[m]) * U[m * d + j];
     }
-}
-__global__ __launch_bounds__(256) void k_ga_offsets(int* __restrict__ offs, int d, int64_t N) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j <= d) offs[j] = (int)((int64_t)j * N);
 }
 
 // ---- small problems: the whole of rpca_ga in ONE workgroup ------------------------------------------------------
@@ -725,10 +823,9 @@ struct GaBuffers {
     double* partial = nullptr;
     int pstride = 0, nblk = 0;
     uint8_t* mask = nullptr;
-    double *keys_in = nullptr, *keys_out = nullptr;
-    int *idx_in = nullptr, *idx_out = nullptr, *offs = nullptr;
-    void* cub_tmp = nullptr;
-    size_t cub_bytes = 0;
+    double* keys_in = nullptr;
+    GaSel* sel = nullptr;            // selection state, d x (1 or 2) targets
+    unsigned int* sel_hist = nullptr;   // d x targets x 256 counters (kept zero between passes)
 };
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -769,46 +866,49 @@ int ga_alloc(Handle* h, int64_t d, int64_t N, int mode, int64_t hist_cap, bool n
     TLSQ_TRY(ws_get(h, WS_GA_PART, (size_t)b->nblk * b->pstride * 8, &p));
     b->partial = (double*)p;
     if (mode != TLSQ_GA_MEAN) {
-        if ((int64_t)d * N >= (int64_t)1 << 31)
-            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages need d*N < 2^31");
+        if (N >= (int64_t)1 << 32)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages need N < 2^32 columns");
         if (mode == TLSQ_GA_TRIMMED_MEAN) {
             TLSQ_TRY(ws_get(h, WS_GA_MASK, (size_t)d * N, &p));
             b->mask = (uint8_t*)p;
         }
-        TLSQ_TRY(ws_get(h, WS_GA_KEYS, 2 * pn, &p));
+        TLSQ_TRY(ws_get(h, WS_GA_KEYS, pn, &p));
         b->keys_in = (double*)p;
-        b->keys_out = b->keys_in + (size_t)d * N;
-        const size_t ib = align256((size_t)d * N * 4);
-        TLSQ_TRY(ws_get(h, WS_GA_IDX, 2 * ib + align256((size_t)(d + 1) * 4), &p));
-        b->idx_in = (int*)p;
-        b->idx_out = (int*)((char*)p + ib);
-        b->offs = (int*)((char*)p + 2 * ib);
-        hipLaunchKernelGGL(k_ga_offsets, dim3((int)((d + 1 + 255) / 256)), dim3(256), 0, h->stream, b->offs, (int)d, N);
-        TLSQ_HIP(h, hipGetLastError());
-        size_t tb = 0;
-        TLSQ_HIP(h, hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, b->keys_in, b->keys_out, b->idx_in,
-                                                                 b->idx_out, (int)(d * N), (int)d, b->offs,
-                                                                 b->offs + 1, 0, 64, h->stream));
-        b->cub_bytes = tb;
-        TLSQ_TRY(ws_get(h, WS_GA_TMP, tb ? tb : 256, &p));
-        b->cub_tmp = p;
+        const size_t sb = align256((size_t)d * 2 * sizeof(GaSel));
+        TLSQ_TRY(ws_get(h, WS_GA_IDX, sb + (size_t)d * 2 * 256 * 4, &p));
+        b->sel = (GaSel*)p;
+        b->sel_hist = (unsigned int*)((char*)p + sb);
+        TLSQ_HIP(h, hipMemsetAsync(b->sel_hist, 0, (size_t)d * 2 * 256 * 4, h->stream));
     }
     return TLSQ_OK;
 }
 
-// stable ascending sort of every row of the key matrix (keys_in/idx_in -> keys_out/idx_out): sortperm (:332,:356)
-int ga_sort_rows(Handle* h, GaBuffers* b, int64_t d, int64_t N) {
-    size_t tb = b->cub_bytes;
-    TLSQ_HIP(h, hipcub::DeviceSegmentedRadixSort::SortPairs(b->cub_tmp, tb, b->keys_in, b->keys_out, b->idx_in,
-                                                             b->idx_out, (int)(d * N), (int)d, b->offs, b->offs + 1,
-                                                             0, 64, h->stream));
+// The elements of stable rank r0 (and r1 when nt == 2) of every row of the key matrix, as composite keys in b->sel:
+// twelve histogram + pick passes (see the head of the file).  Ranks are 0-based and < N.
+int ga_select_rows(Handle* h, GaBuffers* b, int64_t d, int64_t N, int nt, int64_t r0, int64_t r1, const GaState* st) {
+    hipLaunchKernelGGL(k_ga_sel_init, dim3((int)((d * nt + 255) / 256)), dim3(256), 0, h->stream, b->sel, (int)(d * nt), nt,
+                       (unsigned long long)r0, (unsigned long long)r1, st);
+    int64_t gx = (N + 256 * 16 - 1) / (256 * 16);   // >= 16 elements per thread
+    if (gx < 1) gx = 1;
+    const int64_t cap = std::max<int64_t>(1, 4096 / std::max<int64_t>(d, 1));
+    if (gx > cap) gx = cap;                           // ~4096 workgroups over all rows
+    for (int pass = 0; pass < 12; ++pass) {
+        if (nt == 2)
+            hipLaunchKernelGGL(k_ga_sel_hist<2>, dim3((unsigned)gx, (unsigned)d), dim3(256), 0, h->stream, b->keys_in, N, b->sel,
+                               b->sel_hist, pass, st);
+        else
+            hipLaunchKernelGGL(k_ga_sel_hist<1>, dim3((unsigned)gx, (unsigned)d), dim3(256), 0, h->stream, b->keys_in, N, b->sel,
+                               b->sel_hist, pass, st);
+        hipLaunchKernelGGL(k_ga_sel_pick, dim3((unsigned)(d * nt)), dim3(256), 0, h->stream, b->sel_hist, b->sel, pass, st);
+    }
+    TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
 
 int ga_keys(Handle* h, GaBuffers* b, const double* w, int64_t d, int64_t N, const GaState* st) {
     int64_t g = ((int64_t)d * N + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_ga_keys, dim3((int)g), dim3(256), 0, h->stream, b->U, w, (int)d, N, b->keys_in, b->idx_in, st);
+    hipLaunchKernelGGL(k_ga_keys, dim3((int)g), dim3(256), 0, h->stream, b->U, w, (int)d, N, b->keys_in, st);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -816,13 +916,17 @@ int ga_keys(Handle* h, GaBuffers* b, const double* w, int64_t d, int64_t N, cons
 // trimmed mean: mark the entries of U whose rank inside their row lies in `range` (:329); U is fixed per component
 int ga_build_mask(Handle* h, GaBuffers* b, int64_t d, int64_t N, double P) {
     const int64_t lo = (int64_t)std::floor(P * (double)N), hi = (int64_t)std::floor((1.0 - P) * (double)N);
-    TLSQ_HIP(h, hipMemsetAsync(b->mask, 0, (size_t)d * N, h->stream));
-    if (hi <= lo) return TLSQ_OK;
+    if (hi <= lo) {
+        TLSQ_HIP(h, hipMemsetAsync(b->mask, 0, (size_t)d * N, h->stream));
+        return TLSQ_OK;
+    }
     TLSQ_TRY(ga_keys(h, b, nullptr, d, N, nullptr));
-    TLSQ_TRY(ga_sort_rows(h, b, d, N));
-    int64_t g = (d * (hi - lo) + 255) / 256;
+    const int has_hi = hi < N ? 1 : 0;
+    TLSQ_TRY(ga_select_rows(h, b, d, N, 2, lo, has_hi ? hi : lo, nullptr));
+    int64_t g = (d * N + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_ga_mask, dim3((int)g), dim3(256), 0, h->stream, b->idx_out, (int)d, N, lo, hi, b->mask);
+    hipLaunchKernelGGL(k_ga_mask, dim3((int)g), dim3(256), 0, h->stream, (const double*)b->keys_in, (const GaSel*)b->sel, (int)d,
+                       N, has_hi, b->mask);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -839,9 +943,9 @@ int ga_sums(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, const doubl
             w = b->w;
         }
         TLSQ_TRY(ga_keys(h, b, w, d, N, st));
-        TLSQ_TRY(ga_sort_rows(h, b, d, N));
-        hipLaunchKernelGGL(k_ga_pick, dim3((int)((d + 255) / 256)), dim3(256), 0, h->stream, b->idx_out, w, b->U, (int)d,
-                           N, b->sbuf, st);
+        TLSQ_TRY(ga_select_rows(h, b, d, N, 1, N / 2 - 1, 0, st));
+        hipLaunchKernelGGL(k_ga_pick, dim3((int)((d + 255) / 256)), dim3(256), 0, h->stream, (const GaSel*)b->sel, w, b->U,
+                           (int)d, N, b->sbuf, st);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
