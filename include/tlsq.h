@@ -225,10 +225,16 @@ int tlsq_rtls_f32(tlsq_handle h, const float* A, int64_t M, int64_t n, int64_t l
  * D, A, E are interleaved (re, im) complex M x N matrices, column-major, leading dimensions in complex elements;
  * S (optional) receives the min(M,N) singular values of the last Z.  Spectral steps run on the realified
  * 2M x 2N panel with the real path's kernels (full decompositions, N <= 1024).  nonnegA / nonnegE / hankel (no
- * complex method in the reference either), hook modes and row sharding: TLSQ_ERR_UNSUPPORTED.  The singular
- * vectors of `s` are not returned in this release. */
+ * complex method in the reference either), hook modes and row sharding: TLSQ_ERR_UNSUPPORTED. */
 int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
                   double* A, int64_t ldA, double* E, int64_t ldE, double* S, int64_t* sv, tlsq_rpca_info* info);
+/* ... with the singular vectors of the returned `s` (src/robustPCA.jl:194,238): U (M x d complex, ldU), Vt = V' (d x N
+ * complex, ldVt), d = min(M,N), interleaved like D; each may be NULL.  One more complete decomposition of the realified
+ * last Z after the loop (TSQR route when M >= N); vectors are unique up to a phase per singular value (an orthonormal
+ * basis per cluster of equal singular values); left vectors of zero singular values are returned as zero columns. */
+int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      double* A, int64_t ldA, double* E, int64_t ldE, double* U, int64_t ldU, double* S, double* Vt,
+                      int64_t ldVt, int64_t* sv, tlsq_rpca_info* info);
 
 /* ---- batched tiny problems ---------------------------------------------------------
  * The reference's typical use is a loop over thousands of independent small problems

@@ -465,6 +465,18 @@ def test_rpca_complex_vs_oracle_and_reference_thresholds(eng):        # test/run
     assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
     np.testing.assert_allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(s.S[:sv], so[1][:sv], rtol=1e-9)
+    # the returned s = svd(last Z) with its vectors (:194, :238): all of S, orthonormal U and V, and the same matrix
+    # U S Vt as the oracle's factors (the vectors themselves are only unique up to a phase)
+    def check_s(s, so, tag=""):
+        U, S, Vt = np.asarray(s.U), np.asarray(s.S), np.asarray(s.Vt)
+        d = S.size
+        np.testing.assert_allclose(S, so[1], rtol=1e-9, atol=64 * 2.2e-16 * np.sqrt(2 * d) * so[1][0], err_msg=tag)
+        assert np.allclose(Vt @ Vt.conj().T, np.eye(d), atol=1e-10), tag
+        live = S > 1e-10 * S[0]
+        assert np.allclose((U.conj().T @ U)[np.ix_(live, live)], np.eye(int(live.sum())), atol=1e-9), tag
+        Zo = (so[0] * so[1]) @ so[2]
+        assert relerr((U * S) @ Vt, Zo) < 1e-9, tag
+    check_s(s, so, "100x20")
     # a larger one (Cholesky-route eigensolver on the 2N x 2N realified Gram), rank 3, nukeA = false too
     M, N, r = 400, 48, 3
     D = crandn(M, r) @ crandn(r, N) + crandn(M, N) * 10 * (rng.random((M, N)) < 0.05)
@@ -473,6 +485,14 @@ def test_rpca_complex_vs_oracle_and_reference_thresholds(eng):        # test/run
         Ao, Eo, so, svo, io = O.rpca(D, **kw)
         assert (rep.iters_done, sv, rep.svp_hist) == (io.iters_done, svo, io.svp_hist), kw
         assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8, kw
+        check_s(s, so, str(kw))
+    # wide (M < N: Gram route for the vectors) and a matrix with a repeated singular value (cluster of two)
+    Dw = crandn(30, 3) @ crandn(3, 80) + crandn(30, 80) * 10 * (rng.random((30, 80)) < 0.05)
+    A, E, s, sv, rep = eng.rpca(Dw, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(Dw)
+    assert rep.iters_done == io.iters_done and relerr(A, Ao) < 1e-8
+    U, S, Vt = np.asarray(s.U), np.asarray(s.S), np.asarray(s.Vt)
+    assert relerr((U * S) @ Vt, (so[0] * so[1]) @ so[2]) < 1e-7 and np.allclose(Vt @ Vt.conj().T, np.eye(30), atol=1e-8)
 
 
 def test_rpca_unsupported_paths_fail_loudly(eng):

@@ -429,7 +429,15 @@ int tlsq_rtls_f32(tlsq_handle h, const float* A, int64_t M, int64_t n, int64_t l
 // ---- ComplexF64 rpca ---------------------------------------------------------------------------------------
 int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
                   double* A, int64_t ldA, double* E, int64_t ldE, double* S, int64_t* sv, tlsq_rpca_info* info) {
+    return tlsq_rpca_c64_svd(h, D, M, N, ldD, opts, A, ldA, E, ldE, nullptr, 0, S, nullptr, 0, sv, info);
+}
+
+int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      double* A, int64_t ldA, double* E, int64_t ldE, double* U, int64_t ldU, double* S, double* Vt,
+                      int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
     TLSQ_TRY(check_handle(h));
+    if ((U && ldU < M) || (Vt && ldVt < std::min(M, N)))
+        return set_err(h, TLSQ_ERR_ARG, "rpca_c64: ldU < M or ldVt < min(M,N)");
     if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
         return set_err(h, TLSQ_ERR_ARG, "rpca_c64: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
     if (opts && (opts->nonnegA || opts->nonnegE || opts->hankel))
@@ -466,11 +474,20 @@ int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t 
     }
     const int64_t d = std::min(M, N);
     std::vector<double> hS((size_t)(S ? d : 0));
-    const int status = rpca_core_complex(h, dD, M, N, ro, opts, dA, dE, S ? hS.data() : nullptr, sv, info);
+    std::vector<double> hVt((size_t)(Vt ? 2 * d * N : 0));
+    double* dU = nullptr;
+    if (U) {
+        TLSQ_TRY(ws_get(h, WS_UT, (size_t)M * d * 16, &p));
+        dU = (double*)p;
+    }
+    const int status = rpca_core_complex(h, dD, M, N, ro, opts, dA, dE, S ? hS.data() : nullptr, sv, info, dU,
+                                         Vt ? hVt.data() : nullptr, d);
     if (status < 0) return status;
     const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, 16, back));
     if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, 16, back));
+    if (U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, 16, back));
+    if (Vt) TLSQ_TRY(copy2d(h, Vt, ldVt, hVt.data(), d, d, N, 16, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
     if (S) TLSQ_HIP(h, hipMemcpyAsync(S, hS.data(), (size_t)d * 8, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
                                       h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));

@@ -303,6 +303,7 @@ int launch_cupdate(Handle* h, const double* D, const double* A, const double* E,
 int launch_cdiv(Handle* h, const double* D, double* Y, int64_t n, double s);
 int launch_realify(Handle* h, const double* Z, int64_t M, int64_t N, double* W);
 int launch_unrealify(Handle* h, const double* AR, int64_t M, int64_t N, double* A);
+int launch_pack_complex(Handle* h, const double* T, int64_t M, int64_t d, double* U);
 int launch_cmaxabs(Handle* h, const double* x, int64_t n, double* host_out);
 // batched.hip: one workgroup per tiny rpca problem
 size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds);

@@ -141,6 +141,21 @@ int launch_unrealify(Handle* h, const double* AR, int64_t M, int64_t N, double* 
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
+// U[m, i] = T[m, i] + i T[M + m, i]: the complex left vectors from the product of the realified panel with the real images
+// [Re v; Im v] / sigma of the right vectors (T is 2M x d real, ld 2M; U complex M x d, ld M, interleaved)
+__global__ __launch_bounds__(256) void k_pack_complex(const double* __restrict__ T, int64_t M, int64_t d, double2* __restrict__ U) {
+    const int64_t total = M * d, stride = (int64_t)gridDim.x * 256;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const int64_t m = e % M, i = e / M;
+        U[e] = double2{T[m + i * 2 * M], T[M + m + i * 2 * M]};
+    }
+}
+int launch_pack_complex(Handle* h, const double* T, int64_t M, int64_t d, double* U) {
+    if (M <= 0 || d <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL(k_pack_complex, dim3(cgrid(M * d)), dim3(256), 0, h->stream, T, M, d, (double2*)U);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
 int launch_cmaxabs(Handle* h, const double* x, int64_t n, double* host_out) {
     void* slot;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));

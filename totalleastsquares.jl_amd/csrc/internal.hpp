@@ -187,7 +187,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
               T* E, T* U_dev, double* S_host, double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info);
 int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
                       const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
-                      tlsq_rpca_info* info);
+                      tlsq_rpca_info* info,
+                      double* U_dev = nullptr, double* Vt_host = nullptr, int64_t ldVt = 0);
 // staging of caller memory (host or device, any leading dimension) around rpca_core; wide problems are transposed
 template <typename T>
 int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts, T* A,

@@ -1688,7 +1688,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
 // ------------------------------------------------------------------------------------------------
 int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
                              const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
-                             tlsq_rpca_info* info) {
+                             tlsq_rpca_info* info, double* U_dev, double* Vt_host, int64_t ldVt) {
     const int64_t n = M * N, M2 = 2 * M, N2 = 2 * N;
     const int64_t d = std::min(M, N);
     void *Yv, *Zv, *Rv, *Wv, *ARv;
@@ -1788,6 +1788,122 @@ int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const Re
         info->eig_full = n_full;
     }
     if (sv_out) *sv_out = sv;
+    if ((U_dev || Vt_host) && !sig_pairs.empty()) {
+        // The singular vectors of `s` (SVD of the last Z, :194, :238).  The realified panel W = [Re -Im; Im Re] has every
+        // singular value of Z twice; [x; y] is a right singular vector of W exactly when x + i y is one of Z, and the two
+        // real vectors of a pair span {w, J w}, i.e. the same complex vector up to a phase.  So: one more complete and
+        // accurate real decomposition - the TSQR route on the tall one of W and W' (W' is the embedding of Z^H) - gives
+        // the vectors of the short side; per cluster of equal singular values a complex Gram-Schmidt over the images of
+        // its real vectors keeps one complex vector per singular value; the long side follows from one product,
+        // u = Z v / sigma or v = Z^H u / sigma.
+        const bool tall = M >= N;
+        const int64_t np_ = tall ? N : M, no_ = tall ? M : N;   // lengths of the primary / the other side's vectors
+        const int64_t P2 = 2 * np_, O2 = 2 * no_;
+        double* Pm = W;   // the tall real panel (O2 x P2, ld O2)
+        TLSQ_TRY(launch_realify(h, Z, M, N, W));
+        if (!tall) {
+            TLSQ_TRY(launch_transpose<double>(h, W, M2, M2, N2, AR, N2));   // AR <- W' (N2 x M2)
+            Pm = AR;
+        }
+        TLSQ_TRY(svd_via_r<double>(h, Pm, O2, P2, O2, &V, s, &sweeps));
+        for (int64_t i = 0; i < d; ++i) {
+            const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
+            sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
+        }
+        std::vector<double> hv((size_t)P2 * P2);
+        TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, hv.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        std::vector<double> vr((size_t)np_ * d), vi((size_t)np_ * d);   // complex primary vectors, column i
+        const double ctol = 1e-9 * sig_pairs[0];
+        int64_t i0 = 0;
+        while (i0 < d) {
+            int64_t i1 = i0;
+            while (i1 + 1 < d && sig_pairs[i1] - sig_pairs[i1 + 1] <= ctol) ++i1;
+            const int64_t m = i1 - i0 + 1;
+            int64_t got = 0;
+            for (int64_t t = 2 * i0; t <= 2 * i1 + 1 && got < m; ++t) {
+                const double* w = hv.data() + (size_t)s.order[t] * P2;
+                double* xr = vr.data() + (size_t)(i0 + got) * np_;
+                double* xi = vi.data() + (size_t)(i0 + got) * np_;
+                for (int64_t j = 0; j < np_; ++j) {
+                    xr[j] = w[j];
+                    xi[j] = w[np_ + j];
+                }
+                for (int rep = 0; rep < 2; ++rep)       // twice is enough
+                    for (int64_t q = 0; q < got; ++q) {
+                        const double* qr = vr.data() + (size_t)(i0 + q) * np_;
+                        const double* qi = vi.data() + (size_t)(i0 + q) * np_;
+                        double pr = 0.0, pi = 0.0;      // <q, x> = q^H x
+                        for (int64_t j = 0; j < np_; ++j) {
+                            pr += qr[j] * xr[j] + qi[j] * xi[j];
+                            pi += qr[j] * xi[j] - qi[j] * xr[j];
+                        }
+                        for (int64_t j = 0; j < np_; ++j) {
+                            xr[j] -= pr * qr[j] - pi * qi[j];
+                            xi[j] -= pr * qi[j] + pi * qr[j];
+                        }
+                    }
+                double nn = 0.0;
+                for (int64_t j = 0; j < np_; ++j) nn += xr[j] * xr[j] + xi[j] * xi[j];
+                if (nn > 0.25) {   // (a dependent image - J w of an accepted w - leaves ~0)
+                    const double inv = 1.0 / std::sqrt(nn);
+                    for (int64_t j = 0; j < np_; ++j) {
+                        xr[j] *= inv;
+                        xi[j] *= inv;
+                    }
+                    ++got;
+                }
+            }
+            for (int64_t q = got; q < m; ++q)   // (never seen: the TSQR route returns complete orthogonal factors)
+                for (int64_t j = 0; j < np_; ++j) vr[(size_t)(i0 + q) * np_ + j] = vi[(size_t)(i0 + q) * np_ + j] = 0.0;
+            i0 = i1 + 1;
+        }
+        // the other side: T (O2 x d) = Pm [Re p; Im p] / sigma  ->  complex vectors T[0:no] + i T[no:2no]
+        std::vector<double> rv((size_t)P2 * d, 0.0);
+        const double floor_s = (double)P2 * 2.220446049250313e-16 * sig_pairs[0];
+        for (int64_t i = 0; i < d; ++i) {
+            if (!(sig_pairs[i] > floor_s)) continue;   // (zero column, like the real path)
+            const double inv = 1.0 / sig_pairs[i];
+            for (int64_t j = 0; j < np_; ++j) {
+                rv[(size_t)i * P2 + j] = vr[(size_t)i * np_ + j] * inv;
+                rv[(size_t)i * P2 + np_ + j] = vi[(size_t)i * np_ + j] * inv;
+            }
+        }
+        void *Rd, *Td;
+        TLSQ_TRY(ws_get(h, WS_VG, (size_t)P2 * d * 8, &Rd));
+        TLSQ_TRY(ws_get(h, WS_T, (size_t)O2 * d * 8, &Td));
+        TLSQ_HIP(h, hipMemcpyAsync(Rd, rv.data(), rv.size() * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(gemm_mixed(h, true, false, Rd, 0, P2, Pm, 0, O2, Td, 0, O2, d, O2, P2, false));
+        std::vector<double> ht;   // the other side's vectors on the host when they are the right ones (wide Z)
+        if (!tall) {
+            ht.resize((size_t)O2 * d);
+            TLSQ_HIP(h, hipMemcpyAsync(ht.data(), Td, ht.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        if (Vt_host) {   // Vt = V^H: row i = conj(v_i)
+            for (int64_t i = 0; i < d; ++i)
+                for (int64_t j = 0; j < N; ++j) {
+                    const double re = tall ? vr[(size_t)i * N + j] : ht[(size_t)i * O2 + j];
+                    const double im = tall ? vi[(size_t)i * N + j] : ht[(size_t)i * O2 + N + j];
+                    Vt_host[2 * (i + j * ldVt)] = re;
+                    Vt_host[2 * (i + j * ldVt) + 1] = -im;
+                }
+        }
+        if (U_dev) {
+            if (tall) {
+                TLSQ_TRY(launch_pack_complex(h, (const double*)Td, M, d, U_dev));
+            } else {
+                std::vector<double> hu((size_t)2 * M * d);
+                for (int64_t i = 0; i < d; ++i)
+                    for (int64_t j = 0; j < M; ++j) {
+                        hu[2 * ((size_t)i * M + j)] = vr[(size_t)i * M + j];
+                        hu[2 * ((size_t)i * M + j) + 1] = vi[(size_t)i * M + j];
+                    }
+                TLSQ_HIP(h, hipMemcpyAsync(U_dev, hu.data(), hu.size() * 8, hipMemcpyHostToDevice, h->stream));
+            }
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+    }
     if (S_host)
         for (int64_t i = 0; i < d; ++i) S_host[i] = i < (int64_t)sig_pairs.size() ? sig_pairs[i] : 0.0;
     return converged ? TLSQ_OK : TLSQ_MAXITER;                                // :232

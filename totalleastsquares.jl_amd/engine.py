@@ -283,12 +283,15 @@ class Engine:
 
     def _rpca_complex(self, D, *, lam, maxrank, iters, tol, rho, verbose, nonnegA, nonnegE, hankel, nukeA,
                       return_report):
-        """ComplexF64 data (src/robustPCA.jl:3-7): `s` carries the singular values only (U, Vt are None)."""
+        """ComplexF64 data (src/robustPCA.jl:3-7); `s` = (U, S, Vt) of the last Z like the real path (:194, :238)."""
         Df = np.asfortranarray(D, dtype=np.complex128)
         M, N = Df.shape
+        d = min(M, N)
         A = np.empty((M, N), dtype=np.complex128, order="F")
         E = np.empty((M, N), dtype=np.complex128, order="F")
-        S = np.empty(min(M, N))
+        S = np.empty(d)
+        U = np.empty((M, d), dtype=np.complex128, order="F")
+        Vt = np.empty((d, N), dtype=np.complex128, order="F")
         cb = None
         if verbose:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
@@ -296,12 +299,12 @@ class Engine:
                            hankel=hankel, nukeA=nukeA, on_iter=cb)
         info, cost, svp = self._info(int(iters))
         sv = C.c_int64(0)
-        st = self._check(self.lib.tlsq_rpca_c64(self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
-                                                _ptr(S), C.byref(sv), C.byref(info)))
+        st = self._check(self.lib.tlsq_rpca_c64_svd(self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
+                                                    _ptr(U), M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
         rep = RpcaReport(info, cost, svp)
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}")
-        s = SVD(None, S, None)
+        s = SVD(U, S, Vt)
         return (A, E, s, int(sv.value), rep) if return_report else (A, E, s, int(sv.value))
 
     def rpca_device(self, dD, M, N, dA, dE, *, dU=None, dS=None, dVt=None, iters=1000, m_global=0,
