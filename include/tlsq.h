@@ -248,10 +248,17 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
 int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
                           const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,
                           int32_t* iters, int32_t* status, double* cost);
+/* Float32 elements (the reference's functions are generic in the element type): the same kernel with fp32 panels and
+ * fp32 Jacobi SVDs (twice the problems per CU in LDS); default tol = sqrt(eps(Float32)). */
+int tlsq_rpca_batched_f32(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t batch,
+                          const tlsq_rpca_opts* opts, float* A, float* E, float* S, float* Vt, int64_t* sv,
+                          int32_t* iters, int32_t* status, float* cost);
 /* x_b = rtls(A_b, y_b) for b = 1..batch (src/TotalLeastSquares.jl:152-156): A is M x n x batch, y is M x q x batch,
  * x is n x q x batch. */
 int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64_t M, int64_t n, int64_t q,
                           int64_t batch, const tlsq_rpca_opts* opts, double* x, int32_t* iters, int32_t* status);
+int tlsq_rtls_batched_f32(tlsq_handle h, const float* A, const float* y, int64_t M, int64_t n, int64_t q,
+                          int64_t batch, const tlsq_rpca_opts* opts, float* x, int32_t* iters, int32_t* status);
 int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n,
                          double* x, int64_t ldx);
 

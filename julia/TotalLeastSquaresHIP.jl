@@ -319,15 +319,17 @@ end
 
 # Many small problems at once (the loop of test/runtests.jl:205-235 as one launch): A is M x n x B, y is M x B
 # (or M x q x B); returns x as n x B (n x q x B).  One workgroup per problem, everything in LDS.
-function rtls(A::AbstractArray{Float64,3}, y::AbstractArray{Float64}; kwargs...)
-    M, n, B = size(A); ym = reshape(y, M, :, B); q = size(ym, 2)
-    o, box = _opts(Float64, M, n + q; tol = sqrt(eps()), kwargs...)
-    x = Array{Float64}(undef, n, q, B); iters = Vector{Int32}(undef, B); status = Vector{Int32}(undef, B)
-    st = check(ccall((:tlsq_rtls_batched_f64, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Float64},
-         Ptr{Int32}, Ptr{Int32}), handle(), Array(A), Array(ym), M, n, q, B, o, x, iters, status))
-    st == 1 && @warn "Maximum number of iterations reached in $(sum(status)) of $B problems"
-    ndims(y) == 2 ? reshape(x, n, B) : x
+for (T, sym) in ((Float64, :tlsq_rtls_batched_f64), (Float32, :tlsq_rtls_batched_f32))
+    @eval function rtls(A::AbstractArray{$T,3}, y::AbstractArray{$T}; kwargs...)
+        M, n, B = size(A); ym = reshape(y, M, :, B); q = size(ym, 2)
+        o, box = _opts($T, M, n + q; tol = sqrt(eps($T)), kwargs...)
+        x = Array{$T}(undef, n, q, B); iters = Vector{Int32}(undef, B); status = Vector{Int32}(undef, B)
+        st = check(ccall(($(QuoteNode(sym)), LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{$T}, Ptr{$T}, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{$T},
+             Ptr{Int32}, Ptr{Int32}), handle(), Array(A), Array(ym), M, n, q, B, o, x, iters, status))
+        st == 1 && @warn string("Maximum number of iterations reached in ", sum(status), " of ", B, " problems")
+        ndims(y) == 2 ? reshape(x, n, B) : x
+    end
 end
 
 # ---- rpca_ga (src/robustPCA.jl:255-310) and its spherical averages (:312-362) ----------------------------------------

@@ -735,6 +735,37 @@ def test_rpca_batched_vs_oracle_and_reference_statistics(eng):
     assert wins.mean() > 0.9, wins.mean()
 
 
+def test_batched_float32_stacks(eng):
+    """Float32 stacks run the fp32 instantiation of the batched kernel (default tol sqrt(eps(Float32))): against the
+    oracle on the same fp32 data at the same tol, against the per-problem fp32 entry point, and the reference's
+    statistical rtls test (test/runtests.jl:219-235) in fp32."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(11)
+    B, M, N = 8, 300, 8
+    D = np.stack([O.synth_lowrank_sparse(M, N, 2, seed=70 + b)[0] for b in range(B)]).astype(np.float32)
+    tol32 = float(np.sqrt(np.finfo(np.float32).eps))
+    A, E, S, Vt, sv, it, st, cost = eng.rpca_batched(D)
+    assert A.dtype == np.float32 and S.dtype == np.float32 and Vt.dtype == np.float32 and not st.any()
+    for b in range(B):
+        Ao, Eo, so, svo, io = O.rpca(D[b].astype(np.float64), tol=tol32)
+        assert sv[b] == svo and abs(int(it[b]) - io.iters_done) <= 1, (b, sv[b], svo, it[b], io.iters_done)
+        assert relerr(A[b], Ao) < 2e-3 and relerr(A[b] + E[b], D[b]) < 2e-3
+        np.testing.assert_allclose(S[b][:svo], so[1][:svo], rtol=2e-3)
+        assert np.abs(Vt[b] @ Vt[b].T - np.eye(N)).max() < 1e-4
+    A1, E1, *_ = eng.rpca(D[2])
+    assert A1.dtype == np.float32 and relerr(A[2], A1) < 2e-3
+    # a 2000-row stack does not fit LDS in either type: the global-scratch variant in fp32
+    x0, An, yn = _rtls_problem_stack(rng, 6, 2000, 4, 5.0)
+    x32 = eng.rtls_batched(An.astype(np.float32), yn.astype(np.float32))
+    x64 = eng.rtls_batched(An, yn)
+    assert x32.dtype == np.float32 and relerr(x32, x64) < 5e-3
+    x0, An, yn = _rtls_problem_stack(rng, 1000, 50, 3, 50.0)
+    xr = eng.rtls_batched(An.astype(np.float32), yn.astype(np.float32))
+    xt = np.stack([np.ravel(O.tls(An[b], yn[b])) for b in range(1000)])
+    wins = np.linalg.norm(x0 - xr, axis=1) < np.linalg.norm(x0 - xt, axis=1)
+    assert xr.dtype == np.float32 and wins.mean() > 0.9, wins.mean()
+
+
 def test_batched_unsupported_shapes_fail_loudly(eng):
     import tlsq_amd
     with pytest.raises(tlsq_amd.TlsqError):

@@ -20,6 +20,7 @@ ap.add_argument("--sigma", type=float, default=50.0)
 ap.add_argument("--batch", type=int, default=20000)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--cpu-problems", type=int, default=200)
+ap.add_argument("--f32", action="store_true", help="Float32 stacks (tlsq_rtls_batched_f32)")
 a = ap.parse_args()
 M, n, B = a.M, a.n, a.batch
 rng = np.random.default_rng(0)
@@ -32,9 +33,10 @@ yn = yn + a.sigma * rng.standard_normal(yn.shape) * (rng.random(yn.shape) < 0.1)
 torch.zeros(1, device="cuda")
 eng = tlsq_amd.Engine(0)
 from tlsq_amd import _lib as L
-dA = torch.from_numpy(np.ascontiguousarray(np.transpose(An, (0, 2, 1)))).cuda()     # each problem column-major
-dy = torch.from_numpy(np.ascontiguousarray(yn)).cuda()
-dx = torch.empty((B, n), dtype=torch.float64, device="cuda")
+tdt = torch.float32 if a.f32 else torch.float64
+dA = torch.from_numpy(np.ascontiguousarray(np.transpose(An, (0, 2, 1)))).cuda().to(tdt)     # each problem column-major
+dy = torch.from_numpy(np.ascontiguousarray(yn)).cuda().to(tdt)
+dx = torch.empty((B, n), dtype=tdt, device="cuda")
 dit = torch.empty(B, dtype=torch.int32, device="cuda")
 dst = torch.empty(B, dtype=torch.int32, device="cuda")
 o = eng.make_opts(iters=1000, memory=L.MEM_DEVICE)
@@ -42,7 +44,8 @@ p = lambda t: C.c_void_p(t.data_ptr())
 
 
 def run():
-    st = eng.lib.tlsq_rtls_batched_f64(eng.h, p(dA), p(dy), M, n, 1, B, C.byref(o), p(dx), p(dit), p(dst))
+    fn = eng.lib.tlsq_rtls_batched_f32 if a.f32 else eng.lib.tlsq_rtls_batched_f64
+    st = fn(eng.h, p(dA), p(dy), M, n, 1, B, C.byref(o), p(dx), p(dit), p(dst))
     assert st >= 0, st
 
 
@@ -58,10 +61,11 @@ x = dx.cpu().numpy()
 
 nc = min(a.cpu_problems, B)
 t0 = time.perf_counter()
-xo = np.stack([np.ravel(O.rtls(An[b], yn[b])) for b in range(nc)])
+okw = {"tol": float(np.sqrt(np.finfo(np.float32).eps))} if a.f32 else {}          # the fp32 entry point's default tol
+xo = np.stack([np.ravel(O.rtls(An[b], yn[b], **okw)) for b in range(nc)])
 dtc = time.perf_counter() - t0
-err = float(np.max(np.abs(x[:nc] - xo) / (1e-9 + np.abs(xo))))
-out = {"metric": f"rtls problems/sec, {M}x{n}+1 fp64, batch {B}", "value": B / dt, "unit": "problems/s",
+err = float(np.max(np.linalg.norm(x[:nc] - xo, axis=1) / (1e-9 + np.linalg.norm(xo, axis=1))))
+out = {"metric": f"rtls problems/sec, {M}x{n}+1 {'fp32' if a.f32 else 'fp64'}, batch {B}", "value": B / dt, "unit": "problems/s",
        "ms_per_batch": dt * 1e3, "mean_iters": float(it.mean()), "max_iters": int(it.max()),
        "alm_iters_per_s": float(it.sum()) / dt, "unconverged": int(dst.cpu().numpy().sum()),
        "cpu_baseline": {"value": nc / dtc, "unit": "problems/s", "cores": int(os.environ.get("OPENBLAS_NUM_THREADS", 0)) or "default",

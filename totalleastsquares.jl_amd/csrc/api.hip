@@ -497,7 +497,8 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
 
 // ---- batched tiny problems (batched.hip) ---------------------------------------------------------------
 // validates the options shared by the two batched entry points
-static int batched_opts(tlsq_handle h, const tlsq_rpca_opts* opts, int64_t M, int64_t N, const char* who, ResolvedOpts* ro) {
+static int batched_opts(tlsq_handle h, const tlsq_rpca_opts* opts, int64_t M, int64_t N, const char* who, ResolvedOpts* ro,
+                        double default_tol) {
     if (N > 16)
         return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: N = %lld columns; the batched kernel handles N <= 16 (use the "
                        "per-problem entry point)", who, (long long)N);
@@ -507,51 +508,56 @@ static int batched_opts(tlsq_handle h, const tlsq_rpca_opts* opts, int64_t M, in
         return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: hankel / hook modes / on_iter / row sharding are not available "
                        "in the batched kernel", who);
     if (h->comm) return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: not available on a row-sharded handle", who);
-    *ro = resolve(opts, M, N, std::sqrt(std::numeric_limits<double>::epsilon()));
+    *ro = resolve(opts, M, N, default_tol);
     return TLSQ_OK;
 }
 
-int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
-                          const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,
-                          int32_t* iters, int32_t* status, double* cost) {
+}  // extern "C" (templates below)
+
+template <typename T>
+static int rpca_batched_impl(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t batch,
+                             const tlsq_rpca_opts* opts, T* A, T* E, T* S, T* Vt, int64_t* sv,
+                             int32_t* iters, int32_t* status, T* cost) {
+    constexpr size_t ES = sizeof(T);
     TLSQ_TRY(check_handle(h));
     if (!D || !A || !E || M <= 0 || N <= 0 || batch < 0)
         return set_err(h, TLSQ_ERR_ARG, "rpca_batched: bad argument");
     if (batch == 0) return TLSQ_OK;
     TLSQ_HIP(h, hipSetDevice(h->device));
     ResolvedOpts ro;
-    TLSQ_TRY(batched_opts(h, opts, M, N, "rpca_batched", &ro));
+    TLSQ_TRY(batched_opts(h, opts, M, N, "rpca_batched", &ro, std::sqrt((double)std::numeric_limits<T>::epsilon())));
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const size_t pn = (size_t)M * N * batch * 8;
+    const size_t pn = (size_t)M * N * batch * ES;
     bool in_lds;
-    (void)rpca_small_lds_bytes(M, N, &in_lds);
+    (void)rpca_small_lds_bytes(M, N, &in_lds, ES);
     void* scratch = nullptr;
     if (!in_lds) TLSQ_TRY(ws_get(h, WS_BATCH4, 5 * pn, &scratch));
-    const double *dD = D;
-    double *dA = A, *dE = E, *dS = S, *dVt = Vt, *dcost = cost;
+    const T* dD = D;
+    T *dA = A, *dE = E, *dS = S, *dVt = Vt, *dcost = cost;
     int64_t* dsv = sv;
     int32_t *dit = iters, *dst = status;
     void* p;
     if (!dev) {
         TLSQ_TRY(ws_get(h, WS_BATCH0, pn, &p));
         TLSQ_HIP(h, hipMemcpyAsync(p, D, pn, hipMemcpyHostToDevice, h->stream));
-        dD = (const double*)p;
+        dD = (const T*)p;
         TLSQ_TRY(ws_get(h, WS_BATCH1, pn, &p));
-        dA = (double*)p;
+        dA = (T*)p;
         TLSQ_TRY(ws_get(h, WS_BATCH2, pn, &p));
-        dE = (double*)p;
+        dE = (T*)p;
     }
     // the small per-problem outputs always go through one device block: S | Vt | cost | sv | iters | status
-    const size_t oS = 0, oVt = oS + (size_t)N * batch * 8, oC = oVt + (size_t)N * N * batch * 8,
-                 oSv = oC + (size_t)batch * 8, oIt = oSv + (size_t)batch * 8, oSt = oIt + (size_t)batch * 4,
+    auto al8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    const size_t oS = 0, oVt = al8(oS + (size_t)N * batch * ES), oC = al8(oVt + (size_t)N * N * batch * ES),
+                 oSv = al8(oC + (size_t)batch * ES), oIt = oSv + (size_t)batch * 8, oSt = oIt + (size_t)batch * 4,
                  oEnd = oSt + (size_t)batch * 4;
     char* blk = nullptr;
     if (!dev) {
         TLSQ_TRY(ws_get(h, WS_BATCH3, oEnd, &p));
         blk = (char*)p;
-        dS = (double*)(blk + oS);
-        dVt = (double*)(blk + oVt);
-        dcost = (double*)(blk + oC);
+        dS = (T*)(blk + oS);
+        dVt = (T*)(blk + oVt);
+        dcost = (T*)(blk + oC);
         dsv = (int64_t*)(blk + oSv);
         dit = (int32_t*)(blk + oIt);
         dst = (int32_t*)(blk + oSt);
@@ -559,8 +565,8 @@ int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, 
         TLSQ_TRY(ws_get(h, WS_BATCH3, (size_t)batch * 4, &p));
         dst = (int32_t*)p;
     }
-    TLSQ_TRY(launch_rpca_small(h, dD, M, N, batch, ro.lambda, ro.tol, ro.rho, ro.iters, ro.maxrank, ro.nonnegA,
-                               ro.nonnegE, ro.nukeA, dA, dE, dS, dVt, dsv, dit, dst, dcost, (double*)scratch));
+    TLSQ_TRY(launch_rpca_small<T>(h, dD, M, N, batch, ro.lambda, ro.tol, ro.rho, ro.iters, ro.maxrank, ro.nonnegA,
+                               ro.nonnegE, ro.nukeA, dA, dE, dS, dVt, dsv, dit, dst, dcost, (T*)scratch));
     std::vector<int32_t> hst((size_t)batch);
     if (!dev) {
         TLSQ_HIP(h, hipMemcpyAsync(A, dA, pn, hipMemcpyDeviceToHost, h->stream));
@@ -568,9 +574,9 @@ int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, 
         std::vector<char> hb(oEnd);
         TLSQ_HIP(h, hipMemcpyAsync(hb.data(), blk, oEnd, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        if (S) memcpy(S, hb.data() + oS, (size_t)N * batch * 8);
-        if (Vt) memcpy(Vt, hb.data() + oVt, (size_t)N * N * batch * 8);
-        if (cost) memcpy(cost, hb.data() + oC, (size_t)batch * 8);
+        if (S) memcpy(S, hb.data() + oS, (size_t)N * batch * ES);
+        if (Vt) memcpy(Vt, hb.data() + oVt, (size_t)N * N * batch * ES);
+        if (cost) memcpy(cost, hb.data() + oC, (size_t)batch * ES);
         if (sv) memcpy(sv, hb.data() + oSv, (size_t)batch * 8);
         if (iters) memcpy(iters, hb.data() + oIt, (size_t)batch * 4);
         if (status) memcpy(status, hb.data() + oSt, (size_t)batch * 4);
@@ -584,8 +590,10 @@ int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, 
     return TLSQ_OK;
 }
 
-int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64_t M, int64_t n, int64_t q,
-                          int64_t batch, const tlsq_rpca_opts* opts, double* x, int32_t* iters, int32_t* status) {
+template <typename T>
+static int rtls_batched_impl(tlsq_handle h, const T* A, const T* y, int64_t M, int64_t n, int64_t q,
+                             int64_t batch, const tlsq_rpca_opts* opts, T* x, int32_t* iters, int32_t* status) {
+    constexpr size_t ES = sizeof(T);
     TLSQ_TRY(check_handle(h));
     if (!A || !y || !x || M <= 0 || n <= 0 || q <= 0 || batch < 0)
         return set_err(h, TLSQ_ERR_ARG, "rtls_batched: bad argument");
@@ -593,53 +601,78 @@ int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64
     TLSQ_HIP(h, hipSetDevice(h->device));
     const int64_t nc = n + q;
     ResolvedOpts ro;
-    TLSQ_TRY(batched_opts(h, opts, M, nc, "rtls_batched", &ro));
+    TLSQ_TRY(batched_opts(h, opts, M, nc, "rtls_batched", &ro, std::sqrt((double)std::numeric_limits<T>::epsilon())));
     ro.nukeA = false;                                                                  // TotalLeastSquares.jl:154
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const size_t pn = (size_t)M * nc * batch * 8;
+    const size_t pn = (size_t)M * nc * batch * ES;
     void *AA, *Ar, *Er, *blkv, *scratch = nullptr;
     TLSQ_TRY(ws_get(h, WS_BATCH0, pn, &AA));
     TLSQ_TRY(ws_get(h, WS_BATCH1, pn, &Ar));
     TLSQ_TRY(ws_get(h, WS_BATCH2, pn, &Er));
     bool in_lds;
-    (void)rpca_small_lds_bytes(M, nc, &in_lds);
+    (void)rpca_small_lds_bytes(M, nc, &in_lds, ES);
     if (!in_lds) TLSQ_TRY(ws_get(h, WS_BATCH4, 5 * pn, &scratch));
-    const size_t oVt = 0, oIt = (size_t)nc * nc * batch * 8, oSt = oIt + (size_t)batch * 4, oEnd = oSt + (size_t)batch * 4;
+    const size_t oVt = 0, oIt = (((size_t)nc * nc * batch * ES) + 7) & ~(size_t)7, oSt = oIt + (size_t)batch * 4,
+                 oEnd = oSt + (size_t)batch * 4;
     TLSQ_TRY(ws_get(h, WS_BATCH3, oEnd, &blkv));
     char* blk = (char*)blkv;
     // AA_b = [A_b y_b]  (:153): two strided copies, one row of the 2-D copy per problem
     const hipMemcpyKind kin = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    TLSQ_HIP(h, hipMemcpy2DAsync(AA, (size_t)M * nc * 8, A, (size_t)M * n * 8, (size_t)M * n * 8, (size_t)batch, kin,
+    TLSQ_HIP(h, hipMemcpy2DAsync(AA, (size_t)M * nc * ES, A, (size_t)M * n * ES, (size_t)M * n * ES, (size_t)batch, kin,
                                  h->stream));
-    TLSQ_HIP(h, hipMemcpy2DAsync((char*)AA + (size_t)M * n * 8, (size_t)M * nc * 8, y, (size_t)M * q * 8,
-                                 (size_t)M * q * 8, (size_t)batch, kin, h->stream));
-    TLSQ_TRY(launch_rpca_small(h, (const double*)AA, M, nc, batch, ro.lambda, ro.tol, ro.rho, ro.iters, ro.maxrank,
-                               ro.nonnegA, ro.nonnegE, ro.nukeA, (double*)Ar, (double*)Er, nullptr,
-                               (double*)(blk + oVt), nullptr, (int32_t*)(blk + oIt), (int32_t*)(blk + oSt), nullptr,
-                               (double*)scratch));
+    TLSQ_HIP(h, hipMemcpy2DAsync((char*)AA + (size_t)M * n * ES, (size_t)M * nc * ES, y, (size_t)M * q * ES,
+                                 (size_t)M * q * ES, (size_t)batch, kin, h->stream));
+    TLSQ_TRY(launch_rpca_small<T>(h, (const T*)AA, M, nc, batch, ro.lambda, ro.tol, ro.rho, ro.iters, ro.maxrank,
+                                  ro.nonnegA, ro.nonnegE, ro.nukeA, (T*)Ar, (T*)Er, nullptr,
+                                  (T*)(blk + oVt), nullptr, (int32_t*)(blk + oIt), (int32_t*)(blk + oSt), nullptr,
+                                  (T*)scratch));
     std::vector<char> hb(oEnd);
     TLSQ_HIP(h, hipMemcpyAsync(hb.data(), blk, oEnd, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    const double* hVt = reinterpret_cast<const double*>(hb.data() + oVt);
+    const T* hVt = reinterpret_cast<const T*>(hb.data() + oVt);
     const int32_t* hst = reinterpret_cast<const int32_t*>(hb.data() + oSt);
-    std::vector<double> hx((size_t)n * q * batch);
+    std::vector<double> hx((size_t)n * q * batch), vt64((size_t)nc * nc);
     int rc = TLSQ_OK;
     for (int64_t b = 0; b < batch; ++b) {                                              // tls!(s, n)  :155
-        int st = tls_partition_solve(hVt + (size_t)b * nc * nc, nc, nc, n, hx.data() + (size_t)b * n * q, n);
+        for (int64_t e = 0; e < nc * nc; ++e) vt64[(size_t)e] = (double)hVt[(size_t)b * nc * nc + e];
+        int st = tls_partition_solve(vt64.data(), nc, nc, n, hx.data() + (size_t)b * n * q, n);
         if (st < 0) return set_err(h, st, "rtls_batched: partition solve failed for problem %lld", (long long)b);
         if (hst[b] != 0) rc = TLSQ_MAXITER;
     }
+    std::vector<T> hxT(hx.size());
+    for (size_t e = 0; e < hx.size(); ++e) hxT[e] = (T)hx[e];
     if (dev) {
-        TLSQ_HIP(h, hipMemcpyAsync(x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(x, hxT.data(), hxT.size() * ES, hipMemcpyHostToDevice, h->stream));
         if (iters) TLSQ_HIP(h, hipMemcpyAsync(iters, blk + oIt, (size_t)batch * 4, hipMemcpyDeviceToDevice, h->stream));
         if (status) TLSQ_HIP(h, hipMemcpyAsync(status, blk + oSt, (size_t)batch * 4, hipMemcpyDeviceToDevice, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     } else {
-        memcpy(x, hx.data(), hx.size() * 8);
+        memcpy(x, hxT.data(), hxT.size() * ES);
         if (iters) memcpy(iters, hb.data() + oIt, (size_t)batch * 4);
         if (status) memcpy(status, hb.data() + oSt, (size_t)batch * 4);
     }
     return rc;
+}
+
+
+extern "C" {
+int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
+                          const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,
+                          int32_t* iters, int32_t* status, double* cost) {
+    return rpca_batched_impl<double>(h, D, M, N, batch, opts, A, E, S, Vt, sv, iters, status, cost);
+}
+int tlsq_rpca_batched_f32(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t batch,
+                          const tlsq_rpca_opts* opts, float* A, float* E, float* S, float* Vt, int64_t* sv,
+                          int32_t* iters, int32_t* status, float* cost) {
+    return rpca_batched_impl<float>(h, D, M, N, batch, opts, A, E, S, Vt, sv, iters, status, cost);
+}
+int tlsq_rtls_batched_f64(tlsq_handle h, const double* A, const double* y, int64_t M, int64_t n, int64_t q,
+                          int64_t batch, const tlsq_rpca_opts* opts, double* x, int32_t* iters, int32_t* status) {
+    return rtls_batched_impl<double>(h, A, y, M, n, q, batch, opts, x, iters, status);
+}
+int tlsq_rtls_batched_f32(tlsq_handle h, const float* A, const float* y, int64_t M, int64_t n, int64_t q,
+                          int64_t batch, const tlsq_rpca_opts* opts, float* x, int32_t* iters, int32_t* status) {
+    return rtls_batched_impl<float>(h, A, y, M, n, q, batch, opts, x, iters, status);
 }
 
 // ---- kernel-level entry points (device pointers) ---------------------------------------------------

@@ -30,20 +30,32 @@ __device__ __forceinline__ double b_dpp(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ float b_dpp(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ double b_lane(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                             __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-__device__ __forceinline__ double b_wsum(double v) {   // wave all-reduce, fixed order
+__device__ __forceinline__ float b_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <typename T>
+__device__ __forceinline__ T b_wsum(T v) {   // wave all-reduce, fixed order
     v += b_dpp<0xB1>(v);
     v += b_dpp<0x4E>(v);
     v += b_dpp<0x141>(v);
     v += b_dpp<0x140>(v);
     return (b_lane(v, 0) + b_lane(v, 16)) + (b_lane(v, 32) + b_lane(v, 48));
 }
-__device__ __forceinline__ double b_pos(double a) { return (a > 0.0 || a != a) ? a : 0.0; }
-__device__ __forceinline__ double b_neg(double b) { return (b < 0.0 || b != b) ? b : 0.0; }
-__device__ __forceinline__ double b_soft(double x, double e) { return b_pos(x - e) + b_neg(x + e); }   // :1
+template <typename T>
+__device__ __forceinline__ T b_pos(T a) { return (a > (T)0 || a != a) ? a : (T)0; }
+template <typename T>
+__device__ __forceinline__ T b_neg(T b) { return (b < (T)0 || b != b) ? b : (T)0; }
+template <typename T>
+__device__ __forceinline__ T b_soft(T x, T e) { return b_pos<T>(x - e) + b_neg<T>(x + e); }   // :1
 
 __device__ __forceinline__ void b_pair(int n, int r, int idx, int& p, int& q) {   // round-robin tournament
     const int m = n - 1;
@@ -56,31 +68,33 @@ __device__ __forceinline__ void b_pair(int n, int r, int idx, int& p, int& q) { 
     }
 }
 
+template <typename T>
 struct Small {            // per-problem LDS bookkeeping
-    double* V;            // N x N (ld BN)
-    double* nrm;          // squared column norms
-    double* sig;          // singular values, sorted descending
+    T* V;                 // N x N (ld BN)
+    T* nrm;               // squared column norms
+    T* sig;               // singular values, sorted descending
     int* ord;             // column index of the i-th largest
-    double* red;          // BW partials
+    T* red;               // BW partials
     unsigned int* cnt;    // rotation counter
 };
 
 // One-sided Jacobi SVD of the M x N panel P (ld M) in place: on return the columns of P are mutually orthogonal
 // (P = U diag(sigma) in some column order), nrm[j] = ||P[:,j]||^2 and, when V != nullptr, V (N x N, ld BN) holds
 // the accumulated rotations (P_in * V = P_out).  All BT threads must call.
-__device__ void jacobi_svd(double* P, int M, int N, const Small& s, bool want_v) {
+template <typename T>
+__device__ void jacobi_svd(T* P, int M, int N, const Small<T>& s, bool want_v) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (want_v)
-        for (int e = tid; e < N * BN; e += BT) s.V[e] = ((e % BN) == (e / BN)) ? 1.0 : 0.0;
+        for (int e = tid; e < N * BN; e += BT) s.V[e] = ((e % BN) == (e / BN)) ? (T)1 : (T)0;
     const int nslot = (N + 1) & ~1, npair = nslot / 2;
-    const double tol = 2.220446049250313e-16 * sqrt((double)M);   // LAPACK dgesvj's criterion
+    const T tol = std::numeric_limits<T>::epsilon() * (T)sqrt((double)M);   // LAPACK gesvj's criterion
     for (int sweep = 0; sweep < 40; ++sweep) {
         __syncthreads();
         for (int c = w; c < N; c += BW) {   // refresh the cached norms once per sweep
-            const double* x = P + (size_t)c * M;
-            double a = 0.0;
+            const T* x = P + (size_t)c * M;
+            T a = (T)0;
             for (int r = lane; r < M; r += 64) a += x[r] * x[r];
-            a = b_wsum(a);
+            a = b_wsum<T>(a);
             if (lane == 0) s.nrm[c] = a;
         }
         if (tid == 0) *s.cnt = 0;
@@ -96,32 +110,32 @@ __device__ void jacobi_svd(double* P, int M, int N, const Small& s, bool want_v)
                     q = t;
                 }
                 if (q >= N) continue;
-                double* x = P + (size_t)p * M;
-                double* y = P + (size_t)q * M;
-                const double a = s.nrm[p], bb = s.nrm[q];
-                double c = 0.0;
+                T* x = P + (size_t)p * M;
+                T* y = P + (size_t)q * M;
+                const T a = s.nrm[p], bb = s.nrm[q];
+                T c = (T)0;
                 for (int r = lane; r < M; r += 64) c += x[r] * y[r];
-                c = b_wsum(c);
-                if (c * c > tol * tol * a * bb && a > 0.0 && bb > 0.0) {
+                c = b_wsum<T>(c);
+                if (c * c > tol * tol * a * bb && a > (T)0 && bb > (T)0) {
                     // t = 2 c sgn(d) / (|d| + sqrt(d^2 + 4 c^2)), d = bb - a: the smaller root, one sqrt + one division
-                    const double d = bb - a;
-                    const double t = (d >= 0.0 ? 2.0 : -2.0) * c / (fabs(d) + sqrt(d * d + 4.0 * c * c));
-                    const double cs = 1.0 / sqrt(1.0 + t * t);
-                    const double sn = cs * t;
+                    const T d = bb - a;
+                    const T t = (d >= (T)0 ? (T)2 : (T)-2) * c / ((T)fabs(d) + (T)sqrt(d * d + (T)4 * c * c));
+                    const T cs = (T)1 / (T)sqrt((T)1 + t * t);
+                    const T sn = cs * t;
                     for (int r = lane; r < M; r += 64) {
-                        const double u = x[r], v = y[r];
+                        const T u = x[r], v = y[r];
                         x[r] = cs * u - sn * v;
                         y[r] = sn * u + cs * v;
                     }
                     if (want_v && lane < N) {
-                        const double u = s.V[lane + p * BN], v = s.V[lane + q * BN];
+                        const T u = s.V[lane + p * BN], v = s.V[lane + q * BN];
                         s.V[lane + p * BN] = cs * u - sn * v;
                         s.V[lane + q * BN] = sn * u + cs * v;
                     }
                     if (lane == 0) {
-                        const double na = a - t * c, nb = bb + t * c;
-                        s.nrm[p] = na > 0.0 ? na : 0.0;
-                        s.nrm[q] = nb > 0.0 ? nb : 0.0;
+                        const T na = a - t * c, nb = bb + t * c;
+                        s.nrm[p] = na > (T)0 ? na : (T)0;
+                        s.nrm[q] = nb > (T)0 ? nb : (T)0;
                     }
                     ++my;
                 }
@@ -135,19 +149,19 @@ __device__ void jacobi_svd(double* P, int M, int N, const Small& s, bool want_v)
     __syncthreads();
     // exact norms of the final columns, then the descending order
     for (int c = w; c < N; c += BW) {
-        const double* x = P + (size_t)c * M;
-        double a = 0.0;
+        const T* x = P + (size_t)c * M;
+        T a = (T)0;
         for (int r = lane; r < M; r += 64) a += x[r] * x[r];
-        a = b_wsum(a);
+        a = b_wsum<T>(a);
         if (lane == 0) s.nrm[c] = a;
     }
     __syncthreads();
     if (tid < N) {   // rank of column tid (stable: ties keep the column order)
-        const double me = s.nrm[tid];
+        const T me = s.nrm[tid];
         int rank = 0;
         for (int j = 0; j < N; ++j) rank += (s.nrm[j] > me || (s.nrm[j] == me && j < tid)) ? 1 : 0;
         s.ord[rank] = tid;
-        s.sig[rank] = sqrt(me);
+        s.sig[rank] = (T)sqrt(me);
     }
     __syncthreads();
 }
@@ -163,69 +177,70 @@ struct BatchedArgs {
 
 // grid = batch.  Dg/Ag/Eg: batch contiguous M x N problems.  Sg (N per problem), Vtg (N x N per problem, ld N,
 // rows sorted by singular value), svg, itg, stg (0 = converged, 1 = iteration limit) may each be nullptr.
-template <bool IN_LDS>
-__global__ __launch_bounds__(BT) void k_rpca_small(const double* __restrict__ Dg, BatchedArgs a,
-                                                   double* __restrict__ Ag, double* __restrict__ Eg,
-                                                   double* __restrict__ Sg, double* __restrict__ Vtg,
+template <typename T, bool IN_LDS>
+__global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, BatchedArgs a,
+                                                   T* __restrict__ Ag, T* __restrict__ Eg,
+                                                   T* __restrict__ Sg, T* __restrict__ Vtg,
                                                    int64_t* __restrict__ svg, int32_t* __restrict__ itg,
-                                                   int32_t* __restrict__ stg, double* __restrict__ costg,
-                                                   double* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) double bsm[];
+                                                   int32_t* __restrict__ stg, T* __restrict__ costg,
+                                                   T* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bsm_raw[];
+    T* bsm = reinterpret_cast<T*>(bsm_raw);
     const int M = a.M, N = a.N, MN = M * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b = blockIdx.x;
-    Small s;
+    Small<T> s;
     s.V = bsm;                          // BN*BN
     s.nrm = s.V + BN * BN;              // BN
     s.sig = s.nrm + BN;                 // BN
     s.red = s.sig + BN;                 // 8
-    s.ord = reinterpret_cast<int*>(s.red + 8);           // BN ints = 8 doubles
-    s.cnt = reinterpret_cast<unsigned int*>(s.red + 16);   // 1 (+pad) -> 2 doubles
-    double* g = s.red + 18;             // BN  rebuild weights
-    double* big = IN_LDS ? (bsm + BN * BN + 3 * BN + 24) : (scratch + (size_t)b * 5 * MN);
-    double *D = big, *A = D + MN, *E = A + MN, *Y = E + MN, *Z = Y + MN;
-    const double* Din = Dg + (size_t)b * MN;
+    T* g = s.red + 8;                   // BN  rebuild weights
+    s.ord = reinterpret_cast<int*>(g + BN);                  // BN ints
+    s.cnt = reinterpret_cast<unsigned int*>(s.ord + BN);     // 1 (+ 3 of padding: the panels start 16-byte aligned)
+    T* big = IN_LDS ? reinterpret_cast<T*>(s.ord + BN + 4) : (scratch + (size_t)b * 5 * MN);
+    T *D = big, *A = D + MN, *E = A + MN, *Y = E + MN, *Z = Y + MN;
+    const T* Din = Dg + (size_t)b * MN;
 
     // ---- setup, src/robustPCA.jl:171-184 ----
-    double mx = 0.0;
+    T mx = (T)0;
     for (int e = tid; e < MN; e += BT) {
-        const double d = Din[e];
+        const T d = Din[e];
         D[e] = d;
         Z[e] = d;
-        A[e] = 0.0;
-        E[e] = 0.0;
-        const double ad = fabs(d);
+        A[e] = (T)0;
+        E[e] = (T)0;
+        const T ad = (T)fabs(d);
         mx = ad > mx ? ad : mx;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(mx, off, 64);
+        const T o = __shfl_xor(mx, off, 64);
         mx = o > mx ? o : mx;
     }
     if (lane == 0) s.red[w] = mx;
     __syncthreads();
-    double maxabs = 0.0;
+    T maxabs = (T)0;
     for (int k = 0; k < BW; ++k) maxabs = s.red[k] > maxabs ? s.red[k] : maxabs;   // norm(Y, Inf)  :178
     jacobi_svd(Z, M, N, s, false);
-    const double norm2 = s.sig[0];                                  // opnorm(Y)  :177
-    const double lam = a.lambda;
-    const double norminf = maxabs / lam;
-    const double dual_norm = norm2 > norminf ? norm2 : norminf;     // :179
-    const double d_norm = norm2;                                    // :180
+    const T norm2 = s.sig[0];                                  // opnorm(Y)  :177
+    const T lam = (T)a.lambda;
+    const T norminf = maxabs / lam;
+    const T dual_norm = norm2 > norminf ? norm2 : norminf;     // :179
+    const T d_norm = norm2;                                    // :180
     for (int e = tid; e < MN; e += BT) Y[e] = D[e] / dual_norm;     // :181
-    double mu = 1.25 / norm2;                                       // :182
-    const double mubar = mu * 1.0e7;                                // :183
+    T mu = (T)1.25 / norm2;                                       // :182
+    const T mubar = mu * (T)1.0e7;                                // :183
     int64_t sv = 10;
     int svp = 10;                                                   // :184
-    double cost = 0.0;
+    T cost = (T)0;
     int k = 0, converged = 0;
     __syncthreads();
     for (k = 1; k <= a.iters; ++k) {                                // :186
-        const double inv_mu = 1.0 / mu, thr = lam / mu;
+        const T inv_mu = (T)1 / mu, thr = lam / mu;
         for (int e = tid; e < MN; e += BT) {                        // :188-192
-            const double t = inv_mu * Y[e];
-            double ee = b_soft((D[e] - A[e]) + t, thr);
-            if (a.nonnegE) ee = b_pos(ee);
+            const T t = inv_mu * Y[e];
+            T ee = b_soft<T>((D[e] - A[e]) + t, thr);
+            if (a.nonnegE) ee = b_pos<T>(ee);
             E[e] = ee;
             Z[e] = (D[e] - ee) + t;
         }
@@ -238,14 +253,14 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const double* __restrict__ Dg
             sv = t;
         }
         if (tid < svp) {
-            const double sg = s.sig[tid];
-            g[tid] = a.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
+            const T sg = s.sig[tid];
+            g[tid] = a.nukeA ? (sg - inv_mu) / sg : (T)1;            // :205-213
         }
         __syncthreads();
         // A = sum_i g_i (U S)[:, o_i] V[:, o_i]'
         for (int e = tid; e < MN; e += BT) {
             const int r = e % M, c = e / M;
-            double acc = 0.0;
+            T acc = (T)0;
             for (int i = 0; i < svp; ++i) {
                 const int o = s.ord[i];
                 acc += (g[i] * Z[r + (size_t)o * M]) * s.V[c + o * BN];
@@ -254,19 +269,22 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const double* __restrict__ Dg
         }
         __syncthreads();
         for (int e = tid; e < MN; e += BT) {                        // :217-222
-            double av = A[e];
+            T av = A[e];
             if (a.nonnegA) {
-                av = b_pos(av);
+                av = b_pos<T>(av);
                 A[e] = av;
             }
-            const double z = (D[e] - av) - E[e];
+            const T z = (D[e] - av) - E[e];
             Z[e] = z;
             Y[e] = Y[e] + mu * z;
         }
-        mu = fmin(mu * a.rho, mubar);                               // :223
+        {
+            const T mr = mu * (T)a.rho;
+            mu = mr < mubar ? mr : mubar;
+        }                               // :223
         // keep the decomposition of this iteration's Z (the returned `s`, :194,:238): the values-only Jacobi below
         // leaves V alone but overwrites sig / ord
-        double skeep = 0.0;
+        T skeep = (T)0;
         int okeep = 0;
         if (tid < N) {
             skeep = s.sig[tid];
@@ -281,15 +299,15 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const double* __restrict__ Dg
             s.ord[tid] = okeep;
         }
         __syncthreads();
-        if (cost < a.tol) {                                         // :228
+        if (cost < (T)a.tol) {                                         // :228
             converged = 1;
             break;
         }
     }
     if (k > a.iters) k = a.iters;
     // ---- results ----
-    double* Aout = Ag + (size_t)b * MN;
-    double* Eout = Eg + (size_t)b * MN;
+    T* Aout = Ag + (size_t)b * MN;
+    T* Eout = Eg + (size_t)b * MN;
     for (int e = tid; e < MN; e += BT) {
         Aout[e] = A[e];
         Eout[e] = E[e];
@@ -307,17 +325,17 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const double* __restrict__ Dg
     }
 }
 
-size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds) {
-    const size_t small = (size_t)(BN * BN + 3 * BN + 24) * 8;
-    const size_t big = (size_t)5 * M * N * 8;
+size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds, size_t esz) {
+    const size_t small = (size_t)(BN * BN + 3 * BN + 8) * esz + (size_t)(BN + 4) * 4;   // (a multiple of 16 bytes)
+    const size_t big = (size_t)5 * M * N * esz;
     *in_lds = small + big <= 150 * 1024;
     return *in_lds ? small + big : small;
 }
 
-int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,
-                      double rho, int64_t iters, int64_t maxrank, bool nonnegA, bool nonnegE, bool nukeA, double* A,
-                      double* E, double* S, double* Vt, int64_t* sv, int32_t* it, int32_t* st, double* cost,
-                      double* scratch) {
+template <typename T>
+int launch_rpca_small(Handle* h, const T* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,
+                      double rho, int64_t iters, int64_t maxrank, bool nonnegA, bool nonnegE, bool nukeA, T* A,
+                      T* E, T* S, T* Vt, int64_t* sv, int32_t* it, int32_t* st, T* cost, T* scratch) {
     if (batch <= 0) return TLSQ_OK;
     BatchedArgs a;
     a.M = (int)M;
@@ -331,18 +349,24 @@ int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t 
     a.nonnegE = nonnegE;
     a.nukeA = nukeA;
     bool in_lds;
-    const size_t lds = rpca_small_lds_bytes(M, N, &in_lds);
+    const size_t lds = rpca_small_lds_bytes(M, N, &in_lds, sizeof(T));
     if (in_lds) {
-        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rpca_small<true>),
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rpca_small<T, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_rpca_small<true>, dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv, it,
+        hipLaunchKernelGGL((k_rpca_small<T, true>), dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv, it,
                            st, cost, scratch);
     } else {
-        hipLaunchKernelGGL(k_rpca_small<false>, dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv,
+        hipLaunchKernelGGL((k_rpca_small<T, false>), dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv,
                            it, st, cost, scratch);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
+template int launch_rpca_small<double>(Handle*, const double*, int64_t, int64_t, int64_t, double, double, double, int64_t,
+                                       int64_t, bool, bool, bool, double*, double*, double*, double*, int64_t*, int32_t*,
+                                       int32_t*, double*, double*);
+template int launch_rpca_small<float>(Handle*, const float*, int64_t, int64_t, int64_t, double, double, double, int64_t,
+                                      int64_t, bool, bool, bool, float*, float*, float*, float*, int64_t*, int32_t*,
+                                      int32_t*, float*, float*);
 
 }  // namespace tlsq

@@ -306,11 +306,11 @@ int launch_unrealify(Handle* h, const double* AR, int64_t M, int64_t N, double* 
 int launch_pack_complex(Handle* h, const double* T, int64_t M, int64_t d, double* U);
 int launch_cmaxabs(Handle* h, const double* x, int64_t n, double* host_out);
 // batched.hip: one workgroup per tiny rpca problem
-size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds);
-int launch_rpca_small(Handle* h, const double* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,
-                      double rho, int64_t iters, int64_t maxrank, bool nonnegA, bool nonnegE, bool nukeA, double* A,
-                      double* E, double* S, double* Vt, int64_t* sv, int32_t* it, int32_t* st, double* cost,
-                      double* scratch);
+size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds, size_t esz = 8);
+template <typename T>
+int launch_rpca_small(Handle* h, const T* D, int64_t M, int64_t N, int64_t batch, double lambda, double tol,
+                      double rho, int64_t iters, int64_t maxrank, bool nonnegA, bool nonnegE, bool nukeA, T* A,
+                      T* E, T* S, T* Vt, int64_t* sv, int32_t* it, int32_t* st, T* cost, T* scratch);
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p);
 int launch_panel_tn(Handle* h, const double* A, const double* B, double* H, int64_t N, int64_t p,
                     const double* skip_status = nullptr);

@@ -468,43 +468,51 @@ class Engine:
     # -- batched tiny problems -----------------------------------------------
     def rpca_batched(self, D, *, iters=1000, **kw):
         """rpca on every D[b] of a (batch, M, N) stack, N <= 16, one workgroup per problem.  Returns
-        A, E (batch, M, N), S (batch, N), Vt (batch, N, N), sv, iters, status, cost (batch,)."""
-        D = np.asarray(D, dtype=np.float64)
+        A, E (batch, M, N), S (batch, N), Vt (batch, N, N), sv, iters, status, cost (batch,).  A float32 stack is
+        solved in float32 (default tol sqrt(eps(Float32))), everything else in float64."""
+        D = np.asarray(D)
+        dt = np.float32 if D.dtype == np.float32 else np.float64
+        D = D.astype(dt, copy=False)
+        fn = self.lib.tlsq_rpca_batched_f32 if dt == np.float32 else self.lib.tlsq_rpca_batched_f64
         B, M, N = D.shape
         Df = np.ascontiguousarray(np.transpose(D, (0, 2, 1)))          # each problem column-major
         A = np.empty_like(Df)
         E = np.empty_like(Df)
-        S = np.empty((B, N))
-        Vt = np.empty((B, N, N))
+        S = np.empty((B, N), dtype=dt)
+        Vt = np.empty((B, N, N), dtype=dt)
         sv = np.empty(B, dtype=np.int64)
         it = np.empty(B, dtype=np.int32)
         stt = np.empty(B, dtype=np.int32)
-        cost = np.empty(B)
+        cost = np.empty(B, dtype=dt)
         o = self.make_opts(iters=int(iters), **{k: v for k, v in kw.items()
                                                 if k in ("lam", "maxrank", "tol", "rho", "nonnegA", "nonnegE", "nukeA")})
-        st = self._check(self.lib.tlsq_rpca_batched_f64(self.h, _ptr(Df), M, N, B, C.byref(o), _ptr(A), _ptr(E),
-                                                        _ptr(S), _ptr(Vt), _ptr(sv), _ptr(it), _ptr(stt), _ptr(cost)))
+        st = self._check(fn(self.h, _ptr(Df), M, N, B, C.byref(o), _ptr(A), _ptr(E), _ptr(S), _ptr(Vt), _ptr(sv),
+                            _ptr(it), _ptr(stt), _ptr(cost)))
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached in {int(stt.sum())} of {B} problems")
         return (np.transpose(A, (0, 2, 1)), np.transpose(E, (0, 2, 1)), S, np.transpose(Vt, (0, 2, 1)), sv, it, stt,
                 cost)
 
     def rtls_batched(self, A, y, *, iters=1000, return_status=False, **kw):
-        """x[b] = rtls(A[b], y[b]) for a (batch, M, n) stack A and a (batch, M) or (batch, M, q) stack y."""
-        A = np.asarray(A, dtype=np.float64)
-        yv = np.asarray(y, dtype=np.float64)
+        """x[b] = rtls(A[b], y[b]) for a (batch, M, n) stack A and a (batch, M) or (batch, M, q) stack y (float32 when
+        both stacks are float32, float64 otherwise)."""
+        A = np.asarray(A)
+        yv = np.asarray(y)
+        dt = np.float32 if (A.dtype == np.float32 and yv.dtype == np.float32) else np.float64
+        A = A.astype(dt, copy=False)
+        yv = yv.astype(dt, copy=False)
+        fn = self.lib.tlsq_rtls_batched_f32 if dt == np.float32 else self.lib.tlsq_rtls_batched_f64
         B, M, n = A.shape
         y3 = yv.reshape(B, M, -1)
         q = y3.shape[2]
         Af = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
         yf = np.ascontiguousarray(np.transpose(y3, (0, 2, 1)))
-        x = np.empty((B, q, n))
+        x = np.empty((B, q, n), dtype=dt)
         it = np.empty(B, dtype=np.int32)
         stt = np.empty(B, dtype=np.int32)
         o = self.make_opts(iters=int(iters), **{k: v for k, v in kw.items()
                                                 if k in ("lam", "maxrank", "tol", "rho", "nonnegA", "nonnegE")})
-        st = self._check(self.lib.tlsq_rtls_batched_f64(self.h, _ptr(Af), _ptr(yf), M, n, q, B, C.byref(o), _ptr(x),
-                                                        _ptr(it), _ptr(stt)))
+        st = self._check(fn(self.h, _ptr(Af), _ptr(yf), M, n, q, B, C.byref(o), _ptr(x), _ptr(it), _ptr(stt)))
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached in {int(stt.sum())} of {B} problems")
         out = np.transpose(x, (0, 2, 1))
