@@ -103,6 +103,7 @@ enum WsSlot {
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
     WS_HKSUM,     // soft_hankel! on row shards: anti-diagonal sums and counts of the whole matrix (solver.hip)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
+    WS_T2, WS_VS2, WS_VS3,      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
@@ -139,6 +140,20 @@ int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T
 // 64 doubles -> the handle's mailbox ([8..72)), published with sequence number seq
 int launch_publish_slots(Handle* h, const double* slots, double seq);
 // rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored
+// E-free sweep and its companions (sweeps.hip: k_zsweep ...)
+template <typename T>
+int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
+                  int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
+                  double* sumsq, double* zero_slots, const T* hankel_y = nullptr, int64_t hankel_K = 0, int64_t row0 = 0,
+                  int64_t row1 = 0);
+template <typename T>
+int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
+                   int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y = nullptr,
+                   int64_t hankel_K = 0);
+template <typename T>
+int launch_residual_from_y(Handle* h, const T* Y1, const T* Y0, T* R, int64_t n, T inv_mu);
+template <typename T>
+int launch_z_from_y(Handle* h, const T* A, const T* Y1, T* Z, int64_t n, T inv_mu);
 template <typename T>
 bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r);
 template <typename T>

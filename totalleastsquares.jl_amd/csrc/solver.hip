@@ -290,23 +290,31 @@ struct SubspaceState {
 // that is still too coarse, a Lanczos run with the usual 1.5x safety factor follow synchronously - rarely.
 // ||S^(2^levels)||_F^2 of the symmetric S = GD through the general MFMA GEMM (slab reduction with the norm by-product),
 // partial sums read back and added on the host in order: the slow but general form (no mailbox, second squaring)
-static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out) {
+static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out, int first_level = 0) {
+    // out[l - first_level] = ||S^(2^l)||_F^2 for l = max(first_level, 1) .. levels (first_level 0: only the last one)
     const int64_t N = st.cert_N;
-    void *P1, *P2, *part;
-    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
-    TLSQ_TRY(ws_get(h, WS_CPART, (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * 8, &part));
+    void *P[2], *part;
+    const size_t pslots = (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2);
+    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P[0]));
+    if (levels >= 2) TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P[1]));
+    TLSQ_TRY(ws_get(h, WS_CPART, pslots * 8 * (size_t)std::max(1, levels), &part));
     int nb = 0;
-    TLSQ_TRY(gemm_mixed(h, true, true, st.cert_GD, 0, N, st.cert_GD, 0, N, P1, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
-    if (levels >= 2) {
-        TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P2));
-        TLSQ_TRY(gemm_mixed(h, true, true, P1, 0, N, P1, 0, N, P2, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
+    const double* src = st.cert_GD;
+    for (int l = 1; l <= levels; ++l) {
+        double* dst = (double*)P[(l - 1) & 1];
+        TLSQ_TRY(gemm_mixed(h, true, true, src, 0, N, src, 0, N, dst, 0, N, N, N, N, true, nullptr,
+                            (double*)part + (size_t)(l - 1) * pslots, &nb));
+        src = dst;
     }
-    std::vector<double> hp((size_t)nb);
-    TLSQ_HIP(h, hipMemcpyAsync(hp.data(), part, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> hp(pslots * (size_t)levels);
+    TLSQ_HIP(h, hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    double a = 0.0;
-    for (double v : hp) a += v;
-    *out = a;
+    const int l0 = first_level > 0 ? first_level : levels;
+    for (int l = l0; l <= levels; ++l) {
+        double a = 0.0;
+        for (int i = 0; i < nb; ++i) a += hp[(size_t)(l - 1) * pslots + (size_t)i];
+        out[l - l0] = a;
+    }
     return TLSQ_OK;
 }
 
@@ -372,7 +380,38 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
         *pass = true;
         return TLSQ_OK;
     }
-    // still too coarse (an eigenvalue within ~1.5x of the mark, or a very flat tail): a Lanczos run has the last word
+    // Still too coarse: the tail is flat and close to the mark (late iterations of a Hankel filter: hundreds of values
+    // at 0.7x the threshold).  Three more squarings bring the bound to rank^(1/64) above lambda_max, still rigorous;
+    // a Lanczos run (a LOWER bound, hence the 1.5x safety factor) screens first where an N^3 product is not small.
+    static const bool no_deep = [] { const char* e = getenv("TLSQ_NO_DEEP_POWERS"); return e && e[0] == '1'; }();
+    bool lanczos_done = false;
+    if (st.cert_N > 1024 || no_deep) {
+        const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
+        if (lst < 0) return lst;
+        ++st.n_lanczos_cert;
+        lanczos_done = true;
+        if (lmax * 1.5 < st.cert_margin) {
+            *pass = true;
+            st.cert_tail = 0.0;
+            return TLSQ_OK;
+        }
+        st.cert_tail = lmax;
+        if (lmax >= st.cert_margin || no_deep) return TLSQ_OK;   // an eigenvalue above the mark: the count is wrong
+    }
+    double c[3] = {0.0, 0.0, 0.0};
+    TLSQ_TRY(power_norm_sync(h, st, 5, c, 3));
+    const double inf = std::numeric_limits<double>::infinity();
+    const double b3 = std::isfinite(c[0]) ? std::pow(c[0], 1.0 / 16.0) : inf;
+    const double b4 = std::isfinite(c[1]) ? std::pow(c[1], 1.0 / 32.0) : inf;
+    const double b5 = std::isfinite(c[2]) ? std::pow(c[2], 1.0 / 64.0) : inf;
+    if (dbg) fprintf(stderr, "  power certificate: bound3=%.4f bound4=%.4f bound5=%.4f\n", b3, b4, b5);
+    if (std::min(b3, std::min(b4, b5)) < st.cert_margin) {
+        ++st.n_power_l2;
+        *pass = true;
+        st.cert_tail = 0.0;
+        return TLSQ_OK;
+    }
+    if (lanczos_done) return TLSQ_OK;
     const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
     if (lst < 0) return lst;
     ++st.n_lanczos_cert;
@@ -756,15 +795,17 @@ static int svd_subspace_certify(Handle* h, SubspaceState& st, double inv_mu, boo
 template <typename T>
 static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,
                            const std::vector<int32_t>& sel, const std::vector<double>& g, const double** Tm_out,
-                           const double** Vs_out) {
+                           const double** Vs_out, int slot = 0) {
     const int64_t r = (int64_t)sel.size();
     *Tm_out = nullptr;
     *Vs_out = nullptr;
     if (r == 0) return TLSQ_OK;
     void *Vg, *Vs, *T1, *aux;
     TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * r * 8, &Vg));
-    TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * r * 8, &Vs));
-    TLSQ_TRY(ws_get(h, WS_T, (size_t)M * r * 8, &T1));
+    // (slot 1 / 2: buffers of the E-free loop, which keeps the previous iteration's factors alive through the next SVD step
+    //  - WS_VS itself is scratch of the count certificate in svd_subspace)
+    TLSQ_TRY(ws_get(h, slot == 1 ? WS_VS2 : slot == 2 ? WS_VS3 : WS_VS, (size_t)N * r * 8, &Vs));
+    TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : WS_T, (size_t)M * r * 8, &T1));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
     TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
@@ -877,16 +918,32 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
     TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
     T *Y = (T*)Yv, *R = (T*)Rv;
-    // E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
+    static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
+    static const bool no_zsweep = [] { const char* e = getenv("TLSQ_NO_ZSWEEP"); return e && e[0] == '1'; }();
+    static const bool no_first = [] { const char* e = getenv("TLSQ_NO_FIRST_SHRINK"); return e && e[0] == '1'; }();
+    // The E-free loop (sweeps.hip, k_zsweep): E is not kept while the loop runs - Z is updated in place, Y is double-buffered
+    // (the caller's E panel is the second buffer) and the factors of the previous A are kept, from which the returned E is
+    // formed once after the loop.  Every plain call runs this way; the `hankel` flag (A is modified after the rebuild) and
+    // the svd / opnorm hooks keep the classic sweeps with their E and Z double buffers.
+    const bool zmode = !no_zsweep && !no_fuse && !no_first && !ro.hankel && ro.iters >= 1 &&
+                       !(opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT));
+    // classic loop: E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
     // must survive in case iteration k is the last one
-    void *E2v, *Z2v;
-    TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
-    TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+    void *E2v = nullptr, *Z2v = nullptr;
+    if (!zmode) {
+        TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
+        TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+    }
     T* Ebuf[2] = {E, (T*)E2v};
-    T* Zbuf[2] = {(T*)Zv, (T*)Z2v};
+    T* Zbuf[2] = {(T*)Zv, zmode ? (T*)Zv : (T*)Z2v};   // (E-free loop: one Z, both entries)
+    T* Ybuf[2] = {Y, E};         // E-free loop: Y_k sits in Ybuf[ycur], the sweep writes Y_{k+1} to the other one
+    int ycur = 0;
+    const double *Tm_prev = nullptr, *Vs_prev = nullptr;   // factors of A_{k-1} (E-free loop)
+    int64_t r_prev = 0;
+    bool z_swept = false;        // the last iteration ended with an E-free sweep (Z holds Z_{k+1}, E_k is not formed yet)
+    double mu_iter = 0.0;        // mu of the last iteration that ran
     int cur = 0;                 // index of the buffers holding E_k, Z_k
     bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
-    static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
     static const bool no_fuse_rebuild = [] { const char* e = getenv("TLSQ_NO_FUSED_REBUILD"); return e && e[0] == '1'; }();
     static const bool no_cert_overlap = [] { const char* e = getenv("TLSQ_NO_CERT_OVERLAP"); return e && e[0] == '1'; }();
     const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
@@ -926,6 +983,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // hooks) get a real panel built on demand.
     const T* Dm = D;
     bool d_transient = false;
+    const double lam_f = ro.lambda;
     auto build_hankel = [&](T* dst) -> int {
         const int64_t Kh = ro.hankel_K, Nw = Kh - 1 + N;
         if (Kh != M) TLSQ_HIP(h, hipMemsetAsync(dst, 0, (size_t)n * sizeof(T), h->stream));
@@ -942,10 +1000,31 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         *out = Dm;
         return TLSQ_OK;
     };
+    // E-free loop: E_k = soft_th(D - A_{k-1} + Y_k / mu_k, lambda / mu_k) (:188-191) into the caller's panel, A_{k-1} from the
+    // kept factors (above 32 columns through memory: the residual panel is free whenever this runs)
+    auto form_final_e = [&](const T* Yk, double mu_k) -> int {
+        const T* Aprev = nullptr;
+        const T* hy = (const T*)ro.hankel_y;
+        if (r_prev > 32) {
+            TLSQ_TRY(rebuild_from_factors<T>(h, Tm_prev, Vs_prev, M, N, r_prev, R, M));
+            if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, R, n));
+            Aprev = R;
+            hy = nullptr;
+        }
+        const T* Dp = nullptr;
+        if (!hy) {
+            TLSQ_TRY(panel_D(&D));
+            Dp = D;
+        }
+        return launch_final_e<T>(h, Dp, Tm_prev, Vs_prev, Aprev, Yk, Ebuf[0], M, N, r_prev, (T)(1.0 / mu_k), (T)(lam_f / mu_k),
+                                 ro.nonnegA ? 1 : 0, ro.nonnegE ? 1 : 0, hy, ro.hankel_K);
+    };
     if (!D) {
         if (!ro.hankel_lazy || !ro.hankel_y) return set_err(h, TLSQ_ERR_ARG, "rpca: no data panel");
-        TLSQ_TRY(build_hankel(Zbuf[1]));
-        Dm = Zbuf[1];
+        // (E-free loop: R is written for the first time by the first sweep, which reads y itself)
+        T* spare = zmode ? R : Zbuf[1];
+        TLSQ_TRY(build_hankel(spare));
+        Dm = spare;
         d_transient = true;
     }
     D = Dm;   // (set-up below; every later use goes through panel_D or the implicit kernels)
@@ -981,7 +1060,6 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const double d_norm = norm2;                                   // :180
     // :181 Y = D / dual_norm is folded into the first shrink (launch_first_shrink, one pass over D instead of three)
     bool y_pending = true;
-    static const bool no_first = [] { const char* e = getenv("TLSQ_NO_FIRST_SHRINK"); return e && e[0] == '1'; }();
     if (no_first) {
         TLSQ_TRY(launch_div_scalar<T>(h, D, Y, n, (T)dual_norm));      // :181
         y_pending = false;
@@ -1085,14 +1163,22 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const double thr = lam / mu;
         T* E = Ebuf[cur];
         T* Z = Zbuf[cur];
+        mu_iter = mu;
+        z_swept = false;
+        if (zmode) {   // what the previous iteration left as "last" is A_{k-1} now; this iteration's factors go to the other pair
+            Tm_prev = Tm_last;
+            Vs_prev = Vs_last;
+            r_prev = r_last;
+        }
         pt.mark(false, !have_next);
         if (!have_next)
         {
             if (!(d_transient && k == 1)) TLSQ_TRY(panel_D(&D));   // (iteration 1 may still read the transient copy)
             if (y_pending) {   // k = 1: A is zero and Y not formed yet
-                TLSQ_TRY(launch_first_shrink<T>(h, D, Y, E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));
+                TLSQ_TRY(launch_first_shrink<T>(h, D, Y, zmode ? (T*)nullptr : E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr,
+                                                ro.nonnegE ? 1 : 0));
                 y_pending = false;
-                hbm_sweeps += 4.0 * panel_bytes;
+                hbm_sweeps += (zmode ? 3.0 : 4.0) * panel_bytes;
             } else {
                 TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
                 hbm_sweeps += 5.0 * panel_bytes;
@@ -1133,9 +1219,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             fuse = !no_fuse && k < ro.iters;
             // large panels: A = T Vs' is not written at all, the fused sweep below forms it in registers from the
             // factors (7 panel passes per iteration instead of 8 + the pass of the skinny GEMM that writes A)
-            fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
-                           rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
-            TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last));
+            if (zmode) fuse_rebuild = fuse && svp <= 32;   // (A in registers; above 32 columns it is stored and read back)
+            else
+                fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
+                               rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
+            TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last, zmode ? ((k & 1) ? 1 : 2) : 0));
             r_last = svp;
             if (svp > 0) hbm_other += panel_bytes;                      // T = Z Vg reads Z once
             if (!fuse_rebuild) {
@@ -1363,7 +1451,41 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                             !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram;
         bool gram_queued = false;
-        if (fuse_rebuild) {
+        // one launch of the fused sweep over rows [r0, r1) (r1 = 0: the whole panel): E-free form or classic form
+        const T* hy_sweep = (const T*)ro.hankel_y;
+        if (zmode && fuse) {
+            if (!fuse_rebuild) hy_sweep = nullptr;           // A from memory: the linear kernel reads a real D
+            if (!hy_sweep) TLSQ_TRY(panel_D(&D));
+        }
+        auto sweep_rows = [&](int64_t r0, int64_t r1, size_t pad_lds) -> int {
+            if (zmode)
+                return launch_zsweep<T>(h, D, Tm_last, Vs_last, fuse_rebuild ? (T*)nullptr : A, Ybuf[ycur], Ybuf[ycur ^ 1],
+                                        Zbuf[0], Rst, M, N, svp, (T)mu, (T)inv_mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                        (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K,
+                                        r0, r1);
+            return launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp,
+                                                   (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
+                                                   ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, (const T*)ro.hankel_y,
+                                                   ro.hankel_K, r0, r1, pad_lds);
+        };
+        if (zmode && !fuse) {
+            // the last allowed iteration (no next shrink to fuse with): E_k is formed now, then the plain residual :217-221
+            TLSQ_TRY(form_final_e(Ybuf[ycur], mu));
+            if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+            if (ro.hankel_y && (!Dm || d_transient)) {
+                TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, Ebuf[0], R, M, N));
+                hbm_sweeps += 6.0 * panel_bytes;
+            } else {
+                TLSQ_TRY(panel_D(&D));
+                TLSQ_TRY(launch_residual<T>(h, D, A, Ebuf[0], R, n));
+                hbm_sweeps += 7.0 * panel_bytes;
+            }
+        } else if (zmode && !fuse_rebuild) {
+            // A_k above 32 columns: stored by the rebuild, read back here (6 panel passes + R)
+            TLSQ_TRY(sweep_rows(0, 0, 0));
+            z_swept = true;
+            hbm_sweeps += (Rst ? 7.0 : 6.0) * panel_bytes;
+        } else if (fuse_rebuild) {
             // :205-213 (in registers), :217-222 and the next iteration's :188-192 in a single pass over the panels.
             // Very large panels: the sweep is HBM-bound, the Gram of what it writes MFMA-bound, and each takes many
             // milliseconds - the sweep goes row chunk by row chunk and the Gram of a finished chunk runs beside the sweep
@@ -1387,11 +1509,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
                 for (int c = 0; c < nchunks; ++c) {
                     const int64_t r0 = std::min<int64_t>((int64_t)c * rows_c, M), r1 = std::min<int64_t>(r0 + rows_c, M);
-                    if (r1 > r0)
-                        TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M,
-                                                                 N, svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
-                                                                 (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
-                                                                 (const T*)ro.hankel_y, ro.hankel_K, r0, r1, pad_lds));
+                    if (r1 > r0) TLSQ_TRY(sweep_rows(r0, r1, pad_lds));
                     TLSQ_HIP(h, hipEventRecord(h->ev_b[c], h->stream));
                     TLSQ_HIP(h, hipStreamWaitEvent(h->stream_b, h->ev_b[c], 0));
                     TLSQ_TRY(gram_launch_chunk(h, h->stream_b, pl, Zbuf[cur ^ 1] + r0, M, r1 - r0, c));
@@ -1400,12 +1518,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_HIP(h, hipEventRecord(h->ev_b[8], h->stream_b));
                 gram_queued = true;   // (h->stream waits for ev_b[8] below, behind the publication of the Frobenius sums)
             } else {
-                TLSQ_TRY(launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N,
-                                                         svp, (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
-                                                         (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next,
-                                                         (const T*)ro.hankel_y, ro.hankel_K));
+                TLSQ_TRY(sweep_rows(0, 0, 0));
             }
-            hbm_sweeps += ((Rst ? 7.0 : 6.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
+            if (zmode) z_swept = true;
+            hbm_sweeps += ((Rst ? 7.0 : 6.0) - (zmode ? 1.0 : 0.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(panel_D(&D));
@@ -1478,6 +1594,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             if (lower > 2.0 * ro.tol) {
                 cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
                 cost_skipped = true;
+            } else if (!store_R && zmode) {
+                // mispredicted (E-free loop): R_k = (Y_{k+1} - Y_k) / mu_k
+                TLSQ_TRY(launch_residual_from_y<T>(h, Ybuf[ycur ^ 1], Ybuf[ycur], R, n, (T)(1.0 / mu_iter)));
+                hbm_sweeps += 3.0 * panel_bytes;
             } else if (!store_R) {
                 // mispredicted: the residual is needed after all.  R_k = D - A_k - E_k (A_k possibly still in factors)
                 if (a_pending) {
@@ -1560,7 +1680,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             break;
         }
         if (fuse) {
-            cur ^= 1;
+            if (zmode) ycur ^= 1;   // (Z was updated in place)
+            else cur ^= 1;
             have_next = true;
         } else {
             have_next = false;
@@ -1573,6 +1694,16 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     if (a_pending) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
         TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
         if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
+    }
+    if (zmode && z_swept) {
+        // The E-free loop stopped behind a sweep: Y_k in Ybuf[ycur], Y_{k+1} in the other buffer, Z already Z_{k+1}.
+        // Z_k = A_k + Y_{k+1} / mu_k for the returned decomposition (:194, :238), then E_k over whichever Y buffer E is.
+        if (S_host || Vt_host || U_dev) {
+            TLSQ_TRY(launch_z_from_y<T>(h, A, Ybuf[ycur ^ 1], Zbuf[0], n, (T)(1.0 / mu_iter)));
+            hbm_sweeps += 3.0 * panel_bytes;
+        }
+        TLSQ_TRY(form_final_e(Ybuf[ycur], mu_iter));
+        hbm_sweeps += (ro.hankel_y && r_prev <= 32 ? 2.0 : 3.0) * panel_bytes;
     }
     if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));

@@ -278,6 +278,242 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
     }
 }
 
+// ---- the E-free sweep -------------------------------------------------------------------------------------------------
+// The loop state of the reference is (A, E, Y, mu), and Z_k = D - E_k + Y_k / mu_k is what the SVD step reads.  Two
+// identities of the iteration (src/robustPCA.jl:188-222) make E redundant while the loop runs:
+//     R_k     = D - A_k - E_k            = (Z_k - A_k) - Y_k / mu_k                      (:221)
+//     Y_{k+1} = Y_k + mu_k R_k           = mu_k (Z_k - A_k)                              (:222)
+// so update(k) + shrink(k+1) needs D, A_k (from its factors, in registers), Y_k and Z_k and produces Y_{k+1} and Z_{k+1}
+// (in place): 5 panel passes (4 with an implicit Hankel D) instead of the 7 (+ the store of A) of the sweeps above.  E_{k+1}
+// exists only in registers; the caller forms the E it returns once, after the loop, with the reference's own statement
+// E_k = soft_th(D - A_{k-1} + Y_k / mu_k, lambda / mu_k) (k_final_e: exact zeros where the reference has them) from the
+// previous iteration's factors and Y_k - which is why Y is double-buffered here instead of E and Z.  The two identities
+// hold up to the rounding of Z (one ulp of |D|), the same size as the rounding of the reference's own statements.
+template <typename T, int RMAX, int ROWS, bool HK>
+__global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const double* __restrict__ Tm,
+                                                const double* __restrict__ Vs, const T* __restrict__ Yin,
+                                                T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t M,
+                                                int N, int r, int ct, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n,
+                                                int nonnegE, double* __restrict__ sumsq, double* __restrict__ zero_slots,
+                                                int64_t hankel_K, int64_t row0, int64_t row1) {
+    using VR = T __attribute__((ext_vector_type(ROWS)));
+    if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
+    __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
+    const int c0 = blockIdx.y * ct;
+    const int nct = (N - c0 < ct) ? N - c0 : ct;
+    for (int e = threadIdx.x; e < ct * RMAX; e += 256) {
+        const int c = e / RMAX, i = e % RMAX;
+        sVs[e] = (c < nct && i < r) ? Vs[(size_t)(c0 + c) + (size_t)i * N] : 0.0;
+    }
+    __syncthreads();
+    const int64_t row = row0 + ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;   // ROWS = 2: M, row0, row1 are even (launcher)
+    double ss = 0.0;
+    if (row < row1) {
+        double t[ROWS][RMAX];
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) t[q][i] = i < r ? Tm[row + q + (size_t)i * M] : 0.0;
+#pragma unroll 4
+        for (int c = 0; c < nct; ++c) {
+            const int64_t idx = (row + (int64_t)(c0 + c) * M) / ROWS;
+            VR d;
+            if constexpr (HK) {
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+            } else {
+                d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
+            }
+            const VR z = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Z) + idx);
+            const VR y = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Yin) + idx);
+            const double* vs = sVs + c * RMAX;
+            double acc[ROWS];
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) acc[q] = __builtin_fma(t[q][i], vs[i], acc[q]);
+            VR rr, yn, zn;
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                T a = (T)acc[q];
+                if (nonnegA) a = pos_part(a);                // A .= max.(A,0)                          :217-219
+                const T w = z[q] - a;
+                const T res = w - inv_mu * y[q];             // R_k = D - A - E                         :221
+                ss += (double)res * (double)res;
+                rr[q] = res;
+                const T y1 = mu * w;                         // Y_{k+1} = Y + mu R                      :222
+                yn[q] = y1;
+                const T tt = inv_mu_n * y1;                  // next iteration, mu_{k+1}                :188
+                T ee = soft_th((d[q] - a) + tt, thr_n);
+                if (nonnegE) ee = pos_part(ee);              //                                         :189-191
+                zn[q] = (d[q] - ee) + tt;                    //                                         :192
+            }
+            if (R) __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
+            __builtin_nontemporal_store(yn, reinterpret_cast<VR*>(Yout) + idx);
+            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Z) + idx);
+        }
+    }
+    if (sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+        __shared__ double sw[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) sw[w] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicAdd(sumsq + ((blockIdx.x + blockIdx.y) & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+    }
+}
+
+// the same sweep with A_k read from memory (ranks above 32: A does not fit a thread's registers as factors)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* __restrict__ A, const T* __restrict__ Yin,
+                                                    T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t n,
+                                                    T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
+                                                    double* __restrict__ sumsq, double* __restrict__ zero_slots) {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
+    const int64_t nv = n / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double ss = 0.0;
+    auto one = [&](T d, T& a, T y, T z, T& res, T& y1, T& zn) {
+        if (nonnegA) a = pos_part(a);
+        const T w = z - a;
+        res = w - inv_mu * y;
+        ss += (double)res * (double)res;
+        y1 = mu * w;
+        const T tt = inv_mu_n * y1;
+        T ee = soft_th((d - a) + tt, thr_n);
+        if (nonnegE) ee = pos_part(ee);
+        zn = (d - ee) + tt;
+    };
+    for (int64_t i = tid; i < nv; i += stride) {
+        const V d = __builtin_nontemporal_load(reinterpret_cast<const V*>(D) + i);
+        V a = __builtin_nontemporal_load(reinterpret_cast<const V*>(A) + i);
+        const V y = __builtin_nontemporal_load(reinterpret_cast<const V*>(Yin) + i);
+        const V z = __builtin_nontemporal_load(reinterpret_cast<const V*>(Z) + i);
+        V rr, yn, zn;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            T ac = a[c], r1, y1, z1;
+            one(d[c], ac, y[c], z[c], r1, y1, z1);
+            a[c] = ac;
+            rr[c] = r1;
+            yn[c] = y1;
+            zn[c] = z1;
+        }
+        if (nonnegA) __builtin_nontemporal_store(a, reinterpret_cast<V*>(A) + i);
+        if (R) __builtin_nontemporal_store(rr, reinterpret_cast<V*>(R) + i);
+        __builtin_nontemporal_store(yn, reinterpret_cast<V*>(Yout) + i);
+        __builtin_nontemporal_store(zn, reinterpret_cast<V*>(Z) + i);
+    }
+    for (int64_t i = nv * VEC + tid; i < n; i += stride) {
+        T ac = A[i], r1, y1, z1;
+        one(D[i], ac, Yin[i], Z[i], r1, y1, z1);
+        if (nonnegA) A[i] = ac;
+        if (R) R[i] = r1;
+        Yout[i] = y1;
+        Z[i] = z1;
+    }
+    if (sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+        __shared__ double sw[4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) sw[w] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq + (blockIdx.x & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+    }
+}
+
+// E = soft_th(D - A_prev + Y / mu, lambda / mu) (:188-191) once after the E-free loop, A_prev = Tm Vs' from the factors of the
+// previous iteration (r = 0: A_prev = 0, the first iteration).  E may be the buffer Y lives in (same element read, then
+// written): no __restrict__ on the two.
+template <typename T, int RMAX, int ROWS, bool HK>
+__global__ __launch_bounds__(256) void k_final_e(const T* __restrict__ D, const double* __restrict__ Tm,
+                                                 const double* __restrict__ Vs, const T* Y, T* E, int64_t M, int N, int r,
+                                                 int ct, T inv_mu, T thr, int nonnegA, int nonnegE, int64_t hankel_K) {
+    using VR = T __attribute__((ext_vector_type(ROWS)));
+    __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
+    const int c0 = blockIdx.y * ct;
+    const int nct = (N - c0 < ct) ? N - c0 : ct;
+    for (int e = threadIdx.x; e < ct * RMAX; e += 256) {
+        const int c = e / RMAX, i = e % RMAX;
+        sVs[e] = (c < nct && i < r) ? Vs[(size_t)(c0 + c) + (size_t)i * N] : 0.0;
+    }
+    __syncthreads();
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;
+    if (row >= M) return;
+    double t[ROWS][RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) t[q][i] = i < r ? Tm[row + q + (size_t)i * M] : 0.0;
+#pragma unroll 4
+    for (int c = 0; c < nct; ++c) {
+        const int64_t idx = (row + (int64_t)(c0 + c) * M) / ROWS;
+        VR d;
+        if constexpr (HK) {
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+        } else {
+            d = reinterpret_cast<const VR*>(D)[idx];
+        }
+        const VR y = reinterpret_cast<const VR*>(Y)[idx];
+        const double* vs = sVs + c * RMAX;
+        double acc[ROWS];
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) acc[q] = __builtin_fma(t[q][i], vs[i], acc[q]);
+        VR en;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            T a = (T)acc[q];
+            if (nonnegA) a = pos_part(a);
+            T ee = soft_th((d[q] - a) + inv_mu * y[q], thr);
+            if (nonnegE) ee = pos_part(ee);
+            en[q] = ee;
+        }
+        reinterpret_cast<VR*>(E)[idx] = en;
+    }
+}
+
+// ... and with A_prev in memory (ranks above 32)
+template <typename T>
+__global__ __launch_bounds__(256) void k_final_e_lin(const T* __restrict__ D, const T* __restrict__ A, const T* Y, T* E,
+                                                     int64_t n, T inv_mu, T thr, int nonnegE) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T ee = soft_th((D[i] - A[i]) + inv_mu * Y[i], thr);
+        if (nonnegE) ee = pos_part(ee);
+        E[i] = ee;
+    }
+}
+
+// R_k = (Y_{k+1} - Y_k) / mu_k (:222 solved for the residual): only when an E-free sweep was told not to store R_k and
+// the cost evaluation wants it after all
+template <typename T>
+__global__ __launch_bounds__(256) void k_residual_from_y(const T* __restrict__ Y1, const T* __restrict__ Y0,
+                                                         T* __restrict__ R, int64_t n, T inv_mu) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) R[i] = (Y1[i] - Y0[i]) * inv_mu;
+}
+
+// Z_k = A_k + Y_{k+1} / mu_k (:222 with the second identity above): the panel whose SVD the call returns, rebuilt once after
+// an E-free loop whose last sweep already overwrote it with Z_{k+1}
+template <typename T>
+__global__ __launch_bounds__(256) void k_z_from_y(const T* __restrict__ A, const T* __restrict__ Y1, T* __restrict__ Z,
+                                                  int64_t n, T inv_mu) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) Z[i] = A[i] + Y1[i] * inv_mu;
+}
+
 // A (M x N, ld M) = Tm Vs' alone: the store-bound form of the rebuild (src/robustPCA.jl:207-208 / 211-212) for the
 // panels that keep A in memory (C2 size).  Same walk as above: a thread owns two consecutive rows of T in registers,
 // the Vs tile is broadcast from LDS, every store is 16 bytes per lane and 1 KB contiguous per wave.  The 128 x 128
@@ -510,7 +746,7 @@ __global__ __launch_bounds__(256) void k_first_shrink(const T* __restrict__ D, T
             z[c] = (d[c] - ee) + t;                   //                                        :192
         }
         reinterpret_cast<V*>(Y)[i] = y;
-        reinterpret_cast<V*>(E)[i] = e;
+        if (E) reinterpret_cast<V*>(E)[i] = e;   // (E == nullptr: the E-free loop below never reads E_1)
         reinterpret_cast<V*>(Z)[i] = z;
     }
     for (int64_t i = nv * VEC + tid; i < n; i += stride) {
@@ -519,7 +755,7 @@ __global__ __launch_bounds__(256) void k_first_shrink(const T* __restrict__ D, T
         T ee = soft_th(D[i] + t, thr);
         if (nonnegE) ee = pos_part(ee);
         Y[i] = y;
-        E[i] = ee;
+        if (E) E[i] = ee;
         Z[i] = (D[i] - ee) + t;
     }
 }
@@ -637,6 +873,124 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
     return TLSQ_OK;
 }
 
+// E-free sweep (k_zsweep): A_k from its factors (A == nullptr, r <= 32) or from memory (A != nullptr; D must be a real panel
+// and the row range the whole panel).  Rows [row0, row1), row1 <= 0: all.
+template <typename T>
+int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
+                  int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
+                  double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K, int64_t row0, int64_t row1) {
+    if (M <= 0 || N <= 0) return TLSQ_OK;
+    if (row1 <= 0) row1 = M;
+    if (A) {
+        if (hankel_y || row0 != 0 || row1 != M) return set_err(h, TLSQ_ERR_ARG, "zsweep: explicit A needs the whole real panel");
+        const int64_t n = M * N;
+        constexpr int VEC = 16 / sizeof(T);
+        if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(R))
+            hipLaunchKernelGGL((k_zsweep_lin<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z,
+                               R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
+        else
+            hipLaunchKernelGGL((k_zsweep_lin<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z, R, n, mu,
+                               inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    if (r > 32 || N > 2147483647LL) return set_err(h, TLSQ_ERR_ARG, "zsweep: rank above 32 needs the explicit A");
+    const bool pair_ok = (M % 2 == 0) && (row0 % 2 == 0) && (row1 % 2 == 0) && (hankel_y || aligned16(D)) && aligned16(Yin) &&
+                         aligned16(Yout) && aligned16(Z) && aligned16(R);
+    if (row0 < 0 || row0 >= row1 || row1 > M) return set_err(h, TLSQ_ERR_ARG, "zsweep: bad row range");
+    const int64_t want_waves = 4096;
+    bool two = pair_ok && (M / 128) * ((N + 63) / 64) >= 2 * want_waves;
+    int ct = 64;
+    if (!two)
+        while (ct > 8 && ((M + 63) / 64) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
+    static const int env_rows = [] { const char* e = getenv("TLSQ_RUS_ROWS"); return e ? atoi(e) : 0; }();   // tuning knobs
+    static const int env_ct = [] { const char* e = getenv("TLSQ_RUS_CT"); return e ? atoi(e) : 0; }();
+    if (env_rows == 1) two = false;
+    if (env_rows == 2 && pair_ok) two = true;
+    if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
+    const int rows = two ? 2 : 1;
+    const dim3 grid((unsigned)(((row1 - row0) / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
+#define ZS_LAUNCH(RM, RW)                                                                                             \
+    do {                                                                                                              \
+        if (hankel_y)                                                                                                 \
+            hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, R, \
+                               M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
+                               hankel_K, row0, row1);                                                                 \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, R, M, \
+                               (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots,   \
+                               (int64_t)0, row0, row1);                                                               \
+    } while (0)
+    if (two) {
+        if (r <= 8) ZS_LAUNCH(8, 2);
+        else if (r <= 16) ZS_LAUNCH(16, 2);
+        else ZS_LAUNCH(32, 2);
+    } else {
+        if (r <= 8) ZS_LAUNCH(8, 1);
+        else if (r <= 16) ZS_LAUNCH(16, 1);
+        else ZS_LAUNCH(32, 1);
+    }
+#undef ZS_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// E = soft_th(D - A_prev + inv_mu Y, thr): A_prev from factors (Aprev == nullptr, r <= 32; r = 0: zero) or from memory
+template <typename T>
+int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
+                   int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y, int64_t hankel_K) {
+    if (M <= 0 || N <= 0) return TLSQ_OK;
+    if (Aprev) {
+        if (hankel_y) return set_err(h, TLSQ_ERR_ARG, "final_e: explicit A needs the real panel");
+        hipLaunchKernelGGL((k_final_e_lin<T>), dim3(grid_for(M * N)), dim3(256), 0, h->stream, D, Aprev, Y, E, M * N, inv_mu,
+                           thr, nonnegE);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
+    if (r > 32 || N > 2147483647LL) return set_err(h, TLSQ_ERR_ARG, "final_e: rank above 32 needs the explicit A");
+    const bool two = (M % 2 == 0) && (hankel_y || aligned16(D)) && aligned16(Y) && aligned16(E);
+    const int ct = 32;
+    const int rows = two ? 2 : 1;
+    const dim3 grid((unsigned)((M / rows + 255) / 256 + 1), (unsigned)((N + ct - 1) / ct));
+#define FE_LAUNCH(RM, RW)                                                                                             \
+    do {                                                                                                              \
+        if (hankel_y)                                                                                                 \
+            hipLaunchKernelGGL((k_final_e<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Y, E, M,  \
+                               (int)N, (int)r, ct, inv_mu, thr, nonnegA, nonnegE, hankel_K);                          \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_final_e<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Y, E, M, (int)N, \
+                               (int)r, ct, inv_mu, thr, nonnegA, nonnegE, (int64_t)0);                                \
+    } while (0)
+    if (two) {
+        if (r <= 8) FE_LAUNCH(8, 2);
+        else if (r <= 16) FE_LAUNCH(16, 2);
+        else FE_LAUNCH(32, 2);
+    } else {
+        if (r <= 8) FE_LAUNCH(8, 1);
+        else if (r <= 16) FE_LAUNCH(16, 1);
+        else FE_LAUNCH(32, 1);
+    }
+#undef FE_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_residual_from_y(Handle* h, const T* Y1, const T* Y0, T* R, int64_t n, T inv_mu) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_residual_from_y<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, Y1, Y0, R, n, inv_mu);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_z_from_y(Handle* h, const T* A, const T* Y1, T* Z, int64_t n, T inv_mu) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_z_from_y<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, A, Y1, Z, n, inv_mu);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int launch_publish_slots(Handle* h, const double* slots, double seq) {
     hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, h->stream, slots, h->mailbox_dev, seq);
     TLSQ_HIP(h, hipGetLastError());
@@ -742,6 +1096,13 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
                                                  T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*, \
                                                  const T*, int64_t, int64_t, int64_t, size_t);                        \
+    template int launch_zsweep<T>(Handle*, const T*, const double*, const double*, T*, const T*, T*, T*, T*, int64_t, \
+                                  int64_t, int64_t, T, T, int, T, T, int, double*, double*, const T*, int64_t, int64_t, \
+                                  int64_t);                                                                            \
+    template int launch_final_e<T>(Handle*, const T*, const double*, const double*, const T*, const T*, T*, int64_t, \
+                                   int64_t, int64_t, T, T, int, int, const T*, int64_t);                              \
+    template int launch_residual_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                              \
+    template int launch_z_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                                     \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
