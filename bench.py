@@ -179,7 +179,13 @@ def main():
                          (Ml * N >= 1 << 26 or os.environ.get("TLSQ_FUSED_REBUILD", "0") == "1"))
         array_bytes = float(Ml) * N * 8
         sweep_passes = 7.0 if fused_rebuild else 8.0
-        if fused:
+        # the shipped default: the E-free sweep (k_zsweep) - A from its factors in registers, E never stored while the loop
+        # runs: R D,Y,Z / W R,Y',Z' = 6 passes (5 without the residual store); k_first_shrink R D / W Y,Z = 3 passes.
+        # (The returned E is formed once after the loop, outside the two timed phases: not counted here.)
+        zsweep = fused and os.environ.get("TLSQ_NO_ZSWEEP", "0") != "1" and os.environ.get("TLSQ_NO_FIRST_SHRINK", "0") != "1"
+        if zsweep:
+            alg_bytes = (3.0 * args.steps + 6.0 * iters_total - rskip_total) / iters_total * array_bytes
+        elif fused:
             # sweeps that were told not to store the residual panel moved one pass less
             first_passes = 5.0 if os.environ.get("TLSQ_NO_FIRST_SHRINK", "0") == "1" else 4.0
             alg_bytes = (first_passes * args.steps + sweep_passes * iters_total - rskip_total) / iters_total * array_bytes
@@ -199,7 +205,8 @@ def main():
                        "call": "plain (non-verbose) call: no per-iteration cost history is requested, so opnorm(residual) is "
                                "only resolved far enough to settle cost < tol; identical iterations and outputs "
                                "(tests/test_gpu_parity.py::test_rpca_device_mode_and_decision_only_cost)"},
-            "roofline": {"kernel": ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_first_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_first_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_zsweep (E-free fused rebuild + ALM sweep) + k_first_shrink at k=1" if zsweep else
+                                   ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_first_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_first_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
                          "passes_per_iter": alg_bytes / array_bytes, "sweeps_without_residual_store": rskip_total,
@@ -244,7 +251,7 @@ def main():
                     pmc = json.load(f)
                 if Ml == 20000 and N == 512:
                     sk = pmc["sweep_kernels"]
-                    kname = "k_rebuild_update_shrink" if fused_rebuild else "k_update_shrink"
+                    kname = "k_zsweep" if zsweep else "k_rebuild_update_shrink" if fused_rebuild else "k_update_shrink"
                     if fused and kname in sk:   # PMC average over the launches of one solve (with and without the R store)
                         first = sk.get("k_first_shrink", sk.get("k_shrink"))
                         tr = (first["hbm_bytes_per_launch"] +

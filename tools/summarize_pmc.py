@@ -51,7 +51,7 @@ def main():
         per = {}
         for r in rows:
             short = r[0].split("tlsq::")[1].split("<")[0].split("(")[0]
-            if short in ("k_shrink", "k_first_shrink", "k_update", "k_update_shrink", "k_rebuild_update_shrink"):
+            if short in ("k_shrink", "k_first_shrink", "k_update", "k_update_shrink", "k_rebuild_update_shrink", "k_zsweep", "k_zsweep_lin", "k_final_e"):
                 per[short] = {"dispatches": r[1], "hbm_bytes_per_launch": r[6]}
         with open(out_json, "w") as fh:
             json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled "

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows = [r for r in rows if "tlsq::" in r["Kernel_Name"] or "rocclr" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # iterations are delimited by the Gram kernel of Z (k_gemm_f64<true, true...>) that follows a sweep
-marks = [i for i, r in enumerate(rows) if "k_update_shrink" in r["Kernel_Name"] or "k_rebuild_update_shrink" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "k_update_shrink" in r["Kernel_Name"] or "k_rebuild_update_shrink" in r["Kernel_Name"] or "k_zsweep" in r["Kernel_Name"]]
 it = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) // 2
 lo, hi = marks[it] , marks[it + 1] + 1
 t0 = int(rows[lo]["Start_Timestamp"])

@@ -898,11 +898,12 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
     const bool pair_ok = (M % 2 == 0) && (row0 % 2 == 0) && (row1 % 2 == 0) && (hankel_y || aligned16(D)) && aligned16(Yin) &&
                          aligned16(Yout) && aligned16(Z) && aligned16(R);
     if (row0 < 0 || row0 >= row1 || row1 > M) return set_err(h, TLSQ_ERR_ARG, "zsweep: bad row range");
+    // two rows per thread (16-byte accesses for fp64) whenever the panels allow it; 64-column tiles for tall panels, narrower
+    // ones until ~16 waves sit on every CU (measured at 20000 x 512: 75 us with 2 rows x 16 columns, 80 us with 1 x 32)
     const int64_t want_waves = 4096;
-    bool two = pair_ok && (M / 128) * ((N + 63) / 64) >= 2 * want_waves;
+    bool two = pair_ok;
     int ct = 64;
-    if (!two)
-        while (ct > 8 && ((M + 63) / 64) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
+    while (ct > 8 && ((M + (two ? 127 : 63)) / (two ? 128 : 64)) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
     static const int env_rows = [] { const char* e = getenv("TLSQ_RUS_ROWS"); return e ? atoi(e) : 0; }();   // tuning knobs
     static const int env_ct = [] { const char* e = getenv("TLSQ_RUS_CT"); return e ? atoi(e) : 0; }();
     if (env_rows == 1) two = false;
