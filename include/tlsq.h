@@ -327,6 +327,19 @@ int tlsq_k_update_shrink_f32(tlsq_handle h, const float* D, float* A, const floa
 int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* E,
                                      double* Y, double* R, double* En, double* Zn, int64_t M, int64_t N, int64_t r,
                                      double mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE);
+/* The E-free sweep every plain call runs (no E while the loop runs; src/robustPCA.jl:217-223 of iteration k and :188-192 of
+ * iteration k+1 through the identities R_k = (Z_k - A_k) - Y_k / mu_k and Y_{k+1} = mu_k (Z_k - A_k)): reads D, Yin = Y_k
+ * and Z = Z_k, writes Yout = Y_{k+1}, Z = Z_{k+1} in place and, when R is not NULL, R_k.  A_k = Tm * Vs' from its factors
+ * (r <= 32, in registers) when A is NULL, read from A otherwise (clamped in place with nonnegA).  inv_mu = 1 / mu_k as the
+ * element type rounds it.  sumsq (optional, 64 doubles, zeroed by the caller): their sum += ||R_k||_F^2. */
+int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, double* A, const double* Yin,
+                      double* Yout, double* Z, double* R, int64_t M, int64_t N, int64_t r, double mu, double inv_mu,
+                      int nonnegA, double inv_mu_next, double thr_next, int nonnegE, double* sumsq);
+/* E = soft_th(D - A_prev + inv_mu * Y, thr) (:188-191), A_prev = Tm * Vs' (Aprev NULL, r <= 32; r = 0: zero) or read from
+ * Aprev: the E a call returns, formed once after the E-free loop.  E may be the buffer Y lives in. */
+int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,
+                       const double* Y, double* E, int64_t M, int64_t N, int64_t r, double inv_mu, double thr, int nonnegA,
+                       int nonnegE);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

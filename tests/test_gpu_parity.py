@@ -1062,6 +1062,65 @@ def test_fused_rebuild_update_shrink_kernel(eng, torch_mod, M, N, r, nonneg):
         np.testing.assert_allclose(to_host(got), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("M,N,r,nonneg,explicit", [(4096, 96, 16, 0, False), (1001, 130, 5, 1, False), (70000, 64, 29, 0, False),
+                                                    (300, 7, 0, 0, False), (2000, 100, 40, 0, True), (999, 33, 12, 1, True)])
+def test_efree_sweep_kernel(eng, torch_mod, M, N, r, nonneg, explicit):
+    """k_zsweep / k_final_e against the reference's statements (src/robustPCA.jl:188-192, :217-223): started from a consistent
+    state (Z_k = D - E_k + Y_k / mu_k, as every iteration leaves it), the sweep's Y_{k+1}, R_k and Z_{k+1} must be what the
+    classic update + shrink produce from (D, A_k, E_k, Y_k) - to the rounding of Z - and k_final_e must reproduce the
+    reference's E statement (zero pattern included) in place and out of place."""
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    rng = np.random.default_rng(50 + r)
+    D, Y = (rng.standard_normal((M, N)) for _ in range(2))
+    Ek = rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.2)
+    Tm = rng.standard_normal((M, max(r, 1)))[:, :r]
+    Vs = rng.standard_normal((N, max(r, 1)))[:, :r] / max(np.sqrt(r), 1.0)
+    mu, mu_n, lam = 0.27, 0.405, 0.1
+    inv_mu, inv_mu_n, thr_n = 1.0 / mu, 1.0 / mu_n, lam / mu_n
+    Zk = (D - Ek) + inv_mu * Y
+    A = Tm @ Vs.T if r else np.zeros((M, N))
+    if nonneg:
+        A = np.maximum(A, 0)
+    R = (D - A) - Ek                                   # :221
+    Y2 = Y + mu * R                                    # :222
+    t = inv_mu_n * Y2
+    En = O.soft_th((D - A) + t, thr_n)                 # :188
+    if nonneg:
+        En = np.maximum(En, 0)
+    Zn = (D - En) + t                                  # :192
+    dD, dY, dZ = (to_dev(torch, x) for x in (D, Y, Zk))
+    dT = to_dev(torch, Tm if r else np.zeros((M, 1)))
+    dV = to_dev(torch, Vs if r else np.zeros((N, 1)))
+    dA = to_dev(torch, Tm @ Vs.T if r else np.zeros((M, N)))
+    dR, dY2 = torch.empty_like(dD), torch.empty_like(dD)
+    ss = torch.zeros(64, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert eng.lib.tlsq_k_zsweep_f64(eng.h, dptr(dD), dptr(dT), dptr(dV), dptr(dA) if explicit else None, dptr(dY),
+                                     dptr(dY2), dptr(dZ), dptr(dR), M, N, r, mu, inv_mu, nonneg, inv_mu_n, thr_n, nonneg,
+                                     dptr(ss)) == 0
+    eng.synchronize()
+    scale = max(1.0, np.abs(Zk).max())
+    for got, ref in ((dR, R), (dY2, Y2), (dZ, Zn)):
+        np.testing.assert_allclose(to_host(got), ref, rtol=0, atol=2e-13 * scale * max(1.0, np.abs(ref).max()))
+    assert abs(float(ss.sum().item()) - np.sum(R * R)) <= 1e-10 * np.sum(R * R)
+    if explicit and nonneg:
+        np.testing.assert_allclose(to_host(dA), A, rtol=0, atol=1e-12)          # A .= max.(A, 0) stored back (:217-219)
+    # the returned E: E_{k+1} = soft_th(D - A_k + Y_{k+1} / mu_{k+1}) from the stored Y_{k+1}, out of place and in place
+    Y2h = to_host(dY2)
+    Eref = O.soft_th((D - A) + inv_mu_n * Y2h, thr_n)
+    if nonneg:
+        Eref = np.maximum(Eref, 0)
+    dE = torch.empty_like(dD)
+    for target in (dE, dY2):
+        assert eng.lib.tlsq_k_final_e_f64(eng.h, dptr(dD), dptr(dT), dptr(dV), dptr(dA) if explicit else None, dptr(dY2),
+                                          dptr(target), M, N, r, inv_mu_n, thr_n, nonneg, nonneg) == 0
+        eng.synchronize()
+        got = to_host(target)
+        np.testing.assert_allclose(got, Eref, rtol=0, atol=1e-12 * scale)
+        assert np.mean((got == 0) != (Eref == 0)) < 1e-6      # (A differs from the GEMM by summation order only)
+
+
 def test_rpca_large_panel_path_properties(eng):
     """2^26 elements (131072 x 512): the loop takes the fused rebuild + sweep kernel (A is only materialised after the
     loop).  Size-independent properties, as for the full C2 size."""

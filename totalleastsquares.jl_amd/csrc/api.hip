@@ -716,6 +716,23 @@ int tlsq_k_rebuild_update_shrink_f64(tlsq_handle h, const double* D, const doubl
     return launch_rebuild_update_shrink<double>(h, D, Tm, Vs, E, Y, R, En, Zn, M, N, r, mu, nonnegA, inv_mu_next,
                                                 thr_next, nonnegE, nullptr, nullptr);
 }
+int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, double* A, const double* Yin,
+                      double* Yout, double* Z, double* R, int64_t M, int64_t N, int64_t r, double mu, double inv_mu,
+                      int nonnegA, double inv_mu_next, double thr_next, int nonnegE, double* sumsq) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !Yin || !Yout || !Z || M <= 0 || N <= 0 || r < 0 || (!A && r > 32) || Yin == Yout)
+        return set_err(h, TLSQ_ERR_ARG, "k_zsweep: bad argument (factors serve r <= 32; Y is double-buffered)");
+    return launch_zsweep<double>(h, D, Tm, Vs, A, Yin, Yout, Z, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
+                                 nonnegE, sumsq, nullptr);
+}
+int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,
+                       const double* Y, double* E, int64_t M, int64_t N, int64_t r, double inv_mu, double thr, int nonnegA,
+                       int nonnegE) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !Y || !E || M <= 0 || N <= 0 || r < 0 || (!Aprev && r > 32))
+        return set_err(h, TLSQ_ERR_ARG, "k_final_e: bad argument");
+    return launch_final_e<double>(h, D, Tm, Vs, Aprev, Y, E, M, N, r, inv_mu, thr, nonnegA, nonnegE);
+}
 int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !G || M < 0 || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "k_gram_f32: bad arguments");
