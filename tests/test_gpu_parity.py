@@ -1158,6 +1158,24 @@ def test_residual_store_misprediction_path():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_tiny_noise_stays_on_the_subspace_route(eng):
+    """Low rank + sparse + noise at the level of float32 rounding: the loop needs ~10 iterations more, and in those the
+    threshold 1/mu lies below the noise level of G = Z'Z.  While the rank is stable the count is certified on the deflated
+    panel (solver.hip, deflated_certificate) instead of a TSQR + Jacobi decomposition per iteration: same iterations, rank
+    and results as the oracle, no dense decompositions."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(1)
+    M, N, r = 4000, 256, 8
+    D = (rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)
+         + 3e-7 * rng.standard_normal((M, N)))
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert (sv, rep.iters_done) == (svo, io.iters_done) and rep.iters_done > 32
+    assert rep.svp_hist == io.svp_hist
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    assert rep.eig_full <= 1, rep.eig_full        # (the returned decomposition is computed after the loop, not counted)
+
+
 def test_efree_loop_against_classic_sweeps(eng, tmp_path):
     """The default loop keeps no E while it runs (sweeps.hip, k_zsweep: Y' = mu (Z - A), R = Z - A - Y / mu, E formed once
     after the loop from the kept factors of A_{k-1}); TLSQ_NO_ZSWEEP=1 (read once per process, hence the subprocess) runs the

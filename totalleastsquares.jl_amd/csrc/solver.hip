@@ -805,7 +805,7 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     // (slot 1 / 2: buffers of the E-free loop, which keeps the previous iteration's factors alive through the next SVD step
     //  - WS_VS itself is scratch of the count certificate in svd_subspace)
     TLSQ_TRY(ws_get(h, slot == 1 ? WS_VS2 : slot == 2 ? WS_VS3 : WS_VS, (size_t)N * r * 8, &Vs));
-    TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : WS_T, (size_t)M * r * 8, &T1));
+    TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : slot == 3 ? WS_T3 : WS_T, (size_t)M * r * 8, &T1));   // (3: scratch of the deflated certificate)
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
     TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
@@ -1155,6 +1155,57 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                       info ? &info->ms_eig : &zero_sink,    info ? &info->ms_rebuild : &zero_sink,
                       info ? &info->ms_update : &zero_sink, info ? &info->ms_opnorm : &zero_sink,
                       info ? &info->ms_gram : &zero_sink,   info ? &info->ms_opnorm : &zero_sink};
+    // ---- count certificate on the deflated panel (iterations whose threshold lies below the noise level of G = Z'Z) ----------
+    // S = the Ritz values of the block that clear the threshold by G's uncertainty; Z2 = Z - (Z X_S) X_S' is formed in the
+    // residual panel (free at this point of the iteration) and sigma_max(Z2) < 1/mu is certified through the Gram of Z2,
+    // whose rounding is relative to ||Z2||^2 ~ (1/mu)^2 instead of sigma_max(Z)^2.  Courant-Fischer: sigma_{|S|+1}(Z) <=
+    // sigma_max(Z (I - X_S X_S')) < 1/mu, and Cauchy interlacing puts |S| singular values above 1/mu - the count is |S|.
+    // The Ritz values outside S (pad columns: noise of G) are zeroed so that nobody counts them.
+    static const bool no_defl = [] { const char* e = getenv("TLSQ_NO_DEFLATED_CERT"); return e && e[0] == '1'; }();
+    const bool defl_possible = !no_defl && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32;
+    auto deflated_certificate = [&](const T* Zp, const double* X, SmallSvd& sv_, double inv_mu_, bool* pass) -> int {
+        *pass = false;
+        const double tau2 = inv_mu_ * inv_mu_;
+        const double stop = sv_.ncols > 0 ? sv_.sigma[sv_.order[0]] : 0.0;
+        const double dl = noise_rel * stop * stop;
+        std::vector<int32_t> sel;
+        for (int64_t i = 0; i < sv_.ncols; ++i) {
+            const double sg = sv_.sigma[sv_.order[i]];
+            if (sg * sg >= tau2 + 2.0 * dl) sel.push_back(sv_.order[i]);
+        }
+        const int64_t rS = (int64_t)sel.size();
+        if (rS == 0 || rS > 96 || rS + 2 > sv_.ncols) return TLSQ_OK;
+        // rounding of Z2 itself: ~eps sqrt(r) sigma_max(Z) per direction, to be small against 1/mu
+        const double rel = 64.0 * 2.220446049250313e-16 * std::sqrt((double)rS + 1.0) * stop / inv_mu_;
+        if (!(rel < 1e-3)) return TLSQ_OK;
+        std::vector<double> ones((size_t)rS, 1.0);
+        const double *TmS = nullptr, *VsS = nullptr;
+        TLSQ_TRY(rebuild_factors<T>(h, Zp, M, N, M, X, sel, ones, &TmS, &VsS, 3));  // T_S = Z X_S
+        TLSQ_TRY(rebuild_from_factors<T>(h, TmS, VsS, M, N, rS, R, M));              // R = T_S X_S'
+        TLSQ_TRY(launch_diff<T>(h, Zp, R, R, n));                                    // R = Z - T_S X_S' = Z2
+        hbm_other += 6.0 * panel_bytes;
+        double* G2 = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, R, M, N, M, &G2));
+        void* GD;
+        TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+        TLSQ_TRY(launch_deflate(h, G2, N, nullptr, nullptr, (double*)GD, N, 0, 1.0 / tau2));
+        sub.cert_GD = (const double*)GD;
+        sub.cert_N = N;
+        sub.cert_margin = (1.0 - 2.0 * rel) * (1.0 - 1e-9);
+        sub.cert_power = N <= 1024;
+        if (!sub.cert_power) return TLSQ_OK;
+        TLSQ_TRY(power_cert_begin(h, sub));
+        TLSQ_TRY(cert_finish(h, sub, pass));
+        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "  deflated certificate: |S|=%lld margin=%.3e pass=%d\n", (long long)rS, sub.cert_margin, (int)*pass);
+        if (*pass) {
+            std::vector<char> keep((size_t)sv_.sigma.size(), 0);
+            for (int32_t i : sel) keep[(size_t)i] = 1;
+            for (size_t i = 0; i < sv_.sigma.size(); ++i)
+                if (!keep[i]) sv_.sigma[i] = 0.0;
+        }
+        return TLSQ_OK;
+    };
     bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
     const double t_loop0 = now_ms();
     int64_t k = 0;
@@ -1295,9 +1346,15 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         } else {
         const bool hook_now = hook_svd && k >= 2;
         bool r_route = !large && !hook_now && (!use_subspace || hook_svd);
+        // The threshold has reached the noise level of the Gram matrix: its small eigenvalues mean nothing any more.  While the
+        // rank is stable the count can still be certified without the accurate route - on the panel itself, with the
+        // dominant part taken out (deflated_certificate below); everything else goes through the TSQR route.
+        bool noise_limited = false;
         if (!r_route && !large && !hook_now && sigma_top_prev > 0.0 &&
-            !(inv_mu * inv_mu > 2.0 * noise_rel * sigma_top_prev * sigma_top_prev))
-            r_route = true;   // the threshold has reached the noise level of the Gram matrix
+            !(inv_mu * inv_mu > 2.0 * noise_rel * sigma_top_prev * sigma_top_prev)) {
+            if (defl_possible && sub.valid && !bulk_tail) noise_limited = true;
+            else r_route = true;
+        }
         if (!r_route) {
         GramOp op = panel_op(Z);
         const bool gram_queued_earlier = g_ready || implicit_gram;
@@ -1321,6 +1378,21 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             sub.steps += rs.steps;
         } else if (bulk_tail && !large) {
             sub.fail = SubspaceState::FAIL_NONE;   // straight to the dense tier below
+        } else if (noise_limited) {
+            // Ritz pairs of the dominant part from G (they are far above its noise), no window and no Gram certificate: the
+            // count is certified on the deflated panel.  Any failure hands the iteration to the TSQR route.
+            sub.noise_rel = 0.0;
+            sub.skip_certificate = true;
+            sub.defer_certificate = false;
+            const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
+            sub.skip_certificate = false;
+            if (st_sub < 0) return st_sub;
+            if (fast_ok) {
+                bool pass = false;
+                TLSQ_TRY(deflated_certificate(Z, V, s, inv_mu, &pass));
+                if (!pass) fast_ok = false;
+            }
+            if (!fast_ok) sub.fail = SubspaceState::FAIL_WINDOW;   // (no block-growing retries: the accurate route decides)
         } else {
             sub.noise_rel = noise_rel;
             sub.defer_certificate = !no_cert_overlap;
@@ -1447,7 +1519,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // Will the next iteration want the Gram of Z_{k+1}?  (Not on the TSQR route, not with the implicit operator.)  It is
         // queued before the host looks at this iteration's cost - the GPU works through that round trip, and a Gram is
         // wasted only at convergence.
-        const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 &&
+        const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 && !(defl_possible && !bulk_tail) &&
                             !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram;
         bool gram_queued = false;

@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ src, in
 
 // out = a - b (contiguous n)
 template <typename T>
-__global__ __launch_bounds__(256) void k_diff(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+__global__ __launch_bounds__(256) void k_diff(const T* __restrict__ a, const T* b, T* out,   // (out may be b)
                                               int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] - b[i];
