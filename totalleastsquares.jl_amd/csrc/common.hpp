@@ -145,7 +145,7 @@ template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                   double* sumsq, double* zero_slots, const T* hankel_y = nullptr, int64_t hankel_K = 0, int64_t row0 = 0,
-                  int64_t row1 = 0);
+                  int64_t row1 = 0, int maxslot = -1);
 template <typename T>
 int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
                    int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y = nullptr,

@@ -295,9 +295,11 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
                                                 T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t M,
                                                 int N, int r, int ct, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n,
                                                 int nonnegE, double* __restrict__ sumsq, double* __restrict__ zero_slots,
-                                                int64_t hankel_K, int64_t row0, int64_t row1) {
+                                                int64_t hankel_K, int64_t row0, int64_t row1, int maxslot) {
+    // sumsq: 72 doubles - [0, 64) partial sums of ||R_k||_F^2, [64 + maxslot] (maxslot >= 0) max |R_k[i, j]| as a bit
+    // pattern: both are lower bounds of ||R_k||_2 for the convergence test (solver.hip), never results
     using VR = T __attribute__((ext_vector_type(ROWS)));
-    if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
+    if (zero_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 72) zero_slots[threadIdx.x] = 0.0;
     __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
     const int c0 = blockIdx.y * ct;
     const int nct = (N - c0 < ct) ? N - c0 : ct;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
     __syncthreads();
     const int64_t row = row0 + ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;   // ROWS = 2: M, row0, row1 are even (launcher)
     double ss = 0.0;
+    T rmax = (T)0;
     if (row < row1) {
         double t[ROWS][RMAX];
 #pragma unroll
@@ -342,6 +345,8 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
                 const T w = z[q] - a;
                 const T res = w - inv_mu * y[q];             // R_k = D - A - E                         :221
                 ss += (double)res * (double)res;
+                const T ares = res < (T)0 ? -res : res;
+                rmax = ares > rmax ? ares : rmax;            // (a NaN never wins: the bound stays a bound)
                 rr[q] = res;
                 const T y1 = mu * w;                         // Y_{k+1} = Y + mu R                      :222
                 yn[q] = y1;
@@ -364,6 +369,23 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
         __syncthreads();
         if (threadIdx.x == 0)
             atomicAdd(sumsq + ((blockIdx.x + blockIdx.y) & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+        if (maxslot >= 0) {
+            double m = (double)rmax;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(m, off, 64);
+                m = o > m ? o : m;
+            }
+            __syncthreads();
+            if (lane == 0) sw[w] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double mm = sw[0];
+                for (int k = 1; k < 4; ++k) mm = sw[k] > mm ? sw[k] : mm;
+                atomicMax(reinterpret_cast<unsigned long long*>(sumsq + 64 + maxslot),
+                          (unsigned long long)__double_as_longlong(mm));   // (non-negative doubles: monotone bit patterns)
+            }
+        }
     }
 }
 
@@ -372,18 +394,22 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* __restrict__ A, const T* __restrict__ Yin,
                                                     T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t n,
                                                     T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
-                                                    double* __restrict__ sumsq, double* __restrict__ zero_slots) {
+                                                    double* __restrict__ sumsq, double* __restrict__ zero_slots,
+                                                    int maxslot) {
     using V = T __attribute__((ext_vector_type(VEC)));
-    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 64) zero_slots[threadIdx.x] = 0.0;
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 72) zero_slots[threadIdx.x] = 0.0;
     const int64_t nv = n / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double ss = 0.0;
+    T rmax = (T)0;
     auto one = [&](T d, T& a, T y, T z, T& res, T& y1, T& zn) {
         if (nonnegA) a = pos_part(a);
         const T w = z - a;
         res = w - inv_mu * y;
         ss += (double)res * (double)res;
+        const T ares = res < (T)0 ? -res : res;
+        rmax = ares > rmax ? ares : rmax;
         y1 = mu * w;
         const T tt = inv_mu_n * y1;
         T ee = soft_th((d - a) + tt, thr_n);
@@ -426,6 +452,23 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
         if (lane == 0) sw[w] = ss;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(sumsq + (blockIdx.x & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+        if (maxslot >= 0) {
+            double m = (double)rmax;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(m, off, 64);
+                m = o > m ? o : m;
+            }
+            __syncthreads();
+            if (lane == 0) sw[w] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double mm = sw[0];
+                for (int k = 1; k < 4; ++k) mm = sw[k] > mm ? sw[k] : mm;
+                atomicMax(reinterpret_cast<unsigned long long*>(sumsq + 64 + maxslot),
+                          (unsigned long long)__double_as_longlong(mm));
+            }
+        }
     }
 }
 
@@ -576,9 +619,9 @@ template int launch_rebuild_store<float>(Handle*, const double*, const double*, 
 
 // The 64 partial sums of ||R||_F^2 go to the host-visible mailbox ([0] flag, [8..72) values) and are published with
 // the sequence number: the host polls the flag instead of paying a copy command and an event between two kernels.
-__global__ __launch_bounds__(64) void k_publish_slots(const double* __restrict__ slots, double* mailbox, double seq) {
+__global__ __launch_bounds__(128) void k_publish_slots(const double* __restrict__ slots, double* mailbox, double seq) {
     volatile double* mb = mailbox;
-    mb[8 + threadIdx.x] = slots[threadIdx.x];
+    if (threadIdx.x < 72) mb[8 + threadIdx.x] = slots[threadIdx.x];   // (64 sums + 8 per-rank maxima of |R|)
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) mb[0] = seq;
@@ -878,19 +921,21 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
 template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
-                  double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K, int64_t row0, int64_t row1) {
+                  double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K, int64_t row0, int64_t row1,
+                  int maxslot) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     if (row1 <= 0) row1 = M;
+    if (!sumsq || maxslot > 7) maxslot = -1;
     if (A) {
         if (hankel_y || row0 != 0 || row1 != M) return set_err(h, TLSQ_ERR_ARG, "zsweep: explicit A needs the whole real panel");
         const int64_t n = M * N;
         constexpr int VEC = 16 / sizeof(T);
         if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(R))
             hipLaunchKernelGGL((k_zsweep_lin<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z,
-                               R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
+                               R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
         else
             hipLaunchKernelGGL((k_zsweep_lin<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z, R, n, mu,
-                               inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots);
+                               inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
@@ -916,11 +961,11 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
         if (hankel_y)                                                                                                 \
             hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, R, \
                                M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
-                               hankel_K, row0, row1);                                                                 \
+                               hankel_K, row0, row1, maxslot);                                                        \
         else                                                                                                          \
             hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, R, M, \
                                (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots,   \
-                               (int64_t)0, row0, row1);                                                               \
+                               (int64_t)0, row0, row1, maxslot);                                                      \
     } while (0)
     if (two) {
         if (r <= 8) ZS_LAUNCH(8, 2);
@@ -993,7 +1038,7 @@ int launch_z_from_y(Handle* h, const T* A, const T* Y1, T* Z, int64_t n, T inv_m
 }
 
 int launch_publish_slots(Handle* h, const double* slots, double seq) {
-    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(64), 0, h->stream, slots, h->mailbox_dev, seq);
+    hipLaunchKernelGGL(k_publish_slots, dim3(1), dim3(128), 0, h->stream, slots, h->mailbox_dev, seq);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -1099,7 +1144,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
                                                  const T*, int64_t, int64_t, int64_t, size_t);                        \
     template int launch_zsweep<T>(Handle*, const T*, const double*, const double*, T*, const T*, T*, T*, T*, int64_t, \
                                   int64_t, int64_t, T, T, int, T, T, int, double*, double*, const T*, int64_t, int64_t, \
-                                  int64_t);                                                                            \
+                                  int64_t, int);                                                                       \
     template int launch_final_e<T>(Handle*, const T*, const double*, const double*, const T*, const T*, T*, int64_t, \
                                    int64_t, int64_t, T, T, int, int, const T*, int64_t);                              \
     template int launch_residual_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                              \
