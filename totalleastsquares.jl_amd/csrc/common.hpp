@@ -177,6 +177,12 @@ int launch_diff(Handle* h, const T* a, const T* b, T* out, int64_t n);
 template <typename TS, typename TD>
 int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n);
 
+// a short column selection with one weight per column, passed to kernels by value (no upload, no extra command)
+struct SelWeights {
+    int32_t sel[32];
+    double w[32];
+};
+
 // ---------------- gemm.hip ----------------
 // Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j), i<P, j<Q, k<K
 //   A_KC: Aop(i,k) = A[k + i*lda]   else  A[i + k*lda]
@@ -196,6 +202,9 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
 // T (M x r, fp64) = Z (M x K, fp32 or fp64) * W (K x r), r <= 96: Z streamed once, MFMA fed from global memory
 int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
                int64_t M, int64_t K, int64_t r);
+// the same with W = V[:, sel] diag(w) (r <= 32) gathered and packed in one pass; Vs (optional, K x r) = V[:, sel]
+int tsmm_sel(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, const SelWeights& sw, double* Vs, double* Tout,
+             int64_t ldt, int64_t M, int64_t K, int64_t r);
 // Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
 int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t p);
@@ -225,12 +234,11 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
 // warm_v: V holds the previous decomposition's eigenvectors (orthogonal): start from B = G*V.
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 // selection + weights small enough to travel as kernel arguments (r <= 32)
-struct SelWeights {
-    int32_t sel[32];
-    double w[32];
-};
 int launch_gather_scale_arg(Handle* h, const double* V, int64_t N, const SelWeights& sw, int64_t r, double* Vg,
                             double* Vs);
+// GD = scale (G - sum_k w_k X[:, sel_k] X[:, sel_k]') (subspace.hip)
+int launch_deflate_sel(Handle* h, const double* G, int64_t ldG, const double* X, const SelWeights& sw, double* GD, int64_t N,
+                       int64_t r, double scale);
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs);
 

@@ -1193,6 +1193,24 @@ __global__ __launch_bounds__(256) void k_pack_w(const double* __restrict__ W, in
     }
 }
 
+// Vs (K x r, ld K) = V[:, sel] and Wt (row-major K x lw, zero-padded) = the packed form of V[:, sel] diag(w) in one pass:
+// what the rebuild needs from the eigenvectors (the factor product's operand and the sweep's Vs tile) without the
+// intermediate Vg panel and its re-packing
+__global__ __launch_bounds__(256) void k_gather_pack_w(const double* __restrict__ V, int K, SelWeights sw, int r, int lw,
+                                                       double* __restrict__ Vs, double* __restrict__ Wt) {
+    const int total = K * lw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e % lw, k = e / lw;
+        double v = 0.0;
+        if (j < r) {
+            v = V[(size_t)sw.sel[j] * K + k];
+            if (Vs) Vs[(size_t)j * K + k] = v;
+            v *= sw.w[j];
+        }
+        Wt[e] = v;
+    }
+}
+
 template <typename TA, int NCT, int RT>
 __global__ __launch_bounds__(256) void k_tsmm(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ Wt,
                                               double* __restrict__ Tout, int64_t ldt, int64_t M, int K, int r) {
@@ -1257,17 +1275,23 @@ __global__ __launch_bounds__(256) void k_tsmm(const TA* __restrict__ Z, int64_t 
     }
 }
 
-// T (M x r, ldt, fp64) = Z (M x K, ldz; fp32 when z_f32) * W (K x r, ldw), r <= 96
-int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
-               int64_t M, int64_t K, int64_t r) {
+// T (M x r, ldt, fp64) = Z (M x K, ldz; fp32 when z_f32) * W (K x r, ldw), r <= 96.
+// W == nullptr: W = V[:, sel] diag(w) for the K x . matrix V (ld K) and a short selection (r <= 32) passed by value; Vs
+// (optional, K x r, ld K) receives V[:, sel] on the way (tsmm_sel below).
+static int tsmm_impl(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, const double* V,
+                     const SelWeights* sw, double* Vs, double* Tout, int64_t ldt, int64_t M, int64_t K, int64_t r) {
     if (M <= 0 || r <= 0) return TLSQ_OK;
     if (r > 96) return set_err(h, TLSQ_ERR_ARG, "tsmm: r > 96");
     const int nct = (int)((r + 15) / 16);
     const int lw = 16 * nct;
     void* wt;
     TLSQ_TRY(ws_get(h, WS_OPW, (size_t)K * lw * 8, &wt));
-    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)std::min<int64_t>((K * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, W,
-                       ldw, (int)K, (int)r, lw, (double*)wt);
+    if (W)
+        hipLaunchKernelGGL(k_pack_w, dim3((unsigned)std::min<int64_t>((K * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, W,
+                           ldw, (int)K, (int)r, lw, (double*)wt);
+    else
+        hipLaunchKernelGGL(k_gather_pack_w, dim3((unsigned)std::min<int64_t>((K * lw + 255) / 256, 1024)), dim3(256), 0,
+                           h->stream, V, (int)K, *sw, (int)r, lw, Vs, (double*)wt);
     // rows per workgroup: 64 for tall panels, 32 otherwise (fewer than ~1000 workgroups would leave CUs idle); the
     // wide forms (more than 32 columns) keep 16 rows so that the accumulators and the reduction buffer stay small
     const bool tall = M >= 65536;
@@ -1290,6 +1314,17 @@ int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W
 #undef TS_LAUNCH
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
+}
+
+int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W, int64_t ldw, double* Tout, int64_t ldt,
+               int64_t M, int64_t K, int64_t r) {
+    return tsmm_impl(h, Z, z_f32, ldz, W, ldw, nullptr, nullptr, nullptr, Tout, ldt, M, K, r);
+}
+
+int tsmm_sel(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, const SelWeights& sw, double* Vs, double* Tout,
+             int64_t ldt, int64_t M, int64_t K, int64_t r) {
+    if (r > 32) return set_err(h, TLSQ_ERR_ARG, "tsmm_sel: r > 32");
+    return tsmm_impl(h, Z, z_f32, ldz, nullptr, 0, V, &sw, Vs, Tout, ldt, M, K, r);
 }
 
 // Y (N x pc, ld N) = Z' * T for a few columns (pc <= 8): one wave per column of Z (coalesced reads), T (M x pc) from L2.

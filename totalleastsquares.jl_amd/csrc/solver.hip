@@ -715,23 +715,37 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     }
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
     void *Vg = nullptr, *Vs = nullptr;
+    // (explicit G, at most 32 deflated columns, N < 1024: the deflation kernel reads the columns of X itself)
+    static const bool no_fused_defl = [] { const char* e = getenv("TLSQ_NO_FUSED_DEFLATE"); return e && e[0] == '1'; }();
+    const bool fused_deflate = !op.implicit() && svp <= 32 && N < 1024 && !no_fused_defl;
+    SelWeights defl_sw;
     if (svp > 0) {
-        TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
-        TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
         std::vector<int32_t> sel((size_t)svp);
         std::vector<double> th((size_t)svp);
         for (int64_t i = 0; i < svp; ++i) {
             sel[i] = s.order[i];
             th[i] = host[sel[i]];
         }
-        TLSQ_TRY(gather_scale_host(h, (const double*)X, N, sel, th, aux, (double*)Vg, (double*)Vs));
+        if (fused_deflate) {
+            for (int64_t i = 0; i < 32; ++i) {
+                defl_sw.sel[i] = i < svp ? sel[(size_t)i] : 0;
+                defl_sw.w[i] = i < svp ? th[(size_t)i] : 0.0;
+            }
+        } else {
+            TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
+            TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
+            TLSQ_TRY(gather_scale_host(h, (const double*)X, N, sel, th, aux, (double*)Vg, (double*)Vs));
+        }
     }
     const double tau2 = inv_mu * inv_mu;
     // everything below is scaled by 1 / tau^2: the question is lambda_max(GD) < margin = 1 - dlam / tau^2
     st.cert_margin = (1.0 - st.dlam / tau2) * (1.0 - 1e-9);
     if (!op.implicit()) {
         TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
-        TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
+        if (fused_deflate && svp > 0)
+            TLSQ_TRY(launch_deflate_sel(h, op.G, N, (const double*)X, defl_sw, (double*)GD, N, svp, 1.0 / tau2));
+        else
+            TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
         st.cert_GD = (const double*)GD;
         st.cert_N = N;
         static const bool no_power = [] { const char* e = getenv("TLSQ_NO_POWER_CERT"); return e && e[0] == '1'; }();
@@ -807,10 +821,24 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, slot == 1 ? WS_VS2 : slot == 2 ? WS_VS3 : WS_VS, (size_t)N * r * 8, &Vs));
     TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : slot == 3 ? WS_T3 : WS_T, (size_t)M * r * 8, &T1));   // (3: scratch of the deflated certificate)
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
-    TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     // T (M x r, fp64) = Z * Vg
     static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
     static const int64_t tsmm_max = [] { const char* e = getenv("TLSQ_TSMM_MAXR"); return (int64_t)(e ? atoi(e) : 96); }();
+    static const bool no_sel = [] { const char* e = getenv("TLSQ_NO_TSMM_SEL"); return e && e[0] == '1'; }();
+    if (r <= 32 && r <= tsmm_max && !no_tsmm && !no_sel) {
+        // short lists: selection and weights travel as kernel arguments, V[:, sel] diag(g) is gathered straight into the
+        // packed operand of the factor product (no Vg panel, one launch less), Vs on the way
+        SelWeights sw;
+        for (int64_t i = 0; i < 32; ++i) {
+            sw.sel[i] = i < r ? sel[(size_t)i] : 0;
+            sw.w[i] = i < r ? g[(size_t)i] : 0.0;
+        }
+        TLSQ_TRY(tsmm_sel(h, Z, Prec<T>::f32, ldZ, V, sw, (double*)Vs, (double*)T1, M, M, N, r));
+        *Tm_out = (const double*)T1;
+        *Vs_out = (const double*)Vs;
+        return TLSQ_OK;
+    }
+    TLSQ_TRY(gather_scale_host(h, V, N, sel, g, aux, (double*)Vg, (double*)Vs));
     if (r <= tsmm_max && r <= 96 && !no_tsmm) {
         TLSQ_TRY(tsmm_mixed(h, Z, Prec<T>::f32, ldZ, (const double*)Vg, N, (double*)T1, M, M, N, r));
     } else {

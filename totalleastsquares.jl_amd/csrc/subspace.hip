@@ -422,6 +422,21 @@ __global__ __launch_bounds__(256) void k_deflate(const double* __restrict__ G, i
     }
 }
 
+// the same with the deflated columns taken straight from the Ritz block X (N x p) through a short selection / weight list
+// passed as kernel arguments: GD = scale (G - sum_k w_k X[:, sel_k] X[:, sel_k]') - no gather pass, no Vs / Vg panels
+__global__ __launch_bounds__(256) void k_deflate_sel(const double* __restrict__ G, int64_t ldG, const double* __restrict__ X,
+                                                     SelWeights sw, double* __restrict__ GD, int N, int r, double scale) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        double sv = G[i + (int64_t)j * ldG];
+        for (int k = 0; k < r; ++k) {
+            const double* xk = X + (size_t)sw.sel[k] * N;
+            sv -= xk[i] * (sw.w[k] * xk[j]);
+        }
+        GD[e] = sv * scale;
+    }
+}
 
 // H (p x p, ld p) = A' * B for N x p panels A, B: one wave per entry
 __global__ __launch_bounds__(256) void k_panel_tn(const double* __restrict__ A, const double* __restrict__ B,
@@ -775,6 +790,15 @@ int launch_deflate(Handle* h, const double* G, int64_t ldG, const double* Vs, co
         return TLSQ_OK;
     }
     hipLaunchKernelGGL(k_deflate, dim3((int)g), dim3(256), 0, h->stream, G, ldG, Vs, Vg, GD, (int)N, (int)r, scale);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+int launch_deflate_sel(Handle* h, const double* G, int64_t ldG, const double* X, const SelWeights& sw, double* GD, int64_t N,
+                       int64_t r, double scale) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_deflate_sel, dim3((int)g), dim3(256), 0, h->stream, G, ldG, X, sw, GD, (int)N, (int)r, scale);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
