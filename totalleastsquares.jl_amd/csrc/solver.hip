@@ -1058,8 +1058,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     D = Dm;   // (set-up below; every later use goes through panel_D or the implicit kernels)
 
     // ---- setup, src/robustPCA.jl:171-184 ----
-    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
-    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
+    if (!zmode) {   // (the E-free loop writes both panels in full before anything reads them: A by the rebuild, E as Y's second buffer)
+        TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * sizeof(T), h->stream));  // :174
+        TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * sizeof(T), h->stream));
+    }
     double norm2 = 0.0;
     // Very wide problems: G = Z'Z is never formed (see GramOp).  The Gram costs M N^2 flops (lower triangle) per
     // iteration, the ~8 products plus the Lanczos vectors of the implicit form ~130 M N p at the efficiency of the
@@ -1558,7 +1560,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // wasted only at convergence.
         const bool r_next = !large && (!use_subspace || (!hook_svd && sigma_top > 0.0 && !(defl_possible && !bulk_tail) &&
                             !(1.0 / (mu_next * mu_next) > 2.0 * noise_rel * sigma_top * sigma_top)));
-        const bool gram_next = sumsq_dev && !r_next && !implicit_gram;
+        // (not when the previous iteration's cost bound - tight since it is the largest entry of the residual - was already
+        //  within 1.6 tol: this iteration is then most likely the last one, and a Gram queued now would be the wasted one;
+        //  should the loop go on after all, the Gram is computed at the top of the next iteration instead)
+        static const double last_guess = [] { const char* e = getenv("TLSQ_LAST_GUESS"); return e ? atof(e) : 1.6; }();
+        const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;
+        const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last;
         bool gram_queued = false;
         // one launch of the fused sweep over rows [r0, r1) (r1 = 0: the whole panel): E-free form or classic form
         const T* hy_sweep = (const T*)ro.hankel_y;
