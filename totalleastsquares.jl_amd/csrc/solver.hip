@@ -515,6 +515,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     bool conv = false;
     double prev_maxres = 0.0;
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
+    bool cgs2_sticky = false;
     static const bool no_onepass = [] { const char* e = getenv("TLSQ_NO_ONEPASS"); return e && e[0] == '1'; }();
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
@@ -526,7 +527,10 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
         {
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
-            const int q = cold ? 2 : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
+            // (cold: 2 on the random block; from the second step on the block consists of Ritz vectors and takes a higher power
+            //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
+            static const int cold_q = [] { const char* e = getenv("TLSQ_COLD_Q"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
+            const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
             // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
             bool in_q = true;
             for (int t = 1; t < q && nt > 0; ++t) {
@@ -601,10 +605,16 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         if (used_cholqr && host[2 * p + 1] != 0.0) {
             // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
             force_cgs2 = true;
+            cgs2_sticky = true;
             --step;
             --st.steps;
             continue;
         }
+        // a cold start is random only once: from the second step on the block consists of Ritz vectors, whose images under
+        // G^q are nearly orthogonal again (different norms do not hurt the Cholesky factor) - CholeskyQR2 (18 us instead of 60)
+        // unless it has already failed on this block
+        static const bool cold_cgs2 = [] { const char* e = getenv("TLSQ_COLD_CGS2"); return e && e[0] == '1'; }();
+        if (cold && !hook && !cgs2_sticky && !cold_cgs2) force_cgs2 = false;   // (the randomized hook keeps its two plain passes)
         s.sigma.resize((size_t)p);
         double tmax = 0.0;
         bool finite = true;
