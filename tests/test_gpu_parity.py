@@ -601,8 +601,9 @@ def test_lowrankfilter_vs_oracle_and_thresholds(eng):                # test/runt
 
 def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     """with one channel and lag 1 the solver reads H[i, j] = y[i + j] from the series - set-up on a
-    transient copy, sweeps and residual from y - and the E-free loop keeps neither a second E nor a second Z, so a fresh
-    handle ends up holding five panels (A, E, Y, Z, R), not eight, and the result is bit-identical to the run that builds and keeps H (TLSQ_LAZY_HANKEL=0 TLSQ_IMPLICIT_HANKEL=0, separate
+    transient copy, sweeps and residual from y - the E-free loop keeps neither a second E nor a second Z, and the low-rank
+    panel A stays in factors (the anti-diagonal means are taken from them), so a fresh handle ends up holding four panels
+    (E, Y, Z, R), not eight, and the result is bit-identical to the run that builds and keeps H (TLSQ_LAZY_HANKEL=0 TLSQ_IMPLICIT_HANKEL=0, separate
     process: the switches are read once)."""
     import subprocess
     import sys
@@ -621,7 +622,7 @@ def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     K = Ns - n + 1
     panel = (K + 15) // 16 * 16 * n * 8
     assert rep.converged
-    assert (free0 - free1) < 5.4 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
+    assert (free0 - free1) < 4.4 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import torch; torch.zeros(1, device='cuda'); import tlsq_amd;"
             "e = tlsq_amd.Engine(0); y = np.load(%r);"
             "yf, rep = e.lowrankfilter(y, %d, return_report=True, cost_history=False);"

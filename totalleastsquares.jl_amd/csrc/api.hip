@@ -182,10 +182,14 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     static const bool lazy_ok = [] { const char* e = getenv("TLSQ_LAZY_HANKEL"); return !(e && e[0] == '0'); }();
     const bool implicit = implicit_ok && Dch == 1 && lag == 1;
     const bool lazy = implicit && lazy_ok && sv <= 0 && !exact_shape;
-    void *dy, *H = nullptr, *A, *E;
+    // ... and neither is A: the loop keeps it in factors, the anti-diagonal means are taken from them (unhankel_factors),
+    // and the panel only exists if some iteration needed it in memory (rank above 32): four resident panels (E, Y, Z, R)
+    static const bool factors_ok = [] { const char* e = getenv("TLSQ_UNHANKEL_FACTORS"); return !(e && e[0] == '0'); }();
+    const bool factors_out = lazy && !sharded && factors_ok && (size_t)n * 32 * 8 <= 64 * 1024;
+    void *dy, *H = nullptr, *A = nullptr, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
     if (!lazy) TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
-    TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
+    if (!factors_out) TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
     if (!lazy && Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
     TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     const T* yw = (const T*)dy + s0;                                                // this rank's window
@@ -202,6 +206,7 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
             ro.hankel_y = yw;
             ro.hankel_K = K;
             ro.hankel_lazy = lazy;
+            ro.factors_out = factors_out;
         }
         if (std::min(Kg, LD) > kGramMaxN)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: min(K, n*D) = %lld exceeds %lld, the largest Gram "
@@ -234,7 +239,11 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         if (info) info->jacobi_sweeps = sweeps;
     }
     // :127  (dy is reused for the filtered signal)
-    if (!sharded) {
+    if (!sharded && factors_out && sv <= 0 && h->out_factors) {
+        TLSQ_TRY(launch_unhankel_factors<T>(h, h->out_Tm, Kp, h->out_Vs, LD, h->out_r, K, n, Nx, (T*)dy));
+    } else if (!sharded) {
+        if (!A) A = h->ws[WS_A].p;   // (allocated inside the loop: some iteration needed the panel)
+        if (!A) return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: the low-rank panel was never formed");
         TLSQ_TRY(launch_unhankel<T>(h, (const T*)A, K, n, Dch, Kp, lag, Nx, (T*)dy, Nx));
     } else {
         // anti-diagonals that straddle a shard boundary get their partial sums and counts from both neighbours: one

@@ -60,6 +60,11 @@ struct Handle {
     bool in_multi = false;
     // warm start of the full Jacobi solver: WS_V holds the eigenvectors of the previous full decomposition
     int64_t warm_n = 0;      // its size (0 = nothing to reuse)
+    // result of the last rpca_core call with ResolvedOpts::factors_out: A = out_Tm (M x out_r, ld M) * out_Vs' (N x out_r, ld N)
+    // was left in factors (out_factors) instead of being written to the A panel
+    bool out_factors = false;
+    const double *out_Tm = nullptr, *out_Vs = nullptr;
+    int64_t out_r = 0;
     int warm_uses = 0;       // consecutive warm starts (reset to a cold start now and then: drift control)
 };
 
@@ -363,6 +368,11 @@ int launch_unhankel_partial(Handle* h, const T* A, int64_t K, int64_t L, int64_t
                             int64_t Nw, int64_t off, double* sum, double* cnt, int64_t ldy);
 template <typename T>
 int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int64_t n, T* y);
+// y = unhankel(Tm Vs') for one channel and lag 1 without the panel: the same sums in the same order as launch_rebuild_store
+// followed by launch_unhankel (bit-identical), reading only the factors (r <= 32)
+template <typename T>
+int launch_unhankel_factors(Handle* h, const double* Tm, int64_t ldT, const double* Vs, int64_t ldV, int64_t r, int64_t K,
+                            int64_t L, int64_t Nx, T* y);
 template <typename T>
 int launch_soft_hankel(Handle* h, T* A, int64_t K, int64_t L, int64_t ldA, T eps, T* mean_ws);
 template <typename T>

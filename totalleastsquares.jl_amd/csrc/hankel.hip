@@ -59,6 +59,39 @@ __global__ __launch_bounds__(256) void k_unhankel(const T* __restrict__ A, int64
     }
 }
 
+// y = unhankel(A) for A = Tm Vs' (K x L, one channel, lag 1) straight from the factors: entry (k, l) is rebuilt exactly as
+// k_rebuild_store does (fp64 fma chain over the r factor columns, rounded to T) and the anti-diagonal is summed in T in the
+// order of k_unhankel - bit-identical to materialising A first, without its 2 panel passes (and without the panel).
+template <typename T>
+__global__ __launch_bounds__(256) void k_unhankel_factors(const double* __restrict__ Tm, int64_t ldT,
+                                                          const double* __restrict__ Vs, int64_t ldV, int r, int64_t K,
+                                                          int64_t L, int64_t Nx, T* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double sV[];   // [l][i], L x r
+    for (int64_t e = threadIdx.x; e < L * r; e += 256) {
+        const int64_t l = e / r, i = e % r;
+        sV[e] = Vs[l + i * ldV];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < Nx; n += stride) {
+        T tot = T(0);
+        int64_t cnt = 0;
+        const int64_t lmax = n < L - 1 ? n : L - 1;
+        int64_t lmin = n - (K - 1);
+        if (lmin < 0) lmin = 0;
+        for (int64_t l = lmin; l <= lmax; ++l) {
+            const double* v = sV + l * r;
+            const double* t = Tm + (n - l);
+            double a = 0.0;
+            for (int i = 0; i < r; ++i) a = __builtin_fma(t[(int64_t)i * ldT], v[i], a);
+            const T av = (T)a;
+            tot = (cnt == 0) ? av : tot + av;
+            ++cnt;
+        }
+        y[n] = cnt > 0 ? tot / (T)cnt : T(0);
+    }
+}
+
 // Time-window shards (multi-GPU lowrankfilter): the anti-diagonal sums and counts of this rank's rows, written at
 // the window's offset `off` into full-length arrays sum / cnt (Nx_glob x Dch, zero-filled by the caller); after the
 // all-reduce k_unhankel_finish divides (y ./= max.(counts,1), :66).  Same summation order inside a shard as above.
@@ -179,6 +212,22 @@ int launch_unhankel_finish(Handle* h, const double* sum, const double* cnt, int6
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
+
+template <typename T>
+int launch_unhankel_factors(Handle* h, const double* Tm, int64_t ldT, const double* Vs, int64_t ldV, int64_t r, int64_t K,
+                            int64_t L, int64_t Nx, T* y) {
+    if (Nx <= 0) return TLSQ_OK;
+    if (r < 0 || r > 32 || (size_t)L * (size_t)std::max<int64_t>(r, 1) * 8 > 64 * 1024)
+        return set_err(h, TLSQ_ERR_ARG, "unhankel_factors: rank above 32 or window too long for the LDS copy of Vs");
+    hipLaunchKernelGGL((k_unhankel_factors<T>), dim3(gx(Nx)), dim3(256), (size_t)L * std::max<int64_t>(r, 1) * 8, h->stream, Tm,
+                       ldT, Vs, ldV, (int)r, K, L, Nx, y);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template int launch_unhankel_factors<double>(Handle*, const double*, int64_t, const double*, int64_t, int64_t, int64_t, int64_t,
+                                             int64_t, double*);
+template int launch_unhankel_factors<float>(Handle*, const double*, int64_t, const double*, int64_t, int64_t, int64_t, int64_t,
+                                            int64_t, float*);
 
 #define INST(T)                                                                                       \
     template int launch_hankel<T>(Handle*, const T*, int64_t, int64_t, int64_t, int64_t, int64_t, T*, \

@@ -147,6 +147,11 @@ struct ResolvedOpts {
     // transient copy in a buffer the loop only needs later, and the rare kernels without an implicit form build one on
     // demand (seven resident panels instead of eight)
     bool hankel_lazy = false;
+    // The caller wants neither the panel A nor E, only what unhankel makes of A (lowrankfilter, one channel, lag 1): when
+    // the loop ends with A still in factors (rank <= 32, no nonnegA) it is not materialised - Handle::out_factors says so
+    // and out_Tm / out_Vs / out_r describe it - and the returned E is not formed.  rpca_core may then be called with
+    // A == nullptr: the panel is only allocated (WS_A) if some iteration needs it in memory.
+    bool factors_out = false;
 };
 
 inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {

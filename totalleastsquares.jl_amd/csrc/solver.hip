@@ -965,6 +965,17 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // the svd / opnorm hooks keep the classic sweeps with their E and Z double buffers.
     const bool zmode = !no_zsweep && !no_fuse && !no_first && !ro.hankel && ro.iters >= 1 &&
                        !(opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT));
+    // ResolvedOpts::factors_out: the caller may pass A == nullptr; the panel is allocated the first time something needs it
+    auto need_A = [&]() -> int {
+        if (!A) {
+            void* p;
+            TLSQ_TRY(ws_get(h, WS_A, (size_t)n * sizeof(T), &p));
+            A = (T*)p;
+        }
+        return TLSQ_OK;
+    };
+    h->out_factors = false;
+    if (!(zmode && ro.factors_out)) TLSQ_TRY(need_A());
     // classic loop: E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
     // must survive in case iteration k is the last one
     void *E2v = nullptr, *Z2v = nullptr;
@@ -1092,7 +1103,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
     else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
-    TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));                  // :178 norm(Y, Inf)
+    if (ro.hankel_lazy && ro.hankel_y)   // every sample of the series appears in its Hankel matrix: max |H| = max |y|
+        TLSQ_TRY(launch_maxabs<T>(h, (const T*)ro.hankel_y, ro.hankel_K + N - 1, &maxabs));
+    else
+        TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));              // :178 norm(Y, Inf)
     TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
     const double lam = ro.lambda;
     const double norminf = maxabs / lam;
@@ -1318,6 +1332,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             r_last = svp;
             if (svp > 0) hbm_other += panel_bytes;                      // T = Z Vg reads Z once
             if (!fuse_rebuild) {
+                TLSQ_TRY(need_A());
                 TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, svp, A, M));
                 hbm_other += panel_bytes;                               // A = T Vs' written once
             }
@@ -1826,11 +1841,20 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     pt.finish(acc);
     T* Z = Zbuf[cur];
-    if (a_pending) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
+    // (factors_out: the caller takes A as factors - unhankel reads them directly - and does not want E)
+    const bool give_factors = ro.factors_out && zmode && a_pending && !ro.nonnegA && r_last <= 32 && !(S_host || Vt_host || U_dev);
+    if (a_pending && !give_factors) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
+        TLSQ_TRY(need_A());
         TLSQ_TRY(rebuild_from_factors<T>(h, Tm_last, Vs_last, M, N, r_last, A, M));
         if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
     }
-    if (zmode && z_swept) {
+    h->out_factors = give_factors;
+    h->out_Tm = Tm_last;
+    h->out_Vs = Vs_last;
+    h->out_r = r_last;
+    if (zmode && z_swept && ro.factors_out && !(S_host || Vt_host || U_dev)) {
+        // nothing: neither E nor the last Z is wanted
+    } else if (zmode && z_swept) {
         // The E-free loop stopped behind a sweep: Y_k in Ybuf[ycur], Y_{k+1} in the other buffer, Z already Z_{k+1}.
         // Z_k = A_k + Y_{k+1} / mu_k for the returned decomposition (:194, :238), then E_k over whichever Y buffer E is.
         if (S_host || Vt_host || U_dev) {
