@@ -161,7 +161,11 @@ int tlsq_comm_destroy(tlsq_handle h);
  * padding) are returned - the rest of S is NaN and the corresponding vectors are zero.  The subspace block grows to
  * 512 columns; an iteration it cannot serve (a rank beyond ~480, or a cold start on a high-rank problem) goes through
  * the TSQR route up to min(M,N) = 4608 (about a second per decomposition) and is TLSQ_ERR_UNSUPPORTED beyond.
- * min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED. */
+ * min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED.
+ * Device memory held by the handle (grow-only workspace, freed by tlsq_destroy): three M x N panels of the element type
+ * (Y, Z, residual) beside D, A, E - which are the caller's with TLSQ_MEM_DEVICE and three more workspace panels with
+ * TLSQ_MEM_HOST; the hankel flag and the svd / opnorm hook modes add two more (a second E and Z).  The A and E panels
+ * are scratch while the call runs (E holds the second copy of Y); they are written in full before the call returns. */
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE,
                   double* U, int64_t ldU, double* S, double* Vt, int64_t ldVt,
@@ -195,7 +199,11 @@ int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t 
  * The Hankel matrix is built, factored and averaged on the device; it never visits the host.
  * With a communicator (tlsq_comm_init) every rank passes the WHOLE series and receives the whole filtered series: a
  * rank owns a contiguous block of the rows of H — a time window of y with an (n-1)-sample halo — rpca runs
- * row-sharded, and the anti-diagonal averaging exchanges partial sums and counts with one all-reduce. */
+ * row-sharded, and the anti-diagonal averaging exchanges partial sums and counts with one all-reduce.
+ * Device memory: with one channel and lag 1 (robust mode, one GPU) neither the Hankel matrix nor the low-rank panel is
+ * ever stored - the sweeps read y[i + j], the filtered series is averaged from the factors of the low-rank part - and
+ * the handle holds four K x n panels (measured 83 GB for Nx = 1e7, n = 256); several channels, a lag above 1 and row
+ * shards keep H and A as panels (six to eight panels). */
 int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy,
                            int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
                            double* yf, int64_t ldyf, tlsq_rpca_info* info);
