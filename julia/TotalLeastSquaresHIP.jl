@@ -385,4 +385,10 @@ function rpca_ga(X::AbstractMatrix{Float64}, r = minimum(size(X)), U = nothing; 
     Q
 end
 
+# other real element types (the reference is generic): computed in Float64 on the device, returned in the input's float type
+function rpca_ga(X::AbstractMatrix{T}, args...; kwargs...) where {T<:Real}
+    Q = rpca_ga(Matrix{Float64}(X), args...; kwargs...)
+    T <: AbstractFloat ? Matrix{T}(Q) : Q
+end
+
 end # module
