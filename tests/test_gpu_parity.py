@@ -808,6 +808,33 @@ def test_rpca_device_mode_and_decision_only_cost(eng, torch_mod):
         assert abs(rep2.final_cost - rep.final_cost) <= 1e-6 * rep.final_cost
 
 
+def test_rpca_device_mode_unaligned_panels(eng, torch_mod):
+    """Device panels that are used in place (M a multiple of 16) but start 8 bytes off a 16-byte boundary: every sweep has to
+    take its one-row-per-thread / scalar form (the E-free sweep, the final E, the first shrink).  Same result as the aligned call."""
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    M, N = 3008, 96
+    D, _, _ = O.synth_lowrank_sparse(M, N, 6, seed=5)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    n = M * N
+    bufs = [torch.zeros(n + 2, dtype=torch.float64, device="cuda") for _ in range(3)]
+    dD, dA, dE = (b[1:n + 1] for b in bufs)                 # element 1: 8 bytes past the allocation's alignment
+    assert all(t.data_ptr() % 16 == 8 for t in (dD, dA, dE))
+    dD.copy_(torch.from_numpy(np.ascontiguousarray(D.T).ravel()))
+    torch.cuda.synchronize()
+    for kw in ({}, dict(nonnegA=True, nonnegE=True)):
+        if kw:
+            Dp = np.abs(D)
+            dD.copy_(torch.from_numpy(np.ascontiguousarray(Dp.T).ravel()))
+            A, E, s, sv, rep = eng.rpca(Dp, return_report=True, **kw)
+        sv2, rep2, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False, **kw)
+        assert st == 0 and sv2 == sv and rep2.iters_done == rep.iters_done
+        A2 = dA.cpu().numpy().reshape(N, M).T
+        E2 = dE.cpu().numpy().reshape(N, M).T
+        assert relerr(A2, A) < 1e-12 and relerr(E2, E) < 1e-12
+        assert np.array_equal(E2 == 0, E == 0)
+
+
 # --------------------------------------------------------------------------------------------
 # fp32, the svd / opnorm hook modes, wide matrices
 # --------------------------------------------------------------------------------------------
