@@ -15,4 +15,6 @@ echo "== C5 65536x4096 fp32 rank 64";        python tools/large_case.py 65536 40
 echo "== large mode 16384x8192 fp32 rank 40"; python tools/large_case.py 16384 8192 40 --f32 --no-hist 2>&1 | grep " iters="
 echo "== batched rtls 50x(3+1)";             python tools/bench_batched.py 2>&1 | grep -Ev "$F" | tail -1 | cut -c1-260
 echo "== batched rtls 500x(5+1)";            python tools/bench_batched.py --M 500 --n 5 --batch 4000 --cpu-problems 50 2>&1 | grep -Ev "$F" | tail -1 | cut -c1-260
+echo "== batched rtls 50x(3+1) fp32";        python tools/bench_batched.py --f32 2>&1 | grep -Ev "$F" | tail -1 | cut -c1-260
+echo "== noisy data 20000x512 (which solver serves the SVD steps)"; python tools/noisy_case.py 2>&1 | grep "^noise="
 echo "== rpca_ga";                           python tools/bench_ga.py --cases 10x40,10x1000,10x1000000,64x1000000,512x200000,2048x100000,4096x50000 2>&1 | grep "^d="

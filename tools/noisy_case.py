@@ -26,7 +26,7 @@ for noise in a.noise:
         sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False)
         dt = time.perf_counter() - t0
     line = (f"noise={noise:g}: iters={rep.iters_done} conv={rep.converged} sv={sv} subspace={rep.eig_fast} dense/tsqr={rep.eig_full} "
-            f"(tsqr {rep.tsqr_route if hasattr(rep, 'tsqr_route') else '?'}) steps={rep.subspace_steps} loop={rep.ms['loop']:.1f} ms wall={dt*1e3:.1f} ms")
+            f"steps={rep.subspace_steps} loop={rep.ms['loop']:.1f} ms wall={dt*1e3:.1f} ms")
     if a.check:
         from oracle import rpca_oracle as O
         Ao, Eo, so, svo, io = O.rpca(D)
