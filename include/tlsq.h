@@ -348,6 +348,11 @@ int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const do
 int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,
                        const double* Y, double* E, int64_t M, int64_t N, int64_t r, double inv_mu, double thr, int nonnegA,
                        int nonnegE);
+/* Matrix functions of a symmetric N x N device matrix (ld N, N <= 1024) by Newton-Schulz iterations on the MFMA GEMM
+ * (matfun.hip): X = sign(C); W = B^(-1/2) for positive definite B with eigenvalues <= hi.  *iters = steps taken; returns
+ * TLSQ_ERR_NOCONV when the iteration does not converge (an eigenvalue of C too close to zero / B not definite). */
+int tlsq_k_matfun_sign_f64(tlsq_handle h, const double* C, int64_t N, double* X, int32_t* iters);
+int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double hi, double* W, int32_t* iters);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

@@ -1149,6 +1149,41 @@ def test_efree_sweep_kernel(eng, torch_mod, M, N, r, nonneg, explicit):
         assert np.mean((got == 0) != (Eref == 0)) < 1e-6      # (A differs from the GEMM by summation order only)
 
 
+@pytest.mark.parametrize("N,gap", [(96, 1e-2), (256, 1e-3), (512, 1e-4), (130, 1e-6)])
+def test_matrix_functions_by_newton_schulz(eng, torch_mod, N, gap):
+    """matfun.hip: sign(C) and B^(-1/2) of symmetric matrices through MFMA products only, against the eigen-decomposition.
+    The spectrum mimics the use in the ALM loop: a flat bulk on both sides of zero with the nearest eigenvalue `gap` away
+    (relative to the largest), a few large ones."""
+    torch = torch_mod
+    rng = np.random.default_rng(N)
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    lam = np.concatenate([rng.uniform(gap, 0.3, N // 2), -rng.uniform(gap, 0.2, N - N // 2 - 3), [1.0, 0.7, 0.5]])
+    C = (Q * lam) @ Q.T
+    C = 0.5 * (C + C.T)
+    dC = to_dev(torch, C)
+    dX = torch.empty_like(dC)
+    import ctypes
+    its = ctypes.c_int32(0)
+    assert eng.lib.tlsq_k_matfun_sign_f64(eng.h, dptr(dC), N, dptr(dX), ctypes.byref(its)) == 0
+    eng.synchronize()
+    X = to_host(dX)
+    Xref = (Q * np.sign(lam)) @ Q.T
+    assert np.abs(X - Xref).max() < 1e-9 * max(1.0, 1e-3 / gap), (its.value, np.abs(X - Xref).max())
+    assert abs(np.trace(0.5 * (np.eye(N) + X)) - np.sum(lam > 0)) < 1e-8
+    assert its.value <= 12 + int(np.ceil(np.log(N / gap) / np.log(1.5)))
+    # inverse square root of a positive definite matrix with condition 1e3
+    mu = np.concatenate([rng.uniform(1e-3, 1.0, N - 1), [1.0]])
+    B = (Q * mu) @ Q.T
+    B = 0.5 * (B + B.T)
+    dB = to_dev(torch, B)
+    dW = torch.empty_like(dB)
+    assert eng.lib.tlsq_k_matfun_invsqrt_f64(eng.h, dptr(dB), N, 1.05, dptr(dW), ctypes.byref(its)) == 0
+    eng.synchronize()
+    W = to_host(dW)
+    Wref = (Q / np.sqrt(mu)) @ Q.T
+    assert np.abs(W - Wref).max() < 1e-10 * np.abs(Wref).max(), (its.value, np.abs(W - Wref).max())
+
+
 def test_rpca_large_panel_path_properties(eng):
     """2^26 elements (131072 x 512): the loop takes the fused rebuild + sweep kernel (A is only materialised after the
     loop).  Size-independent properties, as for the full C2 size."""

@@ -742,6 +742,31 @@ int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const d
         return set_err(h, TLSQ_ERR_ARG, "k_final_e: bad argument");
     return launch_final_e<double>(h, D, Tm, Vs, Aprev, Y, E, M, N, r, inv_mu, thr, nonnegA, nonnegE);
 }
+int tlsq_k_matfun_sign_f64(tlsq_handle h, const double* C, int64_t N, double* X, int32_t* iters) {
+    TLSQ_TRY(check_handle(h));
+    if (!C || !X || N <= 0 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "matfun_sign: bad argument (N <= 1024)");
+    void *w1, *w2;
+    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &w1));
+    TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &w2));
+    int it = 0;
+    bool ok = false;
+    TLSQ_TRY(matfun_sign(h, C, N, X, (double*)w1, (double*)w2, 100, &it, &ok));
+    if (iters) *iters = it;
+    return ok ? TLSQ_OK : set_err(h, TLSQ_ERR_NOCONV, "matfun_sign: no convergence in 100 steps");
+}
+int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double hi, double* W, int32_t* iters) {
+    TLSQ_TRY(check_handle(h));
+    if (!B || !W || N <= 0 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "matfun_invsqrt: bad argument (N <= 1024)");
+    void *y, *t, *w;
+    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &y));
+    TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &t));
+    TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &w));
+    int it = 0;
+    bool ok = false;
+    TLSQ_TRY(matfun_invsqrt(h, B, N, hi, W, (double*)y, (double*)t, (double*)w, 100, &it, &ok));
+    if (iters) *iters = it;
+    return ok ? TLSQ_OK : set_err(h, TLSQ_ERR_NOCONV, "matfun_invsqrt: no convergence in 100 steps");
+}
 int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !G || M < 0 || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "k_gram_f32: bad arguments");

@@ -228,6 +228,16 @@ int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG,
              int mfma32 = -1);   // fp32 panels: -1 library's choice, 0 fp64 MFMA on widened operands, 1 fp32 MFMA + fp64 fold-in
 
+// ---------------- matfun.hip ----------------
+// sign function / inverse square root of small symmetric matrices by Newton-Schulz iterations (N x N fp64, ld N; products on
+// the symmetric MFMA GEMM).  *ok = false: not converged within max_iters (an eigenvalue too close to zero) or not finite.
+int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, double* W2, int max_iters, int* iters, bool* ok);
+int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, double* Y, double* T, double* W, int max_iters,
+                   int* iters, bool* ok);
+int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf);
+int matfun_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b);   // Y = a X + b I
+int matfun_mul(Handle* h, const double* A, const double* B, double* C, int64_t N);        // commuting symmetric A, B
+
 // ---------------- jacobi.hip ----------------
 // One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal
 // columns, lam_dev[i] = ||B[:,i]|| (unsorted), V orthogonal (ld N) unless want_v == false.

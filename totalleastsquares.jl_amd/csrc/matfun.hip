@@ -1,0 +1,169 @@
+// Matrix functions of a small symmetric matrix through matrix products only (fp64 MFMA GEMM, gemm.hip): the sign function by
+// Newton-Schulz and the inverse square root by the coupled Newton-Schulz iteration.  Used by the ALM driver where the rank
+// count and the thresholded low-rank matrix are needed but not the singular vectors (solver.hip: noisy data, whose late
+// iterations would otherwise each cost a dense N x N decomposition):
+//     count of eigenvalues of G above t  = trace(P),  P = (I + sign(G - t I)) / 2          (src/robustPCA.jl:198)
+//     sum over them of v (1 - sqrt(t / lambda)) v'  = P - sqrt(t) B^(-1/2) P,  B = P G P + t (I - P)     (:205-213)
+// Every iterate is a polynomial in the input, so all products are products of commuting symmetric matrices: the GEMM runs in
+// its symmetric form (lower tiles computed, mirrored), which also keeps the iterates exactly symmetric.
+#include "common.hpp"
+
+namespace tlsq {
+
+// Y = a X + b I   (N x N, ld N)
+__global__ __launch_bounds__(256) void k_mf_axpbi(const double* X, double* Y, int N, double a, double b) {   // (Y may be X)
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        Y[e] = a * X[e] + (i == j ? b : 0.0);
+    }
+}
+
+// out[0] = ||X - I||_F^2, out[1] = trace(X), out[2] = max_i sum_j |X_ij|   (one workgroup; N <= 1024)
+__global__ __launch_bounds__(1024) void k_mf_stats(const double* __restrict__ X, int N, double* __restrict__ out) {
+    __shared__ double red[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double dev = 0.0, tr = 0.0, rmax = 0.0;
+    for (int i = tid; i < N; i += 1024) {   // row i, read as X[i + j N]: consecutive threads, consecutive addresses
+        double rs = 0.0;
+        for (int j = 0; j < N; ++j) {
+            const double v = X[(size_t)j * N + i];
+            const double dd = v - (i == j ? 1.0 : 0.0);
+            dev += dd * dd;
+            rs += fabs(v);
+            if (i == j) tr += v;
+        }
+        rmax = rs > rmax ? rs : rmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dev += __shfl_down(dev, off, 64);
+        tr += __shfl_down(tr, off, 64);
+        const double o = __shfl_down(rmax, off, 64);
+        rmax = o > rmax ? o : rmax;
+    }
+    if (lane == 0) {
+        red[0][w] = dev;
+        red[1][w] = tr;
+        red[2][w] = rmax;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            a += red[0][k];
+            b += red[1][k];
+            c = red[2][k] > c ? red[2][k] : c;
+        }
+        out[0] = a;
+        out[1] = b;
+        out[2] = c;
+    }
+}
+
+static int mf_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_mf_axpbi, dim3((int)g), dim3(256), 0, h->stream, X, Y, (int)N, a, b);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// host copies of { ||X - I||_F^2, trace(X), ||X||_inf }
+static int mf_stats(Handle* h, const double* X, int64_t N, double out[3]) {
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 1728);   // (behind the two sets of bound slots)
+    hipLaunchKernelGGL(k_mf_stats, dim3(1), dim3(1024), 0, h->stream, X, (int)N, dev);
+    TLSQ_HIP(h, hipGetLastError());
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, dev, 24, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(out, h->pinned, 24);
+    return TLSQ_OK;
+}
+
+// C = A B for commuting symmetric N x N matrices (C symmetric)
+static int mf_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) {
+    return gemm_f64(h, true, true, A, N, B, N, C, N, N, N, N, true);
+}
+
+// X = sign(C) for the symmetric C (N x N): X_0 = C / ||C||_inf, X <- X (1.5 I - 0.5 X^2) until ||X^2 - I||_F <= 1e-4, then
+// two more steps (quadratic convergence: 1e-8, 1e-16).  W1, W2: N x N scratch.  *iters: steps taken; *ok = false when the
+// matrix has an eigenvalue so close to zero that `max_iters` steps do not separate it (each step moves it by 1.5x).
+int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, double* W2, int max_iters, int* iters, bool* ok) {
+    *ok = false;
+    *iters = 0;
+    double st[3];
+    TLSQ_TRY(mf_stats(h, C, N, st));
+    const double nrm = st[2];
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) return TLSQ_OK;
+    TLSQ_TRY(mf_axpbi(h, C, X, N, 1.0 / nrm, 0.0));
+    int extra = -1;   // steps still to do after the error dropped below 1e-4 (-1: not yet)
+    for (int it = 0; it < max_iters; ++it) {
+        TLSQ_TRY(mf_mul(h, X, X, W1, N));                 // W1 = X^2
+        // the convergence test costs a host round trip: not before the linear phase can be over, then every third step
+        if (extra < 0 && it >= 6 && (it % 3) == 0) {
+            TLSQ_TRY(mf_stats(h, W1, N, st));
+            if (!std::isfinite(st[0])) return TLSQ_OK;
+            if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+        }
+        if (extra == 0) {
+            *iters = it;
+            *ok = true;
+            return TLSQ_OK;
+        }
+        TLSQ_TRY(mf_axpbi(h, W1, W1, N, -0.5, 1.5));      // W1 = 1.5 I - 0.5 X^2
+        TLSQ_TRY(mf_mul(h, X, W1, W2, N));                // W2 = X W1
+        TLSQ_HIP(h, hipMemcpyAsync(X, W2, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (extra > 0) --extra;
+    }
+    return TLSQ_OK;
+}
+
+// Z = B^(-1/2) for the symmetric positive definite B (N x N) with eigenvalues in [lo, hi] (hi: any upper bound): coupled
+// Newton-Schulz  T = 1.5 I - 0.5 Z Y,  Y <- Y T,  Z <- T Z  from Y_0 = B / hi, Z_0 = I; Z -> (B / hi)^(-1/2).  Y, T, W: scratch.
+int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, double* Y, double* T, double* W, int max_iters,
+                   int* iters, bool* ok) {
+    *ok = false;
+    *iters = 0;
+    if (!(hi > 0.0) || !std::isfinite(hi)) return TLSQ_OK;
+    TLSQ_TRY(mf_axpbi(h, B, Y, N, 1.0 / hi, 0.0));
+    TLSQ_TRY(mf_axpbi(h, B, Z, N, 0.0, 1.0));
+    int extra = -1;
+    double st[3];
+    for (int it = 0; it < max_iters; ++it) {
+        TLSQ_TRY(mf_mul(h, Z, Y, T, N));                  // T = Z Y  (-> I)
+        if (extra < 0 && it >= 3) {
+            TLSQ_TRY(mf_stats(h, T, N, st));
+            if (!std::isfinite(st[0])) return TLSQ_OK;
+            if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+        }
+        if (extra == 0) {
+            TLSQ_TRY(mf_axpbi(h, Z, Z, N, 1.0 / std::sqrt(hi), 0.0));
+            *iters = it;
+            *ok = true;
+            return TLSQ_OK;
+        }
+        TLSQ_TRY(mf_axpbi(h, T, T, N, -0.5, 1.5));        // T = 1.5 I - 0.5 Z Y
+        TLSQ_TRY(mf_mul(h, Y, T, W, N));                  // Y <- Y T
+        TLSQ_HIP(h, hipMemcpyAsync(Y, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        TLSQ_TRY(mf_mul(h, T, Z, W, N));                  // Z <- T Z
+        TLSQ_HIP(h, hipMemcpyAsync(Z, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (extra > 0) --extra;
+    }
+    return TLSQ_OK;
+}
+
+// trace(X) and ||X||_inf of a symmetric N x N matrix on the host
+int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf) {
+    double st[3];
+    TLSQ_TRY(mf_stats(h, X, N, st));
+    if (trace) *trace = st[1];
+    if (norm_inf) *norm_inf = st[2];
+    return TLSQ_OK;
+}
+
+int matfun_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b) { return mf_axpbi(h, X, Y, N, a, b); }
+int matfun_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) { return mf_mul(h, A, B, C, N); }
+
+}  // namespace tlsq
