@@ -1239,6 +1239,26 @@ def test_tiny_noise_stays_on_the_subspace_route(eng):
     assert rep.eig_full <= 1, rep.eig_full        # (the returned decomposition is computed after the loop, not counted)
 
 
+@pytest.mark.parametrize("M,N,r,noise", [(3000, 200, 8, 1e-4), (2000, 128, 8, 1e-3), (1500, 160, 5, 1e-2)])
+def test_noisy_data_matrix_function_route(eng, M, N, r, noise):
+    """Dense noise on top of low rank + sparse: once noise singular values cross 1/mu the rank jumps to ~N/2 and no subspace
+    block or certificate applies.  The loop then takes the count and A from matrix functions of the deflated panel's Gram
+    matrix (sign function / inverse square root by Newton-Schulz, solver.hip: matfun_route) instead of a dense decomposition
+    per iteration: same iterations, rank trajectory and results as the oracle, and only a few iterations left to TSQR."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(1)
+    D = (rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)
+         + noise * rng.standard_normal((M, N)))
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert (sv, rep.iters_done) == (svo, io.iters_done) and sv > 4 * r
+    assert rep.svp_hist == io.svp_hist
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    assert np.mean((E == 0) != (Eo == 0)) < 1e-6           # (E is formed from D - A - R here: zeros snapped, see sweeps.hip)
+    np.testing.assert_allclose(s[1], so[1], rtol=1e-9, atol=1e-12 * so[1][0])
+    assert rep.tsqr_iterations <= rep.iters_done // 3, (rep.tsqr_iterations, rep.iters_done)   # (without the route: every late iteration)
+
+
 def test_efree_loop_against_classic_sweeps(eng, tmp_path):
     """The default loop keeps no E while it runs (sweeps.hip, k_zsweep: Y' = mu (Z - A), R = Z - A - Y / mu, E formed once
     after the loop from the kept factors of A_{k-1}); TLSQ_NO_ZSWEEP=1 (read once per process, hence the subprocess) runs the

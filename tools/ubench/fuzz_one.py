@@ -18,6 +18,7 @@ eng = tlsq_amd.Engine(0)
 A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
 Ao, Eo, so, svo, io = O.rpca(D, **kw)
 k = next((i for i, (a, b) in enumerate(zip(rep.svp_hist, io.svp_hist)) if a != b), None)
+print(f"errA={np.linalg.norm(A - Ao) / np.linalg.norm(D):.2e} errE={np.linalg.norm(E - Eo) / np.linalg.norm(D):.2e}")
 print(desc, kw, "iters", rep.iters_done, io.iters_done, "sv", sv, svo, "first diff", k,
       "tsqr iters", rep.tsqr_iterations, "full", rep.eig_full, "fast", rep.eig_fast)
 if k is not None:

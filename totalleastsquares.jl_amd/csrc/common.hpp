@@ -108,7 +108,8 @@ enum WsSlot {
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
     WS_HKSUM,     // soft_hankel! on row shards: anti-diagonal sums and counts of the whole matrix (solver.hip)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
-    WS_T2, WS_VS2, WS_VS3, WS_T3,      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
+    WS_T2, WS_VS2, WS_VS3, WS_T3,
+    WS_MF0, WS_MF1, WS_MF2, WS_MF3,   // matrix-function route (solver.hip): N x N iterates      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
@@ -159,6 +160,11 @@ template <typename T>
 int launch_residual_from_y(Handle* h, const T* Y1, const T* Y0, T* R, int64_t n, T inv_mu);
 template <typename T>
 int launch_z_from_y(Handle* h, const T* A, const T* Y1, T* Z, int64_t n, T inv_mu);
+// the returned E without the factors of A_{k-1}: D - A - (Y1 - Y0) / mu, or D - Z + Y / mu; rounding noise snapped to zero
+template <typename T>
+int launch_e_from_residual(Handle* h, const T* D, const T* A, const T* Y1, const T* Y0, T* E, int64_t n, T inv_mu);
+template <typename T>
+int launch_e_from_z(Handle* h, const T* D, const T* Z, const T* Y, T* E, int64_t n, T inv_mu);
 template <typename T>
 bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r);
 template <typename T>
@@ -235,8 +241,13 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
 int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, double* Y, double* T, double* W, int max_iters,
                    int* iters, bool* ok);
 int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf);
+int matfun_stats(Handle* h, const double* X, int64_t N, double out[3]);   // { ||X - I||_F^2, trace(X), ||X||_inf } of a symmetric X
 int matfun_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b);   // Y = a X + b I
 int matfun_mul(Handle* h, const double* A, const double* B, double* C, int64_t N);        // commuting symmetric A, B
+// PhiT = ((I - Xs Xs') F + Xs diag(w) Xs')' for symmetric F, Y = F Xs (see matfun.hip)
+int matfun_phi(Handle* h, const double* F, const double* Xs, const double* Y, const SelWeights& sw, int64_t r, int64_t N,
+               double* PhiT);
+int matfun_lin2(Handle* h, const double* X1, double a1, const double* X2, double a2, double b, double* Y, int64_t N);   // Y = a1 X1 + a2 X2 + b I
 
 // ---------------- jacobi.hip ----------------
 // One-sided block Jacobi on the square matrix G (N x N, ld N): on return B = G*V has orthogonal

@@ -61,6 +61,30 @@ __global__ __launch_bounds__(1024) void k_mf_stats(const double* __restrict__ X,
     }
 }
 
+// Y = a1 X1 + a2 X2 + b I   (Y may be X1 or X2)
+__global__ __launch_bounds__(256) void k_mf_lin2(const double* X1, double a1, const double* X2, double a2, double b, double* Y, int N) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        Y[e] = a1 * X1[e] + a2 * X2[e] + (i == j ? b : 0.0);
+    }
+}
+
+// PhiT[i, k] = F[i, k] + sum_s (w_s Xs[i, s] - Y[i, s]) Xs[k, s]: the transpose of Phi = (I - Xs Xs') F + Xs diag(w) Xs' for a
+// symmetric F and Y = F Xs (N x r panels, ld N, r <= 32) - right-multiplying a panel by Phi takes the Xs directions out of F
+// exactly (to the orthonormality of Xs) and puts the weighted dominant part back
+__global__ __launch_bounds__(256) void k_mf_phi(const double* __restrict__ F, const double* __restrict__ Xs,
+                                                const double* __restrict__ Y, SelWeights sw, int r, int N,
+                                                double* __restrict__ PhiT) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), k = (int)(e / N);
+        double v = F[e];
+        for (int s = 0; s < r; ++s) v += (sw.w[s] * Xs[i + (size_t)s * N] - Y[i + (size_t)s * N]) * Xs[k + (size_t)s * N];
+        PhiT[e] = v;
+    }
+}
+
 static int mf_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b) {
     int64_t g = (N * N + 255) / 256;
     if (g > 2048) g = 2048;
@@ -163,7 +187,23 @@ int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, doub
     return TLSQ_OK;
 }
 
+int matfun_phi(Handle* h, const double* F, const double* Xs, const double* Y, const SelWeights& sw, int64_t r, int64_t N,
+               double* PhiT) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_mf_phi, dim3((int)g), dim3(256), 0, h->stream, F, Xs, Y, sw, (int)r, (int)N, PhiT);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+int matfun_stats(Handle* h, const double* X, int64_t N, double out[3]) { return mf_stats(h, X, N, out); }
 int matfun_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b) { return mf_axpbi(h, X, Y, N, a, b); }
+int matfun_lin2(Handle* h, const double* X1, double a1, const double* X2, double a2, double b, double* Y, int64_t N) {
+    int64_t g = (N * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_mf_lin2, dim3((int)g), dim3(256), 0, h->stream, X1, a1, X2, a2, b, Y, (int)N);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
 int matfun_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) { return mf_mul(h, A, B, C, N); }
 
 }  // namespace tlsq

@@ -1260,6 +1260,176 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         return TLSQ_OK;
     };
+    // ---- the matrix-function route: count and A without singular vectors (noisy data) ------------------------------------------
+    // Once noise singular values cross 1/mu the rank jumps to ~N/2 and no subspace block or certificate applies: every such
+    // iteration used to cost a dense decomposition (TSQR + one-sided Jacobi, 39 ms at N = 512).  The loop only needs the count
+    // and A (:198, :205-213), and both are matrix functions of the Gram matrix G2 of the deflated panel Z2 = Z (I - X_S X_S')
+    // (S = the dominant Ritz pairs, taken out so that G2 is accurate at the scale of the threshold):
+    //     P = (I + sign(G2 mu^2 - I)) / 2,   svp = |S| + trace(P),
+    //     A = Z Phi,  Phi = X_S diag(g) X_S' + F,  F = P - (P G2 mu^2 P + I - P)^(-1/2) P   (F = P without nukeA)
+    // by Newton-Schulz iterations (matfun.hip: ~100 N x N x N MFMA products, 2-3 ms) and one M x N x N product.  A sign
+    // iteration that does not converge (an eigenvalue within ~1e-10 of the threshold) or a trace that is not an integer to
+    // 1e-6 leaves the iteration to the TSQR route.  A_k has no factor form afterwards: see last_no_factors.
+    static const bool no_matfun = [] { const char* e = getenv("TLSQ_NO_MATFUN_ROUTE"); return e && e[0] == '1'; }();
+    const bool matfun_possible = !no_matfun && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32 &&
+                                 N >= 64 && N <= 1024;
+    bool last_no_factors = false, prev_no_factors = false;   // A_k / A_{k-1} exist only as panels (E-free loop: how E is formed)
+    auto matfun_route = [&](const T* Zp, double inv_mu_, int64_t* svp_out, double* sigma_top_out, bool* ok) -> int {
+        *ok = false;
+        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        const double tau2 = inv_mu_ * inv_mu_;
+        // dominant part from the Gram matrix of Z (its Ritz values are far above G's noise): no window, no certificate
+        double* Gz = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, Zp, M, N, M, &Gz));
+        hbm_other += panel_bytes;
+        GramOp gop;
+        gop.G = Gz;
+        SmallSvd ss;
+        double* X = nullptr;
+        bool got = false;
+        // (only the pairs a factor 1e3 above the threshold are wanted: the solver is asked for those - it counts, and checks the
+        //  residuals of, the Ritz values above sqrt(1e3) / mu - on a block cut back to its leading columns)
+        if (sub.valid && sub.p > 48) {
+            sub.p = 48;
+            sub.ntop = std::min<int64_t>(sub.ntop, 40);
+        }
+        sub.noise_rel = 0.0;
+        sub.skip_certificate = true;
+        sub.defer_certificate = false;
+        const int st_sub = svd_subspace(h, gop, N, inv_mu_ * std::sqrt(1e3), sub, &X, ss, &sweeps, &got);
+        sub.skip_certificate = false;
+        if (st_sub < 0) return st_sub;
+        if (!got || !X || ss.ncols <= 0) return TLSQ_OK;
+        const double stop = ss.sigma[ss.order[0]];
+        const double dl = noise_rel * stop * stop;
+        std::vector<int32_t> sel;
+        std::vector<double> gw;
+        // S = the leading Ritz pairs, cut where the spectrum has a gap.  Mixing inside S is harmless (nearly equal weights g);
+        // what must be small is the leak between span(S) and the rest: the solver's residual bound is 2e-13 lambda_top in
+        // absolute terms, so the angle is <= 2e-13 lambda_top / gap, and the error it puts into A is sigma times that - kept
+        // below 1e-10 sigma_top by asking for gap >= 2e-3 sqrt(lambda_top theta) at the cut.  Signal values pass; a noise
+        // value that has grown past 1e3 / mu^2 sits in a cluster of its like and is left to G2, where clusters do not matter.
+        int64_t cnt = 0;
+        while (cnt < ss.ncols && cnt < 32) {
+            const double sg = ss.sigma[ss.order[cnt]];
+            if (!(sg * sg >= std::max(1e3 * tau2, tau2 + 2.0 * dl))) break;
+            ++cnt;
+        }
+        while (cnt > 0) {
+            const double sg = ss.sigma[ss.order[cnt - 1]];
+            const double sg1 = cnt < ss.ncols ? ss.sigma[ss.order[cnt]] : 0.0;
+            if (sg * sg - sg1 * sg1 >= 2e-3 * stop * sg) break;
+            --cnt;
+        }
+        for (int64_t i = 0; i < cnt; ++i) {
+            const double sg = ss.sigma[ss.order[i]];
+            sel.push_back(ss.order[i]);
+            gw.push_back(ro.nukeA ? (sg - inv_mu_) / sg : 1.0);   // :205-213
+        }
+        const int64_t rS = (int64_t)sel.size();
+        // What stays in G2 has to be (a) small enough for G2's own rounding to sit far below the threshold and (b) within
+        // 1e4 of the threshold: the inverse square root loses eps * cond(B) of its relative accuracy.
+        const double next = rS < ss.ncols ? ss.sigma[ss.order[rS]] : 0.0;
+        if (!(noise_rel * next * next < 1e-4 * tau2) || !(next * next <= 1e4 * tau2)) return TLSQ_OK;
+        const T* Z2 = Zp;
+        if (rS > 0) {
+            std::vector<double> ones((size_t)rS, 1.0);
+            const double *TmS = nullptr, *VsS = nullptr;
+            TLSQ_TRY(rebuild_factors<T>(h, Zp, M, N, M, X, sel, ones, &TmS, &VsS, 3));
+            TLSQ_TRY(rebuild_from_factors<T>(h, TmS, VsS, M, N, rS, R, M));
+            TLSQ_TRY(launch_diff<T>(h, Zp, R, R, n));                                    // R = Z2
+            Z2 = R;
+            hbm_other += 5.0 * panel_bytes;
+        }
+        double* G2 = nullptr;
+        TLSQ_TRY(gram_allreduce<T>(h, Z2, M, N, M, &G2));
+        hbm_other += panel_bytes;
+        void *G2s, *Cm, *Xs, *W1, *W2, *Wz, *Yb;
+        TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &G2s));
+        TLSQ_TRY(ws_get(h, WS_MF0, (size_t)N * N * 8, &Cm));
+        TLSQ_TRY(ws_get(h, WS_MF1, (size_t)N * N * 8, &Xs));
+        TLSQ_TRY(ws_get(h, WS_MF2, (size_t)N * N * 8, &Wz));
+        TLSQ_TRY(ws_get(h, WS_MF3, (size_t)N * N * 8, &Yb));
+        TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &W1));
+        TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &W2));
+        TLSQ_TRY(matfun_axpbi(h, G2, (double*)G2s, N, 1.0 / tau2, 0.0));                  // G2 mu^2
+        TLSQ_TRY(matfun_axpbi(h, (const double*)G2s, (double*)Cm, N, 1.0, -1.0));         // C = G2 mu^2 - I
+        int it_s = 0, it_r = 0;
+        bool conv = false;
+        TLSQ_TRY(matfun_sign(h, (const double*)Cm, N, (double*)Xs, (double*)W1, (double*)W2, 70, &it_s, &conv));
+        if (!conv) {
+            if (dbg) fprintf(stderr, "  matrix-function route: sign iteration did not converge (|S|=%lld)\n", (long long)rS);
+            return TLSQ_OK;
+        }
+        double* Pm = (double*)Xs;
+        TLSQ_TRY(matfun_axpbi(h, (const double*)Xs, Pm, N, 0.5, 0.5));                    // P = (I + sign) / 2
+        double tr = 0.0;
+        TLSQ_TRY(matfun_trace_norm(h, Pm, N, &tr, nullptr));
+        const double k2d = std::round(tr);
+        if (!std::isfinite(tr) || std::fabs(tr - k2d) > 1e-6 || k2d < 0.0 || k2d > (double)(N - rS)) {
+            if (dbg) fprintf(stderr, "  matrix-function route: trace(P) = %.9f is not a count\n", tr);
+            return TLSQ_OK;
+        }
+        const int64_t k2 = (int64_t)k2d;
+        double* Fm = (double*)Cm;   // (C is not needed any more)
+        if (ro.nukeA && k2 > 0) {
+            // B = P G2s P + I - P = G2s P + I - P (P is a projector that commutes with G2s)
+            TLSQ_TRY(matfun_mul(h, (const double*)G2s, Pm, (double*)W1, N));
+            TLSQ_TRY(matfun_lin2(h, (const double*)W1, 1.0, Pm, -1.0, 1.0, (double*)W2, N));   // B
+            double bn = 0.0;
+            TLSQ_TRY(matfun_trace_norm(h, (const double*)W2, N, nullptr, &bn));
+            bool conv2 = false;
+            // (W2 = B is only read by the first statement of the iteration; W1 and G2s serve as its scratch)
+            TLSQ_TRY(matfun_invsqrt(h, (const double*)W2, N, bn, (double*)Wz, (double*)Yb, (double*)W1, (double*)G2s, 60, &it_r,
+                                    &conv2));
+            if (!conv2) {
+                if (dbg) fprintf(stderr, "  matrix-function route: inverse square root did not converge\n");
+                return TLSQ_OK;
+            }
+            // The coupled iteration loses accuracy quickly once cond(B) reaches a few thousand (rounding breaks the
+            // commutativity it relies on): accept W only with the residual ||W B W - I||_F <= 1e-9 in hand
+            {
+                TLSQ_TRY(matfun_mul(h, (const double*)Wz, (const double*)W2, (double*)W1, N));      // W B
+                TLSQ_TRY(matfun_mul(h, (const double*)W1, (const double*)Wz, (double*)G2s, N));     // W B W
+                double rs[3];
+                TLSQ_TRY(matfun_stats(h, (const double*)G2s, N, rs));
+                if (!(rs[0] <= 1e-18)) {
+                    if (dbg) fprintf(stderr, "  matrix-function route: inverse square root residual %.2e: rejected\n", std::sqrt(rs[0]));
+                    return TLSQ_OK;
+                }
+            }
+            TLSQ_TRY(matfun_mul(h, (const double*)Wz, Pm, (double*)W1, N));               // B^(-1/2) P
+            TLSQ_TRY(matfun_lin2(h, Pm, 1.0, (const double*)W1, -1.0, 0.0, Fm, N));        // F = P - B^(-1/2) P
+        } else {
+            TLSQ_TRY(matfun_axpbi(h, Pm, Fm, N, 1.0, 0.0));                               // F = P  (:211-212)
+        }
+        // A = Z2 F + (Z X_S) diag(g) X_S' = Z Phi,  Phi = (I - X_S X_S') F + X_S diag(g) X_S'.  (Not Z (F + ...): F only
+        // annihilates X_S to ~1e-9 - rounding of G2 over the gap - and Z X_S is sigma_top large.)  The GEMM takes Phi'.
+        double* Phi = (double*)Yb;
+        if (rS > 0) {
+            SelWeights sw;
+            for (int64_t i = 0; i < 32; ++i) {
+                sw.sel[i] = 0;
+                sw.w[i] = i < rS ? gw[(size_t)i] : 0.0;
+            }
+            const double* XsS = (const double*)h->ws[WS_VS].p;   // X_S, gathered by rebuild_factors above (N x rS)
+            TLSQ_TRY(launch_symm_skinny(h, Fm, N, XsS, (double*)W1, N, rS));              // Y = F X_S
+            TLSQ_TRY(matfun_phi(h, Fm, XsS, (const double*)W1, sw, rS, N, Phi));
+        } else {
+            Phi = Fm;
+        }
+        // A = Z Phi through Phi' (the GEMM's first operand is indexed [column of A, k])
+        TLSQ_TRY(need_A());
+        TLSQ_TRY(gemm_mixed(h, false, false, Phi, 0, N, Zp, Prec<T>::f32, M, A, Prec<T>::f32, M, N, M, N, false));
+        hbm_other += 2.0 * panel_bytes;
+        *svp_out = rS + k2;
+        *sigma_top_out = stop;
+        *ok = true;
+        if (dbg)
+            fprintf(stderr, "  matrix-function route: |S|=%lld + trace(P)=%lld, sign %d steps, inverse sqrt %d steps\n", (long long)rS,
+                    (long long)k2, it_s, it_r);
+        return TLSQ_OK;
+    };
     bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
     const double t_loop0 = now_ms();
     int64_t k = 0;
@@ -1275,6 +1445,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             Vs_prev = Vs_last;
             r_prev = r_last;
         }
+        prev_no_factors = last_no_factors;
+        last_no_factors = false;
         pt.mark(false, !have_next);
         if (!have_next)
         {
@@ -1533,6 +1705,67 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             g_ready = false;
             pt.mark(true);
         }
+        bool matfun_done = false;
+        if (r_route && matfun_possible && k >= 2 && !hook_now) {
+            int64_t svp_m = 0;
+            double stop_m = 0.0;
+            bool okm = false;
+            TLSQ_TRY(matfun_route(Z, inv_mu, &svp_m, &stop_m, &okm));
+            if (okm) {
+                // what count_and_rebuild does, without singular vectors: A is already in memory
+                if (!rebuild_marked) {
+                    pt.mark();
+                    rebuild_marked = true;
+                }
+                static const bool dbg_cmp = [] { const char* e = getenv("TLSQ_DEBUG"); return e && e[0] == '3'; }();
+                if (dbg_cmp) {   // development: the same iteration through the TSQR route, A compared
+                    std::vector<T> a_mf((size_t)n), a_rf((size_t)n);
+                    TLSQ_HIP(h, hipMemcpyAsync(a_mf.data(), A, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+                    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                    double* V2 = nullptr;
+                    SmallSvd s2;
+                    TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V2, s2, &sweeps));
+                    std::vector<int32_t> sel2;
+                    std::vector<double> g2;
+                    for (int64_t i = 0; i < s2.ncols; ++i) {
+                        const double sg = s2.sigma[s2.order[i]];
+                        if (sg >= inv_mu) {
+                            sel2.push_back(s2.order[i]);
+                            g2.push_back(ro.nukeA ? (sg - inv_mu) / sg : 1.0);
+                        }
+                    }
+                    TLSQ_TRY(rebuild_lowrank<T>(h, Z, M, N, M, V2, sel2, g2, R, M));
+                    TLSQ_HIP(h, hipMemcpyAsync(a_rf.data(), R, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+                    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                    double num = 0.0, den = 0.0;
+                    for (size_t i = 0; i < (size_t)n; ++i) {
+                        const double d = (double)a_mf[i] - (double)a_rf[i];
+                        num += d * d;
+                        den += (double)a_rf[i] * (double)a_rf[i];
+                    }
+                    fprintf(stderr, "  [cmp k=%lld] count %lld vs %lld, ||A_mf - A_svd|| / ||A_svd|| = %.3e, sigma_top %.3e, 1/mu %.3e, sigma[cnt] %.3e\n",
+                            (long long)k, (long long)svp_m, (long long)sel2.size(), std::sqrt(num / std::max(den, 1e-300)),
+                            s2.sigma[s2.order[0]], inv_mu, sel2.size() < (size_t)s2.ncols ? s2.sigma[s2.order[sel2.size()]] : 0.0);
+                }
+                r_route = false;
+                matfun_done = true;
+                svp = svp_m;                                               // :198
+                sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
+                sigma_top = stop_m;
+                sigma_top_prev = stop_m;
+                mu_next = std::min(mu * ro.rho, mubar);                    // :223
+                fuse = !no_fuse && k < ro.iters;
+                fuse_rebuild = false;
+                Tm_last = Vs_last = nullptr;
+                r_last = svp;
+                a_pending = false;
+                rebuilt = true;
+                last_no_factors = true;
+                V = nullptr;
+                g_ready = false;
+                ++sub.fast;
+            }
+        }
         if (r_route) {
             TLSQ_TRY(svd_via_r<T>(h, Z, M, N, M, &V, s, &sweeps));
             if (hook_now) s.ncols = std::min<int64_t>(s.ncols, sv);   // rank-sv truncation of the hook
@@ -1542,7 +1775,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         v_is_full = r_route && !hook_now;
         if (!rebuilt) TLSQ_TRY(count_and_rebuild(!rebuild_marked));
-        if (use_subspace) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
+        if (use_subspace && !matfun_done) TLSQ_TRY(carry_block(h, V, N, s, svp, pmax, sub));
         }   // !(cb_svd && k >= 2)
         if (ro.hankel) TLSQ_TRY(soft_hankel(A, (T)thr));  // :214-216
 
@@ -1611,7 +1844,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         };
         if (zmode && !fuse) {
             // the last allowed iteration (no next shrink to fuse with): E_k is formed now, then the plain residual :217-221
-            TLSQ_TRY(form_final_e(Ybuf[ycur], mu));
+            if (prev_no_factors) {   // A_{k-1} has no factor form: E_k = D - Z_k + Y_k / mu_k (:192)
+                TLSQ_TRY(panel_D(&D));
+                TLSQ_TRY(launch_e_from_z<T>(h, D, Zbuf[0], Ybuf[ycur], Ebuf[0], n, (T)inv_mu));
+            } else {
+                TLSQ_TRY(form_final_e(Ybuf[ycur], mu));
+            }
             if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
             if (ro.hankel_y && (!Dm || d_transient)) {
                 TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, Ebuf[0], R, M, N));
@@ -1861,8 +2099,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             TLSQ_TRY(launch_z_from_y<T>(h, A, Ybuf[ycur ^ 1], Zbuf[0], n, (T)(1.0 / mu_iter)));
             hbm_sweeps += 3.0 * panel_bytes;
         }
-        TLSQ_TRY(form_final_e(Ybuf[ycur], mu_iter));
-        hbm_sweeps += (ro.hankel_y && r_prev <= 32 ? 2.0 : 3.0) * panel_bytes;
+        if (prev_no_factors) {   // A_{k-1} has no factor form: E_k = D - A_k - R_k, R_k = (Y_{k+1} - Y_k) / mu_k (:221-222)
+            TLSQ_TRY(panel_D(&D));
+            TLSQ_TRY(launch_e_from_residual<T>(h, D, A, Ybuf[ycur ^ 1], Ybuf[ycur], Ebuf[0], n, (T)(1.0 / mu_iter)));
+            hbm_sweeps += 5.0 * panel_bytes;
+        } else {
+            TLSQ_TRY(form_final_e(Ybuf[ycur], mu_iter));
+            hbm_sweeps += (ro.hankel_y && r_prev <= 32 ? 2.0 : 3.0) * panel_bytes;
+        }
     }
     if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));

@@ -539,6 +539,36 @@ __global__ __launch_bounds__(256) void k_final_e_lin(const T* __restrict__ D, co
     }
 }
 
+// The returned E when A_{k-1} has no factor form (the iteration before was served by the matrix-function route, solver.hip):
+// E_k = D - A_k - R_k with R_k = (Y_{k+1} - Y_k) / mu_k (:221-222), or E_k = D - Z_k + Y_k / mu_k (:192) when no sweep followed.
+// Both equal the reference's soft_th statement up to rounding; entries that are rounding noise of an exact zero (below 32 eps
+// of the magnitudes that went into them) are set to zero, so that E keeps the zero pattern of the shrinkage.
+// E may be the buffer Y0 / Y lives in.
+template <typename T>
+__global__ __launch_bounds__(256) void k_e_from_residual(const T* __restrict__ D, const T* __restrict__ A, const T* Y1,
+                                                         const T* Y0, T* E, int64_t n, T inv_mu) {
+    const T eps32 = (T)32 * std::numeric_limits<T>::epsilon();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T d = D[i], a = A[i], y1 = Y1[i] * inv_mu, y0 = Y0[i] * inv_mu;
+        const T e = (d - a) - (y1 - y0);
+        const T mag = fabs(d) + fabs(a) + fabs(y1) + fabs(y0);
+        E[i] = fabs(e) <= eps32 * mag ? (T)0 : e;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_e_from_z(const T* __restrict__ D, const T* __restrict__ Z, const T* Y, T* E,
+                                                  int64_t n, T inv_mu) {
+    const T eps32 = (T)32 * std::numeric_limits<T>::epsilon();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T d = D[i], z = Z[i], y = Y[i] * inv_mu;
+        const T e = (d - z) + y;
+        const T mag = fabs(d) + fabs(z) + fabs(y);
+        E[i] = fabs(e) <= eps32 * mag ? (T)0 : e;
+    }
+}
+
 // R_k = (Y_{k+1} - Y_k) / mu_k (:222 solved for the residual): only when an E-free sweep was told not to store R_k and
 // the cost evaluation wants it after all
 template <typename T>
@@ -1030,6 +1060,22 @@ int launch_residual_from_y(Handle* h, const T* Y1, const T* Y0, T* R, int64_t n,
 }
 
 template <typename T>
+int launch_e_from_residual(Handle* h, const T* D, const T* A, const T* Y1, const T* Y0, T* E, int64_t n, T inv_mu) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_e_from_residual<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Y1, Y0, E, n, inv_mu);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
+int launch_e_from_z(Handle* h, const T* D, const T* Z, const T* Y, T* E, int64_t n, T inv_mu) {
+    if (n <= 0) return TLSQ_OK;
+    hipLaunchKernelGGL((k_e_from_z<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, Z, Y, E, n, inv_mu);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+template <typename T>
 int launch_z_from_y(Handle* h, const T* A, const T* Y1, T* Z, int64_t n, T inv_mu) {
     if (n <= 0) return TLSQ_OK;
     hipLaunchKernelGGL((k_z_from_y<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, A, Y1, Z, n, inv_mu);
@@ -1149,6 +1195,8 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
                                    int64_t, int64_t, T, T, int, int, const T*, int64_t);                              \
     template int launch_residual_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                              \
     template int launch_z_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                                     \
+    template int launch_e_from_residual<T>(Handle*, const T*, const T*, const T*, const T*, T*, int64_t, T);          \
+    template int launch_e_from_z<T>(Handle*, const T*, const T*, const T*, T*, int64_t, T);                           \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
     template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
