@@ -110,6 +110,16 @@ static int mf_stats(Handle* h, const double* X, int64_t N, double out[3]) {
 static int mf_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) {
     return gemm_f64(h, true, true, A, N, B, N, C, N, N, N, N, true);
 }
+// C = A B in full (no symmetry assumed): C[i, j] = sum_k A[i, k] B[k, j], all three column-major.  The coupled iteration below
+// is stable as written (Higham, Functions of Matrices, sec. 6.4); mirroring one triangle of Y T and T Z would replace its
+// small commutator errors by errors of the same size in the iterates themselves (TLSQ_MATFUN_SYM=1: the symmetric form).
+static int mf_mul_full(Handle* h, const double* A, const double* B, double* C, int64_t N) {
+    static const bool sym = [] { const char* e = getenv("TLSQ_MATFUN_SYM"); return e && e[0] == '1'; }();
+    if (sym) return mf_mul(h, A, B, C, N);
+    // gemm convention: Cm[j + i ldc] = sum_k Aop(i, k) Bop(k, j); with Aop(i, k) = B[k + i ld] (B's column i) and
+    // Bop(k, j) = A[j + k ld] (A's row j):  Cm[j + i ld] = sum_k A[j, k] B[k, i] = (A B)[j, i]
+    return gemm_f64(h, true, false, B, N, A, N, C, N, N, N, N, false);
+}
 
 // X = sign(C) for the symmetric C (N x N): X_0 = C / ||C||_inf, X <- X (1.5 I - 0.5 X^2) until ||X^2 - I||_F <= 1e-4, then
 // two more steps (quadratic convergence: 1e-8, 1e-16).  W1, W2: N x N scratch.  *iters: steps taken; *ok = false when the
@@ -156,7 +166,7 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
     int extra = -1;
     double st[3];
     for (int it = 0; it < max_iters; ++it) {
-        TLSQ_TRY(mf_mul(h, Z, Y, T, N));                  // T = Z Y  (-> I)
+        TLSQ_TRY(mf_mul_full(h, Z, Y, T, N));             // T = Z Y  (-> I)
         if (extra < 0 && it >= 3) {
             TLSQ_TRY(mf_stats(h, T, N, st));
             if (!std::isfinite(st[0])) return TLSQ_OK;
@@ -169,9 +179,9 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
             return TLSQ_OK;
         }
         TLSQ_TRY(mf_axpbi(h, T, T, N, -0.5, 1.5));        // T = 1.5 I - 0.5 Z Y
-        TLSQ_TRY(mf_mul(h, Y, T, W, N));                  // Y <- Y T
+        TLSQ_TRY(mf_mul_full(h, Y, T, W, N));             // Y <- Y T
         TLSQ_HIP(h, hipMemcpyAsync(Y, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-        TLSQ_TRY(mf_mul(h, T, Z, W, N));                  // Z <- T Z
+        TLSQ_TRY(mf_mul_full(h, T, Z, W, N));             // Z <- T Z
         TLSQ_HIP(h, hipMemcpyAsync(Z, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
         if (extra > 0) --extra;
     }
