@@ -172,6 +172,24 @@ def test_loopback_tiny_noise_deflated_certificate(loopback):
     assert rep2.tsqr_iterations <= 1 and rep1.tsqr_iterations <= 1
 
 
+def test_loopback_noisy_problem_matrix_function_route(loopback):
+    """Noisy data on row shards: the count and A of the late iterations come from matrix functions of the all-reduced Gram
+    matrix of the deflated panel (replicated N x N work, every rank has to take the same decisions), A = Z Phi per shard."""
+    from oracle import rpca_oracle as O
+    plain, multi, n = loopback
+    rng = np.random.default_rng(5)
+    M, N, r = 2401, 160, 6
+    D = (rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)
+         + 1e-3 * rng.standard_normal((M, N)))
+    A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True)
+    A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert rep2.iters_done == rep1.iters_done == io.iters_done and sv2 == sv1 == svo and sv2 > 4 * r
+    assert rep2.svp_hist == rep1.svp_hist == io.svp_hist
+    assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8 and relerr(A2, A1) < 1e-9
+    assert rep2.tsqr_iterations <= rep2.iters_done // 3
+
+
 def test_loopback_lowrankfilter_time_windows(loopback):
     from oracle import rpca_oracle as O
     plain, multi, n = loopback
