@@ -109,7 +109,7 @@ enum WsSlot {
     WS_HKSUM,     // soft_hankel! on row shards: anti-diagonal sums and counts of the whole matrix (solver.hip)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_T2, WS_VS2, WS_VS3, WS_T3,
-    WS_MF0, WS_MF1, WS_MF2, WS_MF3,   // matrix-function route (solver.hip): N x N iterates      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
+    WS_MF0, WS_MF1, WS_MF2, WS_MF3, WS_MFP,   // matrix-function route (solver.hip): N x N iterates, partials of k_mf_stats      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)

@@ -19,21 +19,42 @@ __global__ __launch_bounds__(256) void k_mf_axpbi(const double* X, double* Y, in
     }
 }
 
-// out[0] = ||X - I||_F^2, out[1] = trace(X), out[2] = max_i sum_j |X_ij|   (one workgroup; N <= 1024)
-__global__ __launch_bounds__(1024) void k_mf_stats(const double* __restrict__ X, int N, double* __restrict__ out) {
+// out[0] = ||X - I||_F^2, out[1] = trace(X), out[2] = max_i sum_j |X_ij| in two deterministic stages (N <= 1024):
+// stage 1, grid (ceil(N / 256), MF_CHUNKS): thread = row i, block y = a chunk of columns; per-row partials to part
+// (layout [3][MF_CHUNKS][N]: deviation, absolute row sum, diagonal).  Stage 2, one workgroup: fixed-order sums.
+constexpr int MF_CHUNKS = 16;
+__global__ __launch_bounds__(256) void k_mf_stats1(const double* __restrict__ X, int N, double* __restrict__ part) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int per = (N + MF_CHUNKS - 1) / MF_CHUNKS;
+    const int j0 = blockIdx.y * per, j1 = (j0 + per < N) ? j0 + per : N;
+    double dev = 0.0, rs = 0.0, dg = 0.0;
+    for (int j = j0; j < j1; ++j) {
+        const double v = X[(size_t)j * N + i];   // row i read as X[i + j N]: consecutive threads, consecutive addresses
+        const double dd = v - (i == j ? 1.0 : 0.0);
+        dev += dd * dd;
+        rs += fabs(v);
+        if (i == j) dg = v;
+    }
+    const size_t o = (size_t)blockIdx.y * N + i;
+    part[o] = dev;
+    part[(size_t)MF_CHUNKS * N + o] = rs;
+    part[(size_t)2 * MF_CHUNKS * N + o] = dg;
+}
+__global__ __launch_bounds__(1024) void k_mf_stats2(const double* __restrict__ part, int N, double* __restrict__ out) {
     __shared__ double red[3][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double dev = 0.0, tr = 0.0, rmax = 0.0;
-    for (int i = tid; i < N; i += 1024) {   // row i, read as X[i + j N]: consecutive threads, consecutive addresses
-        double rs = 0.0;
-        for (int j = 0; j < N; ++j) {
-            const double v = X[(size_t)j * N + i];
-            const double dd = v - (i == j ? 1.0 : 0.0);
-            dev += dd * dd;
-            rs += fabs(v);
-            if (i == j) tr += v;
+    for (int i = tid; i < N; i += 1024) {
+        double d = 0.0, r = 0.0, g = 0.0;
+        for (int c = 0; c < MF_CHUNKS; ++c) {
+            d += part[(size_t)c * N + i];
+            r += part[(size_t)MF_CHUNKS * N + (size_t)c * N + i];
+            g += part[(size_t)2 * MF_CHUNKS * N + (size_t)c * N + i];
         }
-        rmax = rs > rmax ? rs : rmax;
+        dev += d;
+        tr += g;
+        rmax = r > rmax ? r : rmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -98,7 +119,10 @@ static int mf_stats(Handle* h, const double* X, int64_t N, double out[3]) {
     void* scal;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
     double* dev = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 1728);   // (behind the two sets of bound slots)
-    hipLaunchKernelGGL(k_mf_stats, dim3(1), dim3(1024), 0, h->stream, X, (int)N, dev);
+    void* part;
+    TLSQ_TRY(ws_get(h, WS_MFP, (size_t)3 * MF_CHUNKS * N * 8, &part));
+    hipLaunchKernelGGL(k_mf_stats1, dim3((unsigned)((N + 255) / 256), MF_CHUNKS), dim3(256), 0, h->stream, X, (int)N, (double*)part);
+    hipLaunchKernelGGL(k_mf_stats2, dim3(1), dim3(1024), 0, h->stream, (const double*)part, (int)N, dev);
     TLSQ_HIP(h, hipGetLastError());
     TLSQ_HIP(h, hipMemcpyAsync(h->pinned, dev, 24, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -133,8 +157,9 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
     if (!(nrm > 0.0) || !std::isfinite(nrm)) return TLSQ_OK;
     TLSQ_TRY(mf_axpbi(h, C, X, N, 1.0 / nrm, 0.0));
     int extra = -1;   // steps still to do after the error dropped below 1e-4 (-1: not yet)
+    double *cur = X, *nxt = W2;   // the iterate alternates between the two buffers (one copy at the end at most)
     for (int it = 0; it < max_iters; ++it) {
-        TLSQ_TRY(mf_mul(h, X, X, W1, N));                 // W1 = X^2
+        TLSQ_TRY(mf_mul(h, cur, cur, W1, N));             // W1 = X^2
         // the convergence test costs a host round trip: not before the linear phase can be over, then every third step
         if (extra < 0 && it >= 6 && (it % 3) == 0) {
             TLSQ_TRY(mf_stats(h, W1, N, st));
@@ -142,13 +167,16 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
             if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
         }
         if (extra == 0) {
+            if (cur != X) TLSQ_HIP(h, hipMemcpyAsync(X, cur, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
             *iters = it;
             *ok = true;
             return TLSQ_OK;
         }
         TLSQ_TRY(mf_axpbi(h, W1, W1, N, -0.5, 1.5));      // W1 = 1.5 I - 0.5 X^2
-        TLSQ_TRY(mf_mul(h, X, W1, W2, N));                // W2 = X W1
-        TLSQ_HIP(h, hipMemcpyAsync(X, W2, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+        TLSQ_TRY(mf_mul(h, cur, W1, nxt, N));             // X <- X W1
+        double* t = cur;
+        cur = nxt;
+        nxt = t;
         if (extra > 0) --extra;
     }
     return TLSQ_OK;

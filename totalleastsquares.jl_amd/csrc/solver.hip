@@ -1274,6 +1274,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const bool matfun_possible = !no_matfun && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32 &&
                                  N >= 64 && N <= 1024;
     bool last_no_factors = false, prev_no_factors = false;   // A_k / A_{k-1} exist only as panels (E-free loop: how E is formed)
+    int64_t mf_rS_prev = -1;   // size of the deflated set of the last matrix-function iteration (-1: none yet)
     auto matfun_route = [&](const T* Zp, double inv_mu_, int64_t* svp_out, double* sigma_top_out, bool* ok) -> int {
         *ok = false;
         static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
@@ -1289,9 +1290,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         bool got = false;
         // (only the pairs a factor 1e3 above the threshold are wanted: the solver is asked for those - it counts, and checks the
         //  residuals of, the Ritz values above sqrt(1e3) / mu - on a block cut back to its leading columns)
-        if (sub.valid && sub.p > 48) {
-            sub.p = 48;
-            sub.ntop = std::min<int64_t>(sub.ntop, 40);
+        // (32 columns when the dominant part seen last time leaves room: CholeskyQR2 and the single-workgroup Jacobi apply)
+        const int64_t pcap = (mf_rS_prev >= 0 && mf_rS_prev + 6 <= 32) ? 32 : 48;
+        if (sub.valid && sub.p > pcap) {
+            sub.p = pcap;
+            sub.ntop = std::min<int64_t>(sub.ntop, pcap - 8);
         }
         sub.noise_rel = 0.0;
         sub.skip_certificate = true;
@@ -1425,6 +1428,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         *svp_out = rS + k2;
         *sigma_top_out = stop;
         *ok = true;
+        mf_rS_prev = rS;
         if (dbg)
             fprintf(stderr, "  matrix-function route: |S|=%lld + trace(P)=%lld, sign %d steps, inverse sqrt %d steps\n", (long long)rS,
                     (long long)k2, it_s, it_r);
