@@ -1271,8 +1271,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // iteration that does not converge (an eigenvalue within ~1e-10 of the threshold) or a trace that is not an integer to
     // 1e-6 leaves the iteration to the TSQR route.  A_k has no factor form afterwards: see last_no_factors.
     static const bool no_matfun = [] { const char* e = getenv("TLSQ_NO_MATFUN_ROUTE"); return e && e[0] == '1'; }();
+    // (one GPU for now: on row shards a loop-back run inside the full test suite once took a different trajectory than the
+    //  single-GPU solve - not reproduced in isolation, not understood: shards keep the TSQR route)
     const bool matfun_possible = !no_matfun && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32 &&
-                                 N >= 64 && N <= 1024;
+                                 N >= 64 && N <= 1024 && !h->comm;
     bool last_no_factors = false, prev_no_factors = false;   // A_k / A_{k-1} exist only as panels (E-free loop: how E is formed)
     int64_t mf_rS_prev = -1;   // size of the deflated set of the last matrix-function iteration (-1: none yet)
     auto matfun_route = [&](const T* Zp, double inv_mu_, int64_t* svp_out, double* sigma_top_out, bool* ok) -> int {
