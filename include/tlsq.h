@@ -122,6 +122,14 @@ typedef struct tlsq_rpca_info {
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);
+
+/* Development switches (tests and tools only; process-wide; not part of the reference's interface).  Every alternative HIP
+   path of the library - "classic sweeps instead of the E-free loop", "no mailbox read-backs", "poison the workspace" ... -
+   is selected by name through this call (the list: csrc/common.hpp, TLSQ_DEV_LIST).  `name` with or
+   without the TLSQ_ prefix, `value` a short string ("1", "0", "8.0" ...), NULL clears the switch.  Returns TLSQ_ERR_ARG for
+   a name that is not on the list.  The shipped library reads NO environment variable; a build with -DTLSQ_DEV_SWITCHES
+   additionally takes TLSQ_<NAME> from the environment at the first tlsq_create.  Not thread-safe: set between calls. */
+int tlsq_dev_set(const char* name, const char* value);
 void        tlsq_rpca_opts_default(tlsq_rpca_opts* o);
 
 int  tlsq_create(int device_id, tlsq_handle* out);

@@ -1,0 +1,105 @@
+"""Run-to-run determinism of the solvers: the same call on the same handle - after other shapes have
+left their data in the grow-only workspace - must return bit-identical A, E, singular values and rank trajectory every
+time.  The counts `svp` (src/robustPCA.jl:198 under /root/reference) steer the whole ALM trajectory, so a single
+non-reproducible low-order bit in a decision variable is a latent trajectory fork.  Round 2 had one: the reduction
+of the symmetric split-K GEMM let two threads store the (slightly different) sums (i, j) and (j, i) of a diagonal tile to
+the same address; only the matrix-function route multiplies two DIFFERENT symmetric matrices, so only noisy problems
+saw it.  WS_POISON refills every workspace slot with NaN bytes at the start of each call: a kernel that reads something
+this call has not written cannot pass either."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def noisy(seed, M, N, r, noise):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((M, r)) @ rng.standard_normal((r, N))
+            + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05) + noise * rng.standard_normal((M, N)))
+
+
+@pytest.fixture(scope="module")
+def handles():
+    import torch  # noqa: F401
+    import tlsq_amd
+    plain = tlsq_amd.Engine(0)
+    loop3 = tlsq_amd.Engine(devices=[0, 0, 0])
+    yield plain, loop3
+    loop3.close()
+    plain.close()
+
+
+def _same(a, b):
+    return all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+def _solve(eng, D, **kw):
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+    return (A, E, s.S, np.array(rep.svp_hist), np.array([sv, rep.iters_done, rep.tsqr_iterations]))
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_repeated_solves_are_bit_identical(handles, poison):
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    plain, loop3 = handles
+    cases = {
+        "matfun": (plain, noisy(5, 2401, 160, 6, 1e-3)),               # late iterations on the matrix-function route
+        "c2": (plain, O.synth_lowrank_sparse(20000, 512, 16, seed=0)[0]),   # the headline shape (subspace route throughout)
+        "loop3": (loop3, noisy(5, 2401, 160, 6, 1e-3)),                # the same noisy problem on three row shards
+        "loop3-clean": (loop3, O.synth_lowrank_sparse(3001, 130, 30, seed=3001)[0]),
+    }
+    others = [O.synth_lowrank_sparse(M, N, r, seed=M)[0] for M, N, r in [(1500, 96, 6), (700, 300, 5), (4000, 64, 3)]]
+    rng = np.random.default_rng(11)
+    others.append(rng.standard_normal((1200, 3)) @ rng.standard_normal((3, 48)) + 1e-3 * rng.standard_normal((1200, 48)))
+    nrep = 30
+    try:
+        if poison:
+            tlsq_amd.dev_set("WS_POISON", 1)
+            nrep = 6
+        first = {}
+        for rep in range(nrep):
+            for name, (eng, D) in cases.items():
+                out = _solve(eng, D)
+                assert all(np.isfinite(x).all() for x in out[:3]), (name, rep)
+                if name not in first:
+                    first[name] = out
+                else:
+                    assert _same(out, first[name]), f"{name}: repetition {rep} differs from the first run (poison={poison})"
+            # something else in between: other shapes on the same handles (other workspace sizes, other routes)
+            eng = plain if rep % 2 == 0 else loop3
+            eng.rpca(others[rep % len(others)])
+        # the noisy problem really went through the matrix-function route, on one GPU and on shards alike
+        assert first["matfun"][4][2] <= first["matfun"][4][1] // 3 and first["loop3"][4][2] <= first["loop3"][4][1] // 3
+        assert np.array_equal(first["matfun"][3], first["loop3"][3])
+    finally:
+        tlsq_amd.dev_set("WS_POISON", None)
+
+
+def test_poisoned_workspace_changes_nothing(handles):
+    """every result with NaN-filled workspace slots equals the plain run bit for bit (rpca, lowrankfilter, tls, rtls)"""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    plain, loop3 = handles
+    D = O.synth_lowrank_sparse(1500, 96, 6, seed=1500)[0]
+    y, noise = O.synth_series(6000, seed=3)
+    rng = np.random.default_rng(0)
+    Am = rng.standard_normal((300, 5))
+    ym = Am @ rng.standard_normal(5) + 0.01 * rng.standard_normal(300)
+
+    def everything():
+        out = []
+        for eng in (plain, loop3):
+            out += list(_solve(eng, D)) + list(_solve(eng, D, nonnegE=True))
+            out.append(eng.lowrankfilter(y + noise, 40))
+        out += [plain.tls(Am, ym), plain.rtls(Am, ym), plain.lowrankfilter((y + noise).astype(np.float32), 40)]
+        return out
+
+    ref = everything()
+    try:
+        tlsq_amd.dev_set("WS_POISON", 1)
+        got = everything()
+    finally:
+        tlsq_amd.dev_set("WS_POISON", None)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(np.asarray(a), np.asarray(b)), i

@@ -172,9 +172,10 @@ def test_loopback_tiny_noise_deflated_certificate(loopback):
     assert rep2.tsqr_iterations <= 1 and rep1.tsqr_iterations <= 1
 
 
-def test_loopback_noisy_problem_larger_panel(loopback):
-    """Noisy data with N >= 64 on row shards: the one-GPU solve takes the matrix-function route for its late iterations, the
-    shards keep the TSQR route (per-rank factorisation, all-gather of the triangular factors) - same trajectory and results."""
+def test_loopback_noisy_problem_matrix_function_route(loopback):
+    """Noisy data on row shards: the count and A of the late iterations come from matrix functions of the all-reduced Gram
+    matrix of the deflated panel (replicated N x N work, every rank has to take the same decisions), A = Z Phi per shard -
+    the same route as on one GPU, the same trajectory as the oracle."""
     from oracle import rpca_oracle as O
     plain, multi, n = loopback
     rng = np.random.default_rng(5)
@@ -186,8 +187,8 @@ def test_loopback_noisy_problem_larger_panel(loopback):
     Ao, Eo, so, svo, io = O.rpca(D)
     assert rep2.iters_done == rep1.iters_done == io.iters_done and sv2 == sv1 == svo and sv2 > 4 * r
     assert rep2.svp_hist == rep1.svp_hist == io.svp_hist
-    assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8 and relerr(A2, A1) < 1e-8
-    assert rep2.tsqr_iterations > rep1.tsqr_iterations
+    assert relerr(A2, Ao) < 1e-8 and relerr(E2, Eo) < 1e-8 and relerr(A2, A1) < 1e-9
+    assert rep2.tsqr_iterations <= rep2.iters_done // 3 and rep1.tsqr_iterations <= rep1.iters_done // 3
 
 
 def test_loopback_lowrankfilter_time_windows(loopback):

@@ -603,15 +603,12 @@ def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     """with one channel and lag 1 the solver reads H[i, j] = y[i + j] from the series - set-up on a
     transient copy, sweeps and residual from y - the E-free loop keeps neither a second E nor a second Z, and the low-rank
     panel A stays in factors (the anti-diagonal means are taken from them), so a fresh handle ends up holding four panels
-    (E, Y, Z, R), not eight, and the result is bit-identical to the run that builds and keeps H (TLSQ_LAZY_HANKEL=0 TLSQ_IMPLICIT_HANKEL=0, separate
-    process: the switches are read once)."""
-    import subprocess
-    import sys
+    (E, Y, Z, R), not eight, and the result is bit-identical to the run that builds and keeps H (switches LAZY_HANKEL=0,
+    IMPLICIT_HANKEL=0)."""
     import tlsq_amd
     from oracle import rpca_oracle as O
     Ns, n = 300_000, 256                       # K x n = 7.7e7 entries: the large-panel (fused, implicit) sweep
     y, noise = O.synth_series(Ns, seed=3)
-    np.save(tmp_path / "y.npy", y + noise)
     free0, _ = torch_mod.cuda.mem_get_info(0)
     e2 = tlsq_amd.Engine(0)
     try:
@@ -623,15 +620,15 @@ def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     panel = (K + 15) // 16 * 16 * n * 8
     assert rep.converged
     assert (free0 - free1) < 4.4 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import torch; torch.zeros(1, device='cuda'); import tlsq_amd;"
-            "e = tlsq_amd.Engine(0); y = np.load(%r);"
-            "yf, rep = e.lowrankfilter(y, %d, return_report=True, cost_history=False);"
-            "np.save(%r, yf); open(%r, 'w').write(str(rep.iters_done))"
-            % (ROOT, str(tmp_path / "y.npy"), n, str(tmp_path / "yf.npy"), str(tmp_path / "iters.txt")))
-    env = dict(os.environ, TLSQ_LAZY_HANKEL="0", TLSQ_IMPLICIT_HANKEL="0")
-    subprocess.run([sys.executable, "-c", code], env=env, check=True, timeout=600)
-    assert int(open(tmp_path / "iters.txt").read()) == rep.iters_done
-    assert np.array_equal(np.load(tmp_path / "yf.npy"), yf)
+    # the same call with the Hankel panel built and kept (development switches, tlsq_dev_set)
+    with tlsq_amd.dev_switches(LAZY_HANKEL=0, IMPLICIT_HANKEL=0):
+        e3 = tlsq_amd.Engine(0)
+        try:
+            yf2, rep2 = e3.lowrankfilter(y + noise, n, return_report=True, cost_history=False)
+        finally:
+            e3.close()
+    assert rep2.iters_done == rep.iters_done
+    assert np.array_equal(yf2, yf)
 
 
 def test_missing_values(eng):                                        # test/runtests.jl:172-185
@@ -910,8 +907,7 @@ def test_rccl_path_single_rank(torch_mod):
     import os
     import tlsq_amd
     from oracle import rpca_oracle as O
-    os.environ["TLSQ_FORCE_COMM"] = "1"
-    try:
+    with tlsq_amd.dev_switches(FORCE_COMM=1):
         e = tlsq_amd.Engine(0)
         uid = e.unique_id()
         assert len(uid) == 128 and any(uid)
@@ -919,8 +915,6 @@ def test_rccl_path_single_rank(torch_mod):
         D, _, _ = O.synth_lowrank_sparse(600, 48, 4, seed=9)
         A, E, s, sv, rep = e.rpca(D, return_report=True, m_global=600)
         e.close()
-    finally:
-        os.environ.pop("TLSQ_FORCE_COMM", None)
     e2 = tlsq_amd.Engine(0)
     A2, E2, s2, sv2, rep2 = e2.rpca(D, return_report=True)
     e2.close()
@@ -940,8 +934,7 @@ def test_sharded_lowrankfilter_and_rpca_ga_single_rank(torch_mod):
     rng = np.random.default_rng(2)
     X = rng.standard_normal((20, 3)) @ rng.standard_normal((3, 900)) + 0.01 * rng.standard_normal((20, 900))
     q0 = rng.standard_normal((20, 2))
-    os.environ["TLSQ_FORCE_COMM"] = "1"
-    try:
+    with tlsq_amd.dev_switches(FORCE_COMM=1):
         e = tlsq_amd.Engine(0)
         e.comm_init(1, 0, e.unique_id())
         f1 = e.lowrankfilter(y0 + nz, 40)
@@ -949,8 +942,6 @@ def test_sharded_lowrankfilter_and_rpca_ga_single_rank(torch_mod):
         f3 = e.lowrankfilter(y0 + nz, 40, sv=2)
         Q = e.rpca_ga(X, 2, q0=q0)
         e.close()
-    finally:
-        os.environ.pop("TLSQ_FORCE_COMM", None)
     e2 = tlsq_amd.Engine(0)
     g1, g2, g3 = e2.lowrankfilter(y0 + nz, 40), e2.lowrankfilter(y2, 30, lag=2), e2.lowrankfilter(y0 + nz, 40, sv=2)
     Q2 = e2.rpca_ga(X, 2, q0=q0)
@@ -1197,28 +1188,25 @@ def test_rpca_large_panel_path_properties(eng):
     assert np.linalg.matrix_rank(A[:2000], tol=1e-6 * s.S[0]) == r
 
 
-def test_residual_store_misprediction_path():
+def test_residual_store_misprediction_path(eng, torch_mod):
     """The fused sweep stops storing the residual panel while the Frobenius bound is far above tol; when that
-    prediction fails the residual is recomputed.  TLSQ_RSKIP_MARGIN=0 (read once per process, hence the subprocess)
-    makes every sweep skip the store, so every cost evaluation takes the recompute path: same result as the oracle."""
-    import os, subprocess, sys
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import tlsq_amd; from oracle import rpca_oracle as O\n"
-        "torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
-        "for (M, N, r, kw) in ((2000, 128, 8, {}), (600, 64, 5, dict(nonnegA=True, nonnegE=True))):\n"
-        "    D = O.synth_lowrank_sparse(M, N, r, seed=3)[0]; D = np.abs(D) if kw else D\n"
-        "    dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda(); dA = torch.empty_like(dD); dE = torch.empty_like(dD)\n"
-        "    sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False, **kw)\n"
-        "    Ao, Eo, so, svo, io = O.rpca(D, **kw)\n"
-        "    assert rep.residual_stores_skipped >= rep.iters_done - 2, rep.residual_stores_skipped\n"
-        "    assert (rep.iters_done, sv) == (io.iters_done, svo)\n"
-        "    assert np.linalg.norm(dA.cpu().numpy().T - Ao) <= 1e-8 * np.linalg.norm(Ao)\n"
-        "    assert np.linalg.norm(dE.cpu().numpy().T - Eo) <= 1e-8 * np.linalg.norm(Eo)\n"
-        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, TLSQ_RSKIP_MARGIN="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    prediction fails the residual is recomputed.  RSKIP_MARGIN=0 makes every sweep skip the store, so every cost
+    evaluation takes the recompute path: same result as the oracle."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    torch = torch_mod
+    with tlsq_amd.dev_switches(RSKIP_MARGIN=0):
+        for (M, N, r, kw) in ((2000, 128, 8, {}), (600, 64, 5, dict(nonnegA=True, nonnegE=True))):
+            D = O.synth_lowrank_sparse(M, N, r, seed=3)[0]
+            D = np.abs(D) if kw else D
+            dD = torch.from_numpy(np.ascontiguousarray(D.T)).cuda()
+            dA, dE = torch.empty_like(dD), torch.empty_like(dD)
+            sv, rep, st = eng.rpca_device(dD.data_ptr(), M, N, dA.data_ptr(), dE.data_ptr(), want_hist=False, **kw)
+            Ao, Eo, so, svo, io = O.rpca(D, **kw)
+            assert rep.residual_stores_skipped >= rep.iters_done - 2, rep.residual_stores_skipped
+            assert (rep.iters_done, sv) == (io.iters_done, svo)
+            assert np.linalg.norm(dA.cpu().numpy().T - Ao) <= 1e-8 * np.linalg.norm(Ao)
+            assert np.linalg.norm(dE.cpu().numpy().T - Eo) <= 1e-8 * np.linalg.norm(Eo)
 
 
 def test_tiny_noise_stays_on_the_subspace_route(eng):
@@ -1259,30 +1247,27 @@ def test_noisy_data_matrix_function_route(eng, M, N, r, noise):
     assert rep.tsqr_iterations <= rep.iters_done // 3, (rep.tsqr_iterations, rep.iters_done)   # (without the route: every late iteration)
 
 
-def test_efree_loop_against_classic_sweeps(eng, tmp_path):
+def test_efree_loop_against_classic_sweeps(eng):
     """The default loop keeps no E while it runs (sweeps.hip, k_zsweep: Y' = mu (Z - A), R = Z - A - Y / mu, E formed once
-    after the loop from the kept factors of A_{k-1}); TLSQ_NO_ZSWEEP=1 (read once per process, hence the subprocess) runs the
+    after the loop from the kept factors of A_{k-1}); the switch NO_ZSWEEP=1 runs the
     classic sweeps that carry E and Z double buffers.  Same iterations, same results to rounding, and the same zero pattern
     in E - ranks below and above 32 (A in registers / through memory), odd row counts (one row per thread), the non-negative
     flags, the iteration limit hit at an odd and an even count (Y_k in either buffer), and the returned decomposition of
     the last Z, which the E-free loop has to rebuild."""
-    import subprocess
-    import sys
+    import warnings
+    import tlsq_amd
     from oracle import rpca_oracle as O
     cases = [(600, 64, 5, {}), (601, 40, 4, {}), (500, 200, 45, {}), (400, 60, 6, dict(nonnegA=True, nonnegE=True)),
              (300, 50, 4, dict(iters=5)), (300, 50, 4, dict(iters=6)), (500, 200, 45, dict(iters=7)), (90, 120, 7, {})]
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import warnings; warnings.simplefilter('ignore')\n"
-            "import torch; torch.zeros(1, device='cuda'); import tlsq_amd; from oracle import rpca_oracle as O\n"
-            "e = tlsq_amd.Engine(0); out = {}\n"
-            "for i, (M, N, r, kw) in enumerate(%r):\n"
-            "    D = O.synth_lowrank_sparse(M, N, r, seed=20 + i)[0]; D = np.abs(D) if 'nonnegA' in kw else D\n"
-            "    A, E, s, sv, rep = e.rpca(D, return_report=True, **kw)\n"
-            "    out['A%%d' %% i] = A; out['E%%d' %% i] = E; out['S%%d' %% i] = s[1]; out['V%%d' %% i] = s[2]\n"
-            "    out['m%%d' %% i] = np.array([sv, rep.iters_done])\n"
-            "np.savez(%r, **out)\n" % (ROOT, cases, str(tmp_path / "classic.npz")))
-    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TLSQ_NO_ZSWEEP="1"), check=True, timeout=600)
-    ref = np.load(tmp_path / "classic.npz")
-    import warnings
+    ref = {}
+    with tlsq_amd.dev_switches(NO_ZSWEEP=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, (M, N, r, kw) in enumerate(cases):
+            D = O.synth_lowrank_sparse(M, N, r, seed=20 + i)[0]
+            D = np.abs(D) if "nonnegA" in kw else D
+            A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+            ref["A%d" % i], ref["E%d" % i], ref["S%d" % i], ref["V%d" % i] = A, E, s[1], s[2]
+            ref["m%d" % i] = np.array([sv, rep.iters_done])
     for i, (M, N, r, kw) in enumerate(cases):
         D = O.synth_lowrank_sparse(M, N, r, seed=20 + i)[0]
         D = np.abs(D) if "nonnegA" in kw else D
@@ -1300,48 +1285,37 @@ def test_efree_loop_against_classic_sweeps(eng, tmp_path):
         assert np.array_equal(E == 0, Eo == 0), i
 
 
-def test_implicit_gram_operator_path():
+def test_implicit_gram_operator_path(eng):
     """From N = 8192 on the Gram matrix is never formed: products G X = Z'(Z X), operator-form Lanczos with per-vector
-    deflation.  TLSQ_IMPLICIT_GRAM=1 (read once per process, hence the subprocess) forces that path at a size the
-    oracle can follow: same trajectory, A and E."""
-    import os, subprocess, sys
-    code = (
-        "import sys, warnings, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import tlsq_amd; from oracle import rpca_oracle as O\n"
-        "warnings.simplefilter('ignore'); torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
-        "D = O.synth_lowrank_sparse(2400, 2064, 5, seed=12)[0]\n"
-        "A, E, s, sv, rep = eng.rpca(D, iters=5, return_report=True, want_U=False)\n"
-        "Ao, Eo, so, svo, io = O.rpca(D, iters=5)\n"
-        "assert rep.svp_hist == io.svp_hist and sv == svo and rep.eig_full == 0, (rep.svp_hist, io.svp_hist)\n"
-        "assert np.linalg.norm(A - Ao) <= 1e-9 * np.linalg.norm(Ao) and np.linalg.norm(E - Eo) <= 1e-9 * np.linalg.norm(Eo)\n"
-        "assert np.allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)\n"
-        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, TLSQ_IMPLICIT_GRAM="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    deflation.  The switch IMPLICIT_GRAM=1 forces that path at a size the oracle can follow: same trajectory, A and E."""
+    import warnings
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    D = O.synth_lowrank_sparse(2400, 2064, 5, seed=12)[0]
+    with tlsq_amd.dev_switches(IMPLICIT_GRAM=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, E, s, sv, rep = eng.rpca(D, iters=5, return_report=True, want_U=False)
+    Ao, Eo, so, svo, io = O.rpca(D, iters=5)
+    assert rep.svp_hist == io.svp_hist and sv == svo and rep.eig_full == 0, (rep.svp_hist, io.svp_hist)
+    assert np.linalg.norm(A - Ao) <= 1e-9 * np.linalg.norm(Ao) and np.linalg.norm(E - Eo) <= 1e-9 * np.linalg.norm(Eo)
+    assert np.allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
 
 
-def test_implicit_hankel_sweep_is_bit_identical(tmp_path):
+def test_implicit_hankel_sweep_is_bit_identical(eng):
     """lowrankfilter on one channel with lag 1: the fused rebuild+sweep reads y instead of the Hankel panel
-    (D[i,j] = y[i+j], zero pad rows).  Same bits as with the panel (TLSQ_IMPLICIT_HANKEL=0), and the oracle's filter.
-    TLSQ_FUSED_REBUILD=1 selects that sweep at a size the oracle can follow (both read once per process)."""
-    import os, subprocess, sys
-    code = (
-        "import sys, warnings, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import tlsq_amd; from oracle import rpca_oracle as O\n"
-        "warnings.simplefilter('ignore'); torch.zeros(1, device='cuda'); eng = tlsq_amd.Engine(0)\n"
-        "y0, nz = O.synth_series(6001, seed=3); y = y0 + nz\n"
-        "yf, rep = eng.lowrankfilter(y, 40, return_report=True)\n"
-        "yo = O.lowrankfilter(y, 40)\n"
-        "assert np.linalg.norm(yf - yo) <= 1e-8 * np.linalg.norm(yo), np.linalg.norm(yf - yo)\n"
-        "np.save(sys.argv[1], yf); print('ok', rep.iters_done)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    (D[i,j] = y[i+j], zero pad rows).  Same bits as with the panel (IMPLICIT_HANKEL=0), and the oracle's filter.
+    FUSED_REBUILD=1 selects that sweep at a size the oracle can follow."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    y0, nz = O.synth_series(6001, seed=3)
+    y = y0 + nz
+    yo = O.lowrankfilter(y, 40)
     outs = []
-    for tag, extra in (("implicit", {}), ("panel", {"TLSQ_IMPLICIT_HANKEL": "0"})):
-        f = str(tmp_path / (tag + ".npy"))
-        env = dict(os.environ, TLSQ_FUSED_REBUILD="1", **extra)
-        out = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
-        outs.append(np.load(f))
+    for extra in ({}, {"IMPLICIT_HANKEL": 0}):
+        with tlsq_amd.dev_switches(FUSED_REBUILD=1, **extra):
+            yf, rep = eng.lowrankfilter(y, 40, return_report=True)
+        assert np.linalg.norm(yf - yo) <= 1e-8 * np.linalg.norm(yo), np.linalg.norm(yf - yo)
+        outs.append(yf)
     assert np.array_equal(outs[0], outs[1])
 
 

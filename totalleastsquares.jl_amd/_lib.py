@@ -61,7 +61,7 @@ class GaInfo(C.Structure):
 
 # every symbol include/tlsq.h declares (tests check that the .so exports all of them)
 EXPORTS = [
-    "tlsq_version", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_create_multi", "tlsq_ngpus", "tlsq_destroy", "tlsq_last_error",
+    "tlsq_version", "tlsq_dev_set", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_create_multi", "tlsq_ngpus", "tlsq_destroy", "tlsq_last_error",
     "tlsq_stream", "tlsq_synchronize", "tlsq_comm_unique_id", "tlsq_comm_init", "tlsq_comm_destroy",
     "tlsq_rpca_f64", "tlsq_rpca_f32",
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
@@ -92,6 +92,7 @@ def load():
     vp, i64, i32, dbl, flt = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_float
     P = C.POINTER
     lib.tlsq_version.restype = C.c_char_p
+    lib.tlsq_dev_set.argtypes = [C.c_char_p, C.c_char_p]
     lib.tlsq_rpca_opts_default.argtypes = [P(RpcaOpts)]
     lib.tlsq_rpca_opts_default.restype = None
     lib.tlsq_create.argtypes = [i32, P(vp)]
@@ -159,3 +160,44 @@ def load():
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def dev_set(name, value):
+    """tlsq_dev_set: select a development switch of the library by name (value None clears it); raises on unknown names."""
+    lib = load()
+    v = None if value is None else str(value).encode()
+    if lib.tlsq_dev_set(name.encode(), v) != 0:
+        raise ValueError(f"unknown tlsq development switch {name!r}")
+
+
+# environment variables that look like switches but are not the library's (read by the Python / Julia hosts themselves)
+_NOT_SWITCHES = {"TLSQ_LIB", "TLSQ_NGPUS", "TLSQ_DEVICE", "TLSQ_EXTRA_FLAGS", "TLSQ_BUILD_INCREMENTAL"}
+
+
+def dev_from_env(environ=None):
+    """Tools and tests that are steered from the shell call this explicitly: every TLSQ_<NAME> variable of the environment is
+    handed to tlsq_dev_set (a mistyped name raises).  The library itself never looks at the environment."""
+    environ = os.environ if environ is None else environ
+    applied = {}
+    for k, v in environ.items():
+        if k.startswith("TLSQ_") and k not in _NOT_SWITCHES:
+            dev_set(k, v)
+            applied[k] = v
+    return applied
+
+
+class dev_switches:
+    """with dev_switches(NO_ZSWEEP=1, ...): the switches are set inside the block and cleared afterwards"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            dev_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            dev_set(k, None)
+        return False

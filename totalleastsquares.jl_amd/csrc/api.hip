@@ -178,13 +178,13 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     // one channel, lag 1, robust mode - the Hankel matrix is never stored.  The big fused sweep, the
     // residual and the set-up of rpca_core read H[i, j] = y[i + j] from the series (ResolvedOpts::hankel_lazy): seven
     // resident panels instead of eight, six panel passes per iteration instead of seven.
-    static const bool implicit_ok = [] { const char* e = getenv("TLSQ_IMPLICIT_HANKEL"); return !(e && e[0] == '0'); }();
-    static const bool lazy_ok = [] { const char* e = getenv("TLSQ_LAZY_HANKEL"); return !(e && e[0] == '0'); }();
+    const bool implicit_ok = !dev_is(DEV_IMPLICIT_HANKEL, '0');
+    const bool lazy_ok = !dev_is(DEV_LAZY_HANKEL, '0');
     const bool implicit = implicit_ok && Dch == 1 && lag == 1;
     const bool lazy = implicit && lazy_ok && sv <= 0 && !exact_shape;
     // ... and neither is A: the loop keeps it in factors, the anti-diagonal means are taken from them (unhankel_factors),
     // and the panel only exists if some iteration needed it in memory (rank above 32): four resident panels (E, Y, Z, R)
-    static const bool factors_ok = [] { const char* e = getenv("TLSQ_UNHANKEL_FACTORS"); return !(e && e[0] == '0'); }();
+    const bool factors_ok = !dev_is(DEV_UNHANKEL_FACTORS, '0');
     const bool factors_out = lazy && !sharded && factors_ok && (size_t)n * 32 * 8 <= 64 * 1024;
     void *dy, *H = nullptr, *A = nullptr, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
@@ -269,12 +269,14 @@ extern "C" {
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, double* A, int64_t ldA, double* E, int64_t ldE, double* U,
                   int64_t ldU, double* S, double* Vt, int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return rpca_entry<double>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
 }
 
 int tlsq_rpca_f32(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t ldD,
                   const tlsq_rpca_opts* opts, float* A, int64_t ldA, float* E, int64_t ldE, float* U,
                   int64_t ldU, float* S, float* Vt, int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return rpca_entry<float>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
 }
 
@@ -307,10 +309,12 @@ int tlsq_soft_hankel_f32(tlsq_handle h, float* A, int64_t K, int64_t L, int64_t 
 // ---- lowrankfilter: src/robustPCA.jl:119-128 -----------------------------------------------------
 int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t Dch, int64_t ldy, int64_t n, int64_t lag,
                            int64_t sv, const tlsq_rpca_opts* opts, double* yf, int64_t ldyf, tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return lowrankfilter_impl<double>(h, y, Nx, Dch, ldy, n, lag, sv, opts, yf, ldyf, info);
 }
 int tlsq_lowrankfilter_f32(tlsq_handle h, const float* y, int64_t Nx, int64_t Dch, int64_t ldy, int64_t n, int64_t lag,
                            int64_t sv, const tlsq_rpca_opts* opts, float* yf, int64_t ldyf, tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return lowrankfilter_impl<float>(h, y, Nx, Dch, ldy, n, lag, sv, opts, yf, ldyf, info);
 }
 
@@ -418,20 +422,24 @@ extern "C" {
 
 int tlsq_tls_f64(tlsq_handle h, const double* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
                  double* x, int64_t ldx, int memory) {
+    TLSQ_TRY(ws_poison_all(h));
     return tls_impl<double>(h, Ay, M, ncols, ldAy, n, x, ldx, memory);
 }
 int tlsq_tls_f32(tlsq_handle h, const float* Ay, int64_t M, int64_t ncols, int64_t ldAy, int64_t n,
                  float* x, int64_t ldx, int memory) {
+    TLSQ_TRY(ws_poison_all(h));
     return tls_impl<float>(h, Ay, M, ncols, ldAy, n, x, ldx, memory);
 }
 int tlsq_rtls_f64(tlsq_handle h, const double* A, int64_t M, int64_t n, int64_t ldA, const double* y,
                   int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, double* x, int64_t ldx,
                   tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return rtls_impl<double>(h, A, M, n, ldA, y, q, ldy, opts, x, ldx, info);
 }
 int tlsq_rtls_f32(tlsq_handle h, const float* A, int64_t M, int64_t n, int64_t ldA, const float* y,
                   int64_t q, int64_t ldy, const tlsq_rpca_opts* opts, float* x, int64_t ldx,
                   tlsq_rpca_info* info) {
+    TLSQ_TRY(ws_poison_all(h));
     return rtls_impl<float>(h, A, M, n, ldA, y, q, ldy, opts, x, ldx, info);
 }
 

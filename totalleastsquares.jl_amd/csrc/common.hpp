@@ -94,6 +94,44 @@ int set_err(Handle* h, int code, const char* fmt, ...);
 // workspace slot: returns a device pointer of at least `bytes` (grow-only, contents not preserved on growth)
 int ws_get(Handle* h, int slot, size_t bytes, void** out);
 
+
+// ---- development switches (runtime.hip) ---------------------------------------------------------------------------
+// Every alternative HIP path the library can be told to take is one entry of this list.  Values are
+// set through tlsq_dev_set(name, value) - the tests and tools call it; a name that is not on the list is an error - and,
+// only in a build with -DTLSQ_DEV_SWITCHES, from environment variables TLSQ_<NAME> read once at the first tlsq_create.
+// The shipped build reads no environment variable at all: a leaked or mistyped variable cannot change which solver runs.
+#define TLSQ_DEV_LIST(X)                                                                                                  \
+    X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP)                                                \
+    X(NO_ZSWEEP) X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(FUSED_REBUILD) X(NO_REBUILD_STORE)            \
+    X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID)                                                                                    \
+    X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
+    X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
+    X(NO_CERT_OVERLAP) X(NO_FUSED_DEFLATE)                                                                                 \
+    X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_CHOL) X(NO_SYMM_MFMA)             \
+    X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(OVERLAP_CHUNKS)    \
+    X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
+    X(NO_TSMM) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
+    X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
+    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO)
+enum DevKey {
+#define TLSQ_DEV_ENUM(n) DEV_##n,
+    TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
+#undef TLSQ_DEV_ENUM
+    DEV_COUNT
+};
+const char* dev_get(DevKey k);   // the value as a string, nullptr when the switch is not set
+inline bool dev_is(DevKey k, char c) {
+    const char* e = dev_get(k);
+    return e && e[0] == c;
+}
+// name with or without the TLSQ_ prefix; value == nullptr clears the switch.  TLSQ_ERR_ARG for a name not on the list.
+int dev_set(const char* name, const char* value);
+void dev_load_env();             // (no-op unless built with -DTLSQ_DEV_SWITCHES)
+// DEBUG_HASH=1: "[hash] <tag> <64-bit FNV-1a of the buffer>" on stderr after a stream synchronisation - two runs of the same
+// call must print identical lines; the first line that differs names the kernel that is not reproducible
+struct Handle;
+void dbg_hash(Handle* h, const char* tag, const void* dev_ptr, size_t bytes, long long k = -1);
+
 enum WsSlot {
     WS_D = 0, WS_A, WS_E, WS_Y, WS_Z, WS_R,      // M x N panels
     WS_G, WS_B, WS_V, WS_VG, WS_VS, WS_T,        // N x N / M x r

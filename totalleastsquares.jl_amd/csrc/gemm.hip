@@ -279,14 +279,17 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const double* __restrict__ 
     double nacc = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t j = e % Q, i = e / Q;
-        if (symmetric && (j / TJ) > (i / TI)) continue;
+        // symmetric: ONE writer per entry pair - the thread of (i, j), j <= i, stores the entry and its mirror image.  (A
+        // diagonal tile holds both (i, j) and (j, i); for the product of two different commuting matrices the two sums
+        // differ in their last bits, and two threads storing different values to the same two addresses made the result
+        // depend on which one came last: the run-to-run differences of the matrix-function route, round 2.)
+        if (symmetric && j > i) continue;
         // tri (k_gram_kc): diagonal tiles hold only their 16 x 16 MFMA tiles on and below the diagonal, in nsplit_d slabs
         const bool dtile = tri && (j / TJ) == (i / TI);
-        if (dtile && (j / 16) > (i / 16)) continue;
         const int ns = dtile ? nsplit_d : nsplit;
         double s = 0.0;
         for (int zz = 0; zz < ns; ++zz) s += slab[(int64_t)zz * slab_stride + j + i * lds_];
-        const bool twice = symmetric && ((j / TJ) < (i / TI) || (dtile && (j / 16) < (i / 16)));
+        const bool twice = symmetric && j < i;
         nacc += (twice ? 2.0 : 1.0) * s * s;
         if (c_f32) {
             reinterpret_cast<float*>(C)[j + i * ldc] = (float)s;
@@ -659,8 +662,8 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
 int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan* pl) {
     const int64_t nti = (N + TI - 1) / TI, noff = nti * (nti - 1) / 2;
     // relative cost of a diagonal work item per row of Z (9 of 16 MFMA tiles per SIMD + the shared per-stage overhead)
-    static const double rho = [] { const char* e = getenv("TLSQ_GRAM_RHO"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.62; }();
-    static const int64_t target_wgs = [] { const char* e = getenv("TLSQ_GEMM_WGS"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 256); }();
+    const double rho = [] { const char* e = dev_get(DEV_GRAM_RHO); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.62; }();
+    const int64_t target_wgs = [] { const char* e = dev_get(DEV_GEMM_WGS); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 256); }();
     // K splits (nsplit_o for the off-diagonal tiles, nsplit_d for the diagonal ones) by a small cost model, in us:
     // an item of kc rows takes kc * c_row (a CU at ~92 % of its MFMA peak: 2 * 128 * 128 flop per row) + c_item
     // (dispatch, first loads, slab store: fitted), items run in rounds of one per CU, and every slab entry is written and read once more
@@ -717,7 +720,7 @@ int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan*
         }
         if (noff == 0 && so >= hi) break;
     }
-    if (const char* e = getenv("TLSQ_GRAM_SPLIT")) {   // development: "o,d"
+    if (const char* e = dev_get(DEV_GRAM_SPLIT)) {   // development: "o,d"
         long o = 0, d = 0;
         if (sscanf(e, "%ld,%ld", &o, &d) == 2 && o > 0 && d > 0) {
             nsplit_o = noff > 0 ? std::min<int64_t>(o, maxsplit) : 1;
@@ -726,7 +729,7 @@ int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan*
     }
     const int64_t kchunk_o = chunk_of(nsplit_o, TK), kchunk_d = chunk_of(nsplit_d, DTK);
     {
-        static const bool dbg = [] { const char* e = getenv("TLSQ_DEBUG"); return e && e[0] == '2'; }();
+        const bool dbg = dev_is(DEV_DEBUG, '2');
         if (dbg) fprintf(stderr, "[tlsq] gram %lld x %lld: nsplit %lld / %lld, model %.0f us\n", (long long)K, (long long)N,
                          (long long)nsplit_o, (long long)nsplit_d, best);
     }
@@ -742,7 +745,7 @@ int gram_plan(Handle* h, int z_f32, int64_t N, int64_t K, int nchunks, GramPlan*
     // 32 tiles); blocks of 8 x 4 tiles share 12.  From N = 2048 on the kernel is otherwise bound by that traffic
     // (65536 x 4096: 70 GB per Gram).
     const int32_t* order = nullptr;
-    static const bool no_order = [] { const char* e = getenv("TLSQ_GRAM_ROWWISE"); return e && e[0] == '1'; }();
+    const bool no_order = dev_is(DEV_GRAM_ROWWISE, '1');
     if (nti > 8 && !no_order) {
         void* tab;
         TLSQ_TRY(ws_get(h, WS_GRAMTAB, (size_t)noff * 8, &tab));
@@ -857,14 +860,14 @@ int gemm_mixed(Handle* h, bool A_KC, bool B_KC, const void* A, int a_f32, int64_
                const double* skip, double* normpart, int* normblocks) {
     if (P <= 0 || Q <= 0) return TLSQ_OK;
     if (normpart && !symmetric) return set_err(h, TLSQ_ERR_ARG, "gemm: the norm by-product needs the symmetric (slab) path");
-    static const bool old_gram = [] { const char* e = getenv("TLSQ_GRAM_OLD"); return e && e[0] == '1'; }();
+    const bool old_gram = dev_is(DEV_GRAM_OLD, '1');
     if (symmetric && A_KC && B_KC && A == B && lda == ldb && a_f32 == b_f32 && !c_f32 && P == Q && !old_gram)
         return gram_kc(h, A, a_f32, lda, (double*)C, ldc, P, K, skip, normpart, normblocks);   // the Gram matrix of one operand
     const int64_t nti = (P + TI - 1) / TI, ntj = (Q + TJ - 1) / TJ;
     const int64_t tiles = symmetric ? nti * (nti + 1) / 2 : nti * ntj;
     // split K so that the launch has ~256 workgroups (one per CU), each with >= 4 K stages
-    static const int64_t target_wgs = [] {
-        const char* e = getenv("TLSQ_GEMM_WGS");
+    const int64_t target_wgs = [] {
+        const char* e = dev_get(DEV_GEMM_WGS);
         const long v = e ? atol(e) : 0;
         return (int64_t)(v > 0 ? v : 256);   // one workgroup per CU (512 and 768 measured the same on C2)
     }();
@@ -1165,8 +1168,8 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
         return TLSQ_OK;
     }
     // fp32 panels in large mode (no dense eigen-solver behind the count anyway): the fp32 MFMA with fp64 fold-in
-    static const bool no_f32mfma = [] { const char* e = getenv("TLSQ_GRAM_F32MFMA"); return e && e[0] == '0'; }();
-    static const bool all_f32mfma = [] { const char* e = getenv("TLSQ_GRAM_F32MFMA"); return e && e[0] == '2'; }();
+    const bool no_f32mfma = dev_is(DEV_GRAM_F32MFMA, '0');
+    const bool all_f32mfma = dev_is(DEV_GRAM_F32MFMA, '2');
     if (z_f32 && (mfma32 == 1 || (mfma32 < 0 && !no_f32mfma && (N > 2048 || all_f32mfma))))
         return gram_f32mfma(h, (const float*)Z, ldZ, G, ldG, N, M);
     return gemm_mixed(h, true, true, Z, z_f32, ldZ, Z, z_f32, ldZ, G, 0, ldG, N, N, M, true);

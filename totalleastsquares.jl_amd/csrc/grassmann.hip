@@ -721,7 +721,7 @@ inline int pass_blocks(int64_t N, int64_t d) {
     int64_t nb = (N + gpb * 8 - 1) / (gpb * 8);   // >= 8 columns per lane group
     // two blocks per CU: measured best for every column length (256 / 1024 / 2048 / 4096 blocks are slower) — each
     // block costs a partial row in k_ga_reduce, and the columns in flight per lane group already cover the latency
-    static const int env_cap = [] { const char* e = getenv("TLSQ_GA_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int env_cap = [] { const char* e = dev_get(DEV_GA_BLOCKS); return e ? atoi(e) : 0; }();   // tuning knob
     const int64_t cap = env_cap > 0 ? env_cap : 512;
     if (nb < 1) nb = 1;
     if (nb > cap) nb = cap;
@@ -1114,7 +1114,7 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     const int hist_cap = (info && info->dq_hist && info->hist_capacity > 0)
                              ? (int)std::min<int64_t>(info->hist_capacity, iters) : 0;
     // small problems run in one workgroup (k_ga_solo); TLSQ_GA_SOLO=0 sends them through the grid path as well
-    static const bool solo_on = [] { const char* e = getenv("TLSQ_GA_SOLO"); return !(e && e[0] == '0'); }();
+    const bool solo_on = !dev_is(DEV_GA_SOLO, '0');
     const bool solo = solo_on && mode == TLSQ_GA_MEAN && !h->comm && d <= 64 && N * (d + 1) <= 18000;
     GaBuffers b;
     if (!solo) TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));

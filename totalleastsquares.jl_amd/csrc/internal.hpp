@@ -22,6 +22,7 @@ int comm_allgather(Handle* h, const double* send, double* recv, size_t count);
 int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
            hipMemcpyKind kind);
 double now_ms();
+int ws_poison_all(Handle* h);   // WS_POISON=1: refill every workspace slot with 0xFF bytes (start of a solve)
 // Single-process multi-GPU group: runs fn(rank handle, rank, nranks) on every GPU of the group concurrently - rank 0 on
 // the calling thread, the others on worker threads that never call back into the host language - with each rank's
 // communicator attached for the duration.  Returns the first fatal status (its message is copied to h), else the

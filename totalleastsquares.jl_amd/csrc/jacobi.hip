@@ -782,7 +782,7 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         // one half-wave per column pair; whole waves only
         const int npair0 = (int)((N + 1) / 2);
         const int nthr0 = ((npair0 * 32 + 63) / 64) * 64;
-        static const bool no_two = [] { const char* e = getenv("TLSQ_JACOBI2"); return e && e[0] == '0'; }();
+        const bool no_two = dev_is(DEV_JACOBI2, '0');
         if (want_v && two_sided && !no_two)
             hipLaunchKernelGGL(k_jacobi2_small<true>, dim3(1), dim3(nthr0), 0, h->stream, G, ldG, B, V, lam_dev,
                                (int)N, tol0, (double)N * eps0, max_sweeps0, sweeps_dev);

@@ -312,7 +312,7 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
     r.chunk = stop_above > 0.0 ? 5 : (accept_below > 0.0 ? 11 : 16);
-    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
     r.mail_ok = h->mailbox && !no_mailbox && (size_t)(16 + 2 * r.cap) * 8 <= h->mailbox_bytes;
     TLSQ_TRY(lz_launch_chunk(h, r));
     if (!r.use_mail) {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restr
 // apply (N too large for the LDS copy of the vector, no mailbox): the caller runs Lanczos.
 int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool init, int nsteps, double* lb_out) {
     *lb_out = 0.0;
-    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
     const size_t lds = (size_t)(N + 8) * 8;
     if (N <= 0 || nsteps < 1 || nsteps > 8 || lds > 150 * 1024 || !h->mailbox || no_mailbox || h->mailbox_bytes < 1024) return 1;
     void* pwv;

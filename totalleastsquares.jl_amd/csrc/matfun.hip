@@ -138,7 +138,7 @@ static int mf_mul(Handle* h, const double* A, const double* B, double* C, int64_
 // is stable as written (Higham, Functions of Matrices, sec. 6.4); mirroring one triangle of Y T and T Z would replace its
 // small commutator errors by errors of the same size in the iterates themselves (TLSQ_MATFUN_SYM=1: the symmetric form).
 static int mf_mul_full(Handle* h, const double* A, const double* B, double* C, int64_t N) {
-    static const bool sym = [] { const char* e = getenv("TLSQ_MATFUN_SYM"); return e && e[0] == '1'; }();
+    const bool sym = dev_is(DEV_MATFUN_SYM, '1');
     if (sym) return mf_mul(h, A, B, C, N);
     // gemm convention: Cm[j + i ldc] = sum_k Aop(i, k) Bop(k, j); with Aop(i, k) = B[k + i ld] (B's column i) and
     // Bop(k, j) = A[j + k ld] (A's row j):  Cm[j + i ld] = sum_k A[j, k] B[k, i] = (A B)[j, i]

@@ -18,6 +18,44 @@
 
 namespace tlsq {
 
+
+// ------------------------------------------------------------------------------------------------
+// development switches (declared in common.hpp)
+// ------------------------------------------------------------------------------------------------
+static const char* const kDevNames[DEV_COUNT] = {
+#define TLSQ_DEV_NAME(n) #n,
+    TLSQ_DEV_LIST(TLSQ_DEV_NAME)
+#undef TLSQ_DEV_NAME
+};
+static std::string g_dev_val[DEV_COUNT];
+static bool g_dev_set[DEV_COUNT] = {};
+
+const char* dev_get(DevKey k) { return g_dev_set[k] ? g_dev_val[k].c_str() : nullptr; }
+
+int dev_set(const char* name, const char* value) {
+    if (!name) return TLSQ_ERR_ARG;
+    if (strncmp(name, "TLSQ_", 5) == 0) name += 5;
+    for (int k = 0; k < DEV_COUNT; ++k)
+        if (strcmp(name, kDevNames[k]) == 0) {
+            g_dev_set[k] = value != nullptr;
+            g_dev_val[k] = value ? value : "";
+            return TLSQ_OK;
+        }
+    return TLSQ_ERR_ARG;
+}
+
+void dev_load_env() {
+#ifdef TLSQ_DEV_SWITCHES
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (int k = 0; k < DEV_COUNT; ++k) {
+        const std::string var = std::string("TLSQ_") + kDevNames[k];
+        if (const char* e = getenv(var.c_str())) (void)dev_set(kDevNames[k], e);
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // errors / workspace
 // ------------------------------------------------------------------------------------------------
@@ -44,8 +82,47 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out) {
         size_t want = (bytes + 255) & ~size_t(255);
         TLSQ_HIP(h, hipMalloc(&b.p, want));
         b.bytes = want;
+        // WS_POISON: fresh workspace memory reads as NaN (0xFF bytes) in fp64 and fp32 and as -1 in integers, so that a
+        // kernel that reads what this call has not written shows up in the results instead of depending on whatever
+        // the allocator handed back
+        if (dev_is(DEV_WS_POISON, '1')) TLSQ_HIP(h, hipMemsetAsync(b.p, 0xFF, want, h->stream));
     }
     *out = b.p;
+    return TLSQ_OK;
+}
+
+void dbg_hash(Handle* h, const char* tag, const void* dev_ptr, size_t bytes, long long k) {
+    if (!dev_is(DEV_DEBUG_HASH, '1') || !dev_ptr || bytes == 0) return;
+    std::vector<unsigned char> buf(bytes);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return;
+    if (h->stream_b) (void)hipStreamSynchronize(h->stream_b);
+    if (hipMemcpy(buf.data(), dev_ptr, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+    uint64_t x = 1469598103934665603ull;
+    for (size_t i = 0; i < bytes; ++i) {
+        x ^= buf[i];
+        x *= 1099511628211ull;
+    }
+    fprintf(stderr, "[hash] r%d k=%lld %s %016llx\n", h->rank, k, tag, (unsigned long long)x);
+}
+
+// WS_POISON=1: every slot the handle holds is refilled with 0xFF bytes at the start of a solve, and the flags that say
+// "this piece of device state has been initialised" are dropped with it - a solve then cannot see anything an earlier
+// call on the same handle left behind (tests/test_gpu_determinism.py).
+int ws_poison_all(Handle* h) {
+    if (!h || !dev_is(DEV_WS_POISON, '1') || h->in_multi) return TLSQ_OK;
+    for (Handle* sub : h->subs) TLSQ_TRY(ws_poison_all(sub));
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    for (auto& b : h->ws)
+        if (b.p) TLSQ_HIP(h, hipMemsetAsync(b.p, 0xFF, b.bytes, h->stream));
+    h->mail_counter_ready = false;
+    h->cert_ticket_ready = false;
+    h->gram_tab_nti = 0;
+    h->gram_tab2_nti = 0;
+    h->warm_n = 0;
+    if (h->mailbox)
+        for (size_t i = 1; i < h->mailbox_bytes / 8; ++i) h->mailbox[i] = std::numeric_limits<double>::quiet_NaN();
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }
 
@@ -275,7 +352,7 @@ int second_stream(Handle* h) {
     if (h->stream_b) return TLSQ_OK;
     // (highest priority: its workgroups are few and large - they should get a CU as soon as one has room)
     int least = 0, greatest = 0;
-    static const bool no_prio = [] { const char* e = getenv("TLSQ_OVERLAP_NOPRIO"); return e && e[0] == '1'; }();
+    const bool no_prio = dev_is(DEV_OVERLAP_NOPRIO, '1');
     if (!no_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
         hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, greatest) != hipSuccess) {
         (void)hipGetLastError();
@@ -316,6 +393,8 @@ extern "C" {
 
 const char* tlsq_version(void) { return "tlsq-hip 0.1.0 (gfx950)"; }
 
+int tlsq_dev_set(const char* name, const char* value) { return tlsq::dev_set(name, value); }
+
 void tlsq_rpca_opts_default(tlsq_rpca_opts* o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
@@ -336,6 +415,7 @@ int tlsq_create(int device_id, tlsq_handle* out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;  // no GPU: fail loudly
+    dev_load_env();
     if (device_id < 0 || device_id >= ndev) return TLSQ_ERR_ARG;
     if (hipSetDevice(device_id) != hipSuccess) return TLSQ_ERR_HIP;
     tlsq_handle h = new (std::nothrow) tlsq_handle_s();
@@ -485,7 +565,7 @@ int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[T
     if (nranks < 1 || rank < 0 || rank >= nranks || !id) return set_err(h, TLSQ_ERR_ARG, "bad comm args");
     tlsq_comm_destroy(h);
     // a single rank needs no communicator (TLSQ_FORCE_COMM=1 creates one anyway: exercises the RCCL path on one GPU)
-    const char* force = getenv("TLSQ_FORCE_COMM");
+    const char* force = dev_get(DEV_FORCE_COMM);
     if (nranks == 1 && !(force && force[0] == '1')) {
         h->nranks = 1;
         h->rank = 0;

@@ -28,7 +28,7 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
     // Five squarings G -> G^32 (MFMA, each rescaled to unit Frobenius norm) concentrate any column on the dominant
     // cluster; started from the dominant column, the Krylov space is that of a ~16-dimensional problem.
     const double* v0 = nullptr;
-    static const bool no_pow_start = [] { const char* e = getenv("TLSQ_NO_POWER_START"); return e && e[0] == '1'; }();
+    const bool no_pow_start = dev_is(DEV_NO_POWER_START, '1');
     if (stop_above_sigma == 0.0 && rel_tol <= 1e-9 && N >= 64 && N <= 1024 && !no_pow_start) {
         void *P1, *P2, *part, *vst;
         TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P1));
@@ -49,7 +49,7 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
     }
     int st = lanczos_lmax_f64(h, G, N, N, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma, v0);
     if (st < 0) return st;
-    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
     if (dbg) fprintf(stderr, "  opnorm Lanczos: %d steps (rel_tol %.0e, stop %.3e) -> sigma %.6e\n", steps, rel_tol, stop_above_sigma, std::sqrt(lmax));
     if (st == 0 || N > kFullEigMaxN) {   // large mode: no dense fallback; the Lanczos value after 1000 steps stands
         *out = std::sqrt(lmax);
@@ -121,7 +121,7 @@ static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t l
 // full eigen-decomposition of G by the block Jacobi solver: V in WS_V
 // does the full solver go through the Cholesky factor (zero columns for numerically-zero eigenvalues)?
 static bool chol_route(int64_t N) {
-    static const bool no_chol = [] { const char* e = getenv("TLSQ_NO_CHOL"); return e && e[0] == '1'; }();
+    const bool no_chol = dev_is(DEV_NO_CHOL, '1');
     return N > 64 && !no_chol;
 }
 
@@ -132,7 +132,7 @@ static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, Small
     TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     int64_t sw = 0;
-    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
     s.sigma.resize((size_t)N);
     if (chol_route(N) && !need_all_vectors) {
         // Cholesky-preconditioned route: Jacobi on L = chol(G + delta I); far fewer sweeps on graded spectra and
@@ -191,7 +191,7 @@ int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** 
     TLSQ_TRY(jacobi_factor_f64(h, (double*)B, N, (double*)V, (double*)lam, 0.0, &sw));
     if (sweeps) *sweeps += sw;
     h->warm_n = 0;
-    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
     if (dbg) fprintf(stderr, "  svd via R: N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
     s.sigma.resize((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
@@ -319,7 +319,7 @@ static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out
 }
 
 static int power_cert_begin(Handle* h, SubspaceState& st) {
-    static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+    const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
     const int64_t N = st.cert_N;
     const int64_t nt = (N + 31) / 32;
     st.cert_seq = 0.0;
@@ -347,7 +347,7 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
         *pass = lmax * 1.5 < st.cert_margin;
         return TLSQ_OK;
     }
-    static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
     double a = -1.0;
     if (st.cert_seq != 0.0) {
         volatile double* mb = h->mailbox;
@@ -383,7 +383,7 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
     // Still too coarse: the tail is flat and close to the mark (late iterations of a Hankel filter: hundreds of values
     // at 0.7x the threshold).  Three more squarings bring the bound to rank^(1/64) above lambda_max, still rigorous;
     // a Lanczos run (a LOWER bound, hence the 1.5x safety factor) screens first where an N^3 product is not small.
-    static const bool no_deep = [] { const char* e = getenv("TLSQ_NO_DEEP_POWERS"); return e && e[0] == '1'; }();
+    const bool no_deep = dev_is(DEV_NO_DEEP_POWERS, '1');
     bool lanczos_done = false;
     if (st.cert_N > 1024 || no_deep) {
         const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
@@ -516,7 +516,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     double prev_maxres = 0.0;
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
     bool cgs2_sticky = false;
-    static const bool no_onepass = [] { const char* e = getenv("TLSQ_NO_ONEPASS"); return e && e[0] == '1'; }();
+    const bool no_onepass = dev_is(DEV_NO_ONEPASS, '1');
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
         // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
@@ -529,7 +529,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
             // (cold: 2 on the random block; from the second step on the block consists of Ritz vectors and takes a higher power
             //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
-            static const int cold_q = [] { const char* e = getenv("TLSQ_COLD_Q"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
+            const int cold_q = [] { const char* e = dev_get(DEV_COLD_Q); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
             const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
             // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
             bool in_q = true;
@@ -539,20 +539,25 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             }
             if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
         }
+        dbg_hash(h, "sub.chain", Q, (size_t)N * p * 8);
         bool used_cholqr = false;
         // one CholeskyQR pass when the previous step on this block cleared the one-pass pivot bound with room to spare
         const bool one_pass = !cold && !force_cgs2 && !no_onepass && p <= 32 && st.chol_p == p && st.chol_piv >= 0.5;   // (32 = CQ_PMAX: single-block panels)
         TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr, one_pass));
+        dbg_hash(h, "sub.orth", Q, (size_t)N * p * 8);
         // Rayleigh-Ritz: H = Q' (G Q)
         TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
         TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
+        dbg_hash(h, "sub.GQ", GQ, (size_t)N * p * 8);
+        dbg_hash(h, "sub.H", H, (size_t)p * p * 8);
         int64_t sw = 0;
         TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
+        dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
         if (sweeps) *sweeps += sw;
         // X' = Q S,  G X' = (G Q) S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
         // Ritz values did not come out in descending order)
-        static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+        const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
         const bool mail = h->mailbox && !no_mailbox && p <= 512 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
         if (mail) {
             void* scal;
@@ -593,6 +598,8 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                                        h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         }
+        dbg_hash(h, "sub.X", X, (size_t)N * p * 8);
+        dbg_hash(h, "sub.theta", theta_dev, (size_t)(2 * p) * 8);
         st.chol_piv = used_cholqr && host[2 * p + 1] == 0.0 ? host[2 * p + 2] : 0.0;
         st.chol_p = p;
         if (used_cholqr && one_pass && host[2 * p + 1] == 0.0 && host[2 * p + 2] < 0.25) {
@@ -613,7 +620,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // a cold start is random only once: from the second step on the block consists of Ritz vectors, whose images under
         // G^q are nearly orthogonal again (different norms do not hurt the Cholesky factor) - CholeskyQR2 (18 us instead of 60)
         // unless it has already failed on this block
-        static const bool cold_cgs2 = [] { const char* e = getenv("TLSQ_COLD_CGS2"); return e && e[0] == '1'; }();
+        const bool cold_cgs2 = dev_is(DEV_COLD_CGS2, '1');
         if (cold && !hook && !cgs2_sticky && !cold_cgs2) force_cgs2 = false;   // (the randomized hook keeps its two plain passes)
         s.sigma.resize((size_t)p);
         double tmax = 0.0;
@@ -673,7 +680,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             good = good && (host[p + i] <= 2e-13 * tmax);
             maxres = std::max(maxres, host[p + i]);
         }
-        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        const bool dbg = dev_get(DEV_DEBUG) != nullptr;
         if (dbg) {
             int sd = -1;
             void* scal = h->ws[WS_SCAL].p;
@@ -726,7 +733,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
     void *Vg = nullptr, *Vs = nullptr;
     // (explicit G, at most 32 deflated columns, N < 1024: the deflation kernel reads the columns of X itself)
-    static const bool no_fused_defl = [] { const char* e = getenv("TLSQ_NO_FUSED_DEFLATE"); return e && e[0] == '1'; }();
+    const bool no_fused_defl = dev_is(DEV_NO_FUSED_DEFLATE, '1');
     const bool fused_deflate = !op.implicit() && svp <= 32 && N < 1024 && !no_fused_defl;
     SelWeights defl_sw;
     if (svp > 0) {
@@ -758,7 +765,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
         st.cert_GD = (const double*)GD;
         st.cert_N = N;
-        static const bool no_power = [] { const char* e = getenv("TLSQ_NO_POWER_CERT"); return e && e[0] == '1'; }();
+        const bool no_power = dev_is(DEV_NO_POWER_CERT, '1');
         // the two dense squarings cost N^3 flops against ~16 N^2 loads for a Lanczos run: matrix powers up to N = 1024
         st.cert_power = N <= 1024 && !no_power;
         if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
@@ -832,9 +839,9 @@ static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : slot == 3 ? WS_T3 : WS_T, (size_t)M * r * 8, &T1));   // (3: scratch of the deflated certificate)
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16, &aux));
     // T (M x r, fp64) = Z * Vg
-    static const bool no_tsmm = [] { const char* e = getenv("TLSQ_NO_TSMM"); return e && e[0] == '1'; }();
-    static const int64_t tsmm_max = [] { const char* e = getenv("TLSQ_TSMM_MAXR"); return (int64_t)(e ? atoi(e) : 96); }();
-    static const bool no_sel = [] { const char* e = getenv("TLSQ_NO_TSMM_SEL"); return e && e[0] == '1'; }();
+    const bool no_tsmm = dev_is(DEV_NO_TSMM, '1');
+    const int64_t tsmm_max = [] { const char* e = dev_get(DEV_TSMM_MAXR); return (int64_t)(e ? atoi(e) : 96); }();
+    const bool no_sel = dev_is(DEV_NO_TSMM_SEL, '1');
     if (r <= 32 && r <= tsmm_max && !no_tsmm && !no_sel) {
         // short lists: selection and weights travel as kernel arguments, V[:, sel] diag(g) is gathered straight into the
         // packed operand of the factor product (no Vg panel, one launch less), Vs on the way
@@ -867,7 +874,7 @@ static int rebuild_from_factors(Handle* h, const double* Tm, const double* Vs, i
         TLSQ_HIP(h, hipMemset2DAsync(Aout, (size_t)ldA * sizeof(T), 0, (size_t)M * sizeof(T), (size_t)N, h->stream));
         return TLSQ_OK;
     }
-    static const bool no_store = [] { const char* e = getenv("TLSQ_NO_REBUILD_STORE"); return e && e[0] == '1'; }();
+    const bool no_store = dev_is(DEV_NO_REBUILD_STORE, '1');
     if (!no_store && rebuild_store_ok<T>(Aout, M, N, ldA, r)) return launch_rebuild_store<T>(h, Tm, Vs, Aout, M, N, r);
     TLSQ_TRY(gemm_mixed(h, false, false, Vs, 0, N, Tm, 0, M, Aout, Prec<T>::f32, ldA, N, M, r, false));
     return TLSQ_OK;
@@ -887,7 +894,7 @@ int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
 // Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
 static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
                        SubspaceState& sub) {
-    static const int64_t pad_min = [] { const char* e = getenv("TLSQ_PAD"); return (int64_t)(e ? atoi(e) : 4); }();
+    const int64_t pad_min = [] { const char* e = dev_get(DEV_PAD); return (int64_t)(e ? atoi(e) : 4); }();
     int64_t pad = std::max<int64_t>(pad_min, svp / 4);
     // up to 64 (96) columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small / _mid);
     // beyond that it costs ~1 ms per step: give up some padding to stay below when the rank allows
@@ -956,9 +963,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
     TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
     T *Y = (T*)Yv, *R = (T*)Rv;
-    static const bool no_fuse = [] { const char* e = getenv("TLSQ_NO_FUSED_SWEEP"); return e && e[0] == '1'; }();
-    static const bool no_zsweep = [] { const char* e = getenv("TLSQ_NO_ZSWEEP"); return e && e[0] == '1'; }();
-    static const bool no_first = [] { const char* e = getenv("TLSQ_NO_FIRST_SHRINK"); return e && e[0] == '1'; }();
+    const bool no_fuse = dev_is(DEV_NO_FUSED_SWEEP, '1');
+    const bool no_zsweep = dev_is(DEV_NO_ZSWEEP, '1');
+    const bool no_first = dev_is(DEV_NO_FIRST_SHRINK, '1');
     // The E-free loop (sweeps.hip, k_zsweep): E is not kept while the loop runs - Z is updated in place, Y is double-buffered
     // (the caller's E panel is the second buffer) and the factors of the previous A are kept, from which the returned E is
     // formed once after the loop.  Every plain call runs this way; the `hankel` flag (A is modified after the rebuild) and
@@ -993,15 +1000,15 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     double mu_iter = 0.0;        // mu of the last iteration that ran
     int cur = 0;                 // index of the buffers holding E_k, Z_k
     bool have_next = false;      // E_k, Z_k already produced by the previous iteration's fused sweep
-    static const bool no_fuse_rebuild = [] { const char* e = getenv("TLSQ_NO_FUSED_REBUILD"); return e && e[0] == '1'; }();
-    static const bool no_cert_overlap = [] { const char* e = getenv("TLSQ_NO_CERT_OVERLAP"); return e && e[0] == '1'; }();
+    const bool no_fuse_rebuild = dev_is(DEV_NO_FUSED_REBUILD, '1');
+    const bool no_cert_overlap = dev_is(DEV_NO_CERT_OVERLAP, '1');
     const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
     int64_t r_last = 0;
     bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
     double prev_lower = 0.0;                               // Frobenius lower bound of the previous iteration's cost
     int64_t n_rskip = 0;
     bool sumsq_ready = false;   // the two accumulator sets of the Frobenius bound have been cleared
-    static const double rskip_margin = [] { const char* e = getenv("TLSQ_RSKIP_MARGIN"); return e ? atof(e) : 8.0; }();
+    const double rskip_margin = [] { const char* e = dev_get(DEV_RSKIP_MARGIN); return e ? atof(e) : 8.0; }();
     int64_t sweeps = 0;
     // arbitrary hooks of the host language (src/robustPCA.jl:168-169): the panel visits the host and the caller's
     // own function runs there, on the calling thread ("the CPU path with the user's closure")
@@ -1088,7 +1095,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // iteration, the ~8 products plus the Lanczos vectors of the implicit form ~130 M N p at the efficiency of the
     // skinny kernels: measured break-even near N = 128 p (65536 x 4096, p = 80: 41 ms explicit, 58 ms implicit per
     // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
-    static const int force_implicit = [] { const char* e = getenv("TLSQ_IMPLICIT_GRAM"); return e ? atoi(e) : -1; }();
+    const int force_implicit = [] { const char* e = dev_get(DEV_IMPLICIT_GRAM); return e ? atoi(e) : -1; }();
     const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
     auto panel_op = [&](const T* P) {
         GramOp o;
@@ -1132,7 +1139,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
     SubspaceState sub;
     const int64_t pmax = subspace_max_block(N);
-    const char* force_full = getenv("TLSQ_FULL_EIG");
+    const char* force_full = dev_get(DEV_FULL_EIG);
     // Large mode (N > 2048): the full Jacobi solvers do not apply (their column blocks live in LDS); every SVD step
     // has to be served by the certified subspace iteration, whose block is enlarged on demand.  Ranks beyond
     // the largest block (subspace_max_block) are reported as TLSQ_ERR_UNSUPPORTED, and the two-level refinement
@@ -1147,8 +1154,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // subspace solver cannot certify a count there, so it is not even tried until a dense result shows a gap again
     bool bulk_tail = false;
     bool power_vec_valid = false;   // the power-iteration vector of the cost evaluation has been started in this call
-    static const bool no_power_lb = [] { const char* e = getenv("TLSQ_NO_POWER_LB"); return e && e[0] == '1'; }();
-    static const bool no_gram_dense = [] { const char* e = getenv("TLSQ_NO_GRAM_DENSE"); return e && e[0] == '1'; }();
+    const bool no_power_lb = dev_is(DEV_NO_POWER_LB, '1');
+    const bool no_gram_dense = dev_is(DEV_NO_GRAM_DENSE, '1');
     // HBM traffic the panel-sized kernels of this call have to move (algorithmic bytes of what was launched: panel
     // passes x M x N x sizeof(T)); reported in tlsq_rpca_info
     const double panel_bytes = (double)n * sizeof(T);
@@ -1199,7 +1206,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     };
 
     // (all phase marks only on request: tlsq_rpca_opts.phase_timing or TLSQ_PHASE_TIMING=1)
-    static const bool env_phases = [] { const char* e = getenv("TLSQ_PHASE_TIMING"); return e && e[0] == '1'; }();
+    const bool env_phases = dev_is(DEV_PHASE_TIMING, '1');
     PhaseTimer pt(h, timing, env_phases || (opts && opts->phase_timing != 0));
     double zero_sink = 0.0;
     // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | read-back of the Frobenius
@@ -1215,7 +1222,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // whose rounding is relative to ||Z2||^2 ~ (1/mu)^2 instead of sigma_max(Z)^2.  Courant-Fischer: sigma_{|S|+1}(Z) <=
     // sigma_max(Z (I - X_S X_S')) < 1/mu, and Cauchy interlacing puts |S| singular values above 1/mu - the count is |S|.
     // The Ritz values outside S (pad columns: noise of G) are zeroed so that nobody counts them.
-    static const bool no_defl = [] { const char* e = getenv("TLSQ_NO_DEFLATED_CERT"); return e && e[0] == '1'; }();
+    const bool no_defl = dev_is(DEV_NO_DEFLATED_CERT, '1');
     const bool defl_possible = !no_defl && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32;
     auto deflated_certificate = [&](const T* Zp, const double* X, SmallSvd& sv_, double inv_mu_, bool* pass) -> int {
         *pass = false;
@@ -1250,7 +1257,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (!sub.cert_power) return TLSQ_OK;
         TLSQ_TRY(power_cert_begin(h, sub));
         TLSQ_TRY(cert_finish(h, sub, pass));
-        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        const bool dbg = dev_get(DEV_DEBUG) != nullptr;
         if (dbg) fprintf(stderr, "  deflated certificate: |S|=%lld margin=%.3e pass=%d\n", (long long)rS, sub.cert_margin, (int)*pass);
         if (*pass) {
             std::vector<char> keep((size_t)sv_.sigma.size(), 0);
@@ -1270,21 +1277,20 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // by Newton-Schulz iterations (matfun.hip: ~100 N x N x N MFMA products, 2-3 ms) and one M x N x N product.  A sign
     // iteration that does not converge (an eigenvalue within ~1e-10 of the threshold) or a trace that is not an integer to
     // 1e-6 leaves the iteration to the TSQR route.  A_k has no factor form afterwards: see last_no_factors.
-    static const bool no_matfun = [] { const char* e = getenv("TLSQ_NO_MATFUN_ROUTE"); return e && e[0] == '1'; }();
-    // (one GPU for now: on row shards a loop-back run inside the full test suite once took a different trajectory than the
-    //  single-GPU solve - not reproduced in isolation, not understood: shards keep the TSQR route)
+    const bool no_matfun = dev_is(DEV_NO_MATFUN_ROUTE, '1');
     const bool matfun_possible = !no_matfun && use_subspace && !large && !hook_svd && !implicit_gram && !Prec<T>::f32 &&
-                                 N >= 64 && N <= 1024 && !h->comm;
+                                 N >= 64 && N <= 1024;
     bool last_no_factors = false, prev_no_factors = false;   // A_k / A_{k-1} exist only as panels (E-free loop: how E is formed)
     int64_t mf_rS_prev = -1;   // size of the deflated set of the last matrix-function iteration (-1: none yet)
     auto matfun_route = [&](const T* Zp, double inv_mu_, int64_t* svp_out, double* sigma_top_out, bool* ok) -> int {
         *ok = false;
-        static const bool dbg = getenv("TLSQ_DEBUG") != nullptr;
+        const bool dbg = dev_get(DEV_DEBUG) != nullptr;
         const double tau2 = inv_mu_ * inv_mu_;
         // dominant part from the Gram matrix of Z (its Ritz values are far above G's noise): no window, no certificate
         double* Gz = nullptr;
         TLSQ_TRY(gram_allreduce<T>(h, Zp, M, N, M, &Gz));
         hbm_other += panel_bytes;
+        dbg_hash(h, "mf.Gz", Gz, (size_t)N * N * 8);
         GramOp gop;
         gop.G = Gz;
         SmallSvd ss;
@@ -1349,6 +1355,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         double* G2 = nullptr;
         TLSQ_TRY(gram_allreduce<T>(h, Z2, M, N, M, &G2));
         hbm_other += panel_bytes;
+        dbg_hash(h, "mf.Z2", Z2, (size_t)n * sizeof(T));
+        dbg_hash(h, "mf.G2", G2, (size_t)N * N * 8);
         void *G2s, *Cm, *Xs, *W1, *W2, *Wz, *Yb;
         TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &G2s));
         TLSQ_TRY(ws_get(h, WS_MF0, (size_t)N * N * 8, &Cm));
@@ -1366,6 +1374,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             if (dbg) fprintf(stderr, "  matrix-function route: sign iteration did not converge (|S|=%lld)\n", (long long)rS);
             return TLSQ_OK;
         }
+        dbg_hash(h, "mf.sign", Xs, (size_t)N * N * 8);
         double* Pm = (double*)Xs;
         TLSQ_TRY(matfun_axpbi(h, (const double*)Xs, Pm, N, 0.5, 0.5));                    // P = (I + sign) / 2
         double tr = 0.0;
@@ -1403,6 +1412,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     return TLSQ_OK;
                 }
             }
+            dbg_hash(h, "mf.invsqrt", Wz, (size_t)N * N * 8);
             TLSQ_TRY(matfun_mul(h, (const double*)Wz, Pm, (double*)W1, N));               // B^(-1/2) P
             TLSQ_TRY(matfun_lin2(h, Pm, 1.0, (const double*)W1, -1.0, 0.0, Fm, N));        // F = P - B^(-1/2) P
         } else {
@@ -1425,8 +1435,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         // A = Z Phi through Phi' (the GEMM's first operand is indexed [column of A, k])
         TLSQ_TRY(need_A());
+        dbg_hash(h, "mf.Phi", Phi, (size_t)N * N * 8);
         TLSQ_TRY(gemm_mixed(h, false, false, Phi, 0, N, Zp, Prec<T>::f32, M, A, Prec<T>::f32, M, N, M, N, false));
         hbm_other += 2.0 * panel_bytes;
+        dbg_hash(h, "mf.A", A, (size_t)n * sizeof(T));
         *svp_out = rS + k2;
         *sigma_top_out = stop;
         *ok = true;
@@ -1466,6 +1478,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
                 hbm_sweeps += 5.0 * panel_bytes;
             }
+        }
+        if (!have_next) {
+            dbg_hash(h, "shrink.Y", Y, (size_t)n * sizeof(T), k);
+            dbg_hash(h, "shrink.Z", Z, (size_t)n * sizeof(T), k);
         }
         if (d_transient) D = nullptr;   // the copy in Zbuf[1] is not to be read any more
         pt.mark(have_next, !have_next);
@@ -1516,6 +1532,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             }
             a_pending = fuse_rebuild;
             rebuilt = true;
+            if (svp > 0) {
+                dbg_hash(h, "rebuild.Tm", Tm_last, (size_t)M * svp * 8, k);
+                dbg_hash(h, "rebuild.Vs", Vs_last, (size_t)N * svp * 8, k);
+            }
             return TLSQ_OK;
         };
         // How the SVD step is served.  The fast route works on the Gram matrix (warm-started subspace iteration +
@@ -1602,6 +1622,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         g_ready = false;
         pt.mark(gram_queued_earlier);
+        if (G) dbg_hash(h, "G", G, (size_t)N * N * 8, k);
         if (hook_now) {
             // the reference's `svd(Z, sv)` hook (:195-197): a rank-sv randomized SVD; iteration 1 is always full
             SubspaceState rs;
@@ -1723,7 +1744,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     pt.mark();
                     rebuild_marked = true;
                 }
-                static const bool dbg_cmp = [] { const char* e = getenv("TLSQ_DEBUG"); return e && e[0] == '3'; }();
+                const bool dbg_cmp = dev_is(DEV_DEBUG, '3');
                 if (dbg_cmp) {   // development: the same iteration through the TSQR route, A compared
                     std::vector<T> a_mf((size_t)n), a_rf((size_t)n);
                     TLSQ_HIP(h, hipMemcpyAsync(a_mf.data(), A, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
@@ -1810,7 +1831,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // by sqrt(N / rank): the E-free sweep keeps the maximum on the side (one slot per rank: the sum all-reduce of row
         // shards then carries every rank's maximum unchanged), and "not converged" is settled without the Gram of R in all
         // iterations but the last one or two.
-        static const bool no_maxb = [] { const char* e = getenv("TLSQ_NO_MAX_BOUND"); return e && e[0] == '1'; }();
+        const bool no_maxb = dev_is(DEV_NO_MAX_BOUND, '1');
         const int maxslot = (zmode && sumsq_dev && !no_maxb && h->nranks <= 8) ? h->rank : -1;
         // The residual panel R_k is only read by the cost evaluation.  While the Frobenius bound of the previous
         // iteration was far above tol this one's will be too (the cost shrinks by ~rho per iteration): the sweep then
@@ -1827,7 +1848,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // (not when the previous iteration's cost bound - tight since it is the largest entry of the residual - was already
         //  within 1.6 tol: this iteration is then most likely the last one, and a Gram queued now would be the wasted one;
         //  should the loop go on after all, the Gram is computed at the top of the next iteration instead)
-        static const double last_guess = [] { const char* e = getenv("TLSQ_LAST_GUESS"); return e ? atof(e) : 1.6; }();
+        const double last_guess = [] { const char* e = dev_get(DEV_LAST_GUESS); return e ? atof(e) : 1.6; }();
         const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last;
         bool gram_queued = false;
@@ -1878,7 +1899,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // half speed meanwhile (kernel trace at 1e7 x 256, 8 chunks: sweep chunk 2.6 ms alone / 3.7 beside a Gram
             // chunk, Gram chunk 1.5 / 3.6): 30.9 ms for the pair instead of 35.0, nothing at 200000 x 512 (TLSQ_OVERLAP_CHUNKS
             // forces a chunk count, 1 = off).
-            static const int env_chunks = [] { const char* e = getenv("TLSQ_OVERLAP_CHUNKS"); return e ? atoi(e) : -1; }();
+            const int env_chunks = [] { const char* e = dev_get(DEV_OVERLAP_CHUNKS); return e ? atoi(e) : -1; }();
             const bool f32mfma_gram = Prec<T>::f32 && N > 2048;   // (gram_any's choice: that kernel is not chunked)
             int nchunks = (gram_next && !f32mfma_gram && M * N >= ((int64_t)1 << 30)) ? 8 : 1;
             if (env_chunks >= 1 && env_chunks <= 8 && gram_next && !f32mfma_gram) nchunks = env_chunks;
@@ -1886,7 +1907,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(second_stream(h));
                 // (TLSQ_OVERLAP_LDS: unused dynamic LDS per sweep workgroup, caps its residency per CU - measured: 40 KB
                 // no change, 80 KB, i.e. one sweep workgroup per CU, slower)
-                static const size_t pad_lds = [] { const char* e = getenv("TLSQ_OVERLAP_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+                const size_t pad_lds = [] { const char* e = dev_get(DEV_OVERLAP_LDS); return e ? (size_t)atol(e) : (size_t)0; }();
                 const int64_t rows_c = ((M + nchunks - 1) / nchunks + 511) / 512 * 512;
                 GramPlan pl;
                 TLSQ_TRY(gram_plan(h, Prec<T>::f32, N, rows_c, nchunks, &pl));
@@ -1920,13 +1941,18 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             hbm_sweeps += 6.0 * panel_bytes;
         }
         pt.mark(false, true);
+        if (zmode && z_swept) {
+            dbg_hash(h, "sweep.Y", Ybuf[ycur ^ 1], (size_t)n * sizeof(T), k);
+            dbg_hash(h, "sweep.Z", Zbuf[0], (size_t)n * sizeof(T), k);
+            if (Rst) dbg_hash(h, "sweep.R", Rst, (size_t)n * sizeof(T), k);
+        }
         mu = mu_next;
         double rn = 0.0;
         bool cost_skipped = false;
         if (sumsq_dev) {
             double fro2 = 0.0, part[72];
             TLSQ_TRY(comm_allreduce(h, sumsq_dev, maxslot >= 0 ? 72 : 64, ncclSum));   // row shards: same bits on every rank afterwards
-            static const bool no_mailbox = [] { const char* e = getenv("TLSQ_NO_MAILBOX"); return e && e[0] == '1'; }();
+            const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
             const bool mail_sum = h->mailbox && h->mailbox_bytes >= 1024 && !no_mailbox;
             double mail_seq = 0.0;
             if (mail_sum) {

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ G,
 
 int launch_symm_skinny(Handle* h, const double* G, int64_t ldG, const double* X, double* Y, int64_t N, int64_t p) {
     if (p <= 0) return TLSQ_OK;
-    static const bool no_mfma = [] { const char* e = getenv("TLSQ_NO_SYMM_MFMA"); return e && e[0] == '1'; }();
+    const bool no_mfma = dev_is(DEV_NO_SYMM_MFMA, '1');
     if (!no_mfma && (reinterpret_cast<uintptr_t>(X) % 16) == 0) {
         hipLaunchKernelGGL(k_symm_mfma, dim3((unsigned)((N + 15) / 16), (unsigned)((p + 15) / 16)), dim3(256), 0, h->stream, G,
                            ldG, X, Y, (int)N, (int)p);
@@ -862,14 +862,14 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 // step (it arrives with the Ritz values) and repeats the step with both passes when the guess was wrong.
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr, bool one_pass) {
-    static const bool no_cholqr = [] { const char* e = getenv("TLSQ_NO_CHOLQR"); return e && e[0] == '1'; }();
+    const bool no_cholqr = dev_is(DEV_NO_CHOLQR, '1');
     *used_cholqr = allow_cholqr && p <= 512 && !no_cholqr;
     if (!*used_cholqr) {
         // Column-sequential CGS2 is one workgroup: 3.4 ms for a 4096 x 76 block (large-mode cold start).  Wide blocks of
         // long vectors go block by block: 16 columns are projected twice against the finished ones (two multi-workgroup
         // products per projection) and orthonormalised among themselves by the one-workgroup kernel, whose cost falls
         // with the square of the block width.
-        static const bool no_blocked = [] { const char* e = getenv("TLSQ_NO_BLOCKED_CGS2"); return e && e[0] == '1'; }();
+        const bool no_blocked = dev_is(DEV_NO_BLOCKED_CGS2, '1');
         if (no_blocked || N < 2048 || p <= 32) return launch_cgs2(h, Y, N, p, status_dev);
         constexpr int64_t GB = 16;
         for (int64_t c0 = 0; c0 < p; c0 += GB) {

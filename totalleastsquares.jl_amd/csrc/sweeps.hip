@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256) void k_convert(const TS* __restrict__ src, TD*
 }
 
 static inline int grid_for(int64_t work_items) {
-    static const int64_t cap = [] {
-        const char* e = getenv("TLSQ_SWEEP_GRID");   // tuning knob (tools/kbench.py)
+    const int64_t cap = [] {
+        const char* e = dev_get(DEV_SWEEP_GRID);   // tuning knob (tools/kbench.py)
         const long v = e ? atol(e) : 0;
         return (int64_t)(v > 0 ? v : 2048);          // 256 CUs x 8 blocks, grid-stride the rest
     }();
@@ -885,7 +885,7 @@ int launch_update_shrink(Handle* h, const T* D, T* A, const T* E, T* Y, T* R, T*
 // once the panels are large (measured: +16 % at 1e7 x 256, +9 % at 200000 x 512, +2 % at 20000 x 512).
 template <typename T>
 bool rebuild_update_shrink_ok(const T* D, const T* E, T* Y, T* R, T* En, T* Zn, int64_t M, int64_t N, int64_t r) {
-    static const bool force = [] { const char* e = getenv("TLSQ_FUSED_REBUILD"); return e && e[0] == '1'; }();
+    const bool force = dev_is(DEV_FUSED_REBUILD, '1');
     if (!force && M * N < ((int64_t)1 << 26)) return false;
     return (M % 2 == 0) && r <= 32 && aligned16(D) && aligned16(E) && aligned16(Y) && aligned16(R) && aligned16(En) &&
            aligned16(Zn);   // (D is not read when the caller passes an implicit Hankel source instead)
@@ -907,8 +907,8 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
     int ct = 64;
     if (!two)
         while (ct > 8 && ((M + 63) / 64) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
-    static const int env_rows = [] { const char* e = getenv("TLSQ_RUS_ROWS"); return e ? atoi(e) : 0; }();   // tuning knobs
-    static const int env_ct = [] { const char* e = getenv("TLSQ_RUS_CT"); return e ? atoi(e) : 0; }();
+    const int env_rows = [] { const char* e = dev_get(DEV_RUS_ROWS); return e ? atoi(e) : 0; }();   // tuning knobs
+    const int env_ct = [] { const char* e = dev_get(DEV_RUS_CT); return e ? atoi(e) : 0; }();
     bool two2 = two;
     if (env_rows == 1) two2 = false;
     if (env_rows == 2) two2 = true;
@@ -979,8 +979,8 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
     bool two = pair_ok;
     int ct = 64;
     while (ct > 8 && ((M + (two ? 127 : 63)) / (two ? 128 : 64)) * ((N + ct - 1) / ct) < want_waves) ct /= 2;
-    static const int env_rows = [] { const char* e = getenv("TLSQ_RUS_ROWS"); return e ? atoi(e) : 0; }();   // tuning knobs
-    static const int env_ct = [] { const char* e = getenv("TLSQ_RUS_CT"); return e ? atoi(e) : 0; }();
+    const int env_rows = [] { const char* e = dev_get(DEV_RUS_ROWS); return e ? atoi(e) : 0; }();   // tuning knobs
+    const int env_ct = [] { const char* e = dev_get(DEV_RUS_CT); return e ? atoi(e) : 0; }();
     if (env_rows == 1) two = false;
     if (env_rows == 2 && pair_ok) two = true;
     if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
