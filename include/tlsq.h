@@ -14,7 +14,8 @@
  *  - Every entry point returns an int status: 0 OK, >0 non-fatal (TLSQ_MAXITER = the reference's
  *    `@warn "Maximum number of iterations reached"`, src/robustPCA.jl:232), <0 fatal.  No C++
  *    exception or exit() crosses the ABI.  tlsq_last_error(h) gives the text of the last failure.
- *  - A handle is used by one host thread at a time.  All calls block until the device work has completed.
+ *  - A handle is used by one host thread at a time.  All calls block until the device work has completed (except the
+ *    tlsq_k_* kernel entry points at the end of this file, which are asynchronous on the handle's stream).
  *    Multi-GPU, row-sharded, two ways: tlsq_create_multi (one process, one handle, host matrices - the drop-in for
  *    the Julia package), or one handle per GPU / process joined by tlsq_comm_init for device-resident shards.  The
  *    only exchanged data are N x N matrices (Gram all-reduce, TSQR factor all-gather) over RCCL / xGMI.
@@ -97,7 +98,7 @@ typedef struct tlsq_rpca_opts {
 typedef struct tlsq_rpca_info {
     int64_t iters_done;
     int32_t converged;
-    int32_t reserved;        /* iterations whose SVD step went through the TSQR route */
+    int32_t tsqr_iterations; /* iterations whose SVD step went through the TSQR route (TSQR + one-sided Jacobi) */
     double  final_cost;
     double  final_mu;
     double  d_norm;          /* opnorm(D), src/robustPCA.jl:177 */

@@ -41,7 +41,7 @@ end
 
 # mirrors `struct tlsq_rpca_info`, 200 bytes
 mutable struct RpcaInfo
-    iters_done::Int64; converged::Int32; reserved::Int32
+    iters_done::Int64; converged::Int32; tsqr_iterations::Int32
     final_cost::Cdouble; final_mu::Cdouble; d_norm::Cdouble
     cost_hist::Ptr{Cdouble}; svp_hist::Ptr{Int64}; hist_capacity::Int64; jacobi_sweeps::Int64
     ms_total::Cdouble; ms_loop::Cdouble; ms_h2d::Cdouble; ms_d2h::Cdouble

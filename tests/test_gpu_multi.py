@@ -273,3 +273,67 @@ def test_loopback_hankel_flag_on_row_shards(loopback):
     f1 = plain.lowrankfilter(y + noise, 30, hankel=True)
     f2 = multi.lowrankfilter(y + noise, 30, hankel=True)
     assert relerr(f2, f1) < 1e-9
+
+
+def test_group_call_with_user_hooks_runs_on_the_first_gpu(engines):
+    """`rpca(D; svd = my_svd)` on a multi-GPU handle: a caller's hook needs the whole matrix, so the call does not
+    shard - it runs on the first GPU like on a plain handle instead of failing with TLSQ_ERR_UNSUPPORTED."""
+    import scipy.linalg as sla
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    plain, multi = engines
+    D, _, _ = O.synth_lowrank_sparse(900, 40, 4, seed=5)
+
+    def my_svd(Z, sv):
+        U, S, Vt = sla.svd(Z, full_matrices=False, lapack_driver="gesdd")
+        return U, S, Vt
+
+    def my_opnorm(X):
+        return float(sla.svd(X, compute_uv=False, lapack_driver="gesdd")[0])
+
+    A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, svd=my_svd, opnorm=my_opnorm)
+    A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, svd=my_svd, opnorm=my_opnorm)
+    assert rep2.svp_hist == rep1.svp_hist and sv2 == sv1
+    assert np.array_equal(A1, A2) and np.array_equal(E1, E2)
+    loop2 = tlsq_amd.Engine(devices=[0, 0])
+    try:
+        A3, E3, s3, sv3, rep3 = loop2.rpca(D, return_report=True, svd=my_svd, opnorm=my_opnorm)
+        assert np.array_equal(A1, A3) and np.array_equal(E1, E3) and rep3.svp_hist == rep1.svp_hist
+        y, noise = O.synth_series(3000, seed=3)
+        f1 = plain.lowrankfilter(y + noise, 30, opnorm=my_opnorm)
+        f3 = loop2.lowrankfilter(y + noise, 30, opnorm=my_opnorm)
+        assert np.array_equal(f1, f3)
+    finally:
+        loop2.close()
+
+
+def test_comm_init_is_refused_on_a_group_handle(engines):
+    import tlsq_amd
+    plain, multi = engines
+    with pytest.raises(tlsq_amd.TlsqError) as ei:
+        multi.comm_init(1, 0, multi.unique_id())
+    assert ei.value.code == tlsq_amd._lib.TLSQ_ERR_ARG
+
+
+def test_a_failing_rank_takes_the_group_down_instead_of_hanging():
+    """a rank that leaves a group call with an error (OOM, a HIP error on one GPU) used to leave the others blocked
+    in the next collective.  FAIL_RANK injects such an error on one rank of a loop-back group: the call must come back with
+    that rank's error within seconds, and the handle must serve the next call."""
+    import time
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    D, _, _ = O.synth_lowrank_sparse(1500, 96, 6, seed=1500)
+    loop3 = tlsq_amd.Engine(devices=[0, 0, 0])
+    try:
+        A0, E0, *_ = loop3.rpca(D)
+        for bad_rank in (2, 0):
+            with tlsq_amd.dev_switches(FAIL_RANK=bad_rank):
+                t0 = time.time()
+                with pytest.raises(tlsq_amd.TlsqError) as ei:
+                    loop3.rpca(D)
+                assert time.time() - t0 < 20.0
+                assert "injected failure" in str(ei.value) and ei.value.code == tlsq_amd._lib.TLSQ_ERR_HIP
+            A1, E1, *_ = loop3.rpca(D)
+            assert np.array_equal(A0, A1) and np.array_equal(E0, E1)
+    finally:
+        loop3.close()

@@ -35,7 +35,7 @@ class RpcaOpts(C.Structure):
 
 
 class RpcaInfo(C.Structure):
-    _fields_ = [("iters_done", C.c_int64), ("converged", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("iters_done", C.c_int64), ("converged", C.c_int32), ("tsqr_iterations", C.c_int32),
                 ("final_cost", C.c_double), ("final_mu", C.c_double), ("d_norm", C.c_double),
                 ("cost_hist", C.POINTER(C.c_double)), ("svp_hist", C.POINTER(C.c_int64)),
                 ("hist_capacity", C.c_int64), ("jacobi_sweeps", C.c_int64),

@@ -110,7 +110,8 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
         if (dev_mem) return set_err(h, TLSQ_ERR_UNSUPPORTED, "lowrankfilter: a multi-GPU handle takes host vectors");
         const int64_t Kall = (Nx - n) / lag + 1;
-        if (sv <= 0 && Kall >= 64 * (int64_t)h->multi_n) {
+        const bool hook_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
+        if (sv <= 0 && !hook_cb && Kall >= 64 * (int64_t)h->multi_n) {
             const int nr = h->multi_n;
             std::vector<std::vector<T>> scratch((size_t)nr);
             std::vector<tlsq_rpca_info> ri((size_t)nr);
@@ -753,18 +754,21 @@ int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const d
 int tlsq_k_matfun_sign_f64(tlsq_handle h, const double* C, int64_t N, double* X, int32_t* iters) {
     TLSQ_TRY(check_handle(h));
     if (!C || !X || N <= 0 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "matfun_sign: bad argument (N <= 1024)");
+    TLSQ_HIP(h, hipSetDevice(h->device));
     void *w1, *w2;
     TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &w1));
     TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &w2));
     int it = 0;
     bool ok = false;
     TLSQ_TRY(matfun_sign(h, C, N, X, (double*)w1, (double*)w2, 100, &it, &ok));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (the last copy of the iterate into X is still queued)
     if (iters) *iters = it;
     return ok ? TLSQ_OK : set_err(h, TLSQ_ERR_NOCONV, "matfun_sign: no convergence in 100 steps");
 }
 int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double hi, double* W, int32_t* iters) {
     TLSQ_TRY(check_handle(h));
     if (!B || !W || N <= 0 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "matfun_invsqrt: bad argument (N <= 1024)");
+    TLSQ_HIP(h, hipSetDevice(h->device));
     void *y, *t, *w;
     TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &y));
     TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &t));
@@ -772,6 +776,7 @@ int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double 
     int it = 0;
     bool ok = false;
     TLSQ_TRY(matfun_invsqrt(h, B, N, hi, W, (double*)y, (double*)t, (double*)w, 100, &it, &ok));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (the final scaling of W is still queued)
     if (iters) *iters = it;
     return ok ? TLSQ_OK : set_err(h, TLSQ_ERR_NOCONV, "matfun_invsqrt: no convergence in 100 steps");
 }

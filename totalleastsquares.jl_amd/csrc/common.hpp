@@ -101,7 +101,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
 // only in a build with -DTLSQ_DEV_SWITCHES, from environment variables TLSQ_<NAME> read once at the first tlsq_create.
 // The shipped build reads no environment variable at all: a leaked or mistyped variable cannot change which solver runs.
 #define TLSQ_DEV_LIST(X)                                                                                                  \
-    X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP)                                                \
+    X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP) X(FAIL_RANK)                                                \
     X(NO_ZSWEEP) X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(FUSED_REBUILD) X(NO_REBUILD_STORE)            \
     X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID)                                                                                    \
     X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \

@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -138,6 +139,8 @@ struct RcclApi {
                               hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -157,6 +160,8 @@ static bool rccl_load() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(lib, "ncclCommAbort");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         dlclose(lib);
@@ -177,8 +182,11 @@ struct LocalGroup {
     int arrived = 0;
     uint64_t gen = 0;
     std::vector<std::vector<double>> slot;
-    bool barrier() {   // false: the other ranks did not arrive within a minute (one of them left the call with an error)
+    bool failed = false;   // a rank has left the group call with an error: nobody waits for it any more
+    // false: a rank has failed (multi_run says so at once), or the others did not arrive within a minute
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (failed) return false;
         const uint64_t g = gen;
         if (++arrived == n) {
             arrived = 0;
@@ -186,9 +194,19 @@ struct LocalGroup {
             cv.notify_all();
             return true;
         }
-        if (cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g; })) return true;
+        if (cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || failed; }) && gen != g) return true;
         --arrived;
         return false;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        cv.notify_all();
+    }
+    void reset() {
+        std::lock_guard<std::mutex> lk(m);
+        failed = false;
+        arrived = 0;
     }
 };
 
@@ -196,6 +214,8 @@ struct Comm {
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> local;   // set instead of `comm` for a loop-back group
     int local_rank = 0;
+    bool aborted = false;                // ncclCommAbort has been called on `comm` (a rank of the group failed)
+    std::shared_ptr<std::atomic<bool>> group_failed;   // shared by the ranks of a tlsq_create_multi group
 };
 
 #define TLSQ_NCCL(h, expr)                                                                     \
@@ -207,8 +227,15 @@ struct Comm {
     } while (0)
 
 // in-place sum of an N x N Gram over the row shards (the one real exchange of the path)
+static int group_alive(Handle* h) {
+    if (h->comm->group_failed && h->comm->group_failed->load())
+        return set_err(h, TLSQ_ERR_COMM, "multi-GPU group: another rank left the call with an error");
+    return TLSQ_OK;
+}
+
 int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
     if (!h->comm) return TLSQ_OK;
+    TLSQ_TRY(group_alive(h));
     if (h->comm->local) {
         LocalGroup& g = *h->comm->local;
         std::vector<double>& mine = g.slot[(size_t)h->comm->local_rank];
@@ -247,6 +274,7 @@ int comm_allgather(Handle* h, const double* send, double* recv, size_t count) {
         TLSQ_HIP(h, hipMemcpyAsync(recv, send, count * 8, hipMemcpyDeviceToDevice, h->stream));
         return TLSQ_OK;
     }
+    TLSQ_TRY(group_alive(h));
     if (h->comm->local) {
         LocalGroup& g = *h->comm->local;
         std::vector<double>& mine = g.slot[(size_t)h->comm->local_rank];
@@ -306,22 +334,63 @@ int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn) {
     hs[0] = h;
     for (int r = 1; r < n; ++r) hs[(size_t)r] = h->subs[(size_t)r - 1];
     std::vector<int> st((size_t)n, TLSQ_OK);
+    if (h->multi_comm && h->multi_comm->local) {
+        h->multi_comm->local->reset();
+        if (h->multi_comm->group_failed) h->multi_comm->group_failed->store(false);   // (a loop-back group survives a failed call)
+    }
+    for (int r = 0; r < n; ++r)
+        if (hs[(size_t)r]->multi_comm && hs[(size_t)r]->multi_comm->aborted)
+            return set_err(h, TLSQ_ERR_COMM, "multi-GPU group: the communicators were aborted by an earlier failed call; "
+                                             "destroy the handle and create a new one");
+    // A rank that leaves the call with an error before a collective the others have entered would leave them blocked for
+    // ever (ncclAllReduce / the stream synchronisation behind it) and join() below would never return: the failing rank
+    // therefore takes the whole group down - ncclCommAbort on every communicator of the group (the collectives' kernels
+    // poll the abort flag and exit), the fail flag of a loop-back group - and every other rank comes back with an error.
+    std::mutex abort_m;
+    bool group_failed = false;
+    auto fail_group = [&]() {
+        std::lock_guard<std::mutex> lk(abort_m);
+        if (group_failed) return;
+        group_failed = true;
+        for (int q = 0; q < n; ++q)
+            if (hs[(size_t)q]->multi_comm && hs[(size_t)q]->multi_comm->group_failed) hs[(size_t)q]->multi_comm->group_failed->store(true);
+        for (int q = 0; q < n; ++q) {
+            Comm* c = hs[(size_t)q]->multi_comm;
+            if (!c) continue;
+            if (c->local) c->local->fail();
+            else if (c->comm && g_rccl.CommAbort && !c->aborted) {
+                c->aborted = true;
+                (void)g_rccl.CommAbort(c->comm);
+                c->comm = nullptr;
+            }
+        }
+    };
     auto body = [&](int r) {
         Handle* hr = hs[(size_t)r];
         if (hipSetDevice(hr->device) != hipSuccess) {
             st[(size_t)r] = set_err(hr, TLSQ_ERR_HIP, "hipSetDevice(%d) failed", hr->device);
+            fail_group();
             return;
         }
+        Comm* prev_comm = hr->comm;     // (a communicator of tlsq_comm_init on this handle is put back afterwards)
+        const int prev_n = hr->nranks, prev_r = hr->rank;
         hr->comm = hr->multi_comm;
         hr->nranks = n;
         hr->rank = r;
         hr->in_multi = true;
-        st[(size_t)r] = fn(hr, r, n);
+        try {
+            st[(size_t)r] = fn(hr, r, n);
+        } catch (const std::bad_alloc&) {
+            st[(size_t)r] = set_err(hr, TLSQ_ERR_OOM, "out of host memory on rank %d", r);
+        } catch (const std::exception& e) {
+            st[(size_t)r] = set_err(hr, TLSQ_ERR_HIP, "exception on rank %d: %s", r, e.what());
+        }
+        if (st[(size_t)r] < 0 && n > 1) fail_group();
         (void)hipStreamSynchronize(hr->stream);
         hr->in_multi = false;
-        hr->comm = nullptr;
-        hr->nranks = 1;
-        hr->rank = 0;
+        hr->comm = prev_comm;
+        hr->nranks = prev_n;
+        hr->rank = prev_r;
     };
     std::vector<std::thread> workers;
     for (int r = 1; r < n; ++r) workers.emplace_back(body, r);
@@ -329,12 +398,18 @@ int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn) {
     for (auto& t : workers) t.join();
     (void)hipSetDevice(h->device);
     int worst = TLSQ_OK;
+    int first_bad = -1;
     for (int r = 0; r < n; ++r) {
         if (st[(size_t)r] < 0) {
-            if (r > 0) h->err = "rank " + std::to_string(r) + ": " + hs[(size_t)r]->err;
-            return st[(size_t)r];
+            // (the ranks the failure took down report TLSQ_ERR_COMM: the root cause is the first status that is not)
+            if (first_bad < 0 || (st[(size_t)first_bad] == TLSQ_ERR_COMM && st[(size_t)r] != TLSQ_ERR_COMM)) first_bad = r;
+        } else {
+            worst = std::max(worst, st[(size_t)r]);
         }
-        worst = std::max(worst, st[(size_t)r]);
+    }
+    if (first_bad >= 0) {
+        if (first_bad > 0) h->err = "rank " + std::to_string(first_bad) + ": " + hs[(size_t)first_bad]->err;
+        return st[(size_t)first_bad];
     }
     return worst;
 }
@@ -498,8 +573,10 @@ int tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out) {
         undo();
         return TLSQ_ERR_COMM;
     }
+    auto gf = std::make_shared<std::atomic<bool>>(false);
     for (int r = 0; r < ngpus; ++r) {
         hs[(size_t)r]->multi_comm = new Comm();
+        hs[(size_t)r]->multi_comm->group_failed = gf;
         hs[(size_t)r]->multi_comm->comm = comms[(size_t)r];
         hs[(size_t)r]->multi_comm->local = lg;
         hs[(size_t)r]->multi_comm->local_rank = r;
@@ -525,7 +602,6 @@ int tlsq_destroy(tlsq_handle h) {
         delete h->multi_comm;
         h->multi_comm = nullptr;
     }
-    h->comm = nullptr == h->comm ? nullptr : h->comm;
     tlsq_comm_destroy(h);
     for (auto& b : h->ws)
         if (b.p) (void)hipFree(b.p);
@@ -563,6 +639,9 @@ int tlsq_comm_unique_id(unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
 int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[TLSQ_UNIQUE_ID_BYTES]) {
     TLSQ_TRY(check_handle(h));
     if (nranks < 1 || rank < 0 || rank >= nranks || !id) return set_err(h, TLSQ_ERR_ARG, "bad comm args");
+    if (h->multi_comm)
+        return set_err(h, TLSQ_ERR_ARG, "tlsq_comm_init: this handle is a multi-GPU group (tlsq_create_multi) and shards by "
+                                        "itself; use one plain handle per process for a communicator of your own");
     tlsq_comm_destroy(h);
     // a single rank needs no communicator (TLSQ_FORCE_COMM=1 creates one anyway: exercises the RCCL path on one GPU)
     const char* force = dev_get(DEV_FORCE_COMM);

@@ -958,10 +958,24 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                      double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info) {
     const int64_t n = M * N;
     const bool timing = info != nullptr;
-    void *Yv, *Zv, *Rv;
-    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * sizeof(T), &Yv));
-    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
-    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
+    void *Yv = nullptr, *Zv = nullptr, *Rv = nullptr;
+    {
+        // The panels first, and on row shards an agreement on the outcome: a rank that runs out of memory here (the one with
+        // the remainder row, a GPU somebody else is using) must not leave the others waiting in the first collective.
+        const int st_alloc = [&]() -> int {
+            TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * sizeof(T), &Yv));
+            TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * sizeof(T), &Zv));
+            TLSQ_TRY(ws_get(h, WS_R, (size_t)n * sizeof(T), &Rv));
+            return TLSQ_OK;
+        }();
+        if (h->comm) {
+            double bad = st_alloc < 0 ? 1.0 : 0.0;
+            TLSQ_TRY(comm_allreduce_host_scalar(h, &bad, ncclMax));
+            if (bad != 0.0 && st_alloc >= 0)
+                return set_err(h, TLSQ_ERR_OOM, "rpca: another rank of the group could not allocate its panels");
+        }
+        if (st_alloc < 0) return st_alloc;
+    }
     T *Y = (T*)Yv, *R = (T*)Rv;
     const bool no_fuse = dev_is(DEV_NO_FUSED_SWEEP, '1');
     const bool no_zsweep = dev_is(DEV_NO_ZSWEEP, '1');
@@ -1452,6 +1466,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const double t_loop0 = now_ms();
     int64_t k = 0;
     for (k = 1; k <= ro.iters; ++k) {                              // :186
+        // (test hook, FAIL_RANK=r: rank r of a group leaves iteration 3 with an error - the others must not hang)
+        if (k == 3 && h->comm)
+            if (const char* fr = dev_get(DEV_FAIL_RANK))
+                if (atoi(fr) == h->rank) return set_err(h, TLSQ_ERR_HIP, "rpca: injected failure on rank %d (FAIL_RANK)", h->rank);
         const double inv_mu = 1.0 / mu;
         const double thr = lam / mu;
         T* E = Ebuf[cur];
@@ -2153,7 +2171,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->eig_full = sub.full + n_gram_dense;
         info->eig_fast = sub.fast;
         info->subspace_steps = sub.steps;
-        info->reserved = (int32_t)n_rroute;   // iterations served by the TSQR route
+        info->tsqr_iterations = (int32_t)n_rroute;
         info->hbm_bytes_sweeps = hbm_sweeps;
         info->hbm_bytes = hbm_sweeps + hbm_other;
         info->residual_stores_skipped = n_rskip;
@@ -2590,8 +2608,10 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         if (dev_mem)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: a multi-GPU handle takes host matrices (device pointers belong "
                            "to one GPU; use one handle per GPU with tlsq_comm_init for device-resident shards)");
-        // tall problems with enough rows per GPU are row-sharded; anything else runs on the first GPU alone
-        if (M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
+        // tall problems with enough rows per GPU are row-sharded; anything else - and every call with a caller's svd / opnorm
+        // hook, which needs the whole matrix in one place (include/tlsq.h) - runs on the first GPU alone
+        const bool hook_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
+        if (!hook_cb && M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
             return rpca_multi<T>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
     }
     TLSQ_HIP(h, hipSetDevice(h->device));

@@ -58,7 +58,7 @@ class RpcaReport:
         self.eig_full, self.eig_fast = int(info.eig_full), int(info.eig_fast)
         self.subspace_steps = int(info.subspace_steps)
         self.residual_stores_skipped = int(info.residual_stores_skipped)
-        self.tsqr_iterations = int(info.reserved)
+        self.tsqr_iterations = int(info.tsqr_iterations)
         self.hbm_bytes_sweeps, self.hbm_bytes = float(info.hbm_bytes_sweeps), float(info.hbm_bytes)
         self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
 
