@@ -362,6 +362,16 @@ int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const d
  * TLSQ_ERR_NOCONV when the iteration does not converge (an eigenvalue of C too close to zero / B not definite). */
 int tlsq_k_matfun_sign_f64(tlsq_handle h, const double* C, int64_t N, double* X, int32_t* iters);
 int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double hi, double* W, int32_t* iters);
+/* Rayleigh-Ritz of a nearly orthogonal block in one workgroup (subspace.hip, k_rr_small; p <= 32; device pointers): from
+   B = Y'Y and Hg = Y'GY (p x p, ld p) the rotation C (p x p, ld p) with C'BC = I and C'HgC = diag(lam), by a symmetric
+   orthonormalisation (Newton-Schulz inverse square root) and the eigenvector refinement of Ogita & Aishima started from the
+   identity.  The first nt columns are the wanted ones; the other p - nt (pad columns) are orthonormalised and decoupled from
+   them but not rotated among themselves, which is only acceptable while the pad block's eigenvalues (Gershgorin) stay
+   below tau2.  status (8 doubles): [1] = 0 ok / 1 columns too far from orthogonal (C = diag(B)^-1/2) / 2 no convergence /
+   3 a pad column may have reached tau2.  Replaces CholeskyQR2 + the Jacobi solver in warm subspace steps of the rpca loop
+   (the `gesdd` work of src/robustPCA.jl:194). */
+int tlsq_k_rr_small_f64(tlsq_handle h, const double* B, const double* Hg, int64_t p, int64_t nt, double tau2, double* C,
+                        double* lam, double* status);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401
 import tlsq_amd
+tlsq_amd.dev_from_env()   # TLSQ_DEBUG=1 etc. from the shell (the library itself reads no environment)
 from oracle import rpca_oracle as O
 M, N, r = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (20000, 512, 16)
 D, A0, _ = O.synth_lowrank_sparse(M, N, r, seed=0)

@@ -780,6 +780,12 @@ int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double 
     if (iters) *iters = it;
     return ok ? TLSQ_OK : set_err(h, TLSQ_ERR_NOCONV, "matfun_invsqrt: no convergence in 100 steps");
 }
+int tlsq_k_rr_small_f64(tlsq_handle h, const double* B, const double* Hg, int64_t p, int64_t nt, double tau2, double* C,
+                        double* lam, double* status) {
+    TLSQ_TRY(check_handle(h));
+    if (!B || !Hg || !C || !lam || !status || p < 1 || p > 32 || nt < 0) return set_err(h, TLSQ_ERR_ARG, "k_rr_small: bad argument (p <= 32)");
+    return launch_rr_small_only(h, B, Hg, C, lam, status, p, std::min(nt, p), tau2);
+}
 int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !G || M < 0 || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "k_gram_f32: bad arguments");

@@ -107,7 +107,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
     X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
     X(NO_CERT_OVERLAP) X(NO_FUSED_DEFLATE)                                                                                 \
-    X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_CHOL) X(NO_SYMM_MFMA)             \
+    X(NO_RR_FAST) X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_CHOL) X(NO_SYMM_MFMA)             \
     X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(OVERLAP_CHUNKS)    \
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
@@ -369,6 +369,13 @@ int subspace_max_block(int64_t N);
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr, bool one_pass = false);
+// Rayleigh-Ritz of a nearly orthogonal warm block without orthonormalisation pass and Jacobi sweeps (subspace.hip,
+// k_rr_small): B = Y'Y, Hg = Y'GY (scratch, p x p), C (p x p) with X' = Y C the Ritz vectors, lam their Ritz values,
+// status[1] != 0: not applicable (the caller falls back to CholeskyQR2 + Jacobi).  p <= 32.
+int launch_rr_small(Handle* h, const double* Y, const double* GY, double* Bm, double* Hm, double* Cout, double* lam,
+                    double* status, int64_t N, int64_t p, int64_t nt, double tau2);
+int launch_rr_small_only(Handle* h, const double* Bm, const double* Hm, double* Cout, double* lam, double* status, int64_t p,
+                         int64_t nt, double tau2);
 int launch_ritz_resid(Handle* h, const double* GX, const double* X, const double* theta, int64_t N, int64_t p,
                       double* res);
 int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int64_t p, double* theta);

@@ -280,6 +280,8 @@ struct SubspaceState {
     int cert_ntile = 0;
     bool cert_power = false;
     int64_t n_power = 0, n_power_l2 = 0, n_lanczos_cert = 0;   // statistics: served by S^2 / S^4 / Lanczos
+    int64_t n_rr_fast = 0, n_rr_declined = 0;                  // steps served / declined by the fused Rayleigh-Ritz kernel
+    int rr_streak = 0, rr_skip = 0;                            // consecutive declines / calls in which it is not tried
     double cert_tail = 0.0;   // Lanczos estimate of lambda_max(GD) / tau^2 of the last failed certificate (0: unknown)
 };
 
@@ -517,6 +519,15 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
     bool cgs2_sticky = false;
     const bool no_onepass = dev_is(DEV_NO_ONEPASS, '1');
+    const bool no_rr_fast = dev_is(DEV_NO_RR_FAST, '1');
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+    // (declined: for the rest of this call the block is not what k_rr_small is made for.  A kernel that keeps declining -
+    //  near-degenerate pairs of Ritz values, as a Hankel filter has them - is not tried in the next 2, 4, 8, 16 calls.)
+    bool rr_fast_declined = false;
+    if (st.rr_skip > 0) {
+        --st.rr_skip;
+        rr_fast_declined = true;
+    }
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
         // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
@@ -525,8 +536,9 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
         // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
         TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
+        const int64_t nt_step = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);   // leading columns treated as wanted
         {
-            const int64_t nt = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);
+            const int64_t nt = nt_step;
             // (cold: 2 on the random block; from the second step on the block consists of Ritz vectors and takes a higher power
             //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
             const int cold_q = [] { const char* e = dev_get(DEV_COLD_Q); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
@@ -541,8 +553,21 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         }
         dbg_hash(h, "sub.chain", Q, (size_t)N * p * 8);
         bool used_cholqr = false;
+        // Warm single-block panels: the columns of Q = [G^q X_top, G X_pad] are images of Ritz vectors - nearly orthogonal, and
+        // Q'GQ nearly diagonal once they are normalised.  Orthonormalisation, Rayleigh quotient and its eigenvectors then
+        // come from two reductions over the panel and ONE workgroup of p x p products (subspace.hip, k_rr_small) instead of
+        // CholeskyQR2, H = Q'GQ and the Jacobi solver; anything that kernel declines (panel too far from orthogonal, a
+        // cluster of Ritz values with internal coupling) repeats the step on the classic path.
+        const bool rr_fast = !cold && !force_cgs2 && !rr_fast_declined && !no_rr_fast && p <= 32 && !op.implicit();
         // one CholeskyQR pass when the previous step on this block cleared the one-pass pivot bound with room to spare
         const bool one_pass = !cold && !force_cgs2 && !no_onepass && p <= 32 && st.chol_p == p && st.chol_piv >= 0.5;   // (32 = CQ_PMAX: single-block panels)
+        if (rr_fast) {
+            TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
+            TLSQ_TRY(launch_rr_small(h, (const double*)Q, (const double*)GQ, (double*)H, (double*)HB, (double*)S, lamH_dev, stat_dev, N, p,
+                                     nt_step, inv_mu * inv_mu));
+            dbg_hash(h, "sub.GQ", GQ, (size_t)N * p * 8);
+            dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
+        } else {
         TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr, one_pass));
         dbg_hash(h, "sub.orth", Q, (size_t)N * p * 8);
         // Rayleigh-Ritz: H = Q' (G Q)
@@ -554,6 +579,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
         dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
         if (sweeps) *sweeps += sw;
+        }
         // X' = Q S,  G X' = (G Q) S
         // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
         // Ritz values did not come out in descending order)
@@ -600,6 +626,21 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         }
         dbg_hash(h, "sub.X", X, (size_t)N * p * 8);
         dbg_hash(h, "sub.theta", theta_dev, (size_t)(2 * p) * 8);
+        if (rr_fast && host[2 * p + 1] != 0.0) {
+            // k_rr_small declined (it left X = the normalised columns of Q: same span): same step again on the classic path
+            if (dbg) fprintf(stderr, "  subspace step %d: fused Rayleigh-Ritz declined (status %.0f, ||B - I|| = %.2e)\n", step, host[2 * p + 1], host[2 * p + 2]);
+            rr_fast_declined = true;
+            ++st.n_rr_declined;
+            st.rr_streak = std::min(st.rr_streak + 1, 4);
+            st.rr_skip = 1 << st.rr_streak;
+            --step;
+            --st.steps;
+            continue;
+        }
+        if (rr_fast) {
+            ++st.n_rr_fast;
+            st.rr_streak = 0;
+        }
         st.chol_piv = used_cholqr && host[2 * p + 1] == 0.0 ? host[2 * p + 2] : 0.0;
         st.chol_p = p;
         if (used_cholqr && one_pass && host[2 * p + 1] == 0.0 && host[2 * p + 2] < 0.25) {
@@ -680,7 +721,6 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             good = good && (host[p + i] <= 2e-13 * tmax);
             maxres = std::max(maxres, host[p + i]);
         }
-        const bool dbg = dev_get(DEV_DEBUG) != nullptr;
         if (dbg) {
             int sd = -1;
             void* scal = h->ws[WS_SCAL].p;
@@ -707,6 +747,9 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             }
             break;
         }
+        // (the fused Rayleigh-Ritz kernel leaves clusters of Ritz values unresolved - fine for pad columns, not for a cluster
+        //  that reaches into the wanted pairs: the next step of this call goes through the Jacobi solver)
+        if (rr_fast) rr_fast_declined = true;
         // hopeless (no spectral gap behind the block): stop early and let the full solver run
         if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
         prev_maxres = maxres;

@@ -947,6 +947,391 @@ int launch_rayleigh(Handle* h, const double* GX, const double* X, int64_t N, int
     return TLSQ_OK;
 }
 
+// ---- Rayleigh-Ritz of a warm block without an orthonormalisation pass and without Jacobi sweeps ---------------------
+// The warm block Y = [G^q X_top, G X_pad] consists of images of the previous Ritz vectors: its columns are nearly
+// orthogonal and Y'GY is nearly diagonal once they are normalised.  CholeskyQR2 (two launches with a column-sequential
+// factorisation each), the product G Q, H = Q'GQ and the Jacobi solver (57 dependent rotation rounds at p = 20, 33 us)
+// are then replaced by two reductions over the panel - B = Y'Y, Hg = Y'(G Y) (k_panel_tn2x) - and ONE workgroup that works
+// on p x p matrices in LDS through dense p x p x p products only (k_rr_small, p <= 32):
+//   1. D = diag(B)^-1/2, Bh = D B D, Hh = D sym(Hg) D
+//   2. Bh = L L' in LDS (the pad columns G X_pad lean towards the dominant directions by O(1): Bh is well conditioned but
+//      not close to I, so no Newton-Schulz here); T = L^-1; C_0 = T'
+//   3. the refinement of Ogita & Aishima (Japan J. Indust. Appl. Math. 35, 2018) for the pencil (Hh, Bh), started from C_0:
+//      R = I - C'Bh C, S = C'Hh C, lambda_i = S_ii / (1 - R_ii), E_ij = (S_ij + lambda_j R_ij) / (lambda_j - lambda_i) - or
+//      R_ij / 2 for pairs closer than delta_c = 2 (||S - diag||_F + ||Hh||_F ||R||_F) -, C <- C + C E: quadratic convergence
+//      for separated Ritz values, and B-orthonormality is refined along with the vectors - the factorisation only has to
+//      provide a starting point.
+//   4. D C: the caller's rotation kernel forms X' = Y D C, G X' = (G Y) D C, Ritz values and residuals - which remain the
+//      acceptance test, whatever produced C.
+// status[0] = sqrt(smallest pivot), status[1] = 0 ok / 1 Y too far from orthogonal or not finite / 2 no convergence /
+// 3 a pad column may have reached the threshold (nt = number of wanted columns, tau2 = the threshold: pad columns are
+// not rotated among themselves),
+// status[2] = delta.  On failure C = D (X' = the normalised columns of Y: same span, nothing is lost).
+constexpr int RS_P = 32;
+constexpr int RS_LD = 33;
+// Four waves, one 16 x 16 tile of the (padded) 32 x 32 matrices each; all p x p x p products run on
+// v_mfma_f64_16x16x4_f64 with operands read from LDS (a plain one-entry-per-thread product moves 2 p loads per entry
+// through the LDS port: 1.2 us per product at p = 20 with 1024 threads - the port, not the arithmetic, was the limit).
+// Lane l of wave w owns the entries (row ti 16 + (l >> 4) + 4 q, q = 0..3; column tj 16 + (l & 15)), ti = w & 1, tj = w >> 1
+// - the accumulator layout of the MFMA - in every matrix, so all element-wise steps work on registers.
+struct RsLane {
+    int ti, tj, fr, fk, cj;
+    __device__ __forceinline__ int ri(int q) const { return ti * 16 + fk + 4 * q; }
+};
+// C tile = op(A) op(B) over nk k-steps of 4 (A, B: 32 x 32 in LDS, column-major, ld RS_LD)
+// (all operands of a tile are fetched before the first MFMA: one LDS latency per product instead of one per k-step)
+template <bool TA, bool TB>
+__device__ __forceinline__ sm_d4 rs_mfma(const double* A, const double* B, const RsLane& L, int nk) {
+    sm_d4 acc = sm_d4{0.0, 0.0, 0.0, 0.0};
+    const int ar = L.ti * 16 + L.fr, bc = L.tj * 16 + L.fr;
+    double a[8], b[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int k = 4 * s + L.fk;
+        a[s] = (s < nk) ? (TA ? A[k + ar * RS_LD] : A[ar + k * RS_LD]) : 0.0;
+        b[s] = (s < nk) ? (TB ? B[bc + k * RS_LD] : B[k + bc * RS_LD]) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        if (s < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ double rs_wmax(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+// block-wide sums of two values and maxima of three (4 waves), the same bits in every thread
+__device__ __forceinline__ void rs_reduce(double& s0, double& s1, double& m0, double& m1, double& m2, double* red) {
+    s0 = ss_wsum(s0);
+    s1 = ss_wsum(s1);
+    m0 = rs_wmax(m0);
+    m1 = rs_wmax(m1);
+    m2 = rs_wmax(m2);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[w * 5 + 0] = s0;
+        red[w * 5 + 1] = s1;
+        red[w * 5 + 2] = m0;
+        red[w * 5 + 3] = m1;
+        red[w * 5 + 4] = m2;
+    }
+    __syncthreads();
+    s0 = (red[0] + red[5]) + (red[10] + red[15]);
+    s1 = (red[1] + red[6]) + (red[11] + red[16]);
+    m0 = fmax(fmax(red[2], red[7]), fmax(red[12], red[17]));
+    m1 = fmax(fmax(red[3], red[8]), fmax(red[13], red[18]));
+    m2 = fmax(fmax(red[4], red[9]), fmax(red[14], red[19]));
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg, const double* __restrict__ Hg, int p,
+                                                  double* __restrict__ Cout, double* __restrict__ lam_out,
+                                                  double* __restrict__ status, int nt, double tau2) {
+    // seven 32 x 32 buffers (59 KB): Bh and Hh stay; the others change roles between the factorisation and the refinement
+    __shared__ double sBh[RS_P * RS_LD], sH[RS_P * RS_LD], b2[RS_P * RS_LD], b3[RS_P * RS_LD], b4[RS_P * RS_LD];
+    __shared__ double b5[RS_P * RS_LD], b6[RS_P * RS_LD];
+    __shared__ double sd[RS_P], slam[RS_P], red[20];
+    double* const sZ = b4;   // L                      | H C
+    double* const sT = b5;   // T = L^-1
+    double* const sU = b6;   // 2 I - L X (Newton)     | E
+    double* const sV = b2;   // trailing matrix (even) | C
+    double* const sY = b3;   // trailing matrix (odd)  | Bh C
+    double* const sW = b4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    RsLane L;
+    L.ti = w & 1;
+    L.tj = w >> 1;
+    L.fr = lane & 15;
+    L.fk = lane >> 4;
+    L.cj = L.tj * 16 + L.fr;
+    const int cj = L.cj;
+    const int nk = (p + 3) / 4;
+    const bool cin = cj < p;
+    // ---- load, scale: Bh = D B D (unit diagonal), Hh = D sym(Hg) D; identity / zero in the padding ----
+    double bq[4], hq[4], badv = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = L.ri(q);
+        const bool in = cin && i < p;
+        bq[q] = in ? Bg[i + (size_t)cj * p] : (i == cj ? 1.0 : 0.0);
+        hq[q] = in ? 0.5 * (Hg[i + (size_t)cj * p] + Hg[cj + (size_t)i * p]) : 0.0;
+        if (i == cj) {
+            const bool ok = (bq[q] > 0.0) && (bq[q] < 1.0e300);
+            sd[i] = ok ? 1.0 / sqrt(bq[q]) : 0.0;
+            if (!ok) badv = 1.0;
+        }
+        if (!(fabs(hq[q]) < 1.0e300)) badv = 1.0;
+    }
+    double dsum = 0.0, z1 = 0.0, z2 = 0.0, zm = 0.0, zm2 = 0.0;
+    rs_reduce(badv, z1, z2, zm, zm2, red);   // (also orders the writes of sd)
+    const double dj = sd[cj];
+    double a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = L.ri(q);
+        const double di = sd[i];
+        a[q] = (i == cj) ? 1.0 : bq[q] * di * dj;
+        hq[q] *= di * dj;
+        const double dv = (i == cj) ? 0.0 : a[q];
+        dsum += dv * dv;
+        sBh[i + cj * RS_LD] = a[q];
+        sH[i + cj * RS_LD] = hq[q];
+        sV[i + cj * RS_LD] = a[q];
+        sZ[i + cj * RS_LD] = (i == cj && i >= p) ? 1.0 : 0.0;   // L (identity in the padding)
+    }
+    z1 = z2 = zm = zm2 = 0.0;
+    rs_reduce(dsum, z1, z2, zm, zm2, red);   // (its barriers also order the stores above)
+    const double delta = sqrt(dsum);
+    int fail = (badv != 0.0 || !(delta < 1.0e300)) ? 1 : 0;
+    double minpiv = 1.0;
+    int oa_its = 0;
+    double last_numax = -1.0;
+    double lamv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!fail) {
+        // ---- Bh = L L' (right-looking, every thread keeps its entries in registers; the trailing matrix alternates between
+        //      two buffers - step k reads the state step k - 1 wrote and writes its own update to the other one: one barrier per
+        //      column).  The pivots of the unit-diagonal Bh are the squared distances of each column from the span of the ones
+        //      before it (wanted columns first: Gram-Schmidt order).  L only has to be good enough to START the refinement
+        //      below, which works in the metric Bh itself and removes what is left of the non-orthogonality: pivots down to
+        //      1e-4 are accepted (CholeskyQR proper needs a second pass below 0.25). ----
+        for (int k = 0; k < p; ++k) {
+            const double* cur = (k & 1) ? sY : sV;
+            double* nxt = (k & 1) ? sV : sY;
+            const double akk = cur[k + k * RS_LD];
+            if (!(akk >= 1e-4)) {   // (the same value in every thread)
+                fail = 1;
+                break;
+            }
+            minpiv = akk < minpiv ? akk : minpiv;
+            double r = __builtin_amdgcn_rsq(akk);
+            r = r * (1.5 - 0.5 * akk * r * r);
+            r = r * (1.5 - 0.5 * akk * r * r);
+            const double ljk = cur[cj + k * RS_LD] * r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = L.ri(q);
+                if (i >= cj && cin && i < p) {
+                    if (cj == k) sZ[i + cj * RS_LD] = a[q] * r;
+                    else if (cj > k) {
+                        a[q] -= (cur[i + k * RS_LD] * r) * ljk;
+                        nxt[i + cj * RS_LD] = a[q];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!fail) {
+        // ---- T = L^-1 by Newton's iteration X <- X (2 I - L X) from X = diag(L)^-1: I - L X is strictly lower triangular,
+        //      hence nilpotent, and squares in every step - exact after ceil(log2 p) steps ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = L.ri(q);
+            sT[i + cj * RS_LD] = (i == cj) ? 1.0 / sZ[i + i * RS_LD] : 0.0;
+        }
+        __syncthreads();
+        int nst = 0;
+        while ((1 << nst) < p) ++nst;
+        for (int st = 0; st < nst; ++st) {
+            const sm_d4 m = rs_mfma<false, false>(sZ, sT, L, nk);   // L X
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sU[L.ri(q) + cj * RS_LD] = ((L.ri(q) == cj) ? 2.0 : 0.0) - m[q];
+            __syncthreads();
+            const sm_d4 xn = rs_mfma<false, false>(sT, sU, L, nk);  // X (2 I - L X)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sT[L.ri(q) + cj * RS_LD] = (L.ri(q) >= cj) ? xn[q] : 0.0;
+            __syncthreads();
+        }
+        // ---- C = T' to start with (C' Bh C = I up to the rounding of the factorisation, ~eps cond(Bh)); ||Hh||_F ----
+        double hn2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sV[L.ri(q) + cj * RS_LD] = sT[cj + L.ri(q) * RS_LD];
+            hn2 += hq[q] * hq[q];
+            if (L.ri(q) == cj) slam[cj] = hq[q];   // (a first scale for lambda; replaced in the first step)
+        }
+        z1 = z2 = zm = zm2 = 0.0;
+        rs_reduce(hn2, z1, z2, zm, zm2, red);   // (also orders the writes of sV, slam)
+        const double hn = sqrt(hn2);
+        if (!(hn > 0.0) || !(hn < 1.0e300)) fail = 1;
+        if (!fail) {
+            // ---- refinement of Ogita & Aishima for the pencil (Hh, Bh): R = I - C'Bh C, S = C'Hh C, lambda_i = S_ii / (1 - R_ii),
+            //      E_ij = (S_ij + lambda_j R_ij) / (lambda_j - lambda_i), C <- C (I + E) ----
+            // Convergence is judged on what matters downstream, the Ritz residuals: max |S_ij + lambda_j R_ij| over every pair
+            // that is not a pad-pad pair <= 1e-14 lambda_max, and max |R_ij| <= 1e-14 - both a small multiple of their rounding
+            // floor p eps.  Pairs closer than delta_c = 2 (||S - diag||_F + ||Hh||_F ||R||_F), i.e. closer than their own
+            // coupling, are only orthonormalised (E_ij = R_ij / 2): a true multiple Ritz value converges that way, a
+            // near-degenerate pair with coupling does not and ends the attempt (status 2: the Jacobi solver rotates those).
+            // Pad columns (index >= nt) are never rotated among themselves - see the Gershgorin test at the end.
+            bool conv = false;
+            double sq[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
+            double numax_prev = 1.0e300;
+            for (int it = 0; it < 8; ++it) {
+                oa_its = it + 1;
+                const sm_d4 bc = rs_mfma<false, false>(sBh, sV, L, nk);
+                const sm_d4 hc = rs_mfma<false, false>(sH, sV, L, nk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sY[L.ri(q) + cj * RS_LD] = bc[q];
+                    sW[L.ri(q) + cj * RS_LD] = hc[q];
+                }
+                __syncthreads();
+                const sm_d4 gm = rs_mfma<true, false>(sV, sY, L, nk);   // C' Bh C
+                const sm_d4 sm = rs_mfma<true, false>(sV, sW, L, nk);   // C' Hh C
+                double off2 = 0.0, rn2 = 0.0, lmx = 0.0, rmx = 0.0, numax = 0.0;
+                const double ljp = slam[cj];
+                double lnew[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {   // (the products only run over k < 4 nk: nothing is known about the padding)
+                    const int i = L.ri(q);
+                    const bool in = cin && i < p;
+                    sq[q] = in ? sm[q] : 0.0;
+                    rq[q] = in ? ((i == cj) ? 1.0 : 0.0) - gm[q] : 0.0;
+                    lnew[q] = 0.0;
+                    if (i == cj) {
+                        lnew[q] = sq[q] / (1.0 - rq[q]);
+                        if (in) lmx = fabs(lnew[q]);
+                    } else {
+                        off2 += sq[q] * sq[q];
+                        if (in && !(i >= nt && cj >= nt)) numax = fmax(numax, fabs(sq[q] + ljp * rq[q]));
+                    }
+                    rn2 += rq[q] * rq[q];
+                    rmx = fmax(rmx, fabs(rq[q]));
+                }
+                rs_reduce(off2, rn2, lmx, rmx, numax, red);   // (its first barrier also separates the reads of slam above ...
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (L.ri(q) == cj) slam[cj] = lnew[q];   //  ... from this write; the barrier below orders it)
+                last_numax = numax;
+                if (!(numax < 1.0e300) || !(lmx < 1.0e300) || !(rmx < 1.0e300)) {
+                    fail = 2;
+                    break;
+                }
+                if (it >= 1 && numax <= 1e-14 * lmx && rmx <= 1e-14) {   // (step 0 measures with a provisional lambda)
+                    conv = true;
+                    break;
+                }
+                // no progress worth the name after the first corrections: a near-degenerate pair with coupling
+                if (it >= 2 && numax > 0.1 * numax_prev && rmx <= 1e-10) {
+                    fail = 2;
+                    break;
+                }
+                numax_prev = numax;
+                __syncthreads();
+                const double dc = 2.0 * (sqrt(off2) + hn * sqrt(rn2));
+                const double lj = slam[cj];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = L.ri(q);
+                    double e;
+                    if (i == cj || !cin || i >= p || (i >= nt && cj >= nt)) e = 0.5 * rq[q];
+                    else {
+                        const double gap = lj - slam[i];
+                        e = fabs(gap) > dc ? (sq[q] + lj * rq[q]) / gap : 0.5 * rq[q];
+                    }
+                    sU[i + cj * RS_LD] = e;
+                }
+                __syncthreads();
+                const sm_d4 ve = rs_mfma<false, false>(sV, sU, L, nk);
+                double vn[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vn[q] = sV[L.ri(q) + cj * RS_LD] + ve[q];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sV[L.ri(q) + cj * RS_LD] = vn[q];
+                __syncthreads();
+            }
+            if (!fail && !conv) fail = 2;   // no convergence: Jacobi decides
+            if (!fail && nt < p) {
+                // The pad block of C'Hh C is left as it is: the pad columns are orthonormal and decoupled from the wanted ones,
+                // their Rayleigh quotients stand in for Ritz values.  That is all the subspace iteration needs from them AS LONG
+                // AS none of them is about to be counted: every eigenvalue of the pad block lies below its largest Gershgorin
+                // disc edge, which has to stay clear of the threshold tau^2 - otherwise (the rank is growing) status 3.
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sU[L.ri(q) + cj * RS_LD] = fabs(sq[q]);
+                __syncthreads();
+                double gmx = 0.0;
+                if (tid >= nt && tid < p) {
+                    double g = 0.0;
+                    for (int c = nt; c < p; ++c) g += sU[tid + c * RS_LD];
+                    gmx = g;
+                }
+                double z0 = 0.0, za = 0.0, zb = 0.0, zc = 0.0;
+                rs_reduce(z0, za, gmx, zb, zc, red);
+                if (!(gmx < tau2 * (1.0 - 1e-6))) fail = 3;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (L.ri(q) == cj) lamv[q] = slam[cj];
+        }
+    }
+    if (fail == 1) {
+        // C = D: the normalised columns of Y - the same span for the fall-back step
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = L.ri(q);
+            if (cin && i < p) Cout[i + (size_t)cj * p] = (i == cj) ? (sd[i] > 0.0 ? sd[i] : 1.0) : 0.0;
+            if (cin && i == cj) lam_out[i] = 0.0;
+        }
+    } else {
+        // the rotation for the unscaled columns: D C  (status 2 / 3: the last iterate - still a basis of the same span)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = L.ri(q);
+            if (cin && i < p) Cout[i + (size_t)cj * p] = sd[i] * sV[i + cj * RS_LD];
+            if (cin && i == cj) lam_out[i] = lamv[q];
+        }
+    }
+    if (tid == 0) {
+        status[0] = sqrt(minpiv);
+        status[1] = (double)fail;
+        status[2] = delta;
+        status[3] = (double)oa_its;
+        status[4] = last_numax;
+    }
+}
+
+// B = Y'Y and Hg = Y'(GY) (p x p each, ld p) for N x p panels: one wave per entry of each
+__global__ __launch_bounds__(256) void k_panel_tn2x(const double* __restrict__ Y, const double* __restrict__ GY,
+                                                    double* __restrict__ Bm, double* __restrict__ Hm, int N, int p) {
+    const int lane = threadIdx.x & 63;
+    int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= 2 * p * p) return;
+    const bool second = e >= p * p;
+    if (second) e -= p * p;
+    const int i = e % p, j = e / p;
+    const double* a = Y + (size_t)i * N;
+    const double* b = (second ? GY : Y) + (size_t)j * N;
+    double s = 0.0;
+    for (int r = lane; r < N; r += 64) s += a[r] * b[r];
+    s = ss_wsum(s);
+    if (lane == 0) (second ? Hm : Bm)[i + (size_t)j * p] = s;
+}
+
+int launch_rr_small(Handle* h, const double* Y, const double* GY, double* Bm, double* Hm, double* Cout, double* lam,
+                    double* status, int64_t N, int64_t p, int64_t nt, double tau2) {
+    if (p < 1 || p > RS_P) return set_err(h, TLSQ_ERR_ARG, "rr_small: p = %lld (1 .. %d)", (long long)p, RS_P);
+    hipLaunchKernelGGL(k_panel_tn2x, dim3((unsigned)((2 * p * p + 3) / 4)), dim3(256), 0, h->stream, Y, GY, Bm, Hm, (int)N, (int)p);
+    hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(256), 0, h->stream, (const double*)Bm, (const double*)Hm, (int)p, Cout, lam,
+                       status, (int)nt, tau2);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+// the p x p stage alone (tests): C, lambda, status from given B, Hg
+int launch_rr_small_only(Handle* h, const double* Bm, const double* Hm, double* Cout, double* lam, double* status, int64_t p,
+                         int64_t nt, double tau2) {
+    if (p < 1 || p > RS_P) return set_err(h, TLSQ_ERR_ARG, "rr_small: p = %lld (1 .. %d)", (long long)p, RS_P);
+    hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(256), 0, h->stream, Bm, Hm, (int)p, Cout, lam, status, (int)nt, tau2);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 // Rayleigh-Ritz finish in one launch, one workgroup per Ritz vector c:  x = Q S[:,c],  gx = GQ S[:,c],
 // theta_c = x . gx,  res_c = ||gx - theta_c x||  (k_panel_rot2 + k_rayleigh + k_ritz_resid for small panels)
 __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ Q, const double* __restrict__ GQ,
