@@ -670,6 +670,201 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
 }
 
+// ---- register-resident block pair (no eigenvector accumulation, 64 <= N <= 1024): the accurate route's Jacobi ---------------
+// k_jacobi_round keeps its 2b columns in LDS and gives every column pair to one wave: a rotation is a chain of LDS round
+// trips (load both columns, dot product, wave reduction, parameters, rotate, store: ~3 us), and the full 2b-player
+// tournament of every visit rotates the pairs INSIDE a block again and again (961 pair rounds per sweep at N = 512 where
+// 511 cover all pairs): 36 ms for the 12 sweeps a flat bulk of singular values needs.  Here the 32 columns of the block
+// pair live in REGISTERS - lane = row (NW waves cover the rows), c[0..15] = block p, c[16..31] = block q - so a rotation is
+// four FMAs per lane on registers; what crosses lanes is only the 16 dot products of a round (one 16-value butterfly per
+// wave, partial sums through LDS, one barrier per round) and the 16 rotation parameters, which every wave works out for
+// itself (same numbers, same bits).  The schedule keeps the pairs where they are and rotates the DATA through fixed
+// register positions, so one compiled round serves all of them:
+//   cross rounds: pairs (c[i], c[16 + i]); after each round block q's registers rotate by one - 16 rounds, all 256 cross pairs;
+//   intra rounds (only in outer round 0 of a sweep, where every block takes part exactly once): pairs (c[k], c[15 - k]) and
+//     (c[16 + k], c[31 - k]); positions 1..15 of each block rotate, position 0 stays - 15 rounds (the circle method).
+// Both rotations are cyclic and complete, so the registers are back in column order when the schedule ends.
+// 31 x 16 + 15 = 511 pair rounds per sweep, ~0.6 us each.
+template <int NW>
+struct JrShared {
+    double part[2][NW][16];   // per-wave partial dot products of the 16 pairs (double-buffered by round parity)
+    double nrm[NW][32];       // squared column norms by column position, each wave's own copy (set-up, schedule change)
+    double npart[NW][32];
+};
+
+// totals of v[0..15] over the wave: lanes 4 I .. 4 I + 3 end up with the total of value I (17 exchanges instead of 96)
+__device__ __forceinline__ double jr_reduce16(double (&v)[16], int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool up = (lane & 32) != 0;
+        const double send = up ? v[k] : v[k + 8], keep = up ? v[k + 8] : v[k];
+        v[k] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool up = (lane & 16) != 0;
+        const double send = up ? v[k] : v[k + 4], keep = up ? v[k + 4] : v[k];
+        v[k] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bool up = (lane & 8) != 0;
+        const double send = up ? v[k] : v[k + 2], keep = up ? v[k + 2] : v[k];
+        v[k] = keep + __shfl_xor(send, 8, 64);
+    }
+    {
+        const bool up = (lane & 4) != 0;
+        const double send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+        v[0] = keep + __shfl_xor(send, 4, 64);
+    }
+    v[0] += dpp_perm<0x4E>(v[0]);   // quad_perm [2,3,0,1]
+    v[0] += dpp_perm<0xB1>(v[0]);   // quad_perm [1,0,3,2]
+    return v[0];
+}
+
+// one round: rotate the 16 pairs (c[P1(k)], c[P2(k)]) given by the position maps of the schedule.  a, bb: squared norms of
+// the two members of "this lane's" pair I = lane >> 2 (the same numbers in the four lanes of a group and in every wave).
+template <int NW, bool CROSS>
+__device__ __forceinline__ void jr_round(double (&c)[32], JrShared<NW>& sh, int w, int lane, int par, double tol2, double floor2,
+                                         double& a, double& bb, unsigned int& my_rot) {
+    // position of the two members of pair k
+    auto p1 = [](int k) { return CROSS ? k : (k < 8 ? k : 16 + (k - 8)); };
+    auto p2 = [](int k) { return CROSS ? 16 + k : (k < 8 ? 15 - k : 31 - (k - 8)); };
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = c[p1(k)] * c[p2(k)];
+    const double tot = jr_reduce16(v, lane);
+    const int I = lane >> 2;   // lanes 4 I .. 4 I + 3 hold the wave's partial of pair I:  I = b5 8 + b4 4 + b3 2 + b2
+    if ((lane & 3) == 0) sh.part[par][w][I] = tot;
+    __syncthreads();
+    // every wave adds the partials in wave order and works out the rotation of "its lane's" pair: the same bits everywhere
+    double cc = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) cc += sh.part[par][ww][I];
+    const double mn = a < bb ? a : bb;
+    double cs = 1.0, sn = 0.0;
+    if (cc * cc > tol2 * a * bb && mn > floor2) {
+        const double d = bb - a;
+        const double t = (d >= 0.0 ? 2.0 : -2.0) * cc / (fabs(d) + sqrt(d * d + 4.0 * cc * cc));
+        cs = 1.0 / sqrt(1.0 + t * t);
+        sn = cs * t;
+        const double na = a - t * cc, nb = bb + t * cc;
+        a = na > 0.0 ? na : 0.0;
+        bb = nb > 0.0 ? nb : 0.0;
+        if (w == 0 && (lane & 3) == 0) ++my_rot;
+    }
+    // the parameters of pair k sit in lanes 4 k ..: v_readlane hands them to every lane as scalars (no LDS round trip)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double ck = read_lane(cs, 4 * k), sk = read_lane(sn, 4 * k);
+        const double x = c[p1(k)], y = c[p2(k)];
+        c[p1(k)] = ck * x - sk * y;
+        c[p2(k)] = sk * x + ck * y;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, int N, int nblk, int round, double tol,
+                                                        const double* __restrict__ params,
+                                                        unsigned int* __restrict__ rot_count) {
+    __shared__ JrShared<NW> sh;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = w * 64 + lane;
+    int bp, bq;
+    rr_pair(nblk, round, blockIdx.x, bp, bq);
+    if (bp > bq) {   // (keeps the lower block in c[0..15]: the order of the columns inside a pair is that of the LDS kernel)
+        const int t = bp;
+        bp = bq;
+        bq = t;
+    }
+    const double floor2 = params[0], tol2 = tol * tol;
+    double c[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
+        c[s] = (col < N && row < N) ? B[(size_t)col * N + row] : 0.0;
+    }
+    // squared column norms (32-value reduction as two butterflies), each wave keeps a full copy by column position
+    {
+        double v[16];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = c[16 * hlf + k] * c[16 * hlf + k];
+            const double tot = jr_reduce16(v, lane);
+            if ((lane & 3) == 0) sh.npart[w][16 * hlf + (lane >> 2)] = tot;
+        }
+        __syncthreads();
+        if (lane < 32) {
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) t += sh.npart[ww][lane];
+            sh.nrm[w][lane] = t;
+        }
+        __syncthreads();
+    }
+    unsigned int my_rot = 0;
+    int par = 0;
+    const int I = lane >> 2;
+    if (round == 0) {
+        // the pairs inside each of the two blocks: 15 rounds of the circle method, both blocks at once.  Lane group g of a
+        // block (g = I & 7; block = I >> 3) holds the norms of positions g and 15 - g.
+        const int g = I & 7, base = (I >> 3) * 16;
+        double a = sh.nrm[w][base + g], bb = sh.nrm[w][base + 15 - g];
+        for (int r = 0; r < 15; ++r) {
+            jr_round<NW, false>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            par ^= 1;
+            // positions 1..15 of each block move on by one (15 -> 1), position 0 stays; the norms move with them:
+            // a_g <- a_(g-1) (g >= 2), a_1 <- bb_0, a_0 stays;  bb_g <- bb_(g+1) (g <= 6), bb_7 <- a_7
+            const double a_prev = __shfl(a, (lane - 4) & 63, 64), bb_next = __shfl(bb, (lane + 4) & 63, 64);
+            const double bb_0 = __shfl(bb, lane & 32, 64), a_7 = __shfl(a, (lane & 32) + 28, 64);
+            a = (g == 0) ? a : (g == 1 ? bb_0 : a_prev);
+            bb = (g == 7) ? a_7 : bb_next;
+#pragma unroll
+            for (int hb = 0; hb < 32; hb += 16) {
+                const double last = c[hb + 15];
+#pragma unroll
+                for (int k = 15; k >= 2; --k) c[hb + k] = c[hb + k - 1];
+                c[hb + 1] = last;
+            }
+        }
+        // (15 rotations: every column is back in its position) - the norms go back to the position table
+        if ((lane & 3) == 0) {
+            sh.nrm[w][base + g] = a;
+            sh.nrm[w][base + 15 - g] = bb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    {
+        double a = sh.nrm[w][I], bb = sh.nrm[w][16 + I];
+        for (int r = 0; r < 16; ++r) {
+            jr_round<NW, true>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            par ^= 1;
+            // block q's registers move on by one (position 16 + i takes what 16 + i + 1 held): pair i meets q's next column
+            bb = __shfl(bb, (lane + 4) & 63, 64);
+            const double first = c[16];
+#pragma unroll
+            for (int k = 16; k < 31; ++k) c[k] = c[k + 1];
+            c[31] = first;
+        }
+    }
+    // (16 cross rotations and 15 intra rotations are full cycles: the registers are in column order again)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
+        if (col < N && row < N) B[(size_t)col * N + row] = c[s];
+    }
+    if (w == 0) {
+        // lanes 4 I of wave 0 counted the rotations of "their" pairs
+        unsigned int t = my_rot;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0 && t) atomicAdd(rot_count, t);
+    }
+}
+
 // B = G (ld -> N), V = I
 __global__ __launch_bounds__(256) void k_jacobi_init(const double* __restrict__ G, int64_t ldG,
                                                      double* __restrict__ B, double* __restrict__ V,
@@ -955,6 +1150,40 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
         hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params,
                            floor_rel * floor_rel);
         TLSQ_HIP(h, hipGetLastError());
+        const double tol_r = std::max(2.0 * eps * sqrt((double)N), 4.0 * eps);
+        if (N >= 64 && N <= 1024 && !dev_is(DEV_NO_JACOBI_REG, '1')) {
+            // register-resident block pairs (k_jacobi_reg): blocks of 16 columns, nblk - 1 launches per sweep
+            int nblk = (int)((N + 15) / 16);
+            if (nblk & 1) ++nblk;
+            const int max_sweeps = 40;
+            converged = false;
+            for (; sweep < max_sweeps; ++sweep) {
+                TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+                for (int r = 0; r < nblk - 1; ++r) {
+                    if (N <= 512)
+                        hipLaunchKernelGGL(k_jacobi_reg<8>, dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                           (const double*)params, rot);
+                    else
+                        hipLaunchKernelGGL(k_jacobi_reg<16>, dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                           (const double*)params, rot);
+                }
+                TLSQ_HIP(h, hipGetLastError());
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                unsigned int nrot;
+                memcpy(&nrot, h->pinned, 4);
+                if (nrot == 0) {
+                    ++sweep;
+                    converged = true;
+                    break;
+                }
+            }
+            if (sweeps_out) *sweeps_out = sweep;
+            TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
+            if (!converged)
+                return set_err(h, TLSQ_ERR_NOCONV, "one-sided Jacobi did not converge in 40 sweeps (N=%lld)", (long long)N);
+            return TLSQ_OK;
+        }
         bool single = false;
         int b = pick_block(N, false, &single);
         if (!single && b > 16) b = 16;
