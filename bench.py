@@ -4,28 +4,40 @@
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one complete rpca solve (the reference's hot loop, /root/reference/src/robustPCA.jl:156-239,
-run to its own convergence test) on a synthetic rank-16 + 5%-sparse D that is already resident in HBM;
-outputs A, E stay in HBM.  value = ALM iterations completed in the K timed steps / wall time (max over
-ranks).  N>1 row-shards the SAME 20000x512 problem (strong scaling) and exchanges the N x N Gram matrices
-with RCCL inside libtlsqhip.so.
+A "step" is one complete rpca solve (the reference's hot loop, /root/reference/src/robustPCA.jl:156-239, run to its own
+convergence test) on a synthetic rank-16 + 5%-sparse D that is already resident in HBM; outputs A, E stay in HBM.
+value = ALM iterations completed in the K timed steps / wall time (max over ranks).  N>1 row-shards the SAME 20000x512
+problem (strong scaling) and exchanges the N x N Gram matrices with RCCL inside libtlsqhip.so.
 
-Extra objects on the JSON line:
-  roofline      ALM sweeps (HBM-bound): the bytes the shipped fused form has to move (8 passes over M*N*8 per
-                iteration, 7 for panels of 2^26+ elements, + 5 for the lone shrink at k=1; SURVEY.md §8d's unfused figure is 11 and is reported
-                beside it) divided by the sweeps' device time measured with HIP events on the library's
-                stream inside the timed solves (tlsq_rpca_info.ms_shrink + ms_update).
-  cpu_baseline  the oracle (oracle/rpca_oracle.py: LAPACK gesdd + fused OpenMP sweeps) timed on this box's
-                host cores on a bounded sample of the same workload (rank 0, N=1 only).
+Beside `value` (all outside the timed region):
+  value_with_s          the same solve with the returned decomposition s = (U, S, Vt) of the last Z requested as well
+                        (`A, E, s, sv = rpca(D)` of the reference returns it, src/robustPCA.jl:238; `value` does not ask for it)
+  value_host_pointers   the same solve through HOST pointers (what a Julia `Array` call pays: H2D of D, D2H of A, E), no s
+  roofline              the fused ALM sweep against the 8 TB/s HBM peak: algorithmic bytes / device time of the sweep kernels
+                        (HIP events on the library's stream inside the timed solves)
+  roofline_mfma         the Gram kernel against the fp64 MFMA peak
+  cpu_baseline          the oracle (LAPACK gesdd + fused OpenMP sweeps) on this box's host cores, bounded sample (N=1 only)
+  extra.c4              BASELINE config 4 (200000x512, the shape of the >= 6x @ 8 GPUs target) on the GPUs of this run
+  validation            every run checks itself: iterations, rank trajectory, sv and the norms of A and E (summed over the
+                        shards) against values committed from a one-GPU run (tests/golden/bench_reference.json); the ranks
+                        must agree among themselves; rccl_ranks = size of the communicator as RCCL reports it.  Any
+                        disagreement, or a run that exceeds --timeout seconds (a hung collective), ends with a non-zero exit.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+REF_PATH = os.path.join(ROOT, "tests", "golden", "bench_reference.json")
+
+
+def svp_hash(hist):
+    return hashlib.sha256(",".join(str(int(v)) for v in hist).encode()).hexdigest()[:16]
 
 
 def main():
@@ -38,7 +50,20 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--cpu-iters", type=int, default=24, help="ALM iterations of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-c4", action="store_true", help="skip the extra 200000x512 row-sharded measurement (extra.c4)")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_with_s / value_host_pointers")
+    ap.add_argument("--timeout", type=float, default=900.0, help="seconds after which the run is declared hung (exit 3)")
+    ap.add_argument("--write-reference", metavar="PATH", default=None,
+                    help="(one GPU) write the validation values of this run to PATH (committed as tests/golden/bench_reference.json)")
     args = ap.parse_args()
+
+    # a collective that never completes must not hang the driver: the watchdog ends the process (no re-exec, no retry here)
+    def hung():
+        sys.stderr.write(f"bench.py: no result after {args.timeout:.0f} s - a collective or a kernel hangs; giving up\n")
+        sys.stderr.flush()
+        os._exit(3)
+    dog = threading.Timer(args.timeout, hung)
+    dog.daemon = True
+    dog.start()
 
     import numpy as np
     import torch  # first: torch brings its own HIP runtime (see tests/test_gpu_parity.py)
@@ -46,16 +71,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ          # under torch.distributed.run (also with one process)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")
-    if world > 1:
+    use_dist = launched
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import tlsq_amd
@@ -63,6 +90,7 @@ def main():
     from oracle import rpca_oracle as O   # cpu_baseline + input generator only
 
     M, N, r = args.rows, args.cols, args.rank
+    headline = (M, N, r) == (20000, 512, 16)
     D, A0, S0 = O.synth_lowrank_sparse(M, N, r, seed=0)
     lo, hi = tdist.row_partition(M, world, rank)
     Dl = np.ascontiguousarray(D[lo:hi].T)                 # (N, Ml) C-order == (Ml, N) column-major
@@ -72,18 +100,37 @@ def main():
     dE = torch.empty_like(dD)
 
     eng = tlsq_amd.Engine(local_rank)
-    tdist.init_engine_comm(eng, rank, world)
+    if launched and world == 1:
+        # one process under the launcher: a one-rank RCCL communicator, so that a one-GPU box runs the code of an N-GPU run
+        tlsq_amd.dev_set("FORCE_COMM", 1)
+    tdist.init_engine_comm(eng, rank, world, force=launched)
+    rccl_ranks = eng.comm_size()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def solve():
-        # like a non-verbose reference call: no per-iteration cost history requested
-        return eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False)
+    def allmax(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
+    def allsum(vals):
+        if not use_dist:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def solve(**kw):
+        # like a non-verbose reference call: no per-iteration cost history requested
+        return eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False, **kw)
+
+    # ---- the timed region: W warm-up solves, then exactly K solves between two barriers --------------------------------
     for _ in range(args.warmup):
         solve()
     barrier()
@@ -103,18 +150,31 @@ def main():
             ms[k] = ms.get(k, 0.0) + v
         last = (sv, rep, st)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = allmax(time.perf_counter() - t0)
+    sv, rep, st = last
+
+    # ---- validation of the timed work (outside the timing) ----------------------------------------------------------------
+    problems = []
+    A = dA.cpu().numpy().T
+    E = dE.cpu().numpy().T
+    resid = float(np.linalg.norm(D[lo:hi] - (A + E)) / np.linalg.norm(D[lo:hi]))
+    rel_a = float(np.linalg.norm(A - A0[lo:hi]) / np.linalg.norm(A0[lo:hi]))
+    _, rep_h, _ = eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=True)   # rank trajectory
+    na2, ne2 = allsum([float(np.sum(A * A)), float(np.sum(E * E))])
+    mine = {"iters": rep.iters_done, "sv": int(sv), "svp_hash": svp_hash(rep_h.svp_hist), "converged": bool(rep.converged)}
+    if use_dist:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if any(e != everyone[0] for e in everyone):
+            problems.append(f"the ranks disagree: {everyone}")
+    check = {"c2": dict(mine, normA2=na2, normE2=ne2)}
 
     # ---- extra.c4: BASELINE config 4 (rpca 200000 x 512 fp64, row-sharded over the N GPUs of this run) -------------
     # The >= 6x @ 8 GPUs target of the north star is quoted on THIS shape, so every --gpus N run also times it (after
     # the headline measurement, outside its timed region).  The matrix is defined by 8 row blocks of 25000 rows with
     # their own seeds, so N = 1, 2, 4, 8 all solve the same problem and every rank only generates its own rows.
     c4 = None
-    if not args.no_c4 and args.rows == 20000 and args.cols == 512:
+    if not args.no_c4 and headline:
         M4, N4, r4, nb = 200000, 512, 16, 8
         rb = M4 // nb
         lo4, hi4 = tdist.row_partition(M4, world, rank)
@@ -129,68 +189,107 @@ def main():
         M4l = hi4 - lo4
         d4 = torch.from_numpy(D4).cuda()
         a4, e4 = torch.empty_like(d4), torch.empty_like(d4)
-        run4 = lambda: eng.rpca_device(d4.data_ptr(), M4l, N4, a4.data_ptr(), e4.data_ptr(), m_global=M4, want_hist=False)
-        run4()                                   # warm-up (workspace growth)
+        run4 = lambda **kw: eng.rpca_device(d4.data_ptr(), M4l, N4, a4.data_ptr(), e4.data_ptr(), m_global=M4, **kw)
+        run4(want_hist=False)                                   # warm-up (workspace growth)
         barrier()
         t4 = time.perf_counter()
         n4 = 0
         for _ in range(2):
-            sv4, rep4, st4 = run4()
+            sv4, rep4, st4 = run4(want_hist=False)
             n4 += rep4.iters_done
         barrier()
-        t4 = time.perf_counter() - t4
-        if world > 1:
-            tt = torch.tensor([t4], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t4 = float(tt.item())
+        t4 = allmax(time.perf_counter() - t4)
+        _, rep4p, _ = run4(want_hist=False, phase_timing=True)      # all six phases bracketed (the Amdahl term per N)
+        _, rep4h, _ = run4(want_hist=True)
+        n4a, n4e = allsum([float((a4 * a4).sum().item()), float((e4 * e4).sum().item())])
         c4 = {"workload": "rpca 200000x512 fp64 rank-16 + 5% sparse, row-sharded, reference defaults, to convergence",
               "value": n4 / t4, "unit": "iters/s", "n_gpus": world, "rows_per_gpu": M4l, "solves": 2,
               "ms_per_solve": t4 / 2 * 1e3, "iters_per_solve": rep4.iters_done, "sv": sv4, "converged": rep4.converged,
-              "phases_ms_per_iter": {k: v / rep4.iters_done for k, v in rep4.ms.items()
-                                     if k in ("shrink", "update")}}
+              "phases_ms_per_iter": {k: v / rep4p.iters_done for k, v in rep4p.ms.items()
+                                     if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")},
+              "phases_note": "eig = the replicated N x N solve (does not shrink with the number of GPUs); everything else is sharded"}
+        check["c4"] = {"iters": rep4.iters_done, "sv": int(sv4), "svp_hash": svp_hash(rep4h.svp_hist),
+                       "converged": bool(rep4.converged), "normA2": n4a, "normE2": n4e}
         del d4, a4, e4, D4
+
+    # compare with the values a one-GPU run committed (same problems, same seeds)
+    validation = {"rccl_ranks": rccl_ranks, "reference": None, "ok": True}
+    if args.write_reference:
+        if world != 1:
+            raise SystemExit("--write-reference wants a one-GPU run")
+        if rank == 0:
+            with open(args.write_reference, "w") as f:
+                json.dump(check, f, indent=1, sort_keys=True)
+                f.write("\n")
+    elif headline and os.path.exists(REF_PATH):
+        with open(REF_PATH) as f:
+            ref = json.load(f)
+        validation["reference"] = os.path.relpath(REF_PATH, ROOT)
+        for cfg, got in check.items():
+            want = ref.get(cfg)
+            if not want:
+                continue
+            for key in ("iters", "sv", "svp_hash", "converged"):
+                if got[key] != want[key]:
+                    problems.append(f"{cfg}.{key}: {got[key]} (reference {want[key]})")
+            for key in ("normA2", "normE2"):
+                if not abs(got[key] - want[key]) <= 1e-8 * abs(want[key]):
+                    problems.append(f"{cfg}.{key}: {got[key]!r} (reference {want[key]!r})")
+    if rccl_ranks != world and launched:
+        problems.append(f"the communicator has {rccl_ranks} ranks, the run {world}")
+    validation["ok"] = not problems
+    validation["problems"] = problems
+    validation["checked"] = check
+
+    # ---- the same solve with the returned decomposition, and through host pointers (outside the timed region) -------------
+    extras = {}
+    if not args.no_extras and world == 1:
+        d = min(M, N)
+        dU = torch.empty((d, Ml), dtype=torch.float64, device="cuda")
+        dS = torch.empty(d, dtype=torch.float64, device="cuda")
+        dVt = torch.empty((N, d), dtype=torch.float64, device="cuda")
+        with_s = lambda: solve(dU=dU.data_ptr(), dS=dS.data_ptr(), dVt=dVt.data_ptr())
+        with_s()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        ns = 0
+        for _ in range(3):
+            _, rs, _ = with_s()
+            ns += rs.iters_done
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - ts
+        extras["value_with_s"] = ns / ts
+        extras["ms_per_solve_with_s"] = ts / 3 * 1e3
+        Df = np.asfortranarray(D)
+        eng.rpca(Df, want_s=False, cost_history=False)
+        th = time.perf_counter()
+        nh = 0
+        for _ in range(3):
+            _, _, _, _, rh = eng.rpca(Df, want_s=False, cost_history=False, return_report=True)
+            nh += rh.iters_done
+        th = time.perf_counter() - th
+        extras["value_host_pointers"] = nh / th
+        extras["ms_per_solve_host_pointers"] = th / 3 * 1e3
+        extras["host_pointers_note"] = ("pageable numpy arrays: H2D of D, D2H of A and E (246 MB per solve) and the "
+                                        "host-side copies of the ctypes binding are inside the time")
+        del dU, dS, dVt
 
     # one more solve, outside the timed region, with every phase of the iteration bracketed by HIP events: the source of
     # phases_ms_per_iter and of the Gram roofline (the timed solves only bracket the sweep kernels - each recorded
     # event costs ~6 us between two kernels, tlsq_rpca_opts.phase_timing)
-    _, rep_ph, _ = eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False,
-                                   phase_timing=True)
+    _, rep_ph, _ = solve(phase_timing=True)
     barrier()
     ms_ph = dict(rep_ph.ms)
-
-    sv, rep, st = last
-    # sanity of the timed work (not part of the timing): residual and recovery on this rank's shard
-    A = dA.cpu().numpy().T
-    E = dE.cpu().numpy().T
-    resid = float(np.linalg.norm(D[lo:hi] - (A + E)) / np.linalg.norm(D[lo:hi]))
-    rel_a = float(np.linalg.norm(A - A0[lo:hi]) / np.linalg.norm(A0[lo:hi]))
 
     if rank == 0:
         value = iters_total / dt
         sweep_ms_per_iter = (ms["shrink"] + ms["update"]) / iters_total
-        # Bytes the sweeps have to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11
-        # passes per iteration); the shipped path fuses K2(k) with K1(k+1) (R4/W4 = 8 passes) and runs one plain
-        # K1 at k = 1 - folded together with the set-up's Y = D / dual_norm: R D / W Y,E,Z = 4 passes (k_first_shrink) - so
-        # the roofline is priced against the bytes of THAT form - the smaller figure.
-        fused = os.environ.get("TLSQ_NO_FUSED_SWEEP", "0") != "1"
-        # large panels (>= 2^26 elements): the rebuild A = T Vs' is folded in as well (A stays in registers):
-        # R D,E,Y / W R,Y,E',Z' = 7 passes
-        fused_rebuild = (fused and os.environ.get("TLSQ_NO_FUSED_REBUILD", "0") != "1" and Ml % 2 == 0 and
-                         (Ml * N >= 1 << 26 or os.environ.get("TLSQ_FUSED_REBUILD", "0") == "1"))
+        # Bytes the sweeps have to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11 passes per
+        # iteration); the shipped loop is the E-free sweep (k_zsweep: A from its factors in registers, E never stored while
+        # the loop runs): R D,Y,Z / W R,Y',Z' = 6 passes, 5 when the residual store is skipped, and k_first_shrink at k = 1:
+        # R D / W Y,Z = 3 passes.  (The returned E is formed once after the loop, outside the two timed phases.)
         array_bytes = float(Ml) * N * 8
-        sweep_passes = 7.0 if fused_rebuild else 8.0
-        # the shipped default: the E-free sweep (k_zsweep) - A from its factors in registers, E never stored while the loop
-        # runs: R D,Y,Z / W R,Y',Z' = 6 passes (5 without the residual store); k_first_shrink R D / W Y,Z = 3 passes.
-        # (The returned E is formed once after the loop, outside the two timed phases: not counted here.)
-        zsweep = fused and os.environ.get("TLSQ_NO_ZSWEEP", "0") != "1" and os.environ.get("TLSQ_NO_FIRST_SHRINK", "0") != "1"
-        if zsweep:
-            alg_bytes = (3.0 * args.steps + 6.0 * iters_total - rskip_total) / iters_total * array_bytes
-        elif fused:
-            # sweeps that were told not to store the residual panel moved one pass less
-            first_passes = 5.0 if os.environ.get("TLSQ_NO_FIRST_SHRINK", "0") == "1" else 4.0
-            alg_bytes = (first_passes * args.steps + sweep_passes * iters_total - rskip_total) / iters_total * array_bytes
-        else:
-            alg_bytes = 11.0 * array_bytes
+        alg_bytes = (3.0 * args.steps + 6.0 * iters_total - rskip_total) / iters_total * array_bytes
         achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
         out = {
             "metric": "rpca ALM iters/sec on 20000x512 fp64 D",
@@ -202,12 +301,20 @@ def main():
                        "rows_per_gpu": Ml, "iters_per_solve": rep.iters_done, "sv": sv,
                        "converged": rep.converged, "residual": resid, "rel_err_A": rel_a,
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                       "call": "plain (non-verbose) call: no per-iteration cost history is requested, so opnorm(residual) is "
-                               "only resolved far enough to settle cost < tol; identical iterations and outputs "
+                       "call": "A, E, sv of a plain (non-verbose) call on device-resident panels.  `value` does NOT include the "
+                               "returned decomposition s = (U, S, Vt) of the last Z (value_with_s does) nor PCIe transfers "
+                               "(value_host_pointers does); no per-iteration cost history is requested, so opnorm(residual) is "
+                               "only resolved far enough to settle cost < tol - identical iterations and outputs "
                                "(tests/test_gpu_parity.py::test_rpca_device_mode_and_decision_only_cost)"},
-            "roofline": {"kernel": "k_zsweep (E-free fused rebuild + ALM sweep) + k_first_shrink at k=1" if zsweep else
-                                   ("k_rebuild_update_shrink (fused rebuild + ALM sweep) + k_first_shrink at k=1" if fused_rebuild else "k_update_shrink (fused ALM sweep) + k_first_shrink at k=1") if fused else "k_shrink + k_update (ALM sweeps)", "bound": "hbm", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            **extras,
+            "validation": validation,
+            "roofline": {"kernel": "k_zsweep (E-free fused rebuild + ALM sweep) + k_first_shrink at k=1", "bound": "hbm",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         # what the library launched in the timed solves (tlsq_rpca_info.hbm_bytes_sweeps: algorithmic bytes of
+                         # every sweep launch incl. the R stores it decided on), per iteration
+                         "traffic": hbm_sweeps_total / iters_total,
+                         "traffic_source": "tlsq_rpca_info.hbm_bytes_sweeps of the timed solves (bytes of the launches the library made); "
+                                           "PMC cross-check in traffic_pmc",
                          "ms_per_iter": sweep_ms_per_iter, "algorithmic_bytes_per_iter": alg_bytes,
                          "passes_per_iter": alg_bytes / array_bytes, "sweeps_without_residual_store": rskip_total,
                          "survey_11_pass_equivalent_GBps": 11.0 * array_bytes / (sweep_ms_per_iter * 1e-3) / 1e9},
@@ -217,7 +324,8 @@ def main():
                              "that solve runs ~6 % slower than the timed ones)",
             "roofline_mfma": None,
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
-            "svd_step": {"tsqr_route": rep.eig_full, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
+            "svd_step": {"tsqr_route": rep.tsqr_iterations, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
+            "hbm_bytes_per_iter_all_panel_kernels": hbm_total / iters_total,
             "extra": {"c4": c4},
         }
         # on-box reference point for a streaming kernel (SURVEY §8d asks for one beside the 8 TB/s vendor figure): a plain
@@ -239,35 +347,26 @@ def main():
         except Exception as e:  # the bench line must not depend on this extra
             out["roofline"]["torch_copy_GBps"] = None
             print(f"# torch copy rate not measured: {e}", file=sys.stderr)
-        # HBM bytes of the sweep kernels.  `traffic` = the PMC measurement of these kernels (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes, FETCH x2 on gfx950 - collected with tools/profile_round.sh and committed under
-        # profiles/; a counter run cannot happen inside this process) scaled to this run's launches; beside it the
-        # library's own accounting of what it launched in the timed solves (tlsq_rpca_info.hbm_bytes_sweeps).
-        out["roofline"]["library_accounted_bytes_per_iter"] = hbm_sweeps_total / iters_total
-        out["hbm_bytes_per_iter_all_panel_kernels"] = hbm_total / iters_total
-        for pmc_file in ("r02_pmc_sweeps.json", "r01_pmc_sweeps.json"):
+        # PMC cross-check of `traffic`: FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of the sweep kernels from a counter run of this
+        # same command (rocprofv3 --pmc in separate passes, tools/profile_round.sh; a counter pass cannot run inside this
+        # process), committed under profiles/
+        out["roofline"]["traffic_pmc"] = None
+        for pmc_file in ("r03_pmc_sweeps.json", "r02_pmc_sweeps.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     pmc = json.load(f)
                 if Ml == 20000 and N == 512:
                     sk = pmc["sweep_kernels"]
-                    kname = "k_zsweep" if zsweep else "k_rebuild_update_shrink" if fused_rebuild else "k_update_shrink"
-                    if fused and kname in sk:   # PMC average over the launches of one solve (with and without the R store)
-                        first = sk.get("k_first_shrink", sk.get("k_shrink"))
-                        tr = (first["hbm_bytes_per_launch"] +
-                              rep.iters_done * sk[kname]["hbm_bytes_per_launch"]) / rep.iters_done
-                    elif not fused and "k_update" in sk:
-                        tr = sk["k_shrink"]["hbm_bytes_per_launch"] + sk["k_update"]["hbm_bytes_per_launch"]
-                    else:
-                        tr = None
-                    out["roofline"]["traffic"] = tr
-                    out["roofline"]["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc, separate passes)"
+                    first = sk.get("k_first_shrink", sk.get("k_shrink"))
+                    out["roofline"]["traffic_pmc"] = {
+                        "bytes_per_iter": (first["hbm_bytes_per_launch"] + rep.iters_done * sk["k_zsweep"]["hbm_bytes_per_launch"]) / rep.iters_done,
+                        "source": f"profiles/{pmc_file}"}
                 break
             except (OSError, KeyError):
                 continue
-        # second roofline: the Gram kernel (fp64 MFMA, v_mfma_f64_16x16x4_f64), flops actually executed
-        # ALGORITHMIC flops of G = Z'Z: the N (N + 1) / 2 distinct entries, 2 M flop each.  The kernel issues more: the
-        # strictly lower 128 x 128 tiles in full, of the diagonal tiles the 36 of 64 MFMA tiles on and below the diagonal
+        # second roofline: the Gram kernel (fp64 MFMA, v_mfma_f64_16x16x4_f64).  ALGORITHMIC flops of G = Z'Z: the
+        # N (N + 1) / 2 distinct entries, 2 M flop each.  The kernel issues more: the strictly lower 128 x 128 tiles in full, of
+        # the diagonal tiles the 36 of 64 MFMA tiles on and below the diagonal
         nt = (N + 127) // 128
         gram_flops = 1.0 * Ml * N * (N + 1)
         issued_flops = 2.0 * Ml * 128 * 128 * (nt * (nt - 1) // 2 + nt * 36.0 / 64.0)
@@ -275,13 +374,12 @@ def main():
             # Gram launches of the profiled solve: one per iteration, plus the one queued behind the last sweep
             # before its convergence is known (the library hides the host round trip behind it)
             n_gram = rep_ph.iters_done + 1
-            ms = dict(ms, gram=ms_ph["gram"])
-            tf = gram_flops / (ms["gram"] / n_gram * 1e-3) / 1e12
+            tf = gram_flops / (ms_ph["gram"] / n_gram * 1e-3) / 1e12
             out["roofline_mfma"] = {"kernel": "k_gram_kc Gram(Z) + k_slab_reduce", "bound": "mfma",
                                     "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                     "flops_per_launch": gram_flops, "issued_flops_per_launch": issued_flops,
-                                    "issued_TFLOPs": issued_flops / (ms["gram"] / n_gram * 1e-3) / 1e12,
-                                    "ms_per_launch": ms["gram"] / n_gram, "launches": n_gram}
+                                    "issued_TFLOPs": issued_flops / (ms_ph["gram"] / n_gram * 1e-3) / 1e12,
+                                    "ms_per_launch": ms_ph["gram"] / n_gram, "launches": n_gram}
         if world == 1 and args.cpu_iters > 0:
             ncores = os.cpu_count() or 1
             # LAPACK gesdd on a 20000x512 panel does not scale to hundreds of threads: pick the best of a few
@@ -316,10 +414,16 @@ def main():
                                              f"thread count chosen as the fastest of {cands}), {tc:.1f} s"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        for p_ in problems:
+            print("bench.py: VALIDATION FAILED: " + p_, file=sys.stderr)
     eng.close()
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    dog.cancel()
+    if problems:
+        sys.exit(2)
 
 
 if __name__ == "__main__":

@@ -158,6 +158,10 @@ int   tlsq_synchronize(tlsq_handle h);
 int tlsq_comm_unique_id(unsigned char id[TLSQ_UNIQUE_ID_BYTES]);              /* rank 0, then broadcast */
 int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[TLSQ_UNIQUE_ID_BYTES]);
 int tlsq_comm_destroy(tlsq_handle h);
+/* number of ranks of the communicator attached to the handle (tlsq_comm_init, or the group of tlsq_create_multi) as RCCL
+ * itself reports it (ncclCommCount); 1 without a communicator.  bench.py prints it so that a multi-GPU run shows that
+ * the exchange really went through an N-rank communicator. */
+int tlsq_comm_size(tlsq_handle h, int* nranks);
 
 /* ---- rpca: src/robustPCA.jl:156-239 ----------------------------------------------------------
  * D  M x N (ldD)  in;  A, E  M x N out;  optional (may be NULL): U M x d (ldU), S d, Vt d x N (ldVt),

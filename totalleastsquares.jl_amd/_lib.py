@@ -62,7 +62,7 @@ class GaInfo(C.Structure):
 # every symbol include/tlsq.h declares (tests check that the .so exports all of them)
 EXPORTS = [
     "tlsq_version", "tlsq_dev_set", "tlsq_rpca_opts_default", "tlsq_create", "tlsq_create_multi", "tlsq_ngpus", "tlsq_destroy", "tlsq_last_error",
-    "tlsq_stream", "tlsq_synchronize", "tlsq_comm_unique_id", "tlsq_comm_init", "tlsq_comm_destroy",
+    "tlsq_stream", "tlsq_synchronize", "tlsq_comm_unique_id", "tlsq_comm_init", "tlsq_comm_destroy", "tlsq_comm_size",
     "tlsq_rpca_f64", "tlsq_rpca_f32",
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
@@ -107,6 +107,7 @@ def load():
     lib.tlsq_comm_unique_id.argtypes = [C.c_char_p]
     lib.tlsq_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
     lib.tlsq_comm_destroy.argtypes = [vp]
+    lib.tlsq_comm_size.argtypes = [vp, P(i32)]
     lib.tlsq_rpca_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, i64, vp,
                                   vp, i64, P(i64), P(RpcaInfo)]
     lib.tlsq_rpca_f32.argtypes = lib.tlsq_rpca_f64.argtypes

@@ -543,7 +543,9 @@ int tlsq_create_multi(int ngpus, const int* device_ids, tlsq_handle* out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TLSQ_ERR_HIP;   // no GPU: fail loudly
     if (ngpus > 64) return TLSQ_ERR_ARG;
     std::vector<int> devs((size_t)ngpus);
-    bool repeats = false;   // the same device twice: a loop-back group (see LocalGroup), device ids must then be given
+    // the same device twice: a loop-back group (see LocalGroup), device ids must then be given.  FORCE_LOCALGROUP=1 gives
+    // distinct devices the host-staged collectives as well (a debugging aid: takes RCCL out of the picture)
+    bool repeats = dev_is(DEV_FORCE_LOCALGROUP, '1');
     for (int r = 0; r < ngpus; ++r) {
         devs[(size_t)r] = device_ids ? device_ids[r] : r;
         if (devs[(size_t)r] < 0 || devs[(size_t)r] >= ndev) return TLSQ_ERR_ARG;
@@ -664,6 +666,23 @@ int tlsq_comm_init(tlsq_handle h, int nranks, int rank, const unsigned char id[T
     }
     h->nranks = nranks;
     h->rank = rank;
+    return TLSQ_OK;
+}
+
+int tlsq_comm_size(tlsq_handle h, int* nranks) {
+    TLSQ_TRY(check_handle(h));
+    if (!nranks) return set_err(h, TLSQ_ERR_ARG, "comm_size: null argument");
+    *nranks = 1;
+    const Comm* c = h->comm ? h->comm : h->multi_comm;
+    if (!c) return TLSQ_OK;
+    if (c->local) {
+        *nranks = c->local->n;
+        return TLSQ_OK;
+    }
+    if (!c->comm || !g_rccl.CommCount) return set_err(h, TLSQ_ERR_COMM, "comm_size: no live RCCL communicator");
+    int n = 0;
+    TLSQ_NCCL(h, g_rccl.CommCount(c->comm, &n));
+    *nranks = n;
     return TLSQ_OK;
 }
 

@@ -1154,6 +1154,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
     const int force_implicit = [] { const char* e = dev_get(DEV_IMPLICIT_GRAM); return e ? atoi(e) : -1; }();
     const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
+    // The randomized hook in large mode (BASELINE config 5: `svd = rsvd`, src/robustPCA.jl:195-197, test/runtests.jl:388-398) as a
+    // pure sketch - from iteration 2 on nothing but products with the panel, G X = Z'(Z X), and opnorm(residual) as Lanczos on
+    // the operator R'R, no N x N Gram matrix - is wired (HOOK_SKETCH=1) but NOT the default below N = 8192: measured at
+    // 65536 x 4096 fp32 it takes 51 ms per iteration against 21 with the Gram matrix (eig 33 ms: the hook's two steps are six
+    // operator products of 80 GFLOP each on the fp64 MFMA - the skinny kernels widen the fp32 panel - where the Gram runs on
+    // the fp32 MFMA at twice the rate; opnorm 14 ms: ~30 Lanczos steps of two panel passes each).  What it needs to win:
+    // skinny products on the fp32 MFMA with fp64 fold-in, like k_gram_f32mfma.
+    const bool hook_sketch = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED && N > kFullEigMaxN && dev_is(DEV_HOOK_SKETCH, '1');
     auto panel_op = [&](const T* P) {
         GramOp o;
         o.Z = P;
@@ -1671,8 +1679,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         if (!r_route) {
         GramOp op = panel_op(Z);
-        const bool gram_queued_earlier = g_ready || implicit_gram;
-        if (!implicit_gram) {
+        const bool sketch_now = hook_sketch && hook_now;
+        const bool gram_queued_earlier = g_ready || implicit_gram || sketch_now;
+        if (!implicit_gram && !sketch_now) {
             if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
             else {
                 TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
@@ -1911,7 +1920,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         //  should the loop go on after all, the Gram is computed at the top of the next iteration instead)
         const double last_guess = [] { const char* e = dev_get(DEV_LAST_GUESS); return e ? atof(e) : 1.6; }();
         const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;
-        const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last;
+        const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last && !hook_sketch;
         bool gram_queued = false;
         // one launch of the fused sweep over rows [r0, r1) (r1 = 0: the whole panel): E-free form or classic form
         const T* hy_sweep = (const T*)ro.hankel_y;
@@ -2116,7 +2125,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // the reference's to 1e-6); when only the decision matters 1e-6 is enough - a value within 1e-5 of tol is
             // re-evaluated to full accuracy below (residual spectra are flat: 154 -> ~110 Lanczos steps at N = 4096)
             const double cost_rel = want_exact_cost ? 1e-8 : 1e-6;
-            if (implicit_gram) {
+            if (implicit_gram || hook_sketch) {
                 TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, cost_rel, &rn, stop_sigma));
             } else {                                                                               // :225
                 void* Gc;
@@ -2143,7 +2152,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             hbm_other += panel_bytes;
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
-                if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
+                if (implicit_gram || hook_sketch) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
                 else TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
                 cost = rn / d_norm;
             }

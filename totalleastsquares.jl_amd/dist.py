@@ -33,9 +33,10 @@ def exchange_unique_id(make_id, rank: int, world: int):
     return bytes(uid)
 
 
-def init_engine_comm(engine, rank: int, world: int):
-    """join `engine` (one GPU) to the row-shard communicator"""
-    if world <= 1:
+def init_engine_comm(engine, rank: int, world: int, force: bool = False):
+    """join `engine` (one GPU) to the row-shard communicator.  force: create a one-rank RCCL communicator as well (the switch
+    FORCE_COMM has to be set: a single rank normally needs none) - how a one-GPU box exercises the path of an N-GPU run"""
+    if world <= 1 and not force:
         return
     uid = exchange_unique_id(engine.unique_id, rank, world)
     engine.comm_init(world, rank, uid)

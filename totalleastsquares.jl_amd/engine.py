@@ -217,6 +217,12 @@ class Engine:
             raise TlsqError(st, "tlsq_comm_unique_id failed (librccl not loadable?)")
         return buf.raw
 
+    def comm_size(self) -> int:
+        """ranks of the attached communicator as RCCL reports them (1 without one)"""
+        n = C.c_int(0)
+        self._check(self.lib.tlsq_comm_size(self.h, C.byref(n)))
+        return int(n.value)
+
     def comm_init(self, nranks: int, rank: int, uid: bytes):
         self._check(self.lib.tlsq_comm_init(self.h, nranks, rank, C.create_string_buffer(uid, L.UNIQUE_ID_BYTES)))
         self.nranks, self.rank = nranks, rank
