@@ -332,6 +332,23 @@ for (T, sym) in ((Float64, :tlsq_rtls_batched_f64), (Float32, :tlsq_rtls_batched
     end
 end
 
+# rpca on every slice D[:, :, b] of an M x N x B stack (N <= 16): one workgroup per problem.  Returns A, E (M x N x B),
+# S (N x B), Vt (N x N x B), sv, iters, status (0 converged / 1 iteration limit), cost (final) per problem.
+for (T, sym) in ((Float64, :tlsq_rpca_batched_f64), (Float32, :tlsq_rpca_batched_f32))
+    @eval function rpca(D::AbstractArray{$T,3}; kwargs...)
+        M, N, B = size(D)
+        o, box = _opts($T, M, N; tol = sqrt(eps($T)), kwargs...)
+        Dm = Array(D); A = similar(Dm); E = similar(Dm)
+        S = Matrix{$T}(undef, N, B); Vt = Array{$T}(undef, N, N, B)
+        sv = Vector{Int64}(undef, B); iters = Vector{Int32}(undef, B); status = Vector{Int32}(undef, B); cost = Vector{$T}(undef, B)
+        st = check(ccall(($(QuoteNode(sym)), LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{$T}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{$T}, Ptr{$T}, Ptr{$T}, Ptr{$T},
+             Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{$T}), handle(), Dm, M, N, B, o, A, E, S, Vt, sv, iters, status, cost))
+        st == 1 && @warn string("Maximum number of iterations reached in ", sum(status), " of ", B, " problems")
+        A, E, S, Vt, sv, iters, status, cost
+    end
+end
+
 # ---- rpca_ga (src/robustPCA.jl:255-310) and its spherical averages (:312-362) ----------------------------------------
 # mirrors `struct tlsq_ga_opts` (40 bytes) and `struct tlsq_ga_info` (64 bytes)
 mutable struct GaOpts
