@@ -264,7 +264,7 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
  * src/robustPCA.jl:156-239 exactly like tlsq_rpca_f64 (both SVDs of an iteration are one-sided Jacobi SVDs of the
  * panel itself, so there is no Gram-route accuracy limit).  Problems are stored back to back: D is M x N x batch
  * (column-major M x N blocks, ld = M), likewise A, E; optional per-problem outputs S (N), Vt (N x N, ld N), sv,
- * iters, status (0 converged / 1 iteration limit), cost (final).  N <= 16, M >= N; the hankel flag, hook modes
+ * iters, status (0 converged / 1 iteration limit), cost (final).  N <= 32, M >= N; the hankel flag, hook modes
  * and on_iter are not available (TLSQ_ERR_UNSUPPORTED).  Returns TLSQ_MAXITER when any problem hit the limit. */
 int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
                           const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,

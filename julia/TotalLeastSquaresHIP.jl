@@ -332,7 +332,7 @@ for (T, sym) in ((Float64, :tlsq_rtls_batched_f64), (Float32, :tlsq_rtls_batched
     end
 end
 
-# rpca on every slice D[:, :, b] of an M x N x B stack (N <= 16): one workgroup per problem.  Returns A, E (M x N x B),
+# rpca on every slice D[:, :, b] of an M x N x B stack (N <= 32): one workgroup per problem.  Returns A, E (M x N x B),
 # S (N x B), Vt (N x N x B), sv, iters, status (0 converged / 1 iteration limit), cost (final) per problem.
 for (T, sym) in ((Float64, :tlsq_rpca_batched_f64), (Float32, :tlsq_rpca_batched_f32))
     @eval function rpca(D::AbstractArray{$T,3}; kwargs...)

@@ -764,10 +764,44 @@ def test_batched_float32_stacks(eng):
     assert xr.dtype == np.float32 and wins.mean() > 0.9, wins.mean()
 
 
+@pytest.mark.parametrize("M,N,r", [(120, 17, 3), (100, 24, 4), (400, 32, 5), (64, 32, 2)])
+def test_rpca_batched_up_to_32_columns(eng, M, N, r):
+    """16 < N <= 32: the NB = 32 instantiation of the batched kernel (400 x 32 does not fit LDS: global-scratch variant) -
+    per problem the oracle's iterations, sv, A, E, all of S, and Vt orthogonal; float32 stacks as well."""
+    from oracle import rpca_oracle as O
+    B = 6
+    D = np.stack([O.synth_lowrank_sparse(M, N, r, seed=900 + 10 * N + b)[0] for b in range(B)])
+    A, E, S, Vt, sv, it, st, cost = eng.rpca_batched(D)
+    assert not st.any()
+    for b in range(B):
+        Ao, Eo, so, svo, io = O.rpca(D[b])
+        assert (sv[b], it[b]) == (svo, io.iters_done), (b, sv[b], svo, it[b], io.iters_done)
+        assert relerr(A[b], Ao) < 1e-8 and relerr(E[b], Eo) < 1e-8
+        np.testing.assert_allclose(S[b], so[1], rtol=1e-10, atol=1e-13 * so[1][0])
+        assert np.abs(Vt[b] @ Vt[b].T - np.eye(N)).max() < 1e-12
+    D32 = D.astype(np.float32)
+    A3, E3, S3, Vt3, sv3, it3, st3, _ = eng.rpca_batched(D32)
+    tol32 = float(np.sqrt(np.finfo(np.float32).eps))
+    for b in range(B):
+        Ao, Eo, so, svo, io = O.rpca(D32[b].astype(np.float64), tol=tol32)
+        assert sv3[b] == svo and abs(int(it3[b]) - io.iters_done) <= 1
+        assert relerr(A3[b], Ao) < 2e-3
+    # rtls with n + q up to 32 columns
+    rng = np.random.default_rng(5)
+    n = N - 1
+    Am = rng.standard_normal((4, M, n))
+    x0 = rng.standard_normal((4, n))
+    ym = np.einsum("bmn,bn->bm", Am, x0) + 0.01 * rng.standard_normal((4, M))
+    ym[:, ::17] += 3.0
+    xb = eng.rtls_batched(Am, ym)
+    for b in range(4):
+        np.testing.assert_allclose(xb[b], np.ravel(O.rtls(Am[b], ym[b])), rtol=1e-6, atol=1e-8)
+
+
 def test_batched_unsupported_shapes_fail_loudly(eng):
     import tlsq_amd
     with pytest.raises(tlsq_amd.TlsqError):
-        eng.rpca_batched(np.ones((2, 40, 17)))            # N > 16
+        eng.rpca_batched(np.ones((2, 40, 33)))            # N > 32
     with pytest.raises(tlsq_amd.TlsqError):
         eng.rpca_batched(np.ones((2, 3, 5)))              # wide problems
 

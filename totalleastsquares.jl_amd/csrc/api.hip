@@ -517,8 +517,8 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
 // validates the options shared by the two batched entry points
 static int batched_opts(tlsq_handle h, const tlsq_rpca_opts* opts, int64_t M, int64_t N, const char* who, ResolvedOpts* ro,
                         double default_tol) {
-    if (N > 16)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: N = %lld columns; the batched kernel handles N <= 16 (use the "
+    if (N > 32)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: N = %lld columns; the batched kernel handles N <= 32 (use the "
                        "per-problem entry point)", who, (long long)N);
     if (M < N) return set_err(h, TLSQ_ERR_UNSUPPORTED, "%s: needs M >= N (tall problems)", who);
     if (opts && (opts->hankel || opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT ||

@@ -1,5 +1,5 @@
 // Batched rpca for many tiny problems: one workgroup runs the whole inexact-ALM loop of
-// one M x N problem (N <= 16) with every panel resident in LDS.
+// one M x N problem (N <= 32) with every panel resident in LDS.
 //
 // The reference's real workloads are thousands of independent rtls / rpca calls on 50x4 ... 500x6 matrices
 // (/root/reference/test/runtests.jl:205-235, total_vs_robust_demo.jl:7-18): far too small for the streaming
@@ -21,7 +21,8 @@ namespace {
 
 constexpr int BT = 256;          // threads per problem
 constexpr int BW = BT / 64;      // waves
-constexpr int BN = 16;           // largest N
+// NB (template parameter of the kernel): leading dimension of V and length of the small vectors - 16 for N <= 16 (more
+// problems per CU: the reference's own uses are 4 ... 6 columns), 32 for 16 < N <= 32
 
 template <int CTRL>
 __device__ __forceinline__ double b_dpp(double v) {
@@ -81,8 +82,9 @@ struct Small {            // per-problem LDS bookkeeping
 // One-sided Jacobi SVD of the M x N panel P (ld M) in place: on return the columns of P are mutually orthogonal
 // (P = U diag(sigma) in some column order), nrm[j] = ||P[:,j]||^2 and, when V != nullptr, V (N x N, ld BN) holds
 // the accumulated rotations (P_in * V = P_out).  All BT threads must call.
-template <typename T>
+template <typename T, int NB>
 __device__ void jacobi_svd(T* P, int M, int N, const Small<T>& s, bool want_v) {
+    constexpr int BN = NB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (want_v)
         for (int e = tid; e < N * BN; e += BT) s.V[e] = ((e % BN) == (e / BN)) ? (T)1 : (T)0;
@@ -177,13 +179,14 @@ struct BatchedArgs {
 
 // grid = batch.  Dg/Ag/Eg: batch contiguous M x N problems.  Sg (N per problem), Vtg (N x N per problem, ld N,
 // rows sorted by singular value), svg, itg, stg (0 = converged, 1 = iteration limit) may each be nullptr.
-template <typename T, bool IN_LDS>
+template <typename T, bool IN_LDS, int NB>
 __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, BatchedArgs a,
                                                    T* __restrict__ Ag, T* __restrict__ Eg,
                                                    T* __restrict__ Sg, T* __restrict__ Vtg,
                                                    int64_t* __restrict__ svg, int32_t* __restrict__ itg,
                                                    int32_t* __restrict__ stg, T* __restrict__ costg,
                                                    T* __restrict__ scratch) {
+    constexpr int BN = NB;
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm_raw[];
     T* bsm = reinterpret_cast<T*>(bsm_raw);
     const int M = a.M, N = a.N, MN = M * N;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
     __syncthreads();
     T maxabs = (T)0;
     for (int k = 0; k < BW; ++k) maxabs = s.red[k] > maxabs ? s.red[k] : maxabs;   // norm(Y, Inf)  :178
-    jacobi_svd(Z, M, N, s, false);
+    jacobi_svd<T, NB>(Z, M, N, s, false);
     const T norm2 = s.sig[0];                                  // opnorm(Y)  :177
     const T lam = (T)a.lambda;
     const T norminf = maxabs / lam;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
             E[e] = ee;
             Z[e] = (D[e] - ee) + t;
         }
-        jacobi_svd(Z, M, N, s, true);                               // :194  (Z <- U*S, V accumulated)
+        jacobi_svd<T, NB>(Z, M, N, s, true);                               // :194  (Z <- U*S, V accumulated)
         svp = 0;                                                    // :198
         for (int i = 0; i < N; ++i) svp += (s.sig[i] >= inv_mu) ? 1 : 0;
         {
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
             okeep = s.ord[tid];
         }
         __syncthreads();
-        jacobi_svd(Z, M, N, s, false);                              // :225 opnorm(Z)
+        jacobi_svd<T, NB>(Z, M, N, s, false);                              // :225 opnorm(Z)
         cost = s.sig[0] / d_norm;
         __syncthreads();
         if (tid < N) {
@@ -313,10 +316,11 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
         Eout[e] = E[e];
     }
     if (Sg && tid < N) Sg[(size_t)b * N + tid] = s.sig[tid];
-    if (Vtg && tid < N * N) {   // Vt[i, c] = V[c, ord[i]]
-        const int i = tid % N, c = tid / N;
-        Vtg[(size_t)b * N * N + i + (size_t)c * N] = s.V[c + s.ord[i] * BN];
-    }
+    if (Vtg)   // Vt[i, c] = V[c, ord[i]]
+        for (int e = tid; e < N * N; e += BT) {
+            const int i = e % N, c = e / N;
+            Vtg[(size_t)b * N * N + i + (size_t)c * N] = s.V[c + s.ord[i] * BN];
+        }
     if (tid == 0) {
         if (svg) svg[b] = sv;
         if (itg) itg[b] = k;
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
 }
 
 size_t rpca_small_lds_bytes(int64_t M, int64_t N, bool* in_lds, size_t esz) {
+    const size_t BN = N <= 16 ? 16 : 32;
     const size_t small = (size_t)(BN * BN + 3 * BN + 8) * esz + (size_t)(BN + 4) * 4;   // (a multiple of 16 bytes)
     const size_t big = (size_t)5 * M * N * esz;
     *in_lds = small + big <= 150 * 1024;
@@ -350,15 +355,23 @@ int launch_rpca_small(Handle* h, const T* D, int64_t M, int64_t N, int64_t batch
     a.nukeA = nukeA;
     bool in_lds;
     const size_t lds = rpca_small_lds_bytes(M, N, &in_lds, sizeof(T));
+    if (N > 32) return set_err(h, TLSQ_ERR_UNSUPPORTED, "batched rpca: N = %lld > 32", (long long)N);
+#define TLSQ_BATCHED_GO(INL, NBV)                                                                                         \
+    do {                                                                                                                  \
+        if (INL)                                                                                                          \
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rpca_small<T, INL, NBV>),                     \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+        hipLaunchKernelGGL((k_rpca_small<T, INL, NBV>), dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, \
+                           sv, it, st, cost, scratch);                                                                    \
+    } while (0)
     if (in_lds) {
-        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rpca_small<T, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_rpca_small<T, true>), dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv, it,
-                           st, cost, scratch);
+        if (N <= 16) TLSQ_BATCHED_GO(true, 16);
+        else TLSQ_BATCHED_GO(true, 32);
     } else {
-        hipLaunchKernelGGL((k_rpca_small<T, false>), dim3((unsigned)batch), dim3(BT), lds, h->stream, D, a, A, E, S, Vt, sv,
-                           it, st, cost, scratch);
+        if (N <= 16) TLSQ_BATCHED_GO(false, 16);
+        else TLSQ_BATCHED_GO(false, 32);
     }
+#undef TLSQ_BATCHED_GO
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

@@ -473,7 +473,7 @@ class Engine:
 
     # -- batched tiny problems -----------------------------------------------
     def rpca_batched(self, D, *, iters=1000, **kw):
-        """rpca on every D[b] of a (batch, M, N) stack, N <= 16, one workgroup per problem.  Returns
+        """rpca on every D[b] of a (batch, M, N) stack, N <= 32, one workgroup per problem.  Returns
         A, E (batch, M, N), S (batch, N), Vt (batch, N, N), sv, iters, status, cost (batch,).  A float32 stack is
         solved in float32 (default tol sqrt(eps(Float32))), everything else in float64."""
         D = np.asarray(D)
