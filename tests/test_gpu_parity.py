@@ -631,6 +631,32 @@ def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     assert np.array_equal(yf2, yf)
 
 
+@pytest.mark.parametrize("Dch,lag,n", [(2, 1, 20), (1, 2, 40), (3, 2, 16), (2, 3, 24)])
+def test_implicit_hankel_with_lag_and_channels(eng, Dch, lag, n):
+    """SURVEY.md §8f rank 2 for several channels and lag > 1 (`D[k, d:D:L*D] = x[(k-1)*lag .+ (1:L), d]`,
+    src/robustPCA.jl:81-90): the sweeps read the series through the lag / channel index arithmetic instead of a stored
+    Hankel panel - same bits as the run that builds and keeps the panel (LAZY_HANKEL=0, IMPLICIT_HANKEL=0), the oracle's
+    filter to 1e-8, float32 series as well."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    T_ = 6001
+    rng = np.random.default_rng(10 * Dch + lag)
+    t = np.arange(T_)
+    yy = np.column_stack([np.sin((0.07 + 0.05 * d) * t) + 0.5 * np.cos(0.31 * t + d) for d in range(Dch)])
+    yy = yy + 0.1 * rng.standard_normal(yy.shape)
+    yy[::97] += 3.0
+    y_in = yy[:, 0] if Dch == 1 else yy
+    f1, rep1 = eng.lowrankfilter(y_in, n, lag=lag, return_report=True)
+    with tlsq_amd.dev_switches(LAZY_HANKEL=0, IMPLICIT_HANKEL=0):
+        f2, rep2 = eng.lowrankfilter(y_in, n, lag=lag, return_report=True)
+    assert rep1.iters_done == rep2.iters_done and rep1.svp_hist == rep2.svp_hist
+    assert np.array_equal(f1, f2)
+    fo = O.lowrankfilter(y_in, n, lag=lag)
+    assert relerr(f1, fo) < 1e-8
+    f32 = eng.lowrankfilter(y_in.astype(np.float32), n, lag=lag)
+    assert f32.dtype == np.float32 and relerr(f32, fo) < 2e-3
+
+
 def test_missing_values(eng):                                        # test/runtests.jl:172-185
     rng = np.random.default_rng(0)
     res = []

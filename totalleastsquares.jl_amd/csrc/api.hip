@@ -176,17 +176,19 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     const bool exact_shape = (opts && (opts->hankel || opts->svd_mode == TLSQ_SVD_CALLBACK ||
                                        opts->opnorm_mode == TLSQ_OPNORM_CALLBACK)) || (K < LD && !sharded);
     const int64_t Kp = exact_shape ? K : (K + 15) / 16 * 16;
-    // one channel, lag 1, robust mode - the Hankel matrix is never stored.  The big fused sweep, the
-    // residual and the set-up of rpca_core read H[i, j] = y[i + j] from the series (ResolvedOpts::hankel_lazy): seven
-    // resident panels instead of eight, six panel passes per iteration instead of seven.
+    // robust mode - the Hankel matrix is never stored.  The big fused sweep, the residual and the set-up of
+    // rpca_core read H[k, l Dch + d] = y[k lag + l, d] from the series (ResolvedOpts::hankel_lazy, any lag and number of
+    // channels: src/robustPCA.jl:81-90 is arithmetic indexing): seven resident panels instead of eight, six panel passes per
+    // iteration instead of seven.
     const bool implicit_ok = !dev_is(DEV_IMPLICIT_HANKEL, '0');
     const bool lazy_ok = !dev_is(DEV_LAZY_HANKEL, '0');
-    const bool implicit = implicit_ok && Dch == 1 && lag == 1;
+    const bool implicit = implicit_ok && LD <= 65535;
     const bool lazy = implicit && lazy_ok && sv <= 0 && !exact_shape;
-    // ... and neither is A: the loop keeps it in factors, the anti-diagonal means are taken from them (unhankel_factors),
-    // and the panel only exists if some iteration needed it in memory (rank above 32): four resident panels (E, Y, Z, R)
+    // ... and neither is A (one channel, lag 1): the loop keeps it in factors, the anti-diagonal means are taken from them
+    // (unhankel_factors), and the panel only exists if some iteration needed it in memory (rank above 32): four resident
+    // panels (E, Y, Z, R)
     const bool factors_ok = !dev_is(DEV_UNHANKEL_FACTORS, '0');
-    const bool factors_out = lazy && !sharded && factors_ok && (size_t)n * 32 * 8 <= 64 * 1024;
+    const bool factors_out = lazy && !sharded && factors_ok && Dch == 1 && lag == 1 && (size_t)n * 32 * 8 <= 64 * 1024;
     void *dy, *H = nullptr, *A = nullptr, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
     if (!lazy) TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
@@ -206,6 +208,9 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         if (implicit) {
             ro.hankel_y = yw;
             ro.hankel_K = K;
+            ro.hankel_geom.lag = (int32_t)lag;
+            ro.hankel_geom.Dch = (int32_t)Dch;
+            ro.hankel_geom.ldx = Nx;
             ro.hankel_lazy = lazy;
             ro.factors_out = factors_out;
         }

@@ -154,6 +154,16 @@ enum WsSlot {
     WS_COUNT
 };
 
+// An implicit Hankel source (src/robustPCA.jl:76-92): D[k, c] = x[k lag + l, d] with c = l Dch + d; channel d of the series
+// starts ldx elements after channel d - 1.  The default describes one channel with lag 1: D[i, j] = y[i + j].
+struct HankelGeom {
+    int32_t lag = 1, Dch = 1;
+    int64_t ldx = 0;
+};
+__host__ __device__ inline int64_t hankel_coff(const HankelGeom& g, int col) {   // offset of column `col` within row 0
+    return g.Dch == 1 ? (int64_t)col : (int64_t)(col / g.Dch) + (int64_t)(col % g.Dch) * g.ldx;
+}
+
 // ---------------- sweeps.hip ----------------
 template <typename T>
 int launch_shrink(Handle* h, const T* D, const T* A, const T* Y, T* E, T* Z, int64_t n, T inv_mu,
@@ -180,7 +190,8 @@ int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 template <typename T>
 int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t n);
 template <typename T>
-int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N);   // R = (D - A) - E
+int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N,
+                           HankelGeom hg = HankelGeom());   // R = (D - A) - E
 // 64 doubles -> the handle's mailbox ([8..72)), published with sequence number seq
 int launch_publish_slots(Handle* h, const double* slots, double seq);
 // rebuild (A = Tm Vs', kept in registers) + update(k) + shrink(k+1): 7 panel passes, A is not stored
@@ -189,11 +200,11 @@ template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                   double* sumsq, double* zero_slots, const T* hankel_y = nullptr, int64_t hankel_K = 0, int64_t row0 = 0,
-                  int64_t row1 = 0, int maxslot = -1);
+                  int64_t row1 = 0, int maxslot = -1, HankelGeom hg = HankelGeom());
 template <typename T>
 int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
                    int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y = nullptr,
-                   int64_t hankel_K = 0);
+                   int64_t hankel_K = 0, HankelGeom hg = HankelGeom());
 template <typename T>
 int launch_residual_from_y(Handle* h, const T* Y1, const T* Y0, T* R, int64_t n, T inv_mu);
 template <typename T>
@@ -210,7 +221,8 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
                                  int nonnegE, double* sumsq, double* zero_slots = nullptr, const T* hankel_y = nullptr,
                                  int64_t hankel_K = 0, int64_t row0 = 0, int64_t row1 = 0,   // rows [row0, row1), default all
-                                 size_t pad_lds = 0);   // unused dynamic LDS per workgroup (caps the residency per CU)
+                                 size_t pad_lds = 0,   // unused dynamic LDS per workgroup (caps the residency per CU)
+                                 HankelGeom hg = HankelGeom());
 // A (M x N, ld M) = Tm Vs' (Tm M x r fp64, Vs N x r): the streaming-store form of the rebuild (r <= 32, even M)
 template <typename T>
 bool rebuild_store_ok(const T* A, int64_t M, int64_t N, int64_t ldA, int64_t r);

@@ -144,6 +144,8 @@ struct ResolvedOpts {
     // fused sweep reads the vector instead of the panel (set by lowrankfilter; fp64, one channel, lag 1)
     const void* hankel_y = nullptr;
     int64_t hankel_K = 0;
+    // ... in general D[k, l Dch + d] = hankel_y[k lag + l + d ldx] (several channels, lag > 1: src/robustPCA.jl:81-90)
+    HankelGeom hankel_geom;
     // ... and the caller has not built that panel at all (rpca_core is called with D == nullptr): the set-up works on a
     // transient copy in a buffer the loop only needs later, and the rare kernels without an implicit form build one on
     // demand (seven resident panels instead of eight)

@@ -1098,9 +1098,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     bool d_transient = false;
     const double lam_f = ro.lambda;
     auto build_hankel = [&](T* dst) -> int {
-        const int64_t Kh = ro.hankel_K, Nw = Kh - 1 + N;
+        const HankelGeom& hg = ro.hankel_geom;
+        const int64_t Kh = ro.hankel_K, Lw = N / hg.Dch, Nw = (Kh - 1) * hg.lag + Lw;   // samples per channel behind these rows
         if (Kh != M) TLSQ_HIP(h, hipMemsetAsync(dst, 0, (size_t)n * sizeof(T), h->stream));
-        return launch_hankel<T>(h, (const T*)ro.hankel_y, Nw, 1, Nw, N, 1, dst, M);
+        return launch_hankel<T>(h, (const T*)ro.hankel_y, Nw, hg.Dch, hg.Dch == 1 ? Nw : hg.ldx, Lw, hg.lag, dst, M);
     };
     auto panel_D = [&](const T** out) -> int {
         if (!Dm || d_transient) {
@@ -1130,7 +1131,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             Dp = D;
         }
         return launch_final_e<T>(h, Dp, Tm_prev, Vs_prev, Aprev, Yk, Ebuf[0], M, N, r_prev, (T)(1.0 / mu_k), (T)(lam_f / mu_k),
-                                 ro.nonnegA ? 1 : 0, ro.nonnegE ? 1 : 0, hy, ro.hankel_K);
+                                 ro.nonnegA ? 1 : 0, ro.nonnegE ? 1 : 0, hy, ro.hankel_K, ro.hankel_geom);
     };
     if (!D) {
         if (!ro.hankel_lazy || !ro.hankel_y) return set_err(h, TLSQ_ERR_ARG, "rpca: no data panel");
@@ -1175,8 +1176,15 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
     else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
-    if (ro.hankel_lazy && ro.hankel_y)   // every sample of the series appears in its Hankel matrix: max |H| = max |y|
-        TLSQ_TRY(launch_maxabs<T>(h, (const T*)ro.hankel_y, ro.hankel_K + N - 1, &maxabs));
+    if (ro.hankel_lazy && ro.hankel_y) {   // every sample of the window appears in its Hankel matrix (lag <= L): max |H| = max |y|
+        const HankelGeom& hg = ro.hankel_geom;
+        const int64_t Nw = (ro.hankel_K - 1) * hg.lag + N / hg.Dch;
+        for (int d = 0; d < hg.Dch; ++d) {
+            double md = 0.0;
+            TLSQ_TRY(launch_maxabs<T>(h, (const T*)ro.hankel_y + (size_t)d * hg.ldx, Nw, &md));
+            maxabs = std::max(maxabs, md);
+        }
+    }
     else
         TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));              // :178 norm(Y, Inf)
     TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
@@ -1933,11 +1941,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 return launch_zsweep<T>(h, D, Tm_last, Vs_last, fuse_rebuild ? (T*)nullptr : A, Ybuf[ycur], Ybuf[ycur ^ 1],
                                         Zbuf[0], Rst, M, N, svp, (T)mu, (T)inv_mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
                                         (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K,
-                                        r0, r1, maxslot);
+                                        r0, r1, maxslot, ro.hankel_geom);
             return launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp,
                                                    (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
                                                    ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, (const T*)ro.hankel_y,
-                                                   ro.hankel_K, r0, r1, pad_lds);
+                                                   ro.hankel_K, r0, r1, pad_lds, ro.hankel_geom);
         };
         if (zmode && !fuse) {
             // the last allowed iteration (no next shrink to fuse with): E_k is formed now, then the plain residual :217-221
@@ -1949,7 +1957,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             }
             if (ro.nonnegA) TLSQ_TRY(launch_clamp_nonneg<T>(h, A, n));
             if (ro.hankel_y && (!Dm || d_transient)) {
-                TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, Ebuf[0], R, M, N));
+                TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, Ebuf[0], R, M, N, ro.hankel_geom));
                 hbm_sweeps += 6.0 * panel_bytes;
             } else {
                 TLSQ_TRY(panel_D(&D));
@@ -2096,7 +2104,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     a_pending = false;
                 }
                 if (ro.hankel_y && (!Dm || d_transient)) {
-                    TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, E, R, M, N));
+                    TLSQ_TRY(launch_residual_hankel<T>(h, (const T*)ro.hankel_y, ro.hankel_K, A, E, R, M, N, ro.hankel_geom));
                     hbm_sweeps += 3.0 * panel_bytes;
                 } else {
                     TLSQ_TRY(launch_residual<T>(h, D, A, E, R, n));

@@ -193,8 +193,9 @@ __global__ __launch_bounds__(256) void k_update_shrink(const T* __restrict__ D, 
 constexpr int RUS_CT = 64;   // widest column tile
 // ROWS = 2: a thread owns two consecutive rows (16-byte accesses for fp64) - the streaming form for tall panels.
 // ROWS = 1: one row per thread and narrower column tiles, for panels too small to fill the chip otherwise.
-// HK = true: D is a Hankel matrix that is not read at all — D[i, j] = y[i + j] for i < K, zero pad rows below
-// (lowrankfilter with one channel and lag 1, src/robustPCA.jl:76-92); `D` then points at y.  One panel pass less.
+// HK = true: D is a Hankel matrix that is not read at all - D[k, c] = x[k lag + l, d] with c = l Dch + d for k < K (the
+// lag embedding of lowrankfilter, src/robustPCA.jl:76-92: `D[k, d:D:L*D] = x[(k-1)*lag .+ (1:L), d]`; one channel and lag 1:
+// D[i, j] = y[i + j]), zero pad rows below; `D` then points at the series (channel d at offset d ldx).  One panel pass less.
 template <typename T, int RMAX, int ROWS, bool HK>
 __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restrict__ D, const double* __restrict__ Tm,
                                                                const double* __restrict__ Vs,
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
                                                                T mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                                                                double* __restrict__ sumsq,
                                                                double* __restrict__ zero_slots, int64_t hankel_K,
-                                                               int64_t row0, int64_t row1) {
+                                                               int64_t row0, int64_t row1, HankelGeom hg) {
     // rows [row0, row1) of the panels (row0 a multiple of ROWS): the whole panel, or one row chunk of it when the caller
     // interleaves the chunks with the Gram kernel of the rows already swept (solver.hip)
     using VR = T __attribute__((ext_vector_type(ROWS)));
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
             VR d;
             if constexpr (HK) {
 #pragma unroll
-                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[(row + q) * hg.lag + hankel_coff(hg, c0 + c)] : (T)0;
             } else {
                 d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
             }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
                                                 T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t M,
                                                 int N, int r, int ct, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n,
                                                 int nonnegE, double* __restrict__ sumsq, double* __restrict__ zero_slots,
-                                                int64_t hankel_K, int64_t row0, int64_t row1, int maxslot) {
+                                                int64_t hankel_K, int64_t row0, int64_t row1, int maxslot, HankelGeom hg) {
     // sumsq: 72 doubles - [0, 64) partial sums of ||R_k||_F^2, [64 + maxslot] (maxslot >= 0) max |R_k[i, j]| as a bit
     // pattern: both are lower bounds of ||R_k||_2 for the convergence test (solver.hip), never results
     using VR = T __attribute__((ext_vector_type(ROWS)));
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
             VR d;
             if constexpr (HK) {
 #pragma unroll
-                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+                for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[(row + q) * hg.lag + hankel_coff(hg, c0 + c)] : (T)0;
             } else {
                 d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
             }
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
 template <typename T, int RMAX, int ROWS, bool HK>
 __global__ __launch_bounds__(256) void k_final_e(const T* __restrict__ D, const double* __restrict__ Tm,
                                                  const double* __restrict__ Vs, const T* Y, T* E, int64_t M, int N, int r,
-                                                 int ct, T inv_mu, T thr, int nonnegA, int nonnegE, int64_t hankel_K) {
+                                                 int ct, T inv_mu, T thr, int nonnegA, int nonnegE, int64_t hankel_K,
+                                                 HankelGeom hg) {
     using VR = T __attribute__((ext_vector_type(ROWS)));
     __shared__ __attribute__((aligned(16))) double sVs[RUS_CT * RMAX];
     const int c0 = blockIdx.y * ct;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void k_final_e(const T* __restrict__ D, const 
         VR d;
         if constexpr (HK) {
 #pragma unroll
-            for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[row + q + (c0 + c)] : (T)0;
+            for (int q = 0; q < ROWS; ++q) d[q] = (row + q < hankel_K) ? D[(row + q) * hg.lag + hankel_coff(hg, c0 + c)] : (T)0;
         } else {
             d = reinterpret_cast<const VR*>(D)[idx];
         }
@@ -670,13 +672,13 @@ __global__ __launch_bounds__(256) void k_residual(const T* __restrict__ D, const
 template <typename T>
 __global__ __launch_bounds__(256) void k_residual_hankel(const T* __restrict__ y, int64_t K, const T* __restrict__ A,
                                                          const T* __restrict__ E, T* __restrict__ R, int64_t M,
-                                                         int64_t N) {
+                                                         int64_t N, HankelGeom hg) {
     const int64_t j = blockIdx.y;
-    const T* __restrict__ yj = y + j;
+    const T* __restrict__ yj = y + hankel_coff(hg, (int)j);
     const int64_t off = j * M;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
-        const T d = i < K ? yj[i] : (T)0;
+        const T d = i < K ? yj[i * hg.lag] : (T)0;
         R[off + i] = (d - A[off + i]) - E[off + i];
     }
 }
@@ -895,7 +897,7 @@ template <typename T>
 int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const double* Vs, const T* E, T* Y, T* R,
                                  T* En, T* Zn, int64_t M, int64_t N, int64_t r, T mu, int nonnegA, T inv_mu_n, T thr_n,
                                  int nonnegE, double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K,
-                                 int64_t row0, int64_t row1, size_t pad_lds) {
+                                 int64_t row0, int64_t row1, size_t pad_lds, HankelGeom hg) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     if (row1 <= 0) row1 = M;   // (default: the whole panel)
     if (row0 < 0 || row0 >= row1 || row1 > M || (row0 % 2) != 0 || (row1 % 2) != 0)
@@ -926,11 +928,11 @@ int launch_rebuild_update_shrink(Handle* h, const T* D, const double* Tm, const 
         if (hankel_y)                                                                                                 \
             hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, true>), grid, dim3(256), pad_lds, h->stream, hankel_y, Tm, \
                                Vs, E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE,      \
-                               sumsq, zero_slots, hankel_K, row0, row1);                                              \
+                               sumsq, zero_slots, hankel_K, row0, row1, hg);                                          \
         else                                                                                                          \
             hipLaunchKernelGGL((k_rebuild_update_shrink<T, RM, RW, false>), grid, dim3(256), pad_lds, h->stream, D, Tm, Vs, \
                                E, Y, R, En, Zn, M, (int)N, (int)r, ct, mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq,   \
-                               zero_slots, (int64_t)0, row0, row1);                                                   \
+                               zero_slots, (int64_t)0, row0, row1, hg);                                               \
     } while (0)
     if (two2) {
         if (r <= 8) RUS_LAUNCH(8, 2);
@@ -952,7 +954,7 @@ template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                   double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K, int64_t row0, int64_t row1,
-                  int maxslot) {
+                  int maxslot, HankelGeom hg) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     if (row1 <= 0) row1 = M;
     if (!sumsq || maxslot > 7) maxslot = -1;
@@ -991,11 +993,11 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
         if (hankel_y)                                                                                                 \
             hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, R, \
                                M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
-                               hankel_K, row0, row1, maxslot);                                                        \
+                               hankel_K, row0, row1, maxslot, hg);                                                    \
         else                                                                                                          \
             hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, R, M, \
                                (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots,   \
-                               (int64_t)0, row0, row1, maxslot);                                                      \
+                               (int64_t)0, row0, row1, maxslot, hg);                                                  \
     } while (0)
     if (two) {
         if (r <= 8) ZS_LAUNCH(8, 2);
@@ -1014,7 +1016,8 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
 // E = soft_th(D - A_prev + inv_mu Y, thr): A_prev from factors (Aprev == nullptr, r <= 32; r = 0: zero) or from memory
 template <typename T>
 int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
-                   int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y, int64_t hankel_K) {
+                   int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y, int64_t hankel_K,
+                   HankelGeom hg) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     if (Aprev) {
         if (hankel_y) return set_err(h, TLSQ_ERR_ARG, "final_e: explicit A needs the real panel");
@@ -1032,10 +1035,10 @@ int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, co
     do {                                                                                                              \
         if (hankel_y)                                                                                                 \
             hipLaunchKernelGGL((k_final_e<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Y, E, M,  \
-                               (int)N, (int)r, ct, inv_mu, thr, nonnegA, nonnegE, hankel_K);                          \
+                               (int)N, (int)r, ct, inv_mu, thr, nonnegA, nonnegE, hankel_K, hg);                      \
         else                                                                                                          \
             hipLaunchKernelGGL((k_final_e<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Y, E, M, (int)N, \
-                               (int)r, ct, inv_mu, thr, nonnegA, nonnegE, (int64_t)0);                                \
+                               (int)r, ct, inv_mu, thr, nonnegA, nonnegE, (int64_t)0, hg);                            \
     } while (0)
     if (two) {
         if (r <= 8) FE_LAUNCH(8, 2);
@@ -1098,11 +1101,11 @@ int launch_residual(Handle* h, const T* D, const T* A, const T* E, T* R, int64_t
 }
 
 template <typename T>
-int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N) {
+int launch_residual_hankel(Handle* h, const T* y, int64_t K, const T* A, const T* E, T* R, int64_t M, int64_t N, HankelGeom hg) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
     if (N > 65535) return set_err(h, TLSQ_ERR_UNSUPPORTED, "residual: more than 65535 Hankel columns");
     const int64_t gx = std::min<int64_t>((M + 1023) / 1024, 4096);
-    hipLaunchKernelGGL((k_residual_hankel<T>), dim3((unsigned)gx, (unsigned)N), dim3(256), 0, h->stream, y, K, A, E, R, M, N);
+    hipLaunchKernelGGL((k_residual_hankel<T>), dim3((unsigned)gx, (unsigned)N), dim3(256), 0, h->stream, y, K, A, E, R, M, N, hg);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -1187,18 +1190,18 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
     template bool rebuild_update_shrink_ok<T>(const T*, const T*, T*, T*, T*, T*, int64_t, int64_t, int64_t); \
     template int launch_rebuild_update_shrink<T>(Handle*, const T*, const double*, const double*, const T*, T*, T*, \
                                                  T*, T*, int64_t, int64_t, int64_t, T, int, T, T, int, double*, double*, \
-                                                 const T*, int64_t, int64_t, int64_t, size_t);                        \
+                                                 const T*, int64_t, int64_t, int64_t, size_t, HankelGeom);            \
     template int launch_zsweep<T>(Handle*, const T*, const double*, const double*, T*, const T*, T*, T*, T*, int64_t, \
                                   int64_t, int64_t, T, T, int, T, T, int, double*, double*, const T*, int64_t, int64_t, \
-                                  int64_t, int);                                                                       \
+                                  int64_t, int, HankelGeom);                                                           \
     template int launch_final_e<T>(Handle*, const T*, const double*, const double*, const T*, const T*, T*, int64_t, \
-                                   int64_t, int64_t, T, T, int, int, const T*, int64_t);                              \
+                                   int64_t, int64_t, T, T, int, int, const T*, int64_t, HankelGeom);                  \
     template int launch_residual_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                              \
     template int launch_z_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                                     \
     template int launch_e_from_residual<T>(Handle*, const T*, const T*, const T*, const T*, T*, int64_t, T);          \
     template int launch_e_from_z<T>(Handle*, const T*, const T*, const T*, T*, int64_t, T);                           \
     template int launch_residual<T>(Handle*, const T*, const T*, const T*, T*, int64_t);          \
-    template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t); \
+    template int launch_residual_hankel<T>(Handle*, const T*, int64_t, const T*, const T*, T*, int64_t, int64_t, HankelGeom); \
     template int launch_div_scalar<T>(Handle*, const T*, T*, int64_t, T);                         \
     template int launch_clamp_nonneg<T>(Handle*, T*, int64_t);                                    \
     template int launch_maxabs<T>(Handle*, const T*, int64_t, double*);                           \
