@@ -376,6 +376,9 @@ int tlsq_k_matfun_invsqrt_f64(tlsq_handle h, const double* B, int64_t N, double 
    (the `gesdd` work of src/robustPCA.jl:194). */
 int tlsq_k_rr_small_f64(tlsq_handle h, const double* B, const double* Hg, int64_t p, int64_t nt, double tau2, double* C,
                         double* lam, double* status);
+/* Y (N x p, ld N, fp64) = Z'(Z X) for an fp32 panel Z (M x N, ldZ) and X (N x p, ld N, fp64): the operator product of
+ * large mode on the fp32 MFMA with fp64 fold-in (gemm.hip, op_gram_f32) - what the randomized hook's sketch is made of */
+int tlsq_k_op_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, const double* X, int64_t p, double* Y);
 /* G (N x N, ldG) = Z' Z for Z M x N (ldZ) — MFMA f64, deterministic split over rows */
 int tlsq_k_gram_f64(tlsq_handle h, const double* Z, int64_t M, int64_t N, int64_t ldZ,
                     double* G, int64_t ldG);

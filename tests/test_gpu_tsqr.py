@@ -142,3 +142,26 @@ def test_rpca_returned_s_all_singular_values(eng):
     Zo = (Uo * So) @ Vto
     Zg = (np.asarray(s.U) * S) @ np.asarray(s.Vt)
     assert np.linalg.norm(Zg - Zo) / np.linalg.norm(Zo) < 1e-9
+
+
+@pytest.mark.parametrize("M,N,p", [(4096, 512, 20), (8192, 1024, 74), (5000, 700, 96), (3001, 257, 130), (65536, 4096, 74)])
+def test_operator_product_on_the_fp32_mfma(eng, torch_mod, M, N, p):
+    """Y = Z'(Z X) for an fp32 panel (gemm.hip, op_gram_f32: both halves on the fp32 MFMA, fp64 fold-in) against numpy in
+    float64 on the same fp32 data: per column 2e-6 of ||Z||_2^2 ||x|| (X rounded to fp32 on the way in, fp32 partial sums
+    over at most 64 columns / 32 rows) - the randomized hook's sketch in large mode is made of these products."""
+    torch = torch_mod
+    rng = np.random.default_rng(M + N + p)
+    Z = (rng.standard_normal((M, 8)) @ rng.standard_normal((8, N)) + 0.3 * rng.standard_normal((M, N))).astype(np.float32)
+    X = rng.standard_normal((N, p))
+    dZ = torch.from_numpy(np.ascontiguousarray(Z.T)).cuda()
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    dY = torch.full((p, N), float("nan"), dtype=torch.float64, device="cuda")
+    assert eng.lib.tlsq_k_op_gram_f32(eng.h, dZ.data_ptr(), M, N, M, dX.data_ptr(), p, dY.data_ptr()) == 0, \
+        eng.lib.tlsq_last_error(eng.h)
+    eng.synchronize()
+    Y = dY.cpu().numpy().T
+    Zd = Z.astype(np.float64)
+    ref = Zd.T @ (Zd @ X)
+    scale = np.linalg.norm(Zd, 2) ** 2 * np.linalg.norm(X, axis=0)
+    assert np.isfinite(Y).all()
+    assert (np.linalg.norm(Y - ref, axis=0) / scale).max() < 2e-6

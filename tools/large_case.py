@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401  (its HIP runtime has to be the one in the process)
 import tlsq_amd
+tlsq_amd.dev_from_env()
 from oracle import rpca_oracle as O
 
 ap = argparse.ArgumentParser()

@@ -791,6 +791,13 @@ int tlsq_k_rr_small_f64(tlsq_handle h, const double* B, const double* Hg, int64_
     if (!B || !Hg || !C || !lam || !status || p < 1 || p > 32 || nt < 0) return set_err(h, TLSQ_ERR_ARG, "k_rr_small: bad argument (p <= 32)");
     return launch_rr_small_only(h, B, Hg, C, lam, status, p, std::min(nt, p), tau2);
 }
+int tlsq_k_op_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, const double* X, int64_t p, double* Y) {
+    TLSQ_TRY(check_handle(h));
+    if (!Z || !X || !Y || M <= 0 || N <= 0 || p <= 0 || ldZ < M) return set_err(h, TLSQ_ERR_ARG, "k_op_gram_f32: bad arguments");
+    for (int64_t c0 = 0; c0 < p; c0 += 96)
+        TLSQ_TRY(op_gram_f32(h, Z, ldZ, M, N, X + (size_t)c0 * N, N, Y + (size_t)c0 * N, N, std::min<int64_t>(96, p - c0)));
+    return TLSQ_OK;
+}
 int tlsq_k_gram_f32(tlsq_handle h, const float* Z, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG, int mfma32) {
     TLSQ_TRY(check_handle(h));
     if (!Z || !G || M < 0 || N <= 0 || ldZ < M || ldG < N) return set_err(h, TLSQ_ERR_ARG, "k_gram_f32: bad arguments");

@@ -107,8 +107,8 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
     X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
     X(NO_CERT_OVERLAP) X(NO_FUSED_DEFLATE)                                                                                 \
-    X(NO_RR_FAST) X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(NO_CHOL) X(NO_SYMM_MFMA)             \
-    X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(HOOK_SKETCH) X(OVERLAP_CHUNKS)    \
+    X(NO_RR_FAST) X(NO_GX_REUSE) X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(NO_CHOL) X(NO_SYMM_MFMA)             \
+    X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS)    \
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
@@ -269,6 +269,9 @@ int tsmm_sel(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, 
 // Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
 int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t p);
+// Y (N x p, fp64) = Z'(Z X) for an fp32 panel on the fp32 MFMA (fp64 fold-in), p <= 96: the large-mode operator product
+int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, double* Y,
+                int64_t ldy, int64_t p);
 // the Gram of a K-contiguous operand as plan / per-chunk launch / reduction (gemm.hip)
 struct GramPlan {
     int64_t N = 0, K = 0, nti = 0, nsplit_o = 1, nsplit_d = 1, kchunk_o = 0, kchunk_d = 0;

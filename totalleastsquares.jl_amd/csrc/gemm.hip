@@ -931,10 +931,12 @@ constexpr int FTK = 32;             // rows of Z per stage
 constexpr int FLDK = FTK + 4;       // floats per panel column: (36 r + 4 g) distinct multiples of 4 mod 64 over a quarter wave
 constexpr int FPANEL = 128 * FLDK;  // floats per panel (4 panels = 73.7 KB)
 
+// (Zb, ldb, Nb: the matrix whose columns j0.. form the second operand - Z itself for the Gram matrix, the M x 128 fp32 panel
+//  T for the skinny product Z'T of the large-mode operator, k_zt_f32mfma below)
 template <bool FULL>
 __device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t ld, double* __restrict__ Cz, int64_t ldc,
                                             int64_t N, int64_t kbeg, int64_t kend, int64_t i0, int64_t j0,
-                                            float* __restrict__ smem) {
+                                            float* __restrict__ smem, const float* __restrict__ Zb, int64_t ldb, int64_t Nb) {
     constexpr int SL = 2;   // 4-element slots per thread and panel (128 columns x 8 quads / 512 threads)
     const int nstage = (kend > kbeg) ? (int)((kend - kbeg + FTK - 1) / FTK) : 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -958,7 +960,7 @@ __device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t
         sr[s] = e >> 3;
         sk[s] = (e & 7) * 4;
         pa[s] = Z + kbeg + sk[s] + (i0 + sr[s]) * ld;
-        pb[s] = Z + kbeg + sk[s] + (j0 + sr[s]) * ld;
+        pb[s] = Zb + kbeg + sk[s] + (j0 + sr[s]) * ldb;
         so[s] = sr[s] * FLDK + sk[s];
     }
     const int oa = (wi * 64 + fr) * FLDK + 4 * fk, ob = (wj * 32 + fr) * FLDK + 4 * fk;
@@ -985,7 +987,7 @@ __device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t
             const int64_t c_ = ((i) < SL ? i0 : j0) + sr[u_];                                          \
             const float* p_ = ((i) < SL ? pa[u_] : pb[u_]) + (koff);                                   \
             f4 v_;                                                                                     \
-            for (int x_ = 0; x_ < 4; ++x_) v_[x_] = (c_ < N && k_ + x_ < kend) ? p_[x_] : 0.f;         \
+            for (int x_ = 0; x_ < 4; ++x_) v_[x_] = (c_ < ((i) < SL ? N : Nb) && k_ + x_ < kend) ? p_[x_] : 0.f; \
             if ((i) < SL) ra[u_] = v_;                                                                 \
             else rb[u_] = v_;                                                                          \
         }                                                                                              \
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t i = i0 + wi * 64 + a * 16 + 4 * fk + r;
-                if (FULL || (i < N && j < N)) Cz[j + i * ldc] = acc[a][b][r];
+                if (FULL || (i < N && j < Nb)) Cz[j + i * ldc] = acc[a][b][r];
             }
         }
 }
@@ -1095,8 +1097,185 @@ __global__ __launch_bounds__(512) void k_gram_f32mfma(const float* __restrict__ 
     const int64_t i0 = (int64_t)ti * TI, j0 = (int64_t)tj * TJ;
     double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
     // (two kernels rather than one branch: register pressure)
-    if (ALLFULL) gram32_body<true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
-    else gram32_body<false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem);
+    if (ALLFULL) gram32_body<true>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem, Z, ld, N);
+    else gram32_body<false>(Z, ld, Cz, ldc, N, kbeg, kend, i0, j0, smem, Z, ld, N);
+}
+
+// ---- the large-mode operator G X = Z'(Z X) for fp32 panels on the fp32 MFMA (the sketch of the randomized hook, C5) ----------
+// Both halves at twice the rate of the fp64 MFMA the widening kernels (k_tsmm<float>, the 128 x 128-tile GEMM) run on:
+//   T32 (M x lw, fp32) = Z X      k_tsmm_f32: the layout of k_tsmm (A fragments of Z straight from global memory, four waves
+//                                 split K), v_mfma_f32_16x16x4_f32, the fp32 sums folded into fp64 every 64 columns of Z
+//   Y (N x p, fp64)   = Z' T32    k_zt_f32mfma: the Gram kernel's pipeline with T32 as the second operand (one 128-column
+//                                 tile of it), K split over the rows, fp64 fold-in every 32 rows, slabs + k_zt_reduce
+// X is rounded to fp32 on the way in: 6e-8 relative, on top of the fp32 panel's own rounding.
+__global__ __launch_bounds__(256) void k_pack_w_f32(const double* __restrict__ W, int64_t ldw, int K, int r, int lw,
+                                                    float* __restrict__ Wt) {
+    const int total = K * lw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e % lw, k = e / lw;
+        Wt[e] = j < r ? (float)W[(size_t)k + (size_t)j * ldw] : 0.f;
+    }
+}
+
+template <int NCT, int RT>
+__global__ __launch_bounds__(256) void k_tsmm_f32(const float* __restrict__ Z, int64_t ldz, const float* __restrict__ Wt,
+                                                  float* __restrict__ Tout, int64_t ldt, int64_t M, int K) {
+    constexpr int LW = 16 * NCT;
+    __shared__ double sR[4 * RT * NCT * 256];   // [w][t][c][reg][lane]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * (16 * RT);
+    d4 acc[RT][NCT];
+    f4 a32[RT][NCT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            acc[t][c] = d4{0.0, 0.0, 0.0, 0.0};
+            a32[t][c] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float* zrow[RT];
+    bool rok[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t row = r0 + 16 * t + fr;
+        rok[t] = row < M;
+        zrow[t] = Z + (rok[t] ? row : 0);
+    }
+    const int nks = (K + 3) / 4;
+    const int per = (nks + 3) / 4;
+    const int ks0 = w * per, ks1 = (ks0 + per < nks) ? ks0 + per : nks;
+    int trips = 0;
+    for (int ksb = ks0; ksb < ks1; ksb += 4) {
+        float fa[4][RT], fb[4][NCT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kg = (ksb + u) * 4 + fk;
+            const bool kok = (ksb + u < ks1) && kg < K;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) fa[u][t] = (rok[t] && kok) ? zrow[t][(int64_t)kg * ldz] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) fb[u][c] = kok ? Wt[(size_t)kg * LW + c * 16 + fr] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    a32[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][t], fb[u][c], a32[t][c], 0, 0, 0);
+        if ((++trips & 3) == 0) {   // 64 columns of Z summed in fp32: fold
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[t][c][q] += (double)a32[t][c][q];
+                    a32[t][c] = f4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sR[(((w * RT + t) * NCT + c) * 4 + q) * 64 + lane] = acc[t][c][q] + (double)a32[t][c][q];
+    __syncthreads();
+    for (int o = tid; o < RT * NCT * 256; o += 256) {
+        const int l = o & 63, q = (o >> 6) & 3, tc = o >> 8;
+        const int t = tc / NCT, c = tc % NCT;
+        double sum = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) sum += sR[(((ww * RT + t) * NCT + c) * 4 + q) * 64 + l];
+        const int64_t row = r0 + 16 * t + 4 * (l >> 4) + q;   // v_mfma_f32_16x16x4_f32: column j = lane & 15, rows 4 (lane >> 4) + reg
+        const int col = c * 16 + (l & 15);
+        if (row < M) Tout[row + (int64_t)col * ldt] = (float)sum;
+    }
+}
+
+// work items: (K split z, 128-column tile of Z), one 128 x 128 output tile each: slab[z][j + i 128] = (Z' T32)[i, j]
+template <bool ALLFULL>
+__global__ __launch_bounds__(512) void k_zt_f32mfma(const float* __restrict__ Z, int64_t ld, const float* __restrict__ T32,
+                                                    int64_t ldt, double* __restrict__ slab, int64_t N, int64_t K,
+                                                    int64_t kchunk, int64_t slab_stride, int ntiles, int nsplit) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FPANEL];
+    const int64_t nwork = (int64_t)ntiles * nsplit;
+    const int64_t cpx = (nwork + 7) / 8;
+    const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
+    if (item >= nwork) return;
+    const int z = (int)(item / ntiles), ti = (int)(item % ntiles);
+    const int64_t kbeg = (int64_t)z * kchunk;
+    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    double* __restrict__ Cz = slab + (int64_t)z * slab_stride;
+    if (ALLFULL) gram32_body<true>(Z, ld, Cz, 128, N, kbeg, kend, (int64_t)ti * TI, 0, smem, T32, ldt, 128);
+    else gram32_body<false>(Z, ld, Cz, 128, N, kbeg, kend, (int64_t)ti * TI, 0, smem, T32, ldt, 128);
+}
+
+// Y[i + j ldy] = sum over the K splits of slab[z][j + i 128]  (i < N, j < p), fixed order
+__global__ __launch_bounds__(256) void k_zt_reduce(const double* __restrict__ slab, int64_t slab_stride, int nsplit,
+                                                   double* __restrict__ Y, int64_t ldy, int64_t N, int p) {
+    const int64_t total = N * p;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e % N;
+        const int j = (int)(e / N);
+        double sacc = 0.0;
+        for (int z = 0; z < nsplit; ++z) sacc += slab[(int64_t)z * slab_stride + j + i * 128];
+        Y[i + (int64_t)j * ldy] = sacc;
+    }
+}
+
+// Y (N x p, ld ldy, fp64) = Z'(Z X) for an fp32 panel Z (M x N, ld ldz) and X (N x p, ld ldx, fp64), p <= 96
+int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, double* Y,
+                int64_t ldy, int64_t p) {
+    if (p <= 0 || M <= 0) return TLSQ_OK;
+    if (p > 96) return set_err(h, TLSQ_ERR_ARG, "op_gram_f32: p > 96");
+    const int nct = (int)((p + 15) / 16), lw = 16 * nct;
+    void *wt, *t32;
+    TLSQ_TRY(ws_get(h, WS_OPW, (size_t)N * lw * 8, &wt));
+    TLSQ_TRY(ws_get(h, WS_OPT, (size_t)M * 128 * 4 + 256, &t32));
+    hipLaunchKernelGGL(k_pack_w_f32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, X, ldx,
+                       (int)N, (int)p, lw, (float*)wt);
+    {
+        const dim3 grid((unsigned)((M + 31) / 32));
+#define TSF_LAUNCH(NC)                                                                                              \
+    hipLaunchKernelGGL((k_tsmm_f32<NC, 2>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, M, (int)N)
+        switch (nct) {
+            case 1: TSF_LAUNCH(1); break;
+            case 2: TSF_LAUNCH(2); break;
+            case 3: TSF_LAUNCH(3); break;
+            case 4: TSF_LAUNCH(4); break;
+            case 5: TSF_LAUNCH(5); break;
+            default: TSF_LAUNCH(6); break;
+        }
+#undef TSF_LAUNCH
+    }
+    TLSQ_HIP(h, hipGetLastError());
+    // Z' T32: one 128-column tile of Z per work item, the rows split so that ~512 items (two rounds over the CUs) exist
+    const int64_t ntiles = (N + TI - 1) / TI;
+    int64_t nsplit = std::max<int64_t>(1, (512 + ntiles - 1) / ntiles);
+    const int64_t maxsplit = std::max<int64_t>(1, (M + 8 * FTK - 1) / (8 * FTK));
+    nsplit = std::min(nsplit, maxsplit);
+    int64_t kchunk = (M + nsplit - 1) / nsplit;
+    kchunk = (kchunk + FTK - 1) / FTK * FTK;
+    nsplit = (M + kchunk - 1) / kchunk;
+    const int64_t slab_stride = N * 128;
+    void* slab;
+    TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * 8, &slab));
+    const int64_t nwork = ntiles * nsplit, cpx = (nwork + 7) / 8;
+    const bool vec_ok = (ldz % 4) == 0 && (M % 4) == 0 && (reinterpret_cast<uintptr_t>(Z) % 16) == 0;
+    const bool allfull = vec_ok && (N % TI) == 0 && (M % FTK) == 0 && (kchunk % FTK) == 0;
+    if (allfull)
+        hipLaunchKernelGGL(k_zt_f32mfma<true>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ldz, (const float*)t32, M,
+                           (double*)slab, N, M, kchunk, slab_stride, (int)ntiles, (int)nsplit);
+    else
+        hipLaunchKernelGGL(k_zt_f32mfma<false>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ldz, (const float*)t32, M,
+                           (double*)slab, N, M, kchunk, slab_stride, (int)ntiles, (int)nsplit);
+    hipLaunchKernelGGL(k_zt_reduce, dim3((unsigned)std::min<int64_t>((N * p + 255) / 256, 2048)), dim3(256), 0, h->stream,
+                       (const double*)slab, slab_stride, (int)nsplit, Y, ldy, N, (int)p);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 static int gram_f32mfma(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K) {

@@ -217,6 +217,16 @@ struct GramOp {
 static int op_apply(Handle* h, const GramOp& op, int64_t N, const double* X, double* Y, int64_t p) {
     if (p <= 0) return TLSQ_OK;
     if (!op.implicit()) return launch_symm_skinny(h, op.G, N, X, Y, N, p);
+    // fp32 panels, blocks of more than 8 columns: both halves on the fp32 MFMA (gemm.hip, op_gram_f32) - the widening kernels
+    // below run on the fp64 MFMA at half the rate (narrow blocks, the Lanczos vectors, are bandwidth-bound either way)
+    if (op.z_f32 && p > 8 && !dev_is(DEV_NO_F32_SKINNY, '1')) {
+        for (int64_t c0 = 0; c0 < p; c0 += 96) {
+            const int64_t pc = std::min<int64_t>(96, p - c0);
+            TLSQ_TRY(op_gram_f32(h, (const float*)op.Z, op.ldZ, op.M, N, X + (size_t)c0 * N, N, Y + (size_t)c0 * N, N, pc));
+        }
+        TLSQ_TRY(comm_allreduce(h, Y, (size_t)N * p, ncclSum));
+        return TLSQ_OK;
+    }
     void* Tv;
     TLSQ_TRY(ws_get(h, WS_OPT, (size_t)op.M * std::min<int64_t>(p, 96) * 8, &Tv));
     for (int64_t c0 = 0; c0 < p; c0 += 96) {
@@ -516,6 +526,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     int64_t svp = 0;
     bool conv = false;
     double prev_maxres = 0.0;
+    bool gx_valid = false;    // WS_SGX holds G X for the block in WS_SX (see the top of the loop)
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
     bool cgs2_sticky = false;
     const bool no_onepass = dev_is(DEV_NO_ONEPASS, '1');
@@ -535,7 +546,12 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
         // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
         // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
-        TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
+        // (second and later steps: G X is already there - the Rayleigh-Ritz finish of the previous step formed it with the Ritz
+        //  vectors, GX = (G Q) S - as long as the block has not been re-ordered since: one product less per step, of six in
+        //  a step of the randomized hook, 1.4 ms each at 65536 x 4096)
+        if (gx_valid) TLSQ_HIP(h, hipMemcpyAsync(Q, GX, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+        else TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
+        gx_valid = false;
         const int64_t nt_step = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);   // leading columns treated as wanted
         {
             const int64_t nt = nt_step;
@@ -694,6 +710,10 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                 TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
                 TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
                                              (double*)X));
+                // ... and G X with it (two small launches against one operator product saved in the next step)
+                TLSQ_HIP(h, hipMemcpyAsync(XN, GX, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+                TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
+                                             (double*)GX));
             }
             for (int64_t i = 0; i < p; ++i) {
                 host[i] = th_sorted[i];
@@ -701,6 +721,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                 s.sigma[i] = sg_sorted[i];
             }
             std::iota(s.order.begin(), s.order.end(), 0);
+            gx_valid = !dev_is(DEV_NO_GX_REUSE, '1');
         }
         svp = 0;
         for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
@@ -1027,8 +1048,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // (the caller's E panel is the second buffer) and the factors of the previous A are kept, from which the returned E is
     // formed once after the loop.  Every plain call runs this way; the `hankel` flag (A is modified after the rebuild) and
     // the svd / opnorm hooks keep the classic sweeps with their E and Z double buffers.
+    // (the GPU form of the randomized hook only changes where V and the singular values come from: it runs E-free as well)
     const bool zmode = !no_zsweep && !no_fuse && !no_first && !ro.hankel && ro.iters >= 1 &&
-                       !(opts && (opts->svd_mode != TLSQ_SVD_FULL || opts->opnorm_mode != TLSQ_OPNORM_EXACT));
+                       !(opts && ((opts->svd_mode != TLSQ_SVD_FULL && opts->svd_mode != TLSQ_SVD_RANDOMIZED) ||
+                                  opts->opnorm_mode != TLSQ_OPNORM_EXACT));
     // ResolvedOpts::factors_out: the caller may pass A == nullptr; the panel is allocated the first time something needs it
     auto need_A = [&]() -> int {
         if (!A) {
@@ -1155,14 +1178,16 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
     const int force_implicit = [] { const char* e = dev_get(DEV_IMPLICIT_GRAM); return e ? atoi(e) : -1; }();
     const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
-    // The randomized hook in large mode (BASELINE config 5: `svd = rsvd`, src/robustPCA.jl:195-197, test/runtests.jl:388-398) as a
-    // pure sketch - from iteration 2 on nothing but products with the panel, G X = Z'(Z X), and opnorm(residual) as Lanczos on
-    // the operator R'R, no N x N Gram matrix - is wired (HOOK_SKETCH=1) but NOT the default below N = 8192: measured at
-    // 65536 x 4096 fp32 it takes 51 ms per iteration against 21 with the Gram matrix (eig 33 ms: the hook's two steps are six
-    // operator products of 80 GFLOP each on the fp64 MFMA - the skinny kernels widen the fp32 panel - where the Gram runs on
-    // the fp32 MFMA at twice the rate; opnorm 14 ms: ~30 Lanczos steps of two panel passes each).  What it needs to win:
-    // skinny products on the fp32 MFMA with fp64 fold-in, like k_gram_f32mfma.
-    const bool hook_sketch = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED && N > kFullEigMaxN && dev_is(DEV_HOOK_SKETCH, '1');
+    // The randomized hook in large mode (BASELINE config 5: `svd = rsvd`, src/robustPCA.jl:195-197, test/runtests.jl:388-398) is a
+    // sketch: from iteration 2 on nothing but products with the panel - Y = Z'(Z Omega), orthonormalisation, the power passes, the
+    // (sv + 10)-column Rayleigh quotient - and no N x N Gram matrix of Z (2 M N^2 flops: 12 ms of a 24 ms iteration at
+    // 65536 x 4096).  opnorm(residual), in the few iterations whose cost bound does not settle the test, still goes through the
+    // Gram matrix of R (Lanczos on the operator R'R needs ~100 steps of two panel passes: 46 ms).  Iteration 1 is the reference's
+    // full svd: the certified subspace solver on the Gram matrix.  Default for fp32 panels, whose operator products run on the
+    // fp32 MFMA (op_gram_f32); fp64 panels keep the Gram matrix below N = 8192 (their skinny products are not faster than it)
+    // unless HOOK_SKETCH=1.
+    const bool hook_sketch = opts && opts->svd_mode == TLSQ_SVD_RANDOMIZED && N > kFullEigMaxN &&
+                             (Prec<T>::f32 ? !dev_is(DEV_HOOK_SKETCH, '0') : dev_is(DEV_HOOK_SKETCH, '1'));
     auto panel_op = [&](const T* P) {
         GramOp o;
         o.Z = P;
@@ -2133,7 +2158,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // the reference's to 1e-6); when only the decision matters 1e-6 is enough - a value within 1e-5 of tol is
             // re-evaluated to full accuracy below (residual spectra are flat: 154 -> ~110 Lanczos steps at N = 4096)
             const double cost_rel = want_exact_cost ? 1e-8 : 1e-6;
-            if (implicit_gram || hook_sketch) {
+            if (implicit_gram) {
                 TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, cost_rel, &rn, stop_sigma));
             } else {                                                                               // :225
                 void* Gc;
@@ -2160,7 +2185,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             hbm_other += panel_bytes;
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
-                if (implicit_gram || hook_sketch) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
+                if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
                 else TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[cost_gslot].p, N, 1e-13, &rn, &sweeps));
                 cost = rn / d_norm;
             }
