@@ -11,10 +11,19 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+BIG = False   # --big: panels of 200 ... 512 columns, ranks up to 40 (warm subspace blocks of up to 50 columns, the fused
+              # Rayleigh-Ritz kernel on blocks of up to 32); ~20 s of LAPACK per case on the host
+
+
 def make_case(rng):
-    M = int(rng.choice([5, 8, 20, 50, 51, 100, 300, 600, 1500]))
-    N = int(rng.choice([3, 4, 5, 8, 17, 40, 64, 100, 130]))
-    r = int(rng.integers(1, max(2, min(M, N) // 3 + 1)))
+    if BIG:
+        M = int(rng.choice([1500, 3000, 5000]))
+        N = int(rng.choice([200, 256, 384, 512]))
+        r = int(rng.integers(2, 41))
+    else:
+        M = int(rng.choice([5, 8, 20, 50, 51, 100, 300, 600, 1500]))
+        N = int(rng.choice([3, 4, 5, 8, 17, 40, 64, 100, 130]))
+        r = int(rng.integers(1, max(2, min(M, N) // 3 + 1)))
     noise = float(rng.choice([0.0, 0.0, 1e-6, 1e-3, 1e-1]))
     frac = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
     scale = float(rng.choice([1e-3, 1.0, 1e4]))
@@ -73,6 +82,10 @@ def run_cases(eng, seed, ncase, budget_s=300.0, verbose=True):
 
 if __name__ == "__main__":
     import tlsq_amd
+    tlsq_amd.dev_from_env()
+    if "--big" in sys.argv:
+        sys.argv.remove("--big")
+        BIG = True
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 150
     eng = tlsq_amd.Engine(0)

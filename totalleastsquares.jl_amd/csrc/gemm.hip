@@ -1393,6 +1393,82 @@ __global__ __launch_bounds__(256) void k_gather_pack_w(const double* __restrict_
     }
 }
 
+// The same product with W = V[:, sel] diag(w) read straight from V (K x ., ld K, K a multiple of 4): no packed copy and no
+// second launch. Each lane reads four consecutive k of its column at once (k = 16*trip + 4*fk + u for the MFMA of step u; the
+// sum over k does not care about the assignment as long as both operands use it), so a trip touches as many cache lines
+// of V as it would of the packed panel. Vs (K x r) receives V[:, sel], spread over the first workgroups.
+template <typename TA, int NCT, int RT>
+__global__ __launch_bounds__(256) void k_tsmm_selv(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ V,
+                                                   SelWeights sw, double* __restrict__ Vs, double* __restrict__ Tout,
+                                                   int64_t ldt, int64_t M, int K, int r) {
+    __shared__ double sR[4 * RT * NCT * 256];   // [w][t][c][reg][lane]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * (16 * RT);
+    if (Vs)
+        for (int e = blockIdx.x * 256 + tid; e < K * r; e += gridDim.x * 256) Vs[e] = V[(size_t)sw.sel[e / K] * K + (e % K)];
+    d4 acc[RT][NCT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[t][c] = d4{0.0, 0.0, 0.0, 0.0};
+    const TA* zrow[RT];
+    bool rok[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t row = r0 + 16 * t + fr;
+        rok[t] = row < M;
+        zrow[t] = Z + (rok[t] ? row : 0);
+    }
+    const double* vcol[NCT];
+    double wj[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int j = c * 16 + fr;
+        vcol[c] = V + (size_t)(j < r ? sw.sel[j] : 0) * K;
+        wj[c] = j < r ? sw.w[j] : 0.0;
+    }
+    const int nks = K / 4;
+    const int per = (nks + 3) / 4;
+    const int ks0 = w * per, ks1 = (ks0 + per < nks) ? ks0 + per : nks;
+    for (int ksb = ks0; ksb < ks1; ksb += 4) {
+        const bool kok = ksb + fk < ks1;
+        const int kb = (ksb + fk) * 4;
+        double fa[4][RT];
+        d4 fb[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) fb[c] = kok ? *(const d4*)(vcol[c] + kb) : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) fa[u][t] = (rok[t] && kok) ? (double)zrow[t][(int64_t)(kb + u) * ldz] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u][t], fb[c][u] * wj[c], acc[t][c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sR[(((w * RT + t) * NCT + c) * 4 + q) * 64 + lane] = acc[t][c][q];
+    __syncthreads();
+    for (int o = tid; o < RT * NCT * 256; o += 256) {
+        const int l = o & 63, q = (o >> 6) & 3, tc = o >> 8;
+        const int t = tc / NCT, c = tc % NCT;
+        double sum = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) sum += sR[(((ww * RT + t) * NCT + c) * 4 + q) * 64 + l];
+        const int64_t row = r0 + 16 * t + (l >> 4) + 4 * q;
+        const int col = c * 16 + (l & 15);
+        if (row < M && col < r) Tout[row + (int64_t)col * ldt] = sum;
+    }
+}
+
 template <typename TA, int NCT, int RT>
 __global__ __launch_bounds__(256) void k_tsmm(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ Wt,
                                               double* __restrict__ Tout, int64_t ldt, int64_t M, int K, int r) {
@@ -1466,6 +1542,21 @@ static int tsmm_impl(Handle* h, const void* Z, int z_f32, int64_t ldz, const dou
     if (r > 96) return set_err(h, TLSQ_ERR_ARG, "tsmm: r > 96");
     const int nct = (int)((r + 15) / 16);
     const int lw = 16 * nct;
+    if (!W && (K & 3) == 0 && nct <= 2 && !dev_is(DEV_NO_TSMM_SELV, '1')) {
+        const bool tall = M >= 65536;
+        const dim3 grid((unsigned)((M + (tall ? 64 : 32) - 1) / (tall ? 64 : 32)));
+#define TSV_LAUNCH(TA, NC, RTT)                                                                                     \
+    hipLaunchKernelGGL((k_tsmm_selv<TA, NC, RTT>), grid, dim3(256), 0, h->stream, (const TA*)Z, ldz, V, *sw, Vs, Tout, ldt, \
+                       M, (int)K, (int)r)
+#define TSV_TYPE(TA)                                                              \
+    if (nct == 1) { if (tall) TSV_LAUNCH(TA, 1, 4); else TSV_LAUNCH(TA, 1, 2); } \
+    else { if (tall) TSV_LAUNCH(TA, 2, 4); else TSV_LAUNCH(TA, 2, 2); }
+        if (z_f32) { TSV_TYPE(float) } else { TSV_TYPE(double) }
+#undef TSV_TYPE
+#undef TSV_LAUNCH
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
     void* wt;
     TLSQ_TRY(ws_get(h, WS_OPW, (size_t)K * lw * 8, &wt));
     if (W)
