@@ -39,6 +39,35 @@ def make_case(rng):
     return D, kw, f"{M}x{N} r={r} noise={noise} frac={frac} scale={scale}"
 
 
+def reference_unstable(D, kw, err_gpu):
+    """A mismatch is only a finding if the reference's own trajectory is stable on that input.  Replays the case with LAPACK's
+    other dense driver (gesvd) and with one ulp added to Z at k = 5 (see tools/knife_edge.py): when those runs end as far from
+    the gesdd run as the GPU did (or part ways in their counts), the input is 'reference-unstable' - a run that does not
+    converge and amplifies rounding differences - and says nothing about the implementation.  -> (unstable, description)"""
+    from oracle import rpca_oracle as O
+    import scipy.linalg as sla
+    A0, E0, _, _, i0 = O.rpca(D, **kw)
+    dn = max(np.linalg.norm(D), 1e-300)
+    out = []
+    cnt = [0]
+
+    def gesvd(Z, sv):
+        return sla.svd(Z, full_matrices=False, lapack_driver="gesvd", check_finite=False)
+
+    def ulp(Z, sv):
+        cnt[0] += 1
+        return O._svd_full(np.nextafter(Z, np.inf) if cnt[0] == 4 else Z)   # (the hook sees k = 2, 3, ...: the 4th call is k = 5)
+
+    unstable = False
+    for name, f in (("gesvd", gesvd), ("Z+1ulp@k=5", ulp)):
+        A, E, _, _, info = O.rpca(D, svd=f, **kw)
+        kd = next((i + 1 for i, (a, b) in enumerate(zip(info.svp_hist, i0.svp_hist)) if a != b), None)
+        ea = np.linalg.norm(A - A0) / dn
+        out.append(f"{name}: counts differ at k={kd}, errA={ea:.1e}")
+        unstable = unstable or kd is not None or ea > 0.3 * err_gpu
+    return unstable, "; ".join(out)
+
+
 def run_cases(eng, seed, ncase, budget_s=300.0, verbose=True):
     """returns (cases_run, trajectory_mismatches, exceptions, worst_err)"""
     from oracle import rpca_oracle as O
@@ -73,6 +102,11 @@ def run_cases(eng, seed, ncase, budget_s=300.0, verbose=True):
             if verbose:
                 print(f"case {it} {desc} {kw}: iters {rep.iters_done}/{io.iters_done} sv {sv}/{svo} "
                       f"first svp diff at k={k} errA={ea:.1e} errE={ee:.1e}", flush=True)
+                try:
+                    un, why = reference_unstable(D, kw, max(ea, ee))
+                    print(f"    reference-unstable input: {un}  (LAPACK against itself - {why})", flush=True)
+                except Exception as e:   # noqa: BLE001
+                    print("    (stability check failed:", e, ")", flush=True)
         if time.time() - t0 > budget_s:
             if verbose:
                 print("time budget reached at case", it, flush=True)

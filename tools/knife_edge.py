@@ -10,7 +10,7 @@ moved by one unit in the last place at one early iteration.  For each variant it
 the iterations and the first iteration whose count differs from the reference run.  If two LAPACK variants that are
 equally "the reference" part ways, the trajectory past that point is not a property of the algorithm and no implementation
 can be held to it; the parity claim for such a run is the distance of A and E at the end, relative to ||D||.
-    python tools/knife_edge.py [seed] [case]
+    python tools/knife_edge.py [seed] [case] [--big]
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,6 +41,9 @@ def run(D, kw, decomp):
 
 
 def main():
+    if "--big" in sys.argv:   # the case list of `fuzz_parity.py --big`
+        sys.argv.remove("--big")
+        F.BIG = True
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 202
     idx = int(sys.argv[2]) if len(sys.argv) > 2 else 15
     D, kw, desc = case(seed, idx)
