@@ -293,7 +293,9 @@ int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t 
  * Julia's global RNG (:289), which no other program can reproduce; with q0 == NULL the library draws seeded
  * normals (opts->seed).  Returns TLSQ_MAXITER when a component used all `iters` iterations without dq < tol (the
  * `@warn "Reached maximum number of iterations"` of :306).  The entrywise averages need d*N < 2^31.
- * With a communicator (tlsq_comm_init) X holds this rank's COLUMNS; only TLSQ_GA_MEAN is available then. */
+ * With a communicator (tlsq_comm_init) X holds this rank's COLUMNS (contiguous blocks in rank order: the entrywise averages
+ * break ties by the column index within the whole row); a group handle (tlsq_create_multi) splits the columns of a host
+ * matrix itself (at least 64 per GPU, otherwise the first GPU alone).  All three averages are available on shards. */
 enum { TLSQ_GA_MEAN = 0, TLSQ_GA_TRIMMED_MEAN = 1, TLSQ_GA_MEDIAN = 2 };
 typedef struct tlsq_ga_opts {
     double  tol;       /* NaN -> 1e-7   (:286) */

@@ -62,6 +62,18 @@ def main():
     Qo = G.rpca_ga(X, r, q0=q0, info=ginfo)
     res["ga_iters"] = (used, ginfo.iters)
     res["ga_err"] = float(np.abs(Qs - Qo).max())
+    # --- the entrywise averages on column shards: a radix select of whole rows with summed histograms (:322-362)
+    import warnings
+    Xr = X.copy()
+    Xr[:, 7] = Xr[:, 400]                                    # ties across the shards: the column index decides
+    Xr[:, rng.random(Ng) < 0.02] *= 15.0
+    for name, fn in (("trimmed_mean", G.entrywise_trimmed_mean), ("median", G.entrywise_median)):
+        Qs, used = rpca_ga_sharded(Xr[:, clo:chi], 2, q0, allreduce, iters=40, average=name, col_off=clo, N_glob=Ng)
+        ginfo = G.GaInfo()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Qo = G.rpca_ga(Xr, 2, q0=q0, info=ginfo, mu=fn, iters=40)
+        res["ga_" + name] = (used, ginfo.iters, float(np.abs(Qs - Qo).max()))
     # --- time-window sharded lowrankfilter (halo + all-reduce of anti-diagonal sums and counts) == oracle
     from oracle.sharded import lowrankfilter_sharded
     ys, nz = O.synth_series(700, seed=2)

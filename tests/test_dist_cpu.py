@@ -31,6 +31,9 @@ def test_two_rank_gloo_row_sharding(tmp_path):
         assert res["iters"][0] == res["iters"][1] and res["svp_same"] and res["sv"][0] == res["sv"][1]
         assert res["relA"] < 1e-8 and res["relE"] < 1e-8, res
         assert res["ga_iters"][0] == res["ga_iters"][1] and res["ga_err"] < 1e-10, res
+        for name in ("trimmed_mean", "median"):
+            used, want, err = res["ga_" + name]
+            assert used == want and err < 1e-10, (name, res["ga_" + name])
         assert res["lrf_err"] < 1e-8, res
         assert res["tsqr_err"] < 1e-14 and res["tsqr_same_on_all_ranks"], res
 

@@ -205,6 +205,38 @@ def test_loopback_lowrankfilter_time_windows(loopback):
     assert g2.dtype == np.float32 and relerr(g2.astype(np.float64), g1.astype(np.float64)) < 1e-4
 
 
+@pytest.mark.parametrize("mode", [None, "entrywise_trimmed_mean", "entrywise_median"])
+@pytest.mark.parametrize("d,N,r", [(10, 1000, 3), (40, 901, 2), (130, 2000, 2)])
+def test_loopback_rpca_ga_on_column_shards(loopback, mode, d, N, r):
+    """rpca_ga on a group handle (src/robustPCA.jl:255-310): contiguous blocks of the observations per rank, the weighted
+    sums all-reduced (mean), and for the entrywise averages (:322-362) a radix select of whole rows across the shards -
+    composite keys with the column index of the WHOLE row, histograms summed over the ranks in every pass - so that the
+    element the stable sortperm of the full row would pick is found without gathering anything.  Held to the oracle and to
+    the one-GPU solve: same iterations per component, same components."""
+    import warnings
+    from oracle import ga_oracle as G
+    plain, multi, n = loopback
+    rng = np.random.default_rng(d + N)
+    Qt = np.linalg.qr(rng.standard_normal((d, r)))[0]
+    X = Qt @ (rng.standard_normal((r, N)) * np.linspace(5.0, 2.0, r)[:, None]) + 0.05 * rng.standard_normal((d, N))
+    out = rng.random(N) < 0.01
+    X[:, out] += 20.0 * rng.standard_normal((d, int(out.sum())))
+    X[:, 5] = X[:, 3]          # duplicate observations: ties in every row, resolved by the column index
+    q0 = rng.standard_normal((d, r))
+    kw = dict(q0=q0, iters=60, return_report=True)
+    if mode:
+        kw["mu"] = mode
+    info = G.GaInfo()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = G.rpca_ga(X, r, q0=q0, info=info, iters=60, **({"mu": getattr(G, mode)} if mode else {}))
+        got1, rep1 = plain.rpca_ga(X, r, **kw)
+        got, rep = multi.rpca_ga(X, r, **kw)
+    assert rep["iters"] == rep1["iters"] == info.iters
+    assert rep["status"] == rep1["status"]
+    assert np.abs(got - want).max() < 1e-9 and np.abs(got - got1).max() < 1e-9
+
+
 def test_loopback_large_panel_shards_fused_rebuild_sweep():
     """Two ranks whose shards are large panels (>= 2^26 entries each): the fused rebuild + update + shrink sweep, the
     Frobenius shortcut with its all-reduced partial sums and the next iteration's Gram queued behind the sweep - with

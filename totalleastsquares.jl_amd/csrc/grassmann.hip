@@ -474,7 +474,7 @@ struct GaSel {
 template <int NT>
 __global__ __launch_bounds__(256) void k_ga_sel_hist(const double* __restrict__ keys, int64_t N, const GaSel* __restrict__ sel,
                                                      unsigned int* __restrict__ hist, int pass,
-                                                     const GaState* __restrict__ st) {
+                                                     const GaState* __restrict__ st, unsigned int col_off) {
     if (st && st->converged) return;
     __shared__ unsigned int sh[NT * 256];
     const int row = blockIdx.y;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void k_ga_sel_hist(const double* __restrict__ 
                 const bool cand = pass == 0 || (u >> sh_hi) == (my[t].pkey >> sh_hi);
                 if (cand) atomicAdd(&sh[t * 256 + (int)((u >> (8 * (7 - pass))) & 255ull)], 1u);
             } else if (u == my[t].pkey) {
-                const unsigned int i32 = (unsigned int)n;
+                const unsigned int i32 = (unsigned int)n + col_off;   // (column shards: the index within the whole row)
                 const int q = pass - 8, sh_hi = 8 * (4 - q);
                 const bool cand = q == 0 || (i32 >> sh_hi) == (my[t].pidx >> sh_hi);
                 if (cand) atomicAdd(&sh[t * 256 + (int)((i32 >> (8 * (3 - q))) & 255u)], 1u);
@@ -508,13 +508,15 @@ __global__ __launch_bounds__(256) void k_ga_sel_hist(const double* __restrict__ 
 
 // one workgroup per (row, target): the bin that holds rank k, fixed into the state; the histogram is cleared for the
 // next pass
+// (column shards: `tot` holds the histograms summed over the ranks - as doubles, exact below 2^53 - and `hist` only has to be
+//  cleared)
 __global__ __launch_bounds__(256) void k_ga_sel_pick(unsigned int* __restrict__ hist, GaSel* __restrict__ sel, int pass,
-                                                     const GaState* __restrict__ st) {
+                                                     const GaState* __restrict__ st, const double* __restrict__ tot) {
     if (st && st->converged) return;
     __shared__ unsigned long long cum[256];
     const int rt = blockIdx.x, t = threadIdx.x;
     unsigned int* hh = hist + (size_t)rt * 256;
-    const unsigned int mine = hh[t];
+    const unsigned long long mine = tot ? (unsigned long long)tot[(size_t)rt * 256 + t] : (unsigned long long)hh[t];
     cum[t] = mine;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {   // inclusive scan
@@ -549,29 +551,38 @@ __global__ __launch_bounds__(256) void k_ga_sel_init(GaSel* __restrict__ sel, in
     }
 }
 
+// the local histograms as doubles for the sum all-reduce of a column-sharded selection
+__global__ __launch_bounds__(256) void k_ga_hist_f64(const unsigned int* __restrict__ hist, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)hist[i];
+}
+
 // mask[j + n*d] = 1 for the columns whose stable rank within row j lies in [lo, hi): composite (value, column) at or
 // after the element of rank lo (sel[2j]) and before the element of rank hi (sel[2j+1]; no upper limit when hi == N)
 __global__ __launch_bounds__(256) void k_ga_mask(const double* __restrict__ keys, const GaSel* __restrict__ sel, int d,
-                                                 int64_t N, int has_hi, uint8_t* __restrict__ mask) {
+                                                 int64_t N, int has_hi, uint8_t* __restrict__ mask, unsigned int col_off) {
     const int64_t total = (int64_t)d * N, stride = (int64_t)gridDim.x * 256;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
         const int64_t j = e / N, n = e - j * N;
         const unsigned long long u = ga_sortable(keys[e]);
         const GaSel a = sel[2 * j], b = sel[2 * j + 1];
-        const bool ge_lo = u > a.pkey || (u == a.pkey && (unsigned int)n >= a.pidx);
-        const bool lt_hi = !has_hi || u < b.pkey || (u == b.pkey && (unsigned int)n < b.pidx);
+        const unsigned int ng = (unsigned int)n + col_off;
+        const bool ge_lo = u > a.pkey || (u == a.pkey && ng >= a.pidx);
+        const bool lt_hi = !has_hi || u < b.pkey || (u == b.pkey && ng < b.pidx);
         mask[n * d + j] = (ge_lo && lt_hi) ? 1 : 0;
     }
 }
 // s[j] = sign(w[m]) * U[j, m],  m = the column at sorted position N/2 (1-based) of row j            (:357-358)
+// (column shards: the rank that owns column m delivers the value, the others zero - a sum all-reduce follows)
 __global__ __launch_bounds__(256) void k_ga_pick(const GaSel* __restrict__ sel, const double* __restrict__ w,
                                                  const double* __restrict__ U, int d, int64_t N,
-                                                 double* __restrict__ sbuf, const GaState* __restrict__ st) {
+                                                 double* __restrict__ sbuf, const GaState* __restrict__ st,
+                                                 unsigned int col_off) {
     if (st && st->converged) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < d) {
-        const int64_t m = (int64_t)sel[j].pidx;
-        sbuf[j] = ga_sign(w[m]) * U[m * d + j];
+        const int64_t m = (int64_t)sel[j].pidx - (int64_t)col_off;
+        sbuf[j] = (m >= 0 && m < N) ? ga_sign(w[m]) * U[m * d + j] : 0.0;
     }
 }
 
@@ -826,6 +837,9 @@ struct GaBuffers {
     double* keys_in = nullptr;
     GaSel* sel = nullptr;            // selection state, d x (1 or 2) targets
     unsigned int* sel_hist = nullptr;   // d x targets x 256 counters (kept zero between passes)
+    // column shards (a communicator on the handle): this rank holds the columns [col_off, col_off + N) of N_glob
+    int64_t col_off = 0, N_glob = 0;
+    double* hist_f64 = nullptr;      // the histograms as doubles for the all-reduce of a sharded selection
 };
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -875,9 +889,11 @@ int ga_alloc(Handle* h, int64_t d, int64_t N, int mode, int64_t hist_cap, bool n
         TLSQ_TRY(ws_get(h, WS_GA_KEYS, pn, &p));
         b->keys_in = (double*)p;
         const size_t sb = align256((size_t)d * 2 * sizeof(GaSel));
-        TLSQ_TRY(ws_get(h, WS_GA_IDX, sb + (size_t)d * 2 * 256 * 4, &p));
+        const size_t hb = (size_t)d * 2 * 256 * 4;
+        TLSQ_TRY(ws_get(h, WS_GA_IDX, sb + hb + (h->comm ? 2 * hb : 0), &p));
         b->sel = (GaSel*)p;
         b->sel_hist = (unsigned int*)((char*)p + sb);
+        if (h->comm) b->hist_f64 = (double*)((char*)p + sb + hb);
         TLSQ_HIP(h, hipMemsetAsync(b->sel_hist, 0, (size_t)d * 2 * 256 * 4, h->stream));
     }
     return TLSQ_OK;
@@ -892,14 +908,27 @@ int ga_select_rows(Handle* h, GaBuffers* b, int64_t d, int64_t N, int nt, int64_
     if (gx < 1) gx = 1;
     const int64_t cap = std::max<int64_t>(1, 4096 / std::max<int64_t>(d, 1));
     if (gx > cap) gx = cap;                           // ~4096 workgroups over all rows
+    // Column shards: the composite key carries the column index within the WHOLE row, every rank histograms its own
+    // columns, the histograms are summed over the ranks (d x nt x 256 counts per pass) and every rank picks the same digit:
+    // the selected element is the one the stable sortperm of the whole row would put at that rank.
+    const unsigned int off = (unsigned int)b->col_off;
+    const int nh = (int)(d * nt * 256);
     for (int pass = 0; pass < 12; ++pass) {
         if (nt == 2)
             hipLaunchKernelGGL(k_ga_sel_hist<2>, dim3((unsigned)gx, (unsigned)d), dim3(256), 0, h->stream, b->keys_in, N, b->sel,
-                               b->sel_hist, pass, st);
+                               b->sel_hist, pass, st, off);
         else
             hipLaunchKernelGGL(k_ga_sel_hist<1>, dim3((unsigned)gx, (unsigned)d), dim3(256), 0, h->stream, b->keys_in, N, b->sel,
-                               b->sel_hist, pass, st);
-        hipLaunchKernelGGL(k_ga_sel_pick, dim3((unsigned)(d * nt)), dim3(256), 0, h->stream, b->sel_hist, b->sel, pass, st);
+                               b->sel_hist, pass, st, off);
+        const double* tot = nullptr;
+        if (h->comm) {
+            hipLaunchKernelGGL(k_ga_hist_f64, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, h->stream, b->sel_hist,
+                               b->hist_f64, nh);
+            TLSQ_HIP(h, hipGetLastError());
+            TLSQ_TRY(comm_allreduce(h, b->hist_f64, (size_t)nh, ncclSum));
+            tot = b->hist_f64;
+        }
+        hipLaunchKernelGGL(k_ga_sel_pick, dim3((unsigned)(d * nt)), dim3(256), 0, h->stream, b->sel_hist, b->sel, pass, st, tot);
     }
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
@@ -915,18 +944,19 @@ int ga_keys(Handle* h, GaBuffers* b, const double* w, int64_t d, int64_t N, cons
 
 // trimmed mean: mark the entries of U whose rank inside their row lies in `range` (:329); U is fixed per component
 int ga_build_mask(Handle* h, GaBuffers* b, int64_t d, int64_t N, double P) {
-    const int64_t lo = (int64_t)std::floor(P * (double)N), hi = (int64_t)std::floor((1.0 - P) * (double)N);
+    const int64_t Ng = b->N_glob > 0 ? b->N_glob : N;   // (the ranks of :329 are ranks within the whole row)
+    const int64_t lo = (int64_t)std::floor(P * (double)Ng), hi = (int64_t)std::floor((1.0 - P) * (double)Ng);
     if (hi <= lo) {
         TLSQ_HIP(h, hipMemsetAsync(b->mask, 0, (size_t)d * N, h->stream));
         return TLSQ_OK;
     }
     TLSQ_TRY(ga_keys(h, b, nullptr, d, N, nullptr));
-    const int has_hi = hi < N ? 1 : 0;
+    const int has_hi = hi < Ng ? 1 : 0;
     TLSQ_TRY(ga_select_rows(h, b, d, N, 2, lo, has_hi ? hi : lo, nullptr));
     int64_t g = (d * N + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_ga_mask, dim3((int)g), dim3(256), 0, h->stream, (const double*)b->keys_in, (const GaSel*)b->sel, (int)d,
-                       N, has_hi, b->mask);
+                       N, has_hi, b->mask, (unsigned int)b->col_off);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -943,10 +973,12 @@ int ga_sums(Handle* h, GaBuffers* b, int64_t d, int64_t N, int mode, const doubl
             w = b->w;
         }
         TLSQ_TRY(ga_keys(h, b, w, d, N, st));
-        TLSQ_TRY(ga_select_rows(h, b, d, N, 1, N / 2 - 1, 0, st));
+        const int64_t Ng = b->N_glob > 0 ? b->N_glob : N;
+        TLSQ_TRY(ga_select_rows(h, b, d, N, 1, Ng / 2 - 1, 0, st));
         hipLaunchKernelGGL(k_ga_pick, dim3((int)((d + 255) / 256)), dim3(256), 0, h->stream, (const GaSel*)b->sel, w, b->U,
-                           (int)d, N, b->sbuf, st);
+                           (int)d, N, b->sbuf, st, (unsigned int)b->col_off);
         TLSQ_HIP(h, hipGetLastError());
+        if (h->comm) TLSQ_TRY(comm_allreduce(h, b->sbuf, (size_t)d, ncclSum));
         return TLSQ_OK;
     }
     const uint8_t* mask = (mode == TLSQ_GA_TRIMMED_MEAN) ? b->mask : nullptr;
@@ -1087,6 +1119,39 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
                      const tlsq_ga_opts* opts, const double* q0, int64_t ldq0, double* Q, int64_t ldQ,
                      tlsq_ga_info* info) {
     TLSQ_TRY(check_handle(h));
+    if (is_multi_call(h) && X && Q && d > 0 && r > 0 && ldX >= d && ldQ >= d && N >= 64 * (int64_t)h->multi_n &&
+        !(opts && opts->memory == TLSQ_MEM_DEVICE)) {
+        // single-process multi-GPU group: contiguous blocks of the observations (columns of the host matrix) per
+        // rank, the same start vectors everywhere; q and every decision evolve identically on all ranks, rank 0 delivers Q and
+        // the report.  (Fewer than 64 columns per GPU, device pointers: the first GPU alone, below.)
+        const int nr = h->multi_n;
+        std::vector<std::vector<double>> qs((size_t)nr);
+        std::vector<tlsq_ga_opts> ro((size_t)nr);
+        std::vector<double> q0s;
+        if (!q0) {   // (the library's own normals are drawn per handle: draw them once, on the host side of rank 0's stream)
+            q0s.resize((size_t)d * r);
+            TLSQ_HIP(h, hipSetDevice(h->device));
+            void* p;
+            TLSQ_TRY(ws_get(h, WS_GA_Q, (size_t)d * r * 8 * 2, &p));
+            const uint64_t seed = opts ? opts->seed : 0;
+            TLSQ_TRY(launch_fill_gauss(h, (double*)p, d * r, (unsigned int)(seed * 2654435761ull + 0x6a09e667u)));
+            TLSQ_HIP(h, hipMemcpyAsync(q0s.data(), p, (size_t)d * r * 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        const double* q0u = q0 ? q0 : q0s.data();
+        const int64_t ldq0u = q0 ? ldq0 : d;
+        for (int k = 0; k < nr; ++k) {
+            if (opts) ro[(size_t)k] = *opts; else tlsq_ga_opts_default(&ro[(size_t)k]);
+            ro[(size_t)k].memory = TLSQ_MEM_HOST;
+            if (k > 0) qs[(size_t)k].resize((size_t)d * r);
+        }
+        const int64_t base = N / nr, rem = N % nr;
+        return multi_run(h, [&](Handle* hr, int k, int) -> int {
+            const int64_t c0 = k * base + std::min<int64_t>(k, rem), nc = base + (k < rem ? 1 : 0);
+            return tlsq_rpca_ga_f64(static_cast<tlsq_handle>(hr), X + (size_t)c0 * ldX, d, nc, ldX, r, &ro[(size_t)k], q0u, ldq0u,
+                                    k == 0 ? Q : qs[(size_t)k].data(), k == 0 ? ldQ : d, k == 0 ? info : nullptr);
+        });
+    }
     if (!X || !Q || d <= 0 || N <= 0 || ldX < d || ldQ < d || r < 0 || (q0 && ldq0 < d))
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: bad argument");
     if (d > (int64_t)1 << 30) return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: d too large");
@@ -1102,8 +1167,6 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: entrywise_median needs at least 2 columns (I[end÷2])");
     if (mode == TLSQ_GA_TRIMMED_MEAN && !(P >= 0.0 && P < 1.0))
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: trim fraction outside [0,1)");
-    if (mode != TLSQ_GA_MEAN && h->comm != nullptr)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages are not available on column shards");
     if (info) {
         info->ms_total = info->ms_loop = 0.0;
         info->passes = 0;
@@ -1118,6 +1181,20 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     const bool solo = solo_on && mode == TLSQ_GA_MEAN && !h->comm && d <= 64 && N * (d + 1) <= 18000;
     GaBuffers b;
     if (!solo) TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
+    if (h->comm && mode != TLSQ_GA_MEAN) {
+        // column shards: the entrywise averages rank the entries of whole rows (:329, :357) - this rank's place in them
+        int64_t off = 0, tot = 0;
+        for (int k = 0; k < h->nranks; ++k) {
+            double v = (k == h->rank) ? (double)N : 0.0;
+            TLSQ_TRY(comm_allreduce_host_scalar(h, &v, ncclSum));
+            if (k < h->rank) off += (int64_t)v;
+            tot += (int64_t)v;
+        }
+        if (tot >= (int64_t)1 << 32)
+            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: the entrywise averages need N < 2^32 columns");
+        b.col_off = off;
+        b.N_glob = tot;
+    }
     // inputs
     const double* src = X;
     int64_t lds = ldX;
