@@ -73,6 +73,19 @@ def test_multi_lowrankfilter_vs_plain(engines):
     assert relerr(f2, O.lowrankfilter(y + n, 40)) < 1e-8
 
 
+def test_group_handle_wide_hankel_panel_runs_on_the_first_gpu(engines):
+    """A short multichannel series gives a WIDE Hankel panel (47 x 54 here): too few rows to shard, and the single-GPU path
+    goes through the general rpca entry with its own device panel - which used to mistake that for a group call with device
+    pointers (TLSQ_ERR_UNSUPPORTED; found by tools/fuzz_lrf.py)."""
+    plain, multi = engines
+    rng = np.random.default_rng(3)
+    t = np.arange(120)
+    y = np.stack([np.sin(t / 7.0), np.cos(t / 11.0)], axis=1) + 0.01 * rng.standard_normal((120, 2))
+    a = plain.lowrankfilter(y, 27, lag=2)
+    b = multi.lowrankfilter(y, 27, lag=2)
+    assert np.array_equal(a, b)
+
+
 def test_multi_handle_other_entry_points_run_on_first_gpu(engines):
     from oracle import rpca_oracle as O
     plain, multi = engines

@@ -225,8 +225,13 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
             memset(&inner, 0, sizeof(inner));
             if (info) inner = *info;
             if (std::isnan(oo.tol)) oo.tol = 1e-3;   // the lowrankfilter default (:119)
+            // (on a group handle this is the first GPU working alone on its own device panel: the general entry must not
+            //  take the call for a group call with device pointers - found by tools/fuzz_lrf.py)
+            const bool was_in_multi = h->in_multi;
+            h->in_multi = true;
             status = rpca_entry<T>(h, (const T*)H, K, LD, Kp, &oo, (T*)A, Kp, (T*)E, Kp, nullptr, K, nullptr, nullptr,
                                    std::min(K, LD), nullptr, info ? &inner : nullptr);
+            h->in_multi = was_in_multi;
             if (info) *info = inner;
         } else {
             status = rpca_core<T>(h, (const T*)H, Kp, LD, ro, &oo, (T*)A, (T*)E, nullptr, nullptr, nullptr, 0, nullptr, info);
