@@ -1454,3 +1454,49 @@ def test_lowrankfilter_wide_hankel_matrix(eng):
     n = 60                                               # K = 71 rows, n*D = 120 columns
     assert (T - n + 1) < 2 * n
     assert relerr(eng.lowrankfilter(yy, n), O.lowrankfilter(yy, n)) < 1e-8
+
+
+# ---- found by tools/fuzz_misc.py (round 3) ----------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,r", [(900, 150, 28), (200, 64, 12), (30, 900, 4), (64, 200, 2), (30, 30, 1), (30, 30, 7), (900, 7, 1)])
+def test_returned_singular_vectors_are_orthonormal(eng, M, N, r):
+    """`s = svd(Z)` of the last iteration (src/robustPCA.jl:194, :238): LAPACK returns orthonormal U and V whatever the
+    singular values.  The accurate route has V from the one-sided Jacobi and forms U = Z V diag(1/sigma), which loses
+    orthogonality at the level eps sigma_max / sigma_i (1e-6 ... 1e-4 for the tail of an rpca panel) and has no direction at
+    all for sigma_i = 0 (a 30 x 30 rank-1 problem: U'U - I of order 1) - repaired by the Gram-Schmidt-ordered polish of
+    solver.hip (polish_derived_vectors); wide problems: the same for V."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(M + 7 * N + r)
+    D = rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)
+    A, E, s, sv = eng.rpca(D)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    d = min(M, N)
+    U, S, Vt = np.asarray(s.U), np.asarray(s.S), np.asarray(s.Vt)
+    assert np.linalg.norm(U.T @ U - np.eye(d)) < 1e-10
+    assert np.linalg.norm(Vt @ Vt.T - np.eye(d)) < 1e-10
+    Zo = (so[0] * so[1]) @ so[2]
+    assert relerr((U * S) @ Vt, Zo) < 1e-9
+    assert np.max(np.abs(S - so[1])) < 1e-10 * so[1][0]
+
+
+def test_complex_counts_below_the_gram_resolution(eng):
+    """Three small complex problems (tests/golden/complex_late_counts.npz: D as drawn by tools/fuzz_misc.py, seeds 0 / 1 / 3)
+    whose last iterations have 1/mu below what the realified Gram matrix resolves (~sqrt(N eps) sigma_max): the count of
+    src/robustPCA.jl:198 used to be taken against that floor (sv 7 for LAPACK's 9); it now comes from TSQR + Jacobi on the
+    realified panel whenever the threshold or a singular value next to it is inside the Gram's error."""
+    import os
+    from oracle import rpca_oracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "complex_late_counts.npz"))
+    for key in ("D0", "D1", "D2"):
+        D = z[key]
+        A, E, s, sv, rep = eng.rpca(D, return_report=True)
+        Ao, Eo, so, svo, io = O.rpca(D)
+        assert rep.iters_done == io.iters_done and rep.svp_hist == io.svp_hist and sv == svo, key
+        assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    # wide complex input: the accurate route works on the transposed realified panel
+    rng = np.random.default_rng(5)
+    D = (rng.standard_normal((12, 2)) + 1j * rng.standard_normal((12, 2))) @ (rng.standard_normal((2, 20)) + 1j * rng.standard_normal((2, 20)))
+    D[rng.random(D.shape) < 0.05] += 10.0
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert rep.iters_done == io.iters_done and rep.svp_hist == io.svp_hist and sv == svo
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
