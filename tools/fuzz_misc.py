@@ -41,7 +41,8 @@ def main():
     rng = np.random.default_rng(seed)
     eng = tlsq_amd.Engine(0)
     groups = {n: tlsq_amd.Engine(devices=[0] * n) for n in (2, 3, 5)}
-    kinds = ["complex", "device", "group", "returned_s", "opnorm_power", "rsvd", "tls", "rtls", "hankel", "averages"]
+    kinds = ["complex", "device", "group", "returned_s", "opnorm_power", "rsvd", "tls", "rtls", "hankel", "averages",
+             "returned_s_f32", "batched_f32", "ga_group", "options"]
     bad = done = 0
     worst = 0.0
     t0 = time.time()
@@ -175,6 +176,64 @@ def main():
                     eng.soft_hankel_(B1, 0.05)
                     O.soft_hankel_(B2, 0.05)
                     err = max(err, rel(B1, B2) * 1e4)
+            elif kind == "returned_s_f32":
+                M, N = int(rng.choice([30, 200, 900])), int(rng.choice([7, 30, 64]))
+                if rng.random() < 0.3:
+                    M, N = N, M
+                r = int(rng.integers(1, max(2, min(M, N) // 4 + 1)))
+                D = lowrank(rng, M, N, r).astype(np.float32)
+                A, E, s, sv = eng.rpca(D)
+                d = min(M, N)
+                U, S, Vt = (np.asarray(x, dtype=np.float64) for x in (s.U, s.S, s.Vt))
+                Ao, Eo, so, svo, io = O.rpca(D)
+                Zo = (so[0].astype(np.float64) * so[1].astype(np.float64)) @ so[2].astype(np.float64)
+                parts = dict(UtU=float(np.linalg.norm(U.T @ U - np.eye(d))), VtV=float(np.linalg.norm(Vt @ Vt.T - np.eye(d))),
+                             rec=rel((U * S) @ Vt, Zo) * 1e-1)   # (fp32 trajectories agree to ~1e-3)
+                err = max(parts.values())
+                desc = f"{kind} {M}x{N} r={r} " + " ".join(f"{k}={v:.1e}" for k, v in parts.items())
+                tol = 2e-4
+            elif kind == "batched_f32":
+                B, M, N = int(rng.integers(2, 30)), int(rng.choice([50, 200, 500])), int(rng.integers(2, 33))
+                r = int(rng.integers(1, max(2, N // 3 + 1)))
+                Ds = np.stack([lowrank(rng, M, N, r) for _ in range(B)]).astype(np.float32)
+                desc = f"{kind} B={B} {M}x{N} r={r}"
+                A, E, S, Vt, svb, itb, stb, costb = eng.rpca_batched(Ds)
+                for b in range(min(B, 8)):
+                    Ao, Eo, _, svo, io = O.rpca(Ds[b])
+                    err = max(err, rel(A[b].astype(np.float64), Ao.astype(np.float64)))
+                    if abs(int(itb[b]) - io.iters_done) > 1 or int(svb[b]) != svo:
+                        err = max(err, 1.0)
+                tol = 2e-3
+            elif kind == "ga_group":
+                n = int(rng.choice([2, 3, 5]))
+                d, N, r = int(rng.choice([5, 20, 100])), int(rng.choice([400, 1001, 3000])), int(rng.integers(1, 4))
+                X = rng.standard_normal((d, r)) @ (rng.standard_normal((r, N)) * np.linspace(4.0, 2.0, r)[:, None]) \
+                    + 0.05 * rng.standard_normal((d, N))
+                X[:, rng.random(N) < 0.02] *= 10.0
+                q0 = rng.standard_normal((d, r))
+                mode = [None, "entrywise_trimmed_mean", "entrywise_median"][int(rng.integers(0, 3))]
+                desc = f"{kind} n={n} d={d} N={N} r={r} {mode}"
+                kw = {"mu": mode} if mode else {}
+                got, rep = groups[n].rpca_ga(X, r, q0=q0, iters=50, return_report=True, **kw)
+                info = G.GaInfo()
+                want = G.rpca_ga(X, r, q0=q0, info=info, iters=50, **({"mu": getattr(G, mode)} if mode else {}))
+                err = float(np.abs(got - want).max())
+                if rep["iters"] != info.iters:
+                    err = 1.0
+                tol = 1e-9
+            elif kind == "options":
+                M, N = int(rng.choice([100, 400, 1200])), int(rng.choice([10, 40, 100]))
+                r = int(rng.integers(1, max(2, min(M, N) // 4 + 1)))
+                D = lowrank(rng, M, N, r)
+                kw = dict(lam=float(rng.uniform(0.02, 0.3)), rho=float(rng.choice([1.2, 1.5, 2.0])), tol=float(rng.choice([1e-5, 1e-7, 1e-9])),
+                          iters=int(rng.choice([5, 30, 1000])), maxrank=int(rng.choice([1, 3, 1000])))
+                desc = f"{kind} {M}x{N} r={r} {kw}"
+                A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+                Ao, Eo, so, svo, io = O.rpca(D, **kw)
+                err = max(rel(A, Ao), rel(E, Eo))
+                if rep.iters_done != io.iters_done or rep.svp_hist != io.svp_hist or sv != svo:
+                    desc += f" iters {rep.iters_done}/{io.iters_done} sv {sv}/{svo}"
+                    err = 1.0
             else:   # averages
                 d, N = int(rng.choice([3, 10, 64, 300])), int(rng.choice([2, 7, 100, 5000]))
                 U = rng.standard_normal((d, N))
