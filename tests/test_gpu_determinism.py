@@ -103,3 +103,38 @@ def test_poisoned_workspace_changes_nothing(handles):
         tlsq_amd.dev_set("WS_POISON", None)
     for i, (a, b) in enumerate(zip(ref, got)):
         assert np.array_equal(np.asarray(a), np.asarray(b)), i
+
+
+def test_concurrent_handles_on_host_threads():
+    """Four host threads, each with its own handle, solve different problems at the same time (the ctypes calls release the
+    GIL): every result equals the sequential one bit for bit - the library keeps no state outside its handles."""
+    import threading
+    import torch  # noqa: F401
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    shapes = [(1500, 96, 6), (3000, 130, 12), (800, 40, 3), (5000, 256, 10)]
+    probs = [O.synth_lowrank_sparse(M, N, r, seed=10 + t)[0] for t, (M, N, r) in enumerate(shapes)]
+    engs = [tlsq_amd.Engine(0) for _ in shapes]
+    seq = [e.rpca(D, return_report=True) for e, D in zip(engs, probs)]
+    out, errs = [None] * len(shapes), []
+
+    def work(t):
+        try:
+            y = np.sin(np.arange(3000) / (7.0 + t)) + 0.01 * np.random.default_rng(t).standard_normal(3000)
+            for _ in range(4):
+                out[t] = engs[t].rpca(probs[t], return_report=True)
+                engs[t].lowrankfilter(y, 40)
+        except Exception as e:   # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(len(shapes))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for a, b in zip(seq, out):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[4].iters_done == b[4].iters_done and a[4].svp_hist == b[4].svp_hist
+    for e in engs:
+        e.close()
