@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+UNSTABLE = [0]   # mismatches on inputs whose reference trajectory LAPACK itself does not reproduce (reference_unstable)
 BIG = False   # --big: panels of 200 ... 512 columns, ranks up to 40 (warm subspace blocks of up to 50 columns, the fused
               # Rayleigh-Ritz kernel on blocks of up to 32); ~20 s of LAPACK per case on the host
 
@@ -104,6 +105,7 @@ def run_cases(eng, seed, ncase, budget_s=300.0, verbose=True):
                       f"first svp diff at k={k} errA={ea:.1e} errE={ee:.1e}", flush=True)
                 try:
                     un, why = reference_unstable(D, kw, max(ea, ee))
+                    UNSTABLE[0] += int(un)
                     print(f"    reference-unstable input: {un}  (LAPACK against itself - {why})", flush=True)
                 except Exception as e:   # noqa: BLE001
                     print("    (stability check failed:", e, ")", flush=True)
@@ -125,4 +127,5 @@ if __name__ == "__main__":
     eng = tlsq_amd.Engine(0)
     t0 = time.time()
     done, bad, exc, worst = run_cases(eng, seed, ncase, float(os.environ.get("FUZZ_BUDGET_S", "300")))
-    print(f"{done} cases, {bad} mismatches, {exc} exceptions, worst err {worst:.2e}, {time.time()-t0:.0f}s")
+    print(f"{done} cases, {bad} mismatches ({UNSTABLE[0]} of them on reference-unstable inputs), {exc} exceptions, "
+          f"worst err {worst:.2e}, {time.time()-t0:.0f}s")
