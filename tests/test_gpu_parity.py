@@ -1500,3 +1500,21 @@ def test_complex_counts_below_the_gram_resolution(eng):
     Ao, Eo, so, svo, io = O.rpca(D)
     assert rep.iters_done == io.iters_done and rep.svp_hist == io.svp_hist and sv == svo
     assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+
+
+@pytest.mark.parametrize("tool,seed,ncase", [("fuzz_lrf.py", 0, 120), ("fuzz_misc.py", 0, 120), ("fuzz_misc.py", 20, 120)])
+def test_fuzz_entry_points(tool, seed, ncase):
+    """The two wider fuzzers of round 3 as part of the suite (fixed seeds, 120 cases each, ~10 s): lowrankfilter with random
+    geometry / fp32 / loop-back groups / batched stacks (tools/fuzz_lrf.py) and complex data, device pointers, uneven group
+    shards, the returned SVD, hook modes, tls / rtls, the Hankel family, the averages, rpca_ga on groups, option sweeps
+    (tools/fuzz_misc.py) - every case within its tolerance of the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_BUDGET_S="600")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(seed), str(ncase)], capture_output=True, text=True,
+                         env=env, timeout=900)
+    tail = [ln for ln in out.stdout.splitlines() if ln.strip()][-6:]
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert tail and tail[-1].startswith(f"{ncase} cases, 0 bad"), "\n".join(tail)
