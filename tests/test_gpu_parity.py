@@ -1361,6 +1361,23 @@ def test_implicit_gram_operator_path(eng):
     assert np.allclose(rep.cost_hist, io.cost_hist, rtol=1e-6, atol=1e-12)
 
 
+def test_implicit_gram_operator_path_fp32(eng):
+    """The same path on an fp32 panel (what 16384 x 8192 fp32 runs in the default mode): the certified solver needs operator
+    products in full precision - the fp32-MFMA products of the randomized hook's sketch (block rounded to fp32) leave its
+    residual test at 1e-7 for ever (round 3: the large case ended with "could not be served by the subspace solver" while
+    those products were used unconditionally; tools/bench_all.sh caught it)."""
+    import warnings
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    D = O.synth_lowrank_sparse(2400, 2064, 5, seed=12)[0].astype(np.float32)
+    with tlsq_amd.dev_switches(IMPLICIT_GRAM=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, E, s, sv, rep = eng.rpca(D, iters=5, return_report=True, want_U=False)
+    Ao, Eo, so, svo, io = O.rpca(D, iters=5)
+    assert rep.svp_hist == io.svp_hist and sv == svo, (rep.svp_hist, io.svp_hist)
+    assert relerr(A.astype(np.float64), Ao.astype(np.float64)) < 1e-3 and relerr(E.astype(np.float64), Eo.astype(np.float64)) < 1e-3
+
+
 def test_implicit_hankel_sweep_is_bit_identical(eng):
     """lowrankfilter on one channel with lag 1: the fused rebuild+sweep reads y instead of the Hankel panel
     (D[i,j] = y[i+j], zero pad rows).  Same bits as with the panel (IMPLICIT_HANKEL=0), and the oracle's filter.

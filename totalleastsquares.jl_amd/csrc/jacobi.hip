@@ -724,15 +724,20 @@ __device__ __forceinline__ double jr_reduce16(double (&v)[16], int lane) {
 
 // one round: rotate the 16 pairs (c[P1(k)], c[P2(k)]) given by the position maps of the schedule.  a, bb: squared norms of
 // the two members of "this lane's" pair I = lane >> 2 (the same numbers in the four lanes of a group and in every wave).
-template <int NW, bool CROSS>
-__device__ __forceinline__ void jr_round(double (&c)[32], JrShared<NW>& sh, int w, int lane, int par, double tol2, double floor2,
+// (RPL rows per lane: a wave covers 64 RPL rows, so half as many waves meet at the barrier and add up half as many partials)
+template <int NW, bool CROSS, int RPL>
+__device__ __forceinline__ void jr_round(double (&c)[RPL][32], JrShared<NW>& sh, int w, int lane, int par, double tol2, double floor2,
                                          double& a, double& bb, unsigned int& my_rot) {
     // position of the two members of pair k
     auto p1 = [](int k) { return CROSS ? k : (k < 8 ? k : 16 + (k - 8)); };
     auto p2 = [](int k) { return CROSS ? 16 + k : (k < 8 ? 15 - k : 31 - (k - 8)); };
     double v[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = c[p1(k)] * c[p2(k)];
+    for (int k = 0; k < 16; ++k) {
+        v[k] = c[0][p1(k)] * c[0][p2(k)];
+#pragma unroll
+        for (int q = 1; q < RPL; ++q) v[k] = __builtin_fma(c[q][p1(k)], c[q][p2(k)], v[k]);
+    }
     const double tot = jr_reduce16(v, lane);
     const int I = lane >> 2;   // lanes 4 I .. 4 I + 3 hold the wave's partial of pair I:  I = b5 8 + b4 4 + b3 2 + b2
     if ((lane & 3) == 0) sh.part[par][w][I] = tot;
@@ -757,19 +762,22 @@ __device__ __forceinline__ void jr_round(double (&c)[32], JrShared<NW>& sh, int 
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const double ck = read_lane(cs, 4 * k), sk = read_lane(sn, 4 * k);
-        const double x = c[p1(k)], y = c[p2(k)];
-        c[p1(k)] = ck * x - sk * y;
-        c[p2(k)] = sk * x + ck * y;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const double x = c[q][p1(k)], y = c[q][p2(k)];
+            c[q][p1(k)] = ck * x - sk * y;
+            c[q][p2(k)] = sk * x + ck * y;
+        }
     }
 }
 
-template <int NW>
+template <int NW, int RPL>
 __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, int N, int nblk, int round, double tol,
                                                         const double* __restrict__ params,
                                                         unsigned int* __restrict__ rot_count) {
     __shared__ JrShared<NW> sh;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = w * 64 + lane;
+    const int row = (w * 64 + lane) * RPL;   // this lane's rows: row .. row + RPL - 1
     int bp, bq;
     rr_pair(nblk, round, blockIdx.x, bp, bq);
     if (bp > bq) {   // (keeps the lower block in c[0..15]: the order of the columns inside a pair is that of the LDS kernel)
@@ -778,11 +786,12 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         bq = t;
     }
     const double floor2 = params[0], tol2 = tol * tol;
-    double c[32];
+    double c[RPL][32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
-        c[s] = (col < N && row < N) ? B[(size_t)col * N + row] : 0.0;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) c[q][s] = (col < N && row + q < N) ? B[(size_t)col * N + row + q] : 0.0;
     }
     // squared column norms (32-value reduction as two butterflies), each wave keeps a full copy by column position
     {
@@ -790,7 +799,11 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = c[16 * hlf + k] * c[16 * hlf + k];
+            for (int k = 0; k < 16; ++k) {
+                v[k] = c[0][16 * hlf + k] * c[0][16 * hlf + k];
+#pragma unroll
+                for (int q = 1; q < RPL; ++q) v[k] = __builtin_fma(c[q][16 * hlf + k], c[q][16 * hlf + k], v[k]);
+            }
             const double tot = jr_reduce16(v, lane);
             if ((lane & 3) == 0) sh.npart[w][16 * hlf + (lane >> 2)] = tot;
         }
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         const int g = I & 7, base = (I >> 3) * 16;
         double a = sh.nrm[w][base + g], bb = sh.nrm[w][base + 15 - g];
         for (int r = 0; r < 15; ++r) {
-            jr_round<NW, false>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            jr_round<NW, false, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
             par ^= 1;
             // positions 1..15 of each block move on by one (15 -> 1), position 0 stays; the norms move with them:
             // a_g <- a_(g-1) (g >= 2), a_1 <- bb_0, a_0 stays;  bb_g <- bb_(g+1) (g <= 6), bb_7 <- a_7
@@ -821,12 +834,14 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
             a = (g == 0) ? a : (g == 1 ? bb_0 : a_prev);
             bb = (g == 7) ? a_7 : bb_next;
 #pragma unroll
-            for (int hb = 0; hb < 32; hb += 16) {
-                const double last = c[hb + 15];
+            for (int q = 0; q < RPL; ++q)
 #pragma unroll
-                for (int k = 15; k >= 2; --k) c[hb + k] = c[hb + k - 1];
-                c[hb + 1] = last;
-            }
+                for (int hb = 0; hb < 32; hb += 16) {
+                    const double last = c[q][hb + 15];
+#pragma unroll
+                    for (int k = 15; k >= 2; --k) c[q][hb + k] = c[q][hb + k - 1];
+                    c[q][hb + 1] = last;
+                }
         }
         // (15 rotations: every column is back in its position) - the norms go back to the position table
         if ((lane & 3) == 0) {
@@ -840,21 +855,26 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
     {
         double a = sh.nrm[w][I], bb = sh.nrm[w][16 + I];
         for (int r = 0; r < 16; ++r) {
-            jr_round<NW, true>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            jr_round<NW, true, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
             par ^= 1;
             // block q's registers move on by one (position 16 + i takes what 16 + i + 1 held): pair i meets q's next column
             bb = __shfl(bb, (lane + 4) & 63, 64);
-            const double first = c[16];
 #pragma unroll
-            for (int k = 16; k < 31; ++k) c[k] = c[k + 1];
-            c[31] = first;
+            for (int q = 0; q < RPL; ++q) {
+                const double first = c[q][16];
+#pragma unroll
+                for (int k = 16; k < 31; ++k) c[q][k] = c[q][k + 1];
+                c[q][31] = first;
+            }
         }
     }
     // (16 cross rotations and 15 intra rotations are full cycles: the registers are in column order again)
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
-        if (col < N && row < N) B[(size_t)col * N + row] = c[s];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+            if (col < N && row + q < N) B[(size_t)col * N + row + q] = c[q][s];
     }
     if (w == 0) {
         // lanes 4 I of wave 0 counted the rotations of "their" pairs
@@ -1160,11 +1180,22 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
             for (; sweep < max_sweeps; ++sweep) {
                 TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
                 for (int r = 0; r < nblk - 1; ++r) {
-                    if (N <= 512)
-                        hipLaunchKernelGGL(k_jacobi_reg<8>, dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                    // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
+                    const bool one = dev_is(DEV_JACOBI_RPL, '1');
+                    if (N <= 256 && !one)
+                        hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(nblk / 2), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                           (const double*)params, rot);
+                    else if (N <= 512 && !one)
+                        hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(nblk / 2), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                           (const double*)params, rot);
+                    else if (N <= 512)
+                        hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                           (const double*)params, rot);
+                    else if (!one)
+                        hipLaunchKernelGGL((k_jacobi_reg<8, 2>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
                                            (const double*)params, rot);
                     else
-                        hipLaunchKernelGGL(k_jacobi_reg<16>, dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                        hipLaunchKernelGGL((k_jacobi_reg<16, 1>), dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
                                            (const double*)params, rot);
                 }
                 TLSQ_HIP(h, hipGetLastError());

@@ -210,6 +210,10 @@ struct GramOp {
     const void* Z = nullptr;     // implicit: M x N panel (ld ldZ), fp32 when z_f32
     int z_f32 = 0;
     int64_t M = 0, ldZ = 0;
+    // products of an fp32 panel may round the block to fp32 on the way (op_gram_f32: 6e-8 per entry): fine for the range finder
+    // of the randomized hook, which accepts whatever comes out; NOT for the certified solver, whose acceptance test wants
+    // residuals of 2e-13 (16384 x 8192 fp32 in the default mode ended with "could not be served" while this was unconditional)
+    bool lowp_ok = false;
     bool implicit() const { return G == nullptr; }
 };
 
@@ -219,7 +223,7 @@ static int op_apply(Handle* h, const GramOp& op, int64_t N, const double* X, dou
     if (!op.implicit()) return launch_symm_skinny(h, op.G, N, X, Y, N, p);
     // fp32 panels, blocks of more than 8 columns: both halves on the fp32 MFMA (gemm.hip, op_gram_f32) - the widening kernels
     // below run on the fp64 MFMA at half the rate (narrow blocks, the Lanczos vectors, are bandwidth-bound either way)
-    if (op.z_f32 && p > 8 && !dev_is(DEV_NO_F32_SKINNY, '1')) {
+    if (op.z_f32 && op.lowp_ok && p > 8 && !dev_is(DEV_NO_F32_SKINNY, '1')) {
         for (int64_t c0 = 0; c0 < p; c0 += 96) {
             const int64_t pc = std::min<int64_t>(96, p - c0);
             TLSQ_TRY(op_gram_f32(h, (const float*)op.Z, op.ldZ, op.M, N, X + (size_t)c0 * N, N, Y + (size_t)c0 * N, N, pc));
@@ -1866,6 +1870,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (!r_route) {
         GramOp op = panel_op(Z);
         const bool sketch_now = hook_sketch && hook_now;
+        op.lowp_ok = sketch_now;
         const bool gram_queued_earlier = g_ready || implicit_gram || sketch_now;
         if (!implicit_gram && !sketch_now) {
             if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
