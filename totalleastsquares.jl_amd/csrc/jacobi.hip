@@ -693,24 +693,29 @@ struct JrShared {
 };
 
 // totals of v[0..15] over the wave: lanes 4 I .. 4 I + 3 end up with the total of value I (17 exchanges instead of 96)
+// (a, b) -> a' + b' after v_permlane32_swap / v_permlane16_swap (gfx950): the upper half (odd rows) of `a` changes places with
+// the lower half (even rows) of `b`, so that lanes 0-31 (even rows) end up with both halves' a and the others with both
+// halves' b - the first two butterfly stages without the LDS crossbar ds_bpermute goes through, and without the two selects
+__device__ __forceinline__ double jr_swap_add32(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double jr_swap_add16(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
 __device__ __forceinline__ double jr_reduce16(double (&v)[16], int lane) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const bool up = (lane & 32) != 0;
-        const double send = up ? v[k] : v[k + 8], keep = up ? v[k + 8] : v[k];
-        v[k] = keep + __shfl_xor(send, 32, 64);
-    }
+    for (int k = 0; k < 8; ++k) v[k] = jr_swap_add32(v[k], v[k + 8]);   // lanes < 32 keep value k, the others value k + 8
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool up = (lane & 16) != 0;
-        const double send = up ? v[k] : v[k + 4], keep = up ? v[k + 4] : v[k];
-        v[k] = keep + __shfl_xor(send, 16, 64);
-    }
+    for (int k = 0; k < 4; ++k) v[k] = jr_swap_add16(v[k], v[k + 4]);   // even rows keep value k, odd rows value k + 4
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const bool up = (lane & 8) != 0;
         const double send = up ? v[k] : v[k + 2], keep = up ? v[k + 2] : v[k];
-        v[k] = keep + __shfl_xor(send, 8, 64);
+        v[k] = keep + dpp_perm<0x128>(send);   // row_ror:8 = lane ^ 8 within the row of 16
     }
     {
         const bool up = (lane & 4) != 0;
