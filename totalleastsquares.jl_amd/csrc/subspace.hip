@@ -997,12 +997,15 @@ __device__ __forceinline__ sm_d4 rs_mfma(const double* A, const double* B, const
     return acc;
 }
 __device__ __forceinline__ double rs_wmax(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    // (DPP inside the rows of 16, then the four row maxima by v_readlane: no LDS crossbar)
+    double o;
+    o = ss_dpp<0xB1>(v);  v = o > v ? o : v;
+    o = ss_dpp<0x4E>(v);  v = o > v ? o : v;
+    o = ss_dpp<0x141>(v); v = o > v ? o : v;
+    o = ss_dpp<0x140>(v); v = o > v ? o : v;
+    const double a = ss_lane(v, 0), b = ss_lane(v, 16), c = ss_lane(v, 32), d = ss_lane(v, 48);
+    const double ab = b > a ? b : a, cd = d > c ? d : c;
+    return cd > ab ? cd : ab;
 }
 // block-wide sums of two values and maxima of three (4 waves), the same bits in every thread
 __device__ __forceinline__ void rs_reduce(double& s0, double& s1, double& m0, double& m1, double& m2, double* red) {
