@@ -41,7 +41,9 @@ enum {
     TLSQ_ERR_OOM = -3,
     TLSQ_ERR_COMM = -4,         /* RCCL error */
     TLSQ_ERR_UNSUPPORTED = -5,  /* e.g. N too large for the LDS-resident Jacobi, complex T */
-    TLSQ_ERR_NOCONV = -6        /* small eigensolver did not converge */
+    TLSQ_ERR_NOCONV = -6,       /* small eigensolver did not converge */
+    TLSQ_ERR_NONFINITE = -7     /* the input contains Infs or NaNs: what LAPACK's chkfinite throws behind svd! / opnorm in the
+                                   reference (ArgumentError("matrix contains Infs or NaNs"), src/robustPCA.jl:177, :194) */
 };
 
 enum { TLSQ_MEM_HOST = 0, TLSQ_MEM_DEVICE = 1 };

@@ -73,7 +73,9 @@ function handle()
 end
 
 lasterr() = unsafe_string(ccall((:tlsq_last_error, LIB[]), Cstring, (Ptr{Cvoid},), handle()))
-check(st) = st < 0 ? (st == -1 ? throw(AssertionError(lasterr())) : error("tlsq error $st: $(lasterr())")) : st
+check(st) = st < 0 ? (st == -1 ? throw(AssertionError(lasterr())) :
+                       st == -7 ? throw(ArgumentError("matrix contains Infs or NaNs")) :   # what LAPACK.chkfinite throws in the reference
+                       error("tlsq error $st: $(lasterr())")) : st
 
 _print_iter(k::Int64, cost::Cdouble, svp::Int64, ::Ptr{Cvoid}) =
     (println("$(k) cost: $(round(cost, sigdigits=4))"); nothing)      # src/robustPCA.jl:226

@@ -1535,3 +1535,22 @@ def test_fuzz_entry_points(tool, seed, ncase):
     tail = [ln for ln in out.stdout.splitlines() if ln.strip()][-6:]
     assert out.returncode == 0, out.stderr[-2000:]
     assert tail and tail[-1].startswith(f"{ncase} cases, 0 bad"), "\n".join(tail)
+
+
+def test_non_finite_input_is_an_error(eng):
+    """The reference's first statement with arithmetic, opnorm(Y) (src/robustPCA.jl:177), goes through LAPACK's chkfinite and
+    throws ArgumentError("matrix contains Infs or NaNs"); so do svd! (:194) and lowrankfilter / rtls through them.  The
+    library reports TLSQ_ERR_NONFINITE (the Julia shim turns it into that ArgumentError) instead of iterating on NaNs."""
+    import tlsq_amd
+    rng = np.random.default_rng(0)
+    for bad in (np.nan, np.inf, -np.inf):
+        D = rng.standard_normal((60, 12))
+        D[17, 3] = bad
+        for call in (lambda: eng.rpca(D), lambda: eng.rpca(D.astype(np.float32)), lambda: eng.rpca(D + 1j * D),
+                     lambda: eng.rpca(D.T.copy()), lambda: eng.rtls(D[:, :5], D[:, 5]),
+                     lambda: eng.lowrankfilter(np.where(np.arange(400) == 77, bad, np.sin(0.1 * np.arange(400))), 20)):
+            with pytest.raises(tlsq_amd.TlsqError) as ei:
+                call()
+            assert ei.value.code == tlsq_amd._lib.TLSQ_ERR_NONFINITE, ei.value
+    A, E, s, sv = eng.rpca(rng.standard_normal((60, 12)))   # the handle is fine afterwards
+    assert np.isfinite(A).all()

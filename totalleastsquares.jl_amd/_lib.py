@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("TLSQ_LIB") or os.path.join(_HERE, "libtlsqhip.so")  #
 
 TLSQ_OK, TLSQ_MAXITER = 0, 1
 TLSQ_ERR_ARG, TLSQ_ERR_HIP, TLSQ_ERR_OOM, TLSQ_ERR_COMM, TLSQ_ERR_UNSUPPORTED, TLSQ_ERR_NOCONV = -1, -2, -3, -4, -5, -6
+TLSQ_ERR_NONFINITE = -7   # the input contains Infs or NaNs (the reference: ArgumentError from LAPACK's chkfinite)
 MEM_HOST, MEM_DEVICE = 0, 1
 SVD_FULL, SVD_RANDOMIZED, SVD_CALLBACK = 0, 1, 2
 OPNORM_EXACT, OPNORM_POWER, OPNORM_CALLBACK = 0, 1, 2

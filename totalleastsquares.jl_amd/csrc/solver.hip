@@ -1353,10 +1353,6 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         o.ldZ = M;
         return o;
     };
-    if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
-    else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
-    else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
-    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
     double maxabs = 0.0;
     if (ro.hankel_lazy && ro.hankel_y) {   // every sample of the window appears in its Hankel matrix (lag <= L): max |H| = max |y|
         const HankelGeom& hg = ro.hankel_geom;
@@ -1370,6 +1366,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     else
         TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));              // :178 norm(Y, Inf)
     TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
+    // (the reference's svd! / opnorm go through LAPACK's chkfinite and throw ArgumentError("matrix contains Infs or NaNs") at
+    //  :177 before anything else happens: the same input is an error here, from the max-abs pass the set-up needs anyway)
+    if (!std::isfinite(maxabs)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
+    if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
+    else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
+    else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
+    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
     const double lam = ro.lambda;
     const double norminf = maxabs / lam;
     const double dual_norm = std::max(norm2, norminf);             // :179
@@ -2532,9 +2535,10 @@ int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const Re
     TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 16, h->stream));            // :174
     TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 16, h->stream));
     double norm2 = 0.0, maxabs = 0.0;
+    TLSQ_TRY(launch_cmaxabs(h, D, n, &maxabs));                               // :178
+    if (!std::isfinite(maxabs)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");   // (chkfinite at :177)
     TLSQ_TRY(launch_realify(h, D, M, N, W));
     TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &norm2, &sweeps));         // :177
-    TLSQ_TRY(launch_cmaxabs(h, D, n, &maxabs));                               // :178
     const double lam = ro.lambda;
     const double dual_norm = std::max(norm2, maxabs / lam);                   // :179
     const double d_norm = norm2;                                              // :180

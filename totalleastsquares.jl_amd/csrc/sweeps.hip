@@ -715,6 +715,7 @@ __global__ __launch_bounds__(256) void k_maxabs(const T* __restrict__ x, int64_t
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double v = fabs((double)x[i]);
+        if (!(v <= 1.7976931348623157e308)) v = __longlong_as_double(0x7FF0000000000000ll);   // NaN counts as Inf: "not finite"
         m = v > m ? v : m;
     }
 #pragma unroll
