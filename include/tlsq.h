@@ -267,7 +267,9 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
  * panel itself, so there is no Gram-route accuracy limit).  Problems are stored back to back: D is M x N x batch
  * (column-major M x N blocks, ld = M), likewise A, E; optional per-problem outputs S (N), Vt (N x N, ld N), sv,
  * iters, status (0 converged / 1 iteration limit), cost (final).  N <= 32, M >= N; the hankel flag, hook modes
- * and on_iter are not available (TLSQ_ERR_UNSUPPORTED).  Returns TLSQ_MAXITER when any problem hit the limit. */
+ * and on_iter are not available (TLSQ_ERR_UNSUPPORTED).  Returns TLSQ_MAXITER when any problem did not converge: per-problem
+ * status 0 = converged, 1 = iteration limit, 2 = the problem contains Infs or NaNs (NaN results, no iterations; where a loop of
+ * reference calls would stop with LAPACK's ArgumentError - the other problems of the batch are solved). */
 int tlsq_rpca_batched_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t batch,
                           const tlsq_rpca_opts* opts, double* A, double* E, double* S, double* Vt, int64_t* sv,
                           int32_t* iters, int32_t* status, double* cost);

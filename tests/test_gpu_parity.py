@@ -1552,5 +1552,27 @@ def test_non_finite_input_is_an_error(eng):
             with pytest.raises(tlsq_amd.TlsqError) as ei:
                 call()
             assert ei.value.code == tlsq_amd._lib.TLSQ_ERR_NONFINITE, ei.value
+        with pytest.raises(tlsq_amd.TlsqError) as ei:          # tls! -> svd! -> chkfinite (src/TotalLeastSquares.jl:63)
+            eng.tls(D[:, :5], D[:, 5])
+        assert ei.value.code == tlsq_amd._lib.TLSQ_ERR_NONFINITE
+        # a stack of tiny problems: the bad one is reported (status 2, NaN results), the others are solved as if it were not there
+        Ds = rng.standard_normal((4, 40, 6))
+        clean = eng.rpca_batched(Ds)
+        Ds2 = Ds.copy()
+        Ds2[1, 2, 3] = bad
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = eng.rpca_batched(Ds2)
+            As = rng.standard_normal((5, 50, 3))
+            ys = rng.standard_normal((5, 50))
+            x0 = eng.rtls_batched(As, ys)
+            As[2, 4, 1] = bad
+            x1, _, st1 = eng.rtls_batched(As, ys, return_status=True)
+        assert got[6].tolist() == [0, 2, 0, 0] and np.isnan(got[0][1]).all()
+        for b in (0, 2, 3):
+            assert np.array_equal(got[0][b], clean[0][b]) and np.array_equal(got[1][b], clean[1][b])
+        assert list(st1) == [0, 0, 2, 0, 0] and np.isnan(x1[2]).all()
+        assert np.array_equal(np.delete(x1, 2, axis=0), np.delete(x0, 2, axis=0))
     A, E, s, sv = eng.rpca(rng.standard_normal((60, 12)))   # the handle is fine afterwards
     assert np.isfinite(A).all()

@@ -390,6 +390,8 @@ static int tls_impl(tlsq_handle h, const T* Ay, int64_t M, int64_t ncols, int64_
     }
     std::vector<double> Vt;
     TLSQ_TRY(vt_of<T>(h, dAy, M, ncols, ld, Vt));
+    for (double v : Vt)   // (finite input never gives a non-finite V; svd! of the reference throws on Infs / NaNs: chkfinite)
+        if (!std::isfinite(v)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
     const int64_t q = ncols - n;
     std::vector<double> hx((size_t)n * q);
     const int st = tls_partition_solve(Vt.data(), ncols, ncols, n, hx.data(), n);   // :65-69
@@ -662,6 +664,11 @@ static int rtls_batched_impl(tlsq_handle h, const T* A, const T* y, int64_t M, i
     std::vector<double> hx((size_t)n * q * batch), vt64((size_t)nc * nc);
     int rc = TLSQ_OK;
     for (int64_t b = 0; b < batch; ++b) {                                              // tls!(s, n)  :155
+        if (hst[b] == 2) {   // Infs / NaNs in this problem (batched.hip): x = NaN, the others are solved
+            for (int64_t e = 0; e < n * q; ++e) hx[(size_t)(b * n * q + e)] = std::numeric_limits<double>::quiet_NaN();
+            rc = TLSQ_MAXITER;
+            continue;
+        }
         for (int64_t e = 0; e < nc * nc; ++e) vt64[(size_t)e] = (double)hVt[(size_t)b * nc * nc + e];
         int st = tls_partition_solve(vt64.data(), nc, nc, n, hx.data() + (size_t)b * n * q, n);
         if (st < 0) return set_err(h, st, "rtls_batched: partition solve failed for problem %lld", (long long)b);

@@ -11,6 +11,7 @@
 //
 // Layout: D, A, E, Y, Z (M x N, column-major, ld = M) + V (N x N) in LDS when 5*M*N*8 B fits, otherwise the five
 // panels live in a per-problem global scratch area (L2 resident) and only V and the small vectors stay in LDS.
+#include <limits>
 #include "common.hpp"
 
 #pragma clang fp contract(off)
@@ -212,7 +213,8 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
         Z[e] = d;
         A[e] = (T)0;
         E[e] = (T)0;
-        const T ad = (T)fabs(d);
+        T ad = (T)fabs(d);
+        if (!(ad <= std::numeric_limits<T>::max())) ad = std::numeric_limits<T>::infinity();   // NaN counts as Inf: "not finite"
         mx = ad > mx ? ad : mx;
     }
 #pragma unroll
@@ -224,6 +226,27 @@ __global__ __launch_bounds__(BT) void k_rpca_small(const T* __restrict__ Dg, Bat
     __syncthreads();
     T maxabs = (T)0;
     for (int k = 0; k < BW; ++k) maxabs = s.red[k] > maxabs ? s.red[k] : maxabs;   // norm(Y, Inf)  :178
+    if (!(maxabs <= std::numeric_limits<T>::max())) {
+        // Infs / NaNs in this problem: the reference's loop would stop here with LAPACK's ArgumentError (chkfinite behind
+        // opnorm, :177).  The other problems of the batch are not affected: status 2, NaN results, no iterations.
+        const T qnan = std::numeric_limits<T>::quiet_NaN();
+        T* Ao = Ag + (size_t)b * MN;
+        T* Eo = Eg + (size_t)b * MN;
+        for (int e = tid; e < MN; e += BT) {
+            Ao[e] = qnan;
+            Eo[e] = qnan;
+        }
+        if (Sg && tid < N) Sg[(size_t)b * N + tid] = qnan;
+        if (Vtg)
+            for (int e = tid; e < N * N; e += BT) Vtg[(size_t)b * N * N + e] = qnan;
+        if (tid == 0) {
+            if (svg) svg[b] = 0;
+            if (itg) itg[b] = 0;
+            if (stg) stg[b] = 2;
+            if (costg) costg[b] = qnan;
+        }
+        return;
+    }
     jacobi_svd<T, NB>(Z, M, N, s, false);
     const T norm2 = s.sig[0];                                  // opnorm(Y)  :177
     const T lam = (T)a.lambda;

@@ -495,7 +495,10 @@ class Engine:
         st = self._check(fn(self.h, _ptr(Df), M, N, B, C.byref(o), _ptr(A), _ptr(E), _ptr(S), _ptr(Vt), _ptr(sv),
                             _ptr(it), _ptr(stt), _ptr(cost)))
         if st == L.TLSQ_MAXITER:
-            warnings.warn(f"Maximum number of iterations reached in {int(stt.sum())} of {B} problems")
+            if int((stt == 1).sum()):
+                warnings.warn(f"Maximum number of iterations reached in {int((stt == 1).sum())} of {B} problems")
+            if int((stt == 2).sum()):
+                warnings.warn(f"{int((stt == 2).sum())} of {B} problems contain Infs or NaNs (status 2, NaN results)")
         return (np.transpose(A, (0, 2, 1)), np.transpose(E, (0, 2, 1)), S, np.transpose(Vt, (0, 2, 1)), sv, it, stt,
                 cost)
 
@@ -520,7 +523,10 @@ class Engine:
                                                 if k in ("lam", "maxrank", "tol", "rho", "nonnegA", "nonnegE")})
         st = self._check(fn(self.h, _ptr(Af), _ptr(yf), M, n, q, B, C.byref(o), _ptr(x), _ptr(it), _ptr(stt)))
         if st == L.TLSQ_MAXITER:
-            warnings.warn(f"Maximum number of iterations reached in {int(stt.sum())} of {B} problems")
+            if int((stt == 1).sum()):
+                warnings.warn(f"Maximum number of iterations reached in {int((stt == 1).sum())} of {B} problems")
+            if int((stt == 2).sum()):
+                warnings.warn(f"{int((stt == 2).sum())} of {B} problems contain Infs or NaNs (status 2, NaN results)")
         out = np.transpose(x, (0, 2, 1))
         out = out[:, :, 0].copy() if yv.ndim == 2 else out
         return (out, it, stt) if return_status else out
