@@ -3,13 +3,18 @@
 flags - the implicit Hankel panel with any lag / channel count included), the batched tiny-problem kernels (rtls / rpca
 stacks up to 32 columns), the fp32 solver, the group handle (row shards through the loop-back communicator).  GPU against
 the oracle; every case that differs in iteration count / rank trajectory or by more than its tolerance is printed.
-    python tools/fuzz_lrf.py [seed] [ncases]"""
+    python tools/fuzz_lrf.py [seed] [ncases] [--tiny]"""
 import os, sys, time, warnings
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
 os.environ.setdefault("OMP_NUM_THREADS", "4")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+
+
+TINY = "--tiny" in sys.argv   # adds series of 8 ... 61 samples (windows up to N/2, lags up to the window)
+if TINY:
+    sys.argv.remove("--tiny")
 
 
 def series(rng, Nx, Dch):
@@ -49,10 +54,14 @@ def main():
         desc = kind
         try:
             if kind.startswith("lrf"):
-                Nx = int(rng.choice([120, 257, 600, 1500, 4000]))
+                Nx = int(rng.choice([120, 257, 600, 1500, 4000] + ([8, 13, 30, 61] if TINY else [])))
                 Dch = int(rng.choice([1, 1, 2, 3]))
-                n = int(rng.integers(4, max(5, min(Nx // 4, 48))))
-                lag = int(rng.integers(1, min(n, 4) + 1))
+                if Nx < 100:   # tiny series: windows up to N/2 (the reference's assertion), lags up to the window
+                    n = int(rng.integers(2, Nx // 2 + 1))
+                    lag = int(rng.integers(1, n + 1))
+                else:
+                    n = int(rng.integers(4, max(5, min(Nx // 4, 48))))
+                    lag = int(rng.integers(1, min(n, 4) + 1))
                 sv = int(rng.choice([0, 0, 0, 2]))
                 kw = {}
                 if sv == 0 and rng.random() < 0.2:
