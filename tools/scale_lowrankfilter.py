@@ -19,6 +19,7 @@ y, noise = O.synth_series(a.N, seed=0)
 yn = y + noise
 import torch
 free0, total = torch.cuda.mem_get_info(0)
+tlsq_amd.dev_from_env()   # TLSQ_* development switches from the shell (after torch: its HIP runtime is loaded first)
 eng = tlsq_amd.Engine(0)
 t0 = time.perf_counter()
 yf, rep = eng.lowrankfilter(yn, a.n, return_report=True, cost_history=not a.no_hist, phase_timing=a.phases)
