@@ -916,18 +916,20 @@ int gemm_f64(Handle* h, bool A_KC, bool B_KC, const double* A, int64_t lda, cons
     return gemm_mixed(h, A_KC, B_KC, A, 0, lda, B, 0, ldb, C, 0, ldc, P, Q, K, symmetric);
 }
 
-// ---- Gram matrix of an fp32 panel on the fp32 MFMA, folded into fp64 every 32 rows (large mode, C5) -----------------
+// ---- Gram matrix of an fp32 panel on the fp32 MFMA, folded into fp64 every 64 rows (large mode, C5) -----------------
 // v_mfma_f32_16x16x4_f32 runs at twice the rate of the fp64 form (32 cycles per 2048 flop).  A plain fp32 accumulation
 // over M ~ 1e5 rows would lose every eigenvalue below ~4e-3 sigma_max^2 - the count sigma >= 1/mu is taken at
-// ~5e-4 sigma_max late in a solve - so the fp32 accumulators only ever hold the sum over one 32-row stage: at the start
-// of the next stage every tile's sum is converted and added to the fp64 accumulators (VALU, between the MFMAs) and the
-// tile's first MFMA restarts from zero.  What is left is the rounding of the 32-term sums, ~1e-8 sigma_max^2 in
-// norm at 65536 x 4096, i.e. singular values are resolved down to ~1e-4 sigma_max.
+// ~5e-4 sigma_max late in a solve - so the fp32 accumulators only ever hold the sum over FFOLD = 2 stages of 32 rows: at the start
+// of every second stage each tile's sum is converted and added to the fp64 accumulators (VALU, between the MFMAs) and the
+// tile's first MFMA restarts from zero.  What is left is the rounding of the 64-term sums, ~2e-8 sigma_max^2 in
+// norm at 65536 x 4096, i.e. singular values are resolved down to ~1.4e-4 sigma_max.
 // Same tile / wave grid / software pipeline as gram_body (8 waves, wave tile 64 x 32, panels of 128 columns x 32 rows of
 // fp32 in LDS, 16-byte fragment reads: lane (r, g) holds k = 16 q + 4 g + {0..3} of its column, element m feeds MFMA m).
 // Diagonal tiles are computed in full (large N: 32 of 528 tiles at N = 4096).
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int FTK = 32;             // rows of Z per stage
+constexpr int FFOLD = 2;            // stages per fp64 fold-in: every 64 rows (1: 11.3 ms per Gram at 65536 x 4096, error ~1e-8 sigma_max^2;
+                                    // 2: 10.1 ms, ~2e-8; 4: 9.4 ms, ~4e-8 - too close to the last thresholds of a solve, ~2.5e-7 sigma_max^2)
 constexpr int FLDK = FTK + 4;       // floats per panel column: (36 r + 4 g) distinct multiples of 4 mod 64 over a quarter wave
 constexpr int FPANEL = 128 * FLDK;  // floats per panel (4 panels = 73.7 KB)
 
@@ -1051,13 +1053,15 @@ __device__ __forceinline__ void gram32_body(const float* __restrict__ Z, int64_t
         const int cur = s & 1;
         // (the last two stages load the final stage again instead of branching: those values are never stored)
         const int64_t koff = (int64_t)(s + 2 < nstage ? s + 2 : nstage - 1) * FTK;
-        half(K1, ZY, cur, 0, (int64_t)0);
+        if ((s % FFOLD) == 0) half(K1, ZY, cur, 0, (int64_t)0);   // (fold + restart every FFOLD stages)
+        else half(K1, ZN, cur, 0, (int64_t)0);
         __syncthreads();
         half(K2, ZN, cur, 1, koff);
     }
     if (nstage > 0) {
         const int cur = (nstage - 1) & 1;
-        half(K0, ZY, cur, 0, (int64_t)0);
+        if (((nstage - 1) % FFOLD) == 0) half(K0, ZY, cur, 0, (int64_t)0);
+        else half(K0, ZN, cur, 0, (int64_t)0);
         half(K3, ZN, cur, 1, (int64_t)0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) F_FOLD(i);
