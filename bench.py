@@ -18,10 +18,13 @@ Beside `value` (all outside the timed region):
   roofline_mfma         the Gram kernel against the fp64 MFMA peak
   cpu_baseline          the oracle (LAPACK gesdd + fused OpenMP sweeps) on this box's host cores, bounded sample (N=1 only)
   extra.c4              BASELINE config 4 (200000x512, the shape of the >= 6x @ 8 GPUs target) on the GPUs of this run
-  validation            every run checks itself: iterations, rank trajectory, sv and the norms of A and E (summed over the
-                        shards) against values committed from a one-GPU run (tests/golden/bench_reference.json); the ranks
-                        must agree among themselves; rccl_ranks = size of the communicator as RCCL reports it.  Any
-                        disagreement, or a run that exceeds --timeout seconds (a hung collective), ends with a non-zero exit.
+  validation            every run checks itself against the CPU ORACLE's run of the same two full-size problems, frozen as data in
+                        tests/golden/bench_vectors.json (tests/golden/make_bench_vectors.py: LAPACK gesdd, reference expression
+                        order): identical iterations, sv and rank trajectory, cost history to 1e-6, strided samples of A and E
+                        (each rank checks the samples in its row block) and ||A||^2, ||E||^2 to 1e-8, the returned singular values
+                        to 1e-10 (N = 1).  The ranks must agree among themselves; rccl_ranks = size of the communicator as RCCL
+                        reports it.  Any disagreement, or a run that exceeds --timeout seconds (a hung collective), ends with a
+                        non-zero exit.
 """
 import argparse
 import hashlib
@@ -33,7 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-REF_PATH = os.path.join(ROOT, "tests", "golden", "bench_reference.json")
+REF_PATH = os.path.join(ROOT, "tests", "golden", "bench_vectors.json")
 
 
 def svp_hash(hist):
@@ -52,8 +55,6 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the extra 200000x512 row-sharded measurement (extra.c4)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_with_s / value_host_pointers")
     ap.add_argument("--timeout", type=float, default=900.0, help="seconds after which the run is declared hung (exit 3)")
-    ap.add_argument("--write-reference", metavar="PATH", default=None,
-                    help="(one GPU) write the validation values of this run to PATH (committed as tests/golden/bench_reference.json)")
     args = ap.parse_args()
 
     # a collective that never completes must not hang the driver: the watchdog ends the process (no re-exec, no retry here)
@@ -87,11 +88,11 @@ def main():
 
     import tlsq_amd
     from tlsq_amd import dist as tdist
-    from oracle import rpca_oracle as O   # cpu_baseline + input generator only
+    from tlsq_amd import workloads as W   # seeded synthetic inputs (numpy only; the oracle is imported for cpu_baseline alone)
 
     M, N, r = args.rows, args.cols, args.rank
     headline = (M, N, r) == (20000, 512, 16)
-    D, A0, S0 = O.synth_lowrank_sparse(M, N, r, seed=0)
+    D, A0, S0 = W.synth_lowrank_sparse(M, N, r, seed=0)
     lo, hi = tdist.row_partition(M, world, rank)
     Dl = np.ascontiguousarray(D[lo:hi].T)                 # (N, Ml) C-order == (Ml, N) column-major
     Ml = hi - lo
@@ -153,22 +154,64 @@ def main():
     dt = allmax(time.perf_counter() - t0)
     sv, rep, st = last
 
-    # ---- validation of the timed work (outside the timing) ----------------------------------------------------------------
+    # ---- validation of the timed work against the oracle's frozen run (outside the timing) -------------------------------
+    ref = None
+    if headline and os.path.exists(REF_PATH):
+        with open(REF_PATH) as f:
+            ref = json.load(f)
     problems = []
+
+    def sample_check(dX, key, want, lo_, hi_, Mg):
+        """strided samples of the column-major Mg x N oracle panel that fall into this rank's rows [lo_, hi_): squared
+        difference and squared reference (summed over the ranks by the caller)"""
+        st_ = want["sample_stride"]
+        idx = np.arange(0, Mg * N, st_, dtype=np.int64)
+        rows, cols = idx % Mg, idx // Mg
+        m = (rows >= lo_) & (rows < hi_)
+        wv = np.asarray(want[key], dtype=np.float64)[m]
+        flat = torch.from_numpy(cols[m] * (hi_ - lo_) + (rows[m] - lo_)).cuda()
+        got = dX.reshape(-1)[flat].cpu().numpy()
+        return float(np.sum((got - wv) ** 2)), float(np.sum(wv ** 2))
+
+    def check_problem(cfg, dAx, dEx, lo_, hi_, Mg, rep_plain, sv_, rep_hist):
+        mine_ = {"iters": rep_plain.iters_done, "sv": int(sv_), "svp_hash": svp_hash(rep_hist.svp_hist),
+                 "converged": bool(rep_plain.converged)}
+        if use_dist:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine_)
+            if any(e != everyone[0] for e in everyone):
+                problems.append(f"{cfg}: the ranks disagree: {everyone}")
+        na2_, ne2_ = allsum([float((dAx * dAx).sum().item()), float((dEx * dEx).sum().item())])
+        got = dict(mine_, normA2=na2_, normE2=ne2_)
+        want = ref.get(cfg) if ref else None
+        if want:
+            for key in ("iters", "sv", "svp_hash", "converged"):
+                if got[key] != want[key]:
+                    problems.append(f"{cfg}.{key}: {got[key]} (oracle {want[key]})")
+            for key in ("normA2", "normE2"):
+                if not abs(got[key] - want[key]) <= 1e-8 * abs(want[key]):
+                    problems.append(f"{cfg}.{key}: {got[key]!r} (oracle {want[key]!r})")
+            if list(rep_hist.svp_hist) != list(want["svp_hist"]):
+                problems.append(f"{cfg}.svp_hist: {list(rep_hist.svp_hist)} (oracle {want['svp_hist']})")
+            ch, cw = np.asarray(rep_hist.cost_hist, dtype=np.float64), np.asarray(want["cost_hist"])
+            if ch.shape != cw.shape or not np.allclose(ch, cw, rtol=1e-6, atol=1e-12):
+                problems.append(f"{cfg}.cost_hist differs from the oracle's beyond rtol 1e-6")
+            for key, dX in (("A_sample", dAx), ("E_sample", dEx)):
+                num, den = allsum(sample_check(dX, key, want, lo_, hi_, Mg))
+                rel = (num / max(den, 1e-300)) ** 0.5
+                got[key + "_relerr"] = rel
+                if not rel <= 1e-8:
+                    problems.append(f"{cfg}.{key}: relative error {rel:.3e} against the oracle (bar 1e-8)")
+        return got
+
     A = dA.cpu().numpy().T
     E = dE.cpu().numpy().T
     resid = float(np.linalg.norm(D[lo:hi] - (A + E)) / np.linalg.norm(D[lo:hi]))
     rel_a = float(np.linalg.norm(A - A0[lo:hi]) / np.linalg.norm(A0[lo:hi]))
-    # (the rank trajectory of a plain call: no per-iteration cost is asked for, so this solve launches exactly what the timed ones do)
-    _, rep_h, _ = eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=False)
-    na2, ne2 = allsum([float(np.sum(A * A)), float(np.sum(E * E))])
-    mine = {"iters": rep.iters_done, "sv": int(sv), "svp_hash": svp_hash(rep_h.svp_hist), "converged": bool(rep.converged)}
-    if use_dist:
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        if any(e != everyone[0] for e in everyone):
-            problems.append(f"the ranks disagree: {everyone}")
-    check = {"c2": dict(mine, normA2=na2, normE2=ne2)}
+    # (one more solve WITH the per-iteration cost: the rank trajectory and the cost history the oracle's are compared with; the
+    #  plain solves above settle cost < tol only - same iterations and outputs, tests/test_gpu_parity.py)
+    _, rep_h, _ = eng.rpca_device(dD.data_ptr(), Ml, N, dA.data_ptr(), dE.data_ptr(), m_global=M, want_hist=True)
+    check = {"c2": check_problem("c2", dA, dE, lo, hi, M, rep, sv, rep_h)} if headline else {}
 
     # ---- extra.c4: BASELINE config 4 (rpca 200000 x 512 fp64, row-sharded over the N GPUs of this run) -------------
     # The >= 6x @ 8 GPUs target of the north star is quoted on THIS shape, so every --gpus N run also times it (after
@@ -176,17 +219,9 @@ def main():
     # their own seeds, so N = 1, 2, 4, 8 all solve the same problem and every rank only generates its own rows.
     c4 = None
     if not args.no_c4 and headline:
-        M4, N4, r4, nb = 200000, 512, 16, 8
-        rb = M4 // nb
+        M4, N4, r4, nb = W.C4_SHAPE
         lo4, hi4 = tdist.row_partition(M4, world, rank)
-        G2 = np.random.default_rng([4, 999]).standard_normal((r4, N4))
-        parts = []
-        for b in range(lo4 // rb, (hi4 - 1) // rb + 1):
-            rg = np.random.default_rng([4, b])
-            blk = rg.standard_normal((rb, r4)) @ G2 + 10.0 * rg.standard_normal((rb, N4)) * (rg.random((rb, N4)) < 0.05)
-            parts.append(blk[max(lo4 - b * rb, 0): min(hi4 - b * rb, rb)])
-        D4 = np.ascontiguousarray(np.vstack(parts).T)
-        del parts
+        D4 = np.ascontiguousarray(W.c4_rows(lo4, hi4).T)
         M4l = hi4 - lo4
         d4 = torch.from_numpy(D4).cuda()
         a4, e4 = torch.empty_like(d4), torch.empty_like(d4)
@@ -201,41 +236,19 @@ def main():
         barrier()
         t4 = allmax(time.perf_counter() - t4)
         _, rep4p, _ = run4(want_hist=False, phase_timing=True)      # all six phases bracketed (the Amdahl term per N)
-        _, rep4h, _ = run4(want_hist=False)
-        n4a, n4e = allsum([float((a4 * a4).sum().item()), float((e4 * e4).sum().item())])
+        _, rep4h, _ = run4(want_hist=True)
         c4 = {"workload": "rpca 200000x512 fp64 rank-16 + 5% sparse, row-sharded, reference defaults, to convergence",
               "value": n4 / t4, "unit": "iters/s", "n_gpus": world, "rows_per_gpu": M4l, "solves": 2,
               "ms_per_solve": t4 / 2 * 1e3, "iters_per_solve": rep4.iters_done, "sv": sv4, "converged": rep4.converged,
               "phases_ms_per_iter": {k: v / rep4p.iters_done for k, v in rep4p.ms.items()
                                      if k in ("shrink", "gram", "eig", "rebuild", "update", "opnorm")},
               "phases_note": "eig = the replicated N x N solve (does not shrink with the number of GPUs); everything else is sharded"}
-        check["c4"] = {"iters": rep4.iters_done, "sv": int(sv4), "svp_hash": svp_hash(rep4h.svp_hist),
-                       "converged": bool(rep4.converged), "normA2": n4a, "normE2": n4e}
+        check["c4"] = check_problem("c4", a4, e4, lo4, hi4, M4, rep4, sv4, rep4h)
         del d4, a4, e4, D4
 
-    # compare with the values a one-GPU run committed (same problems, same seeds)
-    validation = {"rccl_ranks": rccl_ranks, "reference": None, "ok": True}
-    if args.write_reference:
-        if world != 1:
-            raise SystemExit("--write-reference wants a one-GPU run")
-        if rank == 0:
-            with open(args.write_reference, "w") as f:
-                json.dump(check, f, indent=1, sort_keys=True)
-                f.write("\n")
-    elif headline and os.path.exists(REF_PATH):
-        with open(REF_PATH) as f:
-            ref = json.load(f)
-        validation["reference"] = os.path.relpath(REF_PATH, ROOT)
-        for cfg, got in check.items():
-            want = ref.get(cfg)
-            if not want:
-                continue
-            for key in ("iters", "sv", "svp_hash", "converged"):
-                if got[key] != want[key]:
-                    problems.append(f"{cfg}.{key}: {got[key]} (reference {want[key]})")
-            for key in ("normA2", "normE2"):
-                if not abs(got[key] - want[key]) <= 1e-8 * abs(want[key]):
-                    problems.append(f"{cfg}.{key}: {got[key]!r} (reference {want[key]!r})")
+    validation = {"rccl_ranks": rccl_ranks, "reference": os.path.relpath(REF_PATH, ROOT) if ref else None,
+                  "reference_kind": "CPU oracle (LAPACK gesdd, reference expression order), frozen by tests/golden/make_bench_vectors.py",
+                  "ok": True}
     if rccl_ranks != world and launched:
         problems.append(f"the communicator has {rccl_ranks} ranks, the run {world}")
     validation["ok"] = not problems
@@ -261,6 +274,13 @@ def main():
         ts = time.perf_counter() - ts
         extras["value_with_s"] = ns / ts
         extras["ms_per_solve_with_s"] = ts / 3 * 1e3
+        if ref and "c2" in ref:   # the returned singular values against the oracle's s.S of the last Z (:194, :238)
+            Sg, Sw = dS.cpu().numpy(), np.asarray(ref["c2"]["S"])
+            floor = 64 * np.finfo(float).eps * np.sqrt(d) * Sw[0]
+            bad = np.abs(Sg - Sw) > 1e-10 * Sw + floor
+            check["c2"]["S_max_relerr"] = float(np.max(np.abs(Sg - Sw) / Sw))
+            if bad.any():
+                problems.append(f"c2.S: {int(bad.sum())} of {d} returned singular values differ from the oracle's beyond rtol 1e-10")
         Df = np.asfortranarray(D)
         eng.rpca(Df, want_s=False, cost_history=False)
         th = time.perf_counter()
@@ -271,9 +291,22 @@ def main():
         th = time.perf_counter() - th
         extras["value_host_pointers"] = nh / th
         extras["ms_per_solve_host_pointers"] = th / 3 * 1e3
-        extras["host_pointers_note"] = ("pageable numpy arrays: H2D of D, D2H of A and E (246 MB per solve) and the "
-                                        "host-side copies of the ctypes binding are inside the time")
+        extras["host_pointers_note"] = ("numpy arrays of the caller (pageable memory): H2D of D, D2H of A and E (246 MB per "
+                                        "solve) inside the time")
+        # the drop-in call: what `A, E, s, sv = rpca(D)` of the Julia shim executes (julia/TotalLeastSquaresHIP.jl: host
+        # pointers AND the returned decomposition U, S, Vt) - src/robustPCA.jl:156, :238
+        eng.rpca(Df, cost_history=False)
+        td = time.perf_counter()
+        nd = 0
+        for _ in range(3):
+            _, _, _, _, rd = eng.rpca(Df, cost_history=False, return_report=True)
+            nd += rd.iters_done
+        td = time.perf_counter() - td
+        extras["value_dropin"] = nd / td
+        extras["ms_per_solve_dropin"] = td / 3 * 1e3
+        extras["dropin_note"] = "host pointers and s = (U, S, Vt): +82 MB of U and 2 MB of Vt over PCIe, + the accurate SVD of the last Z"
         del dU, dS, dVt
+        validation["ok"] = not problems
 
     # one more solve, outside the timed region, with every phase of the iteration bracketed by HIP events: the source of
     # phases_ms_per_iter and of the Gram roofline (the timed solves only bracket the sweep kernels - each recorded
@@ -382,6 +415,7 @@ def main():
                                     "issued_TFLOPs": issued_flops / (ms_ph["gram"] / n_gram * 1e-3) / 1e12,
                                     "ms_per_launch": ms_ph["gram"] / n_gram, "launches": n_gram}
         if world == 1 and args.cpu_iters > 0:
+            from oracle import rpca_oracle as O   # the checker, timed as the CPU baseline (nothing else of bench.py uses it)
             ncores = os.cpu_count() or 1
             # LAPACK gesdd on a 20000x512 panel does not scale to hundreds of threads: pick the best of a few
             # thread counts on one iteration, then time the sample with it (a fair best-effort host baseline)

@@ -6,6 +6,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 import tlsq_amd
@@ -81,3 +82,32 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "rpca_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_workload_generators_match_the_checkers_copies():
+    """bench.py and the GPU tests draw their inputs from the package's neutral module (numpy only); the oracle keeps its
+    own copies of the two generators: same seeds, same bits."""
+    from oracle import rpca_oracle as O
+    from tlsq_amd import workloads as W
+    for a, b in zip(W.synth_lowrank_sparse(300, 40, 4, seed=3), O.synth_lowrank_sparse(300, 40, 4, seed=3)):
+        assert np.array_equal(a, b)
+    for a, b in zip(W.synth_series(5000, seed=2), O.synth_series(5000, seed=2)):
+        assert np.array_equal(a, b)
+    blk = W.c4_rows(24990, 25010)       # straddles two seeded row blocks
+    assert blk.shape == (20, 512) and np.array_equal(blk[:10], W.c4_rows(24990, 25000))
+
+
+def test_bench_vectors_are_the_oracles():
+    """tests/golden/bench_vectors.json (what bench.py validates against) is the ORACLE's output: the config-2 entry is
+    reproduced here for the first iterations (the full run takes half a minute: tests/golden/make_bench_vectors.py)."""
+    import hashlib
+    import json
+    from oracle import rpca_oracle as O
+    from tlsq_amd import workloads as W
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_vectors.json")))["c2"]
+    D = W.synth_lowrank_sparse(20000, 512, 16, seed=0)[0]
+    assert hashlib.sha256(D.tobytes(order="F")).hexdigest() == ref["D_sha256_of_float64_column_major"]
+    _, _, _, _, info = O.rpca(D, iters=3)
+    assert info.svp_hist == ref["svp_hist"][:3]
+    assert np.allclose(info.cost_hist, ref["cost_hist"][:3], rtol=1e-12)
+    assert ref["iters"] == len(ref["svp_hist"]) == len(ref["cost_hist"]) and ref["converged"]

@@ -142,3 +142,41 @@ def test_large_mode_rank_beyond_the_old_block_limit(eng):
     assert rep.eig_fast >= rep.iters_done - 2            # the subspace solver serves the loop once the block fits
     assert np.linalg.norm(D - (A + E)) / np.linalg.norm(D) < math.sqrt(np.finfo(float).eps)
     assert relerr(A, A0) < 1e-6
+
+
+# ---- the two bench problems at FULL size against the oracle's frozen run -------------------------------------------------
+@pytest.fixture(scope="module")
+def bench_vectors():
+    with open(os.path.join(ROOT, "tests", "golden", "bench_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["c2", "c4"])
+def test_bench_problem_full_size_vs_oracle(eng, bench_vectors, name):
+    """BASELINE configs 2 (20000 x 512, the headline) and 4 (200000 x 512) at full size against the CPU oracle's run of
+    the same inputs (tests/golden/bench_vectors.json, made by tests/golden/make_bench_vectors.py - LAPACK gesdd behind both
+    decompositions of every iteration, src/robustPCA.jl:186-233): identical iterations, sv and rank trajectory (:198), cost
+    history (:225) to 1e-6, strided samples of A and E and their norms to 1e-8, every returned singular value (:194, :238) to
+    1e-10 (+ the fp64 floor where LAPACK's own values are noise)."""
+    import hashlib
+    from tlsq_amd import workloads as W
+    ref = bench_vectors[name]
+    if name == "c2":
+        D = W.synth_lowrank_sparse(20000, 512, 16, seed=0)[0]
+    else:
+        D = np.asfortranarray(W.c4_rows(0, W.C4_SHAPE[0]))
+    assert hashlib.sha256(D.tobytes(order="F")).hexdigest() == ref["D_sha256_of_float64_column_major"]
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False)
+    assert (rep.iters_done, int(sv), bool(rep.converged)) == (ref["iters"], ref["sv"], ref["converged"])
+    assert list(rep.svp_hist) == ref["svp_hist"]
+    np.testing.assert_allclose(rep.cost_hist, ref["cost_hist"], rtol=1e-6, atol=1e-12)
+    st = ref["sample_stride"]
+    for X, key in ((A, "A_sample"), (E, "E_sample")):
+        w = np.asarray(ref[key])
+        assert np.linalg.norm(X.ravel(order="F")[::st] - w) <= 1e-8 * np.linalg.norm(w), key
+    assert abs(float(np.sum(A * A)) - ref["normA2"]) <= 1e-8 * ref["normA2"]
+    assert abs(float(np.sum(E * E)) - ref["normE2"]) <= 1e-8 * ref["normE2"]
+    assert int(np.count_nonzero(E)) == ref["nnzE"]          # soft_th leaves exact zeros (:1): same support as the oracle
+    Sw = np.asarray(ref["S"])
+    floor = 64 * np.finfo(float).eps * math.sqrt(len(Sw)) * Sw[0]
+    assert np.all(np.abs(s.S - Sw) <= 1e-10 * Sw + floor)

@@ -550,6 +550,36 @@ def test_rpca_user_hooks_through_the_c_callbacks(eng):
         eng.rpca(D, svd=bad)
 
 
+def test_rpca_zero_rank_iterations_through_whole_solves(eng):
+    """`svp = 0  =>  A = 0` at the level of a solve (src/robustPCA.jl:198-208: the rank-0 product is an all-zero A and the
+    loop goes on).  (a) default path (E-free sweeps): a panel of isolated spikes plus a faint rank-1 part - the first five
+    iterations count no singular value above 1/mu; (b) an over-estimating `opnorm` closure (3 x the true norm, :177): mu
+    starts too small and iteration 1 counts nothing.  Both against the oracle: same trajectory incl. the zeros, A, E 1e-8."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(5)
+    D = np.zeros((200, 50))
+    for j in range(50):
+        D[rng.integers(200), j] = 10 * (1 + rng.random())
+    D += 0.01 * rng.standard_normal((200, 1)) @ rng.standard_normal((1, 50))
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert io.svp_hist[:5] == [0] * 5 and svo == 1
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    assert rep.iters_done == io.iters_done and rep.svp_hist == io.svp_hist and sv == svo
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+    # ... and stopped inside the zero-rank phase: A is exactly zero, sv = max(svp, 1) = 1 (:199-204)
+    A3, E3, s3, sv3, rep3 = eng.rpca(D, iters=3, return_report=True)
+    Ao3, Eo3, _, svo3, io3 = O.rpca(D, iters=3)
+    assert rep3.svp_hist == [0, 0, 0] == io3.svp_hist and sv3 == svo3 == 1
+    assert not A3.any() and not Ao3.any() and relerr(E3, Eo3) < 1e-8
+    D2, _, _ = O.synth_lowrank_sparse(700, 60, 5, seed=9)
+    big = lambda X: 3.0 * float(sla.svdvals(X)[0])
+    Ao, Eo, so, svo, io = O.rpca(D2, opnorm=big)
+    assert io.svp_hist[0] == 0
+    A, E, s, sv, rep = eng.rpca(D2, opnorm=big, return_report=True)
+    assert rep.iters_done == io.iters_done and rep.svp_hist == io.svp_hist and sv == svo
+    assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8
+
+
 def test_lowrankfilter_user_hooks_reference_thresholds(eng):         # test/runtests.jl:383-398 with real closures
     rng = np.random.default_rng(1)
     T = 1000

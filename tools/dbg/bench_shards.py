@@ -1,12 +1,12 @@
 """The two bench problems (C2 and extra.c4 of bench.py) on loop-back groups of 2, 4 and 8 ranks on one GPU: iterations, sv and the
-rank trajectory must equal the committed one-GPU reference (tests/golden/bench_reference.json) - what bench.py --gpus N validates."""
+rank trajectory must equal the committed one-GPU reference (tests/golden/bench_vectors.json) - what bench.py --gpus N validates."""
 import os, sys, json, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, tlsq_amd
 from oracle import rpca_oracle as O
 sys.argv = [sys.argv[0]]
-ref = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_reference.json")))
+ref = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_vectors.json")))
 
 
 def svp_hash(hist):   # (bench.py)
