@@ -23,6 +23,7 @@ struct DevBuf {
 };
 
 struct Comm;  // RCCL state (runtime.hip)
+struct Stager;   // pinned staging pipeline of host-pointer calls (staging.hip)
 
 struct Handle {
     int device = 0;
@@ -66,6 +67,7 @@ struct Handle {
     const double *out_Tm = nullptr, *out_Vs = nullptr;
     int64_t out_r = 0;
     int warm_uses = 0;       // consecutive warm starts (reset to a cold start now and then: drift control)
+    Stager* stager = nullptr;   // created by the first large host <-> device transfer (staging.hip)
 };
 
 }  // namespace tlsq

@@ -21,6 +21,18 @@ int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op);
 int comm_allgather(Handle* h, const double* send, double* recv, size_t count);
 int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
            hipMemcpyKind kind);
+// ---- staging.hip: large host <-> device transfers of host-pointer calls through pinned slots on worker threads -------
+struct StageJob {
+    void* dst;
+    int64_t ldd;
+    const void* src;
+    int64_t lds;
+    int64_t rows, cols;
+    size_t esz;
+    bool to_device;   // host -> device (src is the caller's memory) or device -> host (dst is)
+};
+int staged_copy(Handle* h, const StageJob* jobs, int njobs);
+void stager_destroy(Handle* h);
 double now_ms();
 int ws_poison_all(Handle* h);   // WS_POISON=1: refill every workspace slot with 0xFF bytes (start of a solve)
 // Single-process multi-GPU group: runs fn(rank handle, rank, nranks) on every GPU of the group concurrently - rank 0 on

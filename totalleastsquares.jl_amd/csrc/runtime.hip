@@ -607,6 +607,7 @@ int tlsq_destroy(tlsq_handle h) {
     tlsq_comm_destroy(h);
     for (auto& b : h->ws)
         if (b.p) (void)hipFree(b.p);
+    stager_destroy(h);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->up_ring) (void)hipHostFree(h->up_ring);
     if (h->mailbox) (void)hipHostFree(h->mailbox);

@@ -2934,7 +2934,13 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     const bool priv = !dev || transposed || pad;    // work on private panels?
     if (!dev || ldD != M) {
         TLSQ_TRY(ws_get(h, WS_D, (size_t)n * es, &p));
-        TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        if (dev) {
+            TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, hipMemcpyDeviceToDevice));
+        } else {
+            // the caller's (pageable) matrix: pinned slots on worker threads instead of the runtime's one-thread bounce buffer
+            const StageJob up{p, M, D, ldD, M, N, es, true};
+            TLSQ_TRY(staged_copy(h, &up, 1));
+        }
         dD = (const T*)p;
     }
     if (!dev || ldA != M) {
@@ -3008,9 +3014,20 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
 
     th = now_ms();
     const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
-    if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
-    if (U && !transposed && !pad && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
+    if (dev) {
+        if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
+        if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
+        if (U && !transposed && !pad && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
+    } else {
+        // A, E (and U) go back to the caller's memory together, pipelined through the pinned slots
+        StageJob down[3];
+        int nd = 0;
+        if (dA != A) down[nd++] = StageJob{A, ldA, dA, M, M, N, es, false};
+        if (dE != E) down[nd++] = StageJob{E, ldE, dE, M, M, N, es, false};
+        if (U && !transposed && !pad && dU != U) down[nd++] = StageJob{U, ldU, dU, M, M, d, es, false};
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        TLSQ_TRY(staged_copy(h, down, nd));
+    }
     std::vector<T> tS, tVt;
     if (S) {
         tS.resize((size_t)d);
