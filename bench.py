@@ -138,7 +138,8 @@ def main():
     t0 = time.perf_counter()
     iters_total = 0
     rskip_total = 0
-    hbm_sweeps_total = hbm_total = 0.0
+    hbm_sweeps_total = hbm_total = hbm_timed_total = 0.0
+    sweeps_timed_total = 0
     ms = {}
     last = None
     for _ in range(args.steps):
@@ -147,6 +148,8 @@ def main():
         rskip_total += rep.residual_stores_skipped
         hbm_sweeps_total += rep.hbm_bytes_sweeps
         hbm_total += rep.hbm_bytes
+        hbm_timed_total += rep.hbm_bytes_sweeps_timed
+        sweeps_timed_total += rep.sweeps_timed
         for k, v in rep.ms.items():
             ms[k] = ms.get(k, 0.0) + v
         last = (sv, rep, st)
@@ -323,14 +326,22 @@ def main():
 
     if rank == 0:
         value = iters_total / dt
-        sweep_ms_per_iter = (ms["shrink"] + ms["update"]) / iters_total
-        # Bytes the sweeps have to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11 passes per
+        # The sweep kernels of the timed solves between HIP events on the library's stream: the first shrink of every solve and
+        # the fused sweep of every fourth iteration (an event record is a packet between two kernels, ~6 us: bracketing all of
+        # them cost 3 % of the headline; tlsq_rpca_info.sweeps_timed launches, .hbm_bytes_sweeps_timed their algorithmic bytes).
+        # Bytes a sweep has to move.  SURVEY.md §8d prices the two-kernel form (K1 R3/W2 + K2 R4/W2 = 11 passes per
         # iteration); the shipped loop is the E-free sweep (k_zsweep: A from its factors in registers, E never stored while
         # the loop runs): R D,Y,Z / W R,Y',Z' = 6 passes, 5 when the residual store is skipped, and k_first_shrink at k = 1:
         # R D / W Y,Z = 3 passes.  (The returned E is formed once after the loop, outside the two timed phases.)
         array_bytes = float(Ml) * N * 8
-        alg_bytes = (3.0 * args.steps + 6.0 * iters_total - rskip_total) / iters_total * array_bytes
-        achieved = alg_bytes / (sweep_ms_per_iter * 1e-3) / 1e9
+        sweep_ms_timed = ms["shrink"] + ms["update"]
+        ms_per_sweep = sweep_ms_timed / max(sweeps_timed_total, 1)
+        bytes_per_sweep = hbm_timed_total / max(sweeps_timed_total, 1)
+        achieved = hbm_timed_total / (sweep_ms_timed * 1e-3) / 1e9
+        passes_timed = hbm_timed_total / array_bytes
+        assert abs(passes_timed - round(passes_timed)) < 1e-9 and 3 * args.steps <= passes_timed <= 6 * sweeps_timed_total
+        alg_bytes = (3.0 * args.steps + 6.0 * iters_total - rskip_total) / iters_total * array_bytes   # all sweeps, per iteration
+        sweep_ms_per_iter = alg_bytes / (achieved * 1e9) * 1e3
         out = {
             "metric": "rpca ALM iters/sec on 20000x512 fp64 D",
             "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -350,6 +361,9 @@ def main():
             "validation": validation,
             "roofline": {"kernel": "k_zsweep (E-free fused rebuild + ALM sweep) + k_first_shrink at k=1", "bound": "hbm",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "how": "algorithmic bytes of the bracketed launches / their device time between HIP events on the library's "
+                                "stream, inside the timed solves (a sample: every solve's first shrink + the sweep of every 4th iteration)",
+                         "launches_timed": sweeps_timed_total, "ms_per_launch": ms_per_sweep, "bytes_per_launch": bytes_per_sweep,
                          # what the library launched in the timed solves (tlsq_rpca_info.hbm_bytes_sweeps: algorithmic bytes of
                          # every sweep launch incl. the R stores it decided on), per iteration
                          "traffic": hbm_sweeps_total / iters_total,

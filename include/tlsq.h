@@ -108,8 +108,11 @@ typedef struct tlsq_rpca_info {
     int64_t* svp_hist;
     int64_t hist_capacity;
     int64_t jacobi_sweeps;   /* total sweeps of the small eigensolver */
-    /* wall/device time in ms.  ms_shrink / ms_update (the sweep kernels, HIP events on the handle's stream) are always
-     * measured; the other phases only with opts->phase_timing (zero otherwise) */
+    /* wall/device time in ms.  ms_shrink / ms_update: the sweep kernels between HIP events on the handle's stream - every
+     * sweep with opts->phase_timing, otherwise a SAMPLE of them (the first shrink and the sweep of every fourth iteration:
+     * an event record is a packet of its own between two kernels, ~6 us each; sweeps_timed / hbm_bytes_sweeps_timed
+     * below say how many launches and how many bytes the two figures cover).  The other phases only with
+     * opts->phase_timing (zero otherwise) */
     double ms_total, ms_loop, ms_h2d, ms_d2h;
     double ms_shrink, ms_update, ms_gram, ms_eig, ms_rebuild, ms_opnorm;
     /* how the SVD step of each iteration was served: full Jacobi decompositions vs warm-started subspace
@@ -122,6 +125,10 @@ typedef struct tlsq_rpca_info {
      * M x N x sizeof(T) panels): the sweep kernels alone, and everything (sweeps + Gram reads + the
      * rebuild's read of Z and write of A + residual Gram).  Per GPU when row-sharded. */
     double hbm_bytes_sweeps, hbm_bytes;
+    /* the sweep launches bracketed by HIP events (ms_shrink + ms_update are their device time) and the algorithmic bytes
+     * of exactly those launches */
+    int64_t sweeps_timed;
+    double hbm_bytes_sweeps_timed;
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);

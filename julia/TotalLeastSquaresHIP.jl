@@ -39,7 +39,7 @@ mutable struct RpcaOpts
     RpcaOpts() = new()
 end
 
-# mirrors `struct tlsq_rpca_info`, 200 bytes
+# mirrors `struct tlsq_rpca_info`, 216 bytes
 mutable struct RpcaInfo
     iters_done::Int64; converged::Int32; tsqr_iterations::Int32
     final_cost::Cdouble; final_mu::Cdouble; d_norm::Cdouble
@@ -49,6 +49,7 @@ mutable struct RpcaInfo
     eig_full::Int64; eig_fast::Int64; subspace_steps::Int64
     residual_stores_skipped::Int64
     hbm_bytes_sweeps::Cdouble; hbm_bytes::Cdouble
+    sweeps_timed::Int64; hbm_bytes_sweeps_timed::Cdouble
     RpcaInfo() = new()
 end
 

@@ -1375,6 +1375,50 @@ def test_efree_loop_against_classic_sweeps(eng):
         assert np.array_equal(E == 0, Eo == 0), i
 
 
+def test_speculative_loop_and_a_failed_asynchronous_certificate(eng):
+    """The E-free loop speculates (solver.hip, `spec`): the count certificate of iteration k runs on the second stream beside
+    the factor product, the sweep (Z and the Gram matrix double-buffered) and the next Gram, and its verdict is read after
+    those are queued.  NO_CERT_ASYNC=1 is the in-line form: the two must agree bit for bit (same kernels on the same inputs).
+    A certificate that says no (injected with FAIL_CERT_AT=k) throws the queued sweep away and serves iteration k again from
+    the intact Z_k, Y_k, G_k: same trajectory, A and E to rounding, against the oracle as always - with and without the
+    per-iteration cost (whose evaluation takes the other branch of the loop), with nonneg flags, on a shard group."""
+    import warnings
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    cases = [(2000, 128, 8, {}), (1501, 96, 6, {}), (800, 64, 5, dict(nonnegA=True, nonnegE=True)), (3000, 256, 12, dict(iters=9))]
+    for i, (M, N, r, kw) in enumerate(cases):
+        D = O.synth_lowrank_sparse(M, N, r, seed=70 + i)[0]
+        D = np.abs(D) if "nonnegA" in kw else D
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Ao, Eo, so, svo, io = O.rpca(D, **kw)
+            A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+            with tlsq_amd.dev_switches(NO_CERT_ASYNC=1):
+                A1, E1, s1, sv1, rep1 = eng.rpca(D, return_report=True, **kw)
+            assert np.array_equal(A, A1) and np.array_equal(E, E1) and rep.svp_hist == rep1.svp_hist, i
+            # (the returned s: the double-buffered loop still holds Z_k itself, the in-place one rebuilds it as A_k + Y_{k+1} / mu_k)
+            np.testing.assert_allclose(s.S, s1.S, rtol=1e-10, atol=1e-13 * s.S[0])
+            assert (sv, rep.iters_done, rep.svp_hist) == (svo, io.iters_done, io.svp_hist), i
+            assert relerr(A, Ao) < 1e-8 and relerr(E, Eo) < 1e-8, i
+            for kfail in (2, 5, rep.iters_done - 1):
+                for hist in (True, False):
+                    with tlsq_amd.dev_switches(FAIL_CERT_AT=kfail):
+                        A2, E2, s2, sv2, rep2 = eng.rpca(D, return_report=True, cost_history=hist, **kw)
+                    assert (sv2, rep2.iters_done, rep2.svp_hist) == (sv, rep.iters_done, rep.svp_hist), (i, kfail, hist)
+                    assert relerr(A2, A) < 1e-10 and relerr(E2, E) < 1e-10, (i, kfail, hist)
+                    assert np.array_equal(E2 == 0, E == 0), (i, kfail, hist)
+    D = O.synth_lowrank_sparse(2400, 128, 8, seed=77)[0]
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    grp = tlsq_amd.Engine(devices=[0, 0, 0])
+    try:
+        with tlsq_amd.dev_switches(FAIL_CERT_AT=4):
+            A3, E3, s3, sv3, rep3 = grp.rpca(D, return_report=True)
+        assert (sv3, rep3.iters_done, rep3.svp_hist) == (sv, rep.iters_done, rep.svp_hist)
+        assert relerr(A3, A) < 1e-9 and relerr(E3, E) < 1e-9
+    finally:
+        grp.close()
+
+
 def test_implicit_gram_operator_path(eng):
     """From N = 8192 on the Gram matrix is never formed: products G X = Z'(Z X), operator-form Lanczos with per-vector
     deflation.  The switch IMPLICIT_GRAM=1 forces that path at a size the oracle can follow: same trajectory, A and E."""

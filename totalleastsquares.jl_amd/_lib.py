@@ -46,7 +46,8 @@ class RpcaInfo(C.Structure):
                 ("ms_opnorm", C.c_double),
                 ("eig_full", C.c_int64), ("eig_fast", C.c_int64), ("subspace_steps", C.c_int64),
                 ("residual_stores_skipped", C.c_int64),
-                ("hbm_bytes_sweeps", C.c_double), ("hbm_bytes", C.c_double)]
+                ("hbm_bytes_sweeps", C.c_double), ("hbm_bytes", C.c_double),
+                ("sweeps_timed", C.c_int64), ("hbm_bytes_sweeps_timed", C.c_double)]
 
 
 class GaOpts(C.Structure):

@@ -105,10 +105,10 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
 #define TLSQ_DEV_LIST(X)                                                                                                  \
     X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP) X(FAIL_RANK)                                                \
     X(NO_ZSWEEP) X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(FUSED_REBUILD) X(NO_REBUILD_STORE)            \
-    X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID)                                                                                    \
+    X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID) X(SWEEP_TIMING_STRIDE)                                                                                   \
     X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
     X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
-    X(NO_CERT_OVERLAP) X(NO_FUSED_DEFLATE)                                                                                 \
+    X(NO_CERT_OVERLAP) X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_FUSED_DEFLATE)                                                                                 \
     X(NO_RR_FAST) X(NO_U_POLISH) X(NO_GX_REUSE) X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(JACOBI_RPL) X(NO_CHOL) X(NO_SYMM_MFMA)             \
     X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS)    \
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
@@ -153,6 +153,7 @@ enum WsSlot {
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
+    WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction
     WS_COUNT
 };
@@ -203,7 +204,7 @@ template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                   double* sumsq, double* zero_slots, const T* hankel_y = nullptr, int64_t hankel_K = 0, int64_t row0 = 0,
-                  int64_t row1 = 0, int maxslot = -1, HankelGeom hg = HankelGeom());
+                  int64_t row1 = 0, int maxslot = -1, HankelGeom hg = HankelGeom(), T* Zout = nullptr);   // Zout: Z_{k+1} out of place
 template <typename T>
 int launch_final_e(Handle* h, const T* D, const double* Tm, const double* Vs, const T* Aprev, const T* Y, T* E, int64_t M,
                    int64_t N, int64_t r, T inv_mu, T thr, int nonnegA, int nonnegE, const T* hankel_y = nullptr,

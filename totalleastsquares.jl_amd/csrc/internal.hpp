@@ -67,6 +67,9 @@ struct PhaseTimer {
     // what the HBM roofline needs) - every recorded event is a barrier packet the command processor works through
     // between two kernels (~5.7 us each at C2 size: six of them were 7 % of an iteration).
     bool full;
+    // light mode: the essential marks are recorded only while `sample` is set (rpca_core sets it for the first shrink and the
+    // sweep of every few iterations: two packets per bracketed sweep are 3 % of a C2 iteration)
+    bool sample = true;
     int bank = 0;
     int n[2] = {0, 0};
     int slot[2][16] = {};   // event behind each mark (an empty phase reuses the previous mark's event; -1: none)
@@ -76,7 +79,7 @@ struct PhaseTimer {
     void mark(bool empty = false, bool essential = false) {
         if (!on || n[bank] >= 16) return;
         const int i = n[bank]++;
-        if (!full && !essential) empty = true;
+        if (!full && !(essential && sample)) empty = true;
         if (empty) {
             slot[bank][i] = i > 0 ? slot[bank][i - 1] : -1;
             return;

@@ -109,9 +109,9 @@ static int opnorm_power(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld,
 
 // G (WS_G) = Z'Z summed over the row shards
 template <typename T>
-static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out) {
+static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out, int slot = WS_G) {
     void* G;
-    TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &G));
+    TLSQ_TRY(ws_get(h, slot, (size_t)N * N * 8, &G));
     TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
     TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
     *G_out = (double*)G;
@@ -274,6 +274,11 @@ struct SubspaceState {
     // queued; the caller queues its own work (the rebuild) behind them and then asks svd_subspace_certify
     bool defer_certificate = false;
     bool cert_pending = false;
+    // ... and its kernels run on the handle's second stream with a mailbox region of their own (cert_async): the caller may
+    // queue anything that does not modify G or the block X on the main stream meanwhile - rpca_core queues the factor
+    // product, the next sweep and the next Gram before it asks for the verdict
+    bool cert_async = false;
+    volatile double* cert_mb = nullptr;   // where cert_finish polls (nullptr: the main mailbox)
     LanczosRun cert;
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
     int q_floor = 1;       // smallest count that may be tried again (raised when a count needed a second step)
@@ -297,6 +302,20 @@ struct SubspaceState {
     int64_t n_rr_fast = 0, n_rr_declined = 0;                  // steps served / declined by the fused Rayleigh-Ritz kernel
     int rr_streak = 0, rr_skip = 0;                            // consecutive declines / calls in which it is not tried
     double cert_tail = 0.0;   // Lanczos estimate of lambda_max(GD) / tau^2 of the last failed certificate (0: unknown)
+};
+
+// the asynchronous certificate's region of the mailbox (in doubles; the main region - flag at [0], payloads from [8] - ends
+// below it for every block size in use)
+constexpr size_t kCertMailboxOffset = 2048;
+
+// runs a scope's launches on another stream of the handle (every launcher takes h->stream)
+struct StreamScope {
+    Handle* h;
+    hipStream_t saved;
+    StreamScope(Handle* hh, hipStream_t s) : h(hh), saved(hh->stream) {
+        if (s) h->stream = s;
+    }
+    ~StreamScope() { h->stream = saved; }
 };
 
 // ---- count certificate: lambda_max(GD) < margin for the deflated, scaled Gram matrix GD ---------------------------
@@ -339,7 +358,8 @@ static int power_cert_begin(Handle* h, SubspaceState& st) {
     const int64_t N = st.cert_N;
     const int64_t nt = (N + 31) / 32;
     st.cert_seq = 0.0;
-    if (!(h->mailbox && !no_mailbox && (size_t)(16 + nt * (nt + 1) / 2) * 8 <= h->mailbox_bytes)) return TLSQ_OK;
+    st.cert_mb = nullptr;
+    if (!(h->mailbox && !no_mailbox && (size_t)(kCertMailboxOffset + 16 + nt * (nt + 1) / 2) * 8 <= h->mailbox_bytes)) return TLSQ_OK;
     void* scal;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
     unsigned int* ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 336);   // self-resetting
@@ -348,7 +368,9 @@ static int power_cert_begin(Handle* h, SubspaceState& st) {
         h->cert_ticket_ready = true;
     }
     st.cert_seq = (h->mail_seq += 1.0);
-    TLSQ_TRY(launch_sq_norm(h, st.cert_GD, N, h->mailbox_dev, ticket, st.cert_seq, &st.cert_ntile));
+    const size_t mb_off = st.cert_async ? kCertMailboxOffset : 0;
+    st.cert_mb = h->mailbox + mb_off;
+    TLSQ_TRY(launch_sq_norm(h, st.cert_GD, N, h->mailbox_dev + mb_off, ticket, st.cert_seq, &st.cert_ntile));
     return TLSQ_OK;
 }
 
@@ -366,7 +388,7 @@ static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
     const bool dbg = dev_get(DEV_DEBUG) != nullptr;
     double a = -1.0;
     if (st.cert_seq != 0.0) {
-        volatile double* mb = h->mailbox;
+        volatile double* mb = st.cert_mb ? st.cert_mb : h->mailbox;
         const double t_poll = now_ms();
         while (mb[0] != st.cert_seq && now_ms() - t_poll < 2000.0) {
         }
@@ -827,15 +849,21 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     st.cert_margin = (1.0 - st.dlam / tau2) * (1.0 - 1e-9);
     if (!op.implicit()) {
         TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
+        const bool no_power = dev_is(DEV_NO_POWER_CERT, '1');
+        // the two dense squarings cost N^3 flops against ~16 N^2 loads for a Lanczos run: matrix powers up to N = 1024
+        st.cert_power = N <= 1024 && !no_power;
+        // Asynchronous form: the host has just read this step's results from the mailbox, so everything the certificate reads
+        // (G, the block X) is complete - its two kernels go to the second stream and run beside whatever the caller queues next
+        const bool async = st.cert_async && st.defer_certificate && st.cert_power && fused_deflate && svp > 0 && h->stream_b &&
+                           h->mailbox && !dev_is(DEV_NO_MAILBOX, '1');
+        st.cert_async = async;
+        StreamScope on_b(h, async ? h->stream_b : nullptr);
         if (fused_deflate && svp > 0)
             TLSQ_TRY(launch_deflate_sel(h, op.G, N, (const double*)X, defl_sw, (double*)GD, N, svp, 1.0 / tau2));
         else
             TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
         st.cert_GD = (const double*)GD;
         st.cert_N = N;
-        const bool no_power = dev_is(DEV_NO_POWER_CERT, '1');
-        // the two dense squarings cost N^3 flops against ~16 N^2 loads for a Lanczos run: matrix powers up to N = 1024
-        st.cert_power = N <= 1024 && !no_power;
         if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
         else TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, st.cert_margin, 0.0));
         if (st.defer_certificate) {
@@ -1223,12 +1251,28 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // classic loop: E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
     // must survive in case iteration k is the last one
     void *E2v = nullptr, *Z2v = nullptr;
+    // Speculative E-free loop (panels up to 2 GB): the count certificate of iteration k (deflation + ||S^2||_F, ~22 us of small
+    // kernels) runs on the handle's second stream BESIDE the factor product, the sweep and the next Gram, and its verdict is
+    // read when those are queued.  For that a sweep must not destroy anything iteration k still needs should the verdict be
+    // "not certified": Z is double-buffered like Y (the sweep writes Z_{k+1} to the other buffer) and so is the Gram matrix
+    // (the Gram of Z_{k+1} goes to the other slot); a failed certificate throws the queued work away and serves iteration k
+    // again through the retries / the TSQR route (FAIL_CERT_AT=k injects one for the tests).
+    const bool spec = zmode && !dev_is(DEV_NO_CERT_ASYNC, '1') && !dev_is(DEV_NO_CERT_OVERLAP, '1') && N <= kFullEigMaxN &&
+                      (size_t)n * sizeof(T) <= ((size_t)1 << 31) && h->mailbox && h->mailbox_bytes >= 32768 &&
+                      !dev_is(DEV_NO_MAILBOX, '1');
     if (!zmode) {
         TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
         TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+    } else if (spec) {
+        TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
+        TLSQ_TRY(second_stream(h));
     }
     T* Ebuf[2] = {E, (T*)E2v};
-    T* Zbuf[2] = {(T*)Zv, zmode ? (T*)Zv : (T*)Z2v};   // (E-free loop: one Z, both entries)
+    T* Zbuf[2] = {(T*)Zv, (zmode && !spec) ? (T*)Zv : (T*)Z2v};   // (E-free loop without speculation: one Z, both entries)
+    int zc = 0;                  // E-free loop: Z_k sits in Zbuf[zc], the sweep writes Z_{k+1} to Zbuf[zc ^ 1] (the same panel unless spec)
+    const int Gslot[2] = {WS_G, spec ? WS_G3 : WS_G};
+    int gcur = 0;                // the Gram matrix of the current Z sits in (or is computed into) workspace slot Gslot[gcur]
+    const int64_t fail_cert_at = [] { const char* e = dev_get(DEV_FAIL_CERT_AT); return (int64_t)(e ? atoll(e) : 0); }();
     T* Ybuf[2] = {Y, E};         // E-free loop: Y_k sits in Ybuf[ycur], the sweep writes Y_{k+1} to the other one
     int ycur = 0;
     const double *Tm_prev = nullptr, *Vs_prev = nullptr;   // factors of A_{k-1} (E-free loop)
@@ -1466,6 +1510,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // (all phase marks only on request: tlsq_rpca_opts.phase_timing or TLSQ_PHASE_TIMING=1)
     const bool env_phases = dev_is(DEV_PHASE_TIMING, '1');
     PhaseTimer pt(h, timing, env_phases || (opts && opts->phase_timing != 0));
+    // light mode: which sweeps are bracketed by events (tlsq_rpca_info::sweeps_timed)
+    const int64_t tstride = [] { const char* e = dev_get(DEV_SWEEP_TIMING_STRIDE); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+    int64_t n_timed = 0;
+    double hbm_timed = 0.0;
     double zero_sink = 0.0;
     // phase windows between consecutive marks: shrink | gram | eig | rebuild | sweep | read-back of the Frobenius
     // bound (booked under the cost evaluation) | next iteration's Gram queued behind the sweep (booked under gram) |
@@ -1717,7 +1765,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const double inv_mu = 1.0 / mu;
         const double thr = lam / mu;
         T* E = Ebuf[cur];
-        T* Z = Zbuf[cur];
+        T* Z = zmode ? Zbuf[zc] : Zbuf[cur];
         mu_iter = mu;
         z_swept = false;
         if (zmode) {   // what the previous iteration left as "last" is A_{k-1} now; this iteration's factors go to the other pair
@@ -1727,6 +1775,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         prev_no_factors = last_no_factors;
         last_no_factors = false;
+        pt.sample = pt.full || tstride == 1 || k % tstride == 1;
+        const double hbm_sweeps_at_top = hbm_sweeps;
         pt.mark(false, !have_next);
         if (!have_next)
         {
@@ -1747,8 +1797,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
         if (d_transient) D = nullptr;   // the copy in Zbuf[1] is not to be read any more
         pt.mark(have_next, !have_next);
+        bool redo_cert_failed = false;   // second pass through the SVD step: the asynchronous certificate said no
+    redo_svd_step:
         double* G = nullptr;                                                                   // :193-194
         bool fast_ok = false;
+        bool cert_late = false;          // the certificate's verdict is still out (asked for once the sweep is queued)
         // Rank count, singular-value thresholding and the factors of A for the decomposition currently in (s, V).
         // Normally called once after the SVD step; with a deferred count certificate it is called right after the
         // subspace solver (the rebuild kernels queue up behind the certificate's Lanczos steps) and, should the
@@ -1876,9 +1929,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         op.lowp_ok = sketch_now;
         const bool gram_queued_earlier = g_ready || implicit_gram || sketch_now;
         if (!implicit_gram && !sketch_now) {
-            if (g_ready) G = (double*)h->ws[WS_G].p;   // already queued behind the previous iteration's sweep (see below)
+            if (g_ready) G = (double*)h->ws[Gslot[gcur]].p;   // already queued behind the previous iteration's sweep (see below)
             else {
-                TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G));
+                TLSQ_TRY(gram_allreduce<T>(h, Z, M, N, M, &G, Gslot[gcur]));
                 hbm_other += panel_bytes;
             }
             op = GramOp();
@@ -1911,24 +1964,35 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 if (!pass) fast_ok = false;
             }
             if (!fast_ok) sub.fail = SubspaceState::FAIL_WINDOW;   // (no block-growing retries: the accurate route decides)
+        } else if (redo_cert_failed) {
+            // (back here after an asynchronous certificate failed: what the synchronous form does then - larger block, retries)
+            fast_ok = false;
+            sub.cert_pending = false;
+            sub.fail = SubspaceState::FAIL_CERT;
         } else {
             sub.noise_rel = noise_rel;
             sub.defer_certificate = !no_cert_overlap;
+            sub.cert_async = spec && k < ro.iters;
             const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
             sub.defer_certificate = false;
             if (st_sub < 0) return st_sub;
             if (fast_ok && sub.cert_pending) {
-                // the certificate's Lanczos steps are queued: put the rebuild right behind them, then wait for the
+                // the certificate's kernels are queued: put the rebuild right behind them, then wait for the
                 // certificate's read-back only - the host round trip is hidden behind the rebuild kernels.  (Z and G
                 // are not modified by the rebuild, so a failed certificate costs nothing but the redo below.)
                 TLSQ_TRY(count_and_rebuild(true));
-                bool cert_ok = false;
-                TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
-                if (!cert_ok) {
-                    fast_ok = false;
-                    rebuilt = false;
+                // asynchronous form (second stream): the verdict is read after the sweep and the next Gram are queued as well
+                cert_late = sub.cert_async && zmode && fuse;
+                if (!cert_late) {
+                    bool cert_ok = false;
+                    TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
+                    if (!cert_ok) {
+                        fast_ok = false;
+                        rebuilt = false;
+                    }
                 }
             }
+            sub.cert_async = false;
         }
         if (!fast_ok && !hook_now && sub.fail != SubspaceState::FAIL_NONE && sub.fail != SubspaceState::FAIL_WINDOW) {
             // enlarge the block (random columns behind the current Ritz vectors) / grant more steps, and retry.
@@ -2075,6 +2139,27 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // the Gram + Lanczos evaluation of opnorm(R) is skipped altogether.
         const bool want_exact_cost = (info && info->cost_hist) || (opts && opts->on_iter) || k == ro.iters;
         double *sumsq_dev = nullptr, *sumsq_next = nullptr;
+        // The verdict of this iteration's count certificate when it runs asynchronously (second stream: it has had the factor
+        // product, the sweep and the launch of the next Gram to finish).  "Not certified": Z_k, Y_k, G_k and the factors of
+        // A_{k-1} are all intact - the queued sweep wrote the other buffers - so the SVD step is served again, without the
+        // subspace shortcut, and its sweep overwrites what the discarded one left.
+        auto late_verdict = [&](bool* redo) -> int {
+            *redo = false;
+            if (!cert_late) return TLSQ_OK;
+            cert_late = false;
+            bool cert_ok = false;
+            TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
+            if (fail_cert_at == k && !redo_cert_failed) cert_ok = false;   // (test hook)
+            if (cert_ok) return TLSQ_OK;
+            if (dev_get(DEV_DEBUG)) fprintf(stderr, "  iteration %lld: asynchronous certificate failed, redoing the SVD step\n", (long long)k);
+            if (sumsq_dev) TLSQ_HIP(h, hipMemsetAsync(sumsq_dev, 0, 72 * 8, h->stream));   // (the discarded sweep's partial sums)
+            mu = mu_iter;
+            g_ready = false;
+            z_swept = false;
+            redo_cert_failed = true;
+            *redo = true;
+            return TLSQ_OK;
+        };
         if (fuse && !want_exact_cost && !hook_opnorm) {
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
@@ -2125,9 +2210,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         auto sweep_rows = [&](int64_t r0, int64_t r1, size_t pad_lds) -> int {
             if (zmode)
                 return launch_zsweep<T>(h, D, Tm_last, Vs_last, fuse_rebuild ? (T*)nullptr : A, Ybuf[ycur], Ybuf[ycur ^ 1],
-                                        Zbuf[0], Rst, M, N, svp, (T)mu, (T)inv_mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
+                                        Zbuf[zc], Rst, M, N, svp, (T)mu, (T)inv_mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next),
                                         (T)(lam / mu_next), ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K,
-                                        r0, r1, maxslot, ro.hankel_geom);
+                                        r0, r1, maxslot, ro.hankel_geom, Zbuf[zc ^ 1]);
             return launch_rebuild_update_shrink<T>(h, D, Tm_last, Vs_last, E, Y, Rst, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp,
                                                    (T)mu, ro.nonnegA ? 1 : 0, (T)(1.0 / mu_next), (T)(lam / mu_next),
                                                    ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, (const T*)ro.hankel_y,
@@ -2137,7 +2222,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // the last allowed iteration (no next shrink to fuse with): E_k is formed now, then the plain residual :217-221
             if (prev_no_factors) {   // A_{k-1} has no factor form: E_k = D - Z_k + Y_k / mu_k (:192)
                 TLSQ_TRY(panel_D(&D));
-                TLSQ_TRY(launch_e_from_z<T>(h, D, Zbuf[0], Ybuf[ycur], Ebuf[0], n, (T)inv_mu));
+                TLSQ_TRY(launch_e_from_z<T>(h, D, Zbuf[zc], Ybuf[ycur], Ebuf[0], n, (T)inv_mu));
             } else {
                 TLSQ_TRY(form_final_e(Ybuf[ycur], mu));
             }
@@ -2182,7 +2267,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     if (r1 > r0) TLSQ_TRY(sweep_rows(r0, r1, pad_lds));
                     TLSQ_HIP(h, hipEventRecord(h->ev_b[c], h->stream));
                     TLSQ_HIP(h, hipStreamWaitEvent(h->stream_b, h->ev_b[c], 0));
-                    TLSQ_TRY(gram_launch_chunk(h, h->stream_b, pl, Zbuf[cur ^ 1] + r0, M, r1 - r0, c));
+                    TLSQ_TRY(gram_launch_chunk(h, h->stream_b, pl, (zmode ? Zbuf[zc ^ 1] : Zbuf[cur ^ 1]) + r0, M, r1 - r0, c));
                 }
                 TLSQ_TRY(gram_reduce(h, h->stream_b, pl, (double*)Gv, N));
                 TLSQ_HIP(h, hipEventRecord(h->ev_b[8], h->stream_b));
@@ -2205,9 +2290,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             hbm_sweeps += 6.0 * panel_bytes;
         }
         pt.mark(false, true);
+        if (timing && pt.sample) {   // this iteration's sweep launches (first shrink included) sit between recorded events
+            n_timed += (hbm_sweeps > hbm_sweeps_at_top) ? (have_next ? 1 : 2) : 0;
+            hbm_timed += hbm_sweeps - hbm_sweeps_at_top;
+        }
         if (zmode && z_swept) {
             dbg_hash(h, "sweep.Y", Ybuf[ycur ^ 1], (size_t)n * sizeof(T), k);
-            dbg_hash(h, "sweep.Z", Zbuf[0], (size_t)n * sizeof(T), k);
+            dbg_hash(h, "sweep.Z", Zbuf[zc ^ 1], (size_t)n * sizeof(T), k);
             if (Rst) dbg_hash(h, "sweep.R", Rst, (size_t)n * sizeof(T), k);
         }
         mu = mu_next;
@@ -2239,12 +2328,17 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 g_ready = true;
             } else if (gram_next) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
-                TLSQ_TRY(gram_allreduce<T>(h, Zbuf[cur ^ 1], M, N, M, &Gn));
+                TLSQ_TRY(gram_allreduce<T>(h, zmode ? Zbuf[zc ^ 1] : Zbuf[cur ^ 1], M, N, M, &Gn, Gslot[gcur ^ 1]));
                 hbm_other += panel_bytes;
                 g_ready = true;
             }
             pt.mark();
             pt.collect_previous(acc);                      // (host work hidden behind the sweep + Gram just queued)
+            {
+                bool redo = false;
+                TLSQ_TRY(late_verdict(&redo));
+                if (redo) goto redo_svd_step;
+            }
             bool got_mail = false;
             if (mail_sum) {
                 volatile double* mb = h->mailbox;
@@ -2300,6 +2394,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         } else {
             pt.mark();   // (empty read-back and "next Gram" windows)
             pt.mark();
+            bool redo = false;
+            TLSQ_TRY(late_verdict(&redo));
+            if (redo) goto redo_svd_step;
         }
         const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
         if (cost_skipped) {
@@ -2364,8 +2461,13 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             break;
         }
         if (fuse) {
-            if (zmode) ycur ^= 1;   // (Z was updated in place)
-            else cur ^= 1;
+            if (zmode) {
+                ycur ^= 1;
+                zc ^= 1;                         // (both entries are the same panel unless the loop speculates)
+                if (g_ready) gcur ^= 1;          // (likewise)
+            } else {
+                cur ^= 1;
+            }
             have_next = true;
         } else {
             have_next = false;
@@ -2374,7 +2476,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     if (k > ro.iters) k = ro.iters;
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     pt.finish(acc);
-    T* Z = Zbuf[cur];
+    T* Z = zmode ? Zbuf[zc] : Zbuf[cur];
     // (factors_out: the caller takes A as factors - unhankel reads them directly - and does not want E)
     const bool give_factors = ro.factors_out && zmode && a_pending && !ro.nonnegA && r_last <= 32 && !(S_host || Vt_host || U_dev);
     if (a_pending && !give_factors) {   // the loop never stored A: materialise the final one (:205-213, :217-219)
@@ -2391,8 +2493,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     } else if (zmode && z_swept) {
         // The E-free loop stopped behind a sweep: Y_k in Ybuf[ycur], Y_{k+1} in the other buffer, Z already Z_{k+1}.
         // Z_k = A_k + Y_{k+1} / mu_k for the returned decomposition (:194, :238), then E_k over whichever Y buffer E is.
-        if (S_host || Vt_host || U_dev) {
-            TLSQ_TRY(launch_z_from_y<T>(h, A, Ybuf[ycur ^ 1], Zbuf[0], n, (T)(1.0 / mu_iter)));
+        if ((S_host || Vt_host || U_dev) && Zbuf[zc] == Zbuf[zc ^ 1]) {   // (a double-buffered Z still holds Z_k itself)
+            TLSQ_TRY(launch_z_from_y<T>(h, A, Ybuf[ycur ^ 1], Z, n, (T)(1.0 / mu_iter)));
             hbm_sweeps += 3.0 * panel_bytes;
         }
         if (prev_no_factors) {   // A_{k-1} has no factor form: E_k = D - A_k - R_k, R_k = (Y_{k+1} - Y_k) / mu_k (:221-222)
@@ -2421,6 +2523,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->hbm_bytes_sweeps = hbm_sweeps;
         info->hbm_bytes = hbm_sweeps + hbm_other;
         info->residual_stores_skipped = n_rskip;
+        info->sweeps_timed = n_timed;
+        info->hbm_bytes_sweeps_timed = hbm_timed;
     }
     if (sv_out) *sv_out = sv;
 

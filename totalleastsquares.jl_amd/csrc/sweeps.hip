@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
 template <typename T, int RMAX, int ROWS, bool HK>
 __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const double* __restrict__ Tm,
                                                 const double* __restrict__ Vs, const T* __restrict__ Yin,
-                                                T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t M,
+                                                T* __restrict__ Yout, const T* __restrict__ Z, T* __restrict__ Zo,
+                                                T* __restrict__ R, int64_t M,
                                                 int N, int r, int ct, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n,
                                                 int nonnegE, double* __restrict__ sumsq, double* __restrict__ zero_slots,
                                                 int64_t hankel_K, int64_t row0, int64_t row1, int maxslot, HankelGeom hg) {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
             }
             if (R) __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
             __builtin_nontemporal_store(yn, reinterpret_cast<VR*>(Yout) + idx);
-            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Z) + idx);
+            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Zo) + idx);   // (Zo == Z: in place, every entry read before it is written)
         }
     }
     if (sumsq) {
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
 // the same sweep with A_k read from memory (ranks above 32: A does not fit a thread's registers as factors)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* __restrict__ A, const T* __restrict__ Yin,
-                                                    T* __restrict__ Yout, T* __restrict__ Z, T* __restrict__ R, int64_t n,
+                                                    T* __restrict__ Yout, const T* __restrict__ Z, T* __restrict__ Zo,
+                                                    T* __restrict__ R, int64_t n,
                                                     T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                                                     double* __restrict__ sumsq, double* __restrict__ zero_slots,
                                                     int maxslot) {
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
         if (nonnegA) __builtin_nontemporal_store(a, reinterpret_cast<V*>(A) + i);
         if (R) __builtin_nontemporal_store(rr, reinterpret_cast<V*>(R) + i);
         __builtin_nontemporal_store(yn, reinterpret_cast<V*>(Yout) + i);
-        __builtin_nontemporal_store(zn, reinterpret_cast<V*>(Z) + i);
+        __builtin_nontemporal_store(zn, reinterpret_cast<V*>(Zo) + i);
     }
     for (int64_t i = nv * VEC + tid; i < n; i += stride) {
         T ac = A[i], r1, y1, z1;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
         if (nonnegA) A[i] = ac;
         if (R) R[i] = r1;
         Yout[i] = y1;
-        Z[i] = z1;
+        Zo[i] = z1;
     }
     if (sumsq) {
 #pragma unroll
@@ -955,26 +957,27 @@ template <typename T>
 int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* A, const T* Yin, T* Yout, T* Z, T* R,
                   int64_t M, int64_t N, int64_t r, T mu, T inv_mu, int nonnegA, T inv_mu_n, T thr_n, int nonnegE,
                   double* sumsq, double* zero_slots, const T* hankel_y, int64_t hankel_K, int64_t row0, int64_t row1,
-                  int maxslot, HankelGeom hg) {
+                  int maxslot, HankelGeom hg, T* Zout) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
+    if (!Zout) Zout = Z;   // in place (the default): Z_{k+1} over Z_k
     if (row1 <= 0) row1 = M;
     if (!sumsq || maxslot > 7) maxslot = -1;
     if (A) {
         if (hankel_y || row0 != 0 || row1 != M) return set_err(h, TLSQ_ERR_ARG, "zsweep: explicit A needs the whole real panel");
         const int64_t n = M * N;
         constexpr int VEC = 16 / sizeof(T);
-        if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(R))
+        if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(Zout) && aligned16(R))
             hipLaunchKernelGGL((k_zsweep_lin<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z,
-                               R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
+                               Zout, R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
         else
-            hipLaunchKernelGGL((k_zsweep_lin<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z, R, n, mu,
+            hipLaunchKernelGGL((k_zsweep_lin<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z, Zout, R, n, mu,
                                inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
     if (r > 32 || N > 2147483647LL) return set_err(h, TLSQ_ERR_ARG, "zsweep: rank above 32 needs the explicit A");
     const bool pair_ok = (M % 2 == 0) && (row0 % 2 == 0) && (row1 % 2 == 0) && (hankel_y || aligned16(D)) && aligned16(Yin) &&
-                         aligned16(Yout) && aligned16(Z) && aligned16(R);
+                         aligned16(Yout) && aligned16(Z) && aligned16(Zout) && aligned16(R);
     if (row0 < 0 || row0 >= row1 || row1 > M) return set_err(h, TLSQ_ERR_ARG, "zsweep: bad row range");
     // two rows per thread (16-byte accesses for fp64) whenever the panels allow it; 64-column tiles for tall panels, narrower
     // ones until ~16 waves sit on every CU (measured at 20000 x 512: 75 us with 2 rows x 16 columns, 80 us with 1 x 32)
@@ -992,11 +995,11 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
 #define ZS_LAUNCH(RM, RW)                                                                                             \
     do {                                                                                                              \
         if (hankel_y)                                                                                                 \
-            hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, R, \
+            hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, Zout, R, \
                                M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
                                hankel_K, row0, row1, maxslot, hg);                                                    \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, R, M, \
+            hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, Zout, R, M, \
                                (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots,   \
                                (int64_t)0, row0, row1, maxslot, hg);                                                  \
     } while (0)
@@ -1194,7 +1197,7 @@ template int launch_convert<float, float>(Handle*, const float*, float*, int64_t
                                                  const T*, int64_t, int64_t, int64_t, size_t, HankelGeom);            \
     template int launch_zsweep<T>(Handle*, const T*, const double*, const double*, T*, const T*, T*, T*, T*, int64_t, \
                                   int64_t, int64_t, T, T, int, T, T, int, double*, double*, const T*, int64_t, int64_t, \
-                                  int64_t, int, HankelGeom);                                                           \
+                                  int64_t, int, HankelGeom, T*);                                                           \
     template int launch_final_e<T>(Handle*, const T*, const double*, const double*, const T*, const T*, T*, int64_t, \
                                    int64_t, int64_t, T, T, int, int, const T*, int64_t, HankelGeom);                  \
     template int launch_residual_from_y<T>(Handle*, const T*, const T*, T*, int64_t, T);                              \
