@@ -330,7 +330,9 @@ for (T, sym) in ((Float64, :tlsq_rtls_batched_f64), (Float32, :tlsq_rtls_batched
         st = check(ccall(($(QuoteNode(sym)), LIB[]), Cint,
             (Ptr{Cvoid}, Ptr{$T}, Ptr{$T}, Int64, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{$T},
              Ptr{Int32}, Ptr{Int32}), handle(), Array(A), Array(ym), M, n, q, B, o, x, iters, status))
-        st == 1 && @warn string("Maximum number of iterations reached in ", sum(status), " of ", B, " problems")
+        # (status per problem: 0 converged, 1 iteration limit, 2 the problem contains Infs / NaNs - the reference throws there)
+        any(==(Int32(2)), status) && throw(ArgumentError(string("matrix contains Infs or NaNs (", count(==(Int32(2)), status), " of ", B, " problems)")))
+        st == 1 && @warn string("Maximum number of iterations reached in ", count(==(Int32(1)), status), " of ", B, " problems")
         ndims(y) == 2 ? reshape(x, n, B) : x
     end
 end
@@ -347,7 +349,9 @@ for (T, sym) in ((Float64, :tlsq_rpca_batched_f64), (Float32, :tlsq_rpca_batched
         st = check(ccall(($(QuoteNode(sym)), LIB[]), Cint,
             (Ptr{Cvoid}, Ptr{$T}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{$T}, Ptr{$T}, Ptr{$T}, Ptr{$T},
              Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{$T}), handle(), Dm, M, N, B, o, A, E, S, Vt, sv, iters, status, cost))
-        st == 1 && @warn string("Maximum number of iterations reached in ", sum(status), " of ", B, " problems")
+        # (status per problem: 0 converged, 1 iteration limit, 2 the problem contains Infs / NaNs - the reference throws there)
+        any(==(Int32(2)), status) && throw(ArgumentError(string("matrix contains Infs or NaNs (", count(==(Int32(2)), status), " of ", B, " problems)")))
+        st == 1 && @warn string("Maximum number of iterations reached in ", count(==(Int32(1)), status), " of ", B, " problems")
         A, E, S, Vt, sv, iters, status, cost
     end
 end

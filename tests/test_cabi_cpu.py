@@ -111,3 +111,27 @@ def test_bench_vectors_are_the_oracles():
     assert info.svp_hist == ref["svp_hist"][:3]
     assert np.allclose(info.cost_hist, ref["cost_hist"][:3], rtol=1e-12)
     assert ref["iters"] == len(ref["svp_hist"]) == len(ref["cost_hist"]) and ref["converged"]
+
+
+def test_dev_switches_restore_the_previous_value():
+    """nested / overlapping uses of the context manager keep the outer setting; unknown TLSQ_* variables of the
+    environment are skipped with a warning instead of aborting a tool"""
+    import warnings
+    tlsq_amd.dev_set("PAD", 7)
+    try:
+        with tlsq_amd.dev_switches(PAD=3):
+            assert L._dev_shadow["PAD"] == "3"
+            with tlsq_amd.dev_switches(PAD=5, NO_ZSWEEP=1):
+                assert L._dev_shadow["PAD"] == "5" and L._dev_shadow["NO_ZSWEEP"] == "1"
+            assert L._dev_shadow["PAD"] == "3" and "NO_ZSWEEP" not in L._dev_shadow
+        assert L._dev_shadow["PAD"] == "7"
+    finally:
+        tlsq_amd.dev_set("PAD", None)
+    assert "PAD" not in L._dev_shadow
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = tlsq_amd.dev_from_env({"TLSQ_NO_SUCH_SWITCH": "1", "TLSQ_PAD": "4", "TLSQ_LIB": "x", "HOME": "/"})
+    try:
+        assert got == {"TLSQ_PAD": "4"} and any("NO_SUCH_SWITCH" in str(x.message) for x in w)
+    finally:
+        tlsq_amd.dev_set("PAD", None)

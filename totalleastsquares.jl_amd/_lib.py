@@ -167,12 +167,24 @@ def load():
     return lib
 
 
+_dev_shadow = {}   # what this process has set through dev_set (the library has no getter): name without prefix -> string
+
+
+def _dev_key(name):
+    return name[5:] if name.startswith("TLSQ_") else name
+
+
 def dev_set(name, value):
-    """tlsq_dev_set: select a development switch of the library by name (value None clears it); raises on unknown names."""
+    """tlsq_dev_set: select a development switch of the library by name (value None clears it); raises on unknown names.
+    Process-wide state of the library: set it between solves, never while another thread is inside one."""
     lib = load()
     v = None if value is None else str(value).encode()
     if lib.tlsq_dev_set(name.encode(), v) != 0:
         raise ValueError(f"unknown tlsq development switch {name!r}")
+    if value is None:
+        _dev_shadow.pop(_dev_key(name), None)
+    else:
+        _dev_shadow[_dev_key(name)] = str(value)
 
 
 # environment variables that look like switches but are not the library's (read by the Python / Julia hosts themselves)
@@ -180,29 +192,38 @@ _NOT_SWITCHES = {"TLSQ_LIB", "TLSQ_NGPUS", "TLSQ_DEVICE", "TLSQ_EXTRA_FLAGS", "T
 
 
 def dev_from_env(environ=None):
-    """Tools and tests that are steered from the shell call this explicitly: every TLSQ_<NAME> variable of the environment is
-    handed to tlsq_dev_set (a mistyped name raises).  The library itself never looks at the environment."""
+    """Tools and tests that are steered from the shell call this explicitly: every TLSQ_<NAME> variable of the environment that
+    names a switch of the library is handed to tlsq_dev_set; a variable the library does not know (one a harness set, a typo)
+    is reported with a warning and skipped.  The library itself never looks at the environment."""
+    import warnings
     environ = os.environ if environ is None else environ
     applied = {}
     for k, v in environ.items():
         if k.startswith("TLSQ_") and k not in _NOT_SWITCHES:
-            dev_set(k, v)
+            try:
+                dev_set(k, v)
+            except ValueError:
+                warnings.warn(f"{k} is not a development switch of libtlsqhip (ignored)")
+                continue
             applied[k] = v
     return applied
 
 
 class dev_switches:
-    """with dev_switches(NO_ZSWEEP=1, ...): the switches are set inside the block and cleared afterwards"""
+    """with dev_switches(NO_ZSWEEP=1, ...): the switches are set inside the block and put back to what they were before it
+    (nested and overlapping uses keep the outer setting)."""
 
     def __init__(self, **kw):
         self.kw = kw
+        self.prev = {}
 
     def __enter__(self):
         for k, v in self.kw.items():
+            self.prev[k] = _dev_shadow.get(_dev_key(k))
             dev_set(k, v)
         return self
 
     def __exit__(self, *exc):
         for k in self.kw:
-            dev_set(k, None)
+            dev_set(k, self.prev.get(k))
         return False

@@ -388,9 +388,23 @@ static int tls_impl(tlsq_handle h, const T* Ay, int64_t M, int64_t ncols, int64_
         dAy = (const T*)p;
         ld = M;
     }
+    // svd! of the reference goes through LAPACK's chkfinite and throws ArgumentError("matrix contains Infs or NaNs") before it
+    // decomposes anything (src/TotalLeastSquares.jl:63): one max-abs pass over the panel (k_maxabs maps NaN to Inf) settles it
+    // on every route - the decomposition's own NaN propagation is not a contract
+    if (ld == M) {
+        double mx = 0.0;
+        TLSQ_TRY(launch_maxabs<T>(h, dAy, M * ncols, &mx));
+        if (!std::isfinite(mx)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
+    } else {
+        for (int64_t c = 0; c < ncols; ++c) {
+            double mx = 0.0;
+            TLSQ_TRY(launch_maxabs<T>(h, dAy + (size_t)c * ld, M, &mx));
+            if (!std::isfinite(mx)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
+        }
+    }
     std::vector<double> Vt;
     TLSQ_TRY(vt_of<T>(h, dAy, M, ncols, ld, Vt));
-    for (double v : Vt)   // (finite input never gives a non-finite V; svd! of the reference throws on Infs / NaNs: chkfinite)
+    for (double v : Vt)   // (an assertion only: finite input never gives a non-finite V)
         if (!std::isfinite(v)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
     const int64_t q = ncols - n;
     std::vector<double> hx((size_t)n * q);

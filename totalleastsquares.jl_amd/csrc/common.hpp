@@ -108,7 +108,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID) X(SWEEP_TIMING_STRIDE)                                                                                   \
     X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
     X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
-    X(NO_CERT_OVERLAP) X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_FUSED_DEFLATE)                                                                                 \
+    X(NO_CERT_OVERLAP) X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(NO_FUSED_DEFLATE)                                                                                 \
     X(NO_RR_FAST) X(NO_U_POLISH) X(NO_GX_REUSE) X(COLD_CGS2) X(COLD_Q) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(JACOBI_RPL) X(NO_CHOL) X(NO_SYMM_MFMA)             \
     X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS)    \
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
@@ -247,6 +247,15 @@ struct SelWeights {
     int32_t sel[32];
     double w[32];
 };
+// The same list in device memory, written by the last workgroup of k_ritz_finish from the Ritz values it has just formed
+// (count of values >= 1/mu, their weights (sigma - 1/mu) / sigma: src/robustPCA.jl:198, :205-213) so that the factor product
+// of the rebuild can be queued before the host has seen them.  ok = 0: the step is not one the host will accept as it stands
+// (values out of order, a declined Rayleigh-Ritz kernel, non-finite numbers): the product is skipped.
+struct SpecCtrl {
+    int32_t ok, r;
+    int32_t pad[2];
+    SelWeights sw;
+};
 
 // ---------------- gemm.hip ----------------
 // Cm[j + i*ldc] = sum_k Aop(i,k) * Bop(k,j), i<P, j<Q, k<K
@@ -270,6 +279,10 @@ int tsmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* W
 // the same with W = V[:, sel] diag(w) (r <= 32) gathered and packed in one pass; Vs (optional, K x r) = V[:, sel]
 int tsmm_sel(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, const SelWeights& sw, double* Vs, double* Tout,
              int64_t ldt, int64_t M, int64_t K, int64_t r);
+// ... with the list (and r) read from device memory when the kernel runs (k_tsmm_selv only: K a multiple of 4); nct = 1 / 2
+// accumulator tiles of 16 columns are compiled in: the launch does nothing when ctrl->ok == 0 or ctrl->r > 16 nct
+int tsmm_sel_dev(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, const SpecCtrl* ctrl, int nct, double* Vs,
+                 double* Tout, int64_t ldt, int64_t M, int64_t K);
 // Y (N x p, fp64) = Z' * T  (Z: M x N fp32/fp64, T: M x p fp64): column dots for p <= 8, the tiled MFMA kernel beyond
 int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* Tm, int64_t ldt, double* Y, int64_t ldy,
                int64_t M, int64_t N, int64_t p);
@@ -433,7 +446,8 @@ int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r,
 // and published with sequence number seq (see k_ritz_finish)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p, const double* status = nullptr,
-                       double* mailbox_dev = nullptr, unsigned int* arrivals = nullptr, double seq = 0.0);
+                       double* mailbox_dev = nullptr, unsigned int* arrivals = nullptr, double seq = 0.0,
+                       SpecCtrl* ctrl = nullptr, double inv_mu = 0.0, int nukeA = 1);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
                       int64_t N, int64_t p);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);

@@ -1401,11 +1401,18 @@ __global__ __launch_bounds__(256) void k_gather_pack_w(const double* __restrict_
 // second launch. Each lane reads four consecutive k of its column at once (k = 16*trip + 4*fk + u for the MFMA of step u; the
 // sum over k does not care about the assignment as long as both operands use it), so a trip touches as many cache lines
 // of V as it would of the packed panel. Vs (K x r) receives V[:, sel], spread over the first workgroups.
-template <typename TA, int NCT, int RT>
+template <typename TA, int NCT, int RT, bool DEVLIST = false>
 __global__ __launch_bounds__(256) void k_tsmm_selv(const TA* __restrict__ Z, int64_t ldz, const double* __restrict__ V,
-                                                   SelWeights sw, double* __restrict__ Vs, double* __restrict__ Tout,
-                                                   int64_t ldt, int64_t M, int K, int r) {
+                                                   SelWeights sw_arg, double* __restrict__ Vs, double* __restrict__ Tout,
+                                                   int64_t ldt, int64_t M, int K, int r, const SpecCtrl* __restrict__ ctrl) {
     __shared__ double sR[4 * RT * NCT * 256];   // [w][t][c][reg][lane]
+    // DEVLIST: selection, weights and r come from device memory (written by k_ritz_finish one launch earlier); nothing to do
+    // when that kernel did not vouch for them or the count needs more accumulator tiles than this instance has
+    if constexpr (DEVLIST) {
+        if (ctrl->ok == 0 || ctrl->r > 16 * NCT) return;
+        r = ctrl->r;
+    }
+    const SelWeights& sw = DEVLIST ? ctrl->sw : sw_arg;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * (16 * RT);
@@ -1551,7 +1558,7 @@ static int tsmm_impl(Handle* h, const void* Z, int z_f32, int64_t ldz, const dou
         const dim3 grid((unsigned)((M + (tall ? 64 : 32) - 1) / (tall ? 64 : 32)));
 #define TSV_LAUNCH(TA, NC, RTT)                                                                                     \
     hipLaunchKernelGGL((k_tsmm_selv<TA, NC, RTT>), grid, dim3(256), 0, h->stream, (const TA*)Z, ldz, V, *sw, Vs, Tout, ldt, \
-                       M, (int)K, (int)r)
+                       M, (int)K, (int)r, (const SpecCtrl*)nullptr)
 #define TSV_TYPE(TA)                                                              \
     if (nct == 1) { if (tall) TSV_LAUNCH(TA, 1, 4); else TSV_LAUNCH(TA, 1, 2); } \
     else { if (tall) TSV_LAUNCH(TA, 2, 4); else TSV_LAUNCH(TA, 2, 2); }
@@ -1602,6 +1609,25 @@ int tsmm_sel(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, 
              int64_t ldt, int64_t M, int64_t K, int64_t r) {
     if (r > 32) return set_err(h, TLSQ_ERR_ARG, "tsmm_sel: r > 32");
     return tsmm_impl(h, Z, z_f32, ldz, nullptr, 0, V, &sw, Vs, Tout, ldt, M, K, r);
+}
+
+int tsmm_sel_dev(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* V, const SpecCtrl* ctrl, int nct, double* Vs,
+                 double* Tout, int64_t ldt, int64_t M, int64_t K) {
+    if ((K & 3) != 0 || nct < 1 || nct > 2 || !ctrl) return set_err(h, TLSQ_ERR_ARG, "tsmm_sel_dev: bad argument");
+    const bool tall = M >= 65536;
+    const dim3 grid((unsigned)((M + (tall ? 64 : 32) - 1) / (tall ? 64 : 32)));
+    const SelWeights none{};
+#define TSD_LAUNCH(TA, NC, RTT)                                                                                       \
+    hipLaunchKernelGGL((k_tsmm_selv<TA, NC, RTT, true>), grid, dim3(256), 0, h->stream, (const TA*)Z, ldz, V, none, Vs, Tout, \
+                       ldt, M, (int)K, 0, ctrl)
+#define TSD_TYPE(TA)                                                              \
+    if (nct == 1) { if (tall) TSD_LAUNCH(TA, 1, 4); else TSD_LAUNCH(TA, 1, 2); } \
+    else { if (tall) TSD_LAUNCH(TA, 2, 4); else TSD_LAUNCH(TA, 2, 2); }
+    if (z_f32) { TSD_TYPE(float) } else { TSD_TYPE(double) }
+#undef TSD_TYPE
+#undef TSD_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 // Y (N x pc, ld N) = Z' * T for a few columns (pc <= 8): one wave per column of Z (coalesced reads), T (M x pc) from L2.

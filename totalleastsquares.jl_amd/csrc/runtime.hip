@@ -194,11 +194,20 @@ struct LocalGroup {
             cv.notify_all();
             return true;
         }
-        if (cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || failed; }) && gen != g) return true;
+        // (wait_until on the system clock = pthread_cond_timedwait; wait_for goes through pthread_cond_clockwait, which the
+        //  ThreadSanitizer runtime of this toolchain does not intercept: it then believes the mutex is held across the wait)
+        if (cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(60), [&] { return gen != g || failed; }) &&
+            gen != g)
+            return true;
         --arrived;
         return false;
     }
     void fail() {
+#ifdef TLSQ_TSAN_PLANT_RACE   // (tests/test_tsan_cpu.py: the harness must report this)
+        failed = true;
+        cv.notify_all();
+        return;
+#endif
         std::lock_guard<std::mutex> lk(m);
         failed = true;
         cv.notify_all();
@@ -211,10 +220,15 @@ struct LocalGroup {
 };
 
 struct Comm {
+    // `comm` is used by its rank's thread (collectives) and may be aborted from ANOTHER rank's thread (multi_run's
+    // fail_group, when that rank leaves the group call with an error): every use of the communicator - the enqueue of a
+    // collective, the abort - happens under `m`, and an aborted communicator is never handed to RCCL again (ncclCommAbort
+    // frees it).  ADVICE r3: the abort used to race with a collective that had just read the pointer.
+    std::mutex m;
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> local;   // set instead of `comm` for a loop-back group
     int local_rank = 0;
-    bool aborted = false;                // ncclCommAbort has been called on `comm` (a rank of the group failed)
+    std::atomic<bool> aborted{false};    // ncclCommAbort has been called on `comm` (a rank of the group failed)
     std::shared_ptr<std::atomic<bool>> group_failed;   // shared by the ranks of a tlsq_create_multi group
 };
 
@@ -264,7 +278,12 @@ int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op) {
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         return TLSQ_OK;
     }
-    TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
+    {
+        std::lock_guard<std::mutex> lk(h->comm->m);
+        if (h->comm->aborted.load() || !h->comm->comm)
+            return set_err(h, TLSQ_ERR_COMM, "multi-GPU group: the communicator was aborted (another rank left the call with an error)");
+        TLSQ_NCCL(h, g_rccl.AllReduce(dev, dev, count, ncclDouble, op, h->comm->comm, h->stream));
+    }
     return TLSQ_OK;
 }
 
@@ -297,7 +316,12 @@ int comm_allgather(Handle* h, const double* send, double* recv, size_t count) {
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         return TLSQ_OK;
     }
-    TLSQ_NCCL(h, g_rccl.AllGather(send, recv, count, ncclDouble, h->comm->comm, h->stream));
+    {
+        std::lock_guard<std::mutex> lk(h->comm->m);
+        if (h->comm->aborted.load() || !h->comm->comm)
+            return set_err(h, TLSQ_ERR_COMM, "multi-GPU group: the communicator was aborted (another rank left the call with an error)");
+        TLSQ_NCCL(h, g_rccl.AllGather(send, recv, count, ncclDouble, h->comm->comm, h->stream));
+    }
     return TLSQ_OK;
 }
 
@@ -339,7 +363,7 @@ int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn) {
         if (h->multi_comm->group_failed) h->multi_comm->group_failed->store(false);   // (a loop-back group survives a failed call)
     }
     for (int r = 0; r < n; ++r)
-        if (hs[(size_t)r]->multi_comm && hs[(size_t)r]->multi_comm->aborted)
+        if (hs[(size_t)r]->multi_comm && hs[(size_t)r]->multi_comm->aborted.load())
             return set_err(h, TLSQ_ERR_COMM, "multi-GPU group: the communicators were aborted by an earlier failed call; "
                                              "destroy the handle and create a new one");
     // A rank that leaves the call with an error before a collective the others have entered would leave them blocked for
@@ -357,11 +381,17 @@ int multi_run(Handle* h, const std::function<int(Handle*, int, int)>& fn) {
         for (int q = 0; q < n; ++q) {
             Comm* c = hs[(size_t)q]->multi_comm;
             if (!c) continue;
-            if (c->local) c->local->fail();
-            else if (c->comm && g_rccl.CommAbort && !c->aborted) {
-                c->aborted = true;
-                (void)g_rccl.CommAbort(c->comm);
-                c->comm = nullptr;
+            if (c->local) {
+                c->local->fail();
+            } else {
+                // (under the communicator's own lock: its rank is either before the enqueue of a collective - it will find the
+                //  flag - or past it, in which case the abort makes the collective's kernel give up)
+                std::lock_guard<std::mutex> ck(c->m);
+                if (c->comm && g_rccl.CommAbort && !c->aborted.load()) {
+                    c->aborted.store(true);
+                    (void)g_rccl.CommAbort(c->comm);
+                    c->comm = nullptr;
+                }
             }
         }
     };

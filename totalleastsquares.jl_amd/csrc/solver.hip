@@ -279,6 +279,23 @@ struct SubspaceState {
     // product, the next sweep and the next Gram before it asks for the verdict
     bool cert_async = false;
     volatile double* cert_mb = nullptr;   // where cert_finish polls (nullptr: the main mailbox)
+    // Speculative factor product of the rebuild (rpca_core): queued right behind k_ritz_finish of a warm block's first step,
+    // with the selection, the weights and the count taken from the device-side decision block that kernel writes - the host
+    // round trip (poll, sort, count, launch: ~10 us) is then hidden behind the product instead of standing in front of it.
+    // The host checks afterwards that the device decided what it decides itself (dev_ok, dev_r); anything else - a second
+    // step, a re-ordered block, a rank that needs more accumulator tiles - simply launches the product again.
+    struct SpecRebuild {
+        bool enable = false;             // the caller wants it for this call (buffers below are valid)
+        const void* Z = nullptr;
+        int z_f32 = 0;
+        int64_t M = 0, ldz = 0;
+        double *Tout = nullptr, *Vs = nullptr;   // room for 32 columns each
+        bool nukeA = true;
+        bool launched = false;           // result: a product was queued in the step that converged ...
+        int nct = 0;                     // ... with this many 16-column accumulator tiles
+        bool dev_ok = false;             // ... and this is what the device decided
+        int64_t dev_r = 0;
+    } spec;
     LanczosRun cert;
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
     int q_floor = 1;       // smallest count that may be tried again (raised when a count needed a second step)
@@ -553,6 +570,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     bool conv = false;
     double prev_maxres = 0.0;
     bool gx_valid = false;    // WS_SGX holds G X for the block in WS_SX (see the top of the loop)
+    bool x_settled = false;   // nothing that writes the block X has been queued since the host read the last step's results
     bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
     bool cgs2_sticky = false;
     const bool no_onepass = dev_is(DEV_NO_ONEPASS, '1');
@@ -567,6 +585,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
     }
     for (int step = 0; step < max_steps; ++step) {
         ++st.steps;
+        st.spec.launched = false;
         // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
         // vectors; q-1 extra multiplications of those columns cost one skinny GEMM each and raise their
         // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
@@ -636,8 +655,17 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                 h->mail_counter_ready = true;
             }
             const double seq = (h->mail_seq += 1.0);
+            const bool spec_now = st.spec.enable && rr_fast && step == 0 && (N & 3) == 0 && nt_step <= 32 && p <= 32;
+            SpecCtrl* ctrl = spec_now ? reinterpret_cast<SpecCtrl*>(reinterpret_cast<char*>(scal) + 2048) : nullptr;
             TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
-                                        (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq));
+                                        (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq, ctrl,
+                                        inv_mu, st.spec.nukeA ? 1 : 0));
+            if (spec_now) {
+                st.spec.nct = nt_step <= 16 ? 1 : 2;
+                TLSQ_TRY(tsmm_sel_dev(h, st.spec.Z, st.spec.z_f32, st.spec.ldz, (const double*)X, ctrl, st.spec.nct, st.spec.Vs,
+                                      st.spec.Tout, st.spec.M, st.spec.M, N));
+                st.spec.launched = true;
+            }
             // poll the flag (the kernel publishes it once every workgroup has delivered); generous time-out, then the
             // classic read-back
             volatile double* mb = h->mailbox;
@@ -651,8 +679,11 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                 if (now_ms() - t_poll > 2000.0) break;
             }
             if (got) {
-                for (int64_t i = 0; i < 2 * p + 3; ++i) host[(size_t)i] = mb[8 + i];
+                for (int64_t i = 0; i < 2 * p + 5; ++i) host[(size_t)i] = mb[8 + i];
+                st.spec.dev_ok = st.spec.launched && host[(size_t)(2 * p + 3)] != 0.0;
+                st.spec.dev_r = (int64_t)host[(size_t)(2 * p + 4)];
             } else {
+                st.spec.launched = false;
                 // never seen in practice; do not pay the time-out again on this handle
                 h->mailbox_bytes = 0;
                 TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
@@ -731,6 +762,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             }
             bool sorted = true;
             for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[i] == (int32_t)i;
+            x_settled = sorted && mail;   // (a re-ordering is queued on the main stream: the block is in flux until that has run)
             if (!sorted) {
                 TLSQ_HIP(h, hipMemcpyAsync(XN, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
                 TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
@@ -855,7 +887,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         // Asynchronous form: the host has just read this step's results from the mailbox, so everything the certificate reads
         // (G, the block X) is complete - its two kernels go to the second stream and run beside whatever the caller queues next
         const bool async = st.cert_async && st.defer_certificate && st.cert_power && fused_deflate && svp > 0 && h->stream_b &&
-                           h->mailbox && !dev_is(DEV_NO_MAILBOX, '1');
+                           x_settled && h->mailbox && h->mailbox_bytes >= 32768 && !dev_is(DEV_NO_MAILBOX, '1');
         st.cert_async = async;
         StreamScope on_b(h, async ? h->stream_b : nullptr);
         if (fused_deflate && svp > 0)
@@ -1259,7 +1291,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // again through the retries / the TSQR route (FAIL_CERT_AT=k injects one for the tests).
     const bool spec = zmode && !dev_is(DEV_NO_CERT_ASYNC, '1') && !dev_is(DEV_NO_CERT_OVERLAP, '1') && N <= kFullEigMaxN &&
                       (size_t)n * sizeof(T) <= ((size_t)1 << 31) && h->mailbox && h->mailbox_bytes >= 32768 &&
-                      !dev_is(DEV_NO_MAILBOX, '1');
+                      !dev_is(DEV_NO_MAILBOX, '1') &&
+                      // (lowrankfilter on an implicit Hankel panel promises four resident panels: a fifth only while it is small)
+                      !(ro.hankel_lazy && (size_t)n * sizeof(T) > ((size_t)1 << 28));
     if (!zmode) {
         TLSQ_TRY(ws_get(h, WS_E2, (size_t)n * sizeof(T), &E2v));
         TLSQ_TRY(ws_get(h, WS_Z2, (size_t)n * sizeof(T), &Z2v));
@@ -1272,6 +1306,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     int zc = 0;                  // E-free loop: Z_k sits in Zbuf[zc], the sweep writes Z_{k+1} to Zbuf[zc ^ 1] (the same panel unless spec)
     const int Gslot[2] = {WS_G, spec ? WS_G3 : WS_G};
     int gcur = 0;                // the Gram matrix of the current Z sits in (or is computed into) workspace slot Gslot[gcur]
+    // ... and the factor product of the rebuild is queued behind the Rayleigh-Ritz finish with a device-side selection list
+    const bool spec_rebuild = zmode && !dev_is(DEV_NO_SPEC_REBUILD, '1') && !dev_is(DEV_NO_TSMM, '1') && !dev_is(DEV_NO_TSMM_SEL, '1') &&
+                              !dev_is(DEV_NO_TSMM_SELV, '1') && !dev_is(DEV_NO_MAILBOX, '1') && (N & 3) == 0 && N <= kFullEigMaxN &&
+                              ro.maxrank >= 32;
+    int64_t n_spec_hits = 0;
     const int64_t fail_cert_at = [] { const char* e = dev_get(DEV_FAIL_CERT_AT); return (int64_t)(e ? atoll(e) : 0); }();
     T* Ybuf[2] = {Y, E};         // E-free loop: Y_k sits in Ybuf[ycur], the sweep writes Y_{k+1} to the other one
     int ycur = 0;
@@ -1837,7 +1876,18 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             else
                 fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
                                rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
-            TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last, zmode ? ((k & 1) ? 1 : 2) : 0));
+            // (the factor product may already be queued: SubspaceState::SpecRebuild - same kernel, same list, decided on the device)
+            bool spec_hit = sub.spec.launched && sub.spec.dev_ok && sub.spec.dev_r == svp && svp >= 1 &&
+                            svp <= 16 * sub.spec.nct && V == (const double*)h->ws[WS_SX].p && sub.spec.Z == (const void*)Z;
+            for (int64_t p = 0; p < svp && spec_hit; ++p) spec_hit = sel[(size_t)p] == (int32_t)p;
+            sub.spec.launched = false;
+            if (spec_hit) {
+                Tm_last = sub.spec.Tout;
+                Vs_last = sub.spec.Vs;
+                ++n_spec_hits;
+            } else {
+                TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, M, V, sel, g, &Tm_last, &Vs_last, zmode ? ((k & 1) ? 1 : 2) : 0));
+            }
             r_last = svp;
             if (svp > 0) hbm_other += panel_bytes;                      // T = Z Vg reads Z once
             if (!fuse_rebuild) {
@@ -1973,7 +2023,22 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             sub.noise_rel = noise_rel;
             sub.defer_certificate = !no_cert_overlap;
             sub.cert_async = spec && k < ro.iters;
+            if (spec_rebuild && sub.valid && G) {
+                // the buffers rebuild_factors would take for this iteration (the E-free loop keeps two pairs in turn), at full width
+                void *tb, *vb;
+                TLSQ_TRY(ws_get(h, (k & 1) ? WS_T2 : WS_T, (size_t)M * 32 * 8, &tb));
+                TLSQ_TRY(ws_get(h, (k & 1) ? WS_VS2 : WS_VS3, (size_t)N * 32 * 8, &vb));
+                sub.spec.enable = true;
+                sub.spec.Z = Z;
+                sub.spec.z_f32 = Prec<T>::f32;
+                sub.spec.M = M;
+                sub.spec.ldz = M;
+                sub.spec.Tout = (double*)tb;
+                sub.spec.Vs = (double*)vb;
+                sub.spec.nukeA = ro.nukeA;
+            }
             const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
+            sub.spec.enable = false;
             sub.defer_certificate = false;
             if (st_sub < 0) return st_sub;
             if (fast_ok && sub.cert_pending) {
@@ -2475,6 +2540,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     }
     if (k > ro.iters) k = ro.iters;
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (dev_get(DEV_DEBUG)) fprintf(stderr, "  speculative factor products used: %lld of %lld iterations\n", (long long)n_spec_hits, (long long)k);
     pt.finish(acc);
     T* Z = zmode ? Zbuf[zc] : Zbuf[cur];
     // (factors_out: the caller takes A as factors - unhankel reads them directly - and does not want E)

@@ -1346,7 +1346,8 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
                                                      double* __restrict__ GX, double* __restrict__ theta,
                                                      double* __restrict__ res, int N, int p,
                                                      const double* __restrict__ status, double* mailbox,
-                                                     unsigned int* arrivals, double seq) {
+                                                     unsigned int* arrivals, double seq, SpecCtrl* ctrl, double inv_mu,
+                                                     int nukeA) {
     __shared__ double sS[CQ_PMAX * 16];   // p <= 512
     __shared__ double red[4];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1392,6 +1393,34 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
                 mb[8 + 2 * p] = status ? status[0] : 0.0;
                 mb[8 + 2 * p + 1] = status ? status[1] : 0.0;
                 mb[8 + 2 * p + 2] = status ? status[2] : 0.0;
+                if (ctrl) {
+                    // The decision the host takes from these numbers (solver.hip: sorted block, count of sigma >= 1/mu, weights of
+                    // the thresholded rebuild), in the same arithmetic (IEEE sqrt and division), so that the factor product
+                    // queued behind this kernel runs without waiting for the host.  The other workgroups' Ritz values were
+                    // released by their fences before they arrived here; they are read past this CU's L1.
+                    bool ok = !(status && status[1] != 0.0);
+                    double prev = 0.0;
+                    int r = 0;
+                    for (int i = 0; i < p; ++i) {
+                        const double t = __hip_atomic_load(theta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(t - t == 0.0)) ok = false;
+                        const double sg = sqrt(t > 0.0 ? t : 0.0);
+                        if (i > 0 && sg > prev) ok = false;   // (the host's stable sort would move this column)
+                        prev = sg;
+                        if (sg >= inv_mu) {
+                            if (r < 32) {
+                                ctrl->sw.sel[r] = i;
+                                ctrl->sw.w[r] = nukeA ? (sg - inv_mu) / sg : 1.0;
+                            }
+                            ++r;
+                        }
+                    }
+                    if (r > 32) ok = false;
+                    ctrl->r = r;
+                    ctrl->ok = ok ? 1 : 0;
+                    mb[8 + 2 * p + 3] = ok ? 1.0 : 0.0;
+                    mb[8 + 2 * p + 4] = (double)r;
+                }
                 *arrivals = 0u;
                 __threadfence_system();
                 mb[0] = seq;
@@ -1404,10 +1433,10 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
 // for blocks of more than 256 columns (k_panel_rot2 keeps S in LDS: p <= 90 there)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p, const double* status, double* mailbox_dev,
-                       unsigned int* arrivals, double seq) {
+                       unsigned int* arrivals, double seq, SpecCtrl* ctrl, double inv_mu, int nukeA) {
     if (p <= 512) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
         hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
-                           (int)p, status, mailbox_dev, arrivals, seq);
+                           (int)p, status, mailbox_dev, arrivals, seq, mailbox_dev ? ctrl : nullptr, inv_mu, nukeA);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
