@@ -1569,6 +1569,36 @@ def test_returned_singular_vectors_are_orthonormal(eng, M, N, r):
     assert np.max(np.abs(S - so[1])) < 1e-10 * so[1][0]
 
 
+def test_float32_returned_vectors_are_repaired_on_the_device(eng):
+    """a Float32 call that returns U (the default of the Python engine and of the Julia drop-in) used to send every
+    tail column (sigma_i <= 1e4 eps32 sigma_max = 1.2e-3 sigma_max: all of them) through a single-threaded HOST Gram-Schmidt -
+    seconds at 10000 x 512 against a millisecond-scale solve.  The repair is on the device now (first-order passes; block
+    Gram-Schmidt only for columns below 10 sqrt(d) eps sigma_max): orthonormal to fp32 working precision, and timed."""
+    import time
+    from oracle import rpca_oracle as O
+    D = O.synth_lowrank_sparse(10000, 512, 12, seed=41, dtype=np.float32)[0]
+    eng.rpca(D)                                    # (workspace growth, first-use costs)
+    t0 = time.perf_counter()
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    dt = time.perf_counter() - t0
+    U, S, Vt = (np.asarray(x, dtype=np.float64) for x in (s.U, s.S, s.Vt))
+    assert s.U.dtype == np.float32 and rep.converged
+    assert np.abs(U.T @ U - np.eye(512)).max() < 2e-5 and np.abs(Vt @ Vt.T - np.eye(512)).max() < 2e-5
+    assert dt < 0.5, f"{dt:.3f} s for a 10000 x 512 Float32 call with U"
+    # exact zero singular values (zero columns of D stay zero columns of Z): directions from seeded normals + the device
+    # Gram-Schmidt, fp32 and fp64, tall and square
+    for dt_, M, N in ((np.float32, 3000, 96), (np.float64, 3000, 96), (np.float64, 64, 64)):
+        rng = np.random.default_rng(M + N)
+        Dz = (rng.standard_normal((M, 5)) @ rng.standard_normal((5, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)).astype(dt_)
+        Dz[:, ::3] = 0
+        A, E, s, sv = eng.rpca(Dz)
+        U = np.asarray(s.U, dtype=np.float64)
+        tol = 2e-5 if dt_ == np.float32 else 1e-10
+        assert np.abs(U.T @ U - np.eye(min(M, N))).max() < tol, (dt_, M, N)
+        Z = (U * np.asarray(s.S, dtype=np.float64)) @ np.asarray(s.Vt, dtype=np.float64)
+        assert np.abs(Z[:, ::3]).max() < (1e-3 if dt_ == np.float32 else 1e-9) * np.abs(Z).max()
+
+
 def test_complex_counts_below_the_gram_resolution(eng):
     """Three small complex problems (tests/golden/complex_late_counts.npz: D as drawn by tools/fuzz_misc.py, seeds 0 / 1 / 3)
     whose last iterations have 1/mu below what the realified Gram matrix resolves (~sqrt(N eps) sigma_max): the count of

@@ -400,7 +400,8 @@ int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool i
 int subspace_max_block(int64_t N);
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
-                bool allow_cholqr, bool* used_cholqr, bool one_pass = false);
+                bool allow_cholqr, bool* used_cholqr, bool one_pass = false, int64_t c_start = 0);   // c_start: the columns in
+                // front of it are orthonormal already (Gram-Schmidt path only): they are projected out of the rest, not touched
 // Rayleigh-Ritz of a nearly orthogonal warm block without orthonormalisation pass and Jacobi sweeps (subspace.hip,
 // k_rr_small): B = Y'Y, Hg = Y'GY (scratch, p x p), C (p x p) with X' = Y C the Ritz vectors, lam their Ritz values,
 // status[1] != 0: not applicable (the caller falls back to CholeskyQR2 + Jacobi).  p <= 32.

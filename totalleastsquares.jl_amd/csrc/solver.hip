@@ -180,6 +180,8 @@ int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double
 // then one-sided Jacobi on R' (jacobi.hip).  Both steps are orthogonal transformations, so every singular value
 // carries an absolute error of a few eps * sigma_max like LAPACK's gesdd (src/robustPCA.jl:194) — the Gram route only
 // reaches eps * sigma_max^2 / sigma.  V in WS_V (all N right singular vectors), s = all N singular values.
+static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X);
+
 template <typename T>
 int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s, int64_t* sweeps) {
     void *B, *V, *lam;
@@ -187,18 +189,63 @@ int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** 
     TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &V));
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lam));
     TLSQ_TRY(tsqr_lt(h, Z, Prec<T>::f32, M, N, ld, (double*)B));
+    // A rank-deficient panel (zero columns of D stay zero columns of Z; exact low rank): the columns of R' that belong to the
+    // zero singular values come out of the rotations as rounding noise, eps sqrt(N) ||R|| in norm, whose mutual angles never
+    // settle - the sweeps would not end.  Seen on the diagonal of R (a zero or negligible pivot): such columns are then kept
+    // out of the rotations (noise floor 8 sqrt(N) eps ||R||_F - below what any singular value is known to anyway), reported
+    // as sigma = 0, and their right singular vectors are completed to an orthonormal basis afterwards (what LAPACK returns
+    // for a null space: any orthonormal basis of it).
+    const double eps = 2.220446049250313e-16;
+    double floor_rel = 0.0;
+    {
+        std::vector<double> dg((size_t)N);
+        TLSQ_HIP(h, hipMemcpy2DAsync(dg.data(), 8, B, (size_t)(N + 1) * 8, 8, (size_t)N, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        double dmax = 0.0, dmin = std::numeric_limits<double>::infinity();
+        for (double v : dg) {
+            dmax = std::max(dmax, std::fabs(v));
+            dmin = std::min(dmin, std::fabs(v));
+        }
+        if (!(dmin > 8.0 * std::sqrt((double)N) * eps * dmax)) floor_rel = 8.0 * std::sqrt((double)N) * eps;
+    }
     int64_t sw = 0;
-    TLSQ_TRY(jacobi_factor_f64(h, (double*)B, N, (double*)V, (double*)lam, 0.0, &sw));
+    TLSQ_TRY(jacobi_factor_f64(h, (double*)B, N, (double*)V, (double*)lam, floor_rel, &sw));
     if (sweeps) *sweeps += sw;
     h->warm_n = 0;
     const bool dbg = dev_get(DEV_DEBUG) != nullptr;
-    if (dbg) fprintf(stderr, "  svd via R: N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
+    if (dbg) fprintf(stderr, "  svd via R: N=%lld sweeps=%lld floor=%.1e\n", (long long)N, (long long)sw, floor_rel);
     s.sigma.resize((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     s.ncols = N;
     sort_desc(s);
     *V_out = (double*)V;
+    if (floor_rel > 0.0) {
+        double fro2 = 0.0;
+        for (double v : s.sigma) fro2 += v * v;
+        const double cut = floor_rel * std::sqrt(fro2);
+        int64_t ngood = 0;
+        while (ngood < N && s.sigma[(size_t)s.order[(size_t)ngood]] > cut) ++ngood;
+        if (ngood < N) {
+            // sorted copy [kept columns | seeded random columns], block Gram-Schmidt of the second part against the first
+            // (launch_orth with c_start: the kept columns are orthonormal already and stay as they are)
+            void *P, *wk, *stv;
+            TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P));
+            std::vector<int32_t> keep(s.order.begin(), s.order.begin() + ngood);
+            TLSQ_TRY(gather_cols(h, (const double*)V, N, keep, (double*)P));
+            TLSQ_TRY(launch_fill_hash(h, (double*)P + (size_t)N * ngood, N * (N - ngood), 0x27D4EB2Fu));
+            TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(N * 16, 64) * 8, &wk));
+            TLSQ_TRY(ws_get(h, WS_AUX1, 64 * 8, &stv));
+            bool used = false;
+            TLSQ_TRY(launch_orth(h, (double*)P, nullptr, (double*)wk, N, N, (double*)stv, false, &used, false, ngood));
+            TLSQ_HIP(h, hipMemcpyAsync(V, P, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+            std::vector<double> sg((size_t)N, 0.0);
+            for (int64_t i = 0; i < ngood; ++i) sg[(size_t)i] = s.sigma[(size_t)s.order[(size_t)i]];
+            s.sigma = sg;
+            std::iota(s.order.begin(), s.order.end(), 0);
+            if (dbg) fprintf(stderr, "  svd via R: %lld numerically zero singular values, null-space basis completed\n", (long long)(N - ngood));
+        }
+    }
     return TLSQ_OK;
 }
 
@@ -279,6 +326,10 @@ struct SubspaceState {
     // product, the next sweep and the next Gram before it asks for the verdict
     bool cert_async = false;
     volatile double* cert_mb = nullptr;   // where cert_finish polls (nullptr: the main mailbox)
+    // asynchronous form: the two kernels are not queued by svd_subspace itself but by whoever calls cert_launch - rpca_core does
+    // once the HBM-bound sweep is through (beside the sweep they cost it ~8 % of its bandwidth; beside the MFMA-bound Gram of
+    // the next iteration they are not noticed)
+    std::function<int()> cert_launch;
     // Speculative factor product of the rebuild (rpca_core): queued right behind k_ritz_finish of a warm block's first step,
     // with the selection, the weights and the count taken from the device-side decision block that kernel writes - the host
     // round trip (poll, sort, count, launch: ~10 us) is then hidden behind the product instead of standing in front of it.
@@ -295,6 +346,7 @@ struct SubspaceState {
         int nct = 0;                     // ... with this many 16-column accumulator tiles
         bool dev_ok = false;             // ... and this is what the device decided
         int64_t dev_r = 0;
+        std::function<void()> before_launch;   // phase accounting of the caller: the eig window ends where the product starts
     } spec;
     LanczosRun cert;
     int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
@@ -661,6 +713,7 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                                         (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq, ctrl,
                                         inv_mu, st.spec.nukeA ? 1 : 0));
             if (spec_now) {
+                if (st.spec.before_launch) st.spec.before_launch();
                 st.spec.nct = nt_step <= 16 ? 1 : 2;
                 TLSQ_TRY(tsmm_sel_dev(h, st.spec.Z, st.spec.z_f32, st.spec.ldz, (const double*)X, ctrl, st.spec.nct, st.spec.Vs,
                                       st.spec.Tout, st.spec.M, st.spec.M, N));
@@ -889,15 +942,28 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
         const bool async = st.cert_async && st.defer_certificate && st.cert_power && fused_deflate && svp > 0 && h->stream_b &&
                            x_settled && h->mailbox && h->mailbox_bytes >= 32768 && !dev_is(DEV_NO_MAILBOX, '1');
         st.cert_async = async;
-        StreamScope on_b(h, async ? h->stream_b : nullptr);
-        if (fused_deflate && svp > 0)
-            TLSQ_TRY(launch_deflate_sel(h, op.G, N, (const double*)X, defl_sw, (double*)GD, N, svp, 1.0 / tau2));
-        else
-            TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
         st.cert_GD = (const double*)GD;
         st.cert_N = N;
-        if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
-        else TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, st.cert_margin, 0.0));
+        st.cert_launch = nullptr;
+        if (async) {
+            const double* Gp = op.G;
+            const double* Xp = (const double*)X;
+            double* GDp = (double*)GD;
+            const double sc = 1.0 / tau2;
+            SubspaceState* stp = &st;
+            st.cert_launch = [h, Gp, Xp, GDp, N, svp, sc, defl_sw, stp]() -> int {
+                StreamScope on_b(h, h->stream_b);
+                TLSQ_TRY(launch_deflate_sel(h, Gp, N, Xp, defl_sw, GDp, N, svp, sc));
+                return power_cert_begin(h, *stp);
+            };
+        } else {
+            if (fused_deflate && svp > 0)
+                TLSQ_TRY(launch_deflate_sel(h, op.G, N, (const double*)X, defl_sw, (double*)GD, N, svp, 1.0 / tau2));
+            else
+                TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
+            if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
+            else TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, st.cert_margin, 0.0));
+        }
         if (st.defer_certificate) {
             st.cert_pending = true;
             *V_out = (double*)X;
@@ -1141,8 +1207,14 @@ static int polish_derived_vectors(Handle* h, T* U, int64_t M, int64_t d, const s
         if (sig_desc[(size_t)p] > eps_t * (double)std::max<int64_t>(m_global, d) * smax && smax > 0.0) break;
         ++nr;
     }
+    // Column i of U = Z V / sigma carries ~eps sigma_max / sigma_i of the other directions.  The first-order passes below
+    // square the departure from orthonormality as long as the whole of it is small in norm: contaminations of c per column
+    // add up to ~c sqrt(d), kept below 0.1 - i.e. columns with sigma_i <= 10 sqrt(d) eps sigma_max (fp32 at d = 512: 2.7e-5
+    // sigma_max, far below the tail of an rpca panel) are NOT left to them: they get a proper Gram-Schmidt on the device.
+    // (the round-3 bound, 1e4 eps, sent every tail column of a Float32 call to a host-side Gram-Schmidt.)
+    const double bar = 10.0 * std::sqrt((double)d) * eps_t * smax;
     for (int64_t p = d - 1; p >= 0; --p) {
-        if (sig_desc[(size_t)p] > 1e4 * eps_t * smax && smax > 0.0) break;
+        if (sig_desc[(size_t)p] > bar && smax > 0.0) break;
         ++nz;
     }
     nz = std::max(nz, nr);
@@ -1156,74 +1228,66 @@ static int polish_derived_vectors(Handle* h, T* U, int64_t M, int64_t d, const s
                            0x51ed270bu + 977u * (unsigned int)h->rank, 1.0 / std::sqrt((double)std::max<int64_t>(m_global, 1)));
         TLSQ_HIP(h, hipGetLastError());
     }
-    if (nz > 0 && !h->comm && (double)M * (double)d * (double)nz <= 4e9) {
-        // a random vector is nearly inside the span of the other columns when the matrix is (almost) square - outside the
-        // basin of the first-order passes below: these few columns get a plain Gram-Schmidt (twice) on the host
-        std::vector<T> hu((size_t)M * d);
-        TLSQ_HIP(h, hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        std::vector<double> x((size_t)M);
-        for (int64_t c = d - nz; c < d; ++c) {
-            for (int64_t r = 0; r < M; ++r) {
-                const double v = (double)hu[(size_t)(r + c * M)];
-                x[(size_t)r] = (v == v && std::fabs(v) < 1e300) ? v : 0.0;
-            }
-            for (int rep = 0; rep < 3; ++rep) {
-                for (int64_t k = 0; k < c; ++k) {
-                    const T* q = hu.data() + (size_t)k * M;
-                    double dot = 0.0, qq = 0.0;
-                    for (int64_t r = 0; r < M; ++r) {
-                        dot += (double)q[r] * x[(size_t)r];
-                        qq += (double)q[r] * (double)q[r];
-                    }
-                    if (qq > 0.0) {
-                        const double f = dot / qq;
-                        for (int64_t r = 0; r < M; ++r) x[(size_t)r] -= f * (double)q[r];
-                    }
-                }
-                double nn = 0.0;
-                for (int64_t r = 0; r < M; ++r) nn += x[(size_t)r] * x[(size_t)r];
-                nn = std::sqrt(nn);
-                if (!(nn > 0.0)) break;   // (M == c: no direction left - a zero column, like sigma = 0 before)
-                for (int64_t r = 0; r < M; ++r) x[(size_t)r] /= nn;
-            }
-            for (int64_t r = 0; r < M; ++r) hu[(size_t)(r + c * M)] = (T)x[(size_t)r];
-        }
-        TLSQ_HIP(h, hipMemcpyAsync(U + (size_t)(d - nz) * M, hu.data() + (size_t)(d - nz) * M, (size_t)M * nz * sizeof(T),
-                                   hipMemcpyHostToDevice, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    }
     void *tmpv, *bv;
     TLSQ_TRY(ws_get(h, WS_UPOL, (size_t)M * d * sizeof(T), &tmpv));
     TLSQ_TRY(ws_get(h, WS_UPB, (size_t)d * d * 16 + 64, &bv));
     double* B = (double*)bv;
     double* C = B + (size_t)d * d;
     unsigned long long* stat = (unsigned long long*)(C + (size_t)d * d);
-    T* cur = U;
-    T* oth = (T*)tmpv;
     const double tol_orth = std::max(2e-13, 64.0 * eps_t);
-    for (int pass = 0; pass < 10; ++pass) {
-        TLSQ_TRY(gram_any(h, cur, Prec<T>::f32, M, d, M, B, d, 0));
-        if (h->comm) TLSQ_TRY(comm_allreduce(h, B, (size_t)d * d, ncclSum));   // row shards: the Gram adds up
-        TLSQ_HIP(h, hipMemsetAsync(stat, 0, 24, h->stream));
-        int64_t g = (d * d + 255) / 256;
-        if (g > 1024) g = 1024;
-        hipLaunchKernelGGL(k_gs_correction, dim3((int)g), dim3(256), 0, h->stream, (const double*)B, (int)d, C, stat);
-        TLSQ_HIP(h, hipGetLastError());
-        unsigned long long hs[3];
-        TLSQ_HIP(h, hipMemcpyAsync(hs, stat, 24, hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        double e_off, e_diag;
-        memcpy(&e_off, &hs[0], 8);
-        memcpy(&e_diag, &hs[1], 8);
-        if (dev_get(DEV_DEBUG)) fprintf(stderr, "  polish pass %d: e_off=%.3e e_diag=%.3e bad=%llu (d=%lld, nz=%lld, nr=%lld)\n", pass, e_off, e_diag, hs[2], (long long)d, (long long)nz, (long long)nr);
-        if (hs[2] != 0ull) break;                                  // not finite: leave U as it is
-        if (e_off <= tol_orth && e_diag <= tol_orth) break;        // orthonormal to working precision
-        if (!(e_off < 0.7)) break;                                 // outside the basin of the first-order step (never seen)
-        TLSQ_TRY(gemm_mixed(h, true, false, C, 0, d, cur, Prec<T>::f32, M, oth, Prec<T>::f32, M, d, M, d, false));
-        std::swap(cur, oth);
+    // first-order passes on the leading nc columns of U (in place: the result ends up in U)
+    auto first_order = [&](int64_t nc) -> int {
+        if (nc <= 0) return TLSQ_OK;
+        T* cur = U;
+        T* oth = (T*)tmpv;
+        for (int pass = 0; pass < 10; ++pass) {
+            TLSQ_TRY(gram_any(h, cur, Prec<T>::f32, M, nc, M, B, nc, 0));
+            if (h->comm) TLSQ_TRY(comm_allreduce(h, B, (size_t)nc * nc, ncclSum));   // row shards: the Gram adds up
+            TLSQ_HIP(h, hipMemsetAsync(stat, 0, 24, h->stream));
+            int64_t g = (nc * nc + 255) / 256;
+            if (g > 1024) g = 1024;
+            hipLaunchKernelGGL(k_gs_correction, dim3((int)g), dim3(256), 0, h->stream, (const double*)B, (int)nc, C, stat);
+            TLSQ_HIP(h, hipGetLastError());
+            unsigned long long hs[3];
+            TLSQ_HIP(h, hipMemcpyAsync(hs, stat, 24, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            double e_off, e_diag;
+            memcpy(&e_off, &hs[0], 8);
+            memcpy(&e_diag, &hs[1], 8);
+            if (dev_get(DEV_DEBUG)) fprintf(stderr, "  polish pass %d: e_off=%.3e e_diag=%.3e bad=%llu (%lld of d=%lld columns, nz=%lld, nr=%lld)\n", pass, e_off, e_diag, hs[2], (long long)nc, (long long)d, (long long)nz, (long long)nr);
+            if (hs[2] != 0ull) break;                                  // not finite: leave U as it is
+            if (e_off <= tol_orth && e_diag <= tol_orth) break;        // orthonormal to working precision
+            if (!(e_off < 0.7)) break;                                 // outside the basin of the first-order step (never seen)
+            TLSQ_TRY(gemm_mixed(h, true, false, C, 0, nc, cur, Prec<T>::f32, M, oth, Prec<T>::f32, M, nc, M, nc, false));
+            std::swap(cur, oth);
+        }
+        if (cur != U) TLSQ_HIP(h, hipMemcpyAsync(U, cur, (size_t)M * nc * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+        return TLSQ_OK;
+    };
+    if (nz > 0 && !h->comm) {
+        // The well-determined columns first; then the nz trailing ones by block Gram-Schmidt with re-orthogonalisation on the
+        // device (subspace.hip, launch_orth with c_start: every 16-column block is projected twice against everything in front
+        // of it - two multi-workgroup products per projection - and orthonormalised by the column-sequential CGS2 kernel), in
+        // fp64 whatever the panel's type.  A column without any direction left (M == its index) stays zero, like sigma = 0 before.
+        const int64_t nq = d - nz;
+        TLSQ_TRY(first_order(nq));
+        double* Uw = nullptr;
+        void* wv = nullptr;
+        if (Prec<T>::f32) {
+            TLSQ_TRY(ws_get(h, WS_QRW, (size_t)M * d * 8, &wv));
+            Uw = (double*)wv;
+            TLSQ_TRY((launch_convert<T, double>(h, U, Uw, M * d)));
+        } else {
+            Uw = reinterpret_cast<double*>(U);
+        }
+        void *wk, *stv;
+        TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(d * 16, 64) * 8, &wk));     // c0 x 16 projections
+        TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(d, 64) * 8, &stv));
+        bool used = false;
+        TLSQ_TRY(launch_orth(h, Uw, nullptr, (double*)wk, M, d, (double*)stv, false, &used, false, nq));
+        if (Prec<T>::f32) TLSQ_TRY((launch_convert<double, T>(h, Uw + (size_t)nq * M, U + (size_t)nq * M, M * nz)));
     }
-    if (cur != U) TLSQ_HIP(h, hipMemcpyAsync(U, cur, (size_t)M * d * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    TLSQ_TRY(first_order(d));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }
@@ -1848,7 +1912,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         double sigma_top = 0.0, mu_next = mu;
         bool fuse = false, fuse_rebuild = false, rebuilt = false, rebuild_marked = false;
         auto count_and_rebuild = [&](bool mark) -> int {
-            if (mark) {
+            if (mark && !rebuild_marked) {
                 pt.mark();
                 rebuild_marked = true;
             }
@@ -2036,9 +2100,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 sub.spec.Tout = (double*)tb;
                 sub.spec.Vs = (double*)vb;
                 sub.spec.nukeA = ro.nukeA;
+                sub.spec.before_launch = [&]() {
+                    if (!rebuild_marked) pt.mark();
+                    rebuild_marked = true;
+                };
             }
             const int st_sub = svd_subspace(h, op, N, inv_mu, sub, &V, s, &sweeps, &fast_ok);
             sub.spec.enable = false;
+            sub.spec.before_launch = nullptr;
             sub.defer_certificate = false;
             if (st_sub < 0) return st_sub;
             if (fast_ok && sub.cert_pending) {
@@ -2049,6 +2118,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 // asynchronous form (second stream): the verdict is read after the sweep and the next Gram are queued as well
                 cert_late = sub.cert_async && zmode && fuse;
                 if (!cert_late) {
+                    if (sub.cert_launch) {
+                        TLSQ_TRY(sub.cert_launch());
+                        sub.cert_launch = nullptr;
+                    }
                     bool cert_ok = false;
                     TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
                     if (!cert_ok) {
@@ -2212,6 +2285,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             *redo = false;
             if (!cert_late) return TLSQ_OK;
             cert_late = false;
+            if (sub.cert_launch) {   // (not queued yet: the exact-cost branch has no read-back to wait for first)
+                TLSQ_TRY(sub.cert_launch());
+                sub.cert_launch = nullptr;
+            }
             bool cert_ok = false;
             TLSQ_TRY(svd_subspace_certify(h, sub, inv_mu, &cert_ok));
             if (fail_cert_at == k && !redo_cert_failed) cert_ok = false;   // (test hook)
@@ -2399,11 +2476,6 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             }
             pt.mark();
             pt.collect_previous(acc);                      // (host work hidden behind the sweep + Gram just queued)
-            {
-                bool redo = false;
-                TLSQ_TRY(late_verdict(&redo));
-                if (redo) goto redo_svd_step;
-            }
             bool got_mail = false;
             if (mail_sum) {
                 volatile double* mb = h->mailbox;
@@ -2422,6 +2494,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_HIP(h, hipEventSynchronize(h->ev[32]));   // the copy only, not the Gram queued behind it
             }
             if (!got_mail) memcpy(part, h->pinned, 576);
+            {   // (the sweep is through - its sums have arrived: now the certificate's kernels, beside the Gram just queued)
+                bool redo = false;
+                TLSQ_TRY(late_verdict(&redo));
+                if (redo) goto redo_svd_step;
+            }
             for (int i = 0; i < 64; ++i) fro2 += part[i];
             double lower = std::sqrt(fro2 / (double)std::min(ro.m_global, N)) / d_norm;   // <= cost
             bool max_settles = false;

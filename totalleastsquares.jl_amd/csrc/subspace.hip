@@ -861,7 +861,7 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 // and the two launches of a second pass that would find nothing to do are not.  The caller checks status[2] of THIS
 // step (it arrives with the Ritz values) and repeats the step with both passes when the guess was wrong.
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
-                bool allow_cholqr, bool* used_cholqr, bool one_pass) {
+                bool allow_cholqr, bool* used_cholqr, bool one_pass, int64_t c_start) {
     const bool no_cholqr = dev_is(DEV_NO_CHOLQR, '1');
     *used_cholqr = allow_cholqr && p <= 512 && !no_cholqr;
     if (!*used_cholqr) {
@@ -870,9 +870,9 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
         // products per projection) and orthonormalised among themselves by the one-workgroup kernel, whose cost falls
         // with the square of the block width.
         const bool no_blocked = dev_is(DEV_NO_BLOCKED_CGS2, '1');
-        if (no_blocked || N < 2048 || p <= 32) return launch_cgs2(h, Y, N, p, status_dev);
+        if (no_blocked || ((N < 2048 || p <= 32) && c_start == 0)) return launch_cgs2(h, Y, N, p, status_dev);
         constexpr int64_t GB = 16;
-        for (int64_t c0 = 0; c0 < p; c0 += GB) {
+        for (int64_t c0 = c_start; c0 < p; c0 += GB) {
             const int64_t pb = std::min<int64_t>(GB, p - c0);
             double* Yb = Y + (size_t)c0 * N;
             if (c0 > 0) {
@@ -886,7 +886,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
             }
             const size_t lds = (size_t)(pb + 16) * 8;
             hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Yb, (int)N, (int)pb, status_dev,
-                               c0 > 0 ? 1 : 0);
+                               c0 > c_start ? 1 : 0);
         }
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
