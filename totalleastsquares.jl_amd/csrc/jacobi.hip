@@ -732,7 +732,7 @@ __device__ __forceinline__ double jr_reduce16(double (&v)[16], int lane) {
 // (RPL rows per lane: a wave covers 64 RPL rows, so half as many waves meet at the barrier and add up half as many partials)
 template <int NW, bool CROSS, int RPL>
 __device__ __forceinline__ void jr_round(double (&c)[RPL][32], JrShared<NW>& sh, int w, int lane, int par, double tol2, double floor2,
-                                         double& a, double& bb, unsigned int& my_rot) {
+                                         double& a, double& bb, unsigned int& my_rot, double& my_tmax) {
     // position of the two members of pair k
     auto p1 = [](int k) { return CROSS ? k : (k < 8 ? k : 16 + (k - 8)); };
     auto p2 = [](int k) { return CROSS ? 16 + k : (k < 8 ? 15 - k : 31 - (k - 8)); };
@@ -762,6 +762,8 @@ __device__ __forceinline__ void jr_round(double (&c)[RPL][32], JrShared<NW>& sh,
         a = na > 0.0 ? na : 0.0;
         bb = nb > 0.0 ? nb : 0.0;
         if (w == 0 && (lane & 3) == 0) ++my_rot;
+        const double at = fabs(t);
+        my_tmax = at > my_tmax ? at : my_tmax;   // (largest rotation of the sweep: quadratic convergence lets the host stop early)
     }
     // the parameters of pair k sit in lanes 4 k ..: v_readlane hands them to every lane as scalars (no LDS round trip)
 #pragma unroll
@@ -822,6 +824,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         __syncthreads();
     }
     unsigned int my_rot = 0;
+    double my_tmax = 0.0;
     int par = 0;
     const int I = lane >> 2;
     if (round == 0) {
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         const int g = I & 7, base = (I >> 3) * 16;
         double a = sh.nrm[w][base + g], bb = sh.nrm[w][base + 15 - g];
         for (int r = 0; r < 15; ++r) {
-            jr_round<NW, false, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            jr_round<NW, false, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot, my_tmax);
             par ^= 1;
             // positions 1..15 of each block move on by one (15 -> 1), position 0 stays; the norms move with them:
             // a_g <- a_(g-1) (g >= 2), a_1 <- bb_0, a_0 stays;  bb_g <- bb_(g+1) (g <= 6), bb_7 <- a_7
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
     {
         double a = sh.nrm[w][I], bb = sh.nrm[w][16 + I];
         for (int r = 0; r < 16; ++r) {
-            jr_round<NW, true, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot);
+            jr_round<NW, true, RPL>(c, sh, w, lane, par, tol2, floor2, a, bb, my_rot, my_tmax);
             par ^= 1;
             // block q's registers move on by one (position 16 + i takes what 16 + i + 1 held): pair i meets q's next column
             bb = __shfl(bb, (lane + 4) & 63, 64);
@@ -887,6 +890,15 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
         if (lane == 0 && t) atomicAdd(rot_count, t);
+        // [rot_count + 4 .. +12): the largest |tan| of a rotation in this sweep, as the bit pattern of a non-negative double
+        double m = my_tmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0 && m > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(rot_count + 4), (unsigned long long)__double_as_longlong(m));
     }
 }
 
@@ -1183,7 +1195,7 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
             const int max_sweeps = 40;
             converged = false;
             for (; sweep < max_sweeps; ++sweep) {
-                TLSQ_HIP(h, hipMemsetAsync(rot, 0, 4, h->stream));
+                TLSQ_HIP(h, hipMemsetAsync(rot, 0, 24, h->stream));   // rotation count [0], largest |tan| [16..24)
                 for (int r = 0; r < nblk - 1; ++r) {
                     // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
                     const bool one = dev_is(DEV_JACOBI_RPL, '1');
@@ -1204,11 +1216,16 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
                                            (const double*)params, rot);
                 }
                 TLSQ_HIP(h, hipGetLastError());
-                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 4, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 24, hipMemcpyDeviceToHost, h->stream));
                 TLSQ_HIP(h, hipStreamSynchronize(h->stream));
                 unsigned int nrot;
+                double tmax;
                 memcpy(&nrot, h->pinned, 4);
-                if (nrot == 0) {
+                memcpy(&tmax, (const char*)h->pinned + 16, 8);
+                // converged: a sweep without rotations - or one whose largest rotation was so small (|tan| < 1e-8) that, Jacobi
+                // converging quadratically, what it left behind (~1e-16) is below the rotation threshold: the confirming sweep
+                // would rotate nothing (0.8 ms at N = 512)
+                if (nrot == 0 || tmax < 1e-8) {
                     ++sweep;
                     converged = true;
                     break;

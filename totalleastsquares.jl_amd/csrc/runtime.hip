@@ -458,8 +458,10 @@ int second_stream(Handle* h) {
     // (highest priority: its workgroups are few and large - they should get a CU as soon as one has room)
     int least = 0, greatest = 0;
     const bool no_prio = dev_is(DEV_OVERLAP_NOPRIO, '1');
-    if (!no_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
-        hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, greatest) != hipSuccess) {
+    const char* cp = dev_get(DEV_CERT_PRIO);   // (experiment: "low" / "normal" instead of the highest priority)
+    const bool want_low = cp && cp[0] == 'l', want_normal = cp && cp[0] == 'n';
+    if (!no_prio && !want_normal && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+        hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, want_low ? least : greatest) != hipSuccess) {
         (void)hipGetLastError();
         h->stream_b = nullptr;
     }
