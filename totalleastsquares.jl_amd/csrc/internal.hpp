@@ -170,6 +170,9 @@ struct ResolvedOpts {
     // and out_Tm / out_Vs / out_r describe it - and the returned E is not formed.  rpca_core may then be called with
     // A == nullptr: the panel is only allocated (WS_A) if some iteration needs it in memory.
     bool factors_out = false;
+    // called once A and E are final (the loop is over, the stream synchronised), before the returned decomposition is computed:
+    // a host-pointer call starts their way back to the caller's memory here, beside the SVD of the last Z (solver.hip, rpca_entry)
+    const std::function<void()>* ae_final = nullptr;
 };
 
 inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {

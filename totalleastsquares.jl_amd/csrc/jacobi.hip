@@ -778,10 +778,25 @@ __device__ __forceinline__ void jr_round(double (&c)[RPL][32], JrShared<NW>& sh,
     }
 }
 
+// end of a sweep (one thread): the sweep counts as done and, when it rotated nothing - or nothing larger than |tan| = 1e-8:
+// Jacobi converges quadratically, what such a sweep leaves behind is below the rotation threshold - the `done` flag stops every
+// kernel of the sweeps the host has queued ahead (it queues a few at a time and reads the state once per batch).
+// rot_count: [0] rotations, [4..6) largest |tan| as bits (both cleared here for the next sweep); state: [0] done, [1] sweeps
+__global__ void k_jr_sweep_end(unsigned int* __restrict__ rot_count, int* __restrict__ state) {
+    if (state[0]) return;
+    const unsigned int nrot = rot_count[0];
+    const double tmax = __longlong_as_double((long long)*reinterpret_cast<unsigned long long*>(rot_count + 4));
+    state[1] += 1;
+    if (nrot == 0 || tmax < 1e-8) state[0] = 1;
+    rot_count[0] = 0;
+    *reinterpret_cast<unsigned long long*>(rot_count + 4) = 0ull;
+}
+
 template <int NW, int RPL>
 __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, int N, int nblk, int round, double tol,
                                                         const double* __restrict__ params,
-                                                        unsigned int* __restrict__ rot_count) {
+                                                        unsigned int* __restrict__ rot_count, const int* __restrict__ done) {
+    if (*done) return;   // (converged in a sweep the host has not heard of yet)
     __shared__ JrShared<NW> sh;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = (w * 64 + lane) * RPL;   // this lane's rows: row .. row + RPL - 1
@@ -1194,42 +1209,40 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
             if (nblk & 1) ++nblk;
             const int max_sweeps = 40;
             converged = false;
-            for (; sweep < max_sweeps; ++sweep) {
-                TLSQ_HIP(h, hipMemsetAsync(rot, 0, 24, h->stream));   // rotation count [0], largest |tan| [16..24)
-                for (int r = 0; r < nblk - 1; ++r) {
-                    // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
-                    const bool one = dev_is(DEV_JACOBI_RPL, '1');
-                    if (N <= 256 && !one)
-                        hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(nblk / 2), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                           (const double*)params, rot);
-                    else if (N <= 512 && !one)
-                        hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(nblk / 2), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                           (const double*)params, rot);
-                    else if (N <= 512)
-                        hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                           (const double*)params, rot);
-                    else if (!one)
-                        hipLaunchKernelGGL((k_jacobi_reg<8, 2>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                           (const double*)params, rot);
-                    else
-                        hipLaunchKernelGGL((k_jacobi_reg<16, 1>), dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                           (const double*)params, rot);
+            // state (device): [0] done, [1] sweeps performed - at scal + 160; the host queues four sweeps at a time (kernels of
+            // sweeps behind the converged one return at once) and reads the state once per batch instead of once per sweep
+            int* state = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 160);
+            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 48, h->stream));   // rotation count, largest |tan|, sweeps_dev (unused here), state
+            const bool one = dev_is(DEV_JACOBI_RPL, '1');   // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
+            while (sweep < max_sweeps && !converged) {
+                const int batch = std::min(4, max_sweeps - sweep);
+                for (int sb = 0; sb < batch; ++sb) {
+                    for (int r = 0; r < nblk - 1; ++r) {
+                        if (N <= 256 && !one)
+                            hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(nblk / 2), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                               (const double*)params, rot, (const int*)state);
+                        else if (N <= 512 && !one)
+                            hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(nblk / 2), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                               (const double*)params, rot, (const int*)state);
+                        else if (N <= 512)
+                            hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                               (const double*)params, rot, (const int*)state);
+                        else if (!one)
+                            hipLaunchKernelGGL((k_jacobi_reg<8, 2>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                               (const double*)params, rot, (const int*)state);
+                        else
+                            hipLaunchKernelGGL((k_jacobi_reg<16, 1>), dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
+                                               (const double*)params, rot, (const int*)state);
+                    }
+                    hipLaunchKernelGGL(k_jr_sweep_end, dim3(1), dim3(1), 0, h->stream, rot, state);
                 }
                 TLSQ_HIP(h, hipGetLastError());
-                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, rot, 24, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, state, 8, hipMemcpyDeviceToHost, h->stream));
                 TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-                unsigned int nrot;
-                double tmax;
-                memcpy(&nrot, h->pinned, 4);
-                memcpy(&tmax, (const char*)h->pinned + 16, 8);
-                // converged: a sweep without rotations - or one whose largest rotation was so small (|tan| < 1e-8) that, Jacobi
-                // converging quadratically, what it left behind (~1e-16) is below the rotation threshold: the confirming sweep
-                // would rotate nothing (0.8 ms at N = 512)
-                if (nrot == 0 || tmax < 1e-8) {
-                    ++sweep;
-                    converged = true;
-                    break;
-                }
+                int hs[2];
+                memcpy(hs, h->pinned, 8);
+                sweep = hs[1];
+                converged = hs[0] != 0;
             }
             if (sweeps_out) *sweeps_out = sweep;
             TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));

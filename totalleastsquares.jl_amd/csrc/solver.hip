@@ -12,6 +12,7 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "internal.hpp"
 
@@ -1188,10 +1189,32 @@ __global__ __launch_bounds__(256) void k_gs_correction(const double* __restrict_
             C[e] = i < j ? -di * bh : 0.0;   // column j is corrected by the columns before it only
         }
     }
-    if (e_off == e_off) atomicMax(&stat[0], (unsigned long long)__double_as_longlong(e_off));
-    else atomicMax(&stat[2], 1ull);
-    atomicMax(&stat[1], (unsigned long long)__double_as_longlong(e_diag == e_diag ? e_diag : 0.0));
-    if (badv != 0.0) atomicMax(&stat[2], 1ull);
+    // (one atomic per workgroup: every thread hitting the same three words took 100 us at d = 512)
+    __shared__ double sm[3][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double nanv = e_off == e_off ? 0.0 : 1.0;
+    if (!(e_off == e_off)) e_off = 0.0;
+    if (!(e_diag == e_diag)) e_diag = 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        e_off = fmax(e_off, __shfl_xor(e_off, off, 64));
+        e_diag = fmax(e_diag, __shfl_xor(e_diag, off, 64));
+        badv = fmax(fmax(badv, nanv), __shfl_xor(fmax(badv, nanv), off, 64));
+    }
+    if (lane == 0) {
+        sm[0][w] = e_off;
+        sm[1][w] = e_diag;
+        sm[2][w] = badv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double eo = fmax(fmax(sm[0][0], sm[0][1]), fmax(sm[0][2], sm[0][3]));
+        const double ed = fmax(fmax(sm[1][0], sm[1][1]), fmax(sm[1][2], sm[1][3]));
+        const double bd = fmax(fmax(sm[2][0], sm[2][1]), fmax(sm[2][2], sm[2][3]));
+        atomicMax(&stat[0], (unsigned long long)__double_as_longlong(eo));
+        atomicMax(&stat[1], (unsigned long long)__double_as_longlong(ed));
+        if (bd != 0.0) atomicMax(&stat[2], 1ull);
+    }
 }
 
 template <typename T>
@@ -2657,6 +2680,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (ro.hankel) TLSQ_TRY(soft_hankel(E, (T)(lam / mu)));  // :234-236
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    if (ro.ae_final && *ro.ae_final && (S_host || Vt_host || U_dev)) (*ro.ae_final)();
     if (info) {
         info->ms_loop = now_ms() - t_loop0;
         info->converged = converged ? 1 : 0;
@@ -3300,10 +3324,29 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     // S / Vt are small: always produced on the host in fp64, then converted / copied to the caller's memory
     std::vector<double> hS((size_t)(S ? d : 0)), hVt((size_t)(Vt ? d * N : 0));
     int status;
+    // Host-pointer call that also returns s: A and E are final when the loop ends, 10+ ms before U, S, Vt are - their 164 MB go
+    // back to the caller's memory on the staging workers WHILE the decomposition of the last Z runs (a thread of its own drives
+    // the staged copy; the solver thread keeps queueing kernels).
+    std::thread ae_thread;
+    int ae_status = TLSQ_OK;
+    bool ae_sent = false;
     if (!transposed && !pad) {
-        status = rpca_core<T>(h, dD, M, N, ro, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
+        ResolvedOpts ro2 = ro;
+        const std::function<void()> send_ae = [&]() {
+            if (dev || dA == A || dE == E) return;
+            ae_sent = true;
+            ae_thread = std::thread([&]() {
+                StageJob down[2] = {StageJob{A, ldA, dA, M, M, N, es, false}, StageJob{E, ldE, dE, M, M, N, es, false}};
+                ae_status = staged_copy(h, down, 2);
+            });
+        };
+        ro2.ae_final = &send_ae;
+        status = rpca_core<T>(h, dD, M, N, ro2, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
                               Vt ? hVt.data() : nullptr, d, sv, info);
+        if (ae_thread.joinable()) ae_thread.join();
+        (void)hipSetDevice(h->device);
         if (status < 0) return status;
+        if (ae_status < 0) return ae_status;
     } else {
         // working copies: Dw (Mp x Nw) = D or D', zero pad row; Aw, Ew results; Uw (Mp x d) left vectors of Zw
         void *Dw, *Aw, *Ew, *Uw = nullptr;
@@ -3360,8 +3403,8 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         // A, E (and U) go back to the caller's memory together, pipelined through the pinned slots
         StageJob down[3];
         int nd = 0;
-        if (dA != A) down[nd++] = StageJob{A, ldA, dA, M, M, N, es, false};
-        if (dE != E) down[nd++] = StageJob{E, ldE, dE, M, M, N, es, false};
+        if (dA != A && !ae_sent) down[nd++] = StageJob{A, ldA, dA, M, M, N, es, false};
+        if (dE != E && !ae_sent) down[nd++] = StageJob{E, ldE, dE, M, M, N, es, false};
         if (U && !transposed && !pad && dU != U) down[nd++] = StageJob{U, ldU, dU, M, M, d, es, false};
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         TLSQ_TRY(staged_copy(h, down, nd));
