@@ -232,7 +232,7 @@ int tlsq_lowrankfilter_f64(tlsq_handle h, const double* y, int64_t Nx, int64_t D
 
 int tlsq_lowrankfilter_f32(tlsq_handle h, const float* y, int64_t Nx, int64_t Dch, int64_t ldy,
                            int64_t n, int64_t lag, int64_t sv, const tlsq_rpca_opts* opts,
-                           float* yf, int64_t ldyf, tlsq_rpca_info* info);   /* single GPU */
+                           float* yf, int64_t ldyf, tlsq_rpca_info* info);   /* same forms as _f64 (group handles and communicators included) */
 
 /* ---- tls! / rtls: src/TotalLeastSquares.jl:63-69, 152-156 -------------------------------------
  * tls:  Ay (M x ncols, ldAy; NOT destroyed, unlike svd!) , n = columns of A -> x (n x q), q=ncols-n
@@ -264,6 +264,14 @@ int tlsq_rpca_c64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t 
  * basis per cluster of equal singular values); left vectors of zero singular values are returned as zero columns. */
 int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
                       double* A, int64_t ldA, double* E, int64_t ldE, double* U, int64_t ldU, double* S, double* Vt,
+                      int64_t ldVt, int64_t* sv, tlsq_rpca_info* info);
+
+/* ComplexF32 data (`rpca(D::Matrix{ComplexF32})`: the generic method of src/robustPCA.jl:156 with the complex soft_th of
+ * :3-7): interleaved (re, im) FLOAT matrices in and out, S in float.  The panels are widened on the device and the solve
+ * runs in the ComplexF64 path above (fp64 arithmetic throughout; default tol = sqrt(eps(Float32)) like the reference's
+ * `tol = sqrt(eps(real(T)))`, :160); results are rounded to float on the way out.  Same restrictions as tlsq_rpca_c64. */
+int tlsq_rpca_c32_svd(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      float* A, int64_t ldA, float* E, int64_t ldE, float* U, int64_t ldU, float* S, float* Vt,
                       int64_t ldVt, int64_t* sv, tlsq_rpca_info* info);
 
 /* ---- batched tiny problems ---------------------------------------------------------

@@ -302,22 +302,25 @@ function rtls(A::AbstractMatrix{T}, y::AbstractVecOrMat{T}; kwargs...) where {T<
     y isa AbstractVector ? vec(x) : x
 end
 
-# ComplexF64 data: the complex soft_th method, src/robustPCA.jl:3-7.  `s` = svd of the last Z like the real methods.
-function rpca(D::AbstractMatrix{ComplexF64}; λ = 1 / sqrt(maximum(size(D))), iters = 1000, tol = sqrt(eps()), ρ = 1.5,
-              nukeA = true, kwargs...)
-    Dm = Matrix(D); M, N = size(Dm)
-    o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
-    o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA ? 1 : 0; o.memory = MEM_HOST
-    info = _info()
-    d = min(M, N)
-    A = similar(Dm); E = similar(Dm); S = Vector{Float64}(undef, d); sv = Ref{Int64}(0)
-    U = Matrix{ComplexF64}(undef, M, d); Vt = Matrix{ComplexF64}(undef, d, N)
-    st = check(ccall((:tlsq_rpca_c64_svd, LIB[]), Cint,
-        (Ptr{Cvoid}, Ptr{ComplexF64}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{ComplexF64}, Int64, Ptr{ComplexF64},
-         Int64, Ptr{ComplexF64}, Int64, Ptr{Float64}, Ptr{ComplexF64}, Int64, Ref{Int64}, Ref{RpcaInfo}),
-        handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info))
-    st == 1 && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
-    A, E, LinearAlgebra.SVD(U, S, Vt), sv[]
+# Complex data: the complex soft_th method, src/robustPCA.jl:3-7.  `s` = svd of the last Z like the real methods.  ComplexF32
+# stays ComplexF32 (eltype-generic like the reference; tol = sqrt(eps(Float32)), :160): tlsq_rpca_c32_svd widens on the device.
+for (T, sym) in ((Float64, :tlsq_rpca_c64_svd), (Float32, :tlsq_rpca_c32_svd))
+    @eval function rpca(D::AbstractMatrix{Complex{$T}}; λ = 1 / sqrt(maximum(size(D))), iters = 1000, tol = sqrt(eps($T)), ρ = 1.5,
+                        nukeA = true, kwargs...)
+        Dm = Matrix(D); M, N = size(Dm)
+        o = RpcaOpts(); ccall((:tlsq_rpca_opts_default, LIB[]), Cvoid, (Ref{RpcaOpts},), o)
+        o.lambda = λ; o.iters = iters; o.tol = tol; o.rho = ρ; o.nukeA = nukeA ? 1 : 0; o.memory = MEM_HOST
+        info = _info()
+        d = min(M, N)
+        A = similar(Dm); E = similar(Dm); S = Vector{$T}(undef, d); sv = Ref{Int64}(0)
+        U = Matrix{Complex{$T}}(undef, M, d); Vt = Matrix{Complex{$T}}(undef, d, N)
+        st = check(ccall(($(QuoteNode(sym)), LIB[]), Cint,
+            (Ptr{Cvoid}, Ptr{Complex{$T}}, Int64, Int64, Int64, Ref{RpcaOpts}, Ptr{Complex{$T}}, Int64, Ptr{Complex{$T}},
+             Int64, Ptr{Complex{$T}}, Int64, Ptr{$T}, Ptr{Complex{$T}}, Int64, Ref{Int64}, Ref{RpcaInfo}),
+            handle(), Dm, M, N, M, o, A, M, E, M, U, M, S, Vt, d, sv, info))
+        st == 1 && @warn "Maximum number of iterations reached, cost: $(info.final_cost), tol: $tol"
+        A, E, LinearAlgebra.SVD(U, S, Vt), sv[]
+    end
 end
 
 # Many small problems at once (the loop of test/runtests.jl:205-235 as one launch): A is M x n x B, y is M x B

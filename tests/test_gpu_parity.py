@@ -505,6 +505,33 @@ def test_rpca_unsupported_paths_fail_loudly(eng):
         eng.rpca(np.ones((4, 4)), opnorm=3.0)
 
 
+def test_rpca_complex_float32(eng):
+    """`rpca(D::Matrix{ComplexF32})` - the reference's method is eltype-generic (src/robustPCA.jl:3-7, :156; tol =
+    sqrt(eps(Float32)), :160): ComplexF32 in, ComplexF32 out (tlsq_rpca_c32_svd: widened on the device, solved by the
+    ComplexF64 path).  The reference's complex test problem (test/runtests.jl:187-199) in single precision against its own
+    thresholds, and against the oracle run in complex64 to the fp32 bar (1e-3, iterations +-1)."""
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(43)
+    crandn = lambda *sh: ((rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) / np.sqrt(2)).astype(np.complex64)
+    for (M, N, r) in ((100, 20, 1), (300, 40, 3)):
+        A0 = crandn(M, r) @ crandn(r, N)
+        E0 = crandn(M, N) * 10 * (rng.random((M, N)) < 0.01)
+        D = (A0 + E0).astype(np.complex64)
+        A, E, s, sv, rep = eng.rpca(D, return_report=True)
+        assert A.dtype == np.complex64 and E.dtype == np.complex64 and s.S.dtype == np.float32 and s.U.dtype == np.complex64
+        assert rep.converged and sv == r
+        assert np.sum(np.abs(E - E0) ** 2) / np.sum(np.abs(E0) ** 2) < 1e-5
+        assert np.sum(np.abs(A - A0) ** 2) / np.sum(np.abs(A0) ** 2) < 1e-5
+        Ao, Eo, so, svo, io = O.rpca(D)
+        assert abs(rep.iters_done - io.iters_done) <= 1 and sv == svo
+        assert relerr(A.astype(np.complex128), Ao.astype(np.complex128)) < 1e-3
+        assert relerr(E.astype(np.complex128), Eo.astype(np.complex128)) < 1e-3
+        U, S, Vt = (np.asarray(x, dtype=np.complex128) for x in (s.U, s.S, s.Vt))
+        d = min(M, N)
+        assert np.allclose(Vt @ Vt.conj().T, np.eye(d), atol=1e-5)
+        np.testing.assert_allclose(np.real(S[:sv]), so[1][:sv], rtol=1e-3)
+
+
 def test_rpca_user_hooks_through_the_c_callbacks(eng):
     """src/robustPCA.jl:168-169, test/runtests.jl:384-398: ANY `svd(Z, sv)` / `opnorm(X)` function of the host language.
     The library copies the panel to the host and calls back (tlsq_svd_cb / tlsq_opnorm_cb).  With LAPACK behind both

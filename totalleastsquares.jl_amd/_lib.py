@@ -69,7 +69,7 @@ EXPORTS = [
     "tlsq_hankel_f64", "tlsq_unhankel_f64", "tlsq_soft_hankel_f64",
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
     "tlsq_lowrankfilter_f64", "tlsq_lowrankfilter_f32", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_f32", "tlsq_rtls_f32", "tlsq_tls_from_vt_f64",
-    "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_batched_f32", "tlsq_rtls_batched_f32", "tlsq_rpca_c64", "tlsq_rpca_c64_svd",
+    "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_batched_f32", "tlsq_rtls_batched_f32", "tlsq_rpca_c64", "tlsq_rpca_c64_svd", "tlsq_rpca_c32_svd",
     "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
@@ -137,6 +137,8 @@ def load():
     lib.tlsq_rtls_f32.argtypes = lib.tlsq_rtls_f64.argtypes
     lib.tlsq_tls_from_vt_f64.argtypes = [vp, i64, i64, i64, vp, i64]
     lib.tlsq_rpca_c64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, P(i64), P(RpcaInfo)]
+    lib.tlsq_rpca_c32_svd.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, i64, vp, vp, i64, P(i64),
+                                      P(RpcaInfo)]
     lib.tlsq_rpca_c64_svd.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, i64, vp, i64, vp, i64, vp, vp, i64, P(i64),
                                       P(RpcaInfo)]
     lib.tlsq_rpca_batched_f64.argtypes = [vp, vp, i64, i64, i64, P(RpcaOpts), vp, vp, vp, vp, vp, vp, vp, vp]

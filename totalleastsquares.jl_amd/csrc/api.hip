@@ -539,6 +539,57 @@ int tlsq_rpca_c64_svd(tlsq_handle h, const double* D, int64_t M, int64_t N, int6
     return status;
 }
 
+// ---- ComplexF32 rpca: widened on the device, solved by the ComplexF64 path, rounded on the way out ------------------------
+int tlsq_rpca_c32_svd(tlsq_handle h, const float* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
+                      float* A, int64_t ldA, float* E, int64_t ldE, float* U, int64_t ldU, float* S, float* Vt,
+                      int64_t ldVt, int64_t* sv, tlsq_rpca_info* info) {
+    TLSQ_TRY(check_handle(h));
+    const int64_t d = std::min(M, N);
+    if ((U && ldU < M) || (Vt && ldVt < d))
+        return set_err(h, TLSQ_ERR_ARG, "rpca_c32: ldU < M or ldVt < min(M,N)");
+    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
+        return set_err(h, TLSQ_ERR_ARG, "rpca_c32: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    tlsq_rpca_opts o;
+    if (opts) o = *opts; else tlsq_rpca_opts_default(&o);
+    if (std::isnan(o.tol)) o.tol = std::sqrt((double)std::numeric_limits<float>::epsilon());   // :160 with T = ComplexF32
+    o.memory = TLSQ_MEM_DEVICE;
+    const int64_t n = M * N;
+    // float staging (contiguous, ld M) and the fp64 panels of the inner call: slots the ComplexF64 path does not take itself
+    void *f32v, *D64, *A64, *E64, *U64 = nullptr, *S64 = nullptr, *V64 = nullptr;
+    TLSQ_TRY(ws_get(h, WS_C32_F, (size_t)std::max(n, M * d) * 8, &f32v));
+    TLSQ_TRY(ws_get(h, WS_C32_D, (size_t)n * 16, &D64));
+    TLSQ_TRY(ws_get(h, WS_C32_A, (size_t)n * 16, &A64));
+    TLSQ_TRY(ws_get(h, WS_C32_E, (size_t)n * 16, &E64));
+    if (U) TLSQ_TRY(ws_get(h, WS_C32_U, (size_t)M * d * 16, &U64));
+    if (S) TLSQ_TRY(ws_get(h, WS_C32_S, (size_t)d * 8, &S64));
+    if (Vt) TLSQ_TRY(ws_get(h, WS_C32_V, (size_t)d * N * 16, &V64));
+    float* f32 = (float*)f32v;
+    TLSQ_TRY(copy2d(h, f32, M, D, ldD, M, N, 8, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    TLSQ_TRY((launch_convert<float, double>(h, f32, (double*)D64, 2 * n)));
+    const int status = tlsq_rpca_c64_svd(h, (const double*)D64, M, N, M, &o, (double*)A64, M, (double*)E64, M, (double*)U64, M,
+                                         (double*)S64, (double*)V64, d, sv, info);
+    if (status < 0) return status;
+    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    auto out = [&](const void* src64, int64_t rows, int64_t cols, float* dst, int64_t ldd) -> int {
+        TLSQ_TRY((launch_convert<double, float>(h, (const double*)src64, f32, 2 * rows * cols)));
+        TLSQ_TRY(copy2d(h, dst, ldd, f32, rows, rows, cols, 8, back));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (the staging panel is reused by the next output)
+        return TLSQ_OK;
+    };
+    TLSQ_TRY(out(A64, M, N, A, ldA));
+    TLSQ_TRY(out(E64, M, N, E, ldE));
+    if (U) TLSQ_TRY(out(U64, M, d, U, ldU));
+    if (Vt) TLSQ_TRY(out(V64, d, N, Vt, ldVt));
+    if (S) {
+        TLSQ_TRY((launch_convert<double, float>(h, (const double*)S64, f32, d)));
+        TLSQ_HIP(h, hipMemcpyAsync(S, f32, (size_t)d * 4, back, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return status;
+}
+
 // ---- batched tiny problems (batched.hip) ---------------------------------------------------------------
 // validates the options shared by the two batched entry points
 static int batched_opts(tlsq_handle h, const tlsq_rpca_opts* opts, int64_t M, int64_t N, const char* who, ResolvedOpts* ro,

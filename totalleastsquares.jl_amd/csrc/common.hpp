@@ -154,6 +154,7 @@ enum WsSlot {
     WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
+    WS_C32_F, WS_C32_D, WS_C32_A, WS_C32_E, WS_C32_U, WS_C32_V, WS_C32_S,   // ComplexF32 entry (api.hip): float staging, widened panels
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction
     WS_COUNT
 };

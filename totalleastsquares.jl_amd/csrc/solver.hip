@@ -1218,8 +1218,18 @@ __global__ __launch_bounds__(256) void k_gs_correction(const double* __restrict_
 }
 
 template <typename T>
-static int polish_derived_vectors(Handle* h, T* U, int64_t M, int64_t d, const std::vector<double>& sig_desc, int64_t m_global) {
+static int polish_derived_vectors(Handle* h, T* U, int64_t M, int64_t d, const std::vector<double>& sig_desc, int64_t m_global,
+                                  bool replicated = false) {
     if (d <= 0 || M <= 0 || dev_is(DEV_NO_U_POLISH, '1')) return TLSQ_OK;
+    // replicated: the panel is the same on every rank of a group (the N x N right vectors), not a row shard: no collectives
+    struct CommOff {
+        Handle* h;
+        Comm* saved;
+        CommOff(Handle* hh, bool off) : h(hh), saved(hh->comm) {
+            if (off) h->comm = nullptr;
+        }
+        ~CommOff() { h->comm = saved; }
+    } comm_off(h, replicated);
     const double eps_t = (double)std::numeric_limits<T>::epsilon();
     const double smax = sig_desc.empty() ? 0.0 : sig_desc[0];
     // trailing columns without a direction (nr: replaced by seeded normals) and - a superset - those whose contamination
@@ -2826,7 +2836,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     for (int64_t i = 0; i < N; ++i) sg[(size_t)i] = s2.sigma[(size_t)s2.order[(size_t)i]];
                     s2.sigma = sg;
                     std::iota(s2.order.begin(), s2.order.end(), 0);
-                    TLSQ_TRY(polish_derived_vectors<double>(h, V2, N, N, sg, N));
+                    TLSQ_TRY(polish_derived_vectors<double>(h, V2, N, N, sg, N, true));
                     s = s2;
                     V = V2;
                     deflated_ok = true;

@@ -290,15 +290,18 @@ class Engine:
 
     def _rpca_complex(self, D, *, lam, maxrank, iters, tol, rho, verbose, nonnegA, nonnegE, hankel, nukeA,
                       return_report):
-        """ComplexF64 data (src/robustPCA.jl:3-7); `s` = (U, S, Vt) of the last Z like the real path (:194, :238)."""
-        Df = np.asfortranarray(D, dtype=np.complex128)
+        """Complex data (src/robustPCA.jl:3-7); `s` = (U, S, Vt) of the last Z like the real path (:194, :238).  ComplexF32
+        input (numpy complex64) stays ComplexF32 - eltype-generic like the reference - through tlsq_rpca_c32_svd."""
+        c32 = np.asarray(D).dtype == np.complex64
+        ct, rt = (np.complex64, np.float32) if c32 else (np.complex128, np.float64)
+        Df = np.asfortranarray(D, dtype=ct)
         M, N = Df.shape
         d = min(M, N)
-        A = np.empty((M, N), dtype=np.complex128, order="F")
-        E = np.empty((M, N), dtype=np.complex128, order="F")
-        S = np.empty(d)
-        U = np.empty((M, d), dtype=np.complex128, order="F")
-        Vt = np.empty((d, N), dtype=np.complex128, order="F")
+        A = np.empty((M, N), dtype=ct, order="F")
+        E = np.empty((M, N), dtype=ct, order="F")
+        S = np.empty(d, dtype=rt)
+        U = np.empty((M, d), dtype=ct, order="F")
+        Vt = np.empty((d, N), dtype=ct, order="F")
         cb = None
         if verbose:
             cb = L.ON_ITER(lambda k, cost, svp, user: print(f"{k} cost: {float(f'{cost:.4g}')}"))
@@ -306,8 +309,9 @@ class Engine:
                            hankel=hankel, nukeA=nukeA, on_iter=cb)
         info, cost, svp = self._info(int(iters))
         sv = C.c_int64(0)
-        st = self._check(self.lib.tlsq_rpca_c64_svd(self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
-                                                    _ptr(U), M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
+        fn = self.lib.tlsq_rpca_c32_svd if c32 else self.lib.tlsq_rpca_c64_svd
+        st = self._check(fn(self.h, _ptr(Df), M, N, M, C.byref(o), _ptr(A), M, _ptr(E), M,
+                            _ptr(U), M, _ptr(S), _ptr(Vt), d, C.byref(sv), C.byref(info)))
         rep = RpcaReport(info, cost, svp)
         if st == L.TLSQ_MAXITER:
             warnings.warn(f"Maximum number of iterations reached, cost: {rep.final_cost}")
