@@ -22,6 +22,94 @@ __global__ __launch_bounds__(256) void k_mf_axpbi(const double* X, double* Y, in
 // out[0] = ||X - I||_F^2, out[1] = trace(X), out[2] = max_i sum_j |X_ij| in two deterministic stages (N <= 1024):
 // stage 1, grid (ceil(N / 256), MF_CHUNKS): thread = row i, block y = a chunk of columns; per-row partials to part
 // (layout [3][MF_CHUNKS][N]: deviation, absolute row sum, diagonal).  Stage 2, one workgroup: fixed-order sums.
+// ---- product of two SYMMETRIC N x N matrices without split-K slabs (N <= 2048) --------------------------------------------
+// The Newton-Schulz iterations multiply N x N iterates a hundred times per noisy ALM iteration.  Through the 128 x 128-tile
+// GEMM an N = 512 product is 10-16 tiles: it has to be split over K to fill the chip, and pays for it with 16 MB of slabs, a
+// reduction launch and (for X <- 1.5 I - 0.5 X^2) an element-wise launch: 25 us for 0.27 GFLOP.  Here one workgroup (16
+// waves) owns a 32 x 32 tile of the result: wave w computes 16 x 16 sub-tile (w & 3) over K-quarter (w >> 2) with
+// v_mfma_f64_16x16x4_f64 fed straight from L2 - both operands are symmetric, so the A fragment "rows i0.., column k" and the B
+// fragment "rows j0.., column k" (= B[k, j0..]) are 16 consecutive doubles of one column each (one 128-byte line per 16 lanes) -
+// the four quarters meet in LDS in a fixed order, and the epilogue applies alpha, beta I.  SYM: the result is known to be
+// symmetric (commuting iterates): only the tiles on and below the diagonal are computed, every entry pair written by one thread.
+// (layout of the accumulator of v_mfma_f64_16x16x4_f64: lane l, register q hold D[4 q + (l >> 4)][l & 15].)
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+template <bool SYM>
+__global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                                   int N, int nt, double alpha, double beta) {
+    __shared__ double sR[16 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    int ti, tj;
+    if (SYM) {
+        const int t = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x % nt;
+        tj = blockIdx.x / nt;
+    }
+    const int sub = w & 3, kq = w >> 2;
+    const int i0 = ti * 32 + (sub & 1) * 16, j0 = tj * 32 + (sub >> 1) * 16;
+    const int gi = i0 + fr, gj = j0 + fr;
+    const bool iok = gi < N, jok = gj < N;
+    const double* Ai = A + (iok ? gi : 0);
+    // SYM: B is symmetric, B[k, j] is read as B[j, k] (16 consecutive doubles per k).  Otherwise the true column j of B: the
+    // four lanes of a k-group read 32 consecutive bytes, a line is used up over the eight MFMAs of a trip.  (The coupled
+    // inverse-square-root iteration does not survive the symmetric shortcut: its iterates are symmetric only to rounding, and
+    // feeding B' for B breaks the commutativity the iteration relies on - residuals of 1e-6 at cond 130.)
+    const double* Bj = SYM ? B + (jok ? gj : 0) : B + (int64_t)(jok ? gj : 0) * N;
+    mf_d4 acc = mf_d4{0.0, 0.0, 0.0, 0.0};
+    const int kper = ((N + 3) / 4 + 3) / 4 * 4;   // inner indices per K-quarter, a multiple of 4
+    const int kbeg = kq * kper, kend = (kbeg + kper < N) ? kbeg + kper : N;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + fk;
+            const bool kok = k < kend;
+            a[u] = (iok && kok) ? Ai[(int64_t)k * N] : 0.0;
+            b[u] = (jok && kok) ? (SYM ? Bj[(int64_t)k * N] : Bj[k]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q];
+    __syncthreads();
+    // thread (sub2, q2, l2): entry D[4 q2 + (l2 >> 4)][l2 & 15] of sub-tile sub2, the four K-quarters added in order
+    const int sub2 = tid >> 8, e = tid & 255, q2 = e >> 6, l2 = e & 63;
+    const double v = ((sR[sub2 * 256 + e] + sR[(4 + sub2) * 256 + e]) + sR[(8 + sub2) * 256 + e]) + sR[(12 + sub2) * 256 + e];
+    const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
+    if (i < N && j < N) {
+        const double out = alpha * v + (i == j ? beta : 0.0);
+        if (SYM) {
+            if (ti != tj) {
+                C[i + (int64_t)j * N] = out;
+                C[j + (int64_t)i * N] = out;
+            } else if (j <= i) {   // diagonal tile: both (i, j) and (j, i) are computed here - the lower one is the one that is kept
+                C[i + (int64_t)j * N] = out;
+                C[j + (int64_t)i * N] = out;
+            }
+        } else {
+            C[i + (int64_t)j * N] = out;
+        }
+    }
+}
+
+// C = alpha A B + beta I (N <= 2048; C must not alias A or B).  sym_out: A, B symmetric and commuting - the result is symmetric,
+// lower tiles + mirror; otherwise a general product (A(i, k), B(k, j) as they stand)
+static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out) {
+    const int nt = (int)((N + 31) / 32);
+    if (sym_out)
+        hipLaunchKernelGGL(k_small_mm<true>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta);
+    else
+        hipLaunchKernelGGL(k_small_mm<false>, dim3((unsigned)(nt * nt)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 constexpr int MF_CHUNKS = 16;
 __global__ __launch_bounds__(256) void k_mf_stats1(const double* __restrict__ X, int N, double* __restrict__ part) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -131,7 +219,9 @@ static int mf_stats(Handle* h, const double* X, int64_t N, double out[3]) {
 }
 
 // C = A B for commuting symmetric N x N matrices (C symmetric)
+static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out);
 static int mf_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) {
+    if (N <= 2048 && C != A && C != B && !dev_is(DEV_NO_SMALL_MM, '1')) return small_mm(h, A, B, C, N, 1.0, 0.0, true);
     return gemm_f64(h, true, true, A, N, B, N, C, N, N, N, N, true);
 }
 // C = A B in full (no symmetry assumed): C[i, j] = sum_k A[i, k] B[k, j], all three column-major.  The coupled iteration below
@@ -158,22 +248,30 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
     TLSQ_TRY(mf_axpbi(h, C, X, N, 1.0 / nrm, 0.0));
     int extra = -1;   // steps still to do after the error dropped below 1e-4 (-1: not yet)
     double *cur = X, *nxt = W2;   // the iterate alternates between the two buffers (one copy at the end at most)
+    const bool small = N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1');   // (k_small_mm: no slabs, the element-wise step in the epilogue)
     for (int it = 0; it < max_iters; ++it) {
-        TLSQ_TRY(mf_mul(h, cur, cur, W1, N));             // W1 = X^2
         // the convergence test costs a host round trip: not before the linear phase can be over, then every third step
-        if (extra < 0 && it >= 6 && (it % 3) == 0) {
-            TLSQ_TRY(mf_stats(h, W1, N, st));
-            if (!std::isfinite(st[0])) return TLSQ_OK;
-            if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+        const bool test_now = extra < 0 && it >= 6 && (it % 3) == 0;
+        if (small && !test_now && extra != 0) {
+            TLSQ_TRY(small_mm(h, cur, cur, W1, N, -0.5, 1.5, true));   // W1 = 1.5 I - 0.5 X^2 in one launch
+        } else {
+            if (small) TLSQ_TRY(small_mm(h, cur, cur, W1, N, 1.0, 0.0, true));
+            else TLSQ_TRY(mf_mul(h, cur, cur, W1, N));        // W1 = X^2
+            if (test_now) {
+                TLSQ_TRY(mf_stats(h, W1, N, st));
+                if (!std::isfinite(st[0])) return TLSQ_OK;
+                if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+            }
+            if (extra == 0) {
+                if (cur != X) TLSQ_HIP(h, hipMemcpyAsync(X, cur, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+                *iters = it;
+                *ok = true;
+                return TLSQ_OK;
+            }
+            TLSQ_TRY(mf_axpbi(h, W1, W1, N, -0.5, 1.5));      // W1 = 1.5 I - 0.5 X^2
         }
-        if (extra == 0) {
-            if (cur != X) TLSQ_HIP(h, hipMemcpyAsync(X, cur, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-            *iters = it;
-            *ok = true;
-            return TLSQ_OK;
-        }
-        TLSQ_TRY(mf_axpbi(h, W1, W1, N, -0.5, 1.5));      // W1 = 1.5 I - 0.5 X^2
-        TLSQ_TRY(mf_mul(h, cur, W1, nxt, N));             // X <- X W1
+        if (small) TLSQ_TRY(small_mm(h, cur, W1, nxt, N, 1.0, 0.0, true));
+        else TLSQ_TRY(mf_mul(h, cur, W1, nxt, N));            // X <- X W1
         double* t = cur;
         cur = nxt;
         nxt = t;
@@ -193,30 +291,46 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
     TLSQ_TRY(mf_axpbi(h, B, Z, N, 0.0, 1.0));
     int extra = -1;
     double st[3];
+    // (k_small_mm, full results: three launches per step - the element-wise step rides in the first product's epilogue and the
+    //  iterates change buffers instead of being copied back - against nine through the tiled GEMM)
+    const bool small = N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1') && !dev_is(DEV_MATFUN_SYM, '1');
+    double *Zc = Z, *Yc = Y, *Wc = W;   // current Z, current Y, the free buffer
     for (int it = 0; it < max_iters; ++it) {
-        TLSQ_TRY(mf_mul_full(h, Z, Y, T, N));             // T = Z Y  (-> I)
-        if (extra < 0 && it >= 3) {
-            TLSQ_TRY(mf_stats(h, T, N, st));
-            if (!std::isfinite(st[0])) return TLSQ_OK;
-            if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+        const bool test_now = extra < 0 && it >= 3;
+        if (small && !test_now && extra != 0) {
+            TLSQ_TRY(small_mm(h, Zc, Yc, T, N, -0.5, 1.5, false));   // T = 1.5 I - 0.5 Z Y
+        } else {
+            if (small) TLSQ_TRY(small_mm(h, Zc, Yc, T, N, 1.0, 0.0, false));
+            else TLSQ_TRY(mf_mul_full(h, Zc, Yc, T, N));         // T = Z Y  (-> I)
+            if (test_now) {
+                TLSQ_TRY(mf_stats(h, T, N, st));
+                if (!std::isfinite(st[0])) return TLSQ_OK;
+                if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+            }
+            if (extra == 0) {
+                TLSQ_TRY(mf_axpbi(h, Zc, Z, N, 1.0 / std::sqrt(hi), 0.0));   // (into the caller's buffer, wherever the iterate sits)
+                *iters = it;
+                *ok = true;
+                return TLSQ_OK;
+            }
+            TLSQ_TRY(mf_axpbi(h, T, T, N, -0.5, 1.5));        // T = 1.5 I - 0.5 Z Y
         }
-        if (extra == 0) {
-            TLSQ_TRY(mf_axpbi(h, Z, Z, N, 1.0 / std::sqrt(hi), 0.0));
-            *iters = it;
-            *ok = true;
-            return TLSQ_OK;
+        if (small) {
+            TLSQ_TRY(small_mm(h, Yc, T, Wc, N, 1.0, 0.0, false));    // Y <- Y T
+            std::swap(Yc, Wc);
+            TLSQ_TRY(small_mm(h, T, Zc, Wc, N, 1.0, 0.0, false));    // Z <- T Z
+            std::swap(Zc, Wc);
+        } else {
+            TLSQ_TRY(mf_mul_full(h, Yc, T, Wc, N));           // Y <- Y T
+            TLSQ_HIP(h, hipMemcpyAsync(Yc, Wc, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+            TLSQ_TRY(mf_mul_full(h, T, Zc, Wc, N));           // Z <- T Z
+            TLSQ_HIP(h, hipMemcpyAsync(Zc, Wc, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
         }
-        TLSQ_TRY(mf_axpbi(h, T, T, N, -0.5, 1.5));        // T = 1.5 I - 0.5 Z Y
-        TLSQ_TRY(mf_mul_full(h, Y, T, W, N));             // Y <- Y T
-        TLSQ_HIP(h, hipMemcpyAsync(Y, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-        TLSQ_TRY(mf_mul_full(h, T, Z, W, N));             // Z <- T Z
-        TLSQ_HIP(h, hipMemcpyAsync(Z, W, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
         if (extra > 0) --extra;
     }
     return TLSQ_OK;
 }
 
-// trace(X) and ||X||_inf of a symmetric N x N matrix on the host
 int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf) {
     double st[3];
     TLSQ_TRY(mf_stats(h, X, N, st));
