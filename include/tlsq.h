@@ -176,16 +176,17 @@ int tlsq_comm_size(tlsq_handle h, int* nranks);
  * D  M x N (ldD)  in;  A, E  M x N out;  optional (may be NULL): U M x d (ldU), S d, Vt d x N (ldVt),
  * d = min(M_global,N) — the SVD of the last Z = D-E+Y/mu (the reference's returned `s`, :194,:238).
  * *sv = estimated rank (:204,:238).  When row-sharded, M/D/A/E/U are the local shard.
- * Large mode, min(M,N) in (2048, 16384]: every SVD step of the loop is served by the certified subspace solver (there
+ * Large mode, min(M,N) in (2048, 65536]: every SVD step of the loop is served by the certified subspace solver (there
  * is no dense eigensolver of that size in the loop); A, E, sv, the iteration count and the costs are the same as
  * always.  The returned U/S/Vt are complete up to min(M,N) = 4608 (TSQR + one-sided Jacobi once after the loop, a
  * few seconds, only when asked for); beyond that only the leading triplets (the sigma >= 1/mu ones plus the solver's
  * padding) are returned - the rest of S is NaN and the corresponding vectors are zero.  The subspace block grows to
  * 512 columns; an iteration it cannot serve (a rank beyond ~480, or a cold start on a high-rank problem) goes through
  * the TSQR route up to min(M,N) = 4608 (about a second per decomposition) and is TLSQ_ERR_UNSUPPORTED beyond.
- * min(M,N) > 16384: TLSQ_ERR_UNSUPPORTED.
+ * From min(M,N) = 8192 on no N x N matrix is formed at all (operator products G X = Z'(Z X)); min(M,N) > 65536:
+ * TLSQ_ERR_UNSUPPORTED (untested beyond; 40000 x 20000 fp32 and 20000 x 17000 fp64 are part of the GPU suite's sizes).
  * Device memory held by the handle (grow-only workspace, freed by tlsq_destroy): three M x N panels of the element type
- * (Y, Z, residual) beside D, A, E - which are the caller's with TLSQ_MEM_DEVICE and three more workspace panels with
+ * (Y, Z, residual; a fourth - the second Z of the speculative loop - for panels up to 2 GB) beside D, A, E - which are the caller's with TLSQ_MEM_DEVICE and three more workspace panels with
  * TLSQ_MEM_HOST; the hankel flag and the svd / opnorm hook modes add two more (a second E and Z).  The A and E panels
  * are scratch while the call runs (E holds the second copy of Y); they are written in full before the call returns. */
 int tlsq_rpca_f64(tlsq_handle h, const double* D, int64_t M, int64_t N, int64_t ldD,

@@ -180,3 +180,21 @@ def test_bench_problem_full_size_vs_oracle(eng, bench_vectors, name):
     Sw = np.asarray(ref["S"])
     floor = 64 * np.finfo(float).eps * math.sqrt(len(Sw)) * Sw[0]
     assert np.all(np.abs(s.S - Sw) <= 1e-10 * Sw + floor)
+
+
+def test_min_dimension_beyond_16384(eng):
+    """The reference has no size limit; the library's used to be min(M, N) <= 16384 (missing item 3).  From N = 8192
+    on the loop forms no N x N matrix at all (operator products on the panel), so the limit was only a constant: 20000 x 17000
+    fp32, rank 10 + 5 % sparse, to convergence - properties only (two LAPACK decompositions of that panel per iteration are out
+    of the oracle's reach in a test)."""
+    from tlsq_amd import workloads as W
+    M, N, r = 20000, 17000, 10
+    D, A0, S0 = W.synth_lowrank_sparse(M, N, r, seed=5, dtype=np.float32)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_s=False, cost_history=False)
+    assert rep.converged and sv == r and all(v == r for v in rep.svp_hist[3:])
+    # (the stopping rule is spectral, opnorm(D - A - E) / opnorm(D) < sqrt(eps(Float32)) = 3.5e-4: the Frobenius ratio of a
+    #  residual spread over many small singular values is larger)
+    assert rep.final_cost < math.sqrt(np.finfo(np.float32).eps)
+    assert np.linalg.norm((D[::7] - A[::7] - E[::7]).astype(np.float64)) / np.linalg.norm(D[::7].astype(np.float64)) < 2e-2
+    assert relerr(A[::7].astype(np.float64), A0[::7].astype(np.float64)) < 1e-3
+    assert np.mean((E[::11] != 0) == (S0[::11] != 0)) > 0.99

@@ -124,7 +124,7 @@ struct PhaseTimer {
 // Largest Gram dimension the LDS-resident full Jacobi solvers handle.  Above it ("large mode") rpca relies on the
 // certified subspace iteration alone; see rpca_core.
 constexpr int64_t kFullEigMaxN = 2048;
-constexpr int64_t kGramMaxN = 16384;
+constexpr int64_t kGramMaxN = 65536;   // (round 4: beyond 16384 everything runs through the operator form - no N x N matrix exists from N = 8192 on)
 // largest N for which the complete returned SVD is computed after a large-mode loop (one-sided Jacobi on R' with at
 // least two resident columns per workgroup: 2 * 2 * N * 8 bytes of LDS)
 constexpr int64_t kReturnedSvdMaxN = 4608;
