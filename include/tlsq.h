@@ -316,7 +316,12 @@ int tlsq_tls_from_vt_f64(const double* Vt, int64_t ncols, int64_t ldVt, int64_t 
  * With a communicator (tlsq_comm_init) X holds this rank's COLUMNS (contiguous blocks in rank order: the entrywise averages
  * break ties by the column index within the whole row); a group handle (tlsq_create_multi) splits the columns of a host
  * matrix itself (at least 64 per GPU, otherwise the first GPU alone).  All three averages are available on shards. */
-enum { TLSQ_GA_MEAN = 0, TLSQ_GA_TRIMMED_MEAN = 1, TLSQ_GA_MEDIAN = 2 };
+enum { TLSQ_GA_MEAN = 0, TLSQ_GA_TRIMMED_MEAN = 1, TLSQ_GA_MEDIAN = 2, TLSQ_GA_CALLBACK = 3 };
+/* TLSQ_GA_CALLBACK: ANY spherical average of the host language - the reference's `μ = f` keyword (src/robustPCA.jl:286, :297:
+ * `μᵢ = μ(q, w, U)`).  Once per iteration the library hands the weights w (N) and the unit columns U (d x N, ldU; copied to the
+ * host once per component) to the caller's function on the calling thread; it writes the average to s (d; on entry the current q,
+ * as in the reference, where the closure works in place on q) and returns 0.  One GPU only (a group handle uses its first GPU). */
+typedef int (*tlsq_ga_avg_cb)(double* s, const double* w, const double* U, int64_t d, int64_t N, int64_t ldU, void* user);
 typedef struct tlsq_ga_opts {
     double  tol;       /* NaN -> 1e-7   (:286) */
     int64_t iters;     /* <=0 -> 1000   (:286) */
@@ -324,6 +329,8 @@ typedef struct tlsq_ga_opts {
     int32_t memory;    /* TLSQ_MEM_* for X, q0, Q */
     double  trim;      /* NaN -> 0.1    (:327) */
     uint64_t seed;
+    tlsq_ga_avg_cb avg_cb;   /* TLSQ_GA_CALLBACK */
+    void*   user;
 } tlsq_ga_opts;
 /* optional per-component reports (arrays of r entries; dq_hist is hist_capacity x r, column i = the `dq` of every
  * iteration of component i — what `verbose` prints at :300 — NaN padded) */

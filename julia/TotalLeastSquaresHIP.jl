@@ -363,7 +363,27 @@ end
 # mirrors `struct tlsq_ga_opts` (40 bytes) and `struct tlsq_ga_info` (64 bytes)
 mutable struct GaOpts
     tol::Cdouble; iters::Int64; average::Int32; memory::Int32; trim::Cdouble; seed::UInt64
+    avg_cb::Ptr{Cvoid}; user::Ptr{Cvoid}
     GaOpts() = new()
+end
+
+# a user's spherical average `μ(q, w, U)` (src/robustPCA.jl:286, :297) behind tlsq_ga_avg_cb: runs in Julia, on this thread
+mutable struct AvgBox
+    f::Any
+    err::Any
+end
+function _avg_tramp(sp::Ptr{Cdouble}, wp::Ptr{Cdouble}, Up::Ptr{Cdouble}, d::Int64, N::Int64, ldU::Int64, user::Ptr{Cvoid})::Cint
+    box = unsafe_pointer_to_objref(user)::AvgBox
+    try
+        s = unsafe_wrap(Array, sp, (d,)); w = unsafe_wrap(Array, wp, (N,))
+        U = view(unsafe_wrap(Array, Up, (ldU, N)), 1:d, :)
+        out = box.f(s, w, U)                                             # :297  μᵢ = μ(q, w, U)
+        out === s || out === nothing || (s .= out)
+        return Cint(0)
+    catch e
+        box.err = e
+        return Cint(1)
+    end
 end
 mutable struct GaInfo
     iters::Ptr{Int64}; status::Ptr{Int32}; dq::Ptr{Cdouble}; dq_hist::Ptr{Cdouble}; hist_capacity::Int64
@@ -391,17 +411,25 @@ whole iteration runs on the device; an arbitrary Julia closure cannot).  The sta
 """
 function rpca_ga(X::AbstractMatrix{Float64}, r = minimum(size(X)), U = nothing; μ = μ!, tol = 1e-7, iters = 1000,
                  verbose = false, P = 0.1, q0 = randn(size(X, 1), r))
-    code = μ === μ! ? 0 : μ === entrywise_trimmed_mean ? 1 : μ === entrywise_median ? 2 :
-           throw(ArgumentError("rpca_ga: μ must be μ!, entrywise_trimmed_mean or entrywise_median on the GPU path"))
+    # the three exported averages run on the device; any other function is the reference's `μ = f`: it runs here, in Julia,
+    # through the C callback (weights and unit columns visit the host)
+    code = μ === μ! ? 0 : μ === entrywise_trimmed_mean ? 1 : μ === entrywise_median ? 2 : 3
     Xm = Matrix(X); d, N = size(Xm); Q = zeros(d, r)
     o = GaOpts(); ccall((:tlsq_ga_opts_default, LIB[]), Cvoid, (Ref{GaOpts},), o)
     o.tol = tol; o.iters = iters; o.average = code; o.trim = P; o.memory = MEM_HOST
+    box = AvgBox(μ, nothing)
+    if code == 3
+        o.avg_cb = @cfunction(_avg_tramp, Cint, (Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Int64, Ptr{Cvoid}))
+        o.user = pointer_from_objref(box)
+    end
     its = zeros(Int64, r); status = zeros(Int32, r); dq = zeros(r); hist = fill(NaN, verbose ? iters : 1, r)
     info = GaInfo(); info.iters = pointer(its); info.status = pointer(status); info.dq = pointer(dq)
     info.dq_hist = verbose ? pointer(hist) : C_NULL; info.hist_capacity = verbose ? iters : 0
-    st = GC.@preserve its status dq hist check(ccall((:tlsq_rpca_ga_f64, LIB[]), Cint,
+    st = GC.@preserve its status dq hist box ccall((:tlsq_rpca_ga_f64, LIB[]), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ref{GaOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
-         Ref{GaInfo}), handle(), Xm, d, N, d, r, o, Matrix{Float64}(q0), d, Q, d, info))
+         Ref{GaInfo}), handle(), Xm, d, N, d, r, o, Matrix{Float64}(q0), d, Q, d, info)
+    box.err === nothing || throw(box.err)                                                       # the user's own exception
+    st = check(st)
     if verbose
         for i in 1:r
             for k in 1:its[i]; @info "Change at iteration $k: $(hist[k, i])"; end                  # :300

@@ -47,7 +47,7 @@ def test_struct_sizes_match_header():
     # natural alignment, no packing: these are the sizes the Julia shim's struct mirrors must have
     assert C.sizeof(L.RpcaOpts) == 128
     assert C.sizeof(L.RpcaInfo) == 216
-    assert C.sizeof(L.GaOpts) == 40 and C.sizeof(L.GaInfo) == 64
+    assert C.sizeof(L.GaOpts) == 56 and C.sizeof(L.GaInfo) == 64
 
 
 def test_tls_from_vt_is_host_only_math():

@@ -139,6 +139,51 @@ def test_rpca_ga_robust_matches_oracle(eng, G, mode, d, N, r):
     assert np.abs(got - want).max() < 1e-9
 
 
+@pytest.mark.parametrize("d,N,r", [(10, 400, 3), (40, 301, 2), (130, 2000, 2)])
+def test_rpca_ga_user_average_through_the_callback(eng, G, d, N, r):
+    """`rpca_ga(X, r; μ = f)` with ANY function of the host language (src/robustPCA.jl:286, :297): the weights and the unit
+    columns visit the host, `f(q, w, U)` runs there (tlsq_ga_avg_cb) - the reference's own averages passed as plain callables
+    reproduce the device averages and the oracle (same iterations, same dq trace), a made-up robust average (weighted mean
+    of the entries within two scaled MADs of the row median) reproduces the oracle run with the same function, and an
+    exception inside the function comes back as that exception."""
+    rng = np.random.default_rng(11 * d + N)
+    _, X = _data(rng, d, N, r, outliers=0.02)
+    q0 = rng.standard_normal((d, r))
+
+    def mad_mean(s, w, U):
+        out = np.empty(U.shape[0])
+        for j in range(U.shape[0]):
+            v = w * U[j]
+            med = np.median(v)
+            keep = np.abs(v - med) <= 2.0 * 1.4826 * np.median(np.abs(v - med)) + 1e-300
+            out[j] = np.sum(v[keep]) / np.sum(w[keep])
+        return out
+
+    for f, dev in ((G.mu_mean, None), (G.entrywise_median, "entrywise_median"), (mad_mean, None)):
+        info = G.GaInfo()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = G.rpca_ga(X, r, q0=q0, info=info, mu=f, iters=60)
+            got, rep = eng.rpca_ga(X, r, q0=q0, mu=f, iters=60, return_report=True)
+        assert rep["iters"] == info.iters and rep["status"] == [int(b) for b in info.maxiter], f.__name__
+        assert np.abs(got - want).max() < 1e-9, f.__name__
+        for i in range(r):
+            assert np.allclose(rep["dq_hist"][i], info.dq_hist[i], rtol=1e-6, atol=1e-12)
+        if f is not mad_mean:   # ... and equals the device average of the same name
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gd, rd = eng.rpca_ga(X, r, q0=q0, mu=dev, iters=60, return_report=True)
+            assert rd["iters"] == rep["iters"] and np.abs(gd - got).max() < 1e-9
+
+    class Boom(Exception):
+        pass
+
+    def bad(s, w, U):
+        raise Boom("average failed")
+    with pytest.raises(Boom):
+        eng.rpca_ga(X, r, q0=q0, mu=bad)
+
+
 def test_rpca_ga_reference_property(eng):             # test/runtests.jl:446-464, library start vectors
     rng = np.random.default_rng(1)
     for shape in ((10, 40), (40, 10)):

@@ -16,7 +16,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SVD_FULL, SVD_RANDOMIZED, SVD_CALLBACK = 0, 1, 2
 OPNORM_EXACT, OPNORM_POWER, OPNORM_CALLBACK = 0, 1, 2
 UNIQUE_ID_BYTES = 128
-GA_MEAN, GA_TRIMMED_MEAN, GA_MEDIAN = 0, 1, 2
+GA_MEAN, GA_TRIMMED_MEAN, GA_MEDIAN, GA_CALLBACK = 0, 1, 2, 3
 
 ON_ITER = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_int64, C.c_void_p)
 SVD_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
@@ -50,9 +50,13 @@ class RpcaInfo(C.Structure):
                 ("sweeps_timed", C.c_int64), ("hbm_bytes_sweeps_timed", C.c_double)]
 
 
+GA_AVG_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,
+                        C.c_int64, C.c_int64, C.c_void_p)
+
+
 class GaOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("iters", C.c_int64), ("average", C.c_int32), ("memory", C.c_int32),
-                ("trim", C.c_double), ("seed", C.c_uint64)]
+                ("trim", C.c_double), ("seed", C.c_uint64), ("avg_cb", GA_AVG_CB), ("user", C.c_void_p)]
 
 
 class GaInfo(C.Structure):

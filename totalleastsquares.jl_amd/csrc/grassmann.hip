@@ -1120,7 +1120,7 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
                      tlsq_ga_info* info) {
     TLSQ_TRY(check_handle(h));
     if (is_multi_call(h) && X && Q && d > 0 && r > 0 && ldX >= d && ldQ >= d && N >= 64 * (int64_t)h->multi_n &&
-        !(opts && opts->memory == TLSQ_MEM_DEVICE)) {
+        !(opts && opts->memory == TLSQ_MEM_DEVICE) && !(opts && opts->average == TLSQ_GA_CALLBACK)) {
         // single-process multi-GPU group: contiguous blocks of the observations (columns of the host matrix) per
         // rank, the same start vectors everywhere; q and every decision evolve identically on all ranks, rank 0 delivers Q and
         // the report.  (Fewer than 64 columns per GPU, device pointers: the first GPU alone, below.)
@@ -1161,7 +1161,11 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     const double P = (opts && opts->trim == opts->trim) ? opts->trim : 0.1;           // :327
     const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
     const uint64_t seed = opts ? opts->seed : 0;
-    if (mode != TLSQ_GA_MEAN && mode != TLSQ_GA_TRIMMED_MEAN && mode != TLSQ_GA_MEDIAN)
+    const bool cb_mode = mode == TLSQ_GA_CALLBACK;
+    if (cb_mode && !(opts && opts->avg_cb)) return set_err(h, TLSQ_ERR_ARG, "rpca_ga: TLSQ_GA_CALLBACK without a callback");
+    if (cb_mode && h->comm)
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca_ga: a caller's average needs all observations on one GPU (not column shards)");
+    if (mode != TLSQ_GA_MEAN && mode != TLSQ_GA_TRIMMED_MEAN && mode != TLSQ_GA_MEDIAN && !cb_mode)
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: unknown average %d", mode);
     if (mode == TLSQ_GA_MEDIAN && N < 2)
         return set_err(h, TLSQ_ERR_ARG, "rpca_ga: entrywise_median needs at least 2 columns (I[end÷2])");
@@ -1180,7 +1184,14 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     const bool solo_on = !dev_is(DEV_GA_SOLO, '0');
     const bool solo = solo_on && mode == TLSQ_GA_MEAN && !h->comm && d <= 64 && N * (d + 1) <= 18000;
     GaBuffers b;
-    if (!solo) TLSQ_TRY(ga_alloc(h, d, N, mode, hist_cap, true, &b));
+    // (a caller's average: buffers of the plain mean - w, q, sbuf, state are all it needs)
+    if (!solo) TLSQ_TRY(ga_alloc(h, d, N, cb_mode ? TLSQ_GA_MEAN : mode, hist_cap, true, &b));
+    std::vector<double> cbU, cbW, cbS;
+    if (cb_mode) {
+        cbU.resize((size_t)d * N);
+        cbW.resize((size_t)N);
+        cbS.resize((size_t)d);
+    }
     if (h->comm && mode != TLSQ_GA_MEAN) {
         // column shards: the entrywise averages rank the entries of whole rows (:329, :357) - this rank's place in them
         int64_t off = 0, tot = 0;
@@ -1242,7 +1253,31 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
         // kernels of iterations queued past the converged one return at once (a few microseconds each), a host round
         // trip costs more: queue 8 at a time.  The median's sort cannot be gated by the flag.
         const int64_t burst = (mode == TLSQ_GA_MEDIAN) ? 1 : 8;
-        while (queued < iters) {
+        if (cb_mode) {
+            // the caller's own average (src/robustPCA.jl:297 with a user closure): U visits the host once per component, then every
+            // iteration is weights down (:294-296 on the device), `μ(q, w, U)` on the calling thread, average up, the
+            // normalisation and the change dq (:298-304) on the device again
+            TLSQ_HIP(h, hipMemcpyAsync(cbU.data(), b.U, (size_t)d * N * 8, hipMemcpyDeviceToHost, h->stream));
+            int64_t g = (N + 3) / 4;
+            if (g > 4096) g = 4096;
+            while (queued < iters) {
+                hipLaunchKernelGGL(k_ga_dots, dim3((int)g), dim3(256), 0, h->stream, b.U, (int)d, N, b.norms, b.q, b.w, b.st);
+                TLSQ_HIP(h, hipGetLastError());
+                TLSQ_HIP(h, hipMemcpyAsync(cbW.data(), b.w, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipMemcpyAsync(cbS.data(), b.q, (size_t)d * 8, hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                const int cst = opts->avg_cb(cbS.data(), cbW.data(), cbU.data(), d, N, d, opts->user);
+                if (cst != 0) return set_err(h, TLSQ_ERR_ARG, "rpca_ga: the average callback failed (status %d)", cst);
+                TLSQ_HIP(h, hipMemcpyAsync(b.sbuf, cbS.data(), (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+                hipLaunchKernelGGL(k_ga_finalize, dim3(1), dim3(256), 0, h->stream, b.sbuf, (int)d, 2, b.q, b.qold, tol, b.st,
+                                   b.hist, hist_cap);
+                TLSQ_HIP(h, hipGetLastError());
+                ++queued;
+                TLSQ_TRY(read_state(h, b.st, &st));
+                if (st.converged) break;
+            }
+        }
+        while (queued < iters && !cb_mode) {
             const int64_t nq = std::min<int64_t>(burst, iters - queued);
             for (int64_t k = 0; k < nq; ++k) TLSQ_TRY(ga_iteration(h, &b, d, N, mode, tol, hist_cap));
             queued += nq;

@@ -544,11 +544,14 @@ class Engine:
         name = getattr(mu, "__name__", mu)
         table = {None: L.GA_MEAN, "mu_": L.GA_MEAN, "μ!": L.GA_MEAN, "mean": L.GA_MEAN,
                  "entrywise_trimmed_mean": L.GA_TRIMMED_MEAN, "entrywise_median": L.GA_MEDIAN}
-        if name not in table:
-            raise TlsqError(L.TLSQ_ERR_UNSUPPORTED,
-                            f"rpca_ga: average {name!r} has no device implementation (μ!, entrywise_trimmed_mean, "
-                            "entrywise_median do)")
-        return table[name]
+        # this module's own mu_ / entrywise_* (and their names) select the device averages; ANY other callable is the
+        # reference's `μ = f` with a user function: it runs on the host through the C callback (TLSQ_GA_CALLBACK)
+        own = mu is None or isinstance(mu, str) or getattr(mu, "__module__", "").endswith("engine")
+        if own and name in table:
+            return table[name]
+        if callable(mu):
+            return L.GA_CALLBACK
+        raise TlsqError(L.TLSQ_ERR_UNSUPPORTED, f"rpca_ga: average {name!r} is neither a device average nor a callable")
 
     def rpca_ga(self, X, r=None, *, tol=1e-7, iters=1000, mu=None, P=0.1, q0=None, seed=0, verbose=False,
                 return_report=False):
@@ -561,6 +564,24 @@ class Engine:
         o = L.GaOpts()
         self.lib.tlsq_ga_opts_default(C.byref(o))
         o.tol, o.iters, o.average, o.trim, o.seed = float(tol), int(iters), self._average_code(mu), float(P), int(seed)
+        errbox = []
+        if o.average == L.GA_CALLBACK:
+            def _avg(sp, wp, Up, dd, NN, ldU, user):
+                # `μᵢ = μ(q, w, U)` (src/robustPCA.jl:297): s holds the current q on entry; the result is what the function
+                # returns (or s itself when it works in place and returns None)
+                try:
+                    sv = np.ctypeslib.as_array(sp, shape=(dd,))
+                    wv = np.ctypeslib.as_array(wp, shape=(NN,))
+                    Uv = np.ctypeslib.as_array(Up, shape=(NN, ldU)).T[:dd]      # column-major d x N view
+                    out = mu(sv, wv, Uv)
+                    if out is not None and out is not sv:
+                        sv[:] = np.asarray(out, dtype=np.float64).reshape(dd)
+                    return 0
+                except BaseException as e:   # noqa: BLE001 - must not unwind through the C frames
+                    errbox.append(e)
+                    return 1
+            keep_cb = L.GA_AVG_CB(_avg)
+            o.avg_cb = keep_cb
         it = np.zeros(max(r, 1), dtype=np.int64)
         stt = np.zeros(max(r, 1), dtype=np.int32)
         dq = np.zeros(max(r, 1))
@@ -575,9 +596,11 @@ class Engine:
         q0f = None if q0 is None else _f(np.asarray(q0, dtype=np.float64).reshape(d, -1))
         if q0f is not None and q0f.shape[1] < r:
             raise TlsqError(L.TLSQ_ERR_ARG, "rpca_ga: q0 needs one column per component")
-        st = self._check(self.lib.tlsq_rpca_ga_f64(self.h, _ptr(Xf), d, N, d, r, C.byref(o),
-                                                   _ptr(q0f) if q0f is not None else None, d, _ptr(Q), d,
-                                                   C.byref(info)))
+        st = self.lib.tlsq_rpca_ga_f64(self.h, _ptr(Xf), d, N, d, r, C.byref(o),
+                                       _ptr(q0f) if q0f is not None else None, d, _ptr(Q), d, C.byref(info))
+        if errbox:
+            raise errbox[0]          # the user's average raised: surface its own exception
+        st = self._check(st)
         if verbose:
             for i in range(r):
                 for k in range(int(it[i])):
