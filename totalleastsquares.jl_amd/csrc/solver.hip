@@ -866,6 +866,17 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
                     svp < p ? s.sigma[s.order[svp]] / inv_mu : 0.0, (int)cold);
         if (good) {
             conv = true;
+            if (cold && !hook) {
+                // The panel changes more between the first two ALM iterations (Y is still zero in the first) than it ever does
+                // again: with the default count the first warm step misses the residual bound and a second one (~190 us on the
+                // classic path) follows.  Two more multiplications of the top columns (~13 us) avoid that; the count relaxes
+                // by itself afterwards (below).  TLSQ_WARM_Q0 overrides.
+                const char* e = dev_get(DEV_WARM_Q0);
+                const int v = e ? atoi(e) : 0;
+                st.q_warm = std::max(st.q_warm, v >= 1 && v <= 7 ? v : 5);
+                // (... and the relaxation stops at 3: probing further down costs a failed step sooner or later)
+                if (!e) st.q_floor = std::max(st.q_floor, 3);
+            }
             if (!cold && !hook) {
                 // a warm block that needed a second step just missed the residual bound after the first one: two more
                 // multiplications of its top columns next time are far cheaper than another step; relax again later

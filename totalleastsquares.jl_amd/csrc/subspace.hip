@@ -1350,6 +1350,7 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
                                                      int nukeA) {
     __shared__ double sS[CQ_PMAX * 16];   // p <= 512
     __shared__ double red[4];
+    __shared__ int s_last;
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int k = tid; k < p; k += 256) sS[k] = S[k + (size_t)c * p];
     __syncthreads();
@@ -1381,52 +1382,68 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
         const double rr = sqrt((red[0] + red[1]) + (red[2] + red[3]));
         theta[c] = th;
         res[c] = rr;
+        s_last = 0;
         if (mailbox) {
-            // Results go straight to host-visible (coherent, pinned) memory: [0] sequence flag, [8..) theta[p], res[p],
-            // status[3].  The workgroup that arrives last publishes the flag; the host polls it instead of paying a
-            // copy command plus a stream synchronisation (~40 us) for 2p+2 numbers.
-            volatile double* mb = mailbox;
-            mb[8 + c] = th;
-            mb[8 + p + c] = rr;
-            __threadfence_system();
-            if (atomicAdd(arrivals, 1u) == (unsigned int)(p - 1)) {
-                mb[8 + 2 * p] = status ? status[0] : 0.0;
-                mb[8 + 2 * p + 1] = status ? status[1] : 0.0;
-                mb[8 + 2 * p + 2] = status ? status[2] : 0.0;
-                if (ctrl) {
-                    // The decision the host takes from these numbers (solver.hip: sorted block, count of sigma >= 1/mu, weights of
-                    // the thresholded rebuild), in the same arithmetic (IEEE sqrt and division), so that the factor product
-                    // queued behind this kernel runs without waiting for the host.  The other workgroups' Ritz values were
-                    // released by their fences before they arrived here; they are read past this CU's L1.
-                    bool ok = !(status && status[1] != 0.0);
-                    double prev = 0.0;
-                    int r = 0;
-                    for (int i = 0; i < p; ++i) {
-                        const double t = __hip_atomic_load(theta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!(t - t == 0.0)) ok = false;
-                        const double sg = sqrt(t > 0.0 ? t : 0.0);
-                        if (i > 0 && sg > prev) ok = false;   // (the host's stable sort would move this column)
-                        prev = sg;
-                        if (sg >= inv_mu) {
-                            if (r < 32) {
-                                ctrl->sw.sel[r] = i;
-                                ctrl->sw.w[r] = nukeA ? (sg - inv_mu) / sg : 1.0;
-                            }
-                            ++r;
-                        }
-                    }
-                    if (r > 32) ok = false;
-                    ctrl->r = r;
-                    ctrl->ok = ok ? 1 : 0;
-                    mb[8 + 2 * p + 3] = ok ? 1.0 : 0.0;
-                    mb[8 + 2 * p + 4] = (double)r;
-                }
-                *arrivals = 0u;
-                __threadfence_system();
-                mb[0] = seq;
-            }
+            // Results go to host-visible (coherent, pinned) memory: [0] sequence flag, [8..) theta[p], res[p], status[3].  The
+            // workgroup that arrives last copies all of them there and publishes the flag; the host polls it instead of paying
+            // a copy command plus a stream synchronisation (~40 us) for 2p+2 numbers.  (Every workgroup used to write its own
+            // pair and fence at system scope: twenty fences over the host link instead of one.)
+            __threadfence();
+            s_last = atomicAdd(arrivals, 1u) == (unsigned int)(p - 1) ? 1 : 0;
         }
     }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last arrival (its first wave): the other workgroups' values were released by their fences; they are read past this
+    // CU's L1 ----
+    if (tid >= 64) return;
+    volatile double* mb = mailbox;
+    double* sT = sS;   // (S's column is not needed any more)
+    for (int i = tid; i < p; i += 64) {
+        const double t = __hip_atomic_load(theta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double e = __hip_atomic_load(res + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sT[i] = t;
+        mb[8 + i] = t;
+        mb[8 + p + i] = e;
+    }
+    if (tid == 0) {
+        mb[8 + 2 * p] = status ? status[0] : 0.0;
+        mb[8 + 2 * p + 1] = status ? status[1] : 0.0;
+        mb[8 + 2 * p + 2] = status ? status[2] : 0.0;
+    }
+    if (ctrl) {
+        // The decision the host takes from these numbers (solver.hip: sorted block, count of sigma >= 1/mu, weights of the
+        // thresholded rebuild), in the same arithmetic (IEEE sqrt and division), so that the factor product queued behind
+        // this kernel runs without waiting for the host.  One lane per Ritz value (blocks of up to 64 columns; wider ones
+        // never take the speculative product: ok = 0).
+        bool ok = !(status && status[1] != 0.0) && p <= 64;
+        const bool mine = tid < p;
+        const double t = mine && p <= 64 ? sT[tid] : 0.0;   // (one wave: its LDS writes above are ordered before this read)
+        const double sg = sqrt(t > 0.0 ? t : 0.0);
+        const double up = __shfl_up(sg, 1, 64);
+        const bool bad = mine && (!(t - t == 0.0) || (tid > 0 && sg > up));   // (the host's stable sort would move this column)
+        const bool above = mine && sg >= inv_mu;
+        const unsigned long long mb_above = __ballot(above);
+        if (__ballot(bad) != 0ull) ok = false;
+        const int r = __popcll(mb_above);
+        if (above) {
+            const int pos = __popcll(mb_above & ((1ull << tid) - 1ull));
+            if (pos < 32) {
+                ctrl->sw.sel[pos] = tid;
+                ctrl->sw.w[pos] = nukeA ? (sg - inv_mu) / sg : 1.0;
+            }
+        }
+        if (r > 32) ok = false;
+        if (tid == 0) {
+            ctrl->r = r;
+            ctrl->ok = ok ? 1 : 0;
+            mb[8 + 2 * p + 3] = ok ? 1.0 : 0.0;
+            mb[8 + 2 * p + 4] = (double)r;
+        }
+    }
+    if (tid == 0) *arrivals = 0u;
+    __threadfence_system();   // (wave-wide: every lane's mailbox writes are out before the flag)
+    if (tid == 0) mb[0] = seq;
 }
 
 // X = Q S, GX = GQ S, theta, res: one launch (every workgroup reads both panels); the three separate kernels remain
