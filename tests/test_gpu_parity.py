@@ -1364,6 +1364,30 @@ def test_noisy_data_matrix_function_route(eng, M, N, r, noise):
     assert rep.tsqr_iterations <= rep.iters_done // 3, (rep.tsqr_iterations, rep.iters_done)   # (without the route: every late iteration)
 
 
+def test_noisy_late_iterations_stay_on_the_matrix_function_route(eng):
+    """Late iterations of a noisy problem: the top of the noise bulk grows past 1e3 / mu^2 and hundreds of pairs would have to be
+    "dominant".  The route then takes its dominant set at 1e5 / mu^2 (solver.hip, matfun_route) instead of handing those
+    iterations to TSQR + Jacobi; the sign function comes from bounded odd quintics + Newton-Schulz (matfun.hip), the inverse
+    square root from the coupled iteration with the minimax quintics' even parts.  Same trajectory and results as the oracle,
+    no dense decomposition at all, and the switches that restore the round-3 behaviour agree with it."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(5)
+    M, N, r, noise = 4000, 256, 8, 1e-2
+    D = (rng.standard_normal((M, r)) @ rng.standard_normal((r, N)) + 10 * rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.05)
+         + noise * rng.standard_normal((M, N)))
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    Ao, Eo, so, svo, io = O.rpca(D)
+    assert (sv, rep.iters_done) == (svo, io.iters_done) and sv > 10 * r
+    assert rep.svp_hist == io.svp_hist
+    assert relerr(A, Ao) < 1e-9 and relerr(E, Eo) < 1e-9
+    assert rep.tsqr_iterations == 0, rep.tsqr_iterations
+    with tlsq_amd.dev_switches(MATFUN_DEFL="1e3", NO_QUINTIC=1):
+        A3, E3, s3, sv3, rep3 = eng.rpca(D, return_report=True)
+    assert (sv3, rep3.iters_done) == (sv, rep.iters_done) and rep3.tsqr_iterations >= 1
+    assert relerr(A, A3) < 1e-10 and relerr(E, E3) < 1e-10
+
+
 def test_efree_loop_against_classic_sweeps(eng):
     """The default loop keeps no E while it runs (sweeps.hip, k_zsweep: Y' = mu (Z - A), R = Z - A - Y / mu, E formed once
     after the loop from the kept factors of A_{k-1}); the switch NO_ZSWEEP=1 runs the

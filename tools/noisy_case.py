@@ -14,6 +14,7 @@ ap.add_argument("--noise", nargs="*", type=float, default=[0.0, 1e-6, 1e-4, 1e-2
 ap.add_argument("--check", action="store_true", help="compare iterations / sv with the CPU oracle (slow)")
 a = ap.parse_args()
 M, N, r = a.shape
+tlsq_amd.dev_from_env()   # TLSQ_DEBUG=1 etc. from the shell
 eng = tlsq_amd.Engine(0)
 for noise in a.noise:
     rng = np.random.default_rng(1)

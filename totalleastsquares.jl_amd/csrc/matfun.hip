@@ -7,6 +7,7 @@
 // Every iterate is a polynomial in the input, so all products are products of commuting symmetric matrices: the GEMM runs in
 // its symmetric form (lower tiles computed, mirrored), which also keeps the iterates exactly symmetric.
 #include "common.hpp"
+#include "quintic.hpp"
 
 namespace tlsq {
 
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(256) void k_mf_axpbi(const double* X, double* Y, in
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
 template <bool SYM>
 __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
-                                                   int N, int nt, double alpha, double beta) {
+                                                   int N, int nt, double alpha, double beta, const double* __restrict__ Add,
+                                                   double gamma) {
     __shared__ double sR[16 * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
     const double v = ((sR[sub2 * 256 + e] + sR[(4 + sub2) * 256 + e]) + sR[(8 + sub2) * 256 + e]) + sR[(12 + sub2) * 256 + e];
     const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
     if (i < N && j < N) {
-        const double out = alpha * v + (i == j ? beta : 0.0);
+        double out = alpha * v + (i == j ? beta : 0.0);
+        if (Add) out += gamma * Add[i + (int64_t)j * N];   // (SYM: Add is symmetric like the result)
         if (SYM) {
             if (ti != tj) {
                 C[i + (int64_t)j * N] = out;
@@ -100,12 +103,14 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
 
 // C = alpha A B + beta I (N <= 2048; C must not alias A or B).  sym_out: A, B symmetric and commuting - the result is symmetric,
 // lower tiles + mirror; otherwise a general product (A(i, k), B(k, j) as they stand)
-static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out) {
+// (+ gamma Add with Add != nullptr: one more N x N term in the epilogue; Add may be A or B)
+static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out,
+                    const double* Add = nullptr, double gamma = 0.0) {
     const int nt = (int)((N + 31) / 32);
     if (sym_out)
-        hipLaunchKernelGGL(k_small_mm<true>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta);
+        hipLaunchKernelGGL(k_small_mm<true>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
     else
-        hipLaunchKernelGGL(k_small_mm<false>, dim3((unsigned)(nt * nt)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta);
+        hipLaunchKernelGGL(k_small_mm<false>, dim3((unsigned)(nt * nt)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -219,7 +224,6 @@ static int mf_stats(Handle* h, const double* X, int64_t N, double out[3]) {
 }
 
 // C = A B for commuting symmetric N x N matrices (C symmetric)
-static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out);
 static int mf_mul(Handle* h, const double* A, const double* B, double* C, int64_t N) {
     if (N <= 2048 && C != A && C != B && !dev_is(DEV_NO_SMALL_MM, '1')) return small_mm(h, A, B, C, N, 1.0, 0.0, true);
     return gemm_f64(h, true, true, A, N, B, N, C, N, N, N, N, true);
@@ -247,36 +251,80 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
     if (!(nrm > 0.0) || !std::isfinite(nrm)) return TLSQ_OK;
     TLSQ_TRY(mf_axpbi(h, C, X, N, 1.0 / nrm, 0.0));
     int extra = -1;   // steps still to do after the error dropped below 1e-4 (-1: not yet)
-    double *cur = X, *nxt = W2;   // the iterate alternates between the two buffers (one copy at the end at most)
+    // the iterate moves through the three buffers (one copy at the end at most): cur, and two free ones
+    double *cur = X, *f1 = W1, *f2 = W2;
     const bool small = N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1');   // (k_small_mm: no slabs, the element-wise step in the epilogue)
-    for (int it = 0; it < max_iters; ++it) {
-        // the convergence test costs a host round trip: not before the linear phase can be over, then every third step
-        const bool test_now = extra < 0 && it >= 6 && (it % 3) == 0;
-        if (small && !test_now && extra != 0) {
-            TLSQ_TRY(small_mm(h, cur, cur, W1, N, -0.5, 1.5, true));   // W1 = 1.5 I - 0.5 X^2 in one launch
+    int it = 0;
+    int first_test = 6;   // the convergence test costs a host round trip: not before the linear phase can be over
+    // ---- phase 1: odd quintics ----
+    // The spectrum of X_0 lies in [-1, 1]; what is known about its distance from zero is the cluster at -1 / nrm (the null
+    // directions of the deflated panel, C = -I there) - and that a noise bulk crosses the threshold with a few hundred
+    // eigenvalues, the nearest of which sits ~1e-3 / mu^2 from it (measured: Newton-Schulz needed 12 more steps behind a
+    // schedule for 0.1 / nrm).  Eigenvalues closer to zero than l = 1e-3 / nrm just arrive later, in phase 2.
+    // Three products per step:   S = X^2,   T = c S^2 + b S + a I,   X <- X T.
+    //  (a) growth: p(x) = 3.4445 x - 4.7750 x^3 + 2.0315 x^5 multiplies an eigenvalue near zero by 3.44 and keeps whatever has
+    //      reached [0.22, 1.13] inside [0.70, 1.13] (Newton-Schulz: 1.5 per step of two products).  The minimax quintic of the
+    //      whole interval [l, 1] (quintic.hpp) would grow by 8.5, then 4.26 per step - but it equioscillates: it sends
+    //      eigenvalues from the top of the spectrum down to the level of the smallest one, where rounding mixes their
+    //      eigenvectors with the other side of zero (measured: A to 5e-11 instead of 3e-13 at 500 x 200, rank 45);
+    //  (b) the minimax quintics of [0.70, 1.13] and of its image: two steps to ~1e-7.
+    if (small && !dev_is(DEV_NO_QUINTIC, '1')) {
+        auto quintic_step = [&](double a, double b, double c) -> int {
+            TLSQ_TRY(small_mm(h, cur, cur, f1, N, 1.0, 0.0, true));          // S
+            TLSQ_TRY(small_mm(h, f1, f1, f2, N, c, a, true, f1, b));         // T
+            TLSQ_TRY(small_mm(h, cur, f2, f1, N, 1.0, 0.0, true));           // X T
+            std::swap(cur, f1);
+            ++it;
+            return TLSQ_OK;
+        };
+        double l = std::min(std::max(1e-3 / nrm, 1e-14), 0.25);
+        const bool minimax_all = dev_is(DEV_NO_QUINTIC, 'm');   // (experiment: the equioscillating schedule from the start)
+        double u = 1.0;
+        if (!minimax_all) {
+            const double ga = 3.4445, gb = -4.7750, gc = 2.0315;
+            while (l < 0.22 && it < max_iters) {
+                TLSQ_TRY(quintic_step(ga, gb, gc));
+                l = l * (ga + l * l * (gb + gc * l * l));
+            }
+            l = 0.70;
+            u = 1.135;
+        }
+        for (int s = 0; s < 24 && it < max_iters; ++s) {
+            OddQuintic p;
+            if (!odd_quintic(l, u, &p)) break;
+            TLSQ_TRY(quintic_step(p.a, p.b, p.c));
+            l = 1.0 - p.E;
+            u = 1.0 + p.E;
+            if (p.E < 1e-3) break;
+        }
+        first_test = it + 1;   // (one classical step takes an error of 1e-3 to 1e-6, the tested one to 1e-12)
+    }
+    // ---- phase 2: Newton-Schulz steps X <- X (1.5 I - 0.5 X^2) with convergence tests ----
+    for (; it < max_iters; ++it) {
+        if (extra == 0) break;
+        const bool test_now = extra < 0 && it >= first_test && ((it - first_test) % 3 == 0 || first_test != 6);
+        if (small && !test_now) {
+            TLSQ_TRY(small_mm(h, cur, cur, f1, N, -0.5, 1.5, true));   // 1.5 I - 0.5 X^2 in one launch
         } else {
-            if (small) TLSQ_TRY(small_mm(h, cur, cur, W1, N, 1.0, 0.0, true));
-            else TLSQ_TRY(mf_mul(h, cur, cur, W1, N));        // W1 = X^2
+            if (small) TLSQ_TRY(small_mm(h, cur, cur, f1, N, 1.0, 0.0, true));
+            else TLSQ_TRY(mf_mul(h, cur, cur, f1, N));        // X^2
             if (test_now) {
-                TLSQ_TRY(mf_stats(h, W1, N, st));
+                TLSQ_TRY(mf_stats(h, f1, N, st));
                 if (!std::isfinite(st[0])) return TLSQ_OK;
                 if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
+                if (extra == 0) break;
             }
-            if (extra == 0) {
-                if (cur != X) TLSQ_HIP(h, hipMemcpyAsync(X, cur, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
-                *iters = it;
-                *ok = true;
-                return TLSQ_OK;
-            }
-            TLSQ_TRY(mf_axpbi(h, W1, W1, N, -0.5, 1.5));      // W1 = 1.5 I - 0.5 X^2
+            TLSQ_TRY(mf_axpbi(h, f1, f1, N, -0.5, 1.5));      // 1.5 I - 0.5 X^2
         }
-        if (small) TLSQ_TRY(small_mm(h, cur, W1, nxt, N, 1.0, 0.0, true));
-        else TLSQ_TRY(mf_mul(h, cur, W1, nxt, N));            // X <- X W1
-        double* t = cur;
-        cur = nxt;
-        nxt = t;
+        if (small) TLSQ_TRY(small_mm(h, cur, f1, f2, N, 1.0, 0.0, true));
+        else TLSQ_TRY(mf_mul(h, cur, f1, f2, N));             // X <- X (1.5 I - 0.5 X^2)
+        std::swap(cur, f2);
         if (extra > 0) --extra;
     }
+    if (extra != 0) return TLSQ_OK;
+    if (cur != X) TLSQ_HIP(h, hipMemcpyAsync(X, cur, (size_t)N * N * 8, hipMemcpyDeviceToDevice, h->stream));
+    *iters = it;
+    *ok = true;
     return TLSQ_OK;
 }
 
@@ -295,9 +343,36 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
     //  iterates change buffers instead of being copied back - against nine through the tiled GEMM)
     const bool small = N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1') && !dev_is(DEV_MATFUN_SYM, '1');
     double *Zc = Z, *Yc = Y, *Wc = W;   // current Z, current Y, the free buffer
-    for (int it = 0; it < max_iters; ++it) {
-        const bool test_now = extra < 0 && it >= 3;
-        if (small && !test_now && extra != 0) {
+    int it = 0;
+    int first_test = 3;
+    // ---- phase 1: the coupled iteration with the optimal quintics' even parts ----
+    // M = Z Y carries m = x^2 for x on the sign iteration's path (m_0 = the eigenvalues of B / hi, in [lo / hi, 1]):
+    // T = q(M) = a I + b M + c M^2,  Y <- Y T,  Z <- T Z  gives  m <- m q(m)^2 = p(sqrt(m))^2  for the odd quintic
+    // p(x) = x q(x^2) - four products per step, and the smallest eigenvalue grows by a^2 ~ 18 - 72 instead of 2.25 for three.
+    // The caller's B has no eigenvalue below 1 (B = P G2 mu^2 P + I - P): the schedule is made for x in [1 / sqrt(hi), 1].
+    if (small && !dev_is(DEV_NO_QUINTIC, '1') && hi >= 4.0) {
+        double l = std::min(std::max(0.9 / std::sqrt(hi), 1e-7), 0.5), u = 1.0;
+        for (int s = 0; s < 24 && it < max_iters; ++s) {
+            OddQuintic p;
+            if (!odd_quintic(l, u, &p)) break;
+            TLSQ_TRY(small_mm(h, Zc, Yc, T, N, 1.0, 0.0, false));                // M = Z Y
+            TLSQ_TRY(small_mm(h, T, T, Wc, N, p.c, p.a, false, T, p.b));         // q(M) = c M^2 + b M + a I
+            TLSQ_TRY(small_mm(h, Yc, Wc, T, N, 1.0, 0.0, false));                // Y q(M)
+            std::swap(Yc, T);
+            TLSQ_TRY(small_mm(h, Wc, Zc, T, N, 1.0, 0.0, false));                // q(M) Z
+            std::swap(Zc, T);
+            ++it;
+            l = 1.0 - p.E;
+            u = 1.0 + p.E;
+            if (p.E < 1e-3) break;
+        }
+        first_test = it + 2;
+    }
+    // ---- phase 2: coupled Newton-Schulz steps with convergence tests ----
+    for (; it < max_iters; ++it) {
+        if (extra == 0) break;
+        const bool test_now = extra < 0 && it >= first_test;
+        if (small && !test_now) {
             TLSQ_TRY(small_mm(h, Zc, Yc, T, N, -0.5, 1.5, false));   // T = 1.5 I - 0.5 Z Y
         } else {
             if (small) TLSQ_TRY(small_mm(h, Zc, Yc, T, N, 1.0, 0.0, false));
@@ -306,12 +381,7 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
                 TLSQ_TRY(mf_stats(h, T, N, st));
                 if (!std::isfinite(st[0])) return TLSQ_OK;
                 if (st[0] <= 1e-8) extra = st[0] <= 1e-24 ? 0 : (st[0] <= 1e-16 ? 1 : 2);
-            }
-            if (extra == 0) {
-                TLSQ_TRY(mf_axpbi(h, Zc, Z, N, 1.0 / std::sqrt(hi), 0.0));   // (into the caller's buffer, wherever the iterate sits)
-                *iters = it;
-                *ok = true;
-                return TLSQ_OK;
+                if (extra == 0) break;
             }
             TLSQ_TRY(mf_axpbi(h, T, T, N, -0.5, 1.5));        // T = 1.5 I - 0.5 Z Y
         }
@@ -328,6 +398,10 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
         }
         if (extra > 0) --extra;
     }
+    if (extra != 0) return TLSQ_OK;
+    TLSQ_TRY(mf_axpbi(h, Zc, Z, N, 1.0 / std::sqrt(hi), 0.0));   // (into the caller's buffer, wherever the iterate sits)
+    *iters = it;
+    *ok = true;
     return TLSQ_OK;
 }
 

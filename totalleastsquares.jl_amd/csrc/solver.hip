@@ -1735,6 +1735,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                                  N >= 64 && N <= 1024;
     bool last_no_factors = false, prev_no_factors = false;   // A_k / A_{k-1} exist only as panels (E-free loop: how E is formed)
     int64_t mf_rS_prev = -1;   // size of the deflated set of the last matrix-function iteration (-1: none yet)
+    int64_t mf_k2_last = 0;    // how many values below the dominant set it counted above the threshold
+    int mf_dfl_level = 0;      // 1: the dominant set is taken at 1e5 / mu^2 from now on (see matfun_route)
     auto matfun_route = [&](const T* Zp, double inv_mu_, int64_t* svp_out, double* sigma_top_out, bool* ok) -> int {
         *ok = false;
         const bool dbg = dev_get(DEV_DEBUG) != nullptr;
@@ -1760,41 +1762,69 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         sub.noise_rel = 0.0;
         sub.skip_certificate = true;
         sub.defer_certificate = false;
-        const int st_sub = svd_subspace(h, gop, N, inv_mu_ * std::sqrt(1e3), sub, &X, ss, &sweeps, &got);
-        sub.skip_certificate = false;
-        if (st_sub < 0) return st_sub;
-        if (!got || !X || ss.ncols <= 0) return TLSQ_OK;
-        const double stop = ss.sigma[ss.order[0]];
-        const double dl = noise_rel * stop * stop;
+        // How far above the threshold a pair has to be to count as dominant: 1e3 / mu^2, and 1e5 / mu^2 once that level stops
+        // working (TLSQ_MATFUN_DEFL fixes it).  What stays below goes into B, whose condition number the inverse square root
+        // pays for with eps * cond(B) of its accuracy - its residual is checked below.  1e3 alone handed the last iterations
+        // of a noisy problem to the TSQR route as soon as the top of the noise bulk had grown past 1e3 / mu^2 - hundreds of
+        // pairs that no block holds: 3 of 35 iterations and half of the run time at 20000 x 512 with noise 1e-2 (110 -> 65
+        // ms).  1e7 fails the residual test; 1e5 from the start costs clean data a digit (A to 5e-11 instead of 1e-11).
+        const double dfl_env = [] { const char* e = dev_get(DEV_MATFUN_DEFL); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 0.0; }();
+        const double cond_base = [] { const char* e = dev_get(DEV_MATFUN_COND); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1e4; }();
         std::vector<int32_t> sel;
         std::vector<double> gw;
-        // S = the leading Ritz pairs, cut where the spectrum has a gap.  Mixing inside S is harmless (nearly equal weights g);
-        // what must be small is the leak between span(S) and the rest: the solver's residual bound is 2e-13 lambda_top in
-        // absolute terms, so the angle is <= 2e-13 lambda_top / gap, and the error it puts into A is sigma times that - kept
-        // below 1e-10 sigma_top by asking for gap >= 2e-3 sqrt(lambda_top theta) at the cut.  Signal values pass; a noise
-        // value that has grown past 1e3 / mu^2 sits in a cluster of its like and is left to G2, where clusters do not matter.
-        int64_t cnt = 0;
-        while (cnt < ss.ncols && cnt < 32) {
-            const double sg = ss.sigma[ss.order[cnt]];
-            if (!(sg * sg >= std::max(1e3 * tau2, tau2 + 2.0 * dl))) break;
-            ++cnt;
+        double stop = 0.0;
+        int64_t rS = 0;
+        bool have_S = false;
+        for (int level = (dfl_env > 0.0 || mf_dfl_level > 0) ? 1 : 0; level < 2 && !have_S; ++level) {
+            const double dfl = dfl_env > 0.0 ? dfl_env : (level == 0 ? 1e3 : 1e5);
+            sub.skip_certificate = true;
+            got = false;
+            const int st_sub = svd_subspace(h, gop, N, inv_mu_ * std::sqrt(dfl), sub, &X, ss, &sweeps, &got);
+            sub.skip_certificate = false;
+            if (st_sub < 0) return st_sub;
+            if (!got || !X || ss.ncols <= 0) {
+                if (dbg) fprintf(stderr, "  matrix-function route: no dominant block at %.0e / mu^2 (subspace solver: %d)\n", dfl, sub.fail);
+                continue;
+            }
+            stop = ss.sigma[ss.order[0]];
+            const double dl = noise_rel * stop * stop;
+            // S = the leading Ritz pairs, cut where the spectrum has a gap.  Mixing inside S is harmless (nearly equal weights g);
+            // what must be small is the leak between span(S) and the rest: the solver's residual bound is 2e-13 lambda_top in
+            // absolute terms, so the angle is <= 2e-13 lambda_top / gap, and the error it puts into A is sigma times that - kept
+            // below 1e-10 sigma_top by asking for gap >= 2e-3 sqrt(lambda_top theta) at the cut.  Signal values pass; a noise
+            // value that has grown past the level sits in a cluster of its like and is left to G2, where clusters do not matter.
+            int64_t cnt = 0;
+            while (cnt < ss.ncols && cnt < 32) {
+                const double sg = ss.sigma[ss.order[cnt]];
+                if (!(sg * sg >= std::max(dfl * tau2, tau2 + 2.0 * dl))) break;
+                ++cnt;
+            }
+            while (cnt > 0) {
+                const double sg = ss.sigma[ss.order[cnt - 1]];
+                const double sg1 = cnt < ss.ncols ? ss.sigma[ss.order[cnt]] : 0.0;
+                if (sg * sg - sg1 * sg1 >= 2e-3 * stop * sg) break;
+                --cnt;
+            }
+            // What stays in G2 has to be (a) small enough for G2's own rounding to sit far below the threshold and (b) within
+            // 10 x the level of the threshold: the inverse square root loses eps * cond(B) of its relative accuracy.
+            const double next = cnt < ss.ncols ? ss.sigma[ss.order[cnt]] : 0.0;
+            const double cond_max = cond_base * (dfl / 1e3);
+            if (!(noise_rel * next * next < 1e-4 * tau2) || !(next * next <= cond_max * tau2)) {
+                if (dbg) fprintf(stderr, "  matrix-function route: declined at %.0e / mu^2 (next^2 mu^2 = %.2e, noise %.2e)\n", dfl, next * next / tau2, noise_rel * next * next / tau2);
+                continue;
+            }
+            sel.clear();
+            gw.clear();
+            for (int64_t i = 0; i < cnt; ++i) {
+                const double sg = ss.sigma[ss.order[i]];
+                sel.push_back(ss.order[i]);
+                gw.push_back(ro.nukeA ? (sg - inv_mu_) / sg : 1.0);   // :205-213
+            }
+            rS = cnt;
+            have_S = true;
+            if (level == 1) mf_dfl_level = 1;   // (the bulk only grows against the threshold: later iterations start here)
         }
-        while (cnt > 0) {
-            const double sg = ss.sigma[ss.order[cnt - 1]];
-            const double sg1 = cnt < ss.ncols ? ss.sigma[ss.order[cnt]] : 0.0;
-            if (sg * sg - sg1 * sg1 >= 2e-3 * stop * sg) break;
-            --cnt;
-        }
-        for (int64_t i = 0; i < cnt; ++i) {
-            const double sg = ss.sigma[ss.order[i]];
-            sel.push_back(ss.order[i]);
-            gw.push_back(ro.nukeA ? (sg - inv_mu_) / sg : 1.0);   // :205-213
-        }
-        const int64_t rS = (int64_t)sel.size();
-        // What stays in G2 has to be (a) small enough for G2's own rounding to sit far below the threshold and (b) within
-        // 1e4 of the threshold: the inverse square root loses eps * cond(B) of its relative accuracy.
-        const double next = rS < ss.ncols ? ss.sigma[ss.order[rS]] : 0.0;
-        if (!(noise_rel * next * next < 1e-4 * tau2) || !(next * next <= 1e4 * tau2)) return TLSQ_OK;
+        if (!have_S) return TLSQ_OK;
         const T* Z2 = Zp;
         if (rS > 0) {
             std::vector<double> ones((size_t)rS, 1.0);
@@ -1896,6 +1926,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         *sigma_top_out = stop;
         *ok = true;
         mf_rS_prev = rS;
+        mf_k2_last = k2;
         if (dbg)
             fprintf(stderr, "  matrix-function route: |S|=%lld + trace(P)=%lld, sign %d steps, inverse sqrt %d steps\n", (long long)rS,
                     (long long)k2, it_s, it_r);
@@ -2290,6 +2321,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 }
                 r_route = false;
                 matfun_done = true;
+                // values of the bulk have crossed the threshold: the subspace solver has no gap to work with until a complete
+                // decomposition says otherwise - the next iterations come straight here instead of growing its block first
+                // (noise 1e-3 at 20000 x 512: 90 -> 48 subspace steps, 107 -> 50 ms)
+                if (mf_k2_last > 0) bulk_tail = true;
                 svp = svp_m;                                               // :198
                 sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
                 sigma_top = stop_m;
