@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_mf_axpbi(const double* X, double* Y, in
 // symmetric (commuting iterates): only the tiles on and below the diagonal are computed, every entry pair written by one thread.
 // (layout of the accumulator of v_mfma_f64_16x16x4_f64: lane l, register q hold D[4 q + (l >> 4)][l & 15].)
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
-template <bool SYM>
+template <bool SYM, bool FULL>
 __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
                                                    int N, int nt, double alpha, double beta, const double* __restrict__ Add,
                                                    double gamma) {
@@ -65,6 +65,78 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
     mf_d4 acc = mf_d4{0.0, 0.0, 0.0, 0.0};
     const int kper = ((N + 3) / 4 + 3) / 4 * 4;   // inner indices per K-quarter, a multiple of 4
     const int kbeg = kq * kper, kend = (kbeg + kper < N) ? kbeg + kper : N;
+    if (FULL) {
+        // N a multiple of 128: every tile and every K-quarter is whole (no predicates: the guarded form compiles to a branch per
+        // load and one s_waitcnt vmcnt(0) in front of eight dependent MFMAs).  Two rounds of 16 loads are in flight, the MFMAs
+        // alternate between two accumulators.
+        mf_d4 acc2 = mf_d4{0.0, 0.0, 0.0, 0.0};
+        double a[8], b[8];
+        const int rounds = (kend - kbeg) / 32;
+        if (SYM) {
+            // element offsets in 32 bits (N <= 2048): one address register per load on top of the uniform base
+            const unsigned int sa = 4u * (unsigned int)N;
+            unsigned int oa = (unsigned int)gi + (unsigned int)(kbeg + fk) * (unsigned int)N;
+            unsigned int ob = (unsigned int)gj + (unsigned int)(kbeg + fk) * (unsigned int)N;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = A[oa + u * sa];
+                b[u] = B[ob + u * sa];
+            }
+            for (int r = 0; r + 1 < rounds; ++r) {
+                oa += 8u * sa;
+                ob += 8u * sa;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+                    // (the slot is free again: the next round's pair goes out behind the MFMA that used it - no branch here, the
+                    //  compiler's s_waitcnt bookkeeping gives up across one)
+                    a[u] = A[oa + u * sa];
+                    b[u] = B[ob + u * sa];
+                }
+            }
+        } else {
+            // B[k, j] as it stands: column j is contiguous in k.  MFMA u of a round takes the inner index
+            //     k = 8 (u >> 1) + 2 fk + (u & 1)
+            // (a permutation of the round's 32 indices, the same for both operands), so that a lane's pair (u, u + 1) is ONE
+            // 16-byte load and the four fk-lanes of a column read 64 contiguous bytes per instruction: 64 line visits per round
+            // for B instead of 128 with one 8-byte load per MFMA (measured: 20.7 -> 14.3 us at N = 512; the kernel is bound by
+            // line visits in the vector memory pipe: ~4.7 us + 0.1 us per visit of a wave's round).
+            typedef double mf_d2 __attribute__((ext_vector_type(2)));
+            const unsigned int n = (unsigned int)N;
+            unsigned int oa = (unsigned int)gi + (unsigned int)(kbeg + 2 * fk) * n;
+            unsigned int ob = (unsigned int)gj * n + (unsigned int)(kbeg + 2 * fk);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const mf_d2 v = *reinterpret_cast<const mf_d2*>(B + ob + 8u * t);
+                b[2 * t] = v[0];
+                b[2 * t + 1] = v[1];
+                a[2 * t] = A[oa + (8u * t) * n];
+                a[2 * t + 1] = A[oa + (8u * t + 1u) * n];
+            }
+            for (int r = 0; r + 1 < rounds; ++r) {
+                oa += 32u * n;
+                ob += 32u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * t], b[2 * t], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * t + 1], b[2 * t + 1], acc2, 0, 0, 0);
+                    const mf_d2 v = *reinterpret_cast<const mf_d2*>(B + ob + 8u * t);
+                    b[2 * t] = v[0];
+                    b[2 * t + 1] = v[1];
+                    a[2 * t] = A[oa + (8u * t) * n];
+                    a[2 * t + 1] = A[oa + (8u * t + 1u) * n];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {   // last round: nothing left to fetch
+            if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
+    } else {
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         double a[8], b[8];
 #pragma unroll
@@ -76,6 +148,7 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q];
@@ -107,10 +180,12 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
 static int small_mm(Handle* h, const double* A, const double* B, double* C, int64_t N, double alpha, double beta, bool sym_out,
                     const double* Add = nullptr, double gamma = 0.0) {
     const int nt = (int)((N + 31) / 32);
-    if (sym_out)
-        hipLaunchKernelGGL(k_small_mm<true>, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
-    else
-        hipLaunchKernelGGL(k_small_mm<false>, dim3((unsigned)(nt * nt)), dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+    const bool full = (N % 128) == 0;
+    const dim3 gs((unsigned)(nt * (nt + 1) / 2)), gg((unsigned)(nt * nt));
+    if (sym_out && full) hipLaunchKernelGGL((k_small_mm<true, true>), gs, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+    else if (sym_out) hipLaunchKernelGGL((k_small_mm<true, false>), gs, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+    else if (full) hipLaunchKernelGGL((k_small_mm<false, true>), gg, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+    else hipLaunchKernelGGL((k_small_mm<false, false>), gg, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
