@@ -1086,6 +1086,32 @@ def test_fuzz_parity(eng):
     assert worst < 1e-8
 
 
+def test_value_within_rounding_of_the_threshold_is_not_counted_by_the_sign_iteration(eng):
+    """Case 199 of `tools/fuzz_parity.py 0` (300 x 64, rank 16, noise 1e-6, 60 iterations without `nukeA`): at k = 49 a singular
+    value lies 1e-12 from 1/mu.  Newton-Schulz alone cannot separate it within its step budget and the iteration goes to the
+    TSQR route; the quintic sign iteration grows small eigenvalues 3.44x per step and used to "converge" - on the wrong side
+    (count 55 instead of 56, A off by 1e-7).  The growth of the smallest resolvable eigenvalue is bounded now, not the step count."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from oracle import rpca_oracle as O
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        D, kw, desc = fz.make_case(rng)
+    assert desc.startswith("300x64 r=16 noise=1e-06"), desc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, E, s, sv, rep = eng.rpca(D, return_report=True, **kw)
+        Ao, Eo, so, svo, io = O.rpca(D, **kw)
+    assert rep.svp_hist == io.svp_hist and sv == svo
+    dn = np.linalg.norm(D)                     # (no sparse part: E is noise-sized, errors are measured against D as in the fuzz tool)
+    assert np.linalg.norm(A - Ao) / dn < 1e-9 and np.linalg.norm(E - Eo) / dn < 1e-9
+    assert 1 <= rep.tsqr_iterations <= 3, rep.tsqr_iterations
+
+
 def test_long_run_converges_like_the_reference(eng):
     """A case that needs 39 iterations (1/mu ends at ~2e-7 ||D||_2): without the two-level decomposition the
     plain Gram route miscounts singular values near the threshold and never converges."""

@@ -331,6 +331,13 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
     const bool small = N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1');   // (k_small_mm: no slabs, the element-wise step in the epilogue)
     int it = 0;
     int first_test = 6;   // the convergence test costs a host round trip: not before the linear phase can be over
+    // How close to zero an eigenvalue of X_0 may lie and still be given a sign: `max_iters` Newton-Schulz steps multiply it by
+    // 1.5^max_iters at most (70 steps: 2e12) - anything closer does not converge and the caller decides by other means (an
+    // eigenvalue within rounding of the threshold must not be counted by its rounding error).  The quintics grow 3.44 per step:
+    // the same bound is kept on the product of the slopes at zero, not on the step count (tools/fuzz_parity.py 0, case 199:
+    // 300 x 64, a value 1e-12 from the threshold "converged" in 36 steps and was counted on the wrong side).
+    const double growth_cap = std::pow(1.5, (double)max_iters);
+    double growth = 1.0;
     // ---- phase 1: odd quintics ----
     // The spectrum of X_0 lies in [-1, 1]; what is known about its distance from zero is the cluster at -1 / nrm (the null
     // directions of the deflated panel, C = -I there) - and that a noise bulk crosses the threshold with a few hundred
@@ -350,6 +357,7 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
             TLSQ_TRY(small_mm(h, cur, f2, f1, N, 1.0, 0.0, true));           // X T
             std::swap(cur, f1);
             ++it;
+            growth *= a;
             return TLSQ_OK;
         };
         double l = std::min(std::max(1e-3 / nrm, 1e-14), 0.25);
@@ -377,6 +385,8 @@ int matfun_sign(Handle* h, const double* C, int64_t N, double* X, double* W1, do
     // ---- phase 2: Newton-Schulz steps X <- X (1.5 I - 0.5 X^2) with convergence tests ----
     for (; it < max_iters; ++it) {
         if (extra == 0) break;
+        if (extra < 0 && growth * 1.5 > growth_cap) break;   // (too close to zero to call: not converged)
+        growth *= 1.5;
         const bool test_now = extra < 0 && it >= first_test && ((it - first_test) % 3 == 0 || first_test != 6);
         if (small && !test_now) {
             TLSQ_TRY(small_mm(h, cur, cur, f1, N, -0.5, 1.5, true));   // 1.5 I - 0.5 X^2 in one launch
