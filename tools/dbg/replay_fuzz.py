@@ -11,6 +11,10 @@ import tlsq_amd
 import fuzz_parity as F
 from oracle import rpca_oracle as O
 warnings.simplefilter("ignore")
+big = "--big" in sys.argv
+if big:
+    sys.argv.remove("--big")
+    F.BIG = True
 seed, case = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 for it in range(case + 1):
