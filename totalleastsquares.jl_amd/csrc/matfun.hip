@@ -174,6 +174,114 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
     }
 }
 
+// The same product with register blocking, N a multiple of 128 (the sizes the noisy route runs at): 8 waves per 32 x 32 tile,
+// every wave owns ALL FOUR 16 x 16 sub-tiles over one eighth of the inner index.  k_small_mm is bound by line visits in the vector
+// memory pipe (one operand fragment = 4 lines, two fragments per MFMA: 8 visits per MFMA); here two A and two B fragments feed
+// four MFMAs (4 visits per MFMA), four independent accumulators.  Rounds of 16 inner indices, the next round's fragments fetched
+// behind the MFMAs that freed their registers.  General product: B[k, j] read as in k_small_mm<false, true> (one 16-byte load
+// per pair of inner indices, the round's indices permuted for both operands).
+template <bool SYM>
+__global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__ A, const double* __restrict__ B,
+                                                      double* __restrict__ C, int N, int nt, double alpha, double beta,
+                                                      const double* __restrict__ Add, double gamma) {
+    __shared__ double sR[8 * 1024];
+    typedef double mf_d2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    int ti, tj;
+    if (SYM) {
+        const int t = blockIdx.x;
+        ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x % nt;
+        tj = blockIdx.x / nt;
+    }
+    const unsigned int n = (unsigned int)N;
+    const int kper = N / 8, kbeg = w * kper, rounds = kper / 16;
+    mf_d4 acc00 = mf_d4{0.0, 0.0, 0.0, 0.0}, acc10 = acc00, acc01 = acc00, acc11 = acc00;   // acc<ih><jh>
+    double a0[4], a1[4], b0[4], b1[4];
+    // inner index of MFMA u of a round: SYM 4 u + fk; general 8 (u >> 1) + 2 fk + (u & 1)
+    unsigned int oa = (unsigned int)(ti * 32 + fr) + (unsigned int)(kbeg + (SYM ? fk : 2 * fk)) * n;
+    unsigned int ob = SYM ? (unsigned int)(tj * 32 + fr) + (unsigned int)(kbeg + fk) * n
+                          : (unsigned int)(tj * 32 + fr) * n + (unsigned int)(kbeg + 2 * fk);
+    auto fetch = [&](int u) {
+        const unsigned int ka = SYM ? 4u * (unsigned int)u : 8u * (unsigned int)(u >> 1) + (unsigned int)(u & 1);
+        a0[u] = A[oa + ka * n];
+        a1[u] = A[oa + ka * n + 16u];
+        if (SYM) {
+            b0[u] = B[ob + ka * n];
+            b1[u] = B[ob + ka * n + 16u];
+        } else if ((u & 1) == 0) {
+            const mf_d2 v0 = *reinterpret_cast<const mf_d2*>(B + ob + 8u * (unsigned int)(u >> 1));
+            const mf_d2 v1 = *reinterpret_cast<const mf_d2*>(B + ob + 16u * n + 8u * (unsigned int)(u >> 1));
+            b0[u] = v0[0];
+            b0[u + 1] = v0[1];
+            b1[u] = v1[0];
+            b1[u + 1] = v1[1];
+        }
+    };
+    auto fma4 = [&](int u) {
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc10, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc01, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc11, 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(u);
+    for (int r = 0; r + 1 < rounds; ++r) {
+        oa += 16u * n;
+        ob += SYM ? 16u * n : 16u;
+        if (SYM) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fma4(u);
+                fetch(u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {   // (a B pair serves two MFMA groups: refilled once both are through)
+                fma4(u);
+                fma4(u + 1);
+                fetch(u);
+                fetch(u + 1);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fma4(u);
+    // sub-tile s = ih + 2 jh, as in k_small_mm
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sR[w * 1024 + 0 * 256 + q * 64 + lane] = acc00[q];
+        sR[w * 1024 + 1 * 256 + q * 64 + lane] = acc10[q];
+        sR[w * 1024 + 2 * 256 + q * 64 + lane] = acc01[q];
+        sR[w * 1024 + 3 * 256 + q * 64 + lane] = acc11[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = tid + 512 * half;   // entry (sub2, q2, l2) of the tile: D[4 q2 + (l2 >> 4)][l2 & 15] of sub-tile sub2
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) v += sR[ww * 1024 + e];   // the eight slices in order
+        const int sub2 = e >> 8, q2 = (e >> 6) & 3, l2 = e & 63;
+        const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
+        double out = alpha * v + (i == j ? beta : 0.0);
+        if (Add) out += gamma * Add[i + (int64_t)j * N];
+        if (SYM) {
+            if (ti != tj || j <= i) {   // diagonal tile: (i, j) and (j, i) are both computed here - the lower one is kept
+                C[i + (int64_t)j * N] = out;
+                C[j + (int64_t)i * N] = out;
+            }
+        } else {
+            C[i + (int64_t)j * N] = out;
+        }
+    }
+}
+
 // C = alpha A B + beta I (N <= 2048; C must not alias A or B).  sym_out: A, B symmetric and commuting - the result is symmetric,
 // lower tiles + mirror; otherwise a general product (A(i, k), B(k, j) as they stand)
 // (+ gamma Add with Add != nullptr: one more N x N term in the epilogue; Add may be A or B)
@@ -182,6 +290,12 @@ static int small_mm(Handle* h, const double* A, const double* B, double* C, int6
     const int nt = (int)((N + 31) / 32);
     const bool full = (N % 128) == 0;
     const dim3 gs((unsigned)(nt * (nt + 1) / 2)), gg((unsigned)(nt * nt));
+    if (full && !dev_is(DEV_NO_SMALL_MM, 'b')) {   // (NO_SMALL_MM=b: the unblocked whole-tile kernels)
+        if (sym_out) hipLaunchKernelGGL((k_small_mm_blk<true>), gs, dim3(512), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+        else hipLaunchKernelGGL((k_small_mm_blk<false>), gg, dim3(512), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
+        TLSQ_HIP(h, hipGetLastError());
+        return TLSQ_OK;
+    }
     if (sym_out && full) hipLaunchKernelGGL((k_small_mm<true, true>), gs, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
     else if (sym_out) hipLaunchKernelGGL((k_small_mm<true, false>), gs, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
     else if (full) hipLaunchKernelGGL((k_small_mm<false, true>), gg, dim3(1024), 0, h->stream, A, B, C, (int)N, nt, alpha, beta, Add, gamma);
