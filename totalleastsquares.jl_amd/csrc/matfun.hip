@@ -604,6 +604,42 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
     return TLSQ_OK;
 }
 
+// S = G / trace(G) for a symmetric positive semi-definite G (eigenvalues of S in [0, 1], the largest >= 1 / N): the trace in a
+// fixed order by every workgroup itself, no host round trip
+__global__ __launch_bounds__(256) void k_mf_scale_by_trace(const double* __restrict__ G, double* __restrict__ S, int N) {
+    __shared__ double red[4];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) t += G[(size_t)i * N + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    const double tr = (red[0] + red[1]) + (red[2] + red[3]);
+    const double sc = tr > 0.0 ? 1.0 / tr : 0.0;
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) S[e] = G[e] * sc;
+}
+
+// (G / trace G)^(2^levels) by repeated squaring through k_small_mm (P1, P2: N x N scratch; *out = the buffer the result is in).
+// Without rescaling between the squarings: the dominant eigenvalue of G / trace G is at least 1 / N, so five squarings of an
+// N <= 1024 matrix stay above 1e-97.  false in *ok: N is not one of the sizes k_small_mm_blk serves - the caller keeps its own form.
+int matfun_power_start(Handle* h, const double* G, int64_t N, double* P1, double* P2, int levels, const double** out, bool* ok) {
+    *ok = false;
+    if ((N % 128) != 0 || N > 1024 || levels < 1 || levels > 5 || dev_is(DEV_NO_SMALL_MM, '1')) return TLSQ_OK;
+    int64_t g = (N * N + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_mf_scale_by_trace, dim3((int)g), dim3(256), 0, h->stream, G, P1, (int)N);
+    TLSQ_HIP(h, hipGetLastError());
+    double *src = P1, *dst = P2;
+    for (int k = 0; k < levels; ++k) {
+        TLSQ_TRY(small_mm(h, src, src, dst, N, 1.0, 0.0, true));
+        std::swap(src, dst);
+    }
+    *out = src;
+    *ok = true;
+    return TLSQ_OK;
+}
+
 int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf) {
     double st[3];
     TLSQ_TRY(mf_stats(h, X, N, st));

@@ -37,13 +37,19 @@ static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_t
         TLSQ_TRY(ws_get(h, WS_CPART, (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * 8, &part));   // (norm partials: one per 32 x 32 block of the lower triangle)
         TLSQ_TRY(ws_get(h, WS_PW, (8 + 3 * (size_t)N + 2 * 1024) * 8, &vst));   // (same size as power_lower_bound asks for)
         const double* src = G;
-        double* dst = (double*)P1;
-        for (int k = 0; k < 5; ++k) {
-            int nb = 0;
-            TLSQ_TRY(gemm_mixed(h, true, true, src, 0, N, src, 0, N, dst, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
-            TLSQ_TRY(launch_scale_by_norm(h, dst, N, (const double*)part, nb));
-            src = dst;
-            dst = (dst == (double*)P1) ? (double*)P2 : (double*)P1;
+        bool quick = false;
+        // (N a multiple of 128: one scaling by the trace and five slab-free products, 8 us each at N = 512, instead of five
+        //  split-K products + slab reductions + rescalings, 26 us each)
+        TLSQ_TRY(matfun_power_start(h, G, N, (double*)P1, (double*)P2, 5, &src, &quick));
+        if (!quick) {
+            double* dst = (double*)P1;
+            for (int k = 0; k < 5; ++k) {
+                int nb = 0;
+                TLSQ_TRY(gemm_mixed(h, true, true, src, 0, N, src, 0, N, dst, 0, N, N, N, N, true, nullptr, (double*)part, &nb));
+                TLSQ_TRY(launch_scale_by_norm(h, dst, N, (const double*)part, nb));
+                src = dst;
+                dst = (dst == (double*)P1) ? (double*)P2 : (double*)P1;
+            }
         }
         TLSQ_TRY(launch_dominant_column(h, src, N, (double*)vst + 8));
         v0 = (const double*)vst + 8;
