@@ -180,15 +180,14 @@ __global__ __launch_bounds__(1024) void k_small_mm(const double* __restrict__ A,
 // four MFMAs (4 visits per MFMA), four independent accumulators.  Rounds of 16 inner indices, the next round's fragments fetched
 // behind the MFMAs that freed their registers.  General product: B[k, j] read as in k_small_mm<false, true> (one 16-byte load
 // per pair of inner indices, the round's indices permuted for both operands).
+// (the tile's 1024 entries, K-slices added in order: thread tid returns entries tid and tid + 512 in v[0], v[1]; entry e =
+//  (sub2, q2, l2) is D[4 q2 + (l2 >> 4)][l2 & 15] of sub-tile sub2 = ih + 2 jh)
 template <bool SYM>
-__global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__ A, const double* __restrict__ B,
-                                                      double* __restrict__ C, int N, int nt, double alpha, double beta,
-                                                      const double* __restrict__ Add, double gamma) {
-    __shared__ double sR[8 * 1024];
+__device__ __forceinline__ void smm_blk_tile(const double* __restrict__ A, const double* __restrict__ B, int N, int nt,
+                                             double* sR, int& ti, int& tj, double (&v)[2]) {
     typedef double mf_d2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
-    int ti, tj;
     if (SYM) {
         const int t = blockIdx.x;
         ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -263,13 +262,29 @@ __global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__
     __syncthreads();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        const int e = tid + 512 * half;   // entry (sub2, q2, l2) of the tile: D[4 q2 + (l2 >> 4)][l2 & 15] of sub-tile sub2
-        double v = 0.0;
+        const int e = tid + 512 * half;
+        double acc = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) v += sR[ww * 1024 + e];   // the eight slices in order
+        for (int ww = 0; ww < 8; ++ww) acc += sR[ww * 1024 + e];   // the eight slices in order
+        v[half] = acc;
+    }
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__ A, const double* __restrict__ B,
+                                                      double* __restrict__ C, int N, int nt, double alpha, double beta,
+                                                      const double* __restrict__ Add, double gamma) {
+    __shared__ double sR[8 * 1024];
+    int ti, tj;
+    double v[2];
+    smm_blk_tile<SYM>(A, B, N, nt, sR, ti, tj, v);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = tid + 512 * half;
         const int sub2 = e >> 8, q2 = (e >> 6) & 3, l2 = e & 63;
         const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
-        double out = alpha * v + (i == j ? beta : 0.0);
+        double out = alpha * v[half] + (i == j ? beta : 0.0);
         if (Add) out += gamma * Add[i + (int64_t)j * N];
         if (SYM) {
             if (ti != tj || j <= i) {   // diagonal tile: (i, j) and (j, i) are both computed here - the lower one is kept
@@ -280,6 +295,43 @@ __global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__
             C[i + (int64_t)j * N] = out;
         }
     }
+}
+
+// ||S^2||_F^2 of the symmetric S, tile sums to the host-visible mailbox: k_sq_norm (subspace.hip) on the blocked tile kernel, for
+// N a multiple of 128 - same mailbox layout and ticket protocol (slot 16 + tile, off-diagonal tiles count twice, the workgroup
+// that arrives last publishes the sequence number)
+__global__ __launch_bounds__(512) void k_sq_norm_blk(const double* __restrict__ S, int N, int nt, int ntile, double* mailbox,
+                                                     unsigned int* ticket, double seq) {
+    __shared__ double sR[8 * 1024];
+    __shared__ double red[8];
+    int ti, tj;
+    double v[2];
+    smm_blk_tile<true>(S, S, N, nt, sR, ti, tj, v);
+    double sq = v[0] * v[0] + v[1] * v[1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int q = 0; q < 8; ++q) tot += red[q];
+        volatile double* mb = mailbox;
+        mb[16 + blockIdx.x] = (ti == tj ? 1.0 : 2.0) * tot;
+        __threadfence_system();
+        if (atomicAdd(ticket, 1u) == (unsigned int)(ntile - 1)) {
+            *ticket = 0u;
+            __threadfence_system();
+            mb[0] = seq;
+        }
+    }
+}
+
+bool sq_norm_blk_ok(int64_t N) { return (N % 128) == 0 && N <= 2048 && !dev_is(DEV_NO_SMALL_MM, '1') && !dev_is(DEV_NO_SMALL_MM, 'b'); }
+int launch_sq_norm_blk(Handle* h, const double* S, int64_t N, double* mailbox_dev, unsigned int* ticket, double seq, int ntile) {
+    const int nt = (int)(N / 32);
+    hipLaunchKernelGGL(k_sq_norm_blk, dim3((unsigned)ntile), dim3(512), 0, h->stream, S, (int)N, nt, ntile, mailbox_dev, ticket, seq);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 // C = alpha A B + beta I (N <= 2048; C must not alias A or B).  sym_out: A, B symmetric and commuting - the result is symmetric,

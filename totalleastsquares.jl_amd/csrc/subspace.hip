@@ -762,6 +762,7 @@ int launch_sq_norm(Handle* h, const double* S, int64_t N, double* mailbox_dev, u
     const int nt = (int)((N + 31) / 32);
     const int ntile = nt * (nt + 1) / 2;
     if (ntile_out) *ntile_out = ntile;
+    if (sq_norm_blk_ok(N)) return launch_sq_norm_blk(h, S, N, mailbox_dev, ticket, seq, ntile);   // (matfun.hip: the register-blocked tile kernel)
     hipLaunchKernelGGL(k_sq_norm, dim3((unsigned)ntile), dim3(1024), 0, h->stream, S, (int)N, ntile, mailbox_dev, ticket, seq);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
