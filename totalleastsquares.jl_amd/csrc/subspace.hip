@@ -566,27 +566,36 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ G,
     const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int gi = i0 + fr, gj = j0 + fr;
     const bool iok = gi < N, jok = gj < p;
-    const double* Gr = G + (iok ? gi : 0);
-    const double* Xc = X + (size_t)(jok ? gj : 0) * N;
-    sm_d4 acc = sm_d4{0.0, 0.0, 0.0, 0.0};
+    // (rows / columns beyond the edge read the last valid one instead of being predicated - a guarded load compiles to a branch
+    //  each, 48 of them in front of the MFMAs; what they contribute lands in output entries that are not stored)
+    const double* Gr = G + (iok ? gi : N - 1);
+    const double* Xc = X + (size_t)(jok ? gj : p - 1) * N;
+    sm_d4 acc = sm_d4{0.0, 0.0, 0.0, 0.0}, acc2 = acc;
     const bool vec = (N % 2 == 0);
     for (int c0 = w * 128; c0 < N; c0 += 512) {
         const int kb = c0 + fk * 32;
         double a[32], b[32];
+        if (c0 + 128 <= N && vec) {   // (whole chunk for every lane of the wave - the MFMAs below must not sit in a divergent branch: two accumulators, no predicates)
+#pragma unroll
+            for (int u = 0; u < 32; ++u) a[u] = Gr[(int64_t)(kb + u) * ldG];
+#pragma unroll
+            for (int u = 0; u < 32; u += 2) {
+                const sm_d2 v = *reinterpret_cast<const sm_d2*>(Xc + kb + u);
+                b[u] = v[0];
+                b[u + 1] = v[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], acc2, 0, 0, 0);
+            }
+            continue;
+        }
         if (kb + 32 <= N) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u) a[u] = iok ? Gr[(int64_t)(kb + u) * ldG] : 0.0;
-            if (vec) {
+            for (int u = 0; u < 32; ++u) a[u] = Gr[(int64_t)(kb + u) * ldG];
 #pragma unroll
-                for (int u = 0; u < 32; u += 2) {
-                    const sm_d2 v = jok ? *reinterpret_cast<const sm_d2*>(Xc + kb + u) : sm_d2{0.0, 0.0};
-                    b[u] = v[0];
-                    b[u + 1] = v[1];
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 32; ++u) b[u] = jok ? Xc[kb + u] : 0.0;
-            }
+            for (int u = 0; u < 32; ++u) b[u] = Xc[kb + u];
         } else {
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(256) void k_symm_mfma(const double* __restrict__ G,
         for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q];
+    for (int q = 0; q < 4; ++q) sR[w * 256 + q * 64 + lane] = acc[q] + acc2[q];
     __syncthreads();
     // lane holds column j = lane & 15, rows (lane >> 4) + 4 q of the tile
     const int q = tid >> 6, l = tid & 63;
