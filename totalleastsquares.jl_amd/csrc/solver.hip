@@ -865,6 +865,11 @@ static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, S
             void* scal = h->ws[WS_SCAL].p;
             (void)hipMemcpy(&sd, (char*)scal + 136, 4, hipMemcpyDeviceToHost);
             fprintf(stderr, "  [small eig sweeps %d]", sd);
+            if (rr_fast) {
+                double st8[8];
+                (void)hipMemcpy(st8, stat_dev, 64, hipMemcpyDeviceToHost);
+                fprintf(stderr, " [rr: its %.0f delta %.2e delta_tt %.2e k_tp %.2e blocked %.0f piv %.2e]", st8[3], st8[2], st8[5], st8[6], st8[7], st8[0]);
+            }
         }
         if (dbg)
             fprintf(stderr, "  subspace step %d: p=%lld ntop=%lld svp=%lld maxres/tmax=%.3e tail/tau=%.3f cold=%d\n", step,

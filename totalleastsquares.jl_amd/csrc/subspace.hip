@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void rs_reduce(double& s0, double& s1, double& m0, do
 
 __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg, const double* __restrict__ Hg, int p,
                                                   double* __restrict__ Cout, double* __restrict__ lam_out,
-                                                  double* __restrict__ status, int nt, double tau2) {
+                                                  double* __restrict__ status, int nt, double tau2, int block_ok) {
     // seven 32 x 32 buffers (59 KB): Bh and Hh stay; the others change roles between the factorisation and the refinement
     __shared__ double sBh[RS_P * RS_LD], sH[RS_P * RS_LD], b2[RS_P * RS_LD], b3[RS_P * RS_LD], b4[RS_P * RS_LD];
     __shared__ double b5[RS_P * RS_LD], b6[RS_P * RS_LD];
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
         }
         if (!(fabs(hq[q]) < 1.0e300)) badv = 1.0;
     }
-    double dsum = 0.0, z1 = 0.0, z2 = 0.0, zm = 0.0, zm2 = 0.0;
+    double dsum = 0.0, z1 = 0.0, z2 = 0.0, zm = 0.0, zm2 = 0.0, dtt = 0.0, ktp = 0.0;
     rs_reduce(badv, z1, z2, zm, zm2, red);   // (also orders the writes of sd)
     const double dj = sd[cj];
     double a[4];
@@ -1091,15 +1091,21 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
         hq[q] *= di * dj;
         const double dv = (i == cj) ? 0.0 : a[q];
         dsum += dv * dv;
+        if (i < nt && cj < nt) dtt += dv * dv;
+        if ((i < nt) != (cj < nt) && cin && i < p) ktp = fmax(ktp, fabs(dv));
         sBh[i + cj * RS_LD] = a[q];
         sH[i + cj * RS_LD] = hq[q];
         sV[i + cj * RS_LD] = a[q];
         sZ[i + cj * RS_LD] = (i == cj && i >= p) ? 1.0 : 0.0;   // L (identity in the padding)
     }
-    z1 = z2 = zm = zm2 = 0.0;
-    rs_reduce(dsum, z1, z2, zm, zm2, red);   // (its barriers also order the stores above)
+    z2 = zm2 = 0.0;
+    z1 = dtt;
+    zm = ktp;
+    rs_reduce(dsum, z1, zm, z2, zm2, red);   // (its barriers also order the stores above)
     const double delta = sqrt(dsum);
+    const double delta_tt = sqrt(z1), k_tp = zm;
     int fail = (badv != 0.0 || !(delta < 1.0e300)) ? 1 : 0;
+    bool blocked = false;
     double minpiv = 1.0;
     int oa_its = 0;
     double last_numax = -1.0;
@@ -1111,7 +1117,35 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
         //      before it (wanted columns first: Gram-Schmidt order).  L only has to be good enough to START the refinement
         //      below, which works in the metric Bh itself and removes what is left of the non-orthogonality: pivots down to
         //      1e-4 are accepted (CholeskyQR proper needs a second pass below 0.25). ----
-        for (int k = 0; k < p; ++k) {
+        // Block form (warm blocks a few iterations old: the wanted columns G^q x_i are orthogonal among themselves to 1e-3 ..
+        // 1e-9 once they are normalised, only the pad columns lean on them by O(1)): with Bh = [I K; K' B_pp] up to that
+        // deviation, L = [I 0; K' L_S], L_S L_S' = S = B_pp - K'K - one p x p x p product and a factorisation of the pad block
+        // (4 columns of 20) instead of p dependent column steps.  What the top block really deviates from I is left to the
+        // refinement below, which has to remove deviations of that size from C'Hh C anyway.
+        blocked = block_ok && nt >= 1 && nt < p && delta_tt <= 3e-3;
+        int k0 = 0;
+        if (blocked) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = L.ri(q);
+                sU[i + cj * RS_LD] = (cin && i < nt && cj >= nt) ? a[q] : 0.0;   // K (top rows, pad columns), zero elsewhere
+            }
+            __syncthreads();
+            const sm_d4 kk = rs_mfma<true, false>(sU, sU, L, nk);   // K'K: only its pad-pad block is non-zero
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = L.ri(q);
+                if (cin && i < p && i >= nt && cj >= nt) {
+                    a[q] -= kk[q];
+                    sV[i + cj * RS_LD] = a[q];
+                    sY[i + cj * RS_LD] = a[q];
+                }
+                if (cj < nt) sZ[i + cj * RS_LD] = (i == cj) ? 1.0 : ((i >= nt && i < p) ? a[q] : 0.0);   // [I; K']
+            }
+            __syncthreads();
+            k0 = nt;
+        }
+        for (int k = k0; k < p; ++k) {
             const double* cur = (k & 1) ? sY : sV;
             double* nxt = (k & 1) ? sV : sY;
             const double akk = cur[k + k * RS_LD];
@@ -1148,7 +1182,8 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
         }
         __syncthreads();
         int nst = 0;
-        while ((1 << nst) < p) ++nst;
+        const int nil = blocked ? p - nt + 1 : p;   // (block form: I - L X is non-zero in the pad rows only)
+        while ((1 << nst) < nil) ++nst;
         for (int st = 0; st < nst; ++st) {
             const sm_d4 m = rs_mfma<false, false>(sZ, sT, L, nk);   // L X
 #pragma unroll
@@ -1311,6 +1346,9 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
         status[2] = delta;
         status[3] = (double)oa_its;
         status[4] = last_numax;
+        status[5] = delta_tt;
+        status[6] = k_tp;
+        status[7] = blocked ? 1.0 : 0.0;
     }
 }
 
@@ -1336,7 +1374,7 @@ int launch_rr_small(Handle* h, const double* Y, const double* GY, double* Bm, do
     if (p < 1 || p > RS_P) return set_err(h, TLSQ_ERR_ARG, "rr_small: p = %lld (1 .. %d)", (long long)p, RS_P);
     hipLaunchKernelGGL(k_panel_tn2x, dim3((unsigned)((2 * p * p + 3) / 4)), dim3(256), 0, h->stream, Y, GY, Bm, Hm, (int)N, (int)p);
     hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(256), 0, h->stream, (const double*)Bm, (const double*)Hm, (int)p, Cout, lam,
-                       status, (int)nt, tau2);
+                       status, (int)nt, tau2, dev_is(DEV_NO_RR_BLOCKED, '1') ? 0 : 1);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -1344,7 +1382,8 @@ int launch_rr_small(Handle* h, const double* Y, const double* GY, double* Bm, do
 int launch_rr_small_only(Handle* h, const double* Bm, const double* Hm, double* Cout, double* lam, double* status, int64_t p,
                          int64_t nt, double tau2) {
     if (p < 1 || p > RS_P) return set_err(h, TLSQ_ERR_ARG, "rr_small: p = %lld (1 .. %d)", (long long)p, RS_P);
-    hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(256), 0, h->stream, Bm, Hm, (int)p, Cout, lam, status, (int)nt, tau2);
+    hipLaunchKernelGGL(k_rr_small, dim3(1), dim3(256), 0, h->stream, Bm, Hm, (int)p, Cout, lam, status, (int)nt, tau2,
+                       dev_is(DEV_NO_RR_BLOCKED, '1') ? 0 : 1);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
