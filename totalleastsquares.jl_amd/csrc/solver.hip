@@ -2909,10 +2909,17 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         std::vector<double> hv((size_t)N * N);
         TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        for (int64_t p = 0; p < d; ++p) {
-            const double* col = hv.data() + (size_t)s.order[p] * N;
-            for (int64_t j = 0; j < N; ++j) Vt_host[p + j * ldVt] = col[j];
-        }
+        // Vt[p, j] = V[j, order[p]] in 32 x 32 tiles: the plain double loop writes with a stride of ldVt doubles - one cache line
+        // (and beyond 512 columns one page) per element, 2.9 ms for 512 x 512 in the kernel trace's host gap, against 0.3 ms tiled
+        constexpr int64_t TB = 32;
+        for (int64_t p0 = 0; p0 < d; p0 += TB)
+            for (int64_t j0 = 0; j0 < N; j0 += TB) {
+                const int64_t p1 = std::min(p0 + TB, d), j1 = std::min(j0 + TB, N);
+                for (int64_t p = p0; p < p1; ++p) {
+                    const double* col = hv.data() + (size_t)s.order[p] * N;
+                    for (int64_t j = j0; j < j1; ++j) Vt_host[p + j * ldVt] = col[j];
+                }
+            }
     }
     if (U_dev && V) {
         // U = Z V diag(1/sigma); columns with sigma == 0 are returned as zeros
