@@ -1305,6 +1305,21 @@ def test_matrix_functions_by_newton_schulz(eng, torch_mod, N, gap):
     assert np.abs(X - Xref).max() < 1e-9 * max(1.0, 1e-3 / gap), (its.value, np.abs(X - Xref).max())
     assert abs(np.trace(0.5 * (np.eye(N) + X)) - np.sum(lam > 0)) < 1e-8
     assert its.value <= 12 + int(np.ceil(np.log(N / gap) / np.log(1.5)))
+    # the same through Newton-Schulz steps alone (no quintics) and through the unblocked product kernels: same function, more
+    # steps without the quintics once the nearest eigenvalue is far from the scale of the matrix
+    import tlsq_amd
+    its_ns = ctypes.c_int32(0)
+    dX2 = torch.empty_like(dC)
+    with tlsq_amd.dev_switches(NO_QUINTIC=1):
+        assert eng.lib.tlsq_k_matfun_sign_f64(eng.h, dptr(dC), N, dptr(dX2), ctypes.byref(its_ns)) == 0
+    eng.synchronize()
+    assert np.abs(to_host(dX2) - Xref).max() < 1e-9 * max(1.0, 1e-3 / gap)
+    if gap <= 1e-3:
+        assert its.value < its_ns.value, (its.value, its_ns.value)
+    with tlsq_amd.dev_switches(NO_SMALL_MM="b"):
+        assert eng.lib.tlsq_k_matfun_sign_f64(eng.h, dptr(dC), N, dptr(dX2), ctypes.byref(its_ns)) == 0
+    eng.synchronize()
+    assert its_ns.value == its.value and np.abs(to_host(dX2) - X).max() < 1e-12
     # inverse square root of a positive definite matrix with condition 1e3
     mu = np.concatenate([rng.uniform(1e-3, 1.0, N - 1), [1.0]])
     B = (Q * mu) @ Q.T
