@@ -314,6 +314,7 @@ int matfun_invsqrt(Handle* h, const double* B, int64_t N, double hi, double* Z, 
 int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf);
 bool sq_norm_blk_ok(int64_t N);
 int launch_sq_norm_blk(Handle* h, const double* S, int64_t N, double* mailbox_dev, unsigned int* ticket, double seq, int ntile);
+int matfun_square(Handle* h, const double* A, double* C, int64_t N, bool* ok);   // C = A^2, symmetric A
 int matfun_power_start(Handle* h, const double* G, int64_t N, double* P1, double* P2, int levels, const double** out, bool* ok);   // (G / tr G)^(2^levels)
 int matfun_stats(Handle* h, const double* X, int64_t N, double out[3]);   // { ||X - I||_F^2, trace(X), ||X||_inf } of a symmetric X
 int matfun_axpbi(Handle* h, const double* X, double* Y, int64_t N, double a, double b);   // Y = a X + b I

@@ -692,6 +692,14 @@ int matfun_power_start(Handle* h, const double* G, int64_t N, double* P1, double
     return TLSQ_OK;
 }
 
+// C = A^2 for a symmetric A through k_small_mm (*ok = false: N is not one of its sizes)
+int matfun_square(Handle* h, const double* A, double* C, int64_t N, bool* ok) {
+    *ok = false;
+    if (N > 2048 || dev_is(DEV_NO_SMALL_MM, '1')) return TLSQ_OK;
+    *ok = true;
+    return small_mm(h, A, A, C, N, 1.0, 0.0, true);
+}
+
 int matfun_trace_norm(Handle* h, const double* X, int64_t N, double* trace, double* norm_inf) {
     double st[3];
     TLSQ_TRY(mf_stats(h, X, N, st));

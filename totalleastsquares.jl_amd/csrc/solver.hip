@@ -408,6 +408,54 @@ static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out
     const size_t pslots = (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2);
     TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P[0]));
     if (levels >= 2) TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P[1]));
+    // N a multiple of 128 (round 4): squarings through k_small_mm_blk (8 us instead of ~30 through the split-K product), the norm
+    // of S^(2^l) from k_sq_norm_blk applied to S^(2^(l-1)) - tile sums to the certificate's mailbox region, added in tile order
+    {
+        const int64_t ntl = (N + 31) / 32;
+        const size_t need = (size_t)(kCertMailboxOffset + 16 + ntl * (ntl + 1) / 2) * 8;
+        if (sq_norm_blk_ok(N) && h->mailbox && need <= h->mailbox_bytes && !dev_is(DEV_NO_MAILBOX, '1')) {
+            void* scal;
+            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+            unsigned int* ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 336);   // (the one of power_cert_begin)
+            if (!h->cert_ticket_ready) {
+                TLSQ_HIP(h, hipMemsetAsync(ticket, 0, 4, h->stream));
+                h->cert_ticket_ready = true;
+            }
+            const int l0 = first_level > 0 ? first_level : levels;
+            const double* cur = st.cert_GD;
+            volatile double* mb = h->mailbox + kCertMailboxOffset;
+            bool mail_ok = true;
+            for (int l = 1; l <= levels && mail_ok; ++l) {
+                if (l >= l0) {
+                    const double seq = (h->mail_seq += 1.0);
+                    int ntile = 0;
+                    TLSQ_TRY(launch_sq_norm(h, cur, N, h->mailbox_dev + kCertMailboxOffset, ticket, seq, &ntile));
+                    const double t_poll = now_ms();
+                    while (mb[0] != seq && now_ms() - t_poll < 2000.0) {
+                    }
+                    if (mb[0] != seq) {
+                        mail_ok = false;
+                        break;
+                    }
+                    double a = 0.0;
+                    for (int t = 0; t < ntile; ++t) a += mb[16 + t];
+                    out[l - l0] = a;
+                }
+                if (l < levels) {
+                    double* dst = (double*)P[(l - 1) & 1];
+                    bool sq_ok = false;
+                    TLSQ_TRY(matfun_square(h, cur, dst, N, &sq_ok));
+                    if (!sq_ok) {
+                        mail_ok = false;
+                        break;
+                    }
+                    cur = dst;
+                }
+            }
+            if (mail_ok) return TLSQ_OK;
+            h->mailbox_bytes = 0;   // (never seen in practice; classic read-backs from now on)
+        }
+    }
     TLSQ_TRY(ws_get(h, WS_CPART, pslots * 8 * (size_t)std::max(1, levels), &part));
     int nb = 0;
     const double* src = st.cert_GD;
