@@ -825,6 +825,23 @@ int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const do
     return launch_zsweep<double>(h, D, Tm, Vs, A, Yin, Yout, Z, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
                                  nonnegE, sumsq, nullptr);
 }
+int tlsq_k_zsweep_gram_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Yin,
+                           double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r,
+                           double mu, double inv_mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE,
+                           double* sumsq, const double* hankel_y, int64_t hankel_K, double* G, int64_t ldG) {
+    TLSQ_TRY(check_handle(h));
+    if ((!D && !hankel_y) || !Yin || !Yout || !Zin || !Zout || !G || M <= 0 || N <= 0 || r < 0 || Yin == Yout || ldG < N ||
+        (r > 0 && (!Tm || !Vs)))
+        return set_err(h, TLSQ_ERR_ARG, "k_zsweep_gram: bad argument");
+    if (!fused_zgram_ok(M, N, r, D, Yin, Yout, Zin, Zout, R, hankel_y != nullptr))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_gram: fp64 panels of 256 / 512 columns, even M above the row floor, rank <= 16, 16-byte alignment");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    GramPlan pl;
+    TLSQ_TRY(fused_zgram_plan(h, M, N, &pl));
+    TLSQ_TRY(launch_fused_zgram(h, pl, D, Tm, Vs, Yin, Yout, Zin, Zout, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
+                                nonnegE, sumsq, nullptr, hankel_y, hankel_K, sumsq ? 0 : -1, HankelGeom()));
+    return gram_reduce(h, h->stream, pl, G, ldG);
+}
 int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,
                        const double* Y, double* E, int64_t M, int64_t N, int64_t r, double inv_mu, double thr, int nonnegA,
                        int nonnegE) {

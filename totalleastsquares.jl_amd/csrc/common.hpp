@@ -114,7 +114,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
-    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO)
+    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -304,6 +304,18 @@ int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_
                 double* normpart = nullptr, int* normblocks = nullptr);
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG,
              int mfma32 = -1);   // fp32 panels: -1 library's choice, 0 fp64 MFMA on widened operands, 1 fp32 MFMA + fp64 fold-in
+
+// ---------------- fused.hip ----------------
+// The E-free sweep and the Gram matrix of the Z_{k+1} it writes in one kernel (fp64 panels of 256 / 512 columns, rank <= 16):
+// fused_zgram_ok says whether a sweep qualifies, fused_zgram_plan sizes the K split and the slabs (a GramPlan: gram_reduce
+// sums them), launch_fused_zgram queues the kernel on the handle's stream.  Arguments as launch_zsweep (Zin != Zout allowed).
+bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
+                    const void* Zout, const void* R, bool hankel);
+int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl);
+int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
+                       double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
+                       double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
+                       const double* hankel_y, int64_t hankel_K, int maxslot, HankelGeom hg);
 
 // ---------------- matfun.hip ----------------
 // sign function / inverse square root of small symmetric matrices by Newton-Schulz iterations (N x N fp64, ld N; products on

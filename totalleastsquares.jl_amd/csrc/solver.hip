@@ -2544,8 +2544,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 const int64_t rows_c = ((M + nchunks - 1) / nchunks + 511) / 512 * 512;
                 GramPlan pl;
                 TLSQ_TRY(gram_plan(h, Prec<T>::f32, N, rows_c, nchunks, &pl));
-                void* Gv;
-                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                void* Gv;   // (the other slot of the speculative loop's double buffer: G_k stays intact for a late verdict)
+                TLSQ_TRY(ws_get(h, Gslot[gcur ^ 1], (size_t)N * N * 8, &Gv));
                 for (int c = 0; c < nchunks; ++c) {
                     const int64_t r0 = std::min<int64_t>((int64_t)c * rows_c, M), r1 = std::min<int64_t>(r0 + rows_c, M);
                     if (r1 > r0) TLSQ_TRY(sweep_rows(r0, r1, pad_lds));
@@ -2605,7 +2605,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // is needed after all, goes to a Gram buffer of its own; a Gram is wasted only at convergence).
             if (gram_queued) {   // the chunks' Gram sits on the second stream: join it (+ the all-reduce of row shards)
                 void* Gv;
-                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                TLSQ_TRY(ws_get(h, Gslot[gcur ^ 1], (size_t)N * N * 8, &Gv));
                 TLSQ_HIP(h, hipStreamWaitEvent(h->stream, h->ev_b[8], 0));
                 TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                 hbm_other += panel_bytes;

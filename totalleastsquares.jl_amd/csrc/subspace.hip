@@ -874,6 +874,21 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
                 bool allow_cholqr, bool* used_cholqr, bool one_pass, int64_t c_start) {
     const bool no_cholqr = dev_is(DEV_NO_CHOLQR, '1');
     *used_cholqr = allow_cholqr && p <= 512 && !no_cholqr;
+    // Yb (N x pb) -= Y[:, 0:c0] (Y[:, 0:c0]' Yb), the finished columns taken PROJ_CHUNK at a time: k_panel_sub keeps its
+    // slice of the coefficients in LDS (64 bytes per finished column), and c_start callers (null-space completion of the
+    // returned vectors, N up to 4608) start far beyond the 512 columns the block orthonormalisation itself ever reaches.
+    // Chunk after chunk is a block modified Gram-Schmidt sweep - at least as accurate as the one-shot projection.
+    constexpr int64_t PROJ_CHUNK = 512;
+    auto project = [&](double* Yb, int64_t pb, int64_t c0, const double* sticky) {
+        for (int64_t cc = 0; cc < c0; cc += PROJ_CHUNK) {
+            const int64_t cn = std::min<int64_t>(PROJ_CHUNK, c0 - cc);
+            const double* Yc = Y + (size_t)cc * N;
+            hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((cn * pb + 3) / 4)), dim3(256), 0, h->stream, Yc, (int)cn,
+                               (const double*)Yb, (int)pb, W, (int)N, sticky);
+            hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64),
+                               (size_t)cn * 8 * 8, h->stream, Yc, (int)cn, (const double*)W, Yb, (int)pb, (int)N, sticky);
+        }
+    };
     if (!*used_cholqr) {
         // Column-sequential CGS2 is one workgroup: 3.4 ms for a 4096 x 76 block (large-mode cold start).  Wide blocks of
         // long vectors go block by block: 16 columns are projected twice against the finished ones (two multi-workgroup
@@ -886,13 +901,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
             const int64_t pb = std::min<int64_t>(GB, p - c0);
             double* Yb = Y + (size_t)c0 * N;
             if (c0 > 0) {
-                for (int rep = 0; rep < 2; ++rep) {
-                    hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((c0 * pb + 3) / 4)), dim3(256), 0, h->stream,
-                                       (const double*)Y, (int)c0, (const double*)Yb, (int)pb, W, (int)N, (const double*)nullptr);
-                    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64),
-                                       (size_t)c0 * 8 * 8, h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb,
-                                       (int)N, (const double*)nullptr);
-                }
+                for (int rep = 0; rep < 2; ++rep) project(Yb, pb, c0, nullptr);
             }
             const size_t lds = (size_t)(pb + 16) * 8;
             hipLaunchKernelGGL(k_cgs2<false>, dim3(1), dim3(SS_THREADS), lds, h->stream, Yb, (int)N, (int)pb, status_dev,
@@ -909,13 +918,7 @@ int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t
         const int first = c0 == 0 ? 1 : 0;
         const double* sticky = first ? nullptr : status_dev;
         if (c0 > 0) {
-            for (int rep = 0; rep < 2; ++rep) {   // project the block against the finished columns, twice
-                hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((c0 * pb + 3) / 4)), dim3(256), 0, h->stream,
-                                   (const double*)Y, (int)c0, (const double*)Yb, (int)pb, W, (int)N, sticky);
-                hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64),
-                                   (size_t)c0 * 8 * 8, h->stream, (const double*)Y, (int)c0, (const double*)W, Yb, (int)pb,
-                                   (int)N, sticky);
-            }
+            for (int rep = 0; rep < 2; ++rep) project(Yb, pb, c0, sticky);   // against the finished columns, twice
         }
         if (one_pass && p <= CQ_PMAX) {   // (k_chol_trsm keeps its rows in registers: in == out is fine)
             TLSQ_TRY(launch_panel_tn(h, Yb, Yb, W, N, pb, nullptr));
