@@ -1,0 +1,171 @@
+"""GPU tests of the fused sweep + Gram kernel (csrc/fused.hip, `tlsq_k_zsweep_gram_f64`) - the E-free sweep of
+src/robustPCA.jl:188-192 / :217-223 and the Gram matrix of the Z it writes (the gesdd work of :194) in one launch.
+
+Parity bar: Y_{k+1}, Z_{k+1}, R_k bit-identical to k_zsweep (which the oracle pins bit for bit in test_gpu_parity.py) and to
+the reference's statements evaluated in numpy; the Gram matrix within 2e-13 of the Gram kernel's on what was written
+(summation order); a whole lowrankfilter call the same with the kernel as without it."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(1, device="cuda")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def eng(torch_mod):
+    import tlsq_amd
+    e = tlsq_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def soft_th(x, e):                      # src/robustPCA.jl:1
+    return np.maximum(x - e, 0) + np.minimum(x + e, 0)
+
+
+@pytest.mark.parametrize("M,r,hankel,nonneg,with_r", [
+    (40_000, 16, False, 0, True),       # whole stages only
+    (40_006, 8, False, 0, False),       # a partial last stage, no residual store
+    (33_334, 3, True, 0, True),         # implicit Hankel D with zero pad rows at the end (hankel_K < M)
+    (40_000, 0, True, 0, False),        # rank 0: A = 0
+    (36_010, 5, False, 1, True),        # nonnegA / nonnegE compiled in
+    (36_010, 16, True, 1, True),
+])
+def test_fused_sweep_gram_kernel(eng, torch_mod, M, r, hankel, nonneg, with_r):
+    """One launch against (a) k_zsweep + the Gram kernel on the same buffers: bit-identical panels, G to 1e-13; (b) the
+    reference's statements in numpy started from a consistent state: to the rounding of Z."""
+    import tlsq_amd
+    torch = torch_mod
+    N = 256
+    rng = np.random.default_rng(M + 7 * r)
+    K = M - 6 if hankel else M
+    if hankel:
+        y = rng.standard_normal(K + N - 1)
+        D = np.zeros((M, N))
+        idx = np.arange(K)[:, None] + np.arange(N)[None, :]
+        D[:K] = y[idx]
+    else:
+        y = None
+        D = rng.standard_normal((M, N))
+    Y = rng.standard_normal((M, N))
+    Ek = rng.standard_normal((M, N)) * (rng.random((M, N)) < 0.2)
+    if hankel:
+        Y[K:] = 0.0
+        Ek[K:] = 0.0
+    Tm = rng.standard_normal((M, max(r, 1)))[:, :r]
+    Vs = rng.standard_normal((N, max(r, 1)))[:, :r] / max(np.sqrt(r), 1.0)
+    if hankel and r:
+        Tm[K:] = 0.0
+    mu, mu_n, lam = 0.27, 0.405, 0.1
+    inv_mu, inv_mu_n, thr_n = 1.0 / mu, 1.0 / mu_n, lam / mu_n
+    Zk = (D - Ek) + inv_mu * Y          # :192 of the previous iteration
+    A = Tm @ Vs.T if r else np.zeros((M, N))
+    if nonneg:
+        A = np.maximum(A, 0)
+    Rref = (D - A) - Ek                 # :221
+    Y2ref = Y + mu * Rref               # :222
+    t = inv_mu_n * Y2ref
+    En = soft_th((D - A) + t, thr_n)    # :188
+    if nonneg:
+        En = np.maximum(En, 0)
+    Znref = (D - En) + t                # :192
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    dD, dY, dZ = dev(D), dev(Y), dev(Zk)
+    dT = dev(Tm if r else np.zeros((M, 1)))
+    dV = dev(Vs if r else np.zeros((N, 1)))
+    dy = torch.from_numpy(y).cuda() if hankel else None
+    Y1, Z1, R1 = torch.empty_like(dY), dZ.clone(), torch.empty_like(dY)
+    G1 = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    Y2, Z2, R2 = torch.empty_like(dY), torch.empty_like(dY), torch.full_like(dY, 7.0)
+    G2 = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    ss1 = torch.zeros(72, dtype=torch.float64, device="cuda")
+    ss2 = torch.zeros(72, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    lib, h = eng.lib, eng.h
+    assert lib.tlsq_k_zsweep_f64(h, dptr(dD), dptr(dT), dptr(dV), None, dptr(dY), dptr(Y1), dptr(Z1), dptr(R1), M, N, r, mu, inv_mu,
+                                 nonneg, inv_mu_n, thr_n, nonneg, dptr(ss1)) == 0
+    assert lib.tlsq_k_gram_f64(h, dptr(Z1), M, N, M, dptr(G1), N) == 0
+    with tlsq_amd.dev_switches(FUSED_ZGRAM_MINROWS=1000):
+        st = lib.tlsq_k_zsweep_gram_f64(h, None if hankel else dptr(dD), dptr(dT), dptr(dV), dptr(dY), dptr(Y2), dptr(dZ), dptr(Z2),
+                                        dptr(R2) if with_r else None, M, N, r, mu, inv_mu, nonneg, inv_mu_n, thr_n, nonneg,
+                                        dptr(ss2), dptr(dy), K if hankel else 0, dptr(G2), N)
+    assert st == 0, eng.lib.tlsq_last_error(h)
+    eng.synchronize()
+    assert torch.equal(Y1, Y2) and torch.equal(Z1, Z2)
+    if with_r:
+        assert torch.equal(R1, R2)
+    else:
+        assert bool((R2 == 7.0).all())                       # nothing stored
+    Gt = Z2 @ Z2.T                                           # (N x M) @ (M x N): Z' Z of the column-major panel
+    scale = Gt.abs().max().item()
+    assert (G2 - Gt).abs().max().item() <= 1e-12 * scale     # (torch's own product: rocBLAS summation order)
+    assert (G2 - G1).abs().max().item() <= 2e-13 * scale     # (the library's Gram kernel: fixed-order split-K sums, like ours)
+    assert (G2 - G2.T).abs().max().item() == 0.0
+    s1, s2 = ss1[:64].sum().item(), ss2[:64].sum().item()
+    assert abs(s1 - s2) <= 1e-11 * abs(s1)
+    assert ss2[64:65].view(torch.int64).view(torch.float64).item() == R1.abs().max().item()
+    # the reference's statements
+    zs = max(1.0, np.abs(Zk).max())
+    for got, ref in ((Y2, Y2ref), (Z2, Znref)) + (((R2, Rref),) if with_r else ()):
+        np.testing.assert_allclose(got.cpu().numpy().T, ref, rtol=0, atol=2e-13 * zs * max(1.0, np.abs(ref).max()))
+
+
+def test_fused_kernel_declines_what_it_does_not_serve(eng, torch_mod):
+    """Other widths, odd M, ranks above 16, short panels: TLSQ_ERR_UNSUPPORTED (rpca then runs the two kernels), never a
+    wrong answer."""
+    torch = torch_mod
+    lib, h = eng.lib, eng.h
+    buf = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    call = lambda M, N, r, thr=0.1: lib.tlsq_k_zsweep_gram_f64(h, dptr(buf), dptr(buf), dptr(buf), dptr(buf), dptr(buf[8:]), dptr(buf),
+                                                               dptr(buf), None, M, N, r, 0.3, 1 / 0.3, 0, 2.0, thr, 0, None, None, 0,
+                                                               dptr(buf), N)
+    unsupported = -5
+    import tlsq_amd
+    from tlsq_amd import _lib as L
+    unsupported = L.TLSQ_ERR_UNSUPPORTED
+    assert call(1000, 256, 4) == unsupported          # short panel
+    with tlsq_amd.dev_switches(FUSED_ZGRAM_MINROWS=16):
+        assert call(1001, 256, 4) == unsupported      # odd M
+        assert call(1000, 512, 4) == unsupported      # other width
+        assert call(1000, 256, 17) == unsupported     # rank
+        assert call(1000, 256, 4, thr=-1.0) == unsupported
+
+
+def test_lowrankfilter_with_and_without_the_fused_kernel(torch_mod):
+    """A lowrankfilter call whose panels are tall enough for the fused kernel (implicit Hankel D, n = 256): same iteration
+    count and the same filtered series (1e-10) as the run that keeps sweep and Gram in separate kernels; the reference's
+    own acceptance threshold (test/runtests.jl:356-381) on top."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    Ns, n = 450_000, 256
+    y, noise = O.synth_series(Ns, seed=5)
+    qn = lambda x: x / np.quantile(np.abs(x), 0.9)
+    out = {}
+    for tag, sw in (("fused", {}), ("split", {"NO_FUSED_ZGRAM": 1})):
+        with tlsq_amd.dev_switches(**sw):
+            e = tlsq_amd.Engine(0)
+            try:
+                out[tag] = e.lowrankfilter(y + noise, n, return_report=True, cost_history=True)
+            finally:
+                e.close()
+    (yf, rep), (yf0, rep0) = out["fused"], out["split"]
+    assert rep.converged and rep.iters_done == rep0.iters_done and rep.svp_hist == rep0.svp_hist
+    assert np.linalg.norm(yf - yf0) <= 1e-10 * np.linalg.norm(yf0)
+    np.testing.assert_allclose(rep.cost_hist, rep0.cost_hist, rtol=1e-8)
+    assert np.mean((y - qn(yf)) ** 2) / np.mean(noise ** 2) < 0.001

@@ -833,13 +833,13 @@ int tlsq_k_zsweep_gram_f64(tlsq_handle h, const double* D, const double* Tm, con
     if ((!D && !hankel_y) || !Yin || !Yout || !Zin || !Zout || !G || M <= 0 || N <= 0 || r < 0 || Yin == Yout || ldG < N ||
         (r > 0 && (!Tm || !Vs)))
         return set_err(h, TLSQ_ERR_ARG, "k_zsweep_gram: bad argument");
-    if (!fused_zgram_ok(M, N, r, D, Yin, Yout, Zin, Zout, R, hankel_y != nullptr))
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_gram: fp64 panels of 256 / 512 columns, even M above the row floor, rank <= 16, 16-byte alignment");
+    if (!fused_zgram_ok(M, N, r, D, Yin, Yout, Zin, Zout, R, hankel_y != nullptr, thr_next))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_gram: fp64 panels of 256 columns, even M above the row floor, rank <= 16, 16-byte alignment");
     TLSQ_HIP(h, hipSetDevice(h->device));
     GramPlan pl;
     TLSQ_TRY(fused_zgram_plan(h, M, N, &pl));
     TLSQ_TRY(launch_fused_zgram(h, pl, D, Tm, Vs, Yin, Yout, Zin, Zout, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
-                                nonnegE, sumsq, nullptr, hankel_y, hankel_K, sumsq ? 0 : -1, HankelGeom()));
+                                nonnegE, sumsq, nullptr, hankel_y, hankel_K, sumsq ? 0 : -1));
     return gram_reduce(h, h->stream, pl, G, ldG);
 }
 int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,

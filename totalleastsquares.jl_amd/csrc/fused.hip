@@ -48,12 +48,17 @@ __device__ __forceinline__ T fz_soft(T x, T e) {   // src/robustPCA.jl:1
 }
 
 constexpr int FZ_R = 16;                      // rows of the panels per stage
+constexpr int FZ_NC = 256;                    // columns of a workgroup
+constexpr int FZ_J = FZ_NC / 32;              // columns per sweep thread and stage
 constexpr int FZ_MW = 8, FZ_SW = 4;           // MFMA waves, sweep waves
 constexpr int FZ_THREADS = 64 * (FZ_MW + FZ_SW);
-constexpr int FZ_PF = 3, FZ_RS = 4;           // columns a sweep thread keeps in flight ahead of the one it works on / ring slots
+constexpr int FZ_RS_HK = 8, FZ_RS_D = 8;      // ring slots of a sweep thread with an implicit / explicit D
+constexpr int FZ_DS = 4;                      // ring slots of D (explicit panels)
+constexpr int FZ_TLO = 4;                     // rows of a T stage a sweep thread keeps in registers (the rest is read per column)
+constexpr int FZ_NT = 17;                     // accumulator tiles per MFMA wave (136 = lower triangle of 16 x 16 tiles)
 
 struct FusedArgs {
-    const double* D;      // the panel D (ld), or the series y of an implicit Hankel D (HK)
+    const double* D;      // the panel D (ld), or the series y of an implicit Hankel D (HK: D[i, j] = y[i + j], i < hankel_K)
     const double* Tm;     // M x r, ld M
     const double* Vs;     // N x r, ld N
     const double* Yin;
@@ -72,7 +77,6 @@ struct FusedArgs {
     int64_t kchunk;       // rows per chunk (a multiple of 16)
     int nz;
     int64_t hankel_K;
-    HankelGeom hg;
     int ablate;           // development (FUSED_ABLATE): 1 no MFMAs, 2 no global stores, 4 no factor product, 8 no global loads
 };
 
@@ -80,46 +84,81 @@ struct FusedArgs {
 // loads the sweep waves keep in flight across the stage boundary
 __device__ __forceinline__ void fz_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// LDS (doubles): two stage buffers [column][16 k, swizzled], Vs [column][RMAX + 2], two T stages [i][16 rows], reductions
-template <int NCL, int RMAX>
+// Panel accesses of the sweep waves: buffer instructions with a uniform base (SGPR descriptor, rebuilt per column by scalar
+// adds) and the thread's constant 32-bit byte offset - no vector instruction goes into an address (a flat 64-bit pointer per
+// column and array costs two, and the compiler keeps dozens of them alive across the stage).  16 bytes, non-temporal.
+typedef unsigned int fz_u4 __attribute__((ext_vector_type(4)));
+// `left` = elements from ubase to the end of the array: the descriptor's range check turns whatever a prefetch reads beyond
+// the panel (the stage after the last one) into zeros instead of a fault, so the loads need no branch
+__device__ __forceinline__ unsigned fz_range(int64_t left) {
+    const int64_t b = left * 8;
+    return b <= 0 ? 0u : (b > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (unsigned)b);
+}
+// (the base is wave-uniform by construction; readfirstlane says so to the compiler, which otherwise wraps the instruction in a
+//  waterfall loop whenever its uniformity analysis loses track - a no-op on values that already sit in scalar registers)
+__device__ __forceinline__ double* fz_uniform(const double* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<double*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ d2 fz_ld(const double* ubase, int64_t left, unsigned voff) {
+    const unsigned range = __builtin_amdgcn_readfirstlane(fz_range(left));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(fz_uniform(ubase), 0, range, 0x00020000);
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 2));
+}
+typedef unsigned int fz_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fz_ld1(const double* ubase, int64_t left, unsigned voff) {   // one double, default cache policy
+    const unsigned range = __builtin_amdgcn_readfirstlane(fz_range(left));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(fz_uniform(ubase), 0, range, 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
+// stores are issued unconditionally as well (a store under a branch makes the compiler's vmcnt bookkeeping assume the shorter
+// path at every join and drain half of the ring): `left` = 0 switches a store off, a lane offset of 0xFFFFFFFF drops that lane
+__device__ __forceinline__ void fz_st(double* ubase, int64_t left, unsigned voff, d2 v) {
+    unsigned range = fz_range(left);
+    range = __builtin_amdgcn_readfirstlane(range > 0xFFFFFFF0u ? 0xFFFFFFF0u : range);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(fz_uniform(ubase), 0, range, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fz_u4, v), r, voff, 0, 2);
+}
+
+// LDS (doubles): two stage buffers [column][16 k, swizzled], Vs [column][RMAX + 2], two T stages [i][16 rows], two windows
+// of the Hankel series (16 + 255 values, padded), reductions
+template <int RMAX>
 struct FzLds {
-    static constexpr int ZS = NCL * FZ_R;
+    static constexpr int ZS = FZ_NC * FZ_R;
     static constexpr int VSP = RMAX + 2;
-    static constexpr int VS = NCL * VSP;
+    static constexpr int VS = FZ_NC * VSP;
     static constexpr int TS = RMAX * FZ_R;
+    static constexpr int WS = 288;
     static constexpr int RED = 16;
-    static constexpr int TOTAL = 2 * ZS + VS + 2 * TS + RED;
+    static constexpr int TOTAL = 2 * ZS + VS + 2 * TS + 2 * WS + RED;
 };
 
-// NCL local columns in 128-column blocks, block lb at global column gcb[lb].  RECT: the tiles of local columns [256, 384) x
-// [0, 256) (8 x 16); otherwise the lower triangle of local columns [0, 256) (136 tiles).  store: this workgroup writes
-// Y_{k+1}, Z_{k+1}, R_k of its columns and accounts their residual sums.
-template <int NCL, bool RECT, int RMAX, bool HK>
-__device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int64_t kend, int gcb0, int gcb1, int gcb2,
-                                           bool store, double* __restrict__ Cz, double* __restrict__ smem) {
-    using L = FzLds<NCL, RMAX>;
-    constexpr int J = NCL / 32;    // columns per sweep thread and stage
-    static_assert(J % FZ_RS == 0, "ring slots are static");
+// One workgroup: rows [kbeg, kend) x columns [gc0, gc0 + 256) of the panels; Cz = its slab of partial Gram entries.
+//   RMAX: compiled length of the factor product (r <= RMAX); HK: implicit Hankel D (one channel, lag 1);
+//   NN: the nonnegA / nonnegE projections are compiled in; RS: ring slots (columns in flight per sweep thread: RS - 1)
+template <int RMAX, bool HK, bool NN, int RS>
+__device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int64_t kend, int gc0, double* __restrict__ Cz,
+                                           double* __restrict__ smem) {
+    using L = FzLds<RMAX>;
+    constexpr int J = FZ_J, PF = RS - 1;
+    static_assert(J % RS == 0, "ring slots are static");
     double* const Zs = smem;
     double* const sVs = smem + 2 * L::ZS;
     double* const sT = sVs + L::VS;
-    double* const sRed = sT + 2 * L::TS;
+    double* const sW = sT + 2 * L::TS;
+    double* const sRed = sW + 2 * L::WS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int nst = (int)((kend - kbeg + FZ_R - 1) / FZ_R);
     const int64_t M = P.M, ld = P.ld;
     const int r = P.r;
-    // (local 128-column blocks 0 and 1 are adjacent in every kind of workgroup; plain arithmetic - a table indexed at run
-    //  time would live in scratch memory)
-    auto gcb = [&](int lb) { return lb < 2 ? gcb0 + 128 * lb : gcb2; };
-    (void)gcb1;
 
     // ---- Vs -> LDS (all waves), zero beyond r -------------------------------------------------------------------------
-    for (int e = tid; e < NCL * RMAX; e += FZ_THREADS) {
-        const int c = e % NCL, i = e / NCL;
-        const int gc = gcb(c >> 7) + (c & 127);
-        sVs[c * L::VSP + i] = i < r ? P.Vs[(size_t)gc + (size_t)i * P.N] : 0.0;
+    for (int e = tid; e < FZ_NC * RMAX; e += FZ_THREADS) {
+        const int c = e % FZ_NC, i = e / FZ_NC;
+        sVs[c * L::VSP + i] = i < r ? P.Vs[(size_t)(gc0 + c) + (size_t)i * P.N] : 0.0;
     }
 
     if (wave < FZ_MW) {
@@ -129,14 +168,12 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
         int lq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lq[q] = fr * FZ_R + ((4 * q + fk) ^ swz);
-        constexpr int NT = RECT ? 16 : 17;
-        d4 acc[NT];
+        d4 acc[FZ_NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-        // tile of position t: rows (A operand) from fragment a(t), columns (B operand) from fragment b(t)
-        //   triangle: wave w owns tile rows 15 - w (columns 0..15 - w: positions 0..15 - w) and w (columns 0..w: the rest)
-        //   rectangle: wave w owns tile row 16 + w, columns 0..15
-        const int hi_row = RECT ? 16 + wave : 15 - wave, lo_row = wave, nhi = RECT ? 16 : 16 - wave;
+        for (int t = 0; t < FZ_NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        // tile of position t: rows (A operand) from fragment a(t), columns (B operand) from fragment b(t):
+        // wave w owns tile rows 15 - w (columns 0..15 - w: positions 0..15 - w) and w (columns 0..w: the other w + 1 positions)
+        const int hi_row = 15 - wave, lo_row = wave, nhi = 16 - wave;
         fz_barrier();   // B0: Vs, T stage 0
         fz_barrier();   // B1: stage 0 in Zs[0]
         for (int s = 0; s < nst; ++s) {
@@ -146,10 +183,10 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
             for (int q = 0; q < 4; ++q) {
                 const double* zq = zb + lq[q];
                 const double fa_hi = zq[hi_row * 256];
-                const double fa_lo = RECT ? 0.0 : zq[lo_row * 256];
+                const double fa_lo = zq[lo_row * 256];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bool hi = RECT || t < 9 || t < nhi;
+                for (int t = 0; t < FZ_NT; ++t) {
+                    const bool hi = t < 9 || t < nhi;
                     const int b = hi ? t : t - nhi;
                     const double fb = zq[b * 256];
                     const double fa = hi ? fa_hi : fa_lo;
@@ -160,90 +197,135 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
         }
         fz_barrier();   // (the sweep waves' reductions)
         // epilogue: lane holds column j = lane & 15, rows i = (lane >> 4) + 4 reg of each 16 x 16 tile (gemm.hip, gram_body)
-        auto gtile = [&](int x) { return (gcb(x >> 3) >> 4) + (x & 7); };
         const int64_t ldc = P.N;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const bool hi = RECT || t < 9 || t < nhi;
+        for (int t = 0; t < FZ_NT; ++t) {
+            const bool hi = t < 9 || t < nhi;
             const int a = hi ? hi_row : lo_row, b = hi ? t : t - nhi;
-            const int64_t j = 16 * (int64_t)gtile(b) + fr;
-            const int64_t i0 = 16 * (int64_t)gtile(a) + fk;
+            const int64_t j = gc0 + 16 * b + fr;
+            const int64_t i0 = gc0 + 16 * a + fk;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) Cz[j + (i0 + 4 * rr) * ldc] = acc[t][rr];
         }
     } else {
         // =================================== sweep waves ===================================
+        // (vector instructions and fp64 MFMAs of one SIMD do not overlap on gfx950 - tools/ubench/coexec_f64.hip - so every
+        //  instruction here is paid in matrix time: addresses are uniform base + a constant 32-bit thread offset, the
+        //  threshold is the two-instruction clamp form, and the sweep wave gets the pipe whenever it is ready)
+        __builtin_amdgcn_s_setprio(3);
         const int st = tid - 64 * FZ_MW;
         const int p = st & 7, cg = st >> 3;                   // row pair of the stage, first column
         const int swc = 2 * ((cg >> 1) & 7);                  // (columns cg + 32 j: the swizzle does not depend on j)
         const int zoff = cg * FZ_R + ((2 * p) ^ swc);         // + 32 j * 16 per column
         const int ti = st >> 4, tr = st & 15;                 // element of a T stage this thread fetches
-        const double mu = P.mu, inv_mu = P.inv_mu, inv_mu_n = P.inv_mu_n, thr_n = P.thr_n;
-        const bool nonnegA = P.nonnegA != 0, nonnegE = P.nonnegE != 0;
-        double* const Rp = store ? P.R : nullptr;
+        const unsigned toff = (unsigned)(((int64_t)cg * ld + 2 * p) * 8);   // byte offset of the thread's row pair in column cg
+        const int woff = 2 * p + cg;                          // Hankel window: D[row0 + 2p + q, gc0 + cg + 32 j] = w[woff + q + 32 j]
+        const double mu = P.mu, inv_mu = P.inv_mu, inv_mu_n = P.inv_mu_n, thr_n = P.thr_n, nthr_n = -P.thr_n;
+        const bool nonnegA = NN && P.nonnegA != 0, nonnegE = NN && P.nonnegE != 0;
+        double* const Rp = P.R;
+        double* const Rbase = Rp ? Rp : P.Zout;                  // (a switched-off store still needs a valid descriptor base)
+        const int64_t stleft = (P.ablate & 2) ? 0 : M * (int64_t)P.N;
         double ss = 0.0, rmax = 0.0;
+        const int64_t colstep = 32 * ld;                      // elements between a thread's consecutive columns
 
+        // The register ring: Y and Z of the next RS - 1 columns, D (explicit panels) of the next DS - 1 - what a sweep thread has
+        // in flight is what hides the HBM latency (one sweep wave per SIMD: nobody else issues loads)
         struct Col {
-            d2 d, y, z;
+            d2 y, z;
         };
-        Col ring[FZ_RS];
-        // loads of column j of the stage that starts at row r0 -> ring slot j % RS
-        // loads of column j (0 <= j < J, possibly a runtime value) of the stage that starts at row r0 -> ring slot `slot`
-        auto issue = [&](Col& c, int j, int64_t r0) {
-            const int64_t row = r0 + 2 * p;
-            const int gc = gcb(j >> 2) + cg + 32 * (j & 3);
-            const int64_t off = (int64_t)gc * ld + row;
-            if (row < kend && !(P.ablate & 8)) {
-                c.y = *reinterpret_cast<const d2*>(P.Yin + off);
-                c.z = *reinterpret_cast<const d2*>(P.Zin + off);
-                if constexpr (HK) {
-                    const int64_t co = hankel_coff(P.hg, gc);
-                    c.d[0] = (row < P.hankel_K) ? P.D[row * P.hg.lag + co] : 0.0;
-                    c.d[1] = (row + 1 < P.hankel_K) ? P.D[(row + 1) * P.hg.lag + co] : 0.0;
-                } else {
-                    c.d = *reinterpret_cast<const d2*>(P.D + off);
-                }
-            } else {
-                c.y = c.z = c.d = d2{0.0, 0.0};
-            }
+        constexpr int DS = HK ? 1 : FZ_DS, DPF = DS - 1;
+        static_assert(J % DS == 0 && RS % DS == 0, "ring slots are static");
+        Col ring[RS];
+        d2 dring[DS];
+        // element offset (uniform) of column j of the stage that starts at row r0
+        auto ubase = [&](int j, int64_t r0) -> int64_t { return (int64_t)gc0 * ld + r0 + (int64_t)j * colstep; };
+        // loads of column j of the stage starting at row r0: unconditional (the ring must stay in registers - a load under a
+        // branch sends its slot to scratch memory); a stage that reaches beyond the chunk or the panel reads rows nobody uses
+        const int64_t ntot = M * (int64_t)P.N;
+        auto issue = [&](int j, int64_t r0) -> Col {
+            Col c;
+            const int64_t u = ubase(j, r0);
+            c.y = fz_ld(P.Yin + u, ntot - u, toff);
+            c.z = fz_ld(P.Zin + u, ntot - u, toff);
+            return c;
         };
-        auto t_fetch = [&](int64_t r0) -> double {
-            const int64_t row = r0 + tr;
-            return (ti < r && ti < RMAX && row < kend) ? P.Tm[row + (size_t)ti * M] : 0.0;
+        auto issue_d = [&](int j, int64_t r0) -> d2 {
+            const int64_t u = ubase(j, r0);
+            return fz_ld(P.D + u, ntot - u, toff);
         };
-        // stage s of this chunk: reads T stage buffer s & 1, writes Zs[s & 1]; T of stage s + 1 goes to the other T buffer.
-        // The columns are worked through strictly one after the other (sched_barrier): left to itself the scheduler
-        // interleaves all of a stage's columns and spills half of them.
+        // element (row r0 + tr, column ti) of T: zero beyond column r - 1 through the range check (rows beyond the panel only
+        // occur in a stage whose rows are masked)
+        const unsigned tvoff = (unsigned)(((int64_t)ti * M + tr) * 8);
+        auto t_fetch = [&](int64_t r0) -> double { return fz_ld1(P.Tm + r0, M * (int64_t)r - r0, ti < RMAX ? tvoff : 0xFFFFFFF8u); };
+        // Hankel window of the stage at r0: w[i] = y[r0 + gc0 + i], i < 16 + 255 (thread st: i = st and, st < 16, 256 + st);
+        // the series has hankel_K + N - 1 samples
+        auto w_fetch = [&](int64_t r0, double& w0, double& w1) {
+            const int64_t base = r0 + gc0, left = P.hankel_K + P.N - 1 - base;
+            w0 = fz_ld1(P.D + base, left, (unsigned)st * 8u);
+            w1 = fz_ld1(P.D + base, left, st < 16 ? (unsigned)(256 + st) * 8u : 0xFFFFFFF8u);
+        };
+        auto stage_full = [&](int64_t r0) { return r0 + FZ_R <= kend && (!HK || r0 + FZ_R <= P.hankel_K); };
+
+        // stage s of this chunk: reads T stage (and window) buffer s & 1, writes Zs[s & 1]; T / window of stage s + 1 go to the
+        // other buffers.  The columns are worked through strictly one after the other (sched_barrier): left to itself the
+        // scheduler interleaves all of a stage's columns and spills half of them.  (One copy of this body in the kernel:
+        // the ring is ~100 registers of loop state.)
         auto sweep_stage = [&](int s) {
-            const int64_t r0 = kbeg + (int64_t)s * FZ_R;
+            // (the stage index is made opaque to the optimiser: otherwise the uniform base of every (array, column) pair - 40
+            //  pointers - is hoisted out of the stage loop and the scalar registers spill into vector lanes; readfirstlane tells
+            //  the uniformity analysis that what comes out of the asm is still a scalar)
+            int so = s;
+            asm volatile("" : "+s"(so));
+            so = __builtin_amdgcn_readfirstlane(so);
+            const int64_t r0 = kbeg + (int64_t)so * FZ_R;
+            const bool full = stage_full(r0);
             const bool more = s + 1 < nst;
-            double tnext = 0.0;
+            double tnext = 0.0, wn0 = 0.0, wn1 = 0.0;
             if (st < L::TS && more) tnext = t_fetch(r0 + FZ_R);
-            // rows of T: the first eight columns stay in registers for the stage, the rest is read again per panel column
+            if (HK && more) w_fetch(r0 + FZ_R, wn0, wn1);
+            // rows of T: the first columns stay in registers for the stage, the rest is read again per panel column
             // (the register file is what limits this kernel: 168 per wave)
-            constexpr int TLO = RMAX < 8 ? RMAX : 8;
+            constexpr int TLO = RMAX < FZ_TLO ? RMAX : FZ_TLO;
             const double* tb = sT + (s & 1) * L::TS + 2 * p;
+            const double* wb = sW + (s & 1) * L::WS + woff;
             d2 t[TLO];
 #pragma unroll
             for (int i = 0; i < TLO; ++i) t[i] = *reinterpret_cast<const d2*>(tb + i * FZ_R);
             double* zs = Zs + (s & 1) * L::ZS + zoff;
-            const int64_t row = r0 + 2 * p;
-            const bool ok = row < kend;
+            const bool ok = r0 + 2 * p < kend;
+            const bool hk0 = r0 + 2 * p < P.hankel_K, hk1 = r0 + 2 * p + 1 < P.hankel_K;
+            const unsigned svoff = (full || ok) ? toff : 0xFFFFFFFFu;   // rows beyond the chunk are not stored
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-            for (int g = 0; g < J / FZ_RS; ++g) {
+            for (int g = 0; g < J / RS; ++g) {
 #pragma unroll
-                for (int jj = 0; jj < FZ_RS; ++jj) {
-                    const int j = FZ_RS * g + jj;
+                for (int jj = 0; jj < RS; ++jj) {
+                    const int j = RS * g + jj;
                     {
-                        int jn = j + FZ_PF;
-                        const bool wrap = jn >= J;
-                        if (wrap) jn -= J;
-                        if (!wrap || more) issue(ring[(jj + FZ_PF) % FZ_RS], jn, wrap ? r0 + FZ_R : r0);
+                        const int jr = (j + PF) % J;
+                        ring[(jj + PF) % RS] = issue(jr, j + PF >= J ? r0 + FZ_R : r0);
+                    }
+                    if constexpr (!HK) {
+                        const int jr = (j + DPF) % J;
+                        dring[(jj + DPF) % DS] = issue_d(jr, j + DPF >= J ? r0 + FZ_R : r0);
                     }
                     const Col c = ring[jj];
+                    d2 cd;
+                    if constexpr (HK) {
+                        // D[row, gc0 + cg + 32 j] = y[row + gc0 + cg + 32 j] from the stage's window; zero rows below the last
+                        // Hankel row (only a stage that is not `full` has any).  No global load here: a load under a branch would
+                        // make the compiler drain the whole ring at the join.
+                        cd[0] = wb[32 * j];
+                        cd[1] = wb[32 * j + 1];
+                        if (!full) {
+                            cd[0] = hk0 ? cd[0] : 0.0;
+                            cd[1] = hk1 ? cd[1] : 0.0;
+                        }
+                    } else {
+                        cd = dring[jj % DS];
+                    }
                     const double* vs = sVs + (cg + 32 * j) * L::VSP;
                     double a0 = 0.0, a1 = 0.0;
-                    if (!(P.ablate & 4))
 #pragma unroll
                     for (int i = 0; i < RMAX; i += 2) {
                         const d2 v = *reinterpret_cast<const d2*>(vs + i);
@@ -261,45 +343,61 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
                         if (nonnegA) a = fz_pos(a);                       // A .= max.(A,0)                          :217-219
                         const double w = c.z[q] - a;
                         const double res = w - inv_mu * c.y[q];          // R_k = D - A - E                         :221
-                        ss += res * res;
-                        const double ares = res < 0.0 ? -res : res;
-                        rmax = ares > rmax ? ares : rmax;                 // (a NaN never wins: the bound stays a bound)
+                        const double resm = (full || ok) ? res : 0.0;    // (rows beyond the chunk: whatever the prefetch read)
+                        ss = __builtin_fma(resm, resm, ss);               // (a bound, never a result)
+                        rmax = __builtin_fmax(rmax, __builtin_fabs(resm)); // (a NaN never wins: the bound stays a bound)
                         rr[q] = res;
                         const double y1 = mu * w;                         // Y_{k+1} = Y + mu R                      :222
                         yn[q] = y1;
                         const double tt = inv_mu_n * y1;                  // next iteration, mu_{k+1}                :188
-                        double ee = fz_soft((c.d[q] - a) + tt, thr_n);
+                        // soft_th(x, e) = max(x - e, 0) + min(x + e, 0) (src/robustPCA.jl:1) = x - clamp(x, -e, e) for e >= 0:
+                        // the same single rounding in all three branches, the same +0 inside the band, NaN / Inf carried by
+                        // the subtraction (the launcher sends negative or non-finite thresholds to k_zsweep)
+                        const double x = (cd[q] - a) + tt;
+                        double ee = x - __builtin_fmin(__builtin_fmax(x, nthr_n), thr_n);
                         if (nonnegE) ee = fz_pos(ee);                     //                                         :189-191
-                        zn[q] = (c.d[q] - ee) + tt;                       //                                         :192
+                        zn[q] = (cd[q] - ee) + tt;                       //                                         :192
                     }
-                    if (!ok) zn = d2{0.0, 0.0};
+                    if (!full && !ok) zn = d2{0.0, 0.0};
                     *reinterpret_cast<d2*>(zs + 32 * j * FZ_R) = zn;
-                    if (store && ok && !(P.ablate & 2)) {
-                        const int gc = gcb(j >> 2) + cg + 32 * (j & 3);
-                        const int64_t off = (int64_t)gc * ld + row;
-                        if (Rp) __builtin_nontemporal_store(rr, reinterpret_cast<d2*>(Rp + off));
-                        __builtin_nontemporal_store(yn, reinterpret_cast<d2*>(P.Yout + off));
-                        __builtin_nontemporal_store(zn, reinterpret_cast<d2*>(P.Zout + off));
+                    {
+                        const int64_t u = ubase(j, r0);
+                        fz_st(Rbase + u, Rp ? stleft - u : 0, svoff, rr);
+                        fz_st(P.Yout + u, stleft - u, svoff, yn);
+                        fz_st(P.Zout + u, stleft - u, svoff, zn);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (st < L::TS && more) sT[((s + 1) & 1) * L::TS + ti * FZ_R + tr] = tnext;
+            if (HK && more) {
+                double* wnx = sW + ((s + 1) & 1) * L::WS;
+                wnx[st] = wn0;
+                if (st < 16) wnx[256 + st] = wn1;
+            }
         };
 
-        // prologue: T stage 0, first loads
+        // prologue: T stage 0, window 0, first loads
         if (st < L::TS) sT[ti * FZ_R + tr] = t_fetch(kbeg);
+        if (HK) {
+            double w0, w1;
+            w_fetch(kbeg, w0, w1);
+            sW[st] = w0;
+            if (st < 16) sW[256 + st] = w1;
+        }
 #pragma unroll
-        for (int j = 0; j < FZ_PF; ++j) issue(ring[j], j, kbeg);
+        for (int j = 0; j < PF; ++j) ring[j] = issue(j, kbeg);
+        if constexpr (!HK) {
+#pragma unroll
+            for (int j = 0; j < DPF; ++j) dring[j] = issue_d(j, kbeg);
+        }
         fz_barrier();   // B0
-        sweep_stage(0);
-        fz_barrier();   // B1
-        for (int s = 0; s < nst; ++s) {
-            if (s + 1 < nst) sweep_stage(s + 1);
+        for (int s = 0; s <= nst; ++s) {   // (stage s is swept while the MFMA waves work on stage s - 1)
+            if (s < nst) sweep_stage(s);
             fz_barrier();
         }
         // ||R_k||_F^2 and max |R_k| of this workgroup's columns (bounds for the convergence test, never results)
-        if (P.sumsq && store) {
+        if (P.sumsq) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 ss += __shfl_down(ss, off, 64);
@@ -312,7 +410,7 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
             }
         }
         fz_barrier();
-        if (P.sumsq && store && st == 0) {
+        if (P.sumsq && st == 0) {
             atomicAdd(P.sumsq + (blockIdx.x & 63), (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
             if (P.maxslot >= 0) {
                 double mm = sRed[4];
@@ -324,32 +422,17 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
     }
 }
 
-// N = 256: one kind of workgroup, chunk z = blockIdx.x
-template <int RMAX, bool HK>
-__global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram_256(const FusedArgs P) {
+// blockIdx.x = chunk * (N / 256) + column block
+template <int RMAX, bool HK, bool NN, int RS>
+__global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram(const FusedArgs P) {
     extern __shared__ __attribute__((aligned(16))) double fz_smem[];
     if (P.zero_slots && blockIdx.x == 0 && threadIdx.x < 72) P.zero_slots[threadIdx.x] = 0.0;
-    const int z = blockIdx.x;
+    const int ncb = P.N / FZ_NC;
+    const int z = blockIdx.x / ncb, cb = blockIdx.x % ncb;
     const int64_t kbeg = (int64_t)z * P.kchunk;
     if (z >= P.nz || kbeg >= P.M) return;
     const int64_t kend = kbeg + P.kchunk < P.M ? kbeg + P.kchunk : P.M;
-    fused_body<256, false, RMAX, HK>(P, kbeg, kend, 0, 128, 0, true, P.slab + (size_t)z * P.N * P.N, fz_smem);
-}
-
-// N = 512: blocks b and b + 8 share an XCD (round-robin dispatch: speed only, nothing depends on it); an XCD takes the
-// chunks z = x, x + 8, ... and, for each, the four kinds in consecutive slots
-template <int RMAX, bool HK>
-__global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram_512(const FusedArgs P) {
-    extern __shared__ __attribute__((aligned(16))) double fz_smem[];
-    if (P.zero_slots && blockIdx.x == 0 && threadIdx.x < 72) P.zero_slots[threadIdx.x] = 0.0;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int z = x + 8 * (q >> 2), kind = q & 3;
-    const int64_t kbeg = (int64_t)z * P.kchunk;
-    if (z >= P.nz || kbeg >= P.M) return;
-    const int64_t kend = kbeg + P.kchunk < P.M ? kbeg + P.kchunk : P.M;
-    double* Cz = P.slab + (size_t)z * P.N * P.N;
-    if (kind < 2) fused_body<256, false, RMAX, HK>(P, kbeg, kend, 256 * kind, 256 * kind + 128, 0, true, Cz, fz_smem);
-    else fused_body<384, true, RMAX, HK>(P, kbeg, kend, 0, 128, 128 * kind, false, Cz, fz_smem);
+    fused_body<RMAX, HK, NN, RS>(P, kbeg, kend, FZ_NC * cb, P.slab + (size_t)z * P.N * P.N, fz_smem);
 }
 
 inline bool fz_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -357,14 +440,21 @@ inline bool fz_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 }  // namespace
 
 // Can the fused kernel serve this sweep?  fp64 panels of 256 or 512 columns, contiguous (ld = M), even M, rank <= 16,
-// 16-byte aligned panels; below ~16 stages per workgroup the separate kernels are the better schedule.
+// 16-byte aligned panels, a thread's 32-bit byte offset must reach its 31st column, a proper threshold; an implicit Hankel
+// D only with one channel and lag 1.  Below ~16 stages per workgroup the separate kernels are the better schedule.
 bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
-                    const void* Zout, const void* R, bool hankel) {
+                    const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg) {
     if (dev_is(DEV_NO_FUSED_ZGRAM, '1')) return false;
-    if (N != 256 && N != 512) return false;
+    if (N != FZ_NC) return false;   // (wider panels: the kernel covers the diagonal 256-column blocks of the Gram matrix only)
     if (r < 0 || r > 16 || (M & 1)) return false;
+    if (!(thr_n >= 0.0) || !std::isfinite(thr_n)) return false;
+    if (hankel && (hg.lag != 1 || hg.Dch != 1)) return false;
+    if ((31 * M + 16) * 8 >= ((int64_t)1 << 32)) return false;
     const int64_t min_rows = [] { const char* e = dev_get(DEV_FUSED_ZGRAM_MINROWS); return e ? atol(e) : 0L; }();
-    if (M < (min_rows > 0 ? min_rows : (N == 256 ? 65536 : 16384))) return false;
+    // one workgroup per CU whatever M is, each with its own 272 KB of partial sums: below ~400k rows the slabs (134 MB, a sixth
+    // of a panel there) and their reduction cost what the fusion saves (measured: 131072 rows 395 us against 402 us for the
+    // two kernels, 1e6 rows 1845 against 2822)
+    if (M < (min_rows > 0 ? min_rows : 400000)) return false;
     if (!(hankel || fz_aligned16(D)) || !fz_aligned16(Yin) || !fz_aligned16(Yout) || !fz_aligned16(Zin) || !fz_aligned16(Zout) ||
         !fz_aligned16(R))
         return false;
@@ -376,7 +466,7 @@ int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
     if (ncu < 8) ncu = 8;
-    const int per = N == 256 ? 1 : 4;            // workgroups per row chunk
+    const int per = (int)(N / FZ_NC);            // workgroups per row chunk
     int64_t nz = std::max<int64_t>(1, ncu / per);
     int64_t kc = ((M + nz - 1) / nz + FZ_R - 1) / FZ_R * FZ_R;
     nz = (M + kc - 1) / kc;
@@ -397,7 +487,7 @@ int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
-                       const double* hankel_y, int64_t hankel_K, int maxslot, HankelGeom hg) {
+                       const double* hankel_y, int64_t hankel_K, int maxslot) {
     if (!sumsq || maxslot > 7) maxslot = -1;
     FusedArgs a;
     a.D = hankel_y ? hankel_y : D;
@@ -425,37 +515,30 @@ int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const dou
     a.kchunk = pl.kchunk_o;
     a.nz = (int)pl.nsplit_o;
     a.hankel_K = hankel_K;
-    a.hg = hg;
     a.ablate = [] { const char* e = dev_get(DEV_FUSED_ABLATE); return e ? atoi(e) : 0; }();
-    const bool hk = hankel_y != nullptr;
-    const int nz8 = (a.nz + 7) / 8 * 8;
-#define FZ_LAUNCH(KERN, NCL, RM, GRID)                                                                              \
+    const bool hk = hankel_y != nullptr, nn = nonnegA || nonnegE;
+    const unsigned grid = (unsigned)(a.nz * (N / FZ_NC));
+#define FZ_LAUNCH(RM, HKF, NNF, RSF)                                                                                \
     do {                                                                                                            \
-        const size_t lds = (size_t)FzLds<NCL, RM>::TOTAL * sizeof(double);                                          \
+        const size_t lds = (size_t)FzLds<RM>::TOTAL * sizeof(double);                                               \
         static bool attr_set = false;   /* (per instantiation; idempotent) */                                        \
         if (!attr_set) {                                                                                            \
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF>),        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3(FZ_THREADS), lds, h->stream, a);                      \
+        hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);    \
     } while (0)
-    if (N == 256) {
-        if (r <= 8) {
-            if (hk) FZ_LAUNCH((k_fused_zgram_256<8, true>), 256, 8, a.nz);
-            else FZ_LAUNCH((k_fused_zgram_256<8, false>), 256, 8, a.nz);
-        } else {
-            if (hk) FZ_LAUNCH((k_fused_zgram_256<16, true>), 256, 16, a.nz);
-            else FZ_LAUNCH((k_fused_zgram_256<16, false>), 256, 16, a.nz);
-        }
-    } else {
-        if (r <= 8) {
-            if (hk) FZ_LAUNCH((k_fused_zgram_512<8, true>), 384, 8, 4 * nz8);
-            else FZ_LAUNCH((k_fused_zgram_512<8, false>), 384, 8, 4 * nz8);
-        } else {
-            if (hk) FZ_LAUNCH((k_fused_zgram_512<16, true>), 384, 16, 4 * nz8);
-            else FZ_LAUNCH((k_fused_zgram_512<16, false>), 384, 16, 4 * nz8);
-        }
-    }
+#define FZ_PICK(RM)                                               \
+    do {                                                          \
+        if (hk && nn) FZ_LAUNCH(RM, true, true, FZ_RS_HK);        \
+        else if (hk) FZ_LAUNCH(RM, true, false, FZ_RS_HK);        \
+        else if (nn) FZ_LAUNCH(RM, false, true, FZ_RS_D);         \
+        else FZ_LAUNCH(RM, false, false, FZ_RS_D);                \
+    } while (0)
+    if (r <= 8) FZ_PICK(8);
+    else FZ_PICK(16);
+#undef FZ_PICK
 #undef FZ_LAUNCH
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;

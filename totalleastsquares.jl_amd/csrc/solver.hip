@@ -2485,6 +2485,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last && !hook_sketch;
         bool gram_queued = false;
+        bool fused_gram = false;   // the sweep kernel has accumulated the Gram of Z_{k+1} as well (fused.hip): only its slabs are left to add
+        GramPlan fused_pl;
         // one launch of the fused sweep over rows [r0, r1) (r1 = 0: the whole panel): E-free form or classic form
         const T* hy_sweep = (const T*)ro.hankel_y;
         if (zmode && fuse) {
@@ -2536,7 +2538,24 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             const bool f32mfma_gram = Prec<T>::f32 && N > 2048;   // (gram_any's choice: that kernel is not chunked)
             int nchunks = (gram_next && !f32mfma_gram && M * N >= ((int64_t)1 << 30)) ? 8 : 1;
             if (env_chunks >= 1 && env_chunks <= 8 && gram_next && !f32mfma_gram) nchunks = env_chunks;
-            if (nchunks > 1) {
+            // fp64 panels of 256 columns (lowrankfilter's n = 256): sweep and Gram in ONE kernel (fused.hip) - the rows of
+            // Z_{k+1} feed the MFMA from LDS on their way to memory, the Gram reads nothing from HBM and needs no second
+            // stream.  Its slabs are reduced where the next Gram is queued below.
+            if constexpr (std::is_same<T, double>::value) {
+                if (zmode && gram_next && env_chunks < 0 &&
+                    fused_zgram_ok(M, N, svp, D, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1], Rst, hy_sweep != nullptr,
+                                   lam / mu_next, ro.hankel_geom)) {
+                    TLSQ_TRY(fused_zgram_plan(h, M, N, &fused_pl));
+                    TLSQ_TRY(launch_fused_zgram(h, fused_pl, D, Tm_last, Vs_last, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1],
+                                                Rst, M, N, svp, mu, inv_mu, ro.nonnegA ? 1 : 0, 1.0 / mu_next, lam / mu_next,
+                                                ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K, maxslot));
+                    fused_gram = true;
+                    nchunks = 0;
+                }
+            }
+            if (nchunks == 0) {
+                // (swept and accumulated above)
+            } else if (nchunks > 1) {
                 TLSQ_TRY(second_stream(h));
                 // (TLSQ_OVERLAP_LDS: unused dynamic LDS per sweep workgroup, caps its residency per CU - measured: 40 KB
                 // no change, 80 KB, i.e. one sweep workgroup per CU, slower)
@@ -2609,6 +2628,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_HIP(h, hipStreamWaitEvent(h->stream, h->ev_b[8], 0));
                 TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                 hbm_other += panel_bytes;
+                g_ready = true;
+            } else if (fused_gram) {
+                void* Gv;
+                TLSQ_TRY(ws_get(h, Gslot[gcur ^ 1], (size_t)N * N * 8, &Gv));
+                TLSQ_TRY(gram_reduce(h, h->stream, fused_pl, (double*)Gv, N));
+                TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                 g_ready = true;
             } else if (gram_next) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
