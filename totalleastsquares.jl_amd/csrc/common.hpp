@@ -308,14 +308,15 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
 // ---------------- fused.hip ----------------
 // The E-free sweep and the Gram matrix of the Z_{k+1} it writes in one kernel (fp64 panels of 256 / 512 columns, rank <= 16):
 // fused_zgram_ok says whether a sweep qualifies, fused_zgram_plan sizes the K split and the slabs (a GramPlan: gram_reduce
-// sums them), launch_fused_zgram queues the kernel on the handle's stream.  Arguments as launch_zsweep (Zin != Zout allowed).
+// sums them), launch_fused_zgram queues the kernel on the handle's stream.  Arguments as launch_zsweep (Zin != Zout allowed);
+// first = true: the first shrink instead (launch_first_shrink: Y_1 = D / s_div, Z_1) with the Gram of Z_1.
 bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
                     const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg = HankelGeom());
 int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl);
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
-                       const double* hankel_y, int64_t hankel_K, int maxslot);
+                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first = false, double s_div = 1.0);
 
 // ---------------- matfun.hip ----------------
 // sign function / inverse square root of small symmetric matrices by Newton-Schulz iterations (N x N fp64, ld N; products on

@@ -69,6 +69,7 @@ struct FusedArgs {
     int64_t M, ld;
     int N, r;
     double mu, inv_mu, inv_mu_n, thr_n;
+    double s_div;         // FIRST: the dual norm Y_1 = D / s_div is formed with (inv_mu = 1 / mu_1, thr_n = lambda / mu_1 then)
     int nonnegA, nonnegE;
     double* sumsq;        // 72 doubles (k_zsweep): [0, 64) partial sums of ||R_k||_F^2, [64 + maxslot] max |R_k[i, j]|
     double* zero_slots;
@@ -91,8 +92,17 @@ typedef unsigned int fz_u4 __attribute__((ext_vector_type(4)));
 // `left` = elements from ubase to the end of the array: the descriptor's range check turns whatever a prefetch reads beyond
 // the panel (the stage after the last one) into zeros instead of a fault, so the loads need no branch
 __device__ __forceinline__ unsigned fz_range(int64_t left) {
-    const int64_t b = left * 8;
-    return b <= 0 ? 0u : (b > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (unsigned)b);
+    // min(8 left, 0xFFFFFFF0), zero for left <= 0 - on the two 32-bit halves: the scalar unit has no 64-bit compare, and a
+    // 64-bit compare on the vector unit is paid in matrix time
+    // (the high halves go through an empty asm: otherwise the optimiser fuses the tests into 64-bit compares again)
+    const uint64_t b = (uint64_t)left << 3;
+    const uint32_t lo = (uint32_t)b;
+    uint32_t hi = (uint32_t)(b >> 32), hi_left = (uint32_t)((uint64_t)left >> 32);
+    asm volatile("" : "+s"(hi), "+s"(hi_left));
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    hi_left = __builtin_amdgcn_readfirstlane(hi_left);
+    if ((int32_t)hi_left < 0 || (hi_left | (uint32_t)left) == 0u) return 0u;
+    return (hi != 0u || lo > 0xFFFFFFF0u) ? 0xFFFFFFF0u : lo;
 }
 // (the base is wave-uniform by construction; readfirstlane says so to the compiler, which otherwise wraps the instruction in a
 //  waterfall loop whenever its uniformity analysis loses track - a no-op on values that already sit in scalar registers)
@@ -115,8 +125,7 @@ __device__ __forceinline__ double fz_ld1(const double* ubase, int64_t left, unsi
 // stores are issued unconditionally as well (a store under a branch makes the compiler's vmcnt bookkeeping assume the shorter
 // path at every join and drain half of the ring): `left` = 0 switches a store off, a lane offset of 0xFFFFFFFF drops that lane
 __device__ __forceinline__ void fz_st(double* ubase, int64_t left, unsigned voff, d2 v) {
-    unsigned range = fz_range(left);
-    range = __builtin_amdgcn_readfirstlane(range > 0xFFFFFFF0u ? 0xFFFFFFF0u : range);
+    const unsigned range = __builtin_amdgcn_readfirstlane(fz_range(left));
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(fz_uniform(ubase), 0, range, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fz_u4, v), r, voff, 0, 2);
 }
@@ -131,13 +140,14 @@ struct FzLds {
     static constexpr int TS = RMAX * FZ_R;
     static constexpr int WS = 288;
     static constexpr int RED = 16;
-    static constexpr int TOTAL = 2 * ZS + VS + 2 * TS + 2 * WS + RED;
+    static constexpr int TOTAL = 2 * ZS + VS + 2 * TS + 3 * WS + RED;   // (third window: zeros)
 };
 
 // One workgroup: rows [kbeg, kend) x columns [gc0, gc0 + 256) of the panels; Cz = its slab of partial Gram entries.
 //   RMAX: compiled length of the factor product (r <= RMAX); HK: implicit Hankel D (one channel, lag 1);
-//   NN: the nonnegA / nonnegE projections are compiled in; RS: ring slots (columns in flight per sweep thread: RS - 1)
-template <int RMAX, bool HK, bool NN, int RS>
+//   NN: the nonnegA / nonnegE projections are compiled in; RS: ring slots (columns in flight per sweep thread: RS - 1);
+//   FIRST: iteration 1 instead (k_first_shrink: Y_1 = D / s, A = 0, Z_1 - src/robustPCA.jl:181, :188-192 - nothing but D is read)
+template <int RMAX, bool HK, bool NN, int RS, bool FIRST>
 __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int64_t kend, int gc0, double* __restrict__ Cz,
                                            double* __restrict__ smem) {
     using L = FzLds<RMAX>;
@@ -147,7 +157,8 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
     double* const sVs = smem + 2 * L::ZS;
     double* const sT = sVs + L::VS;
     double* const sW = sT + 2 * L::TS;
-    double* const sRed = sW + 2 * L::WS;
+    double* const sZero = sW + 2 * L::WS;   // a window of zeros: what the rows below the last Hankel row read
+    double* const sRed = sZero + L::WS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -156,10 +167,13 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
     const int r = P.r;
 
     // ---- Vs -> LDS (all waves), zero beyond r -------------------------------------------------------------------------
+    if (!FIRST)
     for (int e = tid; e < FZ_NC * RMAX; e += FZ_THREADS) {
         const int c = e % FZ_NC, i = e / FZ_NC;
         sVs[c * L::VSP + i] = i < r ? P.Vs[(size_t)(gc0 + c) + (size_t)i * P.N] : 0.0;
     }
+
+    for (int e = tid; e < L::WS; e += FZ_THREADS) sZero[e] = 0.0;
 
     if (wave < FZ_MW) {
         // =================================== MFMA waves ===================================
@@ -242,21 +256,25 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
         // loads of column j of the stage starting at row r0: unconditional (the ring must stay in registers - a load under a
         // branch sends its slot to scratch memory); a stage that reaches beyond the chunk or the panel reads rows nobody uses
         const int64_t ntot = M * (int64_t)P.N;
-        auto issue = [&](int j, int64_t r0) -> Col {
+        // (vo: the thread's byte offset, or 0xFFFFFFFF for a row pair beyond the chunk - the range check then returns zeros, and
+        //  zeros in give zeros out: no mask anywhere downstream)
+        auto issue = [&](int j, int64_t r0, unsigned vo) -> Col {
             Col c;
             const int64_t u = ubase(j, r0);
-            c.y = fz_ld(P.Yin + u, ntot - u, toff);
-            c.z = fz_ld(P.Zin + u, ntot - u, toff);
+            c.y = fz_ld(P.Yin + u, ntot - u, vo);
+            c.z = fz_ld(P.Zin + u, ntot - u, vo);
             return c;
         };
-        auto issue_d = [&](int j, int64_t r0) -> d2 {
+        auto issue_d = [&](int j, int64_t r0, unsigned vo) -> d2 {
             const int64_t u = ubase(j, r0);
-            return fz_ld(P.D + u, ntot - u, toff);
+            return fz_ld(P.D + u, ntot - u, vo);
         };
         // element (row r0 + tr, column ti) of T: zero beyond column r - 1 through the range check (rows beyond the panel only
         // occur in a stage whose rows are masked)
         const unsigned tvoff = (unsigned)(((int64_t)ti * M + tr) * 8);
-        auto t_fetch = [&](int64_t r0) -> double { return fz_ld1(P.Tm + r0, M * (int64_t)r - r0, ti < RMAX ? tvoff : 0xFFFFFFF8u); };
+        auto t_fetch = [&](int64_t r0) -> double {
+            return fz_ld1(P.Tm + r0, M * (int64_t)r - r0, (ti < RMAX && r0 + tr < kend) ? tvoff : 0xFFFFFFF8u);
+        };
         // Hankel window of the stage at r0: w[i] = y[r0 + gc0 + i], i < 16 + 255 (thread st: i = st and, st < 16, 256 + st);
         // the series has hankel_K + N - 1 samples
         auto w_fetch = [&](int64_t r0, double& w0, double& w1) {
@@ -281,7 +299,7 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
             const bool full = stage_full(r0);
             const bool more = s + 1 < nst;
             double tnext = 0.0, wn0 = 0.0, wn1 = 0.0;
-            if (st < L::TS && more) tnext = t_fetch(r0 + FZ_R);
+            if (!FIRST && st < L::TS && more) tnext = t_fetch(r0 + FZ_R);
             if (HK && more) w_fetch(r0 + FZ_R, wn0, wn1);
             // rows of T: the first columns stay in registers for the stage, the rest is read again per panel column
             // (the register file is what limits this kernel: 168 per wave)
@@ -290,40 +308,55 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
             const double* wb = sW + (s & 1) * L::WS + woff;
             d2 t[TLO];
 #pragma unroll
-            for (int i = 0; i < TLO; ++i) t[i] = *reinterpret_cast<const d2*>(tb + i * FZ_R);
+            for (int i = 0; i < TLO; ++i) t[i] = FIRST ? d2{0.0, 0.0} : *reinterpret_cast<const d2*>(tb + i * FZ_R);
             double* zs = Zs + (s & 1) * L::ZS + zoff;
-            const bool ok = r0 + 2 * p < kend;
-            const bool hk0 = r0 + 2 * p < P.hankel_K, hk1 = r0 + 2 * p + 1 < P.hankel_K;
-            const unsigned svoff = (full || ok) ? toff : 0xFFFFFFFFu;   // rows beyond the chunk are not stored
+            // rows beyond the chunk (the panel's last rows, in the last stage of the last chunk): loaded as zeros, not stored;
+            // rows below the last Hankel row (zero pad rows of D): they read the window of zeros
+            const unsigned vo_c = (full || r0 + 2 * p < kend) ? toff : 0xFFFFFFFFu;
+            const unsigned vo_n = (r0 + FZ_R + 2 * p < kend) ? toff : 0xFFFFFFFFu;
+            const double* wb0 = wb;
+            const double* wb1 = wb + 1;
+            if (HK && !full) {
+                if (!(r0 + 2 * p < P.hankel_K)) wb0 = sZero;
+                if (!(r0 + 2 * p + 1 < P.hankel_K)) wb1 = sZero;
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
             for (int g = 0; g < J / RS; ++g) {
 #pragma unroll
                 for (int jj = 0; jj < RS; ++jj) {
                     const int j = RS * g + jj;
-                    {
+                    if constexpr (!FIRST) {
                         const int jr = (j + PF) % J;
-                        ring[(jj + PF) % RS] = issue(jr, j + PF >= J ? r0 + FZ_R : r0);
+                        ring[(jj + PF) % RS] = issue(jr, j + PF >= J ? r0 + FZ_R : r0, j + PF >= J ? vo_n : vo_c);
                     }
                     if constexpr (!HK) {
                         const int jr = (j + DPF) % J;
-                        dring[(jj + DPF) % DS] = issue_d(jr, j + DPF >= J ? r0 + FZ_R : r0);
+                        dring[(jj + DPF) % DS] = issue_d(jr, j + DPF >= J ? r0 + FZ_R : r0, j + DPF >= J ? vo_n : vo_c);
                     }
-                    const Col c = ring[jj];
+                    const Col c = FIRST ? Col{d2{0.0, 0.0}, d2{0.0, 0.0}} : ring[jj];
                     d2 cd;
                     if constexpr (HK) {
-                        // D[row, gc0 + cg + 32 j] = y[row + gc0 + cg + 32 j] from the stage's window; zero rows below the last
-                        // Hankel row (only a stage that is not `full` has any).  No global load here: a load under a branch would
-                        // make the compiler drain the whole ring at the join.
-                        cd[0] = wb[32 * j];
-                        cd[1] = wb[32 * j + 1];
-                        if (!full) {
-                            cd[0] = hk0 ? cd[0] : 0.0;
-                            cd[1] = hk1 ? cd[1] : 0.0;
-                        }
+                        // D[row, gc0 + cg + 32 j] = y[row + gc0 + cg + 32 j] from the stage's window
+                        cd[0] = wb0[32 * j];
+                        cd[1] = wb1[32 * j];
                     } else {
                         cd = dring[jj % DS];
                     }
+                    d2 rr = d2{0.0, 0.0}, yn, zn;
+                    if constexpr (FIRST) {
+                        // k_first_shrink's statements (A = 0): the same clamp form of the threshold as below
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const double y1 = cd[q] / P.s_div;                // Y ./= dual_norm                        :181
+                            yn[q] = y1;
+                            const double tt = inv_mu * y1;
+                            const double x = cd[q] + tt;                      // A = 0                                  :188
+                            double ee = x - __builtin_fmin(__builtin_fmax(x, nthr_n), thr_n);
+                            if (nonnegE) ee = fz_pos(ee);
+                            zn[q] = (cd[q] - ee) + tt;                        //                                        :192
+                        }
+                    } else {
                     const double* vs = sVs + (cg + 32 * j) * L::VSP;
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -336,16 +369,14 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
                         a0 = __builtin_fma(t1[0], v[1], a0);
                         a1 = __builtin_fma(t1[1], v[1], a1);
                     }
-                    d2 rr, yn, zn;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         double a = q == 0 ? a0 : a1;
                         if (nonnegA) a = fz_pos(a);                       // A .= max.(A,0)                          :217-219
                         const double w = c.z[q] - a;
                         const double res = w - inv_mu * c.y[q];          // R_k = D - A - E                         :221
-                        const double resm = (full || ok) ? res : 0.0;    // (rows beyond the chunk: whatever the prefetch read)
-                        ss = __builtin_fma(resm, resm, ss);               // (a bound, never a result)
-                        rmax = __builtin_fmax(rmax, __builtin_fabs(resm)); // (a NaN never wins: the bound stays a bound)
+                        ss = __builtin_fma(res, res, ss);                 // (a bound, never a result)
+                        rmax = __builtin_fmax(rmax, __builtin_fabs(res)); // (a NaN never wins: the bound stays a bound)
                         rr[q] = res;
                         const double y1 = mu * w;                         // Y_{k+1} = Y + mu R                      :222
                         yn[q] = y1;
@@ -358,18 +389,18 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
                         if (nonnegE) ee = fz_pos(ee);                     //                                         :189-191
                         zn[q] = (cd[q] - ee) + tt;                       //                                         :192
                     }
-                    if (!full && !ok) zn = d2{0.0, 0.0};
+                    }
                     *reinterpret_cast<d2*>(zs + 32 * j * FZ_R) = zn;
                     {
                         const int64_t u = ubase(j, r0);
-                        fz_st(Rbase + u, Rp ? stleft - u : 0, svoff, rr);
-                        fz_st(P.Yout + u, stleft - u, svoff, yn);
-                        fz_st(P.Zout + u, stleft - u, svoff, zn);
+                        fz_st(Rbase + u, Rp ? stleft - u : 0, vo_c, rr);
+                        fz_st(P.Yout + u, stleft - u, vo_c, yn);
+                        fz_st(P.Zout + u, stleft - u, vo_c, zn);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (st < L::TS && more) sT[((s + 1) & 1) * L::TS + ti * FZ_R + tr] = tnext;
+            if (!FIRST && st < L::TS && more) sT[((s + 1) & 1) * L::TS + ti * FZ_R + tr] = tnext;
             if (HK && more) {
                 double* wnx = sW + ((s + 1) & 1) * L::WS;
                 wnx[st] = wn0;
@@ -378,18 +409,21 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
         };
 
         // prologue: T stage 0, window 0, first loads
-        if (st < L::TS) sT[ti * FZ_R + tr] = t_fetch(kbeg);
+        if (!FIRST && st < L::TS) sT[ti * FZ_R + tr] = t_fetch(kbeg);
         if (HK) {
             double w0, w1;
             w_fetch(kbeg, w0, w1);
             sW[st] = w0;
             if (st < 16) sW[256 + st] = w1;
         }
+        const unsigned vo_0 = (kbeg + 2 * p < kend) ? toff : 0xFFFFFFFFu;
+        if constexpr (!FIRST) {
 #pragma unroll
-        for (int j = 0; j < PF; ++j) ring[j] = issue(j, kbeg);
+            for (int j = 0; j < PF; ++j) ring[j] = issue(j, kbeg, vo_0);
+        }
         if constexpr (!HK) {
 #pragma unroll
-            for (int j = 0; j < DPF; ++j) dring[j] = issue_d(j, kbeg);
+            for (int j = 0; j < DPF; ++j) dring[j] = issue_d(j, kbeg, vo_0);
         }
         fz_barrier();   // B0
         for (int s = 0; s <= nst; ++s) {   // (stage s is swept while the MFMA waves work on stage s - 1)
@@ -423,7 +457,7 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
 }
 
 // blockIdx.x = chunk * (N / 256) + column block
-template <int RMAX, bool HK, bool NN, int RS>
+template <int RMAX, bool HK, bool NN, int RS, bool FIRST>
 __global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram(const FusedArgs P) {
     extern __shared__ __attribute__((aligned(16))) double fz_smem[];
     if (P.zero_slots && blockIdx.x == 0 && threadIdx.x < 72) P.zero_slots[threadIdx.x] = 0.0;
@@ -432,7 +466,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram(const FusedArgs P) {
     const int64_t kbeg = (int64_t)z * P.kchunk;
     if (z >= P.nz || kbeg >= P.M) return;
     const int64_t kend = kbeg + P.kchunk < P.M ? kbeg + P.kchunk : P.M;
-    fused_body<RMAX, HK, NN, RS>(P, kbeg, kend, FZ_NC * cb, P.slab + (size_t)z * P.N * P.N, fz_smem);
+    fused_body<RMAX, HK, NN, RS, FIRST>(P, kbeg, kend, FZ_NC * cb, P.slab + (size_t)z * P.N * P.N, fz_smem);
 }
 
 inline bool fz_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -484,31 +518,50 @@ int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
     return TLSQ_OK;
 }
 
+namespace {
+template <int RM, bool HKF, bool NNF, int RSF, bool FIRSTF>
+int fz_launch(Handle* h, const FusedArgs& a, unsigned grid) {
+    const size_t lds = (size_t)FzLds<RM>::TOTAL * sizeof(double);
+    static bool attr_set = false;   // (per instantiation; idempotent)
+    if (!attr_set) {
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+}  // namespace
+
+// first = true: iteration 1 (launch_first_shrink's arguments: Y_1 = D / s_div to Yout, Z_1 to Zout, inv_mu = 1 / mu_1,
+// thr_n = lambda / mu_1; Tm, Vs, Yin, Zin, R, mu, inv_mu_n, nonnegA, sumsq unused)
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
-                       const double* hankel_y, int64_t hankel_K, int maxslot) {
+                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first, double s_div) {
     if (!sumsq || maxslot > 7) maxslot = -1;
     FusedArgs a;
     a.D = hankel_y ? hankel_y : D;
     a.Tm = Tm;
     a.Vs = Vs;
-    a.Yin = Yin;
+    a.Yin = first ? Yout : Yin;
     a.Yout = Yout;
-    a.Zin = Zin;
+    a.Zin = first ? Zout : Zin;
     a.Zout = Zout;
-    a.R = R;
+    a.R = first ? nullptr : R;
     a.M = M;
     a.ld = M;
     a.N = (int)N;
-    a.r = (int)r;
+    a.r = first ? 0 : (int)r;
     a.mu = mu;
     a.inv_mu = inv_mu;
     a.inv_mu_n = inv_mu_n;
     a.thr_n = thr_n;
+    a.s_div = s_div;
     a.nonnegA = nonnegA;
     a.nonnegE = nonnegE;
-    a.sumsq = sumsq;
+    a.sumsq = first ? nullptr : sumsq;
     a.zero_slots = zero_slots;
     a.maxslot = maxslot;
     a.slab = pl.slab;
@@ -518,30 +571,20 @@ int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const dou
     a.ablate = [] { const char* e = dev_get(DEV_FUSED_ABLATE); return e ? atoi(e) : 0; }();
     const bool hk = hankel_y != nullptr, nn = nonnegA || nonnegE;
     const unsigned grid = (unsigned)(a.nz * (N / FZ_NC));
-#define FZ_LAUNCH(RM, HKF, NNF, RSF)                                                                                \
-    do {                                                                                                            \
-        const size_t lds = (size_t)FzLds<RM>::TOTAL * sizeof(double);                                               \
-        static bool attr_set = false;   /* (per instantiation; idempotent) */                                        \
-        if (!attr_set) {                                                                                            \
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF>),        \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);    \
-    } while (0)
-#define FZ_PICK(RM)                                               \
-    do {                                                          \
-        if (hk && nn) FZ_LAUNCH(RM, true, true, FZ_RS_HK);        \
-        else if (hk) FZ_LAUNCH(RM, true, false, FZ_RS_HK);        \
-        else if (nn) FZ_LAUNCH(RM, false, true, FZ_RS_D);         \
-        else FZ_LAUNCH(RM, false, false, FZ_RS_D);                \
+    if (first) {
+        if (hk) return nonnegE ? fz_launch<8, true, true, FZ_RS_HK, true>(h, a, grid) : fz_launch<8, true, false, FZ_RS_HK, true>(h, a, grid);
+        return nonnegE ? fz_launch<8, false, true, FZ_RS_D, true>(h, a, grid) : fz_launch<8, false, false, FZ_RS_D, true>(h, a, grid);
+    }
+#define FZ_PICK(RM)                                                                      \
+    do {                                                                                 \
+        if (hk && nn) return fz_launch<RM, true, true, FZ_RS_HK, false>(h, a, grid);     \
+        else if (hk) return fz_launch<RM, true, false, FZ_RS_HK, false>(h, a, grid);     \
+        else if (nn) return fz_launch<RM, false, true, FZ_RS_D, false>(h, a, grid);      \
+        else return fz_launch<RM, false, false, FZ_RS_D, false>(h, a, grid);             \
     } while (0)
     if (r <= 8) FZ_PICK(8);
     else FZ_PICK(16);
 #undef FZ_PICK
-#undef FZ_LAUNCH
-    TLSQ_HIP(h, hipGetLastError());
-    return TLSQ_OK;
 }
 
 }  // namespace tlsq

@@ -2019,10 +2019,31 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         {
             if (!(d_transient && k == 1)) TLSQ_TRY(panel_D(&D));   // (iteration 1 may still read the transient copy)
             if (y_pending) {   // k = 1: A is zero and Y not formed yet
-                TLSQ_TRY(launch_first_shrink<T>(h, D, Y, zmode ? (T*)nullptr : E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr,
-                                                ro.nonnegE ? 1 : 0));
+                bool first_fused = false;
+                if constexpr (std::is_same<T, double>::value) {
+                    // tall fp64 panels of 256 columns: the first shrink and the Gram of the Z_1 it writes in one kernel (fused.hip)
+                    const double* hy1 = (const double*)ro.hankel_y;
+                    if (zmode && !implicit_gram && !hook_svd && !large &&
+                        fused_zgram_ok(M, N, 0, hy1 ? nullptr : D, Y, Y, Z, Z, nullptr, hy1 != nullptr, thr, ro.hankel_geom) &&
+                        (hy1 || D)) {
+                        GramPlan pl1;
+                        TLSQ_TRY(fused_zgram_plan(h, M, N, &pl1));
+                        TLSQ_TRY(launch_fused_zgram(h, pl1, D, nullptr, nullptr, Y, Y, Z, Z, nullptr, M, N, 0, mu, inv_mu,
+                                                    0, 0.0, thr, ro.nonnegE ? 1 : 0, nullptr, nullptr, hy1, ro.hankel_K, -1, true,
+                                                    dual_norm));
+                        void* Gv;
+                        TLSQ_TRY(ws_get(h, Gslot[gcur], (size_t)N * N * 8, &Gv));
+                        TLSQ_TRY(gram_reduce(h, h->stream, pl1, (double*)Gv, N));
+                        TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
+                        g_ready = true;
+                        first_fused = true;
+                    }
+                }
+                if (!first_fused)
+                    TLSQ_TRY(launch_first_shrink<T>(h, D, Y, zmode ? (T*)nullptr : E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr,
+                                                    ro.nonnegE ? 1 : 0));
                 y_pending = false;
-                hbm_sweeps += (zmode ? 3.0 : 4.0) * panel_bytes;
+                hbm_sweeps += (zmode ? 3.0 : 4.0) * panel_bytes - (first_fused && ro.hankel_y ? panel_bytes : 0.0);
             } else {
                 TLSQ_TRY(launch_shrink<T>(h, D, A, Y, E, Z, n, (T)inv_mu, (T)thr, ro.nonnegE ? 1 : 0));  // :188-192
                 hbm_sweeps += 5.0 * panel_bytes;
