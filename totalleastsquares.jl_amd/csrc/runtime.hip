@@ -66,7 +66,11 @@ int set_err(Handle* h, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (h) h->err = buf;
+    if (h) {   // (a host-pointer call's download thread and the solver thread may both fail: one string, one writer at a time)
+        static std::mutex err_mu;
+        std::lock_guard<std::mutex> lk(err_mu);
+        h->err = buf;
+    }
     return code;
 }
 
@@ -194,11 +198,16 @@ struct LocalGroup {
             cv.notify_all();
             return true;
         }
-        // (wait_until on the system clock = pthread_cond_timedwait; wait_for goes through pthread_cond_clockwait, which the
-        //  ThreadSanitizer runtime of this toolchain does not intercept: it then believes the mutex is held across the wait)
-        if (cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(60), [&] { return gen != g || failed; }) &&
-            gen != g)
-            return true;
+        // The product waits on the steady clock (wait_for): a step of the wall clock (NTP, a resumed VM) must neither fail the
+        // group nor stretch the timeout.  Only the ThreadSanitizer build waits on the system clock (wait_until =
+        // pthread_cond_timedwait): wait_for goes through pthread_cond_clockwait, which the TSan runtime of this toolchain does
+        // not intercept - it then believes the mutex is held across the wait.
+#if defined(__SANITIZE_THREAD__) || defined(TLSQ_TSAN_BUILD)
+        const bool woke = cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(60), [&] { return gen != g || failed; });
+#else
+        const bool woke = cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || failed; });
+#endif
+        if (woke && gen != g) return true;
         --arrived;
         return false;
     }

@@ -3500,13 +3500,29 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     bool ae_sent = false;
     if (!transposed && !pad) {
         ResolvedOpts ro2 = ro;
+        // (the download thread shares the handle with the solver thread: it only ever takes the pinned-slot path of
+        //  staged_copy - below 1 MB that function would use the handle's own stream - the stager exists before the thread
+        //  does, set_err is serialised (runtime.hip), and a thread that cannot be created means the copy happens after the
+        //  decomposition as in a call without `s`; the guard joins on every way out of this scope)
+        struct JoinGuard {
+            std::thread& t;
+            ~JoinGuard() {
+                if (t.joinable()) t.join();
+            }
+        } ae_guard{ae_thread};
         const std::function<void()> send_ae = [&]() {
             if (dev || dA == A || dE == E) return;
-            ae_sent = true;
-            ae_thread = std::thread([&]() {
-                StageJob down[2] = {StageJob{A, ldA, dA, M, M, N, es, false}, StageJob{E, ldE, dE, M, M, N, es, false}};
-                ae_status = staged_copy(h, down, 2);
-            });
+            if ((size_t)n * es < ((size_t)1 << 20)) return;
+            if (staged_copy(h, nullptr, 0) < 0) return;   // (creates the staging workers' streams on this thread)
+            try {
+                ae_thread = std::thread([&]() {
+                    StageJob down[2] = {StageJob{A, ldA, dA, M, M, N, es, false}, StageJob{E, ldE, dE, M, M, N, es, false}};
+                    ae_status = staged_copy(h, down, 2);
+                });
+                ae_sent = true;
+            } catch (...) {
+                ae_sent = false;
+            }
         };
         ro2.ae_final = &send_ae;
         status = rpca_core<T>(h, dD, M, N, ro2, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,

@@ -74,8 +74,13 @@ static int stager_get(Handle* h, Stager** out) {
                        ((size_t)want * 2 * kSlotBytes) >> 20);
     }
     for (int w = 0; w < s->nworkers; ++w) {
-        TLSQ_HIP(h, hipStreamCreateWithFlags(&s->stream[w], hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) TLSQ_HIP(h, hipEventCreateWithFlags(&s->ev[w][k], hipEventDisableTiming));
+        hipError_t e = hipStreamCreateWithFlags(&s->stream[w], hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s->ev[w][k], hipEventDisableTiming);
+        if (e != hipSuccess) {   // (a half-built stager must not survive: later calls would reuse its missing streams)
+            (void)hipGetLastError();
+            stager_destroy(h);
+            return set_err(h, TLSQ_ERR_HIP, "staging: cannot create the worker streams / events: %s", hipGetErrorString(e));
+        }
     }
     *out = s;
     return TLSQ_OK;
@@ -87,6 +92,11 @@ static int stager_get(Handle* h, Stager** out) {
 int staged_copy(Handle* h, const StageJob* jobs, int njobs) {
     size_t total = 0;
     for (int j = 0; j < njobs; ++j) total += (size_t)std::max<int64_t>(jobs[j].rows, 0) * (size_t)std::max<int64_t>(jobs[j].cols, 0) * jobs[j].esz;
+    if (njobs == 0) {   // (no job: make sure the staging workers' streams and pinned slots exist - rpca_entry calls this
+                        //  before it hands copies to a thread of its own)
+        Stager* s0 = nullptr;
+        return stager_get(h, &s0);
+    }
     if (total == 0) return TLSQ_OK;
     if (total < ((size_t)1 << 20)) {   // small: the plain copies
         for (int j = 0; j < njobs; ++j) {

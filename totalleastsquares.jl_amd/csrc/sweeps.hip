@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256) void k_rebuild_update_shrink(const T* __restri
 // E_k = soft_th(D - A_{k-1} + Y_k / mu_k, lambda / mu_k) (k_final_e: exact zeros where the reference has them) from the
 // previous iteration's factors and Y_k - which is why Y is double-buffered here instead of E and Z.  The two identities
 // hold up to the rounding of Z (one ulp of |D|), the same size as the rounding of the reference's own statements.
-template <typename T, int RMAX, int ROWS, bool HK>
+// ZIP (in place, Z_{k+1} over Z_k): Z is not used and every read of Z_k goes through Zo as well - two restrict-qualified
+// pointers to one panel, one of them written, would be undefined behaviour however harmless the access order is.
+template <typename T, int RMAX, int ROWS, bool HK, bool ZIP>
 __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const double* __restrict__ Tm,
                                                 const double* __restrict__ Vs, const T* __restrict__ Yin,
                                                 T* __restrict__ Yout, const T* __restrict__ Z, T* __restrict__ Zo,
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
             } else {
                 d = __builtin_nontemporal_load(reinterpret_cast<const VR*>(D) + idx);
             }
-            const VR z = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Z) + idx);
+            const VR z = __builtin_nontemporal_load(reinterpret_cast<const VR*>(ZIP ? (const T*)Zo : Z) + idx);
             const VR y = __builtin_nontemporal_load(reinterpret_cast<const VR*>(Yin) + idx);
             const double* vs = sVs + c * RMAX;
             double acc[ROWS];
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
             }
             if (R) __builtin_nontemporal_store(rr, reinterpret_cast<VR*>(R) + idx);
             __builtin_nontemporal_store(yn, reinterpret_cast<VR*>(Yout) + idx);
-            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Zo) + idx);   // (Zo == Z: in place, every entry read before it is written)
+            __builtin_nontemporal_store(zn, reinterpret_cast<VR*>(Zo) + idx);   // (ZIP: in place, every entry read before it is written)
         }
     }
     if (sumsq) {
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void k_zsweep(const T* __restrict__ D, const d
 }
 
 // the same sweep with A_k read from memory (ranks above 32: A does not fit a thread's registers as factors)
-template <typename T, int VEC>
+template <typename T, int VEC, bool ZIP>
 __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* __restrict__ A, const T* __restrict__ Yin,
                                                     T* __restrict__ Yout, const T* __restrict__ Z, T* __restrict__ Zo,
                                                     T* __restrict__ R, int64_t n,
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
         const V d = __builtin_nontemporal_load(reinterpret_cast<const V*>(D) + i);
         V a = __builtin_nontemporal_load(reinterpret_cast<const V*>(A) + i);
         const V y = __builtin_nontemporal_load(reinterpret_cast<const V*>(Yin) + i);
-        const V z = __builtin_nontemporal_load(reinterpret_cast<const V*>(Z) + i);
+        const V z = __builtin_nontemporal_load(reinterpret_cast<const V*>(ZIP ? (const T*)Zo : Z) + i);
         V rr, yn, zn;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
     }
     for (int64_t i = nv * VEC + tid; i < n; i += stride) {
         T ac = A[i], r1, y1, z1;
-        one(D[i], ac, Yin[i], Z[i], r1, y1, z1);
+        one(D[i], ac, Yin[i], ZIP ? Zo[i] : Z[i], r1, y1, z1);
         if (nonnegA) A[i] = ac;
         if (R) R[i] = r1;
         Yout[i] = y1;
@@ -966,12 +968,19 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
         if (hankel_y || row0 != 0 || row1 != M) return set_err(h, TLSQ_ERR_ARG, "zsweep: explicit A needs the whole real panel");
         const int64_t n = M * N;
         constexpr int VEC = 16 / sizeof(T);
-        if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(Zout) && aligned16(R))
-            hipLaunchKernelGGL((k_zsweep_lin<T, VEC>), dim3(grid_for(n / VEC + 1)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z,
-                               Zout, R, n, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
-        else
-            hipLaunchKernelGGL((k_zsweep_lin<T, 1>), dim3(grid_for(n)), dim3(256), 0, h->stream, D, A, Yin, Yout, Z, Zout, R, n, mu,
-                               inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot);
+        const bool zip = Zout == Z;
+        const T* Zr = zip ? nullptr : Z;
+#define ZL_LAUNCH(VV, ZP, NG)                                                                                          \
+    hipLaunchKernelGGL((k_zsweep_lin<T, VV, ZP>), dim3(grid_for(NG)), dim3(256), 0, h->stream, D, A, Yin, Yout, Zr, Zout, R, n, mu, \
+                       inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot)
+        if (aligned16(D) && aligned16(A) && aligned16(Yin) && aligned16(Yout) && aligned16(Z) && aligned16(Zout) && aligned16(R)) {
+            if (zip) ZL_LAUNCH(VEC, true, n / VEC + 1);
+            else ZL_LAUNCH(VEC, false, n / VEC + 1);
+        } else {
+            if (zip) ZL_LAUNCH(1, true, n);
+            else ZL_LAUNCH(1, false, n);
+        }
+#undef ZL_LAUNCH
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }
@@ -992,16 +1001,21 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
     if (env_ct >= 8 && env_ct <= 64) ct = env_ct;
     const int rows = two ? 2 : 1;
     const dim3 grid((unsigned)(((row1 - row0) / rows + 255) / 256), (unsigned)((N + ct - 1) / ct));
-#define ZS_LAUNCH(RM, RW)                                                                                             \
-    do {                                                                                                              \
-        if (hankel_y)                                                                                                 \
-            hipLaunchKernelGGL((k_zsweep<T, RM, RW, true>), grid, dim3(256), 0, h->stream, hankel_y, Tm, Vs, Yin, Yout, Z, Zout, R, \
-                               M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
-                               hankel_K, row0, row1, maxslot, hg);                                                    \
-        else                                                                                                          \
-            hipLaunchKernelGGL((k_zsweep<T, RM, RW, false>), grid, dim3(256), 0, h->stream, D, Tm, Vs, Yin, Yout, Z, Zout, R, M, \
-                               (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots,   \
-                               (int64_t)0, row0, row1, maxslot, hg);                                                  \
+    const bool zip = Zout == Z;
+    const T* Zr = zip ? nullptr : Z;
+#define ZS_LAUNCH2(RM, RW, HKF, ZP)                                                                                   \
+    hipLaunchKernelGGL((k_zsweep<T, RM, RW, HKF, ZP>), grid, dim3(256), 0, h->stream, HKF ? hankel_y : D, Tm, Vs, Yin, Yout, Zr, \
+                       Zout, R, M, (int)N, (int)r, ct, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, \
+                       HKF ? hankel_K : (int64_t)0, row0, row1, maxslot, hg)
+#define ZS_LAUNCH(RM, RW)                                \
+    do {                                                 \
+        if (hankel_y) {                                  \
+            if (zip) ZS_LAUNCH2(RM, RW, true, true);     \
+            else ZS_LAUNCH2(RM, RW, true, false);        \
+        } else {                                         \
+            if (zip) ZS_LAUNCH2(RM, RW, false, true);    \
+            else ZS_LAUNCH2(RM, RW, false, false);       \
+        }                                                \
     } while (0)
     if (two) {
         if (r <= 8) ZS_LAUNCH(8, 2);
@@ -1013,6 +1027,7 @@ int launch_zsweep(Handle* h, const T* D, const double* Tm, const double* Vs, T* 
         else ZS_LAUNCH(32, 1);
     }
 #undef ZS_LAUNCH
+#undef ZS_LAUNCH2
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
