@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libtlsqhip.so")
-SOURCES = ["sweeps.hip", "fused.hip", "gemm.hip", "jacobi.hip", "hankel.hip", "lanczos.hip", "subspace.hip", "matfun.hip", "cholesky.hip", "tsqr.hip", "batched.hip", "complex.hip", "grassmann.hip", "runtime.hip", "staging.hip", "solver.hip", "api.hip"]
+SOURCES = ["sweeps.hip", "fused.hip", "gemm.hip", "jacobi.hip", "hankel.hip", "lanczos.hip", "subspace.hip", "matfun.hip", "cholesky.hip", "tsqr.hip", "batched.hip", "complex.hip", "grassmann.hip", "runtime.hip", "staging.hip", "svdstep.hip", "solver.hip", "solver_complex.hip", "entry.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
 
@@ -33,7 +33,8 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "internal.hpp"), os.path.join(ROOT, "include", "tlsq.h")]
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "internal.hpp"), os.path.join(CSRC, "svdstep.hpp"),
+               os.path.join(ROOT, "include", "tlsq.h")]
     extra = os.environ.get("TLSQ_EXTRA_FLAGS", "").split()   # development builds (tools/kbench.py ablations)
     force = force or bool(extra)
     objs = []

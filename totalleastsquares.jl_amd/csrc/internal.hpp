@@ -192,6 +192,24 @@ inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, doubl
 }
 
 
+// small-matrix helpers of solver.hip that the complex path (solver_complex.hip) shares:
+// sqrt(lambda_max) of a Gram matrix already on the device (Lanczos from a power start; dense fall-back); the full
+// eigen-decomposition of G (V in workspace slot vslot); X = V[:, sel]
+int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
+                      double stop_above_sigma = 0.0);
+int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps, bool allow_warm = false,
+             int vslot = WS_V, bool need_all_vectors = false);
+int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X);
+// G (workspace slot `slot`) = Z'Z summed over the row shards
+template <typename T>
+inline int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out, int slot = WS_G) {
+    void* G;
+    TLSQ_TRY(ws_get(h, slot, (size_t)N * N * 8, &G));
+    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
+    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
+    *G_out = (double*)G;
+    return TLSQ_OK;
+}
 // sigma_max of Z (device M x N, ld) through the Gram matrix in workspace slot gslot (the default `opnorm`)
 template <typename T>
 int opnorm_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double* out, int64_t* sweeps,

@@ -14,14 +14,14 @@
 #include <numeric>
 #include <thread>
 
-#include "internal.hpp"
+#include "svdstep.hpp"
 
 namespace tlsq {
 
 // sqrt(lambda_max) of the Gram already sitting in G (N x N, ld N): Lanczos to the requested relative residual
 // bound, exact Jacobi eigenvalues as the fallback.  uses WS_B, WS_LAM.
-static int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
-                             double stop_above_sigma = 0.0) {
+int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
+                      double stop_above_sigma) {
     double lmax = 0.0;
     int steps = 0;
     // A tight answer with no yes/no shortcut (the set-up norm ||D||_2, src/robustPCA.jl:177): plain Lanczos needs hundreds
@@ -114,16 +114,6 @@ static int opnorm_power(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld,
     return TLSQ_OK;
 }
 
-// G (WS_G) = Z'Z summed over the row shards
-template <typename T>
-static int gram_allreduce(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** G_out, int slot = WS_G) {
-    void* G;
-    TLSQ_TRY(ws_get(h, slot, (size_t)N * N * 8, &G));
-    TLSQ_TRY(gram_any(h, Z, Prec<T>::f32, M, N, ld, (double*)G, N));
-    TLSQ_TRY(comm_allreduce(h, (double*)G, (size_t)N * N, ncclSum));
-    *G_out = (double*)G;
-    return TLSQ_OK;
-}
 
 // full eigen-decomposition of G by the block Jacobi solver: V in WS_V
 // does the full solver go through the Cholesky factor (zero columns for numerically-zero eigenvalues)?
@@ -132,8 +122,8 @@ static bool chol_route(int64_t N) {
     return N > 64 && !no_chol;
 }
 
-static int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps,
-                    bool allow_warm = false, int vslot = WS_V, bool need_all_vectors = false) {
+int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps, bool allow_warm, int vslot,
+             bool need_all_vectors) {
     void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
     TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
@@ -187,7 +177,6 @@ int svd_via_gram(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double
 // then one-sided Jacobi on R' (jacobi.hip).  Both steps are orthogonal transformations, so every singular value
 // carries an absolute error of a few eps * sigma_max like LAPACK's gesdd (src/robustPCA.jl:194) — the Gram route only
 // reaches eps * sigma_max^2 / sigma.  V in WS_V (all N right singular vectors), s = all N singular values.
-static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X);
 
 template <typename T>
 int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** V_out, SmallSvd& s, int64_t* sweeps) {
@@ -256,838 +245,6 @@ int svd_via_r(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ld, double** 
     return TLSQ_OK;
 }
 
-// The N x N operator the small solvers work on: either the explicit Gram matrix G = Z'Z (summed over the row
-// shards), or - large mode, where forming G would cost far more than the few products the subspace solver needs
-// (2 M N^2 flops against 4 M N p per product) - the panel itself: G X = Z'(Z X), two streaming passes over Z.
-struct GramOp {
-    const double* G = nullptr;   // explicit (N x N, ld N)
-    const void* Z = nullptr;     // implicit: M x N panel (ld ldZ), fp32 when z_f32
-    int z_f32 = 0;
-    int64_t M = 0, ldZ = 0;
-    // products of an fp32 panel may round the block to fp32 on the way (op_gram_f32: 6e-8 per entry): fine for the range finder
-    // of the randomized hook, which accepts whatever comes out; NOT for the certified solver, whose acceptance test wants
-    // residuals of 2e-13 (16384 x 8192 fp32 in the default mode ended with "could not be served" while this was unconditional)
-    bool lowp_ok = false;
-    bool implicit() const { return G == nullptr; }
-};
-
-// Y (N x p, ld N) = G X
-static int op_apply(Handle* h, const GramOp& op, int64_t N, const double* X, double* Y, int64_t p) {
-    if (p <= 0) return TLSQ_OK;
-    if (!op.implicit()) return launch_symm_skinny(h, op.G, N, X, Y, N, p);
-    // fp32 panels, blocks of more than 8 columns: both halves on the fp32 MFMA (gemm.hip, op_gram_f32) - the widening kernels
-    // below run on the fp64 MFMA at half the rate (narrow blocks, the Lanczos vectors, are bandwidth-bound either way)
-    if (op.z_f32 && op.lowp_ok && p > 8 && !dev_is(DEV_NO_F32_SKINNY, '1')) {
-        for (int64_t c0 = 0; c0 < p; c0 += 96) {
-            const int64_t pc = std::min<int64_t>(96, p - c0);
-            TLSQ_TRY(op_gram_f32(h, (const float*)op.Z, op.ldZ, op.M, N, X + (size_t)c0 * N, N, Y + (size_t)c0 * N, N, pc));
-        }
-        TLSQ_TRY(comm_allreduce(h, Y, (size_t)N * p, ncclSum));
-        return TLSQ_OK;
-    }
-    void* Tv;
-    TLSQ_TRY(ws_get(h, WS_OPT, (size_t)op.M * std::min<int64_t>(p, 96) * 8, &Tv));
-    for (int64_t c0 = 0; c0 < p; c0 += 96) {
-        const int64_t pc = std::min<int64_t>(96, p - c0);
-        TLSQ_TRY(tsmm_mixed(h, op.Z, op.z_f32, op.ldZ, X + (size_t)c0 * N, N, (double*)Tv, op.M, op.M, N, pc));
-        TLSQ_TRY(ztmm_mixed(h, op.Z, op.z_f32, op.ldZ, (const double*)Tv, op.M, Y + (size_t)c0 * N, N, op.M, N, pc));
-    }
-    TLSQ_TRY(comm_allreduce(h, Y, (size_t)N * p, ncclSum));
-    return TLSQ_OK;
-}
-
-// sigma_max of the panel behind an implicit operator (Lanczos on Z'Z through products); the same stopping rules
-// as sigma_max_of_gram
-static int sigma_max_of_op(Handle* h, const GramOp& op, int64_t N, double rel_tol, double* out,
-                           double stop_above_sigma = 0.0) {
-    double lmax = 0.0;
-    int steps = 0;
-    const LzApply apply = [&](const double* q, double* w) -> int { return op_apply(h, op, N, q, w, 1); };
-    const int st = lanczos_lmax_op(h, N, apply, rel_tol, 1000, &lmax, &steps, 0.0, stop_above_sigma * stop_above_sigma);
-    if (st < 0) return st;
-    *out = std::sqrt(lmax);   // (no dense fallback in large mode: the value after 1000 steps stands)
-    return TLSQ_OK;
-}
-
-// ---- warm-started subspace iteration (subspace.hip) ------------------------------------------------
-struct SubspaceState {
-    bool valid = false;
-    bool allow_cold = true;
-    int64_t p = 0;       // columns of X (WS_SX, N x p)
-    int64_t ntop = 0;    // the first ntop columns of X were >= 1/mu in the iteration that produced them
-    // hook mode (`svd = rsvd`-style user hook, src/robustPCA.jl:195-197): rank-`hook_rank` randomized SVD from a
-    // fresh random block, fixed number of passes, no convergence test and no count certificate
-    int64_t hook_rank = 0;
-    uint64_t hook_seed = 0;
-    int64_t fast = 0, full = 0, steps = 0;
-    // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
-    enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4, FAIL_WINDOW = 5 };
-    int fail = FAIL_NONE;
-    bool skip_certificate = false;   // the caller certifies the count itself (late iterations, see svd_precise_fast)
-    // deferred certificate: svd_subspace returns with *ok = true as soon as the Lanczos steps of the certificate are
-    // queued; the caller queues its own work (the rebuild) behind them and then asks svd_subspace_certify
-    bool defer_certificate = false;
-    bool cert_pending = false;
-    // ... and its kernels run on the handle's second stream with a mailbox region of their own (cert_async): the caller may
-    // queue anything that does not modify G or the block X on the main stream meanwhile - rpca_core queues the factor
-    // product, the next sweep and the next Gram before it asks for the verdict
-    bool cert_async = false;
-    volatile double* cert_mb = nullptr;   // where cert_finish polls (nullptr: the main mailbox)
-    // asynchronous form: the two kernels are not queued by svd_subspace itself but by whoever calls cert_launch - rpca_core does
-    // once the HBM-bound sweep is through (beside the sweep they cost it ~8 % of its bandwidth; beside the MFMA-bound Gram of
-    // the next iteration they are not noticed)
-    std::function<int()> cert_launch;
-    // Speculative factor product of the rebuild (rpca_core): queued right behind k_ritz_finish of a warm block's first step,
-    // with the selection, the weights and the count taken from the device-side decision block that kernel writes - the host
-    // round trip (poll, sort, count, launch: ~10 us) is then hidden behind the product instead of standing in front of it.
-    // The host checks afterwards that the device decided what it decides itself (dev_ok, dev_r); anything else - a second
-    // step, a re-ordered block, a rank that needs more accumulator tiles - simply launches the product again.
-    struct SpecRebuild {
-        bool enable = false;             // the caller wants it for this call (buffers below are valid)
-        const void* Z = nullptr;
-        int z_f32 = 0;
-        int64_t M = 0, ldz = 0;
-        double *Tout = nullptr, *Vs = nullptr;   // room for 32 columns each
-        bool nukeA = true;
-        bool launched = false;           // result: a product was queued in the step that converged ...
-        int nct = 0;                     // ... with this many 16-column accumulator tiles
-        bool dev_ok = false;             // ... and this is what the device decided
-        int64_t dev_r = 0;
-        std::function<void()> before_launch;   // phase accounting of the caller: the eig window ends where the product starts
-    } spec;
-    LanczosRun cert;
-    int q_warm = 3;        // multiplications by G applied to the top columns of a warm block per step
-    int q_floor = 1;       // smallest count that may be tried again (raised when a count needed a second step)
-    double chol_piv = 0.0; // smallest CholeskyQR pivot of the previous step on this warm block (one-pass guess, launch_orth)
-    int64_t chol_p = 0;    //   ... and the block width it was measured at
-    int64_t cold_p = 18;   // block size of a cold start
-    int extra_steps = 0;   // added to the step budget (retries in large mode)
-    // Uncertainty of an eigenvalue of the computed Gram matrix relative to lambda_max (rounding of G = Z'Z, Ritz
-    // residuals).  An eigenvalue within dlam = noise_rel * lambda_max of the threshold (1/mu)^2 cannot be counted
-    // reliably on this route (FAIL_WINDOW: the caller decides on the TSQR route), and the tail certificate has to
-    // clear the threshold by the same margin.  0: no window (large mode, where no other solver exists).
-    double noise_rel = 0.0;
-    double dlam = 0.0;     // noise_rel * lambda_max of the last call
-    // count certificate in flight (scaled by 1 / tau^2): deflated matrix, pass mark, which bound was queued
-    const double* cert_GD = nullptr;
-    int64_t cert_N = 0;
-    double cert_margin = 0.0, cert_seq = 0.0;
-    int cert_ntile = 0;
-    bool cert_power = false;
-    int64_t n_power = 0, n_power_l2 = 0, n_lanczos_cert = 0;   // statistics: served by S^2 / S^4 / Lanczos
-    int64_t n_rr_fast = 0, n_rr_declined = 0;                  // steps served / declined by the fused Rayleigh-Ritz kernel
-    int rr_streak = 0, rr_skip = 0;                            // consecutive declines / calls in which it is not tried
-    double cert_tail = 0.0;   // Lanczos estimate of lambda_max(GD) / tau^2 of the last failed certificate (0: unknown)
-};
-
-// the asynchronous certificate's region of the mailbox (in doubles; the main region - flag at [0], payloads from [8] - ends
-// below it for every block size in use)
-constexpr size_t kCertMailboxOffset = 2048;
-
-// runs a scope's launches on another stream of the handle (every launcher takes h->stream)
-struct StreamScope {
-    Handle* h;
-    hipStream_t saved;
-    StreamScope(Handle* hh, hipStream_t s) : h(hh), saved(hh->stream) {
-        if (s) h->stream = s;
-    }
-    ~StreamScope() { h->stream = saved; }
-};
-
-// ---- count certificate: lambda_max(GD) < margin for the deflated, scaled Gram matrix GD ---------------------------
-// Matrix powers first: lambda_max(S) <= ||S^(2^k)||_F^(1/2^k) for symmetric S - rigorous, deterministic upper bounds
-// from plain MFMA contractions (a Lanczos Ritz value is only a LOWER bound of lambda_max).  ||GD^2||_F comes from one
-// fused kernel whose per-tile sums land in the host-visible mailbox (k_sq_norm in subspace.hip); ||GD^4||_F and, when
-// that is still too coarse, a Lanczos run with the usual 1.5x safety factor follow synchronously - rarely.
-// ||S^(2^levels)||_F^2 of the symmetric S = GD through the general MFMA GEMM (slab reduction with the norm by-product),
-// partial sums read back and added on the host in order: the slow but general form (no mailbox, second squaring)
-static int power_norm_sync(Handle* h, SubspaceState& st, int levels, double* out, int first_level = 0) {
-    // out[l - first_level] = ||S^(2^l)||_F^2 for l = max(first_level, 1) .. levels (first_level 0: only the last one)
-    const int64_t N = st.cert_N;
-    void *P[2], *part;
-    const size_t pslots = (size_t)std::max<int64_t>(4096, ((N + 31) / 32) * ((N + 31) / 32 + 1) / 2);
-    TLSQ_TRY(ws_get(h, WS_CP1, (size_t)N * N * 8, &P[0]));
-    if (levels >= 2) TLSQ_TRY(ws_get(h, WS_CP2, (size_t)N * N * 8, &P[1]));
-    // N a multiple of 128 (round 4): squarings through k_small_mm_blk (8 us instead of ~30 through the split-K product), the norm
-    // of S^(2^l) from k_sq_norm_blk applied to S^(2^(l-1)) - tile sums to the certificate's mailbox region, added in tile order
-    {
-        const int64_t ntl = (N + 31) / 32;
-        const size_t need = (size_t)(kCertMailboxOffset + 16 + ntl * (ntl + 1) / 2) * 8;
-        if (sq_norm_blk_ok(N) && h->mailbox && need <= h->mailbox_bytes && !dev_is(DEV_NO_MAILBOX, '1')) {
-            void* scal;
-            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-            unsigned int* ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 336);   // (the one of power_cert_begin)
-            if (!h->cert_ticket_ready) {
-                TLSQ_HIP(h, hipMemsetAsync(ticket, 0, 4, h->stream));
-                h->cert_ticket_ready = true;
-            }
-            const int l0 = first_level > 0 ? first_level : levels;
-            const double* cur = st.cert_GD;
-            volatile double* mb = h->mailbox + kCertMailboxOffset;
-            bool mail_ok = true;
-            for (int l = 1; l <= levels && mail_ok; ++l) {
-                if (l >= l0) {
-                    const double seq = (h->mail_seq += 1.0);
-                    int ntile = 0;
-                    TLSQ_TRY(launch_sq_norm(h, cur, N, h->mailbox_dev + kCertMailboxOffset, ticket, seq, &ntile));
-                    const double t_poll = now_ms();
-                    while (mb[0] != seq && now_ms() - t_poll < 2000.0) {
-                    }
-                    if (mb[0] != seq) {
-                        mail_ok = false;
-                        break;
-                    }
-                    double a = 0.0;
-                    for (int t = 0; t < ntile; ++t) a += mb[16 + t];
-                    out[l - l0] = a;
-                }
-                if (l < levels) {
-                    double* dst = (double*)P[(l - 1) & 1];
-                    bool sq_ok = false;
-                    TLSQ_TRY(matfun_square(h, cur, dst, N, &sq_ok));
-                    if (!sq_ok) {
-                        mail_ok = false;
-                        break;
-                    }
-                    cur = dst;
-                }
-            }
-            if (mail_ok) return TLSQ_OK;
-            h->mailbox_bytes = 0;   // (never seen in practice; classic read-backs from now on)
-        }
-    }
-    TLSQ_TRY(ws_get(h, WS_CPART, pslots * 8 * (size_t)std::max(1, levels), &part));
-    int nb = 0;
-    const double* src = st.cert_GD;
-    for (int l = 1; l <= levels; ++l) {
-        double* dst = (double*)P[(l - 1) & 1];
-        TLSQ_TRY(gemm_mixed(h, true, true, src, 0, N, src, 0, N, dst, 0, N, N, N, N, true, nullptr,
-                            (double*)part + (size_t)(l - 1) * pslots, &nb));
-        src = dst;
-    }
-    std::vector<double> hp(pslots * (size_t)levels);
-    TLSQ_HIP(h, hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    const int l0 = first_level > 0 ? first_level : levels;
-    for (int l = l0; l <= levels; ++l) {
-        double a = 0.0;
-        for (int i = 0; i < nb; ++i) a += hp[(size_t)(l - 1) * pslots + (size_t)i];
-        out[l - l0] = a;
-    }
-    return TLSQ_OK;
-}
-
-static int power_cert_begin(Handle* h, SubspaceState& st) {
-    const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
-    const int64_t N = st.cert_N;
-    const int64_t nt = (N + 31) / 32;
-    st.cert_seq = 0.0;
-    st.cert_mb = nullptr;
-    if (!(h->mailbox && !no_mailbox && (size_t)(kCertMailboxOffset + 16 + nt * (nt + 1) / 2) * 8 <= h->mailbox_bytes)) return TLSQ_OK;
-    void* scal;
-    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 336);   // self-resetting
-    if (!h->cert_ticket_ready) {   // (fresh workspace memory is not zero)
-        TLSQ_HIP(h, hipMemsetAsync(ticket, 0, 4, h->stream));
-        h->cert_ticket_ready = true;
-    }
-    st.cert_seq = (h->mail_seq += 1.0);
-    const size_t mb_off = st.cert_async ? kCertMailboxOffset : 0;
-    st.cert_mb = h->mailbox + mb_off;
-    TLSQ_TRY(launch_sq_norm(h, st.cert_GD, N, h->mailbox_dev + mb_off, ticket, st.cert_seq, &st.cert_ntile));
-    return TLSQ_OK;
-}
-
-static int cert_finish(Handle* h, SubspaceState& st, bool* pass) {
-    *pass = false;
-    double lmax = 0.0;
-    int steps = 0;
-    if (!st.cert_power) {
-        const int lst = lanczos_finish(h, st.cert, &lmax, &steps);
-        if (lst < 0) return lst;
-        ++st.n_lanczos_cert;
-        *pass = lmax * 1.5 < st.cert_margin;
-        return TLSQ_OK;
-    }
-    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
-    double a = -1.0;
-    if (st.cert_seq != 0.0) {
-        volatile double* mb = st.cert_mb ? st.cert_mb : h->mailbox;
-        const double t_poll = now_ms();
-        while (mb[0] != st.cert_seq && now_ms() - t_poll < 2000.0) {
-        }
-        if (mb[0] == st.cert_seq) {
-            a = 0.0;
-            for (int t = 0; t < st.cert_ntile; ++t) a += mb[16 + t];   // tile order: reproducible
-        } else {
-            h->mailbox_bytes = 0;   // never seen in practice; classic read-backs from now on
-        }
-    }
-    if (a < 0.0) TLSQ_TRY(power_norm_sync(h, st, 1, &a));
-    const double b1 = std::isfinite(a) ? std::pow(a, 0.25) : std::numeric_limits<double>::infinity();
-    if (dbg) fprintf(stderr, "  power certificate: bound1=%.4f margin=%.6f\n", b1, st.cert_margin);
-    if (b1 < st.cert_margin) {
-        ++st.n_power;
-        *pass = true;
-        return TLSQ_OK;
-    }
-    if (!std::isfinite(a)) return TLSQ_OK;   // NaN / inf in the deflated matrix: not certified
-    // one more squaring tightens the bound from rank^(1/4) to rank^(1/8) above lambda_max
-    double b = 0.0;
-    TLSQ_TRY(power_norm_sync(h, st, 2, &b));
-    const double b2 = std::isfinite(b) ? std::pow(b, 0.125) : std::numeric_limits<double>::infinity();
-    if (dbg) fprintf(stderr, "  power certificate: bound2=%.4f\n", b2);
-    if (b2 < st.cert_margin) {
-        ++st.n_power_l2;
-        *pass = true;
-        return TLSQ_OK;
-    }
-    // Still too coarse: the tail is flat and close to the mark (late iterations of a Hankel filter: hundreds of values
-    // at 0.7x the threshold).  Three more squarings bring the bound to rank^(1/64) above lambda_max, still rigorous;
-    // a Lanczos run (a LOWER bound, hence the 1.5x safety factor) screens first where an N^3 product is not small.
-    const bool no_deep = dev_is(DEV_NO_DEEP_POWERS, '1');
-    bool lanczos_done = false;
-    if (st.cert_N > 1024 || no_deep) {
-        const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
-        if (lst < 0) return lst;
-        ++st.n_lanczos_cert;
-        lanczos_done = true;
-        if (lmax * 1.5 < st.cert_margin) {
-            *pass = true;
-            st.cert_tail = 0.0;
-            return TLSQ_OK;
-        }
-        st.cert_tail = lmax;
-        if (lmax >= st.cert_margin || no_deep) return TLSQ_OK;   // an eigenvalue above the mark: the count is wrong
-    }
-    double c[3] = {0.0, 0.0, 0.0};
-    TLSQ_TRY(power_norm_sync(h, st, 5, c, 3));
-    const double inf = std::numeric_limits<double>::infinity();
-    const double b3 = std::isfinite(c[0]) ? std::pow(c[0], 1.0 / 16.0) : inf;
-    const double b4 = std::isfinite(c[1]) ? std::pow(c[1], 1.0 / 32.0) : inf;
-    const double b5 = std::isfinite(c[2]) ? std::pow(c[2], 1.0 / 64.0) : inf;
-    if (dbg) fprintf(stderr, "  power certificate: bound3=%.4f bound4=%.4f bound5=%.4f\n", b3, b4, b5);
-    if (std::min(b3, std::min(b4, b5)) < st.cert_margin) {
-        ++st.n_power_l2;
-        *pass = true;
-        st.cert_tail = 0.0;
-        return TLSQ_OK;
-    }
-    if (lanczos_done) return TLSQ_OK;
-    const int lst = lanczos_lmax_f64(h, st.cert_GD, st.cert_N, st.cert_N, 0.02, 48, &lmax, &steps, st.cert_margin);
-    if (lst < 0) return lst;
-    ++st.n_lanczos_cert;
-    *pass = lmax * 1.5 < st.cert_margin;
-    st.cert_tail = *pass ? 0.0 : lmax;
-    return TLSQ_OK;
-}
-
-// one stream-ordered upload of an index list and a weight list of the same length r into `aux`
-// (layout: int32 sel[r], padding to 8 bytes, double w[r]); returns the two device pointers
-static int upload_sel_weights(Handle* h, void* aux, const std::vector<int32_t>& sel, const std::vector<double>& w,
-                              int32_t** dsel, double** dw) {
-    const size_t r = sel.size();
-    const size_t off = ((r * 4 + 7) / 8) * 8;
-    std::vector<char> buf(off + r * 8);
-    memcpy(buf.data(), sel.data(), r * 4);
-    memcpy(buf.data() + off, w.data(), r * 8);
-    TLSQ_TRY(upload_async(h, aux, buf.data(), buf.size()));
-    *dsel = (int32_t*)aux;
-    *dw = (double*)((char*)aux + off);
-    return TLSQ_OK;
-}
-
-// Vg = V[:, sel] * diag(w), Vs = V[:, sel] for host-side sel / w: as kernel arguments when short, through `aux` otherwise
-static int gather_scale_host(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel,
-                             const std::vector<double>& w, void* aux, double* Vg, double* Vs) {
-    const int64_t r = (int64_t)sel.size();
-    if (r <= 32) {
-        SelWeights sw;
-        for (int64_t i = 0; i < 32; ++i) {
-            sw.sel[i] = i < r ? sel[i] : 0;
-            sw.w[i] = i < r ? w[i] : 0.0;
-        }
-        return launch_gather_scale_arg(h, V, N, sw, r, Vg, Vs);
-    }
-    int32_t* dsel;
-    double* dw;
-    TLSQ_TRY(upload_sel_weights(h, aux, sel, w, &dsel, &dw));
-    return launch_gather_scale(h, V, N, dsel, dw, r, Vg, Vs);
-}
-
-// upload a column selection and gather X = V[:, sel]
-static int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X) {
-    const int64_t r = (int64_t)sel.size();
-    if (r == 0) return TLSQ_OK;
-    void* aux;
-    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)r * 16 + 64, &aux));
-    TLSQ_TRY(upload_async(h, aux, sel.data(), (size_t)r * 4));
-    TLSQ_TRY(launch_gather_scale(h, V, N, (const int32_t*)aux, nullptr, r, nullptr, X));
-    return TLSQ_OK;
-}
-
-// Try to get the sigma_i >= inv_mu pairs of G from the block carried in st.  *ok = false -> caller must run
-// the full solver.  On success V_out (N x p) / s describe the Ritz pairs (all p of them; the wanted ones are
-// converged, the rest only bound the count).
-static int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, SubspaceState& st,
-                        double** V_out, SmallSvd& s, int64_t* sweeps, bool* ok) {
-    *ok = false;
-    st.fail = SubspaceState::FAIL_NONE;
-    st.cert_pending = false;
-    st.cert_tail = 0.0;
-    const bool hook = st.hook_rank > 0;
-    const bool cold = hook || !st.valid;
-    if (hook) {
-        st.p = std::min<int64_t>(std::min<int64_t>(st.hook_rank + 10, subspace_max_block(N)), N);
-        if (st.p < st.hook_rank || st.p < 3) return TLSQ_OK;   // block too large for this path: full solver + truncation
-    } else if (cold) {
-        // no block yet (first ALM iteration): start from a pseudo-random block of 10 + 8 columns — 10 is the
-        // reference's initial rank guess `sv = 10` (src/robustPCA.jl:184)
-        if (!st.allow_cold) return TLSQ_OK;
-        st.p = std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(18, st.cold_p), subspace_max_block(N)), N);
-        if (st.p < 3) return TLSQ_OK;
-    }
-    if (st.p < 3) return TLSQ_OK;
-    st.fail = SubspaceState::FAIL_NONE;
-    const int64_t p = st.p;
-    void *X, *Q, *GQ, *XN, *GX, *H, *S, *HB, *lam, *aux, *GD;
-    {   // the block lives in WS_SX across calls and may grow: reserve the largest block once (ws_get reallocates)
-        const int64_t pcap = std::max<int64_t>(p, std::min<int64_t>(subspace_max_block(N), N));
-        TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * pcap * 8, &X));
-        TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * pcap * 8, &XN));
-    }
-    if (cold) TLSQ_TRY(launch_fill_hash(h, (double*)X, N * p, hook ? (unsigned int)(st.hook_seed * 2654435761ull + 77u) : 0x9E3779B9u));
-    TLSQ_TRY(ws_get(h, WS_SQ, (size_t)N * p * 8, &Q));
-    TLSQ_TRY(ws_get(h, WS_SGQ, (size_t)N * p * 8, &GQ));
-    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * p * 8, &XN));
-    TLSQ_TRY(ws_get(h, WS_SGX, (size_t)N * p * 8, &GX));
-    TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
-    TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
-    TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
-    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
-    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
-    double* theta_dev = (double*)lam;
-    double* res_dev = theta_dev + p;
-    double* stat_dev = res_dev + p;
-    double* lamH_dev = stat_dev + 8;
-    std::vector<double> host((size_t)2 * p + 8);
-    const int max_steps = hook ? 2 : (cold ? 30 : 10) + st.extra_steps;
-    const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
-    int64_t svp = 0;
-    bool conv = false;
-    double prev_maxres = 0.0;
-    bool gx_valid = false;    // WS_SGX holds G X for the block in WS_SX (see the top of the loop)
-    bool x_settled = false;   // nothing that writes the block X has been queued since the host read the last step's results
-    bool force_cgs2 = cold;   // a random block is far too ill-conditioned for CholeskyQR2
-    bool cgs2_sticky = false;
-    const bool no_onepass = dev_is(DEV_NO_ONEPASS, '1');
-    const bool no_rr_fast = dev_is(DEV_NO_RR_FAST, '1');
-    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
-    // (declined: for the rest of this call the block is not what k_rr_small is made for.  A kernel that keeps declining -
-    //  near-degenerate pairs of Ritz values, as a Hankel filter has them - is not tried in the next 2, 4, 8, 16 calls.)
-    bool rr_fast_declined = false;
-    if (st.rr_skip > 0) {
-        --st.rr_skip;
-        rr_fast_declined = true;
-    }
-    for (int step = 0; step < max_steps; ++step) {
-        ++st.steps;
-        st.spec.launched = false;
-        // Q = orth([G^q X_top, G X_pad]): the block is kept sorted, its first `nt` columns are the dominant
-        // vectors; q-1 extra multiplications of those columns cost one skinny GEMM each and raise their
-        // convergence factor to the q-th power (a whole step costs ~15 GEMMs).  The pad columns get a single
-        // multiplication so that they keep tracking the top of the tail spectrum.  Cold (random) start: every
-        // column, q = 2 (higher powers would make the random block too ill-conditioned for CGS2).
-        // (second and later steps: G X is already there - the Rayleigh-Ritz finish of the previous step formed it with the Ritz
-        //  vectors, GX = (G Q) S - as long as the block has not been re-ordered since: one product less per step, of six in
-        //  a step of the randomized hook, 1.4 ms each at 65536 x 4096)
-        if (gx_valid) TLSQ_HIP(h, hipMemcpyAsync(Q, GX, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
-        else TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
-        gx_valid = false;
-        const int64_t nt_step = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);   // leading columns treated as wanted
-        {
-            const int64_t nt = nt_step;
-            // (cold: 2 on the random block; from the second step on the block consists of Ritz vectors and takes a higher power
-            //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
-            const int cold_q = [] { const char* e = dev_get(DEV_COLD_Q); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
-            const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
-            // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
-            bool in_q = true;
-            for (int t = 1; t < q && nt > 0; ++t) {
-                TLSQ_TRY(op_apply(h, op, N, (const double*)(in_q ? Q : GQ), (double*)(in_q ? GQ : Q), nt));
-                in_q = !in_q;
-            }
-            if (!in_q) TLSQ_HIP(h, hipMemcpyAsync(Q, GQ, (size_t)N * nt * 8, hipMemcpyDeviceToDevice, h->stream));
-        }
-        dbg_hash(h, "sub.chain", Q, (size_t)N * p * 8);
-        bool used_cholqr = false;
-        // Warm single-block panels: the columns of Q = [G^q X_top, G X_pad] are images of Ritz vectors - nearly orthogonal, and
-        // Q'GQ nearly diagonal once they are normalised.  Orthonormalisation, Rayleigh quotient and its eigenvectors then
-        // come from two reductions over the panel and ONE workgroup of p x p products (subspace.hip, k_rr_small) instead of
-        // CholeskyQR2, H = Q'GQ and the Jacobi solver; anything that kernel declines (panel too far from orthogonal, a
-        // cluster of Ritz values with internal coupling) repeats the step on the classic path.
-        const bool rr_fast = !cold && !force_cgs2 && !rr_fast_declined && !no_rr_fast && p <= 32 && !op.implicit();
-        // one CholeskyQR pass when the previous step on this block cleared the one-pass pivot bound with room to spare
-        const bool one_pass = !cold && !force_cgs2 && !no_onepass && p <= 32 && st.chol_p == p && st.chol_piv >= 0.5;   // (32 = CQ_PMAX: single-block panels)
-        if (rr_fast) {
-            TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
-            TLSQ_TRY(launch_rr_small(h, (const double*)Q, (const double*)GQ, (double*)H, (double*)HB, (double*)S, lamH_dev, stat_dev, N, p,
-                                     nt_step, inv_mu * inv_mu));
-            dbg_hash(h, "sub.GQ", GQ, (size_t)N * p * 8);
-            dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
-        } else {
-        TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, stat_dev, !force_cgs2, &used_cholqr, one_pass));
-        dbg_hash(h, "sub.orth", Q, (size_t)N * p * 8);
-        // Rayleigh-Ritz: H = Q' (G Q)
-        TLSQ_TRY(op_apply(h, op, N, (const double*)Q, (double*)GQ, p));
-        TLSQ_TRY(launch_panel_tn(h, (const double*)Q, (const double*)GQ, (double*)H, N, p));
-        dbg_hash(h, "sub.GQ", GQ, (size_t)N * p * 8);
-        dbg_hash(h, "sub.H", H, (size_t)p * p * 8);
-        int64_t sw = 0;
-        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
-        dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
-        if (sweeps) *sweeps += sw;
-        }
-        // X' = Q S,  G X' = (G Q) S
-        // (straight into X: the old block is not an input any more; it only has to be permuted afterwards when the
-        // Ritz values did not come out in descending order)
-        const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
-        const bool mail = h->mailbox && !no_mailbox && p <= 512 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
-        if (mail) {
-            void* scal;
-            TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-            unsigned int* arrivals = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 320);   // self-resetting
-            if (!h->mail_counter_ready) {   // (fresh workspace memory is not zero)
-                TLSQ_HIP(h, hipMemsetAsync(arrivals, 0, 4, h->stream));
-                h->mail_counter_ready = true;
-            }
-            const double seq = (h->mail_seq += 1.0);
-            const bool spec_now = st.spec.enable && rr_fast && step == 0 && (N & 3) == 0 && nt_step <= 32 && p <= 32;
-            SpecCtrl* ctrl = spec_now ? reinterpret_cast<SpecCtrl*>(reinterpret_cast<char*>(scal) + 2048) : nullptr;
-            TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
-                                        (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq, ctrl,
-                                        inv_mu, st.spec.nukeA ? 1 : 0));
-            if (spec_now) {
-                if (st.spec.before_launch) st.spec.before_launch();
-                st.spec.nct = nt_step <= 16 ? 1 : 2;
-                TLSQ_TRY(tsmm_sel_dev(h, st.spec.Z, st.spec.z_f32, st.spec.ldz, (const double*)X, ctrl, st.spec.nct, st.spec.Vs,
-                                      st.spec.Tout, st.spec.M, st.spec.M, N));
-                st.spec.launched = true;
-            }
-            // poll the flag (the kernel publishes it once every workgroup has delivered); generous time-out, then the
-            // classic read-back
-            volatile double* mb = h->mailbox;
-            const double t_poll = now_ms();
-            bool got = false;
-            for (;;) {
-                if (mb[0] == seq) {
-                    got = true;
-                    break;
-                }
-                if (now_ms() - t_poll > 2000.0) break;
-            }
-            if (got) {
-                for (int64_t i = 0; i < 2 * p + 5; ++i) host[(size_t)i] = mb[8 + i];
-                st.spec.dev_ok = st.spec.launched && host[(size_t)(2 * p + 3)] != 0.0;
-                st.spec.dev_r = (int64_t)host[(size_t)(2 * p + 4)];
-            } else {
-                st.spec.launched = false;
-                // never seen in practice; do not pay the time-out again on this handle
-                h->mailbox_bytes = 0;
-                TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
-                                           h->stream));
-                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            }
-        } else {
-            TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
-                                        (double*)GX, theta_dev, res_dev, N, p));
-            TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
-                                       h->stream));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        }
-        dbg_hash(h, "sub.X", X, (size_t)N * p * 8);
-        dbg_hash(h, "sub.theta", theta_dev, (size_t)(2 * p) * 8);
-        if (rr_fast && host[2 * p + 1] != 0.0) {
-            // k_rr_small declined (it left X = the normalised columns of Q: same span): same step again on the classic path
-            if (dbg) fprintf(stderr, "  subspace step %d: fused Rayleigh-Ritz declined (status %.0f, ||B - I|| = %.2e)\n", step, host[2 * p + 1], host[2 * p + 2]);
-            rr_fast_declined = true;
-            ++st.n_rr_declined;
-            st.rr_streak = std::min(st.rr_streak + 1, 4);
-            st.rr_skip = 1 << st.rr_streak;
-            --step;
-            --st.steps;
-            continue;
-        }
-        if (rr_fast) {
-            ++st.n_rr_fast;
-            st.rr_streak = 0;
-        }
-        st.chol_piv = used_cholqr && host[2 * p + 1] == 0.0 ? host[2 * p + 2] : 0.0;
-        st.chol_p = p;
-        if (used_cholqr && one_pass && host[2 * p + 1] == 0.0 && host[2 * p + 2] < 0.25) {
-            // the one-pass guess was wrong (the columns have moved closer together since the last step): Q is only
-            // orthonormal to ~1e-10; same step again with both passes
-            --step;
-            --st.steps;
-            continue;
-        }
-        if (used_cholqr && host[2 * p + 1] != 0.0) {
-            // the panel was too ill-conditioned for CholeskyQR2 (it left Q alone): same step again with CGS2
-            force_cgs2 = true;
-            cgs2_sticky = true;
-            --step;
-            --st.steps;
-            continue;
-        }
-        // a cold start is random only once: from the second step on the block consists of Ritz vectors, whose images under
-        // G^q are nearly orthogonal again (different norms do not hurt the Cholesky factor) - CholeskyQR2 (18 us instead of 60)
-        // unless it has already failed on this block
-        const bool cold_cgs2 = dev_is(DEV_COLD_CGS2, '1');
-        if (cold && !hook && !cgs2_sticky && !cold_cgs2) force_cgs2 = false;   // (the randomized hook keeps its two plain passes)
-        s.sigma.resize((size_t)p);
-        double tmax = 0.0;
-        bool finite = true;
-        for (int64_t i = 0; i < p; ++i) {
-            const double t = host[i];
-            if (!std::isfinite(t) || !std::isfinite(host[p + i])) finite = false;
-            tmax = std::max(tmax, t);
-            s.sigma[i] = std::sqrt(std::max(t, 0.0));
-        }
-        if (!finite) {
-            st.valid = false;
-            st.fail = SubspaceState::FAIL_NUMERIC;
-            break;
-        }
-        s.ncols = p;
-        sort_desc(s);
-        // keep the block sorted by Ritz value: X = X'[:, order]
-        {
-            std::vector<double> res_sorted((size_t)p), th_sorted((size_t)p), sg_sorted((size_t)p);
-            for (int64_t i = 0; i < p; ++i) {
-                res_sorted[i] = host[p + s.order[i]];
-                th_sorted[i] = host[s.order[i]];
-                sg_sorted[i] = s.sigma[s.order[i]];
-            }
-            bool sorted = true;
-            for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[i] == (int32_t)i;
-            x_settled = sorted && mail;   // (a re-ordering is queued on the main stream: the block is in flux until that has run)
-            if (!sorted) {
-                TLSQ_HIP(h, hipMemcpyAsync(XN, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
-                TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
-                TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
-                                             (double*)X));
-                // ... and G X with it (two small launches against one operator product saved in the next step)
-                TLSQ_HIP(h, hipMemcpyAsync(XN, GX, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
-                TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr,
-                                             (double*)GX));
-            }
-            for (int64_t i = 0; i < p; ++i) {
-                host[i] = th_sorted[i];
-                host[p + i] = res_sorted[i];
-                s.sigma[i] = sg_sorted[i];
-            }
-            std::iota(s.order.begin(), s.order.end(), 0);
-            gx_valid = !dev_is(DEV_NO_GX_REUSE, '1');
-        }
-        svp = 0;
-        for (int64_t i = 0; i < p; ++i) svp += (s.sigma[i] >= inv_mu) ? 1 : 0;
-        if (hook) {
-            if (step + 1 < max_steps) continue;
-            s.ncols = std::min<int64_t>(st.hook_rank, p);   // rank-sv truncation, like `svd(Z, sv)`
-            *V_out = (double*)X;
-            *ok = true;
-            return TLSQ_OK;
-        }
-        if (svp > p - 2) {  // the block may not contain every sigma >= 1/mu: full solver, or a larger block
-            st.fail = SubspaceState::FAIL_SMALL;
-            break;
-        }
-        bool good = true;
-        double maxres = 0.0;
-        for (int64_t i = 0; i < svp; ++i) {
-            good = good && (host[p + i] <= 2e-13 * tmax);
-            maxres = std::max(maxres, host[p + i]);
-        }
-        if (dbg) {
-            int sd = -1;
-            void* scal = h->ws[WS_SCAL].p;
-            (void)hipMemcpy(&sd, (char*)scal + 136, 4, hipMemcpyDeviceToHost);
-            fprintf(stderr, "  [small eig sweeps %d]", sd);
-            if (rr_fast) {
-                double st8[8];
-                (void)hipMemcpy(st8, stat_dev, 64, hipMemcpyDeviceToHost);
-                fprintf(stderr, " [rr: its %.0f delta %.2e delta_tt %.2e k_tp %.2e blocked %.0f piv %.2e]", st8[3], st8[2], st8[5], st8[6], st8[7], st8[0]);
-            }
-        }
-        if (dbg)
-            fprintf(stderr, "  subspace step %d: p=%lld ntop=%lld svp=%lld maxres/tmax=%.3e tail/tau=%.3f cold=%d\n", step,
-                    (long long)p, (long long)ntop, (long long)svp, maxres / tmax,
-                    svp < p ? s.sigma[s.order[svp]] / inv_mu : 0.0, (int)cold);
-        if (good) {
-            conv = true;
-            if (cold && !hook) {
-                // The panel changes more between the first two ALM iterations (Y is still zero in the first) than it ever does
-                // again: with the default count the first warm step misses the residual bound and a second one (~190 us on the
-                // classic path) follows.  Two more multiplications of the top columns (~13 us) avoid that; the count relaxes
-                // by itself afterwards (below).  TLSQ_WARM_Q0 overrides.
-                const char* e = dev_get(DEV_WARM_Q0);
-                const int v = e ? atoi(e) : 0;
-                st.q_warm = std::max(st.q_warm, v >= 1 && v <= 7 ? v : 5);
-                // (... and the relaxation stops at 3: probing further down costs a failed step sooner or later)
-                if (!e) st.q_floor = std::max(st.q_floor, 3);
-            }
-            if (!cold && !hook) {
-                // a warm block that needed a second step just missed the residual bound after the first one: two more
-                // multiplications of its top columns next time are far cheaper than another step; relax again later
-                // ... and when a single step landed far below the bound (the spectral gap behind the block grows by
-                // rho^2 per ALM iteration) give a multiplication back - but never return to a count that has failed
-                if (step >= 1) {
-                    st.q_floor = std::max(st.q_floor, std::min(st.q_warm + 1, 3));
-                    st.q_warm = std::min(7, st.q_warm + 2);
-                } else if (st.q_warm > st.q_floor && maxres <= 0.02 * 2e-13 * tmax) {
-                    st.q_warm -= 1;
-                }
-            }
-            break;
-        }
-        // (the fused Rayleigh-Ritz kernel leaves clusters of Ritz values unresolved - fine for pad columns, not for a cluster
-        //  that reaches into the wanted pairs: the next step of this call goes through the Jacobi solver)
-        if (rr_fast) rr_fast_declined = true;
-        // hopeless (no spectral gap behind the block): stop early and let the full solver run
-        if (step >= 4 && prev_maxres > 0.0 && maxres > 0.5 * prev_maxres) break;
-        prev_maxres = maxres;
-    }
-    if (!conv) {
-        if (st.fail == SubspaceState::FAIL_NONE) st.fail = SubspaceState::FAIL_NOCONV;
-        return TLSQ_OK;
-    }
-    {   // count window: a Ritz value this close to the threshold cannot be trusted to fall on the right side
-        const double tau2 = inv_mu * inv_mu;
-        st.dlam = st.noise_rel * host[0];   // (sorted: host[0] is the largest Ritz value)
-        bool in_window = !(tau2 > 2.0 * st.dlam);
-        for (int64_t i = 0; i < p && !in_window; ++i) in_window = std::fabs(host[i] - tau2) <= st.dlam;
-        if (in_window) {
-            st.fail = SubspaceState::FAIL_WINDOW;
-            return TLSQ_OK;
-        }
-    }
-    if (st.skip_certificate) {
-        *V_out = (double*)X;
-        *ok = true;
-        return TLSQ_OK;
-    }
-    // ---- certificate: lambda_max(G - X_r Theta_r X_r') must be clearly below (1/mu)^2 ----
-    void *Vg = nullptr, *Vs = nullptr;
-    // (explicit G, at most 32 deflated columns, N < 1024: the deflation kernel reads the columns of X itself)
-    const bool no_fused_defl = dev_is(DEV_NO_FUSED_DEFLATE, '1');
-    const bool fused_deflate = !op.implicit() && svp <= 32 && N < 1024 && !no_fused_defl;
-    SelWeights defl_sw;
-    if (svp > 0) {
-        std::vector<int32_t> sel((size_t)svp);
-        std::vector<double> th((size_t)svp);
-        for (int64_t i = 0; i < svp; ++i) {
-            sel[i] = s.order[i];
-            th[i] = host[sel[i]];
-        }
-        if (fused_deflate) {
-            for (int64_t i = 0; i < 32; ++i) {
-                defl_sw.sel[i] = i < svp ? sel[(size_t)i] : 0;
-                defl_sw.w[i] = i < svp ? th[(size_t)i] : 0.0;
-            }
-        } else {
-            TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vg));
-            TLSQ_TRY(ws_get(h, WS_VS, (size_t)N * svp * 8, &Vs));
-            TLSQ_TRY(gather_scale_host(h, (const double*)X, N, sel, th, aux, (double*)Vg, (double*)Vs));
-        }
-    }
-    const double tau2 = inv_mu * inv_mu;
-    // everything below is scaled by 1 / tau^2: the question is lambda_max(GD) < margin = 1 - dlam / tau^2
-    st.cert_margin = (1.0 - st.dlam / tau2) * (1.0 - 1e-9);
-    if (!op.implicit()) {
-        TLSQ_TRY(ws_get(h, WS_GD, (size_t)N * N * 8, &GD));
-        const bool no_power = dev_is(DEV_NO_POWER_CERT, '1');
-        // the two dense squarings cost N^3 flops against ~16 N^2 loads for a Lanczos run: matrix powers up to N = 1024
-        st.cert_power = N <= 1024 && !no_power;
-        // Asynchronous form: the host has just read this step's results from the mailbox, so everything the certificate reads
-        // (G, the block X) is complete - its two kernels go to the second stream and run beside whatever the caller queues next
-        const bool async = st.cert_async && st.defer_certificate && st.cert_power && fused_deflate && svp > 0 && h->stream_b &&
-                           x_settled && h->mailbox && h->mailbox_bytes >= 32768 && !dev_is(DEV_NO_MAILBOX, '1');
-        st.cert_async = async;
-        st.cert_GD = (const double*)GD;
-        st.cert_N = N;
-        st.cert_launch = nullptr;
-        if (async) {
-            const double* Gp = op.G;
-            const double* Xp = (const double*)X;
-            double* GDp = (double*)GD;
-            const double sc = 1.0 / tau2;
-            SubspaceState* stp = &st;
-            st.cert_launch = [h, Gp, Xp, GDp, N, svp, sc, defl_sw, stp]() -> int {
-                StreamScope on_b(h, h->stream_b);
-                TLSQ_TRY(launch_deflate_sel(h, Gp, N, Xp, defl_sw, GDp, N, svp, sc));
-                return power_cert_begin(h, *stp);
-            };
-        } else {
-            if (fused_deflate && svp > 0)
-                TLSQ_TRY(launch_deflate_sel(h, op.G, N, (const double*)X, defl_sw, (double*)GD, N, svp, 1.0 / tau2));
-            else
-                TLSQ_TRY(launch_deflate(h, op.G, N, (const double*)Vs, (const double*)Vg, (double*)GD, N, svp, 1.0 / tau2));
-            if (st.cert_power) TLSQ_TRY(power_cert_begin(h, st));
-            else TLSQ_TRY(lanczos_begin(h, st.cert, (const double*)GD, N, N, 0.02, 48, st.cert_margin, 0.0));
-        }
-        if (st.defer_certificate) {
-            st.cert_pending = true;
-            *V_out = (double*)X;
-            *ok = true;   // tentatively: svd_subspace_certify has the last word
-            return TLSQ_OK;
-        }
-        bool pass = false;
-        TLSQ_TRY(cert_finish(h, st, &pass));
-        if (!pass) {
-            st.fail = SubspaceState::FAIL_CERT;   // ambiguous: the accurate route decides (or a larger block)
-            return TLSQ_OK;
-        }
-    } else {
-        // the deflated operator as a product: w = (G q - Vs (Vg' q)); Lanczos bound, unscaled
-        void* cv;
-        TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(p * p, svp) * 8, &cv));
-        const LzApply apply = [&](const double* q, double* w) -> int {
-            TLSQ_TRY(op_apply(h, op, N, q, w, 1));
-            if (svp > 0) TLSQ_TRY(launch_deflate_vec(h, (const double*)Vs, (const double*)Vg, svp, q, (double*)cv, w, N));
-            return TLSQ_OK;
-        };
-        double lmax = 0.0;
-        int steps = 0;
-        const int lst = lanczos_lmax_op(h, N, apply, 0.02, 48, &lmax, &steps, tau2);
-        if (lst < 0) return lst;
-        if (!(lmax * 1.5 + st.dlam < tau2)) {
-            st.fail = SubspaceState::FAIL_CERT;
-            return TLSQ_OK;
-        }
-    }
-    *V_out = (double*)X;
-    *ok = true;
-    return TLSQ_OK;
-}
-
-// Second half of a deferred count certificate (SubspaceState::defer_certificate): waits for the certificate's numbers
-// only - whatever the caller queued behind them keeps running.
-static int svd_subspace_certify(Handle* h, SubspaceState& st, double inv_mu, bool* ok) {
-    (void)inv_mu;
-    *ok = false;
-    st.cert_pending = false;
-    bool pass = false;
-    TLSQ_TRY(cert_finish(h, st, &pass));
-    if (!pass) {
-        st.fail = SubspaceState::FAIL_CERT;
-        return TLSQ_OK;
-    }
-    *ok = true;
-    return TLSQ_OK;
-}
-
-// Factors of the thresholded low-rank matrix A = Z * V[:,sel] * diag(g) * V[:,sel]' (r = sel.size() columns):
-// Tm (M x r, ld M, fp64, WS_T) = Z * V[:,sel] * diag(g) and Vs (N x r, ld N, WS_VS) = V[:,sel].  r = 0: both nullptr.
 template <typename T>
 static int rebuild_factors(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ, const double* V,
                            const std::vector<int32_t>& sel, const std::vector<double>& g, const double** Tm_out,
@@ -1153,57 +310,6 @@ int rebuild_lowrank(Handle* h, const T* Z, int64_t M, int64_t N, int64_t ldZ,
     const double *Tm, *Vs;
     TLSQ_TRY(rebuild_factors<T>(h, Z, M, N, ldZ, V, sel, g, &Tm, &Vs));
     return rebuild_from_factors<T>(h, Tm, Vs, M, N, (int64_t)sel.size(), Aout, ldA);
-}
-
-// Carry the dominant block (svp + pad Ritz/eigen vectors, sorted) to the next ALM iteration: WS_SX = V[:, top].
-// Called after rebuild_lowrank (which has finished reading V, and V may alias WS_SX).
-static int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_t svp, int64_t pmax,
-                       SubspaceState& sub) {
-    const int64_t pad_min = [] { const char* e = dev_get(DEV_PAD); return (int64_t)(e ? atoi(e) : 4); }();
-    int64_t pad = std::max<int64_t>(pad_min, svp / 4);
-    // up to 64 (96) columns the p x p Rayleigh-Ritz problem is solved in a single launch (k_jacobi_small / _mid);
-    // beyond that it costs ~1 ms per step: give up some padding to stay below when the rank allows
-    if (svp + pad > 64 && svp + pad_min <= 64) pad = 64 - svp;
-    else if (svp + pad > 96 && svp + pad_min <= 96) pad = 96 - svp;   // (k_jacobi_mid: one launch up to 96 as well)
-    int64_t want = std::min<int64_t>(N, svp + pad);
-    if (N > kFullEigMaxN) want = std::min(want, pmax);   // large mode has no other solver: keep what fits
-    if (want > pmax || want < 3) {
-        sub.valid = false;
-        // rank beyond the largest block: cold starts would only find that out again - the dense solver serves the
-        // next iterations until the rank fits (this function is called after every one of them)
-        sub.allow_cold = want < 3;
-        return TLSQ_OK;
-    }
-    sub.allow_cold = true;
-    // the sorted vectors we have (a subspace result only carries p of them); any missing pad columns are
-    // pseudo-random — the next iteration's CGS2 orthogonalises them against the rest
-    const int64_t have = std::min<int64_t>(want, s.ncols);
-    std::vector<int32_t> keep((size_t)have);
-    bool identity = true;
-    for (int64_t p = 0; p < have; ++p) {
-        keep[p] = s.order[p];
-        identity = identity && keep[p] == (int32_t)p;
-    }
-    if (identity && h->ws[WS_SX].p && V == (const double*)h->ws[WS_SX].p) {
-        // the usual case: V is the sorted block the subspace solver left in WS_SX - its leading columns stay where
-        // they are, only missing pad columns are (re)filled
-        if (have < want)
-            TLSQ_TRY(launch_fill_hash(h, (double*)h->ws[WS_SX].p + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
-        sub.p = want;
-        sub.ntop = svp;
-        sub.valid = true;
-        return TLSQ_OK;
-    }
-    void *tmp, *X;
-    TLSQ_TRY(ws_get(h, WS_SXN, (size_t)N * want * 8, &tmp));
-    TLSQ_TRY(gather_cols(h, V, N, keep, (double*)tmp));          // out of place (V may be WS_SX itself)
-    if (have < want) TLSQ_TRY(launch_fill_hash(h, (double*)tmp + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
-    TLSQ_TRY(ws_get(h, WS_SX, (size_t)N * want * 8, &X));
-    TLSQ_HIP(h, hipMemcpyAsync(X, tmp, (size_t)N * want * 8, hipMemcpyDeviceToDevice, h->stream));
-    sub.p = want;
-    sub.ntop = svp;
-    sub.valid = true;
-    return TLSQ_OK;
 }
 
 static double large_mode_noise(int64_t N, int64_t m_global) {
@@ -3041,580 +2147,6 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     return converged ? TLSQ_OK : TLSQ_MAXITER;  // :232
 }
 
-// ------------------------------------------------------------------------------------------------
-// ComplexF64 rpca (src/robustPCA.jl:156-239 with the complex soft_th of :3-7; test/runtests.jl:187-199).
-// D, A, E: device, interleaved complex, M x N, ld = M.  The sweeps are complex kernels (complex.hip); every
-// spectral step runs on the realified 2M x 2N panel with the real path's Gram / eigen / rebuild kernels.  The
-// eigenvalues of the realified Gram come in equal pairs: consecutive sorted values are grouped, the pair mean
-// decides sigma_i >= 1/mu, and both eigenvectors of a pair are selected together, so the rebuilt matrix keeps the
-// realified structure.  Full decompositions only (no subspace tier): a coverage path, not a tuned one.
-// ------------------------------------------------------------------------------------------------
-int rpca_core_complex(Handle* h, const double* D, int64_t M, int64_t N, const ResolvedOpts& ro,
-                             const tlsq_rpca_opts* opts, double* A, double* E, double* S_host, int64_t* sv_out,
-                             tlsq_rpca_info* info, double* U_dev, double* Vt_host, int64_t ldVt) {
-    const int64_t n = M * N, M2 = 2 * M, N2 = 2 * N;
-    const int64_t d = std::min(M, N);
-    void *Yv, *Zv, *Rv, *Wv, *ARv;
-    TLSQ_TRY(ws_get(h, WS_Y, (size_t)n * 16, &Yv));
-    TLSQ_TRY(ws_get(h, WS_Z, (size_t)n * 16, &Zv));
-    TLSQ_TRY(ws_get(h, WS_R, (size_t)n * 16, &Rv));
-    TLSQ_TRY(ws_get(h, WS_DT, (size_t)n * 32, &Wv));    // realified panel
-    TLSQ_TRY(ws_get(h, WS_AT, (size_t)n * 32, &ARv));   // realified A
-    double *Y = (double*)Yv, *Z = (double*)Zv, *R = (double*)Rv, *W = (double*)Wv, *AR = (double*)ARv;
-    int64_t sweeps = 0;
-    TLSQ_HIP(h, hipMemsetAsync(A, 0, (size_t)n * 16, h->stream));            // :174
-    TLSQ_HIP(h, hipMemsetAsync(E, 0, (size_t)n * 16, h->stream));
-    double norm2 = 0.0, maxabs = 0.0;
-    TLSQ_TRY(launch_cmaxabs(h, D, n, &maxabs));                               // :178
-    if (!std::isfinite(maxabs)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");   // (chkfinite at :177)
-    TLSQ_TRY(launch_realify(h, D, M, N, W));
-    TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &norm2, &sweeps));         // :177
-    const double lam = ro.lambda;
-    const double dual_norm = std::max(norm2, maxabs / lam);                   // :179
-    const double d_norm = norm2;                                              // :180
-    TLSQ_TRY(launch_cdiv(h, D, Y, n, dual_norm));                             // :181
-    double mu = 1.25 / norm2;                                                 // :182
-    const double mubar = mu * 1.0e7;                                          // :183
-    int64_t sv = 10, svp = 10;                                                // :184
-    if (info) {
-        info->d_norm = d_norm;
-        info->iters_done = 0;
-        info->converged = 0;
-    }
-    h->warm_n = 0;
-    SmallSvd s;
-    double* V = nullptr;
-    std::vector<double> sig_pairs;
-    double cost = std::numeric_limits<double>::quiet_NaN();
-    bool converged = false;
-    int64_t n_full = 0;
-    const double t_loop0 = now_ms();
-    int64_t k = 0;
-    for (k = 1; k <= ro.iters; ++k) {                                         // :186
-        const double inv_mu = 1.0 / mu, thr = lam / mu;
-        TLSQ_TRY(launch_cshrink(h, D, A, Y, E, Z, n, inv_mu, thr));           // :188-192
-        TLSQ_TRY(launch_realify(h, Z, M, N, W));
-        double* G = nullptr;
-        TLSQ_TRY(gram_allreduce<double>(h, W, M2, N2, M2, &G));               // :194
-        TLSQ_TRY(eig_full(h, G, N2, &V, s, &sweeps, false));
-        ++n_full;
-        // pairs of equal eigenvalues -> singular values of the complex Z
-        sig_pairs.assign((size_t)d, 0.0);
-        for (int64_t i = 0; i < d; ++i) {
-            const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
-            sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
-        }
-        // The Gram matrix resolves sigma only down to ~sqrt(N eps) sigma_max, and a singular value near 1/mu with an error of
-        // ~N eps sigma_max^2 / (2 sigma): when the threshold has sunk to that level, or a value sits closer to it than its
-        // own error, the count (:198) is taken from the accurate route instead - TSQR + one-sided Jacobi on the tall one of
-        // W and W' (W' embeds Z^H), exactly as for the returned `s`.  (tools/fuzz_misc.py: three of ~80 small complex
-        // problems had counted against the resolution floor instead of 1/mu in their last iterations: sv 7 for LAPACK's 9.)
-        const double smax0 = sig_pairs[0];
-        const double sigma_res = std::sqrt(8.0 * (double)N2 * 2.220446049250313e-16) * smax0;
-        bool accurate = inv_mu < 4.0 * sigma_res;
-        const double window = 8.0 * (double)N2 * 2.220446049250313e-16 * smax0 * smax0 / inv_mu;
-        for (int64_t i = 0; i < d && !accurate; ++i) accurate = std::fabs(sig_pairs[i] - inv_mu) <= window;
-        const bool acc_tall = M2 >= N2;
-        if (accurate) {
-            double* Pm = W;
-            if (!acc_tall) {
-                TLSQ_TRY(launch_transpose<double>(h, W, M2, M2, N2, AR, N2));   // AR <- W' (N2 x M2)
-                Pm = AR;
-            }
-            const int64_t O2 = acc_tall ? M2 : N2, P2 = acc_tall ? N2 : M2;
-            TLSQ_TRY(svd_via_r<double>(h, Pm, O2, P2, O2, &V, s, &sweeps));
-            for (int64_t i = 0; i < d; ++i) {
-                const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
-                sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
-            }
-        }
-        const double count_thr = accurate ? inv_mu : std::max(inv_mu, sigma_res);
-        svp = 0;                                                              // :198
-        for (int64_t i = 0; i < d; ++i) svp += (sig_pairs[i] >= count_thr) ? 1 : 0;
-        sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);                 // :199-204
-        std::vector<int32_t> sel((size_t)(2 * svp));
-        std::vector<double> g((size_t)(2 * svp));
-        for (int64_t i = 0; i < svp; ++i) {
-            const double sg = sig_pairs[i];
-            const double gi = ro.nukeA ? (sg - inv_mu) / sg : 1.0;            // :205-213
-            sel[2 * i] = s.order[2 * i];
-            sel[2 * i + 1] = s.order[2 * i + 1];
-            g[2 * i] = g[2 * i + 1] = gi;
-        }
-        if (accurate && !acc_tall) {
-            // V holds the LEFT singular vectors of W (the right ones of W'): A' = W' U_sel diag(g) U_sel' on the transposed
-            // panel (in AR), into W, and back
-            TLSQ_TRY(rebuild_lowrank<double>(h, AR, N2, M2, N2, V, sel, g, W, N2));
-            TLSQ_TRY(launch_transpose<double>(h, W, N2, N2, M2, AR, M2));
-        } else {
-            TLSQ_TRY(rebuild_lowrank<double>(h, W, M2, N2, M2, V, sel, g, AR, M2));
-        }
-        TLSQ_TRY(launch_unrealify(h, AR, M, N, A));
-        TLSQ_TRY(launch_cupdate(h, D, A, E, Y, R, n, mu));                    // :221-222
-        mu = std::min(mu * ro.rho, mubar);                                    // :223
-        double rn = 0.0;
-        TLSQ_TRY(launch_realify(h, R, M, N, W));
-        TLSQ_TRY(opnorm_gram<double>(h, W, M2, N2, M2, &rn, &sweeps, 1e-8));  // :225
-        cost = rn / d_norm;
-        if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {
-            TLSQ_TRY(sigma_max_of_gram(h, (const double*)h->ws[WS_G].p, N2, 1e-13, &rn, &sweeps));
-            cost = rn / d_norm;
-        }
-        if (info) {
-            info->iters_done = k;
-            if (info->cost_hist && k <= info->hist_capacity) info->cost_hist[k - 1] = cost;
-            if (info->svp_hist && k <= info->hist_capacity) info->svp_hist[k - 1] = svp;
-        }
-        if (opts && opts->on_iter) opts->on_iter(k, cost, svp, opts->user);   // :226
-        if (cost < ro.tol) {                                                  // :228
-            converged = true;
-            break;
-        }
-    }
-    if (k > ro.iters) k = ro.iters;
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) {
-        info->ms_loop = now_ms() - t_loop0;
-        info->converged = converged ? 1 : 0;
-        info->final_cost = cost;
-        info->final_mu = mu;
-        info->jacobi_sweeps = sweeps;
-        info->eig_full = n_full;
-    }
-    if (sv_out) *sv_out = sv;
-    if ((U_dev || Vt_host) && !sig_pairs.empty()) {
-        // The singular vectors of `s` (SVD of the last Z, :194, :238).  The realified panel W = [Re -Im; Im Re] has every
-        // singular value of Z twice; [x; y] is a right singular vector of W exactly when x + i y is one of Z, and the two
-        // real vectors of a pair span {w, J w}, i.e. the same complex vector up to a phase.  So: one more complete and
-        // accurate real decomposition - the TSQR route on the tall one of W and W' (W' is the embedding of Z^H) - gives
-        // the vectors of the short side; per cluster of equal singular values a complex Gram-Schmidt over the images of
-        // its real vectors keeps one complex vector per singular value; the long side follows from one product,
-        // u = Z v / sigma or v = Z^H u / sigma.
-        const bool tall = M >= N;
-        const int64_t np_ = tall ? N : M, no_ = tall ? M : N;   // lengths of the primary / the other side's vectors
-        const int64_t P2 = 2 * np_, O2 = 2 * no_;
-        double* Pm = W;   // the tall real panel (O2 x P2, ld O2)
-        TLSQ_TRY(launch_realify(h, Z, M, N, W));
-        if (!tall) {
-            TLSQ_TRY(launch_transpose<double>(h, W, M2, M2, N2, AR, N2));   // AR <- W' (N2 x M2)
-            Pm = AR;
-        }
-        TLSQ_TRY(svd_via_r<double>(h, Pm, O2, P2, O2, &V, s, &sweeps));
-        for (int64_t i = 0; i < d; ++i) {
-            const double a = s.sigma[s.order[2 * i]], b = s.sigma[s.order[2 * i + 1]];
-            sig_pairs[i] = std::sqrt(0.5 * (a * a + b * b));
-        }
-        std::vector<double> hv((size_t)P2 * P2);
-        TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, hv.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        std::vector<double> vr((size_t)np_ * d), vi((size_t)np_ * d);   // complex primary vectors, column i
-        const double ctol = 1e-9 * sig_pairs[0];
-        int64_t i0 = 0;
-        while (i0 < d) {
-            int64_t i1 = i0;
-            while (i1 + 1 < d && sig_pairs[i1] - sig_pairs[i1 + 1] <= ctol) ++i1;
-            const int64_t m = i1 - i0 + 1;
-            int64_t got = 0;
-            for (int64_t t = 2 * i0; t <= 2 * i1 + 1 && got < m; ++t) {
-                const double* w = hv.data() + (size_t)s.order[t] * P2;
-                double* xr = vr.data() + (size_t)(i0 + got) * np_;
-                double* xi = vi.data() + (size_t)(i0 + got) * np_;
-                for (int64_t j = 0; j < np_; ++j) {
-                    xr[j] = w[j];
-                    xi[j] = w[np_ + j];
-                }
-                for (int rep = 0; rep < 2; ++rep)       // twice is enough
-                    for (int64_t q = 0; q < got; ++q) {
-                        const double* qr = vr.data() + (size_t)(i0 + q) * np_;
-                        const double* qi = vi.data() + (size_t)(i0 + q) * np_;
-                        double pr = 0.0, pi = 0.0;      // <q, x> = q^H x
-                        for (int64_t j = 0; j < np_; ++j) {
-                            pr += qr[j] * xr[j] + qi[j] * xi[j];
-                            pi += qr[j] * xi[j] - qi[j] * xr[j];
-                        }
-                        for (int64_t j = 0; j < np_; ++j) {
-                            xr[j] -= pr * qr[j] - pi * qi[j];
-                            xi[j] -= pr * qi[j] + pi * qr[j];
-                        }
-                    }
-                double nn = 0.0;
-                for (int64_t j = 0; j < np_; ++j) nn += xr[j] * xr[j] + xi[j] * xi[j];
-                if (nn > 0.25) {   // (a dependent image - J w of an accepted w - leaves ~0)
-                    const double inv = 1.0 / std::sqrt(nn);
-                    for (int64_t j = 0; j < np_; ++j) {
-                        xr[j] *= inv;
-                        xi[j] *= inv;
-                    }
-                    ++got;
-                }
-            }
-            for (int64_t q = got; q < m; ++q)   // (never seen: the TSQR route returns complete orthogonal factors)
-                for (int64_t j = 0; j < np_; ++j) vr[(size_t)(i0 + q) * np_ + j] = vi[(size_t)(i0 + q) * np_ + j] = 0.0;
-            i0 = i1 + 1;
-        }
-        // the other side: T (O2 x d) = Pm [Re p; Im p] / sigma  ->  complex vectors T[0:no] + i T[no:2no]
-        std::vector<double> rv((size_t)P2 * d, 0.0);
-        const double floor_s = (double)P2 * 2.220446049250313e-16 * sig_pairs[0];
-        for (int64_t i = 0; i < d; ++i) {
-            if (!(sig_pairs[i] > floor_s)) continue;   // (zero column, like the real path)
-            const double inv = 1.0 / sig_pairs[i];
-            for (int64_t j = 0; j < np_; ++j) {
-                rv[(size_t)i * P2 + j] = vr[(size_t)i * np_ + j] * inv;
-                rv[(size_t)i * P2 + np_ + j] = vi[(size_t)i * np_ + j] * inv;
-            }
-        }
-        void *Rd, *Td;
-        TLSQ_TRY(ws_get(h, WS_VG, (size_t)P2 * d * 8, &Rd));
-        TLSQ_TRY(ws_get(h, WS_T, (size_t)O2 * d * 8, &Td));
-        TLSQ_HIP(h, hipMemcpyAsync(Rd, rv.data(), rv.size() * 8, hipMemcpyHostToDevice, h->stream));
-        TLSQ_TRY(gemm_mixed(h, true, false, Rd, 0, P2, Pm, 0, O2, Td, 0, O2, d, O2, P2, false));
-        std::vector<double> ht;   // the other side's vectors on the host when they are the right ones (wide Z)
-        if (!tall) {
-            ht.resize((size_t)O2 * d);
-            TLSQ_HIP(h, hipMemcpyAsync(ht.data(), Td, ht.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        }
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        if (Vt_host) {   // Vt = V^H: row i = conj(v_i)
-            for (int64_t i = 0; i < d; ++i)
-                for (int64_t j = 0; j < N; ++j) {
-                    const double re = tall ? vr[(size_t)i * N + j] : ht[(size_t)i * O2 + j];
-                    const double im = tall ? vi[(size_t)i * N + j] : ht[(size_t)i * O2 + N + j];
-                    Vt_host[2 * (i + j * ldVt)] = re;
-                    Vt_host[2 * (i + j * ldVt) + 1] = -im;
-                }
-        }
-        if (U_dev) {
-            if (tall) {
-                TLSQ_TRY(launch_pack_complex(h, (const double*)Td, M, d, U_dev));
-            } else {
-                std::vector<double> hu((size_t)2 * M * d);
-                for (int64_t i = 0; i < d; ++i)
-                    for (int64_t j = 0; j < M; ++j) {
-                        hu[2 * ((size_t)i * M + j)] = vr[(size_t)i * M + j];
-                        hu[2 * ((size_t)i * M + j) + 1] = vi[(size_t)i * M + j];
-                    }
-                TLSQ_HIP(h, hipMemcpyAsync(U_dev, hu.data(), hu.size() * 8, hipMemcpyHostToDevice, h->stream));
-            }
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        }
-    }
-    if (S_host)
-        for (int64_t i = 0; i < d; ++i) S_host[i] = i < (int64_t)sig_pairs.size() ? sig_pairs[i] : 0.0;
-    return converged ? TLSQ_OK : TLSQ_MAXITER;                                // :232
-}
-
-
-// solve X * V22 = -V21 for X (n x q); V = Vt' where Vt is (ncols x ncols, ldVt) — TotalLeastSquares.jl:65-69
-int tls_partition_solve(const double* Vt, int64_t ncols, int64_t ldVt, int64_t n, double* x,
-                               int64_t ldx) {
-    const int64_t q = ncols - n;
-    if (n <= 0 || q <= 0) return TLSQ_ERR_ARG;
-    // V[i][j] = Vt[j + i*ldVt].  V21 = V[0:n, n:], V22 = V[n:, n:]
-    // X V22 = -V21  <=>  V22' X' = -V21'.  Build M = V22' (q x q): M[a][b] = V22[b][a] = V[n+b][n+a] = Vt[(n+a) + (n+b)*ldVt]
-    std::vector<double> Mq((size_t)q * q), rhs((size_t)q * n);
-    for (int64_t a = 0; a < q; ++a)
-        for (int64_t b = 0; b < q; ++b) Mq[a * q + b] = Vt[(n + a) + (n + b) * ldVt];
-    // rhs[a][i] = -V21'[a][i] = -V21[i][a] = -V[i][n+a] = -Vt[(n+a) + i*ldVt]
-    for (int64_t a = 0; a < q; ++a)
-        for (int64_t i = 0; i < n; ++i) rhs[a * n + i] = -Vt[(n + a) + i * ldVt];
-    // LU with partial pivoting on Mq (row-major), applied to rhs
-    for (int64_t c = 0; c < q; ++c) {
-        int64_t piv = c;
-        double best = std::fabs(Mq[c * q + c]);
-        for (int64_t r2 = c + 1; r2 < q; ++r2)
-            if (std::fabs(Mq[r2 * q + c]) > best) best = std::fabs(Mq[r2 * q + c]), piv = r2;
-        if (piv != c) {
-            for (int64_t b = 0; b < q; ++b) std::swap(Mq[c * q + b], Mq[piv * q + b]);
-            for (int64_t i = 0; i < n; ++i) std::swap(rhs[c * n + i], rhs[piv * n + i]);
-        }
-        const double pv = Mq[c * q + c];
-        for (int64_t r2 = c + 1; r2 < q; ++r2) {
-            const double f = Mq[r2 * q + c] / pv;
-            if (f == 0.0) continue;
-            for (int64_t b = c; b < q; ++b) Mq[r2 * q + b] -= f * Mq[c * q + b];
-            for (int64_t i = 0; i < n; ++i) rhs[r2 * n + i] -= f * rhs[c * n + i];
-        }
-    }
-    for (int64_t c = q - 1; c >= 0; --c) {
-        for (int64_t i = 0; i < n; ++i) {
-            double v = rhs[c * n + i];
-            for (int64_t b = c + 1; b < q; ++b) v -= Mq[c * q + b] * rhs[b * n + i];
-            rhs[c * n + i] = v / Mq[c * q + c];
-        }
-    }
-    // rhs = X' (q x n)  ->  x[i + a*ldx] = X[i][a]
-    for (int64_t a = 0; a < q; ++a)
-        for (int64_t i = 0; i < n; ++i) x[i + a * ldx] = rhs[a * n + i];
-    return TLSQ_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// rpca entry (both precisions): staging of caller memory, M < N handled on the transposed problem
-// ------------------------------------------------------------------------------------------------
-// rpca on a single-process multi-GPU group (tlsq_create_multi): host matrices, contiguous row blocks, one worker per
-// GPU.  Every rank runs the ordinary row-sharded entry on its block of the caller's arrays (column-major with the
-// caller's leading dimensions, so a row block is just an offset pointer: the strided 2-D copies of rpca_entry do the
-// scatter and the gather).  All ranks get structurally identical requests - history arrays, an on_iter hook, S / Vt
-// buffers - because those requests steer which collectives a rank enters.
-static void noop_on_iter(int64_t, double, int64_t, void*) {}
-
-template <typename T>
-static int rpca_multi(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts, T* A,
-                      int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt, int64_t* sv,
-                      tlsq_rpca_info* info) {
-    const int n = h->multi_n;
-    const int64_t d = std::min(M, N);
-    tlsq_rpca_opts base;
-    if (opts) base = *opts; else tlsq_rpca_opts_default(&base);
-    base.m_global = M;
-    base.memory = TLSQ_MEM_HOST;
-    std::vector<tlsq_rpca_opts> ro((size_t)n, base);
-    std::vector<tlsq_rpca_info> ri((size_t)n);
-    std::vector<std::vector<double>> ch((size_t)n);
-    std::vector<std::vector<int64_t>> sh((size_t)n);
-    std::vector<std::vector<T>> Sr((size_t)n), Vr((size_t)n);
-    std::vector<int64_t> svr((size_t)n, 0);
-    for (int r = 0; r < n; ++r) {
-        memset(&ri[(size_t)r], 0, sizeof(tlsq_rpca_info));
-        if (r == 0) {
-            if (info) ri[0] = *info;
-        } else {
-            if (base.on_iter) ro[(size_t)r].on_iter = noop_on_iter;   // the caller's hook runs on the calling thread only
-            if (info && info->cost_hist) {
-                ch[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
-                ri[(size_t)r].cost_hist = ch[(size_t)r].data();
-            }
-            if (info && info->svp_hist) {
-                sh[(size_t)r].resize((size_t)std::max<int64_t>(info->hist_capacity, 1));
-                ri[(size_t)r].svp_hist = sh[(size_t)r].data();
-            }
-            ri[(size_t)r].hist_capacity = info ? info->hist_capacity : 0;
-            if (S) Sr[(size_t)r].resize((size_t)d);
-            if (Vt) Vr[(size_t)r].resize((size_t)d * N);
-        }
-    }
-    const int st = multi_run(h, [&](Handle* hr, int r, int nr) -> int {
-        const int64_t bs = M / nr, rem = M % nr;
-        const int64_t lo = r * bs + std::min<int64_t>(r, rem), rows = bs + (r < rem ? 1 : 0);
-        return rpca_entry<T>(static_cast<tlsq_handle>(hr), D + lo, rows, N, ldD, &ro[(size_t)r], A + lo, ldA, E + lo, ldE,
-                             U ? U + lo : nullptr, ldU, S ? (r == 0 ? S : Sr[(size_t)r].data()) : nullptr,
-                             Vt ? (r == 0 ? Vt : Vr[(size_t)r].data()) : nullptr, r == 0 ? ldVt : d, &svr[(size_t)r],
-                             &ri[(size_t)r]);
-    });
-    if (info) *info = ri[0];
-    if (sv) *sv = svr[0];
-    return st;
-}
-
-template <typename T>
-int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, const tlsq_rpca_opts* opts,
-                      T* A, int64_t ldA, T* E, int64_t ldE, T* U, int64_t ldU, T* S, T* Vt, int64_t ldVt,
-                      int64_t* sv, tlsq_rpca_info* info) {
-    TLSQ_TRY(check_handle(h));
-    if (!D || !A || !E || M <= 0 || N <= 0 || ldD < M || ldA < M || ldE < M)
-        return set_err(h, TLSQ_ERR_ARG, "rpca: bad argument (M=%lld N=%lld)", (long long)M, (long long)N);
-    if (is_multi_call(h)) {
-        const bool dev_mem = opts && opts->memory == TLSQ_MEM_DEVICE;
-        if (dev_mem)
-            return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: a multi-GPU handle takes host matrices (device pointers belong "
-                           "to one GPU; use one handle per GPU with tlsq_comm_init for device-resident shards)");
-        // tall problems with enough rows per GPU are row-sharded; anything else - and every call with a caller's svd / opnorm
-        // hook, which needs the whole matrix in one place (include/tlsq.h) - runs on the first GPU alone
-        const bool hook_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
-        if (!hook_cb && M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
-            return rpca_multi<T>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
-    }
-    TLSQ_HIP(h, hipSetDevice(h->device));
-    const double t0 = now_ms();
-    reset_info(info);
-    const double eps_t = (double)std::numeric_limits<T>::epsilon();
-    const ResolvedOpts ro = resolve(opts, M, N, std::sqrt(eps_t));     // tol = sqrt(eps(real(T)))  (:160)
-    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
-    const size_t es = sizeof(T);
-    const int64_t n = M * N;
-    const int64_t d = std::min(ro.m_global, N);
-    if (U && ldU < M) return set_err(h, TLSQ_ERR_ARG, "rpca: ldU < M");
-    if (Vt && ldVt < d) return set_err(h, TLSQ_ERR_ARG, "rpca: ldVt < min(M,N)");
-    // rpca is invariant under transposition (elementwise sweeps, singular-value thresholding, lambda =
-    // 1/sqrt(max(M,N))).  A wide unsharded D is solved as its tall transpose: the Gram matrix is then M x M
-    // and has no structurally-zero eigenvalues (accuracy of the Gram route).
-    const bool transposed = (M < N) && ro.m_global == M && !h->comm;
-    // the small-matrix solvers of this release keep their panels in LDS: the Gram dimension is limited
-    if ((transposed ? M : N) > kGramMaxN)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: min(M,N) = %lld exceeds %lld, the largest Gram dimension of this "
-                       "release", (long long)(transposed ? M : N), (long long)kGramMaxN);
-
-    // The panels the MFMA kernels stream (Z, R, ...) inherit the row count of the working problem as their leading
-    // dimension.  The Gram kernel reads 16-row (128-byte) segments of every column: when the leading dimension is
-    // not a multiple of 16 every segment straddles two cache lines (measured 3x slower at 9,999,745 rows), and an
-    // odd one also forces 8-byte loads.  So the row count is padded with zero rows to a multiple of 16 in private
-    // panels — zero rows change nothing in the algorithm (lambda and d use the true size through m_global).
-    const int64_t Mw = transposed ? N : M;          // rows of the working (tall) problem
-    const int64_t Nw = transposed ? M : N;
-    const bool has_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
-    // soft_hankel! would see the extra rows, and so would a caller's svd / opnorm hook: keep the exact shape there
-    const bool pad = (Mw % 16 != 0) && !ro.hankel && !has_cb;
-    const int64_t Mp = pad ? (Mw + 15) / 16 * 16 : Mw;
-    const size_t nw = (size_t)Mp * Nw;
-
-    const T* dD = D;
-    T *dA = A, *dE = E, *dU = U;
-    void* p;
-    double th = now_ms();
-    const bool priv = !dev || transposed || pad;    // work on private panels?
-    if (!dev || ldD != M) {
-        TLSQ_TRY(ws_get(h, WS_D, (size_t)n * es, &p));
-        if (dev) {
-            TLSQ_TRY(copy2d(h, p, M, D, ldD, M, N, es, hipMemcpyDeviceToDevice));
-        } else {
-            // the caller's (pageable) matrix: pinned slots on worker threads instead of the runtime's one-thread bounce buffer
-            const StageJob up{p, M, D, ldD, M, N, es, true};
-            TLSQ_TRY(staged_copy(h, &up, 1));
-        }
-        dD = (const T*)p;
-    }
-    if (!dev || ldA != M) {
-        TLSQ_TRY(ws_get(h, WS_A, (size_t)n * es, &p));
-        dA = (T*)p;
-    }
-    if (!dev || ldE != M) {
-        TLSQ_TRY(ws_get(h, WS_E, (size_t)n * es, &p));
-        dE = (T*)p;
-    }
-    if (U && !transposed && !pad && (!dev || ldU != M)) {
-        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)M * d * es, &p));
-        dU = (T*)p;
-    }
-    (void)priv;
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) info->ms_h2d = now_ms() - th;
-
-    // S / Vt are small: always produced on the host in fp64, then converted / copied to the caller's memory
-    std::vector<double> hS((size_t)(S ? d : 0)), hVt((size_t)(Vt ? d * N : 0));
-    int status;
-    // Host-pointer call that also returns s: A and E are final when the loop ends, 10+ ms before U, S, Vt are - their 164 MB go
-    // back to the caller's memory on the staging workers WHILE the decomposition of the last Z runs (a thread of its own drives
-    // the staged copy; the solver thread keeps queueing kernels).
-    std::thread ae_thread;
-    int ae_status = TLSQ_OK;
-    bool ae_sent = false;
-    if (!transposed && !pad) {
-        ResolvedOpts ro2 = ro;
-        // (the download thread shares the handle with the solver thread: it only ever takes the pinned-slot path of
-        //  staged_copy - below 1 MB that function would use the handle's own stream - the stager exists before the thread
-        //  does, set_err is serialised (runtime.hip), and a thread that cannot be created means the copy happens after the
-        //  decomposition as in a call without `s`; the guard joins on every way out of this scope)
-        struct JoinGuard {
-            std::thread& t;
-            ~JoinGuard() {
-                if (t.joinable()) t.join();
-            }
-        } ae_guard{ae_thread};
-        const std::function<void()> send_ae = [&]() {
-            if (dev || dA == A || dE == E) return;
-            if ((size_t)n * es < ((size_t)1 << 20)) return;
-            if (staged_copy(h, nullptr, 0) < 0) return;   // (creates the staging workers' streams on this thread)
-            try {
-                ae_thread = std::thread([&]() {
-                    StageJob down[2] = {StageJob{A, ldA, dA, M, M, N, es, false}, StageJob{E, ldE, dE, M, M, N, es, false}};
-                    ae_status = staged_copy(h, down, 2);
-                });
-                ae_sent = true;
-            } catch (...) {
-                ae_sent = false;
-            }
-        };
-        ro2.ae_final = &send_ae;
-        status = rpca_core<T>(h, dD, M, N, ro2, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
-                              Vt ? hVt.data() : nullptr, d, sv, info);
-        if (ae_thread.joinable()) ae_thread.join();
-        (void)hipSetDevice(h->device);
-        if (status < 0) return status;
-        if (ae_status < 0) return ae_status;
-    } else {
-        // working copies: Dw (Mp x Nw) = D or D', zero pad row; Aw, Ew results; Uw (Mp x d) left vectors of Zw
-        void *Dw, *Aw, *Ew, *Uw = nullptr;
-        TLSQ_TRY(ws_get(h, WS_DT, nw * es, &Dw));
-        TLSQ_TRY(ws_get(h, WS_AT, nw * es, &Aw));
-        TLSQ_TRY(ws_get(h, WS_ET, nw * es, &Ew));
-        const bool need_Uw = transposed ? (Vt != nullptr) : (U != nullptr);
-        if (need_Uw) TLSQ_TRY(ws_get(h, WS_UT, (size_t)Mp * d * es, &Uw));
-        if (pad) TLSQ_HIP(h, hipMemsetAsync(Dw, 0, nw * es, h->stream));
-        if (transposed) TLSQ_TRY(launch_transpose<T>(h, dD, M, M, N, (T*)Dw, Mp));
-        else TLSQ_TRY(copy2d(h, Dw, Mp, dD, M, M, N, es, hipMemcpyDeviceToDevice));
-        ResolvedOpts rw = ro;
-        rw.m_global = transposed ? N : ro.m_global;
-        std::vector<double> hVtW((size_t)d * Nw);                      // right vectors of the working problem
-        status = rpca_core<T>(h, (const T*)Dw, Mp, Nw, rw, opts, (T*)Aw, (T*)Ew, need_Uw ? (T*)Uw : nullptr,
-                              S ? hS.data() : nullptr, (transposed ? (U != nullptr) : (Vt != nullptr)) ? hVtW.data() : nullptr,
-                              d, sv, info);
-        if (status < 0) return status;
-        if (transposed) {
-            TLSQ_TRY(launch_transpose<T>(h, (const T*)Aw, Mp, N, M, dA, M));
-            TLSQ_TRY(launch_transpose<T>(h, (const T*)Ew, Mp, N, M, dE, M));
-            if (Vt) {   // Vt (d x N) = Uw^T  (Uw is N(+1) x d, ld Mp)
-                std::vector<T> hu((size_t)Mp * d);
-                TLSQ_HIP(h, hipMemcpyAsync(hu.data(), Uw, (size_t)Mp * d * es, hipMemcpyDeviceToHost, h->stream));
-                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-                for (int64_t pcol = 0; pcol < d; ++pcol)
-                    for (int64_t j = 0; j < N; ++j) hVt[pcol + j * d] = (double)hu[j + pcol * Mp];
-            }
-            if (U) {    // U (M x d) = VtW^T
-                std::vector<T> hu((size_t)M * d);
-                for (int64_t pcol = 0; pcol < d; ++pcol)
-                    for (int64_t i = 0; i < M; ++i) hu[i + pcol * M] = (T)hVtW[pcol + i * d];
-                TLSQ_TRY(copy2d(h, U, ldU, hu.data(), M, M, d, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            }
-        } else {
-            TLSQ_TRY(copy2d(h, dA, M, Aw, Mp, M, N, es, hipMemcpyDeviceToDevice));
-            TLSQ_TRY(copy2d(h, dE, M, Ew, Mp, M, N, es, hipMemcpyDeviceToDevice));
-            if (Vt) hVt = hVtW;
-            if (U) {
-                TLSQ_TRY(copy2d(h, U, ldU, Uw, Mp, M, d, es, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            }
-        }
-    }
-
-    th = now_ms();
-    const hipMemcpyKind back = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (dev) {
-        if (dA != A) TLSQ_TRY(copy2d(h, A, ldA, dA, M, M, N, es, back));
-        if (dE != E) TLSQ_TRY(copy2d(h, E, ldE, dE, M, M, N, es, back));
-        if (U && !transposed && !pad && dU != U) TLSQ_TRY(copy2d(h, U, ldU, dU, M, M, d, es, back));
-    } else {
-        // A, E (and U) go back to the caller's memory together, pipelined through the pinned slots
-        StageJob down[3];
-        int nd = 0;
-        if (dA != A && !ae_sent) down[nd++] = StageJob{A, ldA, dA, M, M, N, es, false};
-        if (dE != E && !ae_sent) down[nd++] = StageJob{E, ldE, dE, M, M, N, es, false};
-        if (U && !transposed && !pad && dU != U) down[nd++] = StageJob{U, ldU, dU, M, M, d, es, false};
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        TLSQ_TRY(staged_copy(h, down, nd));
-    }
-    std::vector<T> tS, tVt;
-    if (S) {
-        tS.resize((size_t)d);
-        for (int64_t i = 0; i < d; ++i) tS[i] = (T)hS[i];
-        TLSQ_HIP(h, hipMemcpyAsync(S, tS.data(), (size_t)d * es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
-                                   h->stream));
-    }
-    if (Vt) {
-        tVt.resize((size_t)d * N);
-        for (size_t i = 0; i < tVt.size(); ++i) tVt[i] = (T)hVt[i];
-        TLSQ_TRY(copy2d(h, Vt, ldVt, tVt.data(), d, d, N, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-    }
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    if (info) {
-        info->ms_d2h = now_ms() - th;
-        info->ms_total = now_ms() - t0;
-    }
-    return status;
-}
-
-
-// explicit instantiations used by api.hip
 template int opnorm_gram<double>(Handle*, const double*, int64_t, int64_t, int64_t, double*, int64_t*, double, double, int);
 template int svd_via_gram<double>(Handle*, const double*, int64_t, int64_t, int64_t, double**, SmallSvd&, int64_t*,
                                   PhaseTimer*);
@@ -3629,9 +2161,4 @@ template int rebuild_lowrank<float>(Handle*, const float*, int64_t, int64_t, int
                                     const std::vector<int32_t>&, const std::vector<double>&, float*, int64_t);
 template int rpca_core<float>(Handle*, const float*, int64_t, int64_t, const ResolvedOpts&, const tlsq_rpca_opts*, float*,
                               float*, float*, double*, double*, int64_t, int64_t*, tlsq_rpca_info*);
-template int rpca_entry<double>(tlsq_handle, const double*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, double*,
-                                int64_t, double*, int64_t, double*, int64_t, double*, double*, int64_t, int64_t*,
-                                tlsq_rpca_info*);
-template int rpca_entry<float>(tlsq_handle, const float*, int64_t, int64_t, int64_t, const tlsq_rpca_opts*, float*, int64_t,
-                               float*, int64_t, float*, int64_t, float*, float*, int64_t, int64_t*, tlsq_rpca_info*);
 }  // namespace tlsq
