@@ -114,7 +114,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
-    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE)
+    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -313,10 +313,12 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
 bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
                     const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg = HankelGeom());
 int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl);
+int fused_zgram_warm(Handle* h);   // first-launch costs of the kernel's instantiations (once per process)
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
-                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first = false, double s_div = 1.0);
+                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first = false, double s_div = 1.0,
+                       bool gram_of_r = false);
 
 // ---------------- matfun.hip ----------------
 // sign function / inverse square root of small symmetric matrices by Newton-Schulz iterations (N x N fp64, ld N; products on

@@ -146,8 +146,10 @@ struct FzLds {
 // One workgroup: rows [kbeg, kend) x columns [gc0, gc0 + 256) of the panels; Cz = its slab of partial Gram entries.
 //   RMAX: compiled length of the factor product (r <= RMAX); HK: implicit Hankel D (one channel, lag 1);
 //   NN: the nonnegA / nonnegE projections are compiled in; RS: ring slots (columns in flight per sweep thread: RS - 1);
-//   FIRST: iteration 1 instead (k_first_shrink: Y_1 = D / s, A = 0, Z_1 - src/robustPCA.jl:181, :188-192 - nothing but D is read)
-template <int RMAX, bool HK, bool NN, int RS, bool FIRST>
+//   FIRST: iteration 1 instead (k_first_shrink: Y_1 = D / s, A = 0, Z_1 - src/robustPCA.jl:181, :188-192 - nothing but D is read);
+//   GR: the Gram matrix accumulated is that of the residual R_k (what the convergence test :225 takes the norm of) instead
+//   of Z_{k+1}'s - the rows of R_k go to the LDS stage, R_k itself need not be stored
+template <int RMAX, bool HK, bool NN, int RS, bool FIRST, bool GR>
 __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int64_t kend, int gc0, double* __restrict__ Cz,
                                            double* __restrict__ smem) {
     using L = FzLds<RMAX>;
@@ -390,7 +392,7 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
                         zn[q] = (cd[q] - ee) + tt;                       //                                         :192
                     }
                     }
-                    *reinterpret_cast<d2*>(zs + 32 * j * FZ_R) = zn;
+                    *reinterpret_cast<d2*>(zs + 32 * j * FZ_R) = GR ? rr : zn;
                     {
                         const int64_t u = ubase(j, r0);
                         fz_st(Rbase + u, Rp ? stleft - u : 0, vo_c, rr);
@@ -457,7 +459,7 @@ __device__ __forceinline__ void fused_body(const FusedArgs& P, int64_t kbeg, int
 }
 
 // blockIdx.x = chunk * (N / 256) + column block
-template <int RMAX, bool HK, bool NN, int RS, bool FIRST>
+template <int RMAX, bool HK, bool NN, int RS, bool FIRST, bool GR>
 __global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram(const FusedArgs P) {
     extern __shared__ __attribute__((aligned(16))) double fz_smem[];
     if (P.zero_slots && blockIdx.x == 0 && threadIdx.x < 72) P.zero_slots[threadIdx.x] = 0.0;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fused_zgram(const FusedArgs P) {
     const int64_t kbeg = (int64_t)z * P.kchunk;
     if (z >= P.nz || kbeg >= P.M) return;
     const int64_t kend = kbeg + P.kchunk < P.M ? kbeg + P.kchunk : P.M;
-    fused_body<RMAX, HK, NN, RS, FIRST>(P, kbeg, kend, FZ_NC * cb, P.slab + (size_t)z * P.N * P.N, fz_smem);
+    fused_body<RMAX, HK, NN, RS, FIRST, GR>(P, kbeg, kend, FZ_NC * cb, P.slab + (size_t)z * P.N * P.N, fz_smem);
 }
 
 inline bool fz_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -519,27 +521,50 @@ int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
 }
 
 namespace {
-template <int RM, bool HKF, bool NNF, int RSF, bool FIRSTF>
+template <int RM, bool HKF, bool NNF, int RSF, bool FIRSTF, bool GRF = false>
 int fz_launch(Handle* h, const FusedArgs& a, unsigned grid) {
     const size_t lds = (size_t)FzLds<RM>::TOTAL * sizeof(double);
     static bool attr_set = false;   // (per instantiation; idempotent)
     if (!attr_set) {
-        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF>),
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF, GRF>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);
+    hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF, GRF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
 }  // namespace
 
+// the dynamic-LDS attribute of every instantiation rpca_core may launch (a launch with zero workgroups each: nothing runs)
+int fused_zgram_warm(Handle* h) {
+    static bool done = false;
+    if (done) return TLSQ_OK;
+    FusedArgs a = {};
+    a.nz = 0;
+    a.N = FZ_NC;
+    a.kchunk = FZ_R;
+#define FZ_WARM(RM, HKF, NNF, RSF)                                   \
+    TLSQ_TRY((fz_launch<RM, HKF, NNF, RSF, false, false>(h, a, 1))); \
+    TLSQ_TRY((fz_launch<RM, HKF, NNF, RSF, false, true>(h, a, 1)))
+    FZ_WARM(8, true, false, FZ_RS_HK);
+    FZ_WARM(16, true, false, FZ_RS_HK);
+    FZ_WARM(8, false, false, FZ_RS_D);
+    FZ_WARM(16, false, false, FZ_RS_D);
+#undef FZ_WARM
+    TLSQ_TRY((fz_launch<8, true, false, FZ_RS_HK, true>(h, a, 1)));
+    TLSQ_TRY((fz_launch<8, false, false, FZ_RS_D, true>(h, a, 1)));
+    done = true;
+    return TLSQ_OK;
+}
+
 // first = true: iteration 1 (launch_first_shrink's arguments: Y_1 = D / s_div to Yout, Z_1 to Zout, inv_mu = 1 / mu_1,
-// thr_n = lambda / mu_1; Tm, Vs, Yin, Zin, R, mu, inv_mu_n, nonnegA, sumsq unused)
+// thr_n = lambda / mu_1; Tm, Vs, Yin, Zin, R, mu, inv_mu_n, nonnegA, sumsq unused); gram_of_r: the slabs receive R_k' R_k
+// instead of Z_{k+1}' Z_{k+1} and R_k is not stored
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
-                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first, double s_div) {
+                       const double* hankel_y, int64_t hankel_K, int maxslot, bool first, double s_div, bool gram_of_r) {
     if (!sumsq || maxslot > 7) maxslot = -1;
     FusedArgs a;
     a.D = hankel_y ? hankel_y : D;
@@ -549,7 +574,7 @@ int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const dou
     a.Yout = Yout;
     a.Zin = first ? Zout : Zin;
     a.Zout = Zout;
-    a.R = first ? nullptr : R;
+    a.R = (first || gram_of_r) ? nullptr : R;
     a.M = M;
     a.ld = M;
     a.N = (int)N;
@@ -575,16 +600,22 @@ int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const dou
         if (hk) return nonnegE ? fz_launch<8, true, true, FZ_RS_HK, true>(h, a, grid) : fz_launch<8, true, false, FZ_RS_HK, true>(h, a, grid);
         return nonnegE ? fz_launch<8, false, true, FZ_RS_D, true>(h, a, grid) : fz_launch<8, false, false, FZ_RS_D, true>(h, a, grid);
     }
-#define FZ_PICK(RM)                                                                      \
-    do {                                                                                 \
-        if (hk && nn) return fz_launch<RM, true, true, FZ_RS_HK, false>(h, a, grid);     \
-        else if (hk) return fz_launch<RM, true, false, FZ_RS_HK, false>(h, a, grid);     \
-        else if (nn) return fz_launch<RM, false, true, FZ_RS_D, false>(h, a, grid);      \
-        else return fz_launch<RM, false, false, FZ_RS_D, false>(h, a, grid);             \
+#define FZ_PICK2(RM, GRF)                                                                     \
+    do {                                                                                      \
+        if (hk && nn) return fz_launch<RM, true, true, FZ_RS_HK, false, GRF>(h, a, grid);     \
+        else if (hk) return fz_launch<RM, true, false, FZ_RS_HK, false, GRF>(h, a, grid);     \
+        else if (nn) return fz_launch<RM, false, true, FZ_RS_D, false, GRF>(h, a, grid);      \
+        else return fz_launch<RM, false, false, FZ_RS_D, false, GRF>(h, a, grid);             \
+    } while (0)
+#define FZ_PICK(RM)                     \
+    do {                                \
+        if (gram_of_r) FZ_PICK2(RM, true); \
+        else FZ_PICK2(RM, false);       \
     } while (0)
     if (r <= 8) FZ_PICK(8);
     else FZ_PICK(16);
 #undef FZ_PICK
+#undef FZ_PICK2
 }
 
 }  // namespace tlsq

@@ -1098,7 +1098,18 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         return TLSQ_OK;
     };
     bool g_ready = false;   // WS_G already holds (or will hold, in stream order) the Gram of the current Z
+    if constexpr (std::is_same<T, double>::value) {
+        // the fused sweep + Gram kernel (fused.hip) will most likely serve this call: its slabs (one 272 KB partial Gram per CU,
+        // 134 MB) and kernel attributes are set up here, not inside the first iterations of the loop
+        if (zmode && !implicit_gram && !hook_svd && !large &&
+            fused_zgram_ok(M, N, 0, ro.hankel_y ? nullptr : Y, Y, Y, Y, Y, nullptr, ro.hankel_y != nullptr, lam / mu, ro.hankel_geom)) {
+            GramPlan pl0;
+            TLSQ_TRY(fused_zgram_plan(h, M, N, &pl0));
+            TLSQ_TRY(fused_zgram_warm(h));
+        }
+    }
     const double t_loop0 = now_ms();
+    bool prev_cost_evaluated = false;   // the previous iteration's convergence test needed opnorm(R) itself (see fused_gr below)
     int64_t k = 0;
     for (k = 1; k <= ro.iters; ++k) {                              // :186
         // (test hook, FAIL_RANK=r: rank r of a group leaves iteration 3 with an error - the others must not hang)
@@ -1613,6 +1624,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last && !hook_sketch;
         bool gram_queued = false;
         bool fused_gram = false;   // the sweep kernel has accumulated the Gram of Z_{k+1} as well (fused.hip): only its slabs are left to add
+        bool fused_gr = false;     // ... the Gram of the residual R_k instead (and R_k was not stored)
+        bool gr_ready = false;     // R_k' R_k sits in the cost evaluation's Gram slot
         GramPlan fused_pl;
         // one launch of the fused sweep over rows [r0, r1) (r1 = 0: the whole panel): E-free form or classic form
         const T* hy_sweep = (const T*)ro.hankel_y;
@@ -1672,10 +1685,20 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 if (zmode && gram_next && env_chunks < 0 &&
                     fused_zgram_ok(M, N, svp, D, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1], Rst, hy_sweep != nullptr,
                                    lam / mu_next, ro.hankel_geom)) {
+                    // The sweep was going to store R_k, i.e. the cost of this iteration will most likely be evaluated (the
+                    // bound is close to tol): the kernel then accumulates R_k' R_k - what opnorm(R_k) (:225) is taken from -
+                    // instead of the Gram of Z_{k+1}, and R_k is not stored at all.  Should the loop go on, the Gram of Z_{k+1}
+                    // is formed at the top of the next iteration (as after any iteration that did not queue it).
+                    // (only when the previous iteration's cost had to be evaluated exactly - its bounds could not settle
+                    //  "not converged" - so that this one's will be too: a sweep that stores R_k is not enough of a sign, at
+                    //  C3 two of four such iterations are still settled by the bounds and would pay for the Gram of Z_{k+1}
+                    //  they did not accumulate)
+                    fused_gr = Rst != nullptr && prev_cost_evaluated && !dev_is(DEV_NO_FUSED_GR, '1');
                     TLSQ_TRY(fused_zgram_plan(h, M, N, &fused_pl));
                     TLSQ_TRY(launch_fused_zgram(h, fused_pl, D, Tm_last, Vs_last, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1],
                                                 Rst, M, N, svp, mu, inv_mu, ro.nonnegA ? 1 : 0, 1.0 / mu_next, lam / mu_next,
-                                                ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K, maxslot));
+                                                ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, hy_sweep, ro.hankel_K, maxslot, false,
+                                                1.0, fused_gr));
                     fused_gram = true;
                     nchunks = 0;
                 }
@@ -1706,7 +1729,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(sweep_rows(0, 0, 0));
             }
             if (zmode) z_swept = true;
-            hbm_sweeps += ((Rst ? 7.0 : 6.0) - (zmode ? 1.0 : 0.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
+            hbm_sweeps += (((Rst && !fused_gr) ? 7.0 : 6.0) - (zmode ? 1.0 : 0.0) - (ro.hankel_y ? 1.0 : 0.0)) * panel_bytes;
         } else if (fuse) {
             // :217-222 of this iteration and :188-192 of the next one in a single pass over the panels
             TLSQ_TRY(panel_D(&D));
@@ -1727,7 +1750,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (zmode && z_swept) {
             dbg_hash(h, "sweep.Y", Ybuf[ycur ^ 1], (size_t)n * sizeof(T), k);
             dbg_hash(h, "sweep.Z", Zbuf[zc ^ 1], (size_t)n * sizeof(T), k);
-            if (Rst) dbg_hash(h, "sweep.R", Rst, (size_t)n * sizeof(T), k);
+            if (Rst && !fused_gr) dbg_hash(h, "sweep.R", Rst, (size_t)n * sizeof(T), k);
         }
         mu = mu_next;
         double rn = 0.0;
@@ -1756,6 +1779,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                 hbm_other += panel_bytes;
                 g_ready = true;
+            } else if (fused_gram && fused_gr) {
+                void* Gv;   // (g_ready stays false: the cost evaluation below reads WS_G)
+                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                TLSQ_TRY(gram_reduce(h, h->stream, fused_pl, (double*)Gv, N));
+                TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
+                gr_ready = true;
             } else if (fused_gram) {
                 void* Gv;
                 TLSQ_TRY(ws_get(h, Gslot[gcur ^ 1], (size_t)N * N * 8, &Gv));
@@ -1857,8 +1886,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             } else {                                                                               // :225
                 void* Gc;
                 TLSQ_TRY(ws_get(h, cost_gslot, (size_t)N * N * 8, &Gc));
-                TLSQ_TRY(gram_any(h, R, Prec<T>::f32, M, N, M, (double*)Gc, N));
-                TLSQ_TRY(comm_allreduce(h, (double*)Gc, (size_t)N * N, ncclSum));
+                if (!gr_ready) {   // (gr_ready: the fused sweep has left R_k' R_k here, all-reduced)
+                    TLSQ_TRY(gram_any(h, R, Prec<T>::f32, M, N, M, (double*)Gc, N));
+                    TLSQ_TRY(comm_allreduce(h, (double*)Gc, (size_t)N * N, ncclSum));
+                }
                 bool settled = false;
                 if (stop_sigma > 0.0 && !no_power_lb) {
                     // "not converged" from three power steps on the vector carried over from the previous evaluation
@@ -1876,7 +1907,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 }
                 if (!settled) TLSQ_TRY(sigma_max_of_gram(h, (const double*)Gc, N, cost_rel, &rn, &sweeps, stop_sigma));
             }
-            hbm_other += panel_bytes;
+            if (!gr_ready) hbm_other += panel_bytes;
             cost = rn / d_norm;
             if (std::fabs(cost - ro.tol) <= 1e-5 * ro.tol) {       // too close to call: full accuracy
                 if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(R), N, 1e-13, &rn));
@@ -1884,6 +1915,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 cost = rn / d_norm;
             }
         }
+        prev_cost_evaluated = !cost_skipped;
         pt.mark(cost_skipped);
         pt.next_iteration(acc);   // (no stream-wide synchronisation here: the next Gram may still be running)
         if (info) {
