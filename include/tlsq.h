@@ -388,7 +388,8 @@ int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const do
 /* The same sweep and the Gram matrix G (N x N, ldG, both triangles) = Zout' Zout of the Z_{k+1} it writes, in one kernel
  * (fused.hip: the rows of Z_{k+1} feed the fp64 MFMA from LDS on their way to memory; split-K slabs summed in a fixed
  * order).  Zin = Z_k is read, Zout = Z_{k+1} written (the same buffer is allowed).  A_k always from its factors.  Serves
- * contiguous fp64 panels (ld = M) of N = 256 columns, even M (>= 400000 rows), r <= 16, a threshold >= 0, 16-byte aligned;
+ * contiguous fp64 panels (ld = M) of N = 256 columns (even M >= 400000 rows) or N = 512 (>= 65536 rows: the kernel covers the
+ * diagonal 256-column blocks, the off-diagonal block follows from the stored Zout), r <= 16, a threshold >= 0, 16-byte aligned, ldG = N;
  * TLSQ_ERR_UNSUPPORTED otherwise (rpca then runs k_zsweep and the Gram kernel one after the other).  hankel_y (optional): D is
  * the implicit Hankel matrix D[i, j] = hankel_y[i + j] for i < hankel_K, zero rows below (D itself is not read).
  * sumsq (optional, 72 doubles, zeroed by the caller): [0, 64) sum to ||R_k||_F^2, [64] = max |R_k[i, j]| as a bit pattern. */

@@ -38,20 +38,22 @@ def soft_th(x, e):                      # src/robustPCA.jl:1
     return np.maximum(x - e, 0) + np.minimum(x + e, 0)
 
 
-@pytest.mark.parametrize("M,r,hankel,nonneg,with_r", [
-    (40_000, 16, False, 0, True),       # whole stages only
-    (40_006, 8, False, 0, False),       # a partial last stage, no residual store
-    (33_334, 3, True, 0, True),         # implicit Hankel D with zero pad rows at the end (hankel_K < M)
-    (40_000, 0, True, 0, False),        # rank 0: A = 0
-    (36_010, 5, False, 1, True),        # nonnegA / nonnegE compiled in
-    (36_010, 16, True, 1, True),
+@pytest.mark.parametrize("M,r,hankel,nonneg,with_r,N", [
+    (40_000, 16, False, 0, True, 256),       # whole stages only
+    (40_006, 8, False, 0, False, 256),       # a partial last stage, no residual store
+    (33_334, 3, True, 0, True, 256),         # implicit Hankel D with zero pad rows at the end (hankel_K < M)
+    (40_000, 0, True, 0, False, 256),        # rank 0: A = 0
+    (36_010, 5, False, 1, True, 256),        # nonnegA / nonnegE compiled in
+    (36_010, 16, True, 1, True, 256),
+    (30_000, 16, False, 0, True, 512),       # N = 512: two diagonal blocks fused + the off-diagonal block from the stored Z
+    (20_010, 7, False, 1, False, 512),
+    (16_390, 4, True, 0, True, 512),
 ])
-def test_fused_sweep_gram_kernel(eng, torch_mod, M, r, hankel, nonneg, with_r):
+def test_fused_sweep_gram_kernel(eng, torch_mod, M, r, hankel, nonneg, with_r, N):
     """One launch against (a) k_zsweep + the Gram kernel on the same buffers: bit-identical panels, G to 1e-13; (b) the
     reference's statements in numpy started from a consistent state: to the rounding of Z."""
     import tlsq_amd
     torch = torch_mod
-    N = 256
     rng = np.random.default_rng(M + 7 * r)
     K = M - 6 if hankel else M
     if hankel:
@@ -142,7 +144,7 @@ def test_fused_kernel_declines_what_it_does_not_serve(eng, torch_mod):
     assert call(1000, 256, 4) == unsupported          # short panel
     with tlsq_amd.dev_switches(FUSED_ZGRAM_MINROWS=16):
         assert call(1001, 256, 4) == unsupported      # odd M
-        assert call(1000, 512, 4) == unsupported      # other width
+        assert call(1000, 384, 4) == unsupported      # other width
         assert call(1000, 256, 17) == unsupported     # rank
         assert call(1000, 256, 4, thr=-1.0) == unsupported
 

@@ -35,6 +35,7 @@ def main():
     torch.zeros(1, device="cuda")
     eng = tlsq_amd.Engine(0)
     lib, h = eng.lib, eng.h
+    lib.tlsq_dev_set(b"FUSED_ZGRAM_N512", b"1")   # (N = 512: the diagonal 256-column blocks only - timing, G mismatches)
     if a.minrows:
         lib.tlsq_dev_set(b"FUSED_ZGRAM_MINROWS", str(a.minrows).encode())
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None

@@ -834,13 +834,14 @@ int tlsq_k_zsweep_gram_f64(tlsq_handle h, const double* D, const double* Tm, con
         (r > 0 && (!Tm || !Vs)))
         return set_err(h, TLSQ_ERR_ARG, "k_zsweep_gram: bad argument");
     if (!fused_zgram_ok(M, N, r, D, Yin, Yout, Zin, Zout, R, hankel_y != nullptr, thr_next))
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_gram: fp64 panels of 256 columns, even M above the row floor, rank <= 16, 16-byte alignment");
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_gram: fp64 panels of 256 or 512 columns, even M above the row floor, rank <= 16, 16-byte alignment");
     TLSQ_HIP(h, hipSetDevice(h->device));
     GramPlan pl;
     TLSQ_TRY(fused_zgram_plan(h, M, N, &pl));
     TLSQ_TRY(launch_fused_zgram(h, pl, D, Tm, Vs, Yin, Yout, Zin, Zout, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
                                 nonnegE, sumsq, nullptr, hankel_y, hankel_K, sumsq ? 0 : -1));
-    return gram_reduce(h, h->stream, pl, G, ldG);
+    if (ldG != N) return set_err(h, TLSQ_ERR_ARG, "k_zsweep_gram: ldG = N");
+    return fused_zgram_finish(h, pl, Zout, M, N, G);
 }
 int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,
                        const double* Y, double* E, int64_t M, int64_t N, int64_t r, double inv_mu, double thr, int nonnegA,

@@ -48,6 +48,7 @@ struct Handle {
     double mail_seq = 0.0;
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     int64_t gram_tab2_nti = 0;
+    bool gram_tab3_ready = false;      // the four-tile list of gram_offdiag_plan is on the device
     int64_t gram_tab_nti = 0;          // tile-order table in WS_GRAMTAB is the one for this many tile rows
     bool cert_ticket_ready = false;    // ... and the one of k_sq_norm
     Comm* comm = nullptr;
@@ -114,7 +115,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
-    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR)
+    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -146,6 +147,7 @@ enum WsSlot {
     WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
+    WS_GRAMTAB3, WS_SLAB2,   // off-diagonal block of an N = 512 Gram matrix beside the fused sweep kernel: tile list, slabs
     WS_HKSUM,     // soft_hankel! on row shards: anti-diagonal sums and counts of the whole matrix (solver.hip)
     WS_CP1, WS_CP2, WS_CPART,   // power certificate: S^2, S^4, norm partials
     WS_T2, WS_VS2, WS_VS3, WS_T3,
@@ -302,6 +304,10 @@ int gram_launch_chunk(Handle* h, hipStream_t st, const GramPlan& pl, const void*
                       const double* skip = nullptr);
 int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_t ldg, const double* skip = nullptr,
                 double* normpart = nullptr, int* normblocks = nullptr);
+// N = 512 beside the fused sweep kernel: the off-diagonal 256 x 256 block from the stored panel, and the reduction of both slab sets
+int gram_offdiag_plan(Handle* h, int64_t N, int64_t K, GramPlan* pl);
+int gram_offdiag_launch(Handle* h, hipStream_t st, const GramPlan& pl, const double* Z, int64_t ld, int64_t rows);
+int gram_reduce2(Handle* h, hipStream_t st, const GramPlan& plA, const GramPlan& plB, double* G, int64_t ldg);
 int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t ldZ, double* G, int64_t ldG,
              int mfma32 = -1);   // fp32 panels: -1 library's choice, 0 fp64 MFMA on widened operands, 1 fp32 MFMA + fp64 fold-in
 
@@ -313,6 +319,7 @@ int gram_any(Handle* h, const void* Z, int z_f32, int64_t M, int64_t N, int64_t 
 bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
                     const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg = HankelGeom());
 int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl);
+int fused_zgram_finish(Handle* h, const GramPlan& pl, const double* Zout, int64_t M, int64_t N, double* G);   // slabs (+ the off-diagonal block at N = 512) -> G
 int fused_zgram_warm(Handle* h);   // first-launch costs of the kernel's instantiations (once per process)
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,

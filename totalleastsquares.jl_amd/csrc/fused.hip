@@ -481,7 +481,10 @@ inline bool fz_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* Yin, const void* Yout, const void* Zin,
                     const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg) {
     if (dev_is(DEV_NO_FUSED_ZGRAM, '1')) return false;
-    if (N != FZ_NC) return false;   // (wider panels: the kernel covers the diagonal 256-column blocks of the Gram matrix only)
+    // N = 512: the kernel covers the two diagonal 256-column blocks of the Gram matrix (two workgroups per row chunk), the caller
+    // adds the off-diagonal block from the stored panel (gemm.hip, gram_offdiag_*): worth it from ~50000 rows (measured
+    // sweep + Gram 389 -> ~350 us at 50000 rows, 793 -> ~690 at 100000, 1534 -> ~1240 at 200000)
+    if (N != FZ_NC && !(N == 2 * FZ_NC && !dev_is(DEV_FUSED_ZGRAM_N512, '0'))) return false;
     if (r < 0 || r > 16 || (M & 1)) return false;
     if (!(thr_n >= 0.0) || !std::isfinite(thr_n)) return false;
     if (hankel && (hg.lag != 1 || hg.Dch != 1)) return false;
@@ -490,7 +493,7 @@ bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* 
     // one workgroup per CU whatever M is, each with its own 272 KB of partial sums: below ~400k rows the slabs (134 MB, a sixth
     // of a panel there) and their reduction cost what the fusion saves (measured: 131072 rows 395 us against 402 us for the
     // two kernels, 1e6 rows 1845 against 2822)
-    if (M < (min_rows > 0 ? min_rows : 400000)) return false;
+    if (M < (min_rows > 0 ? min_rows : (N == FZ_NC ? 400000 : 65536))) return false;
     if (!(hankel || fz_aligned16(D)) || !fz_aligned16(Yin) || !fz_aligned16(Yout) || !fz_aligned16(Zin) || !fz_aligned16(Zout) ||
         !fz_aligned16(R))
         return false;
@@ -517,7 +520,21 @@ int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
     pl->nchunks = 1;
     pl->z_f32 = 0;
     pl->slab = (double*)slab;
+    if (N != FZ_NC) {   // (the off-diagonal block's slabs and tile list exist from here on as well)
+        GramPlan pl2;
+        TLSQ_TRY(gram_offdiag_plan(h, N, M, &pl2));
+    }
     return TLSQ_OK;
+}
+
+// What follows the kernel: N = 256 - the fixed-order sum of its slabs; N = 512 - the off-diagonal block of the Gram matrix from
+// the panel the kernel has written (Zout: device, M x N, ld M), then the sum of both slab sets.  G: N x N, ld N, both triangles.
+int fused_zgram_finish(Handle* h, const GramPlan& pl, const double* Zout, int64_t M, int64_t N, double* G) {
+    if (N == FZ_NC) return gram_reduce(h, h->stream, pl, G, N);
+    GramPlan pl2;
+    TLSQ_TRY(gram_offdiag_plan(h, N, M, &pl2));
+    TLSQ_TRY(gram_offdiag_launch(h, h->stream, pl2, Zout, M, M));
+    return gram_reduce2(h, h->stream, pl, pl2, G, N);
 }
 
 namespace {

@@ -605,10 +605,12 @@ __global__ __launch_bounds__(512) void k_gram_kc(const TZ* __restrict__ Z, int64
                                                  int64_t ldc, int64_t N, int64_t K, int64_t kchunk_o, int64_t kchunk_d,
                                                  int64_t slab_stride, int nti, int nsplit_o, int nsplit_d, int vec_ok,
                                                  const double* __restrict__ skip, const int32_t* __restrict__ order,
-                                                 int zbase_o, int zbase_d) {
+                                                 int zbase_o, int zbase_d, int noff_in) {
     __shared__ __attribute__((aligned(16))) double smem[4 * PANEL];  // A[2], B[2]
     if (skip && skip[0] != 0.0) return;
-    const int noff = nti * (nti - 1) / 2;
+    // (noff_in > 0: only the first noff_in tiles of the order table - gram_offdiag_launch: the off-diagonal block of a Gram
+    //  matrix whose diagonal 256-column blocks come from the fused sweep kernel)
+    const int noff = noff_in > 0 ? noff_in : nti * (nti - 1) / 2;
     const int64_t n_o = (int64_t)noff * nsplit_o;
     const int64_t nwork = n_o + (int64_t)nti * nsplit_d;
     const int64_t cpx = (nwork + 7) / 8;
@@ -790,11 +792,11 @@ int gram_launch_chunk(Handle* h, hipStream_t st, const GramPlan& pl, const void*
     if (pl.z_f32)
         hipLaunchKernelGGL((k_gram_kc<float>), dim3((unsigned)(8 * cpx)), dim3(512), 0, st, (const float*)Z, ld, pl.slab, N, N, rows,
                            pl.kchunk_o, pl.kchunk_d, N * N, (int)pl.nti, (int)pl.nsplit_o, (int)pl.nsplit_d, vec_ok, skip, pl.order,
-                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d));
+                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d), 0);
     else
         hipLaunchKernelGGL((k_gram_kc<double>), dim3((unsigned)(8 * cpx)), dim3(512), 0, st, (const double*)Z, ld, pl.slab, N, N, rows,
                            pl.kchunk_o, pl.kchunk_d, N * N, (int)pl.nti, (int)pl.nsplit_o, (int)pl.nsplit_d, vec_ok, skip, pl.order,
-                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d));
+                           (int)(c * pl.nsplit_o), (int)(c * pl.nsplit_d), 0);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }
@@ -807,6 +809,76 @@ int gram_reduce(Handle* h, hipStream_t st, const GramPlan& pl, double* G, int64_
     if (normblocks) *normblocks = (int)g;
     hipLaunchKernelGGL(k_slab_reduce, dim3((int)g), dim3(256), 0, st, (const double*)pl.slab, N, N * N,
                        (int)(pl.nsplit_o * pl.nchunks), (void*)G, 0, ldg, N, N, 1, skip, normpart, (int)(pl.nsplit_d * pl.nchunks), 1);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// ---- N = 512 with the fused sweep kernel (fused.hip): that kernel leaves the partial sums of the two diagonal 256-column
+// blocks; the off-diagonal block G[256:512, 0:256] - the 128 x 128 tiles (2,0), (2,1), (3,0), (3,1) - is accumulated here from
+// the Z_{k+1} it has written, by k_gram_kc's off-diagonal body on a four-entry tile list, into slabs of its own, and one
+// reduction adds both sets in a fixed order.
+int gram_offdiag_plan(Handle* h, int64_t N, int64_t K, GramPlan* pl) {
+    if (N != 512) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram_offdiag: N = 512 only");
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    const int64_t maxsplit = std::max<int64_t>(1, K / (4 * TK));
+    int64_t ns = std::min<int64_t>(std::max<int64_t>(1, ncu / 4), maxsplit);
+    int64_t kc = ((K + ns - 1) / ns + TK - 1) / TK * TK;
+    ns = (K + kc - 1) / kc;
+    void *slab, *tab;
+    TLSQ_TRY(ws_get(h, WS_SLAB2, (size_t)ns * (size_t)N * (size_t)N * sizeof(double), &slab));
+    TLSQ_TRY(ws_get(h, WS_GRAMTAB3, 64, &tab));
+    if (!h->gram_tab3_ready) {
+        static const int32_t o[8] = {2, 0, 2, 1, 3, 0, 3, 1};
+        TLSQ_HIP(h, hipMemcpyAsync(tab, o, sizeof(o), hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (pageable source; once per handle)
+        h->gram_tab3_ready = true;
+    }
+    *pl = GramPlan();
+    pl->N = N;
+    pl->K = K;
+    pl->nti = 4;
+    pl->nsplit_o = ns;
+    pl->nsplit_d = 0;
+    pl->kchunk_o = kc;
+    pl->kchunk_d = kc;
+    pl->nchunks = 1;
+    pl->slab = (double*)slab;
+    pl->order = (const int32_t*)tab;
+    return TLSQ_OK;
+}
+
+int gram_offdiag_launch(Handle* h, hipStream_t st, const GramPlan& pl, const double* Z, int64_t ld, int64_t rows) {
+    const int64_t N = pl.N, nwork = 4 * pl.nsplit_o, cpx = (nwork + 7) / 8;
+    const int vec_ok = ((ld % 2) == 0 && (pl.kchunk_o % 2) == 0 && (reinterpret_cast<uintptr_t>(Z) % 16) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((k_gram_kc<double>), dim3((unsigned)(8 * cpx)), dim3(512), 0, st, Z, ld, pl.slab, N, N, rows, pl.kchunk_o,
+                       pl.kchunk_d, N * N, 4, (int)pl.nsplit_o, 0, vec_ok, (const double*)nullptr, pl.order, 0, 0, 4);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// G (both triangles) from the two slab sets: entries inside a diagonal 256-column block from slabA (nA slabs), the others from
+// slabB (nB slabs); one writer per entry pair, fixed summation order
+__global__ __launch_bounds__(256) void k_slab_reduce2(const double* __restrict__ slabA, int nA, const double* __restrict__ slabB,
+                                                      int nB, double* __restrict__ G, int64_t ldg, int N) {
+    const int64_t total = (int64_t)N * N, stride = (int64_t)gridDim.x * 256, ss = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const int j = (int)(e % N), i = (int)(e / N);
+        if (j > i) continue;
+        const bool diag = (i >> 8) == (j >> 8);
+        const double* sl = diag ? slabA : slabB;
+        const int ns = diag ? nA : nB;
+        double s = 0.0;
+        for (int z = 0; z < ns; ++z) s += sl[(int64_t)z * ss + j + (int64_t)i * N];
+        G[j + (int64_t)i * ldg] = s;
+        G[i + (int64_t)j * ldg] = s;
+    }
+}
+
+int gram_reduce2(Handle* h, hipStream_t st, const GramPlan& plA, const GramPlan& plB, double* G, int64_t ldg) {
+    const int64_t N = plA.N;
+    hipLaunchKernelGGL(k_slab_reduce2, dim3(1024), dim3(256), 0, st, (const double*)plA.slab, (int)plA.nsplit_o, (const double*)plB.slab,
+                       (int)plB.nsplit_o, G, ldg, (int)N);
     TLSQ_HIP(h, hipGetLastError());
     return TLSQ_OK;
 }

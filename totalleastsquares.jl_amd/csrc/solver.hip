@@ -1150,7 +1150,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                                                     dual_norm));
                         void* Gv;
                         TLSQ_TRY(ws_get(h, Gslot[gcur], (size_t)N * N * 8, &Gv));
-                        TLSQ_TRY(gram_reduce(h, h->stream, pl1, (double*)Gv, N));
+                        TLSQ_TRY(fused_zgram_finish(h, pl1, Z, M, N, (double*)Gv));
                         TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                         g_ready = true;
                         first_fused = true;
@@ -1693,7 +1693,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     //  "not converged" - so that this one's will be too: a sweep that stores R_k is not enough of a sign, at
                     //  C3 two of four such iterations are still settled by the bounds and would pay for the Gram of Z_{k+1}
                     //  they did not accumulate)
-                    fused_gr = Rst != nullptr && prev_cost_evaluated && !dev_is(DEV_NO_FUSED_GR, '1');
+                    //  (N = 256 only: at N = 512 the off-diagonal block would need the stored R_k)
+                    fused_gr = Rst != nullptr && prev_cost_evaluated && N == 256 && !dev_is(DEV_NO_FUSED_GR, '1');
                     TLSQ_TRY(fused_zgram_plan(h, M, N, &fused_pl));
                     TLSQ_TRY(launch_fused_zgram(h, fused_pl, D, Tm_last, Vs_last, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1],
                                                 Rst, M, N, svp, mu, inv_mu, ro.nonnegA ? 1 : 0, 1.0 / mu_next, lam / mu_next,
@@ -1788,8 +1789,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             } else if (fused_gram) {
                 void* Gv;
                 TLSQ_TRY(ws_get(h, Gslot[gcur ^ 1], (size_t)N * N * 8, &Gv));
-                TLSQ_TRY(gram_reduce(h, h->stream, fused_pl, (double*)Gv, N));
+                TLSQ_TRY(fused_zgram_finish(h, fused_pl, (const double*)(const void*)Zbuf[zc ^ 1], M, N, (double*)Gv));   // (fused_gram: T is double)
                 TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
+                if (N != 256) hbm_other += panel_bytes;   // (the off-diagonal block reads the stored panel)
                 g_ready = true;
             } else if (gram_next) {   // (the TSQR route does not use the Gram matrix)
                 double* Gn = nullptr;
