@@ -489,6 +489,10 @@ bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* 
     if (!(thr_n >= 0.0) || !std::isfinite(thr_n)) return false;
     if (hankel && (hg.lag != 1 || hg.Dch != 1)) return false;
     if ((31 * M + 16) * 8 >= ((int64_t)1 << 32)) return false;
+    // a stage touches 16 rows of every column: with a leading dimension that is a multiple of a large power of two all those
+    // 128-byte pieces fall into the same few memory channels (measured: 65536 x 512 602 us against 510 us for the two kernels,
+    // while 50000 and 100000 rows gain 4 % and 13 %) - such panels keep the separate kernels
+    if (M % 2048 == 0 && !dev_is(DEV_FUSED_ZGRAM_N512, '2')) return false;
     const int64_t min_rows = [] { const char* e = dev_get(DEV_FUSED_ZGRAM_MINROWS); return e ? atol(e) : 0L; }();
     // one workgroup per CU whatever M is, each with its own 272 KB of partial sums: below ~400k rows the slabs (134 MB, a sixth
     // of a panel there) and their reduction cost what the fusion saves (measured: 131072 rows 395 us against 402 us for the
