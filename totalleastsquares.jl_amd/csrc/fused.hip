@@ -78,7 +78,7 @@ struct FusedArgs {
     int64_t kchunk;       // rows per chunk (a multiple of 16)
     int nz;
     int64_t hankel_K;
-    int ablate;           // development (FUSED_ABLATE): 1 no MFMAs, 2 no global stores, 4 no factor product, 8 no global loads
+    int ablate;           // development (FUSED_ABLATE): 1 no MFMAs, 2 no global stores
 };
 
 // one barrier of the workgroup that waits for this wave's LDS traffic only: __syncthreads() would also drain the global
