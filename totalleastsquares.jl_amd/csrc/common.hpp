@@ -107,7 +107,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP) X(FAIL_RANK)                                                \
     X(NO_ZSWEEP) X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(FUSED_REBUILD) X(NO_REBUILD_STORE)            \
     X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID) X(SWEEP_TIMING_STRIDE)                                                                                   \
-    X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START)                                         \
+    X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS)                                         \
     X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(MATFUN_COND) X(MATFUN_DEFL) X(NO_QUINTIC) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
     X(NO_CERT_OVERLAP) X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(CERT_EARLY) X(CERT_PRIO) X(NO_DEFLATED_SVD) X(NO_SMALL_MM) X(NO_FUSED_DEFLATE)                                                                                 \
     X(NO_RR_FAST) X(NO_RR_BLOCKED) X(NO_U_POLISH) X(NO_GX_REUSE) X(COLD_CGS2) X(COLD_Q) X(WARM_Q0) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(JACOBI_RPL) X(NO_CHOL) X(NO_SYMM_MFMA)             \

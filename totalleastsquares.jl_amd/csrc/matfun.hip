@@ -674,16 +674,21 @@ __global__ __launch_bounds__(256) void k_mf_scale_by_trace(const double* __restr
 
 // (G / trace G)^(2^levels) by repeated squaring through k_small_mm (P1, P2: N x N scratch; *out = the buffer the result is in).
 // Without rescaling between the squarings: the dominant eigenvalue of G / trace G is at least 1 / N, so five squarings of an
-// N <= 1024 matrix stay above 1e-97.  false in *ok: N is not one of the sizes k_small_mm_blk serves - the caller keeps its own form.
+// N <= 1024 matrix stay above 1e-97 (beyond five the power is scaled by its trace again).  false in *ok: N is not one of the sizes k_small_mm_blk serves - the caller keeps its own form.
 int matfun_power_start(Handle* h, const double* G, int64_t N, double* P1, double* P2, int levels, const double** out, bool* ok) {
     *ok = false;
-    if ((N % 128) != 0 || N > 1024 || levels < 1 || levels > 5 || dev_is(DEV_NO_SMALL_MM, '1')) return TLSQ_OK;
+    if ((N % 128) != 0 || N > 1024 || levels < 1 || levels > 10 || dev_is(DEV_NO_SMALL_MM, '1')) return TLSQ_OK;
     int64_t g = (N * N + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_mf_scale_by_trace, dim3((int)g), dim3(256), 0, h->stream, G, P1, (int)N);
     TLSQ_HIP(h, hipGetLastError());
     double *src = P1, *dst = P2;
     for (int k = 0; k < levels; ++k) {
+        if (k > 0 && k % 5 == 0) {   // (five squarings take the dominant eigenvalue down to N^-32 at worst: scale by the trace again)
+            hipLaunchKernelGGL(k_mf_scale_by_trace, dim3((int)g), dim3(256), 0, h->stream, (const double*)src, dst, (int)N);
+            TLSQ_HIP(h, hipGetLastError());
+            std::swap(src, dst);
+        }
         TLSQ_TRY(small_mm(h, src, src, dst, N, 1.0, 0.0, true));
         std::swap(src, dst);
     }

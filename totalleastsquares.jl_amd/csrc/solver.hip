@@ -40,7 +40,10 @@ int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, dou
         bool quick = false;
         // (N a multiple of 128: one scaling by the trace and five slab-free products, 8 us each at N = 512, instead of five
         //  split-K products + slab reductions + rescalings, 26 us each)
-        TLSQ_TRY(matfun_power_start(h, G, N, (double*)P1, (double*)P2, 5, &src, &quick));
+        // (round 5, measured: eight squarings - G^256, POWER_LEVELS=8 - change nothing at C2: the 15 Lanczos steps that remain
+        //  are the dimension of the dominant cluster of a rank-16 D, not the distance of the start vector from it)
+        const int plev = [] { const char* e = dev_get(DEV_POWER_LEVELS); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 10 ? v : 5; }();
+        TLSQ_TRY(matfun_power_start(h, G, N, (double*)P1, (double*)P2, plev, &src, &quick));
         if (!quick) {
             double* dst = (double*)P1;
             for (int k = 0; k < 5; ++k) {
