@@ -171,3 +171,26 @@ def test_lowrankfilter_with_and_without_the_fused_kernel(torch_mod):
     assert np.linalg.norm(yf - yf0) <= 1e-10 * np.linalg.norm(yf0)
     np.testing.assert_allclose(rep.cost_hist, rep0.cost_hist, rtol=1e-8)
     assert np.mean((y - qn(yf)) ** 2) / np.mean(noise ** 2) < 0.001
+
+
+def test_tall_rpca_512_columns_with_and_without_the_fused_kernel(torch_mod):
+    """rpca on a 70000 x 512 panel (BASELINE config 4's shape at a third of its height): the sweep covers the diagonal
+    256-column blocks of the Gram matrix, the off-diagonal block comes from the stored panel.  Same iterations, rank trajectory,
+    A and E (1e-10) as the run with separate kernels, the same bits from two runs, and the planted low-rank part recovered."""
+    import tlsq_amd
+    from tlsq_amd import workloads as W
+    M, N, r = 70_000, 512, 16
+    D, A0, _ = W.synth_lowrank_sparse(M, N, r, seed=3)
+    out = {}
+    for tag, sw in (("fused", {}), ("again", {}), ("split", {"NO_FUSED_ZGRAM": 1})):
+        with tlsq_amd.dev_switches(**sw):
+            e = tlsq_amd.Engine(0)
+            try:
+                out[tag] = e.rpca(D, return_report=True, want_s=False, cost_history=False)
+            finally:
+                e.close()
+    (A, E, _, sv, rep), (A2, E2, _, _, _), (As, Es, _, svs, reps) = out["fused"], out["again"], out["split"]
+    assert rep.converged and rep.iters_done == reps.iters_done and rep.svp_hist == reps.svp_hist and sv == svs == r
+    assert np.array_equal(A, A2) and np.array_equal(E, E2)
+    assert np.linalg.norm(A - As) <= 1e-10 * np.linalg.norm(As) and np.linalg.norm(E - Es) <= 1e-10 * np.linalg.norm(Es)
+    assert np.linalg.norm(A - A0) <= 1e-6 * np.linalg.norm(A0)
