@@ -1784,8 +1784,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 hbm_other += panel_bytes;
                 g_ready = true;
             } else if (fused_gram && fused_gr) {
-                void* Gv;   // (g_ready stays false: the cost evaluation below reads WS_G)
-                TLSQ_TRY(ws_get(h, WS_G, (size_t)N * N * 8, &Gv));
+                // (WS_G2, never WS_G: with the speculative loop the count certificate of this iteration may still be reading G_k
+                //  from WS_G on the second stream when this reduction runs; g_ready stays false)
+                void* Gv;
+                TLSQ_TRY(ws_get(h, WS_G2, (size_t)N * N * 8, &Gv));
                 TLSQ_TRY(gram_reduce(h, h->stream, fused_pl, (double*)Gv, N));
                 TLSQ_TRY(comm_allreduce(h, (double*)Gv, (size_t)N * N, ncclSum));
                 gr_ready = true;
@@ -1868,7 +1870,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             TLSQ_TRY(late_verdict(&redo));
             if (redo) goto redo_svd_step;
         }
-        const int cost_gslot = g_ready ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration
+        const int cost_gslot = (g_ready || gr_ready) ? WS_G2 : WS_G;   // WS_G may already belong to the next iteration; gr_ready: R'R is in WS_G2
         if (cost_skipped) {
             // nothing to evaluate
         } else if (cb_opnorm) {
