@@ -115,7 +115,8 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
-    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512)
+    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
+    X(OPGRAM_OLD) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(NO_COST_UPPER)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -292,6 +293,10 @@ int ztmm_mixed(Handle* h, const void* Z, int z_f32, int64_t ldz, const double* T
 // Y (N x p, fp64) = Z'(Z X) for an fp32 panel on the fp32 MFMA (fp64 fold-in), p <= 96: the large-mode operator product
 int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, double* Y,
                 int64_t ldy, int64_t p);
+// ... its second form (opgram32.hip: the block through LDS, the panel straight into the MFMA fragments) for aligned shapes
+bool op_gram_f32_fast_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t p);
+int op_gram_f32_fast(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const float* wt, float* t32, double* Y,
+                     int64_t ldy, int64_t p);
 // the Gram of a K-contiguous operand as plan / per-chunk launch / reduction (gemm.hip)
 struct GramPlan {
     int64_t N = 0, K = 0, nti = 0, nsplit_o = 1, nsplit_d = 1, kchunk_o = 0, kchunk_d = 0;

@@ -1313,6 +1313,8 @@ int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
     TLSQ_TRY(ws_get(h, WS_OPT, (size_t)M * 128 * 4 + 256, &t32));
     hipLaunchKernelGGL(k_pack_w_f32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, X, ldx,
                        (int)N, (int)p, lw, (float*)wt);
+    if (op_gram_f32_fast_ok(Z, ldz, M, N, p) && !dev_is(DEV_OPGRAM_OLD, '1'))
+        return op_gram_f32_fast(h, Z, ldz, M, N, (const float*)wt, (float*)t32, Y, ldy, p);
     {
         const dim3 grid((unsigned)((M + 31) / 32));
 #define TSF_LAUNCH(NC)                                                                                              \

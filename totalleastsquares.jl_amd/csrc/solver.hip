@@ -755,6 +755,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // warm-started subspace iteration (falls back to the full Jacobi solver whenever it cannot certify the
     // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
     SubspaceState sub;
+    int64_t hook_cols = 0;   // columns of the block buffer (WS_SX) holding the last decomposition's sorted Ritz vectors: the hook's warm start
     const int64_t pmax = subspace_max_block(N);
     const char* force_full = dev_get(DEV_FULL_EIG);
     // Large mode (N > 2048): the full Jacobi solvers do not apply (their column blocks live in LDS); every SVD step
@@ -1334,8 +1335,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             SubspaceState rs;
             rs.hook_rank = sv;
             rs.hook_seed = seed + (uint64_t)k;
+            rs.hook_carry = hook_cols;     // the previous iteration's sorted Ritz block, when it is still in the block buffer
+            hook_cols = 0;
             TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
+            if (fast_ok) hook_cols = rs.hook_carry;
         } else if (bulk_tail && !large) {
             sub.fail = SubspaceState::FAIL_NONE;   // straight to the dense tier below
         } else if (noise_limited) {
@@ -1455,6 +1459,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                            "rpca: min(M,N) = %lld > %lld and iteration %lld could not be served by the subspace solver "
                            "(block of %lld columns, reason %d): rank too large for this release",
                            (long long)N, (long long)kFullEigMaxN, (long long)k, (long long)sub.p, sub.fail);
+        if (!hook_now) hook_cols = (fast_ok && sub.valid) ? sub.p : 0;   // (the sorted block the certified solver leaves in WS_SX)
         if (fast_ok) {
             ++sub.fast;
         } else if (!hook_now && G && !no_gram_dense && (double)ro.m_global > 400.0 * (double)N) {

@@ -326,13 +326,103 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
     TLSQ_TRY(ws_get(h, WS_SH, (size_t)p * p * 8, &H));
     TLSQ_TRY(ws_get(h, WS_SS, (size_t)p * p * 8, &S));
     TLSQ_TRY(ws_get(h, WS_SHB, (size_t)p * p * 8, &HB));
-    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 8) * 8, &lam));
+    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)std::max<int64_t>(N, 3 * p + 32) * 8, &lam));
     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)p * 16 + 64, &aux));
     double* theta_dev = (double*)lam;
     double* res_dev = theta_dev + p;
     double* stat_dev = res_dev + p;
     double* lamH_dev = stat_dev + 8;
     std::vector<double> host((size_t)2 * p + 8);
+    if (hook && !dev_is(DEV_HOOK_CLASSIC, '1')) {
+        // The randomized hook as a block power method (round 5).  The reference's hook is `svd(Z, sv)` with a user function of
+        // the rsvd kind (src/robustPCA.jl:195-197; test/runtests.jl:388-398 uses rank sv, two power iterations): Q = orth((Z Z')^q Z Omega),
+        // then the SVD of Q'Z.  Here on the small side:  X <- orth(G X) `npow` times (default 2), then ONE Rayleigh-Ritz step
+        // H = Q'(G Q): npow + 1 products with the panel pair instead of the five of the two-step form below, one p x p eigenproblem
+        // instead of two, and CholeskyQR2 (a handful of multi-workgroup launches) for every orthonormalisation: a block is
+        // orthonormalised after EACH product, so its condition number is sigma_1^2 / sigma_p^2 of the panel, not the fourth
+        // power a random block has after two products (which needed the column-sequential CGS2: six 0.26 ms one-workgroup
+        // launches per orthonormalisation at 4096 x 74).  The start block is the previous iteration's sorted Ritz block when
+        // the caller says it is still in WS_SX (hook_carry) - Z_k changes little from one ALM iteration to the next, so the
+        // block enters already near-invariant - with the last few pad columns refreshed from the hash generator, so that a
+        // direction absent from the carried block can still enter; a cold call (iteration 2 after a full decomposition on
+        // another route, HOOK_COLD=1) starts from a random block like the reference's Omega.
+        // A Cholesky factorisation that breaks down (status[1]) repeats the call from a random block with CGS2.
+        const int npow = [] {
+            const char* e = dev_get(DEV_HOOK_POWER);
+            const int v = e ? atoi(e) : 2;
+            return v >= 1 && v <= 6 ? v : 2;
+        }();
+        const unsigned int seed32 = (unsigned int)(st.hook_seed * 2654435761ull + 77u);
+        int64_t carry = dev_is(DEV_HOOK_COLD, '1') ? 0 : std::min<int64_t>(st.hook_carry, p);
+        if (carry > 0) carry = std::max<int64_t>(0, std::min<int64_t>(carry, p - std::max<int64_t>(2, (p - st.hook_rank) / 2)));   // (pad refresh)
+        st.hook_carry = 0;
+        double* stat2 = lamH_dev + p;          // 3 status words per intermediate orthonormalisation (npow <= 6)
+        std::vector<double> host2((size_t)3 * 6);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool chol = attempt == 0 && !dev_is(DEV_HOOK_CGS2, '1');
+            if (attempt > 0) carry = 0;
+            if (carry < p) TLSQ_TRY(launch_fill_hash(h, (double*)X + (size_t)carry * N, N * (p - carry), seed32 + (unsigned int)attempt));
+            double* cur = (double*)Q;
+            double* other = (double*)XN;
+            const double* src = (const double*)X;
+            bool used_any = false;
+            for (int t = 0; t < npow; ++t) {
+                ++st.steps;
+                TLSQ_TRY(op_apply(h, op, N, src, cur, p));
+                bool used = false;
+                TLSQ_TRY(launch_orth(h, cur, (double*)GQ, (double*)H, N, p, t + 1 < npow ? stat2 + 3 * t : stat_dev, chol, &used, false));
+                used_any = used_any || used;
+                src = cur;
+                std::swap(cur, other);
+            }
+            const double* Qf = src;            // the orthonormal block
+            TLSQ_TRY(op_apply(h, op, N, Qf, (double*)GQ, p));
+            TLSQ_TRY(launch_panel_tn(h, Qf, (const double*)GQ, (double*)H, N, p));
+            int64_t sw = 0;
+            TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
+            if (sweeps) *sweeps += sw;
+            TLSQ_TRY(launch_ritz_finish(h, Qf, (const double*)GQ, (const double*)S, (double*)X, (double*)GX, theta_dev, res_dev, N, p));
+            TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost, h->stream));
+            if (npow > 1) TLSQ_HIP(h, hipMemcpyAsync(host2.data(), stat2, (size_t)3 * (npow - 1) * 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            bool failed = false;
+            if (used_any) {
+                failed = host[(size_t)(2 * p + 1)] != 0.0;
+                for (int t = 0; t + 1 < npow; ++t) failed = failed || host2[(size_t)(3 * t + 1)] != 0.0;
+            }
+            bool finite = true;
+            for (int64_t i = 0; i < 2 * p; ++i) finite = finite && std::isfinite(host[(size_t)i]);
+            if (dev_get(DEV_DEBUG) != nullptr)
+                fprintf(stderr, "  hook: p %lld carry %lld npow %d %s%s\n", (long long)p, (long long)carry, npow, chol ? "CholeskyQR2" : "CGS2",
+                        failed ? " - factorisation broke down, again from a random block with CGS2" : "");
+            if ((failed || !finite) && attempt == 0) continue;
+            if (!finite) {
+                st.fail = SubspaceState::FAIL_NUMERIC;
+                return TLSQ_OK;
+            }
+            break;
+        }
+        s.sigma.resize((size_t)p);
+        for (int64_t i = 0; i < p; ++i) s.sigma[(size_t)i] = std::sqrt(std::max(host[(size_t)i], 0.0));
+        s.ncols = p;
+        sort_desc(s);
+        bool sorted = true;
+        for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[(size_t)i] == (int32_t)i;
+        if (!sorted) {
+            std::vector<double> sg((size_t)p);
+            for (int64_t i = 0; i < p; ++i) sg[(size_t)i] = s.sigma[(size_t)s.order[(size_t)i]];
+            TLSQ_HIP(h, hipMemcpyAsync(XN, X, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
+            TLSQ_TRY(upload_async(h, aux, s.order.data(), (size_t)p * 4));
+            TLSQ_TRY(launch_gather_scale(h, (const double*)XN, N, (const int32_t*)aux, nullptr, p, nullptr, (double*)X));
+            s.sigma = sg;
+            std::iota(s.order.begin(), s.order.end(), 0);
+        }
+        s.ncols = std::min<int64_t>(st.hook_rank, p);   // rank-sv truncation, like `svd(Z, sv)`
+        st.hook_carry = p;
+        *V_out = (double*)X;
+        *ok = true;
+        return TLSQ_OK;
+    }
     const int max_steps = hook ? 2 : (cold ? 30 : 10) + st.extra_steps;
     const int64_t ntop = cold ? p : std::min<int64_t>(st.ntop, p);
     int64_t svp = 0;

@@ -31,6 +31,9 @@ struct SubspaceState {
     // fresh random block, fixed number of passes, no convergence test and no count certificate
     int64_t hook_rank = 0;
     uint64_t hook_seed = 0;
+    // (in) leading columns of the block buffer (WS_SX) that still hold the sorted Ritz vectors of the previous iteration's
+    // decomposition: the hook starts from them instead of a fresh random block; (out) the columns this call left there
+    int64_t hook_carry = 0;
     int64_t fast = 0, full = 0, steps = 0;
     // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
     enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4, FAIL_WINDOW = 5 };
