@@ -397,6 +397,16 @@ int tlsq_k_zsweep_gram_f64(tlsq_handle h, const double* D, const double* Tm, con
                            double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r,
                            double mu, double inv_mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE,
                            double* sumsq, const double* hankel_y, int64_t hankel_K, double* G, int64_t ldG);
+/* The E-free sweep for ranks 33..80 on an fp32 panel (sweeps.hip, k_zsweep_wide; rpca on BASELINE config 5): the statements of
+ * k_zsweep (src/robustPCA.jl:217-222, then :188-192 of the next iteration) with A_k = T Vs' formed tile by tile on the fp32 MFMA
+ * inside the sweep instead of read from a stored panel.  Z (M x N fp32, ld M) is the panel Z_k that T = Z Vg is taken from
+ * (the fp32-MFMA product of opgram32.hip) AND the sweep's Z_k; Vg, Vs: N x r fp64 (ld N) - V_sel diag(g) and V_sel.
+ * Writes Yout = Y_{k+1}, Zout = Z_{k+1} (Zout == Z: in place), R_k when R is not NULL, and Tm (M x r fp64, optional): the
+ * factor T widened.  Serves M % 128 == 0, N % 128 == 0, M * N >= 2^26; TLSQ_ERR_UNSUPPORTED otherwise (rpca then stores A_k and
+ * runs k_zsweep on it).  sumsq: as k_zsweep_gram (72 doubles, zeroed by the caller). */
+int tlsq_k_zsweep_wide_f32(tlsq_handle h, const float* D, const double* Vg, const double* Vs, int64_t r, const float* Yin,
+                           float* Yout, float* Z, float* Zout, float* R, double* Tm, int64_t M, int64_t N, float mu,
+                           float inv_mu, int nonnegA, float inv_mu_next, float thr_next, int nonnegE, double* sumsq);
 /* E = soft_th(D - A_prev + inv_mu * Y, thr) (:188-191), A_prev = Tm * Vs' (Aprev NULL, r <= 32; r = 0: zero) or read from
  * Aprev: the E a call returns, formed once after the E-free loop.  E may be the buffer Y lives in. */
 int tlsq_k_final_e_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Aprev,

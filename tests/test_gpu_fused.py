@@ -194,3 +194,102 @@ def test_tall_rpca_512_columns_with_and_without_the_fused_kernel(torch_mod):
     assert np.array_equal(A, A2) and np.array_equal(E, E2)
     assert np.linalg.norm(A - As) <= 1e-10 * np.linalg.norm(As) and np.linalg.norm(E - Es) <= 1e-10 * np.linalg.norm(Es)
     assert np.linalg.norm(A - A0) <= 1e-6 * np.linalg.norm(A0)
+
+
+@pytest.mark.parametrize("M,N,r,nonneg,with_r,inplace", [
+    (32768, 2304, 40, 0, True, True),        # r <= 64: 32 k-steps of the 32 x 32 x 2 MFMA, zero columns behind the rank
+    (32768, 2304, 64, 1, False, False),      # nonnegA / nonnegE, Z double-buffered
+    (16384, 4096, 77, 0, False, True),       # 64 < r <= 80: 40 k-steps
+])
+def test_wide_sweep_kernel_fp32(eng, torch_mod, M, N, r, nonneg, with_r, inplace):
+    """The E-free sweep for ranks above 32 on an fp32 panel (`tlsq_k_zsweep_wide_f32`: T = Z Vg on the fp32 MFMA, A_k = T Vs'
+    formed inside the sweep) against the reference's statements (src/robustPCA.jl:205-213, :217-222, :188-192) evaluated in
+    float64 on the same fp32 inputs: a few fp32 roundings of the panel's scale (A_k itself is an fp32 quantity in the
+    reference), the residual norm to 1e-5, max |R| to 1e-3, the widened factor T to the fp32 rounding of Z Vg."""
+    import tlsq_amd
+    torch = torch_mod
+    g = torch.Generator(device="cuda").manual_seed(M + N + r)
+    f32 = dict(device="cuda", dtype=torch.float32, generator=g)
+    L = torch.randn(N, 24, **f32) @ torch.randn(24, M, **f32) / 5.0          # (N x M row-major = M x N column-major)
+    D = L + 3.0 * torch.randn(N, M, **f32) * (torch.rand(N, M, **f32) < 0.05)
+    Y = torch.randn(N, M, **f32) * 0.3
+    Ek = 3.0 * torch.randn(N, M, **f32) * (torch.rand(N, M, **f32) < 0.05)
+    mu, mu_n, lam = 0.27, 0.405, 0.1
+    inv_mu = float(np.float32(1.0) / np.float32(mu))
+    inv_mu_n, thr_n = float(np.float32(1.0 / mu_n)), float(np.float32(lam / mu_n))
+    Zk = ((D - Ek) + np.float32(inv_mu) * Y).contiguous()                      # :192 of the previous iteration
+    V = torch.linalg.qr(torch.randn(N, r, device="cuda", dtype=torch.float64, generator=g))[0]   # N x r, orthonormal columns
+    gsc = torch.rand(r, device="cuda", dtype=torch.float64, generator=g) * 0.9
+    Vs_cm = V.T.contiguous()                                                    # column-major N x r
+    Vg_cm = (V * gsc).T.contiguous()
+    # float64 statements
+    Z64, D64, Y64 = Zk.double(), D.double(), Y.double()
+    A = ((Z64.T @ (V * gsc)) @ V.T).T                                           # A = (Z Vg) Vs'   (N x M view)
+    if nonneg:
+        A = A.clamp_min(0)
+    w = Z64 - A
+    res = w - inv_mu * Y64
+    y1 = mu_f = float(np.float32(mu)) * w
+    tt = inv_mu_n * y1
+    x = (D64 - A) + tt
+    ee = torch.clamp(x - thr_n, min=0) + torch.clamp(x + thr_n, max=0)
+    if nonneg:
+        ee = ee.clamp_min(0)
+    zn = (D64 - ee) + tt
+    Yo = torch.empty_like(Y)
+    Zin = Zk.clone()
+    Zo = Zin if inplace else torch.empty_like(Zk)
+    R = torch.full_like(Y, 7.0)
+    Tm = torch.empty((r, M), dtype=torch.float64, device="cuda")
+    ss = torch.zeros(72, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    st = eng.lib.tlsq_k_zsweep_wide_f32(eng.h, dptr(D), dptr(Vg_cm), dptr(Vs_cm), r, dptr(Y), dptr(Yo), dptr(Zin), dptr(Zo),
+                                        dptr(R) if with_r else None, dptr(Tm), M, N, mu, inv_mu, nonneg, inv_mu_n, thr_n, nonneg,
+                                        dptr(ss))
+    assert st == 0, eng.lib.tlsq_last_error(eng.h)
+    eng.synchronize()
+    scale = float(Z64.abs().max())
+    eps = float(np.finfo(np.float32).eps)
+    assert float((Yo.double() - y1).abs().max()) <= 32 * eps * scale
+    assert float((Zo.double() - zn).abs().max()) <= 64 * eps * scale
+    if with_r:
+        assert float((R.double() - res).abs().max()) <= 32 * eps * scale
+    else:
+        assert bool((R == 7.0).all())
+    T64 = (Z64.T @ (V * gsc)).T                                                 # r x M
+    assert float((Tm - T64).abs().max()) <= 32 * eps * float(T64.abs().max())
+    fro = float((res * res).sum())
+    assert abs(float(ss[:64].sum()) - fro) <= 1e-5 * fro
+    mx = ss[64:65].view(torch.int64).view(torch.float64).item()
+    assert abs(mx - float(res.abs().max())) <= 1e-3 * float(res.abs().max())
+    # shapes the kernel does not take
+    assert eng.lib.tlsq_k_zsweep_wide_f32(eng.h, dptr(D), dptr(Vg_cm), dptr(Vs_cm), 20, dptr(Y), dptr(Yo), dptr(Zin), dptr(Zo), None,
+                                          None, M, N, mu, inv_mu, 0, inv_mu_n, thr_n, 0, None) != 0
+
+
+def test_large_fp32_rpca_with_and_without_the_wide_sweep(torch_mod):
+    """rpca on a 32768 x 2304 fp32 panel of rank 40 (large mode: min(M, N) > 2048): the loop that forms A_k inside the sweep
+    against the loop that stores it (NO_WIDE_SWEEP): same iterations and rank trajectory, A and E to 1e-4 (fp32 factors
+    against fp64 ones), the planted low-rank part recovered to the fp32 bar, in the exact and the randomized mode."""
+    import tlsq_amd
+    from tlsq_amd import workloads as W
+    M, N, r = 32768, 2304, 40
+    D, A0, _ = W.synth_lowrank_sparse(M, N, r, seed=5)
+    D = D.astype(np.float32)
+    for kw in ({}, {"svd": "randomized"}):
+        out = {}
+        for tag, sw in (("wide", {}), ("stored", {"NO_WIDE_SWEEP": 1})):
+            with tlsq_amd.dev_switches(**sw):
+                e = tlsq_amd.Engine(0)
+                try:
+                    out[tag] = e.rpca(D, return_report=True, want_s=False, cost_history=False, **kw)
+                finally:
+                    e.close()
+        (A, E, _, sv, rep), (As, Es, _, svs, reps) = out["wide"], out["stored"]
+        assert rep.converged and reps.converged and sv == svs == r
+        assert abs(rep.iters_done - reps.iters_done) <= (0 if not kw else 1)
+        if not kw:
+            assert rep.svp_hist == reps.svp_hist
+        assert np.linalg.norm(A.astype(np.float64) - As) <= 1e-4 * np.linalg.norm(As)
+        assert np.linalg.norm(E.astype(np.float64) - Es) <= 1e-3 * np.linalg.norm(Es)
+        assert np.linalg.norm(A.astype(np.float64) - A0) <= 1e-3 * np.linalg.norm(A0)

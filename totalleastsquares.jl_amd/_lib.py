@@ -77,7 +77,7 @@ EXPORTS = [
     "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
-    "tlsq_k_zsweep_f64", "tlsq_k_zsweep_gram_f64", "tlsq_k_final_e_f64", "tlsq_k_matfun_sign_f64", "tlsq_k_matfun_invsqrt_f64", "tlsq_k_rr_small_f64",
+    "tlsq_k_zsweep_f64", "tlsq_k_zsweep_gram_f64", "tlsq_k_zsweep_wide_f32", "tlsq_k_final_e_f64", "tlsq_k_matfun_sign_f64", "tlsq_k_matfun_invsqrt_f64", "tlsq_k_rr_small_f64",
     "tlsq_k_gram_f64", "tlsq_k_gram_f32", "tlsq_k_op_gram_f32", "tlsq_k_gemm_nn_f64", "tlsq_k_gemm_nt_f64", "tlsq_k_symeig_f64", "tlsq_k_symeig_chol_f64",
     "tlsq_k_opnorm_f64", "tlsq_k_maxabs_f64", "tlsq_k_tsqr_f64", "tlsq_k_svd_r_f64",
 ]
@@ -127,6 +127,7 @@ def load():
     lib.tlsq_k_zsweep_f64.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, dbl, dbl, i32, dbl, dbl, i32, vp]
     lib.tlsq_k_zsweep_gram_f64.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, dbl, dbl, i32, dbl, dbl, i32, vp,
                                            vp, i64, vp, i64]
+    lib.tlsq_k_zsweep_wide_f32.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, flt, flt, i32, flt, flt, i32, vp]
     lib.tlsq_k_final_e_f64.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, dbl, dbl, i32, i32]
     lib.tlsq_k_matfun_sign_f64.argtypes = [vp, vp, i64, vp, vp]
     lib.tlsq_k_matfun_invsqrt_f64.argtypes = [vp, vp, i64, dbl, vp, vp]

@@ -825,6 +825,21 @@ int tlsq_k_zsweep_f64(tlsq_handle h, const double* D, const double* Tm, const do
     return launch_zsweep<double>(h, D, Tm, Vs, A, Yin, Yout, Z, R, M, N, r, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
                                  nonnegE, sumsq, nullptr);
 }
+int tlsq_k_zsweep_wide_f32(tlsq_handle h, const float* D, const double* Vg, const double* Vs, int64_t r, const float* Yin,
+                           float* Yout, float* Z, float* Zout, float* R, double* Tm, int64_t M, int64_t N, float mu,
+                           float inv_mu, int nonnegA, float inv_mu_next, float thr_next, int nonnegE, double* sumsq) {
+    TLSQ_TRY(check_handle(h));
+    if (!D || !Vg || !Vs || !Yin || !Yout || !Z || !Zout || M <= 0 || N <= 0 || Yin == Yout)
+        return set_err(h, TLSQ_ERR_ARG, "k_zsweep_wide: bad argument");
+    if (!zsweep_wide_ok(M, N, r) || !wide_factors_ok(Z, M, M, N, r))
+        return set_err(h, TLSQ_ERR_UNSUPPORTED, "k_zsweep_wide: fp32 panels with M %% 128 == 0, N %% 128 == 0, M N >= 2^26, ranks 33..80");
+    TLSQ_HIP(h, hipSetDevice(h->device));
+    const float *t32 = nullptr, *vs32 = nullptr;
+    int lw = 0;
+    TLSQ_TRY(wide_factors_f32(h, Z, M, M, N, Vg, Vs, r, Tm, &t32, &vs32, &lw));
+    return launch_zsweep_wide(h, D, t32, M, vs32, r, Yin, Yout, Z, Zout, R, M, N, mu, inv_mu, nonnegA, inv_mu_next, thr_next,
+                              nonnegE, sumsq, nullptr, sumsq ? 0 : -1);
+}
 int tlsq_k_zsweep_gram_f64(tlsq_handle h, const double* D, const double* Tm, const double* Vs, const double* Yin,
                            double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r,
                            double mu, double inv_mu, int nonnegA, double inv_mu_next, double thr_next, int nonnegE,

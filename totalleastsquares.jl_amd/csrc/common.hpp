@@ -116,7 +116,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(NO_COST_UPPER)
+    X(OPGRAM_OLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(NO_COST_UPPER)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -144,7 +144,7 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW,
+    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW, WS_T32, WS_VS32,
     WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
@@ -295,6 +295,14 @@ int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
                 int64_t ldy, int64_t p);
 // ... its second form (opgram32.hip: the block through LDS, the panel straight into the MFMA fragments) for aligned shapes
 bool op_gram_f32_fast_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t p);
+// the factors of A_k in fp32 for the wide sweep (ranks 33..80, fp32 panels; opgram32.hip) and that sweep (sweeps.hip)
+bool wide_factors_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t r);
+int wide_factors_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* Vg, const double* Vs,
+                     int64_t r, double* Tm, const float** T32_out, const float** Vs32_out, int* lw_out);
+bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r);
+int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt, const float* Vs32, int64_t r, const float* Yin,
+                       float* Yout, float* Z, float* Zout, float* R, int64_t M, int64_t N, float mu, float inv_mu, int nonnegA,
+                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot);
 int op_gram_f32_fast(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const float* wt, float* t32, double* Y,
                      int64_t ldy, int64_t p);
 // the Gram of a K-contiguous operand as plan / per-chunk launch / reduction (gemm.hip)
@@ -358,7 +366,8 @@ int matfun_lin2(Handle* h, const double* X1, double a1, const double* X2, double
 // async_small: when the matrix fits the single-workgroup path, do not read the sweep count back (no host sync).
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
                bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false,
-               bool warm_v = false, bool two_sided = false);   // two_sided (N <= 64): rotate G itself (absolute accuracy)
+               bool warm_v = false, bool two_sided = false,    // two_sided (N <= 64): rotate G itself (absolute accuracy)
+               double rot_tol = 0.0);   // > 0 (N <= 96): rotation threshold |cos| of a column pair instead of 2 eps sqrt(N)
 // warm_v: V holds the previous decomposition's eigenvectors (orthogonal): start from B = G*V.
 // Vg[:,p] = g[p] * V[:,sel[p]], Vs[:,p] = V[:,sel[p]]  for p < r  (all N x r, ld N)
 // selection + weights small enough to travel as kernel arguments (r <= 32)

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_small(const double* __restrict_
         }
         // converged: a sweep without rotations - or one whose largest rotation was so small (|cos| < 1e-8) that,
         // Jacobi converging quadratically, what is left is below the rotation threshold anyway
-        if (r == 0 || swmax < 1e-16) {
+        if (r == 0 || swmax < (tol > 1e-12 ? tol : 1e-16)) {   // (a caller's loose threshold t: the sweep after cos^2 < t leaves cos ~ t)
             ++sweep;
             break;
         }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_jacobi2_small(const double* __restrict
         }
         // converged: a sweep without rotations - or one whose largest rotation was so small (h_pq^2 < 1e-16 h_pp h_qq)
         // that, Jacobi converging quadratically, what is left is below the rotation threshold anyway
-        if (r == 0 || swmax < 1e-16) {
+        if (r == 0 || swmax < (tol > 1e-12 ? tol : 1e-16)) {   // (a caller's loose threshold t: the sweep after cos^2 < t leaves cos ~ t)
             ++sweep;
             break;
         }
@@ -513,8 +513,17 @@ __global__ __launch_bounds__(1024) void k_jacobi2_small(const double* __restrict
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
 }
 
-// The same for 64 < N <= 96 (Rayleigh-Ritz problems of blocks of 65..96 columns): three rows per lane, up to 48
-// column pairs per round shared out over the 32 half-waves, B and V in dynamic LDS (2 N (N+1) doubles <= 149 KB).
+// The same for 64 < N <= 96 (Rayleigh-Ritz problems of blocks of 65..96 columns): B and V in dynamic LDS (2 N (N+1) doubles
+// <= 149 KB), one ROW OF 16 LANES per column pair - six rows per lane, the pair's dot product from four DPP steps inside the
+// row - so that the up to 48 pairs of a round run at once on the 64 rows of the workgroup (with half-waves, 32 of them, a
+// round took two passes: 1.9 us per round, 0.14 ms per sweep at N = 74 - the randomized hook's 1.1 ms eigenproblem).
+__device__ __forceinline__ double row_allsum(double v) {   // sum over the 16 lanes of this DPP row
+    v += dpp_perm<0xB1>(v);
+    v += dpp_perm<0x4E>(v);
+    v += dpp_perm<0x141>(v);
+    v += dpp_perm<0x140>(v);
+    return v;
+}
 template <bool WANT_V>
 __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ G, int64_t ldG,
                                                        double* __restrict__ Bout, double* __restrict__ Vout,
@@ -524,13 +533,14 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
     __shared__ double red[16];
     __shared__ unsigned int s_rot;
     __shared__ unsigned long long s_max;
+    constexpr int RL = 6;                     // rows per lane: 16 RL >= 96
     const int LD = N + 1;
     double* sB = jm_sm;
     double* sV = jm_sm + (size_t)N * LD;
     double* sN = jm_sm + (size_t)(WANT_V ? 2 : 1) * N * LD;
     const int tid = threadIdx.x;
-    const int hw = tid >> 5, hl = tid & 31;   // half-wave index, lane within it
-    const int nthr = blockDim.x, nhw = nthr >> 5;   // the launcher sizes the block to the number of pairs
+    const int hw = tid >> 4, hl = tid & 15;   // lane row (one column pair of the round), lane within it
+    const int nthr = blockDim.x, nhw = nthr >> 4;
     // init + ||G||_F^2
     double fro = 0.0;
     for (int e = tid; e < N * N; e += nthr) {
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
     for (int k = 0; k < (nthr >> 6); ++k) fsum += red[k];
     const double floor2 = nfloor * nfloor * fsum;
     const int nslot = (N + 1) & ~1;          // even number of tournament players
-    const int npair = nslot / 2;             // <= 32
+    const int npair = nslot / 2;             // <= 48
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         unsigned int my_rot = 0;
@@ -559,14 +569,19 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
         // squared column norms, refreshed once per sweep and updated by the rotation formulas in between
         for (int c = hw; c < N; c += nhw) {
             const double* x = sB + c * LD;
-            const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0,
-                         v2 = hl + 64 < N ? x[hl + 64] : 0.0;
-            const double ssum = half_allsum(v0 * v0 + v1 * v1 + v2 * v2);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int r = hl + 16 * k;
+                const double v = r < N ? x[r] : 0.0;
+                acc += v * v;
+            }
+            const double ssum = row_allsum(acc);
             if (hl == 0) sN[c] = ssum;
         }
         __syncthreads();
         for (int ir = 0; ir < nslot - 1; ++ir) {
-            for (int ip = hw; ip < npair; ip += nhw) {   // up to 48 pairs per round on 32 half-waves
+            for (int ip = hw; ip < npair; ip += nhw) {   // (one pass: 64 lane rows, at most 48 pairs)
                 int s1, s2;
                 rr_pair(nslot, ir, ip, s1, s2);
                 if (s1 > s2) {
@@ -577,12 +592,17 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
                 if (s2 < N) {
                     double* x = sB + s1 * LD;
                     double* y = sB + s2 * LD;
-                    const int r0 = hl, r1 = hl + 32, r2 = hl + 64;
-                    const double x0 = r0 < N ? x[r0] : 0.0, y0 = r0 < N ? y[r0] : 0.0;
-                    const double x1 = r1 < N ? x[r1] : 0.0, y1 = r1 < N ? y[r1] : 0.0;
-                    const double x2 = r2 < N ? x[r2] : 0.0, y2 = r2 < N ? y[r2] : 0.0;
+                    double xv[RL], yv[RL];
+                    double dot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int r = hl + 16 * k;
+                        xv[k] = r < N ? x[r] : 0.0;
+                        yv[k] = r < N ? y[r] : 0.0;
+                        dot += xv[k] * yv[k];
+                    }
                     const double a = sN[s1], bb = sN[s2];
-                    const double c = half_allsum(x0 * y0 + x1 * y1 + x2 * y2);
+                    const double c = row_allsum(dot);
                     const double mn = a < bb ? a : bb;
                     if (c * c > tol * tol * a * bb && mn > floor2) {
                         const double ratio2 = c * c / (a * bb);   // cos^2 of the angle between the two columns
@@ -597,35 +617,25 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
                             sN[s1] = na > 0.0 ? na : 0.0;
                             sN[s2] = nb2 > 0.0 ? nb2 : 0.0;
                         }
-                        if (r0 < N) {
-                            x[r0] = cs * x0 - sn * y0;
-                            y[r0] = sn * x0 + cs * y0;
-                        }
-                        if (r1 < N) {
-                            x[r1] = cs * x1 - sn * y1;
-                            y[r1] = sn * x1 + cs * y1;
-                        }
-                        if (r2 < N) {
-                            x[r2] = cs * x2 - sn * y2;
-                            y[r2] = sn * x2 + cs * y2;
+#pragma unroll
+                        for (int k = 0; k < RL; ++k) {
+                            const int r = hl + 16 * k;
+                            if (r < N) {
+                                x[r] = cs * xv[k] - sn * yv[k];
+                                y[r] = sn * xv[k] + cs * yv[k];
+                            }
                         }
                         if (WANT_V) {
                             double* vx = sV + s1 * LD;
                             double* vy = sV + s2 * LD;
-                            if (r0 < N) {
-                                const double u = vx[r0], w = vy[r0];
-                                vx[r0] = cs * u - sn * w;
-                                vy[r0] = sn * u + cs * w;
-                            }
-                            if (r1 < N) {
-                                const double u = vx[r1], w = vy[r1];
-                                vx[r1] = cs * u - sn * w;
-                                vy[r1] = sn * u + cs * w;
-                            }
-                            if (r2 < N) {
-                                const double u = vx[r2], w = vy[r2];
-                                vx[r2] = cs * u - sn * w;
-                                vy[r2] = sn * u + cs * w;
+#pragma unroll
+                            for (int k = 0; k < RL; ++k) {
+                                const int r = hl + 16 * k;
+                                if (r < N) {
+                                    const double u = vx[r], w = vy[r];
+                                    vx[r] = cs * u - sn * w;
+                                    vy[r] = sn * u + cs * w;
+                                }
                             }
                         }
                         ++my_rot;
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
         }
         // converged: a sweep without rotations - or one whose largest rotation was so small (|cos| < 1e-8) that,
         // Jacobi converging quadratically, what is left is below the rotation threshold anyway
-        if (r == 0 || swmax < 1e-16) {
+        if (r == 0 || swmax < (tol > 1e-12 ? tol : 1e-16)) {   // (a caller's loose threshold t: the sweep after cos^2 < t leaves cos ~ t)
             ++sweep;
             break;
         }
@@ -659,12 +669,17 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
         Bout[e] = sB[c * LD + r];
         if (WANT_V) Vout[e] = sV[c * LD + r];
     }
-    // lam[c] = ||B[:,c]||: half-wave per column
+    // lam[c] = ||B[:,c]||: lane row per column
     for (int c = hw; c < N; c += nhw) {
         const double* x = sB + c * LD;
-        const double v0 = hl < N ? x[hl] : 0.0, v1 = hl + 32 < N ? x[hl + 32] : 0.0,
-                     v2 = hl + 64 < N ? x[hl + 64] : 0.0;
-        const double ssum = half_allsum(v0 * v0 + v1 * v1 + v2 * v2);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int r = hl + 16 * k;
+            const double v = r < N ? x[r] : 0.0;
+            acc += v * v;
+        }
+        const double ssum = row_allsum(acc);
         if (hl == 0) lam[c] = sqrt(ssum);
     }
     if (tid == 0 && sweeps_done) *sweeps_done = sweep;
@@ -1011,7 +1026,7 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
 }
 
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,
-               double* lam_dev, int64_t* sweeps_out, bool async_small, bool warm_v, bool two_sided) {
+               double* lam_dev, int64_t* sweeps_out, bool async_small, bool warm_v, bool two_sided, double rot_tol) {
     if (sweeps_out) *sweeps_out = 0;
     if (N <= 0) return TLSQ_OK;
     void* scal;
@@ -1025,6 +1040,7 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         const double eps0 = 2.220446049250313e-16;
         double tol0 = 2.0 * eps0 * sqrt((double)N);
         if (tol0 < 4.0 * eps0) tol0 = 4.0 * eps0;
+        if (rot_tol > tol0) tol0 = rot_tol;
         const int max_sweeps0 = 40;
         // one half-wave per column pair; whole waves only
         const int npair0 = (int)((N + 1) / 2);
@@ -1054,7 +1070,7 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     if (N > 64 && N <= 96 && !(warm_v && want_v)) {
         // one launch as well: init, noise floor, sweeps, column norms (k_jacobi_mid)
         const double eps0 = 2.220446049250313e-16;
-        const double tol0 = 2.0 * eps0 * sqrt((double)N);
+        const double tol0 = std::max(2.0 * eps0 * sqrt((double)N), rot_tol);
         const int max_sweeps0 = 40;
         const size_t lds = ((size_t)(want_v ? 2 : 1) * N * (N + 1) + N) * 8;
         if (want_v) {

@@ -65,7 +65,21 @@ __device__ __forceinline__ double lz_rows(const double* __restrict__ G, int64_t 
     for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
         const double* __restrict__ col = G + (int64_t)r * ldG;
         double a0 = 0.0, a1 = 0.0;
-        for (int c = 2 * lane; c < n2; c += 128) {
+        int c = 2 * lane;
+        // eight 16-byte loads of the row in flight per lane (one at a time left a 4096-column row latency-bound: 32 dependent
+        // round trips to HBM per row, 57-70 us per step at N = 4096 = 134 MB at 2 TB/s)
+        for (; c + 7 * 128 < n2; c += 8 * 128) {
+            lz_d2 g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = *reinterpret_cast<const lz_d2*>(col + c + 128 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const lz_d2 x = *reinterpret_cast<const lz_d2*>(q + c + 128 * u);
+                a0 += g[u][0] * x[0];
+                a1 += g[u][1] * x[1];
+            }
+        }
+        for (; c < n2; c += 128) {
             const lz_d2 g = *reinterpret_cast<const lz_d2*>(col + c);
             const lz_d2 x = *reinterpret_cast<const lz_d2*>(q + c);
             a0 += g[0] * x[0];
@@ -157,7 +171,13 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
         const double* u = ubuf + (size_t)((j + 1) % 2) * N;   // u of launch j-1
         const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS_MAX;
         double alpha = 0.0;
-        for (int k = 0; k < nwg; ++k) alpha += pp[k];
+        if (nwg <= 64) {
+            for (int k = 0; k < nwg; ++k) alpha += pp[k];
+        } else {   // (N > 1024: hundreds of partial sums - every thread adding all of them was half of a 4096-column step)
+            double a = 0.0;
+            for (int k = tid; k < nwg; k += LZ_THREADS) a += pp[k];
+            alpha = block_sum4(a, red);
+        }
         const double beta_prev = (j >= 2) ? ab[maxsteps + (j - 2)] : 0.0;
         double nn = 0.0;
         for (int i = tid; i < N; i += LZ_THREADS) {
@@ -457,7 +477,13 @@ __global__ __launch_bounds__(LZ_THREADS) void k_power_step(const double* __restr
         const double* u = ubuf + (size_t)((j + 1) % 2) * N;
         const double* pp = part + (size_t)((j + 1) % 2) * LZ_WGS_MAX;
         double nn = 0.0;
-        for (int k = 0; k < nwg; ++k) nn += pp[k];
+        if (nwg <= 64) {
+            for (int k = 0; k < nwg; ++k) nn += pp[k];
+        } else {
+            double a = 0.0;
+            for (int k = threadIdx.x; k < nwg; k += LZ_THREADS) a += pp[k];
+            nn = block_sum4(a, red);
+        }
         const double beta = sqrt(nn);                 // ||G v_{j-1}||, v_{j-1} a unit vector
         const double inv = beta > 1e-290 ? 1.0 / beta : 0.0;
         for (int i = tid; i < N; i += LZ_THREADS) q[i] = u[i] * inv;

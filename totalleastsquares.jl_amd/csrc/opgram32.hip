@@ -284,6 +284,34 @@ __global__ __launch_bounds__(256) void k_zty_reduce(const double* __restrict__ s
         Y[i + (int64_t)j * ldy] = sacc;
     }
 }
+// Wt[k lw + j] = (float) W[k + j ldw]  (j < r, else 0): the packed second operand of k_zx_f32
+__global__ __launch_bounds__(256) void k_pack_wt32(const double* __restrict__ W, int64_t ldw, int K, int r, int lw,
+                                                   float* __restrict__ Wt) {
+    const int total = K * lw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e % lw, k = e / lw;
+        Wt[e] = j < r ? (float)W[(size_t)k + (size_t)j * ldw] : 0.f;
+    }
+}
+// out (n x lw fp32, ld n) = (float) V (n x r fp64, ld ldv), columns r.. zero
+__global__ __launch_bounds__(256) void k_cols_to_f32(const double* __restrict__ V, int64_t ldv, int64_t n, int r, int lw,
+                                                     float* __restrict__ out) {
+    const int64_t total = n * lw;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e % n;
+        const int j = (int)(e / n);
+        out[e] = j < r ? (float)V[i + (int64_t)j * ldv] : 0.f;
+    }
+}
+// Tm (M x r fp64, ld M) = (double) T32 (M x lw fp32, ld ldt)
+__global__ __launch_bounds__(256) void k_cols_to_f64(const float* __restrict__ T32, int64_t ldt, int64_t M, int r,
+                                                     double* __restrict__ Tm) {
+    const int64_t total = M * r;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e % M, j = e / M;
+        Tm[e] = (double)T32[i + j * ldt];
+    }
+}
 }   // namespace
 
 bool op_gram_f32_fast_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t p) {
@@ -332,6 +360,40 @@ int op_gram_f32_fast(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t 
     hipLaunchKernelGGL(k_zty_reduce, dim3((unsigned)std::min<int64_t>((N * p + 255) / 256, 2048)), dim3(256), 0, h->stream,
                        (const double*)slab, slab_stride, (int)nsplit, lw, Y, ldy, N, (int)p);
     TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+
+// The factors of A_k for the wide sweep (sweeps.hip, k_zsweep_wide) on an fp32 panel, ranks 33..80:
+//   T32  (M x lw fp32, ld M) = Z Vg   on the fp32 MFMA (k_zx_f32: 0.43 ms at 65536 x 4096 against 1.11 ms of the widening
+//                                     fp64 product), lw = 64 for r <= 64, else 80
+//   Vs32 (N x lw fp32, ld N) = Vs
+//   Tm   (M x r fp64)        = T32 widened: what every other consumer of the factors reads (final A, final E)
+bool wide_factors_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t r) {
+    return r > 32 && r <= 80 && op_gram_f32_fast_ok(Z, ldz, M, N, r <= 64 ? 64 : 80);
+}
+
+int wide_factors_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* Vg, const double* Vs,
+                     int64_t r, double* Tm, const float** T32_out, const float** Vs32_out, int* lw_out) {
+    const int lw = r <= 64 ? 64 : 80;
+    void *wt, *t32, *vs32;
+    TLSQ_TRY(ws_get(h, WS_OPW, (size_t)N * lw * 8, &wt));
+    TLSQ_TRY(ws_get(h, WS_T32, (size_t)M * lw * 4, &t32));
+    TLSQ_TRY(ws_get(h, WS_VS32, (size_t)N * lw * 4, &vs32));
+    hipLaunchKernelGGL(k_pack_wt32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, Vg, N,
+                       (int)N, (int)r, lw, (float*)wt);
+    hipLaunchKernelGGL(k_cols_to_f32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, Vs, N,
+                       N, (int)r, lw, (float*)vs32);
+    const dim3 grid((unsigned)(M / 128));
+    if (lw == 64) hipLaunchKernelGGL((k_zx_f32<4>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
+    else hipLaunchKernelGGL((k_zx_f32<5>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
+    if (Tm)
+        hipLaunchKernelGGL(k_cols_to_f64, dim3((unsigned)std::min<int64_t>((M * r + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           (const float*)t32, M, M, (int)r, Tm);
+    TLSQ_HIP(h, hipGetLastError());
+    *T32_out = (const float*)t32;
+    *Vs32_out = (const float*)vs32;
+    *lw_out = lw;
     return TLSQ_OK;
 }
 

@@ -1187,6 +1187,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // certificate fail, once more after the fall-back.
         double sigma_top = 0.0, mu_next = mu;
         bool fuse = false, fuse_rebuild = false, rebuilt = false, rebuild_marked = false;
+        bool wide_sweep = false;                     // ranks 33..80 on an fp32 panel: A_k formed on the fp32 MFMA inside the sweep
+        const float *wide_T32 = nullptr, *wide_Vs32 = nullptr;
         auto count_and_rebuild = [&](bool mark) -> int {
             if (mark && !rebuild_marked) {
                 pt.mark();
@@ -1216,6 +1218,36 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             else
                 fuse_rebuild = fuse && !no_fuse_rebuild && !ro.hankel && !hook_opnorm &&
                                rebuild_update_shrink_ok<T>(D, E, Y, R, Ebuf[cur ^ 1], Zbuf[cur ^ 1], M, N, svp);
+            // fp32 panels, ranks 33..80 (BASELINE config 5: 65536 x 4096, rank 64): the factors in fp32 - T32 = Z Vg on the fp32 MFMA
+            // (opgram32.hip) - and A_k formed tile by tile on the fp32 MFMA inside the sweep (sweeps.hip, k_zsweep_wide) instead of a
+            // stored A (skinny GEMM + k_zsweep_lin): 1.11 + 0.78 + 1.42 ms -> 0.43 + ~1.1 ms per iteration there.  The fp64 copy of T
+            // (what the final A / E are formed from) is T32 widened.
+            wide_sweep = false;
+            if constexpr (Prec<T>::f32) {
+                if (zmode && fuse && svp > 32 && !ro.hankel_y && !dev_is(DEV_NO_WIDE_SWEEP, '1') && zsweep_wide_ok(M, N, svp) &&
+                    wide_factors_ok((const float*)Z, M, M, N, svp)) {
+                    void *Vgp, *Vsp, *T1, *auxp;
+                    const int slot = (k & 1) ? 1 : 2;   // (the buffer pairs rebuild_factors alternates between in the E-free loop)
+                    TLSQ_TRY(ws_get(h, WS_VG, (size_t)N * svp * 8, &Vgp));
+                    TLSQ_TRY(ws_get(h, slot == 1 ? WS_VS2 : WS_VS3, (size_t)N * svp * 8, &Vsp));
+                    TLSQ_TRY(ws_get(h, slot == 1 ? WS_T2 : WS_T, (size_t)M * svp * 8, &T1));
+                    TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)svp * 16, &auxp));
+                    TLSQ_TRY(gather_scale_host(h, V, N, sel, g, auxp, (double*)Vgp, (double*)Vsp));
+                    int lw = 0;
+                    TLSQ_TRY(wide_factors_f32(h, (const float*)Z, M, M, N, (const double*)Vgp, (const double*)Vsp, svp, (double*)T1,
+                                              &wide_T32, &wide_Vs32, &lw));
+                    Tm_last = (const double*)T1;
+                    Vs_last = (const double*)Vsp;
+                    r_last = svp;
+                    hbm_other += panel_bytes;
+                    wide_sweep = true;
+                    fuse_rebuild = true;
+                    a_pending = true;
+                    rebuilt = true;
+                    sub.spec.launched = false;
+                    return TLSQ_OK;
+                }
+            }
             // (the factor product may already be queued: SubspaceState::SpecRebuild - same kernel, same list, decided on the device)
             bool spec_hit = sub.spec.launched && sub.spec.dev_ok && sub.spec.dev_r == svp && svp >= 1 &&
                             svp <= 16 * sub.spec.nct && V == (const double*)h->ws[WS_SX].p && sub.spec.Z == (const void*)Z;
@@ -1669,6 +1701,17 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(launch_residual<T>(h, D, A, Ebuf[0], R, n));
                 hbm_sweeps += 7.0 * panel_bytes;
             }
+        } else if (wide_sweep) {
+            // A_k above 32 columns on an fp32 panel: formed on the fp32 MFMA inside the sweep (3 reads + 2 writes + R)
+            if constexpr (Prec<T>::f32) {
+                TLSQ_TRY(panel_D(&D));
+                TLSQ_TRY(launch_zsweep_wide(h, (const float*)D, wide_T32, M, wide_Vs32, svp, (const float*)Ybuf[ycur], (float*)Ybuf[ycur ^ 1],
+                                            (float*)Zbuf[zc], (float*)Zbuf[zc ^ 1], (float*)Rst, M, N, (float)mu, (float)inv_mu,
+                                            ro.nonnegA ? 1 : 0, (float)(1.0 / mu_next), (float)(lam / mu_next), ro.nonnegE ? 1 : 0,
+                                            sumsq_dev, sumsq_next, maxslot));
+            }
+            z_swept = true;
+            hbm_sweeps += (Rst ? 6.0 : 5.0) * panel_bytes;
         } else if (zmode && !fuse_rebuild) {
             // A_k above 32 columns: stored by the rebuild, read back here (6 panel passes + R)
             TLSQ_TRY(sweep_rows(0, 0, 0));

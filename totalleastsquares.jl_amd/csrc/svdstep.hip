@@ -370,7 +370,15 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
                 ++st.steps;
                 TLSQ_TRY(op_apply(h, op, N, src, cur, p));
                 bool used = false;
-                TLSQ_TRY(launch_orth(h, cur, (double*)GQ, (double*)H, N, p, t + 1 < npow ? stat2 + 3 * t : stat_dev, chol, &used, false));
+                // (a carried block consists of Ritz vectors: their images are nearly orthogonal, and the column scaling of the
+                //  second product does not hurt the scaled Cholesky factor - only the last product's block is orthonormalised;
+                //  the refreshed pad columns are projected against the blocks in front of them first, HOOK_ORTH_ALL=1 for every product)
+                const bool skip_orth = chol && carry >= st.hook_rank && t + 1 < npow && !dev_is(DEV_HOOK_ORTH_ALL, '1');
+                if (skip_orth) {
+                    TLSQ_HIP(h, hipMemsetAsync(stat2 + 3 * t, 0, 24, h->stream));
+                } else {
+                    TLSQ_TRY(launch_orth(h, cur, (double*)GQ, (double*)H, N, p, t + 1 < npow ? stat2 + 3 * t : stat_dev, chol, &used, false));
+                }
                 used_any = used_any || used;
                 src = cur;
                 std::swap(cur, other);
@@ -379,7 +387,10 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
             TLSQ_TRY(op_apply(h, op, N, Qf, (double*)GQ, p));
             TLSQ_TRY(launch_panel_tn(h, Qf, (const double*)GQ, (double*)H, N, p));
             int64_t sw = 0;
-            TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
+            // (sketch products carry the fp32 rounding of the block, ~1e-7: Ritz vectors orthogonal to 1e-9 lose nothing, and the
+            //  Jacobi sweeps from there to 4e-15 - three of eight at p = 74, 0.14 ms each - are saved)
+            TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true,
+                                op.implicit() && op.lowp_ok ? 1e-9 : 0.0));
             if (sweeps) *sweeps += sw;
             TLSQ_TRY(launch_ritz_finish(h, Qf, (const double*)GQ, (const double*)S, (double*)X, (double*)GX, theta_dev, res_dev, N, p));
             TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost, h->stream));
@@ -392,9 +403,12 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
             }
             bool finite = true;
             for (int64_t i = 0; i < 2 * p; ++i) finite = finite && std::isfinite(host[(size_t)i]);
-            if (dev_get(DEV_DEBUG) != nullptr)
-                fprintf(stderr, "  hook: p %lld carry %lld npow %d %s%s\n", (long long)p, (long long)carry, npow, chol ? "CholeskyQR2" : "CGS2",
-                        failed ? " - factorisation broke down, again from a random block with CGS2" : "");
+            if (dev_get(DEV_DEBUG) != nullptr) {
+                int sd = -1;
+                (void)hipMemcpy(&sd, (char*)h->ws[WS_SCAL].p + 136, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "  hook: p %lld carry %lld npow %d %s, %d Jacobi sweeps%s\n", (long long)p, (long long)carry, npow,
+                        chol ? "CholeskyQR2" : "CGS2", sd, failed ? " - factorisation broke down, again from a random block with CGS2" : "");
+            }
             if ((failed || !finite) && attempt == 0) continue;
             if (!finite) {
                 st.fail = SubspaceState::FAIL_NUMERIC;

@@ -477,6 +477,176 @@ __global__ __launch_bounds__(256) void k_zsweep_lin(const T* __restrict__ D, T* 
     }
 }
 
+// ---- the E-free sweep for ranks above 32 on fp32 panels: A_k on the fp32 MFMA inside the sweep (round 5) ---------------------
+// Above 32 columns A_k = T Vs' does not fit a thread's registers as factors: the loop stored it (a skinny GEMM writing the
+// panel: 0.78 ms at 65536 x 4096, r = 64) and k_zsweep_lin read it back (4 reads + 2 writes: 1.42 ms).  Here a wave owns a strip
+// of 32 panel columns and walks down a run of 32-row tiles; for every tile A_k[32 x 32] = Vs[strip] T[tile]' comes out of
+// 2 KH v_mfma_f32_32x32x2_f32 (the factors as fp32: Vs fragments stay in registers for the whole run, the T fragments of the
+// tile are re-read from L2 - T32 is 17 MB) with the ROW index in the lanes: register (g, e) of lane l is the element (row
+// m0 + l % 32, column n0 + 8 g + 4 (l / 32) + e), so every D / Y / Z access of the sweep's element-wise part (:217-222 and
+// the next :188-192, exactly the statements of k_zsweep_lin) is two 128-byte runs per instruction, and consecutive tiles
+// continue the same 32 column streams.  3 reads + 2 writes of the panel (+ R), no stored A.
+// Workgroup = 4 waves = 4 neighbouring strips on the same rows (the T fragments are shared through L1/L2).
+typedef float zw_f16 __attribute__((ext_vector_type(16)));
+
+// (buffer addressing: a wave-uniform 64-bit base in a descriptor, ONE 32-bit lane offset per tile and the element's column
+//  offset as the instruction's scalar offset - 16 global pointers per array would not fit the register file beside the fragments)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t zw_rsrc(const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ float zw_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void zw_st(float v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff, (int)soff, AUX);
+}
+
+template <int KH, bool ZIP, bool HASR>
+__global__ __launch_bounds__(256, 3) void k_zsweep_wide(const float* __restrict__ D, const float* __restrict__ T32, int64_t ldt,
+                                                        const float* __restrict__ Vs32, const float* __restrict__ Yin,
+                                                        float* __restrict__ Yout, const float* __restrict__ Z, float* __restrict__ Zo,
+                                                        float* __restrict__ R, int64_t M, int N, int64_t rows_per_chunk, float mu,
+                                                        float inv_mu, int nonnegA, float inv_mu_n, float thr_n, int nonnegE,
+                                                        double* __restrict__ sumsq, double* __restrict__ zero_slots, int maxslot) {
+    if (zero_slots && blockIdx.x == 0 && threadIdx.x < 72) zero_slots[threadIdx.x] = 0.0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int jl = lane & 31, kh = lane >> 5;
+    const int nsg = N / 128;
+    const int64_t chunk = blockIdx.x / nsg;
+    const int n0 = ((int)(blockIdx.x % nsg) * 4 + w) * 32;
+    float af[KH];
+#pragma unroll
+    for (int s = 0; s < KH; ++s) af[s] = Vs32[(size_t)(n0 + jl) + (size_t)(2 * s + kh) * N];
+    const int64_t mbeg = chunk * rows_per_chunk;
+    const int64_t mend = (mbeg + rows_per_chunk < M) ? mbeg + rows_per_chunk : M;
+    const int ntile = (int)((mend - mbeg) / 32);
+    // element i = 4 g + e of the tile at row m0: (row m0 + jl, column n0 + 4 kh + 8 g + e)
+    const int64_t strip = (int64_t)n0 * M + mbeg;                  // first element of the strip's run
+    const __amdgpu_buffer_rsrc_t rD = zw_rsrc(D + strip), rY = zw_rsrc(Yin + strip), rYo = zw_rsrc(Yout + strip),
+                                 rZ = zw_rsrc((ZIP ? (const float*)Zo : Z) + strip), rZo = zw_rsrc(Zo + strip),
+                                 rR = zw_rsrc(HASR ? R + strip : Zo + strip), rT = zw_rsrc(T32 + mbeg);
+    const uint32_t m4 = (uint32_t)M * 4u, ldt4 = (uint32_t)ldt * 4u;
+    const uint32_t voff0 = (uint32_t)(4 * kh) * m4 + (uint32_t)jl * 4u;   // + 128 t
+    const uint32_t toff0 = (uint32_t)kh * ldt4 + (uint32_t)jl * 4u;
+    double ss = 0.0;
+    float rmax = 0.f;
+    // No software pipeline across tiles: a wave requests the 2 KH + 48 values of its tile at once (up to the 63 requests the
+    // counter allows in flight), and 8-12 waves per CU x 20 KB cover the HBM latency by themselves (Little: 2048 waves x 20 KB
+    // / 2 us = 20 TB/s) - registers carried over the loop's back edge only brought copies and waits.
+    for (int t = 0; t < ntile; ++t) {
+        const uint32_t to = toff0 + 128u * (uint32_t)t;
+        const uint32_t vo = voff0 + 128u * (uint32_t)t;
+        float bf[KH];
+        float dv[16], yv[16], zv[16];
+#pragma unroll
+        for (int s = 0; s < KH; ++s) bf[s] = zw_ld<0>(rT, to, (uint32_t)(2 * s) * ldt4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t so = (uint32_t)(8 * (i >> 2) + (i & 3)) * m4;
+            zv[i] = zw_ld<2>(rZ, vo, so);
+            yv[i] = zw_ld<2>(rY, vo, so);
+            dv[i] = zw_ld<2>(rD, vo, so);
+        }
+        zw_f16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+        float s32 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t so = (uint32_t)(8 * (i >> 2) + (i & 3)) * m4;
+            float a = acc[i];
+            if (nonnegA) a = pos_part(a);                   // :217-219
+            const float wv = zv[i] - a;
+            const float res = wv - inv_mu * yv[i];          // :221 through Z_k = D - E_k + Y_k / mu_k
+            s32 += res * res;
+            const float ares = res < 0.f ? -res : res;
+            rmax = ares > rmax ? ares : rmax;
+            const float y1 = mu * wv;                       // :222
+            const float tt = inv_mu_n * y1;
+            float ee = soft_th((dv[i] - a) + tt, thr_n);    // :188
+            if (nonnegE) ee = pos_part(ee);
+            const float zn = (dv[i] - ee) + tt;             // :192
+            if (HASR) zw_st<2>(res, rR, vo, so);
+            zw_st<2>(y1, rYo, vo, so);
+            zw_st<2>(zn, rZo, vo, so);
+        }
+        ss += (double)s32;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+        __shared__ double sw[4];
+        if (lane == 0) sw[w] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sumsq + (blockIdx.x & 63), (sw[0] + sw[1]) + (sw[2] + sw[3]));
+        if (maxslot >= 0) {
+            double m = (double)rmax;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_down(m, off, 64);
+                m = o > m ? o : m;
+            }
+            __syncthreads();
+            if (lane == 0) sw[w] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double mm = sw[0];
+                for (int k = 1; k < 4; ++k) mm = sw[k] > mm ? sw[k] : mm;
+                atomicMax(reinterpret_cast<unsigned long long*>(sumsq + 64 + maxslot),
+                          (unsigned long long)__double_as_longlong(mm));
+            }
+        }
+    }
+}
+
+bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r) {
+    return r > 32 && r <= 80 && (M % 32) == 0 && (N % 128) == 0 && M >= 4096 && M <= (1 << 24) && N <= 1000000;   // (32-bit byte offsets inside a strip: 108 M < 2^32)
+}
+
+// T32: M x 2 KH (ld ldt) and Vs32: N x 2 KH (ld N), KH = 32 for r <= 64 and 40 for r <= 80, columns r.. zero
+int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt, const float* Vs32, int64_t r, const float* Yin,
+                       float* Yout, float* Z, float* Zout, float* R, int64_t M, int64_t N, float mu, float inv_mu, int nonnegA,
+                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot) {
+    if (!zsweep_wide_ok(M, N, r)) return set_err(h, TLSQ_ERR_ARG, "zsweep_wide: shape");
+    if (!Zout) Zout = Z;
+    if (!sumsq || maxslot > 7) maxslot = -1;
+    const bool zip = Zout == Z;
+    const float* Zr = zip ? nullptr : Z;
+    // ~16 waves per CU (126 registers: four waves per SIMD): 4096 waves over N / 32 strips
+    const int64_t nstrips = N / 32;
+    int64_t nchunks = std::max<int64_t>(1, (4096 + nstrips - 1) / nstrips);
+    int64_t rpc = (M + nchunks - 1) / nchunks;
+    rpc = (rpc + 31) / 32 * 32;
+    nchunks = (M + rpc - 1) / rpc;
+    const dim3 grid((unsigned)(nchunks * (N / 128)));
+#define ZW_LAUNCH(KHV, ZP, HR)                                                                                              \
+    hipLaunchKernelGGL((k_zsweep_wide<KHV, ZP, HR>), grid, dim3(256), 0, h->stream, D, T32, ldt, Vs32, Yin, Yout, Zr, Zout, R, M, \
+                       (int)N, rpc, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot)
+#define ZW_PICK(KHV)                          \
+    do {                                      \
+        if (zip) {                            \
+            if (R) ZW_LAUNCH(KHV, true, true); \
+            else ZW_LAUNCH(KHV, true, false);  \
+        } else {                              \
+            if (R) ZW_LAUNCH(KHV, false, true); \
+            else ZW_LAUNCH(KHV, false, false);  \
+        }                                     \
+    } while (0)
+    if (r <= 64) ZW_PICK(32);
+    else ZW_PICK(40);
+#undef ZW_PICK
+#undef ZW_LAUNCH
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 // E = soft_th(D - A_prev + Y / mu, lambda / mu) (:188-191) once after the E-free loop, A_prev = Tm Vs' from the factors of the
 // previous iteration (r = 0: A_prev = 0, the first iteration).  E may be the buffer Y lives in (same element read, then
 // written): no __restrict__ on the two.
