@@ -1356,7 +1356,34 @@ int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
     return TLSQ_OK;
 }
 
+// the lower-triangle 128 x 128 tiles (diagonal ones included) of an nti x nti tile grid as pairs (ti, tj) in blocked order -
+// 8 x 4 tiles share 8 + 4 panels, so a run of work items on one XCD finds them in its L2 -, on the device (kept per handle)
+int gram_tile_table(Handle* h, int64_t nti, const int32_t** tab_out) {
+    const int64_t ntiles = nti * (nti + 1) / 2;
+    void* tab;
+    TLSQ_TRY(ws_get(h, WS_GRAMTAB2, (size_t)ntiles * 8, &tab));
+    if (h->gram_tab2_nti != nti) {
+        std::vector<int32_t> o;
+        o.reserve((size_t)ntiles * 2);
+        for (int64_t I = 0; I < nti; I += 8)
+            for (int64_t J = 0; J < std::min(I + 8, nti); J += 4)
+                for (int64_t ti = I; ti < std::min(I + 8, nti); ++ti)
+                    for (int64_t tj = J; tj < std::min(J + 4, ti + 1); ++tj) {
+                        o.push_back((int32_t)ti);
+                        o.push_back((int32_t)tj);
+                    }
+        if ((int64_t)o.size() != 2 * ntiles) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: tile order table");
+        TLSQ_HIP(h, hipMemcpyAsync(tab, o.data(), o.size() * 4, hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        h->gram_tab2_nti = nti;
+    }
+    *tab_out = (const int32_t*)tab;
+    return TLSQ_OK;
+}
+
 static int gram_f32mfma(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64_t N, int64_t K) {
+    // (aligned tall panels: the fp16 MFMA on the two-plane split of the panel, gram16.hip - 3.4x faster at 65536 x 4096)
+    if (gram_h3_ok(Z, ld, N, K) && !dev_is(DEV_GRAM_H3, '0')) return gram_h3(h, Z, ld, G, ldg, N, K);
     const int64_t nti = (N + TI - 1) / TI, ntiles = nti * (nti + 1) / 2;
     static const int64_t target_wgs = 256;
     // uniform K split: rounds of one item per CU, + a quarter item for the drift, + the slab traffic (see gram_kc)
@@ -1380,24 +1407,10 @@ static int gram_f32mfma(Handle* h, const float* Z, int64_t ld, double* G, int64_
         }
     }
     const int64_t slab_stride = N * N;
-    void *slab, *tab;
+    void* slab;
+    const int32_t* tab = nullptr;
     TLSQ_TRY(ws_get(h, WS_SLAB, (size_t)(nsplit * slab_stride) * sizeof(double), &slab));
-    TLSQ_TRY(ws_get(h, WS_GRAMTAB2, (size_t)ntiles * 8, &tab));
-    if (h->gram_tab2_nti != nti) {   // blocked tile order, diagonal tiles included (see gram_kc)
-        std::vector<int32_t> o;
-        o.reserve((size_t)ntiles * 2);
-        for (int64_t I = 0; I < nti; I += 8)
-            for (int64_t J = 0; J < std::min(I + 8, nti); J += 4)
-                for (int64_t ti = I; ti < std::min(I + 8, nti); ++ti)
-                    for (int64_t tj = J; tj < std::min(J + 4, ti + 1); ++tj) {
-                        o.push_back((int32_t)ti);
-                        o.push_back((int32_t)tj);
-                    }
-        if ((int64_t)o.size() != 2 * ntiles) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: tile order table");
-        TLSQ_HIP(h, hipMemcpyAsync(tab, o.data(), o.size() * 4, hipMemcpyHostToDevice, h->stream));
-        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-        h->gram_tab2_nti = nti;
-    }
+    TLSQ_TRY(gram_tile_table(h, nti, &tab));
     const int64_t nwork = ntiles * nsplit, cpx = (nwork + 7) / 8;
     if (8 * cpx > 2147483647LL) return set_err(h, TLSQ_ERR_UNSUPPORTED, "gram: grid too large");
     const int vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(Z) % 16) == 0) ? 1 : 0;
@@ -1405,10 +1418,10 @@ static int gram_f32mfma(Handle* h, const float* Z, int64_t ld, double* G, int64_
     const bool allfull = vec_ok && (N % TI) == 0 && (K % FTK) == 0;
     if (allfull)
         hipLaunchKernelGGL(k_gram_f32mfma<true>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ld, (double*)slab, N, N, K,
-                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, (const int32_t*)tab);
+                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, tab);
     else
         hipLaunchKernelGGL(k_gram_f32mfma<false>, dim3((unsigned)(8 * cpx)), dim3(512), 0, h->stream, Z, ld, (double*)slab, N, N, K,
-                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, (const int32_t*)tab);
+                           kchunk, slab_stride, (int)ntiles, (int)nsplit, vec_ok, tab);
     TLSQ_HIP(h, hipGetLastError());
     int64_t g = (N * N + 255) / 256;
     if (g > 2048) g = 2048;
