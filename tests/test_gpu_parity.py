@@ -1528,7 +1528,7 @@ def test_implicit_gram_operator_path(eng):
 
 
 def test_implicit_gram_operator_path_fp32(eng):
-    """The same path on an fp32 panel (what 16384 x 8192 fp32 runs in the default mode): the certified solver needs operator
+    """The same path on an fp32 panel (what fp32 panels beyond 8192 columns run in the default mode): the certified solver needs operator
     products in full precision - the fp32-MFMA products of the randomized hook's sketch (block rounded to fp32) leave its
     residual test at 1e-7 for ever (round 3: the large case ended with "could not be served by the subspace solver" while
     those products were used unconditionally; tools/bench_all.sh caught it)."""

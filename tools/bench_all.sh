@@ -12,6 +12,7 @@ print(f\"{d['value']:.1f} iters/s  sweep {r['achieved']:.0f} GB/s (frac {r['frac
 echo "== C3 lowrankfilter N=1e7 n=256";      python tools/scale_lowrankfilter.py --no-hist 2>&1 | grep "^N="
 echo "== C4 200000x512 fp64 on one GPU";     python tools/large_case.py 200000 512 16 --no-hist 2>&1 | grep " iters="
 echo "== C5 65536x4096 fp32 rank 64";        python tools/large_case.py 65536 4096 64 --f32 --no-hist 2>&1 | grep " iters="
+echo "== C5 with svd = randomized (BASELINE config 5's algorithm)"; python tools/large_case.py 65536 4096 64 --f32 --no-hist --randomized 2>&1 | grep " iters="
 echo "== large mode 16384x8192 fp32 rank 40"; python tools/large_case.py 16384 8192 40 --f32 --no-hist 2>&1 | grep " iters="
 echo "== batched rtls 50x(3+1)";             python tools/bench_batched.py 2>&1 | grep -Ev "$F" | tail -1 | cut -c1-260
 echo "== batched rtls 500x(5+1)";            python tools/bench_batched.py --M 500 --n 5 --batch 4000 --cpu-problems 50 2>&1 | grep -Ev "$F" | tail -1 | cut -c1-260

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 import tlsq_amd
+tlsq_amd.dev_from_env()
 
 noeig = '--noeig' in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith('--')]

@@ -31,12 +31,11 @@ typedef double gd4 __attribute__((ext_vector_type(4)));
 typedef unsigned int gu4 __attribute__((ext_vector_type(4)));
 
 constexpr int HT = 128;               // tile of G
-constexpr int HK = 32;                // rows per stage = one 16 x 16 x 32 step
-constexpr int HP = 32;                // halfs per staged column (64 bytes: the stage's four 16-byte row groups, swizzled - h3_sw)
-constexpr int HPANEL = HT * HP;       // halfs per plane of a panel (10 KB)
-constexpr int HBUF = 4 * HPANEL;      // A hi, A lo, B hi, B lo (40 KB)
-constexpr int HRING = 4;              // stages of global loads in flight (registers)
-// (stages per fp64 fold-in: template parameter of the kernel - 2, 4 or 8 stages = 64, 128, 256 rows; GRAM_H3_FOLD, default 4)
+constexpr int HK = 64;                // rows per stage = two 16 x 16 x 32 steps: a column of a stage is one 128-byte line
+constexpr int HP = 64;                // halfs per staged column (128 bytes: the stage's eight 16-byte row groups, swizzled - h3_sw)
+constexpr int HPANEL = HT * HP;       // halfs per plane of a panel (16 KB)
+constexpr int HBUF = 4 * HPANEL;      // A hi, A lo, B hi, B lo (64 KB)
+// (fp64 fold-in: template parameter of the kernel - every stage or every 2 or 4 stages = 64, 128, 256 rows; GRAM_H3_FOLD, default 128)
 
 __global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ Z, int64_t n, unsigned int* __restrict__ out) {
     const int64_t nv = n / 4;
@@ -92,10 +91,11 @@ __global__ __launch_bounds__(256) void k_split_f16(const float* __restrict__ Z, 
 
 // ds_read_b128 serves a wave in four groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - with
 // the bank = (byte address / 4) mod 64: a group holds all 16 columns of a fragment, eight of them with row group g and eight with
-// g + 1.  With an unpadded 64-byte column pitch the four columns c, c + 4, c + 8, c + 12 share a 16-bank quarter; storing row group
-// g of column c in slot g ^ sw(c), sw = (0, 3, 2, 1)[(c >> 2) & 3], gives them four different slots in every group (checked by
-// enumeration for all four groups) - a plain 80-byte pitch left three two-way conflicts per group.
-__device__ __forceinline__ int h3_sw(int c) { return (-(c >> 2)) & 3; }
+// g + 1 (g even).  With a 128-byte column pitch even and odd columns own one half of the banks each; storing row group g of column c
+// in slot g ^ sw(c), sw = (c >> 1) & 7, gives the eight columns of a half eight different slots in every group (the two kinds
+// differ in bit 0 only, and sw separates {0, 1, 6, 7} from {2, 3, 4, 5}; checked by enumeration) - a padded pitch left two-way
+// conflicts on three columns of every group.  The stores (eight lanes per column) stay conflict-free under any such swizzle.
+__device__ __forceinline__ int h3_sw(int c) { return (c >> 1) & 7; }
 
 template <int HFOLD>
 __global__ __launch_bounds__(512, 2) void k_gram_h3(const _Float16* __restrict__ H, const _Float16* __restrict__ L, int64_t ld,
@@ -116,23 +116,26 @@ __global__ __launch_bounds__(512, 2) void k_gram_h3(const _Float16* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wj = w & 3, wi = w >> 2;
     const int fr = lane & 15, kg = lane >> 4;
-    // staging: thread -> (column tid / 4, rows 8 (tid % 4) .. + 7) of each of the four planes
-    const int scol = tid >> 2, spart = tid & 3;
-    const int64_t ga = (i0 + scol) * ld + kbeg + 8 * spart;
-    const int64_t gb = (j0 + scol) * ld + kbeg + 8 * spart;
-    const int so = scol * HP + 8 * (spart ^ h3_sw(scol));
-    gu4 ring[HRING][4];
-    auto gload = [&](gu4* r, int s) {
+    // Staging: global -> LDS loads that bypass the registers (global_load_lds_dwordx4: a wave instruction fills 1 KB of LDS, lane l
+    // at base + 16 l) - wave w brings columns 8 w .. 8 w + 7 (+ 64) of each plane, lane = (column l / 8, slot l % 8), and the row
+    // group swizzle is applied on the global side: slot q of column c receives row group q ^ sw(c).  A wave's instruction covers
+    // eight whole 128-byte lines; no staging registers, no ds_write_b128.
+    const int dcol = w * 8 + (lane >> 3), dslot = lane & 7;
+    const int64_t da0 = (i0 + dcol) * ld + kbeg + 8 * (dslot ^ h3_sw(dcol));
+    const int64_t da1 = (i0 + dcol + 64) * ld + kbeg + 8 * (dslot ^ h3_sw(dcol + 64));
+    const int64_t db0 = (j0 + dcol) * ld + kbeg + 8 * (dslot ^ h3_sw(dcol));
+    const int64_t db1 = (j0 + dcol + 64) * ld + kbeg + 8 * (dslot ^ h3_sw(dcol + 64));
+    auto dload = [&](int buf, int s) {
         const int64_t o = (int64_t)s * HK;
-        r[0] = *reinterpret_cast<const gu4*>(H + ga + o);
-        r[1] = *reinterpret_cast<const gu4*>(L + ga + o);
-        r[2] = *reinterpret_cast<const gu4*>(H + gb + o);
-        r[3] = *reinterpret_cast<const gu4*>(L + gb + o);
-    };
-    auto sstore = [&](const gu4* r, int buf) {
-        _Float16* b = hsm + buf * HBUF + so;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<gu4*>(b + p * HPANEL) = r[p];
+        _Float16* b = hsm + buf * HBUF + (w * 8) * HP;
+        __builtin_amdgcn_global_load_lds(H + da0 + o, b, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(H + da1 + o, b + 64 * HP, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(L + da0 + o, b + HPANEL, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(L + da1 + o, b + HPANEL + 64 * HP, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(H + db0 + o, b + 2 * HPANEL, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(H + db1 + o, b + 2 * HPANEL + 64 * HP, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(L + db0 + o, b + 3 * HPANEL, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(L + db1 + o, b + 3 * HPANEL + 64 * HP, 16, 0, 0);
     };
     gf4 acc[4][2];
     gd4 acc64[4][2];
@@ -155,75 +158,77 @@ __global__ __launch_bounds__(512, 2) void k_gram_h3(const _Float16* __restrict__
     };
     const int last = nst - 1;
     auto clamps = [&](int s) { return s < last ? s : last; };
-    const int oa = (wi * 64 + fr) * HP + 8 * (kg ^ h3_sw(fr)), ob = (wj * 32 + fr) * HP + 8 * (kg ^ h3_sw(fr));   // (tile bases are multiples of 16)
-    // Stage s: its planes are in LDS buffer s & 1 (stored during stage s - 1).  The waves of a workgroup meet at a barrier every
-    // stage, i.e. they run in step: fragment reads must overlap the MFMAs inside each wave, not across waves.  First third: the
-    // hi x hi products on fragments fetched during the previous stage, while the lo fragments of this stage are read and the
-    // registers of ring slot (s + 1) % 4 - stage s + 1, requested during stage s - 3 - go to the other buffer; barrier; the other
-    // two thirds (hi x lo, lo x hi) while the hi fragments of stage s + 1 are read from that buffer.  Ring slot s % 4 then
-    // requests stage s + 4.
-    gh8 ah[2][4], bh[2][2];
-    auto read_hi = [&](gh8* a4, gh8* b2, int buf) {
-        const _Float16* base = hsm + buf * HBUF;
+    // fragment of k-step ks (row groups 4 ks + kg) of the 16 columns at `col0` of a plane: column col0 + fr, slot (4 ks + kg) ^ sw
+    const int ca = (wi * 64 + fr) * HP, cb = (wj * 32 + fr) * HP;
+    const int swf = h3_sw(fr);                     // (tile bases are multiples of 16: sw(col) = sw(fr))
+    const int g0 = 8 * (kg ^ swf), g1 = 8 * ((4 + kg) ^ swf);
+    auto read_a = [&](gh8* a4, const _Float16* plane, int g) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) a4[a] = *reinterpret_cast<const gh8*>(base + oa + a * 16 * HP);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) b2[b] = *reinterpret_cast<const gh8*>(base + 2 * HPANEL + ob + b * 16 * HP);
+        for (int a = 0; a < 4; ++a) a4[a] = *reinterpret_cast<const gh8*>(plane + ca + a * 16 * HP + g);
     };
+    auto read_b = [&](gh8* b2, const _Float16* plane, int g) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) b2[b] = *reinterpret_cast<const gh8*>(plane + cb + b * 16 * HP + g);
+    };
+    auto mm = [&](const gh8* a4, const gh8* b2) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a4[a], b2[b], acc[a][b], 0, 0, 0);
+    };
+    // Stage s (64 rows, two MFMA steps, six groups of 8 MFMAs): its planes are in LDS buffer s & 1.  The waves of a workgroup meet at
+    // a barrier every stage, i.e. they run in step and request their fragments in bursts (8 waves x 6 KB): a group of 8 MFMAs is
+    // 128 cycles, shorter than such a burst takes - so every fragment set is requested TWO groups before its first use (four
+    // sets of 24 registers; with one group of distance the MFMA pipe was busy 35 % of the time).  Before the fifth group: this
+    // wave's part of stage s + 1 has landed (vmcnt), behind the barrier everybody's has, and nobody reads buffer s & 1 any more
+    // (the last fragments taken from it are in registers) - stage s + 2 is requested into it, and the first two fragment sets of
+    // stage s + 1 from the other buffer.
+    gh8 ah0[4], bh0[2], al0[4], bl0[2], ah1[4], bh1[2], al1[4], bl1[2];
     auto stage = [&](auto uc, int s) {
         constexpr int u = decltype(uc)::value;
-        constexpr int c = u & 1;
-        const _Float16* base = hsm + (u & 1) * HBUF;
-        gh8 al[4], bl[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) bl[b] = *reinterpret_cast<const gh8*>(base + 3 * HPANEL + ob + b * 16 * HP);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) al[a] = *reinterpret_cast<const gh8*>(base + HPANEL + oa + a * 16 * HP);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][a], bh[c][b], acc[a][b], 0, 0, 0);
-        sstore(ring[(u + 1) % HRING], (u + 1) & 1);
+        const _Float16* base = hsm + u * HBUF;
+        const _Float16* nbase = hsm + (u ^ 1) * HBUF;
+        read_a(ah1, base, g1);
+        read_b(bh1, base + 2 * HPANEL, g1);
+        mm(ah0, bh0);                              // hi x hi, step 0
+        read_a(al1, base + HPANEL, g1);
+        read_b(bl1, base + 3 * HPANEL, g1);
+        mm(ah0, bl0);                              // hi x lo, step 0
+        mm(al0, bh0);                              // lo x hi, step 0
+        mm(ah1, bh1);                              // hi x hi, step 1
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) (lgkmcnt / expcnt untouched)
         __syncthreads();
-        read_hi(ah[c ^ 1], bh[c ^ 1], (u + 1) & 1);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][a], bl[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[c][b], acc[a][b], 0, 0, 0);
+#if !defined(H3_ABLATE) || H3_ABLATE != 1
+        dload(u, clamps(s + 2));
+#endif
+        read_a(ah0, nbase, g0);
+        read_b(bh0, nbase + 2 * HPANEL, g0);
+        read_a(al0, nbase + HPANEL, g0);
+        read_b(bl0, nbase + 3 * HPANEL, g0);
+        mm(ah1, bl1);                              // hi x lo, step 1
+        mm(al1, bh1);                              // lo x hi, step 1
 #if !defined(H3_ABLATE) || H3_ABLATE != 3
         if ((s % HFOLD) == HFOLD - 1) fold();
-#endif
-#if !defined(H3_ABLATE) || H3_ABLATE != 1
-        gload(ring[u], clamps(s + HRING));
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
     if (nst > 0) {
-        gload(ring[0], 0);
-        gload(ring[1], clamps(1));
-        gload(ring[2], clamps(2));
-        gload(ring[3], clamps(3));
-        sstore(ring[0], 0);
+        dload(0, 0);
+        dload(1, clamps(1));
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        read_hi(ah[0], bh[0], 0);
+        read_a(ah0, hsm, g0);
+        read_b(bh0, hsm + 2 * HPANEL, g0);
+        read_a(al0, hsm + HPANEL, g0);
+        read_b(bl0, hsm + 3 * HPANEL, g0);
         std::integral_constant<int, 0> U0;
         std::integral_constant<int, 1> U1;
-        std::integral_constant<int, 2> U2;
-        std::integral_constant<int, 3> U3;
         int s = 0;
-        for (; s + HRING <= nst; s += HRING) {
+        for (; s + 2 <= nst; s += 2) {
             stage(U0, s);
             stage(U1, s + 1);
-            stage(U2, s + 2);
-            stage(U3, s + 3);
         }
         if (s < nst) stage(U0, s);
-        if (s + 1 < nst) stage(U1, s + 1);
-        if (s + 2 < nst) stage(U2, s + 2);
         fold();
     }
     // register q of lane (fr, kg): D[i = 4 kg + q][j = fr] - row i of the A tile (column of Z i0 + ...), column j of the B tile
@@ -278,10 +283,10 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
     const int64_t nti = N / HT, ntiles = nti * (nti + 1) / 2;
     // row splits: ~2 rounds of 512 work items (two workgroups per CU), at least 32 stages each, slabs below 2 GB
     int64_t nsplit = std::max<int64_t>(1, (1024 + ntiles - 1) / ntiles);
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, K / (32 * HK)));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, K / (16 * HK)));
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, (int64_t)(((size_t)2 << 30) / ((size_t)N * N * 8))));
     int64_t kchunk = (K + nsplit - 1) / nsplit;
-    kchunk = (kchunk + HK * 8 - 1) / (HK * 8) * (HK * 8);
+    kchunk = (kchunk + HK * 4 - 1) / (HK * 4) * (HK * 4);
     nsplit = (K + kchunk - 1) / kchunk;
     const int64_t slab_stride = N * N;
     void* slab;
@@ -290,7 +295,7 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
     TLSQ_TRY(gram_tile_table(h, nti, &tab));
     const int64_t nwork = ntiles * nsplit, cpx = (nwork + 7) / 8;
     const size_t lds = (size_t)2 * HBUF * 2;
-    const int fold = [] { const char* e = dev_get(DEV_GRAM_H3_FOLD); const int v = e ? atoi(e) : 4; return v == 2 || v == 8 ? v : 4; }();
+    const int fold = [] { const char* e = dev_get(DEV_GRAM_H3_FOLD); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();   // stages of 64 rows
 #define H3_LAUNCH(F)                                                                                                             \
     do {                                                                                                                         \
         TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_h3<F>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -298,9 +303,9 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
         hipLaunchKernelGGL(k_gram_h3<F>, dim3((unsigned)(8 * cpx)), dim3(512), lds, h->stream, (const _Float16*)hp,              \
                            (const _Float16*)lp, ld, (double*)slab, N, K, kchunk, slab_stride, (int)ntiles, (int)nsplit, tab);    \
     } while (0)
-    if (fold == 2) H3_LAUNCH(2);
-    else if (fold == 8) H3_LAUNCH(8);
-    else H3_LAUNCH(4);
+    if (fold == 1) H3_LAUNCH(1);
+    else if (fold == 4) H3_LAUNCH(4);
+    else H3_LAUNCH(2);
 #undef H3_LAUNCH
     hipLaunchKernelGGL(k_h3_reduce, dim3(2048), dim3(256), 0, h->stream, (const double*)slab, slab_stride, (int)nsplit,
                        (const double*)sc, G, ldg, (int)N);

@@ -693,7 +693,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // skinny kernels: measured break-even near N = 128 p (65536 x 4096, p = 80: 41 ms explicit, 58 ms implicit per
     // iteration), so the switch sits at N >= 8192.  TLSQ_IMPLICIT_GRAM=0/1 overrides it (large mode only).
     const int force_implicit = [] { const char* e = dev_get(DEV_IMPLICIT_GRAM); return e ? atoi(e) : -1; }();
-    const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : N >= 8192);
+    // (round 5: fp32 panels the fp16-split Gram kernel takes - gram16.hip, 2x the fp32 MFMA's rate - keep the Gram matrix at
+    //  N = 8192 as well: 16384 x 8192 rank 40, 176 ms per solve against 305 in operator form)
+    const bool h3_shape = Prec<T>::f32 && (N % 128) == 0 && (M % 64) == 0 && M >= 4096 && !dev_is(DEV_GRAM_H3, '0');
+    const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : (h3_shape ? N > 8192 : N >= 8192));
     // The randomized hook in large mode (BASELINE config 5: `svd = rsvd`, src/robustPCA.jl:195-197, test/runtests.jl:388-398) is a
     // sketch: from iteration 2 on nothing but products with the panel - Y = Z'(Z Omega), orthonormalisation, the power passes, the
     // (sv + 10)-column Rayleigh quotient - and no N x N Gram matrix of Z (2 M N^2 flops: 12 ms of a 24 ms iteration at

@@ -347,10 +347,15 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         // direction absent from the carried block can still enter; a cold call (iteration 2 after a full decomposition on
         // another route, HOOK_COLD=1) starts from a random block like the reference's Omega.
         // A Cholesky factorisation that breaks down (status[1]) repeats the call from a random block with CGS2.
-        const int npow = [] {
+        // (products before the Rayleigh-Ritz step: two on the panel operator - three products in all, the work of rsvd with two power
+        //  iterations; three on an explicit Gram matrix, where a product is a 12 us kernel and the extra half power that rsvd's
+        //  Q'Z step has over a Rayleigh-Ritz step on G^2 X is cheaper to exceed than to argue about: tools/fuzz_misc.py compares
+        //  with the oracle's rsvd to 1e-5)
+        const int npow_default = op.implicit() ? 2 : 3;
+        const int npow = [npow_default] {
             const char* e = dev_get(DEV_HOOK_POWER);
-            const int v = e ? atoi(e) : 2;
-            return v >= 1 && v <= 6 ? v : 2;
+            const int v = e ? atoi(e) : npow_default;
+            return v >= 1 && v <= 6 ? v : npow_default;
         }();
         const unsigned int seed32 = (unsigned int)(st.hook_seed * 2654435761ull + 77u);
         int64_t carry = dev_is(DEV_HOOK_COLD, '1') ? 0 : std::min<int64_t>(st.hook_carry, p);
