@@ -18,6 +18,7 @@ Beside `value` (all outside the timed region):
   roofline_mfma         the Gram kernel against the fp64 MFMA peak
   cpu_baseline          the oracle (LAPACK gesdd + fused OpenMP sweeps) on this box's host cores, bounded sample (N=1 only)
   extra.c4              BASELINE config 4 (200000x512, the shape of the >= 6x @ 8 GPUs target) on the GPUs of this run
+  extra.c5              BASELINE config 5 (65536x4096 fp32 rank 64, svd = randomized and exact) on one GPU: ms per iteration
   validation            every run checks itself against the CPU ORACLE's run of the same two full-size problems, frozen as data in
                         tests/golden/bench_vectors.json (tests/golden/make_bench_vectors.py: LAPACK gesdd, reference expression
                         order): identical iterations, sv and rank trajectory, cost history to 1e-6, strided samples of A and E
@@ -54,6 +55,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=24, help="ALM iterations of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-c4", action="store_true", help="skip the extra 200000x512 row-sharded measurement (extra.c4)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_with_s / value_host_pointers")
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra 65536x4096 fp32 measurement (extra.c5, one GPU only)")
     ap.add_argument("--timeout", type=float, default=900.0, help="seconds after which the run is declared hung (exit 3)")
     args = ap.parse_args()
 
@@ -249,6 +251,39 @@ def main():
         check["c4"] = check_problem("c4", a4, e4, lo4, hi4, M4, rep4, sv4, rep4h)
         del d4, a4, e4, D4
 
+    # ---- extra.c5: BASELINE config 5 (rpca 65536 x 4096 fp32, rank 64 + 5 % sparse, svd = randomized) on ONE GPU --------------
+    # The panel is generated on the device (same distribution as workloads.synth_lowrank_sparse; 1.07 GB per panel), solved once
+    # for the workspace and twice for the clock, in the reference's hook mode (:195-197) and in the exact mode.
+    c5 = None
+    if not args.no_c5 and headline and world == 1:
+        from tlsq_amd import _lib as L5
+        M5, N5, r5 = 65536, 4096, 64
+        g5 = torch.Generator(device="cuda").manual_seed(5)
+        A05 = (torch.randn(N5, r5, device="cuda", generator=g5) @ torch.randn(r5, M5, device="cuda", generator=g5))   # (N x M row-major = M x N column-major)
+        d5 = A05 + 10.0 * torch.randn(N5, M5, device="cuda", generator=g5) * (torch.rand(N5, M5, device="cuda", generator=g5) < 0.05)
+        a5, e5 = torch.empty_like(d5), torch.empty_like(d5)
+        torch.cuda.synchronize()
+        c5 = {"workload": "rpca 65536x4096 fp32 rank-64 + 5% sparse, one GPU, reference defaults, to convergence", "unit": "ms per iteration"}
+        for tag, kw in (("randomized", dict(svd_mode=L5.SVD_RANDOMIZED)), ("exact", {})):
+            run5 = lambda: eng.rpca_device(d5.data_ptr(), M5, N5, a5.data_ptr(), e5.data_ptr(), want_hist=False, dtype=np.float32, **kw)
+            run5()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            n5 = 0
+            for _ in range(2):
+                sv5, rep5, st5 = run5()
+                n5 += rep5.iters_done
+            torch.cuda.synchronize()
+            t5 = time.perf_counter() - t5
+            err5 = float(torch.linalg.norm(a5 - A05) / torch.linalg.norm(A05))
+            c5[tag] = {"ms_per_iter": t5 / n5 * 1e3, "ms_per_solve": t5 / 2 * 1e3, "iters_per_solve": rep5.iters_done, "sv": int(sv5),
+                       "converged": bool(rep5.converged), "rel_err_A_vs_planted": err5}
+            if not (rep5.converged and int(sv5) == r5 and err5 < 1e-3):
+                problems.append(f"c5 {tag}: converged={rep5.converged} sv={sv5} rel_err_A={err5:.2e}")
+        c5["value"] = c5["randomized"]["ms_per_iter"]
+        del d5, a5, e5, A05
+        torch.cuda.empty_cache()
+
     validation = {"rccl_ranks": rccl_ranks, "reference": os.path.relpath(REF_PATH, ROOT) if ref else None,
                   "reference_kind": "CPU oracle (LAPACK gesdd, reference expression order), frozen by tests/golden/make_bench_vectors.py",
                   "ok": True}
@@ -384,7 +419,7 @@ def main():
             "jacobi_sweeps_per_solve": rep.jacobi_sweeps,
             "svd_step": {"tsqr_route": rep.tsqr_iterations, "subspace": rep.eig_fast, "subspace_steps": rep.subspace_steps},
             "hbm_bytes_per_iter_all_panel_kernels": hbm_total / iters_total,
-            "extra": {"c4": c4},
+            "extra": {"c4": c4, "c5": c5},
         }
         # on-box reference point for a streaming kernel (SURVEY §8d asks for one beside the 8 TB/s vendor figure): a plain
         # torch device-to-device copy of 1 GiB (read + write = 2 GiB moved), best of 5, on torch's stream.  NOT a ceiling:

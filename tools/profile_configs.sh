@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun) from the repo root: rocprofv3 kernel stats of one solve of C3, C4 (one GPU) and C5, and the
 # HBM traffic of their kernels (PMC FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled on gfx950).
-#   bash tools/profile_configs.sh <tag>   -> gpurun_out/<tag>_{c3,c4,c5}_kernel_stats.csv, <tag>_{c3,c4,c5}_pmc_hbm.csv
+#   bash tools/profile_configs.sh <tag>   -> gpurun_out/<tag>_{c3,c4,c5,c5r}_kernel_stats.csv (c5r: svd = randomized), <tag>_{c3,c4,c5}_pmc_hbm.csv
 set -u
 tag=${1:-prof}
 export TMPDIR=/tmp
@@ -22,6 +22,7 @@ pmc() {   # name, program args...
   rm -rf "$out/${tag}_${name}_fetch" "$out/${tag}_${name}_write"
 }
 run c5 $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist
+run c5r $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist --randomized
 run c4 $PWD/tools/large_case.py 200000 512 16 --no-hist
 run c3 $PWD/tools/scale_lowrankfilter.py --no-hist
 pmc c5 $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist

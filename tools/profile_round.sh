@@ -7,7 +7,7 @@ tag=${1:-prof}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 mkdir -p "$out"
-B="python3 $PWD/bench.py --steps 1 --warmup 0 --cpu-iters 0 --no-c4 --no-extras"
+B="python3 $PWD/bench.py --steps 1 --warmup 0 --cpu-iters 0 --no-c4 --no-c5 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- $B > "$out/${tag}_stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/${tag}_fetch" -- $B > "$out/${tag}_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/${tag}_write" -- $B > "$out/${tag}_write.log" 2>&1

@@ -12,9 +12,10 @@
 //
 //   k_absmax_bits   max |z| of the panel as a bit pattern (one atomicMax per workgroup)
 //   k_split_f16     the two fp16 planes H, L (same column-major layout as Z) and the scale
-//   k_gram_h3       lower-triangle 128 x 128 tiles x row splits -> fp64 slabs: 8 waves, wave tile 64 x 32, stages of 32 rows (one
-//                   MFMA step), both planes of both panels through LDS (64-byte columns, row groups swizzled: conflict-free reads),
-//                   global loads four stages ahead in registers (a stage is 24 MFMAs = 0.2 us: the HBM latency spans several)
+//   k_gram_h3       lower-triangle 128 x 128 tiles x row splits -> fp64 slabs: 8 waves, wave tile 64 x 32, stages of 64 rows (two
+//                   MFMA steps; a staged column is one 128-byte line), both planes of both panels through two LDS buffers filled by
+//                   global_load_lds_dwordx4 (no staging registers; row groups swizzled: conflict-free 16-byte fragment reads),
+//                   every fragment set requested two groups of 8 MFMAs before its first use, one barrier per stage
 //   k_h3_reduce     G = c^-2 sum of the slabs, one writer per entry pair (exactly symmetric)
 #include <hip/hip_fp16.h>
 
