@@ -299,6 +299,35 @@ def test_loopback_large_mode_fp32_shards():
     assert relerr(A2.astype(np.float64), A0.astype(np.float64)) < 1e-3
 
 
+def test_loopback_large_fp32_shards_round5_kernels():
+    """The round-5 kernels of BASELINE config 5 on row shards (two ranks, 32768 rows each, 2304 columns, rank 40): the
+    fp16-split Gram kernel on every shard (each with the scale of ITS rows: the all-reduce adds rescaled fp64 matrices), the
+    fp32 factors and the sweep that forms A_k on the MFMA, and - with svd = "randomized" - the block power hook whose products
+    are all-reduced; against the one-GPU solve of the same panel."""
+    import torch  # noqa: F401
+    import tlsq_amd
+    from tlsq_amd import workloads as W
+    M, N, r = 65536, 2304, 40
+    D, A0, _ = W.synth_lowrank_sparse(M, N, r, seed=9)
+    D = D.astype(np.float32)
+    for kw in ({}, {"svd": "randomized"}):
+        plain = tlsq_amd.Engine(0)
+        try:
+            A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, want_s=False, cost_history=False, **kw)
+        finally:
+            plain.close()
+        multi = tlsq_amd.Engine(devices=[0, 0])
+        try:
+            A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, want_s=False, cost_history=False, **kw)
+        finally:
+            multi.close()
+        assert rep1.converged and rep2.converged and sv2 == sv1 == r, kw
+        assert abs(rep2.iters_done - rep1.iters_done) <= 1, kw
+        assert relerr(A2.astype(np.float64), A1.astype(np.float64)) < 1e-4, kw
+        assert relerr(E2.astype(np.float64), E1.astype(np.float64)) < 1e-3, kw
+        assert relerr(A2.astype(np.float64), A0) < 1e-3, kw
+
+
 def test_loopback_hankel_flag_on_row_shards(loopback):
     """rpca(H; hankel=true) and lowrankfilter(...; hankel=true) on row shards: the anti-diagonal means of soft_hankel!
     (src/robustPCA.jl:214-216, 234-236) run through several ranks' row blocks - block sums and counts at the block's
