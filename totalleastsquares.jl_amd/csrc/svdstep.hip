@@ -482,6 +482,21 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
             //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
             const int cold_q = [] { const char* e = dev_get(DEV_COLD_Q); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
             const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
+            // Cold start of a wide block (large mode: 76 columns of length 4096 at BASELINE config 5): the random block is
+            // orthonormalised after its FIRST product as well (round 5) - G X has the condition number of G on the block, its second
+            // product the square of it, which CholeskyQR2 cannot take and the column-sequential CGS2 needs 0.26 ms per 16 columns
+            // for (2.6 ms per cold step at p = 76, four cold rounds while the block grows to the rank).  With the intermediate
+            // pass both orthonormalisations are CholeskyQR2 (~0.3 ms each); a breakdown of the final one repeats the step with
+            // CGS2 as before (a breakdown of the intermediate one leaves G X as it is: the final one then decides).
+            const bool cold_chol = cold && step == 0 && force_cgs2 && !cgs2_sticky && q == 2 && nt == p && (N > 2048 || p > 32) &&
+                                   !dev_is(DEV_COLD_CGS2, '1') && !dev_is(DEV_NO_CHOLQR, '1') &&
+                                   // (the status-guarded finish of the mailbox path leaves X alone when the factorisation breaks down)
+                                   h->mailbox && !dev_is(DEV_NO_MAILBOX, '1') && p <= 512 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
+            if (cold_chol) {
+                bool used0 = false;
+                TLSQ_TRY(launch_orth(h, (double*)Q, (double*)GQ, (double*)H, N, p, lamH_dev + p, true, &used0, false));
+                force_cgs2 = false;
+            }
             // the extra multiplications ping-pong between Q and GQ; an odd count ends in GQ and is copied back
             bool in_q = true;
             for (int t = 1; t < q && nt > 0; ++t) {
