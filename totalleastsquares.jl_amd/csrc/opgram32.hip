@@ -13,14 +13,15 @@
 //                                               covers four 128-byte lines; 10 MFMAs per k-step and wave.
 //   k_zty_f32  slab[z] (N x LW, fp64) = Z[rows z]' T32[rows z]
 //                                               workgroup = 4 waves x 16 panel columns; per chunk of 32 rows the 32 x LW slice
-//                                               of T32 is staged as [column][32 + 4] (conflict-free ds_read_b128); a lane loads
+//                                               of T32 is staged as [column][32 + 4]; a lane loads
 //                                               8 consecutive rows of its panel column (2 x dwordx4) - the contraction index is a
 //                                               label too: MFMA x of a chunk contracts over rows {8 fk + x}; 5 MFMAs per row
 //                                               quad; the rows are split over gridDim / (N / 64) workgroups, slabs reduced in
-//                                               fixed order (k_zt_reduce).
+//                                               fixed order (k_zty_reduce).  (The 36-float pitch was chosen for "lanes 0-15" as a
+//                                               ds_read_b128 group; the real groups - see gram16.hip - leave two 2-way conflicts per group.)
 // fp32 sums are folded into fp64 accumulators after every fourth chunk (128 terms), as in the first form: the result carries the
 // fp32 rounding of X and T32 (6e-8) and ~1e-7 from the sums.  Shapes the fast form does not take (M % 128, N % 64, alignment)
-// run the first form.
+// run the first form (also panels below 64 M entries, where its finer grid wins, and blocks of more than 80 columns).
 #include "common.hpp"
 #include "internal.hpp"
 

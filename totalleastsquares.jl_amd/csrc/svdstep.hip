@@ -336,8 +336,8 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
     if (hook && !dev_is(DEV_HOOK_CLASSIC, '1')) {
         // The randomized hook as a block power method (round 5).  The reference's hook is `svd(Z, sv)` with a user function of
         // the rsvd kind (src/robustPCA.jl:195-197; test/runtests.jl:388-398 uses rank sv, two power iterations): Q = orth((Z Z')^q Z Omega),
-        // then the SVD of Q'Z.  Here on the small side:  X <- orth(G X) `npow` times (default 2), then ONE Rayleigh-Ritz step
-        // H = Q'(G Q): npow + 1 products with the panel pair instead of the five of the two-step form below, one p x p eigenproblem
+        // then the SVD of Q'Z.  Here on the small side:  X <- orth(G X) `npow` times (2 on the panel operator, 3 on an explicit Gram matrix), then ONE Rayleigh-Ritz step
+        // H = Q'(G Q): three products with the panel pair instead of the five of the two-step form below, one p x p eigenproblem
         // instead of two, and CholeskyQR2 (a handful of multi-workgroup launches) for every orthonormalisation: a block is
         // orthonormalised after EACH product, so its condition number is sigma_1^2 / sigma_p^2 of the panel, not the fourth
         // power a random block has after two products (which needed the column-sequential CGS2: six 0.26 ms one-workgroup
