@@ -444,7 +444,7 @@ def main():
         # same command (rocprofv3 --pmc in separate passes, tools/profile_round.sh; a counter pass cannot run inside this
         # process), committed under profiles/
         out["roofline"]["traffic_pmc"] = None
-        for pmc_file in ("r04_pmc_sweeps.json", "r03_pmc_sweeps.json", "r02_pmc_sweeps.json"):
+        for pmc_file in ("r05_pmc_sweeps.json", "r04_pmc_sweeps.json", "r03_pmc_sweeps.json", "r02_pmc_sweeps.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     pmc = json.load(f)
