@@ -116,7 +116,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)
+    X(OPGRAM_OLD) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -303,6 +303,9 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
 bool wide_factors_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t r);
 int wide_factors_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* Vg, const double* Vs,
                      int64_t r, double* Tm, const float** T32_out, const float** Vs32_out, int* lw_out);
+int wide_factors_from_zq(Handle* h, const float* ZQ, int64_t M, int64_t N, int64_t p, const double* S_dev, const int32_t* cols_dev,
+                         const double* g_dev, const double* Vs, int64_t r, double* Tm, const float** T32_out,
+                         const float** Vs32_out, int* lw_out);
 bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r);
 int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt, const float* Vs32, int64_t r, const float* Yin,
                        float* Yout, float* Z, float* Zout, float* R, int64_t M, int64_t N, float mu, float inv_mu, int nonnegA,

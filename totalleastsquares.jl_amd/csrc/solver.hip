@@ -759,6 +759,12 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
     SubspaceState sub;
     int64_t hook_cols = 0;   // columns of the block buffer (WS_SX) holding the last decomposition's sorted Ritz vectors: the hook's warm start
+    // (the hook's Rayleigh-Ritz product Z Q and eigenvector matrix of this iteration, when they are still on the device: the
+    //  factor of the rebuild is taken from them - SubspaceState::hook_zq)
+    const float* hook_zq = nullptr;
+    int64_t hook_zq_p = 0;
+    const double* hook_S = nullptr;
+    std::vector<int32_t> hook_order;
     const int64_t pmax = subspace_max_block(N);
     const char* force_full = dev_get(DEV_FULL_EIG);
     // Large mode (N > 2048): the full Jacobi solvers do not apply (their column blocks live in LDS); every SVD step
@@ -1237,12 +1243,37 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)svp * 16, &auxp));
                     TLSQ_TRY(gather_scale_host(h, V, N, sel, g, auxp, (double*)Vgp, (double*)Vsp));
                     int lw = 0;
-                    TLSQ_TRY(wide_factors_f32(h, (const float*)Z, M, M, N, (const double*)Vgp, (const double*)Vsp, svp, (double*)T1,
-                                              &wide_T32, &wide_Vs32, &lw));
+                    bool from_zq = false;
+                    if (hook_zq && hook_zq == (const float*)h->ws[WS_OPT].p && (int64_t)hook_order.size() == hook_zq_p &&
+                        !dev_is(DEV_NO_HOOK_ZQ, '1')) {
+                        // Z X[:, sel] diag(g) = (Z Q) S[:, order[sel]] diag(g): the product Z Q of the hook's Rayleigh-Ritz step is
+                        // still in WS_OPT (nothing has run an operator product since) - no pass over the panel
+                        std::vector<int32_t> cols((size_t)svp);
+                        bool okc = true;
+                        for (int64_t j = 0; j < svp; ++j) {
+                            okc = okc && sel[(size_t)j] >= 0 && sel[(size_t)j] < hook_zq_p;
+                            cols[(size_t)j] = okc ? hook_order[(size_t)sel[(size_t)j]] : 0;
+                        }
+                        if (okc) {
+                            void* aux2;
+                            TLSQ_TRY(ws_get(h, WS_AUX1, (size_t)svp * 16 + 64, &aux2));
+                            double* g_dev = (double*)aux2;
+                            int32_t* c_dev = (int32_t*)((char*)aux2 + (size_t)svp * 8);
+                            TLSQ_TRY(upload_async(h, g_dev, g.data(), (size_t)svp * 8));
+                            TLSQ_TRY(upload_async(h, c_dev, cols.data(), (size_t)svp * 4));
+                            TLSQ_TRY(wide_factors_from_zq(h, hook_zq, M, N, hook_zq_p, hook_S, c_dev, g_dev, (const double*)Vsp, svp,
+                                                          (double*)T1, &wide_T32, &wide_Vs32, &lw));
+                            from_zq = true;
+                        }
+                    }
+                    hook_zq = nullptr;
+                    if (!from_zq)
+                        TLSQ_TRY(wide_factors_f32(h, (const float*)Z, M, M, N, (const double*)Vgp, (const double*)Vsp, svp, (double*)T1,
+                                                  &wide_T32, &wide_Vs32, &lw));
                     Tm_last = (const double*)T1;
                     Vs_last = (const double*)Vsp;
                     r_last = svp;
-                    hbm_other += panel_bytes;
+                    if (!from_zq) hbm_other += panel_bytes;
                     wide_sweep = true;
                     fuse_rebuild = true;
                     a_pending = true;
@@ -1372,9 +1403,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             rs.hook_seed = seed + (uint64_t)k;
             rs.hook_carry = hook_cols;     // the previous iteration's sorted Ritz block, when it is still in the block buffer
             hook_cols = 0;
+            hook_zq = nullptr;
             TLSQ_TRY(svd_subspace(h, op, N, inv_mu, rs, &V, s, &sweeps, &fast_ok));
             sub.steps += rs.steps;
             if (fast_ok) hook_cols = rs.hook_carry;
+            hook_zq = fast_ok ? rs.hook_zq : nullptr;
+            hook_zq_p = rs.p;
+            hook_S = rs.hook_S;
+            hook_order = rs.hook_order;
         } else if (bulk_tail && !large) {
             sub.fail = SubspaceState::FAIL_NONE;   // straight to the dense tier below
         } else if (noise_limited) {

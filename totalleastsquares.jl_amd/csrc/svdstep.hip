@@ -425,6 +425,14 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         for (int64_t i = 0; i < p; ++i) s.sigma[(size_t)i] = std::sqrt(std::max(host[(size_t)i], 0.0));
         s.ncols = p;
         sort_desc(s);
+        st.hook_zq = nullptr;
+        if (op.implicit() && op.z_f32 && op.lowp_ok && p > 8 && p <= 80 && !dev_is(DEV_NO_F32_SKINNY, '1') &&
+            !dev_is(DEV_OPGRAM_OLD, '1') && op_gram_f32_fast_ok((const float*)op.Z, op.ldZ, op.M, N, p) && op.ldZ == op.M) {
+            st.hook_zq = (const float*)h->ws[WS_OPT].p;   // (the T32 of the last op_apply: Z Qf, 16 ceil(p / 16) columns)
+            st.hook_zq_lw = 16 * (int)((p + 15) / 16);
+            st.hook_S = (const double*)S;
+            st.hook_order = s.order;
+        }
         bool sorted = true;
         for (int64_t i = 0; i < p; ++i) sorted = sorted && s.order[(size_t)i] == (int32_t)i;
         if (!sorted) {

@@ -34,6 +34,14 @@ struct SubspaceState {
     // (in) leading columns of the block buffer (WS_SX) that still hold the sorted Ritz vectors of the previous iteration's
     // decomposition: the hook starts from them instead of a fresh random block; (out) the columns this call left there
     int64_t hook_carry = 0;
+    // (out, sketch on an fp32 panel) the product Z Q of the hook's Rayleigh-Ritz step (fp32, rows x hook_zq_lw, ld = rows, in
+    // WS_OPT until the next operator product), the eigenvector matrix S of Q'GQ on the device (p x p, WS_SS) and the order in
+    // which its columns were sorted: the caller forms the factor Z X[:, sel] = (Z Q) S[:, order[sel]] from them instead of a pass
+    // over the panel.  hook_zq == nullptr: not available.
+    const float* hook_zq = nullptr;
+    int hook_zq_lw = 0;
+    const double* hook_S = nullptr;
+    std::vector<int32_t> hook_order;
     int64_t fast = 0, full = 0, steps = 0;
     // why the last call gave up (0 = it did not): the caller may enlarge the block and try again
     enum { FAIL_NONE = 0, FAIL_SMALL = 1, FAIL_NOCONV = 2, FAIL_CERT = 3, FAIL_NUMERIC = 4, FAIL_WINDOW = 5 };
