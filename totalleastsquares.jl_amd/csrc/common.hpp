@@ -48,6 +48,9 @@ struct Handle {
     double mail_seq = 0.0;
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     int64_t gram_tab2_nti = 0;
+    // max |z| of an fp32 panel as a bit pattern, left by the kernel that wrote it (k_zsweep_wide) for the split Gram kernel that
+    // reads it next (gram16.hip): absmax_panel == the panel it describes, nullptr = none.  The word lives in WS_H16S + 40.
+    const void* absmax_panel = nullptr;
     bool gram_tab3_ready = false;      // the four-tile list of gram_offdiag_plan is on the device
     int64_t gram_tab_nti = 0;          // tile-order table in WS_GRAMTAB is the one for this many tile rows
     bool cert_ticket_ready = false;    // ... and the one of k_sq_norm
@@ -309,7 +312,8 @@ int wide_factors_from_zq(Handle* h, const float* ZQ, int64_t M, int64_t N, int64
 bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r);
 int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt, const float* Vs32, int64_t r, const float* Yin,
                        float* Yout, float* Z, float* Zout, float* R, int64_t M, int64_t N, float mu, float inv_mu, int nonnegA,
-                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot);
+                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot,
+                       bool leave_absmax = false);   // leave_absmax: max |Z_{k+1}| for the next split Gram (Handle::absmax_panel)
 int op_gram_f32_fast(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const float* wt, float* t32, double* Y,
                      int64_t ldy, int64_t p);
 // the Gram of a K-contiguous operand as plan / per-chunk launch / reduction (gemm.hip)

@@ -124,6 +124,7 @@ int ws_poison_all(Handle* h) {
     h->cert_ticket_ready = false;
     h->gram_tab_nti = 0;
     h->gram_tab2_nti = 0;
+    h->absmax_panel = nullptr;
     h->gram_tab3_ready = false;
     h->warm_n = 0;
     if (h->mailbox)

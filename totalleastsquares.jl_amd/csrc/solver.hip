@@ -1394,6 +1394,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             op.G = G;
         }
         g_ready = false;
+        h->absmax_panel = nullptr;   // (a max |Z| left by the previous sweep described THIS Z: whatever needed it has been queued)
         pt.mark(gram_queued_earlier);
         if (G) dbg_hash(h, "G", G, (size_t)N * N * 8, k);
         if (hook_now) {
@@ -1747,7 +1748,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(launch_zsweep_wide(h, (const float*)D, wide_T32, M, wide_Vs32, svp, (const float*)Ybuf[ycur], (float*)Ybuf[ycur ^ 1],
                                             (float*)Zbuf[zc], (float*)Zbuf[zc ^ 1], (float*)Rst, M, N, (float)mu, (float)inv_mu,
                                             ro.nonnegA ? 1 : 0, (float)(1.0 / mu_next), (float)(lam / mu_next), ro.nonnegE ? 1 : 0,
-                                            sumsq_dev, sumsq_next, maxslot));
+                                            sumsq_dev, sumsq_next, maxslot, true));
             }
             z_swept = true;
             hbm_sweeps += (Rst ? 6.0 : 5.0) * panel_bytes;

@@ -511,10 +511,12 @@ __global__ __launch_bounds__(256, 3) void k_zsweep_wide(const float* __restrict_
                                                         float* __restrict__ Yout, const float* __restrict__ Z, float* __restrict__ Zo,
                                                         float* __restrict__ R, int64_t M, int N, int64_t rows_per_chunk, float mu,
                                                         float inv_mu, int nonnegA, float inv_mu_n, float thr_n, int nonnegE,
-                                                        double* __restrict__ sumsq, double* __restrict__ zero_slots, int maxslot) {
+                                                        double* __restrict__ sumsq, double* __restrict__ zero_slots, int maxslot,
+                                                        unsigned int* __restrict__ zmax_bits) {
     if (zero_slots && blockIdx.x == 0 && threadIdx.x < 72) zero_slots[threadIdx.x] = 0.0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int jl = lane & 31, kh = lane >> 5;
+    unsigned int zmax = 0;   // max |Z_{k+1}| as a bit pattern (the scale of the split Gram kernel that reads the panel next)
     const int nsg = N / 128;
     const int64_t chunk = blockIdx.x / nsg;
     const int n0 = ((int)(blockIdx.x % nsg) * 4 + w) * 32;
@@ -575,9 +577,19 @@ __global__ __launch_bounds__(256, 3) void k_zsweep_wide(const float* __restrict_
             if (HASR) zw_st<2>(res, rR, vo, so);
             zw_st<2>(y1, rYo, vo, so);
             zw_st<2>(zn, rZo, vo, so);
+            const unsigned int zb = __float_as_uint(zn) & 0x7FFFFFFFu;
+            zmax = zb > zmax ? zb : zmax;
         }
         ss += (double)s32;
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (zmax_bits) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned int o = (unsigned int)__shfl_xor((int)zmax, off, 64);
+            zmax = o > zmax ? o : zmax;
+        }
+        if (lane == 0 && zmax) atomicMax(zmax_bits, zmax);
     }
     if (sumsq) {
 #pragma unroll
@@ -613,8 +625,16 @@ bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r) {
 // T32: M x 2 KH (ld ldt) and Vs32: N x 2 KH (ld N), KH = 32 for r <= 64 and 40 for r <= 80, columns r.. zero
 int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt, const float* Vs32, int64_t r, const float* Yin,
                        float* Yout, float* Z, float* Zout, float* R, int64_t M, int64_t N, float mu, float inv_mu, int nonnegA,
-                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot) {
+                       float inv_mu_n, float thr_n, int nonnegE, double* sumsq, double* zero_slots, int maxslot, bool leave_absmax) {
     if (!zsweep_wide_ok(M, N, r)) return set_err(h, TLSQ_ERR_ARG, "zsweep_wide: shape");
+    unsigned int* zmax_bits = nullptr;
+    h->absmax_panel = nullptr;
+    if (leave_absmax) {
+        void* sc;
+        TLSQ_TRY(ws_get(h, WS_H16S, 64, &sc));
+        zmax_bits = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(sc) + 40);
+        TLSQ_HIP(h, hipMemsetAsync(zmax_bits, 0, 4, h->stream));
+    }
     if (!Zout) Zout = Z;
     if (!sumsq || maxslot > 7) maxslot = -1;
     const bool zip = Zout == Z;
@@ -628,7 +648,7 @@ int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt,
     const dim3 grid((unsigned)(nchunks * (N / 128)));
 #define ZW_LAUNCH(KHV, ZP, HR)                                                                                              \
     hipLaunchKernelGGL((k_zsweep_wide<KHV, ZP, HR>), grid, dim3(256), 0, h->stream, D, T32, ldt, Vs32, Yin, Yout, Zr, Zout, R, M, \
-                       (int)N, rpc, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot)
+                       (int)N, rpc, mu, inv_mu, nonnegA, inv_mu_n, thr_n, nonnegE, sumsq, zero_slots, maxslot, zmax_bits)
 #define ZW_PICK(KHV)                          \
     do {                                      \
         if (zip) {                            \
@@ -644,6 +664,7 @@ int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt,
 #undef ZW_PICK
 #undef ZW_LAUNCH
     TLSQ_HIP(h, hipGetLastError());
+    if (leave_absmax) h->absmax_panel = Zout;
     return TLSQ_OK;
 }
 
