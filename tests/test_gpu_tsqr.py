@@ -165,3 +165,17 @@ def test_operator_product_on_the_fp32_mfma(eng, torch_mod, M, N, p):
     scale = np.linalg.norm(Zd, 2) ** 2 * np.linalg.norm(X, axis=0)
     assert np.isfinite(Y).all()
     assert (np.linalg.norm(Y - ref, axis=0) / scale).max() < 2e-6
+    if M * N >= 1 << 26:
+        # third form (opgram16.hip): every operand split in registers into two fp16 numbers, products on the fp16 MFMA - what the
+        # randomized hook runs when the sweep has left the panel's maximum; here forced, with a pass for the maximum.  22 bits
+        # of every operand: a few 1e-9 of the same scale, and the same T32 = Z X panel to the fp32 rounding
+        import tlsq_amd
+        dY3 = torch.full((p, N), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        with tlsq_amd.dev_switches(OPGRAM_H3=2):
+            assert eng.lib.tlsq_k_op_gram_f32(eng.h, dZ.data_ptr(), M, N, M, dX.data_ptr(), p, dY3.data_ptr()) == 0, \
+                eng.lib.tlsq_last_error(eng.h)
+        eng.synchronize()
+        Y3 = dY3.cpu().numpy().T
+        assert np.isfinite(Y3).all()
+        assert (np.linalg.norm(Y3 - ref, axis=0) / scale).max() < 1e-7

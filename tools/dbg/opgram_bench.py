@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import tlsq_amd
+tlsq_amd.dev_from_env()
 
 M, N, p = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (65536, 4096, 74)
 g = torch.Generator(device="cuda").manual_seed(1)

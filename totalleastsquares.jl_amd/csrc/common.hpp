@@ -119,7 +119,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)
+    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -147,7 +147,7 @@ enum WsSlot {
     WS_LAM, WS_AUX0, WS_AUX1, WS_AUX2, WS_AUX3, WS_AUX4,
     WS_SX, WS_SQ, WS_SGQ, WS_SXN, WS_SGX, WS_SH, WS_SS, WS_SHB, WS_GD,   // subspace iteration panels
     WS_DT, WS_AT, WS_ET, WS_UT,
-    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW, WS_T32, WS_VS32, WS_H16, WS_L16, WS_H16S,
+    WS_V2, WS_VC, WS_E2, WS_Z2, WS_BATCH0, WS_BATCH1, WS_BATCH2, WS_BATCH3, WS_BATCH4, WS_G2, WS_LZOP, WS_OPT, WS_OPW, WS_T32, WS_VS32, WS_H16, WS_L16, WS_H16S, WS_OPSC,
     WS_PW,   // persistent power-iteration vector of the cost evaluation
     WS_GRAMTAB,   // tile order of the Gram kernel (gemm.hip, gram_kc)
     WS_GRAMTAB2,  // ... of the fp32-MFMA Gram kernel (diagonal tiles included)
@@ -298,6 +298,11 @@ int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
                 int64_t ldy, int64_t p);
 // ... its second form (opgram32.hip: the block through LDS, the panel straight into the MFMA fragments) for aligned shapes
 bool op_gram_f32_fast_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int64_t p);
+// ... its third form (opgram16.hip): every operand split in registers into two fp16 numbers, products on the fp16 MFMA - when the
+// panel's maximum is known (zmax_bits: device word holding the float bits of max |Z|)
+int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, float* t32, double* Y,
+                   int64_t ldy, int64_t p, const unsigned int* zmax_bits);
+int absmax_bits_f32(Handle* h, const float* Z, int64_t n, unsigned int* out_bits);   // (gram16.hip: max |z| as float bits)
 // G = Z'Z of an fp32 panel on the fp16 MFMA at fp32 accuracy (two fp16 planes, three products; gram16.hip)
 int gram_tile_table(Handle* h, int64_t nti, const int32_t** tab_out);   // (gemm.hip)
 bool gram_h3_ok(const float* Z, int64_t ld, int64_t N, int64_t K);

@@ -1313,8 +1313,22 @@ int op_gram_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
     TLSQ_TRY(ws_get(h, WS_OPT, (size_t)M * 128 * 4 + 256, &t32));
     hipLaunchKernelGGL(k_pack_w_f32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, X, ldx,
                        (int)N, (int)p, lw, (float*)wt);
-    if (op_gram_f32_fast_ok(Z, ldz, M, N, p) && !dev_is(DEV_OPGRAM_OLD, '1'))
+    if (op_gram_f32_fast_ok(Z, ldz, M, N, p) && !dev_is(DEV_OPGRAM_OLD, '1')) {
+        // third form (opgram16.hip: fp16 MFMA on operands split in registers) when the sweep that wrote the panel left its maximum
+        // (Handle::absmax_panel); OPGRAM_H3=0: never, =2: always, with a pass for the maximum (tests)
+        const bool force_h3 = dev_is(DEV_OPGRAM_H3, '2');
+        if (ldz == M && !dev_is(DEV_OPGRAM_H3, '0') && (h->absmax_panel == (const void*)Z || force_h3)) {
+            void* sc;
+            TLSQ_TRY(ws_get(h, WS_H16S, 64, &sc));
+            unsigned int* zmax = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(sc) + 40);
+            if (h->absmax_panel != (const void*)Z) {
+                zmax = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(sc) + 48);
+                TLSQ_TRY(absmax_bits_f32(h, Z, M * N, zmax));
+            }
+            return op_gram_f32_h3(h, Z, ldz, M, N, X, ldx, (float*)t32, Y, ldy, p, zmax);
+        }
         return op_gram_f32_fast(h, Z, ldz, M, N, (const float*)wt, (float*)t32, Y, ldy, p);
+    }
     {
         const dim3 grid((unsigned)((M + 31) / 32));
 #define TSF_LAUNCH(NC)                                                                                              \

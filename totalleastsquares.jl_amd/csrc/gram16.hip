@@ -264,6 +264,13 @@ __global__ __launch_bounds__(256) void k_h3_reduce(const double* __restrict__ sl
 }
 }   // namespace
 
+int absmax_bits_f32(Handle* h, const float* Z, int64_t n, unsigned int* out_bits) {
+    TLSQ_HIP(h, hipMemsetAsync(out_bits, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_absmax_bits, dim3(2048), dim3(256), 0, h->stream, Z, n, out_bits);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 bool gram_h3_ok(const float* Z, int64_t ld, int64_t N, int64_t K) {
     return N >= 1024 && (N % HT) == 0 && (K % HK) == 0 && K >= 4096 && ld == K && (reinterpret_cast<uintptr_t>(Z) % 16) == 0 &&
            N <= 16384;
@@ -283,7 +290,7 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
         TLSQ_HIP(h, hipMemsetAsync(maxbits, 0, 4, h->stream));
         hipLaunchKernelGGL(k_absmax_bits, dim3(2048), dim3(256), 0, h->stream, Z, n, maxbits);
     }
-    h->absmax_panel = nullptr;
+
     hipLaunchKernelGGL(k_split_f16, dim3(4096), dim3(256), 0, h->stream, Z, n, (const unsigned int*)maxbits, (_Float16*)hp,
                        (_Float16*)lp, (double*)sc);
     TLSQ_HIP(h, hipGetLastError());

@@ -555,6 +555,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         return TLSQ_OK;
     };
     h->out_factors = false;
+    h->absmax_panel = nullptr;   // (no panel of this call has been written yet)
     if (!(zmode && ro.factors_out)) TLSQ_TRY(need_A());
     // classic loop: E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
     // must survive in case iteration k is the last one
@@ -1394,7 +1395,6 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             op.G = G;
         }
         g_ready = false;
-        h->absmax_panel = nullptr;   // (a max |Z| left by the previous sweep described THIS Z: whatever needed it has been queued)
         pt.mark(gram_queued_earlier);
         if (G) dbg_hash(h, "G", G, (size_t)N * N * 8, k);
         if (hook_now) {
@@ -1724,6 +1724,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                                                    ro.nonnegE ? 1 : 0, sumsq_dev, sumsq_next, (const T*)ro.hankel_y,
                                                    ro.hankel_K, r0, r1, pad_lds, ro.hankel_geom);
         };
+        // (a max |Z| left by the previous sweep - Handle::absmax_panel - described the Z_k of this iteration's SVD step: whatever
+        //  needed it has been queued, and the panel is about to be rewritten)
+        h->absmax_panel = nullptr;
         if (zmode && !fuse) {
             // the last allowed iteration (no next shrink to fuse with): E_k is formed now, then the plain residual :217-221
             if (prev_no_factors) {   // A_{k-1} has no factor form: E_k = D - Z_k + Y_k / mu_k (:192)
