@@ -2040,6 +2040,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
     }
     if (k > ro.iters) k = ro.iters;
+    h->absmax_panel = nullptr;   // (what follows may rewrite Z: the maximum a sweep left for it does not describe it any more)
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     if (dev_get(DEV_DEBUG)) fprintf(stderr, "  speculative factor products used: %lld of %lld iterations\n", (long long)n_spec_hits, (long long)k);
     pt.finish(acc);
