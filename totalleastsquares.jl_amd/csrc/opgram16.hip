@@ -227,19 +227,22 @@ __global__ __launch_bounds__(256, 2) void k_zx_h(const float* __restrict__ Z, in
 
 constexpr int QZ_WAVES = 4;
 constexpr int QZ_COLS = 16 * QZ_WAVES;
+constexpr int QZK = 64;       // rows per stage of k_zty_h: two MFMA steps per barrier (one step per barrier: 0.30 ms, barrier-paced)
+constexpr int QZRING = 2;     // stages of panel fragments in flight
 // slab[z] (N x LW fp64, [n LW + j]) = Z[rows z]' T32[rows z]
 template <int NCT>
-__global__ __launch_bounds__(64 * QZ_WAVES, 3) void k_zty_h(const float* __restrict__ Z, int64_t ldz, const float* __restrict__ T32,
+__global__ __launch_bounds__(64 * QZ_WAVES, 2) void k_zty_h(const float* __restrict__ Z, int64_t ldz, const float* __restrict__ T32,
                                                             int64_t ldt, double* __restrict__ slab, int64_t N, int64_t K,
                                                             int64_t kchunk, int64_t slab_stride, int ntiles, int nsplit,
                                                             const unsigned int* __restrict__ zmax,
                                                             const unsigned int* __restrict__ tmax) {
     constexpr int NT = 64 * QZ_WAVES;
     constexpr int LW = 16 * NCT;
-    constexpr int CH = LW * 32;               // halfs per plane and chunk
-    constexpr int NV = LW * 8;                // float4 of T32 per chunk
+    constexpr int CH = LW * 32;               // halfs per plane and MFMA step
+    constexpr int SB = 4 * CH;                // halfs per stage buffer: step 0 (hi, lo), step 1 (hi, lo)
+    constexpr int NV = LW * 16;               // float4 of T32 per stage
     constexpr int SL = (NV + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) _Float16 sT[QRING * 2 * CH];
+    __shared__ __attribute__((aligned(16))) _Float16 sT[2 * SB];
     const int64_t nwork = (int64_t)ntiles * nsplit;
     const int64_t cpx = (nwork + 7) / 8;
     const int64_t item = (int64_t)(blockIdx.x % 8) * cpx + (int64_t)(blockIdx.x / 8);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * QZ_WAVES, 3) void k_zty_h(const float* __restr
     const int fr = lane & 15, kg = lane >> 4;
     const int64_t kbeg = (int64_t)z * kchunk;
     const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    const int nch = (int)((kend - kbeg) / QK);
+    const int nst = (int)((kend - kbeg) / QZK);
     const int64_t n0 = (int64_t)ti * QZ_COLS + 16 * w;
     const bool active = n0 < N;
     const float cz = q_scale(*zmax, 13), ct = q_scale(*tmax, 13);
@@ -263,23 +266,23 @@ __global__ __launch_bounds__(64 * QZ_WAVES, 3) void k_zty_h(const float* __restr
         acc64[c] = qd4{0.0, 0.0, 0.0, 0.0};
     }
     qf4 treg[SL];
-    qf4 a[QRING][2];
-    auto load_t = [&](int ch) {
+    qf4 a[QZRING + 1][4];
+    auto load_t = [&](int st) {
 #pragma unroll
         for (int i = 0; i < SL; ++i) {
             int e = tid + NT * i;
             if (SL * NT != NV && e >= NV) e = tid;
-            const int j = e >> 3, q = e & 7;
-            treg[i] = *reinterpret_cast<const qf4*>(T32 + kbeg + (int64_t)ch * QK + 4 * q + (int64_t)j * ldt);
+            const int j = e >> 4, q = e & 15;
+            treg[i] = *reinterpret_cast<const qf4*>(T32 + kbeg + (int64_t)st * QZK + 4 * q + (int64_t)j * ldt);
         }
     };
-    // (rows 4 q .. 4 q + 3 of column j: the half of row group q / 2 at offset 4 (q & 1), both planes)
+    // (rows 4 q .. 4 q + 3 of column j, q < 16: MFMA step q / 8, row group (q % 8) / 2, offset 4 (q & 1); both planes)
     auto store_t = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < SL; ++i) {
             int e = tid + NT * i;
             if (SL * NT != NV && e >= NV) e = tid;
-            const int j = e >> 3, q = e & 7;
+            const int j = e >> 4, q = e & 15;
             qh4 hh, ll;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -288,15 +291,17 @@ __global__ __launch_bounds__(64 * QZ_WAVES, 3) void k_zty_h(const float* __restr
                 hh[k] = hv;
                 ll[k] = lv;
             }
-            _Float16* d = sT + buf * 2 * CH + j * 32 + 8 * ((q >> 1) ^ q_sw(j)) + 4 * (q & 1);
+            _Float16* d = sT + buf * SB + (q >> 3) * 2 * CH + j * 32 + 8 * (((q & 7) >> 1) ^ q_sw(j)) + 4 * (q & 1);
             *reinterpret_cast<qh4*>(d) = hh;
             *reinterpret_cast<qh4*>(d + CH) = ll;
         }
     };
-    auto load_a = [&](qf4* av, int ch) {
-        const qf4* p = reinterpret_cast<const qf4*>(za + (int64_t)ch * QK);
-        av[0] = p[0];
-        av[1] = p[1];
+    auto load_a = [&](qf4* av, int st) {
+        const float* p = za + (int64_t)st * QZK;
+        av[0] = *reinterpret_cast<const qf4*>(p);
+        av[1] = *reinterpret_cast<const qf4*>(p + 4);
+        av[2] = *reinterpret_cast<const qf4*>(p + 32);
+        av[3] = *reinterpret_cast<const qf4*>(p + 36);
     };
     auto fold = [&]() {
 #pragma unroll
@@ -306,54 +311,65 @@ __global__ __launch_bounds__(64 * QZ_WAVES, 3) void k_zty_h(const float* __restr
             acc[c] = qf4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    const int last = nch - 1;
-    auto clampc = [&](int ch) { return ch < last ? ch : last; };
+    const int last = nst - 1;
+    auto clamps = [&](int st) { return st < last ? st : last; };
     const int ob = fr * 32 + 8 * (kg ^ q_sw(fr));
-    auto step = [&](auto uc, int ch) {
+    // stage st: planes in LDS buffer st & 1; the fragments of ring slot u (= st % 3) were requested three stages ago
+    auto stage = [&](auto uc, auto bc, int st) {
         constexpr int u = decltype(uc)::value;
-        qh8 ah, al;   // rows 8 kg .. 8 kg + 7 of the chunk, this lane's panel column
+        constexpr int bsel = decltype(bc)::value;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            _Float16 hv, lv;
-            q_split(a[u][q >> 2][q & 3] * cz, hv, lv);
-            ah[q] = hv;
-            al[q] = lv;
-        }
-        const _Float16* sh = sT + u * 2 * CH + ob;
+        for (int ks = 0; ks < 2; ++ks) {
+            qh8 ah, al;   // rows 32 ks + 8 kg .. + 7 of the stage, this lane's panel column
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const qh8 bh = *reinterpret_cast<const qh8*>(sh + (16 * c) * 32);
-            const qh8 bl = *reinterpret_cast<const qh8*>(sh + CH + (16 * c) * 32);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                _Float16 hv, lv;
+                q_split(a[u][2 * ks + (q >> 2)][q & 3] * cz, hv, lv);
+                ah[q] = hv;
+                al[q] = lv;
+            }
+            const _Float16* sh = sT + bsel * SB + ks * 2 * CH + ob;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const qh8 bh = *reinterpret_cast<const qh8*>(sh + (16 * c) * 32);
+                const qh8 bl = *reinterpret_cast<const qh8*>(sh + CH + (16 * c) * 32);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
+            }
         }
-        if ((ch % QFOLD) == QFOLD - 1) fold();
+        if ((st & 1) == 1) fold();                 // every 128 rows
         __builtin_amdgcn_sched_barrier(0);
-        store_t((u + 1) % QRING);
+        store_t(bsel ^ 1);
         __syncthreads();
-        load_t(clampc(ch + 2));
-        load_a(a[u], clampc(ch + QRING));
+        load_t(clamps(st + 2));
+        load_a(a[u], clamps(st + 3));
         __builtin_amdgcn_sched_barrier(0);
     };
     load_t(0);
     load_a(a[0], 0);
-    load_a(a[1], clampc(1));
-    load_a(a[2], clampc(2));
+    load_a(a[1], clamps(1));
+    load_a(a[2], clamps(2));
     store_t(0);
     __syncthreads();
-    load_t(clampc(1));
-    std::integral_constant<int, 0> U0;
-    std::integral_constant<int, 1> U1;
-    std::integral_constant<int, 2> U2;
-    int ch = 0;
-    for (; ch + QRING <= nch; ch += QRING) {
-        step(U0, ch);
-        step(U1, ch + 1);
-        step(U2, ch + 2);
+    load_t(clamps(1));
+    std::integral_constant<int, 0> I0;
+    std::integral_constant<int, 1> I1;
+    std::integral_constant<int, 2> I2;
+    int st = 0;
+    for (; st + 6 <= nst; st += 6) {               // (ring of three fragment slots x two LDS buffers: period six)
+        stage(I0, I0, st);
+        stage(I1, I1, st + 1);
+        stage(I2, I0, st + 2);
+        stage(I0, I1, st + 3);
+        stage(I1, I0, st + 4);
+        stage(I2, I1, st + 5);
     }
-    if (ch < nch) step(U0, ch);
-    if (ch + 1 < nch) step(U1, ch + 1);
+    if (st < nst) stage(I0, I0, st);
+    if (st + 1 < nst) stage(I1, I1, st + 1);
+    if (st + 2 < nst) stage(I2, I0, st + 2);
+    if (st + 3 < nst) stage(I0, I1, st + 3);
+    if (st + 4 < nst) stage(I1, I0, st + 4);
     fold();
     if (!active) return;
     double* out = slab + (int64_t)z * slab_stride;
@@ -408,9 +424,9 @@ int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N,
     TLSQ_HIP(h, hipGetLastError());
     const int64_t ntiles = (N + QZ_COLS - 1) / QZ_COLS;
     int64_t nsplit = std::max<int64_t>(1, (1024 + ntiles - 1) / ntiles);
-    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, M / (4 * QK)));
+    nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, M / (4 * QZK)));
     int64_t kchunk = (M + nsplit - 1) / nsplit;
-    kchunk = (kchunk + QK - 1) / QK * QK;
+    kchunk = (kchunk + QZK - 1) / QZK * QZK;
     nsplit = (M + kchunk - 1) / kchunk;
     const int64_t slab_stride = N * lw;
     void* slab;
