@@ -138,3 +138,34 @@ def test_concurrent_handles_on_host_threads():
         assert a[4].iters_done == b[4].iters_done and a[4].svp_hist == b[4].svp_hist
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("mode", ["randomized", "exact"])
+def test_large_fp32_paths_are_bit_identical(mode):
+    """The round-5 kernels of large fp32 panels (fp16-split Gram, A_k inside the sweep, the block power hook and its
+    fp16-split operator products with the scale hints travelling between kernels through atomicMax words): four solves - two
+    on one handle, two on a fresh one - of a 16384 x 4096 rank-64 panel return the same bits."""
+    import torch
+    import tlsq_amd
+    from tlsq_amd import _lib as L
+    M, N, r = 16384, 4096, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A0 = torch.randn(N, r, device="cuda", generator=g) @ torch.randn(r, M, device="cuda", generator=g)
+    D = (A0 + 10.0 * torch.randn(N, M, device="cuda", generator=g) * (torch.rand(N, M, device="cuda", generator=g) < 0.05)).contiguous()
+    torch.cuda.synchronize()
+    kw = dict(svd_mode=L.SVD_RANDOMIZED) if mode == "randomized" else {}
+    outs = []
+    for _ in range(2):
+        eng = tlsq_amd.Engine(0)
+        try:
+            for _ in range(2):
+                A, E = torch.empty_like(D), torch.empty_like(D)
+                sv, info, st = eng.rpca_device(D.data_ptr(), M, N, A.data_ptr(), E.data_ptr(), want_hist=False, dtype=np.float32, **kw)
+                torch.cuda.synchronize()
+                outs.append((A, E, info.iters_done, int(sv), bool(info.converged)))
+        finally:
+            eng.close()
+    assert outs[0][4] and outs[0][3] == r
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and outs[0][2:] == o[2:]
+    assert float(torch.linalg.norm(outs[0][0] - A0) / torch.linalg.norm(A0)) < 1e-3
