@@ -302,6 +302,8 @@ bool op_gram_f32_fast_ok(const float* Z, int64_t ldz, int64_t M, int64_t N, int6
 // panel's maximum is known (zmax_bits: device word holding the float bits of max |Z|)
 int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, float* t32, double* Y,
                    int64_t ldy, int64_t p, const unsigned int* zmax_bits);
+int tsmm_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, int64_t p, int lw,
+                float* t32, const unsigned int* zmax_bits, unsigned int** tmax_out);   // (its first half alone: T32 = Z X)
 int absmax_bits_f32(Handle* h, const float* Z, int64_t n, unsigned int* out_bits);   // (gram16.hip: max |z| as float bits)
 // G = Z'Z of an fp32 panel on the fp16 MFMA at fp32 accuracy (two fp16 planes, three products; gram16.hip)
 int gram_tile_table(Handle* h, int64_t nti, const int32_t** tab_out);   // (gemm.hip)

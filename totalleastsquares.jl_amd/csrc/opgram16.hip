@@ -394,11 +394,14 @@ __global__ __launch_bounds__(256) void k_zty_h_reduce(const double* __restrict__
 
 // Y (N x p fp64, ld ldy) = Z'(Z X) with the panel's maximum known (zmax_bits: device word, float bits of max |Z|); T32 (M x 16
 // ceil(p / 16), ld M) = Z X is left in t32 as in the other forms.  Shapes: as op_gram_f32_fast_ok.
-int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, float* t32, double* Y,
-                   int64_t ldy, int64_t p, const unsigned int* zmax_bits) {
-    const int nct = (int)((p + 15) / 16), lw = 16 * nct;
+// first half alone: T32 (M x lw fp32, ld M; lw a multiple of 16 >= p, columns p.. zero) = Z X - the factor product of the rebuild
+// for ranks above 32 (opgram32.hip, wide_factors_f32) when the panel's maximum is known.  tmax_out (optional): device word that
+// receives max |T32| as float bits.
+int tsmm_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, int64_t p, int lw,
+                float* t32, const unsigned int* zmax_bits, unsigned int** tmax_out) {
+    const int nct = lw / 16;
     void *wh, *wl, *sc;
-    TLSQ_TRY(ws_get(h, WS_OPW, (size_t)N * lw * 8, &wh));   // (both planes: 2 x N lw halfs = N lw 4 bytes)
+    TLSQ_TRY(ws_get(h, WS_OPW, (size_t)N * lw * 8, &wh));
     wl = reinterpret_cast<_Float16*>(wh) + (size_t)N * lw;
     TLSQ_TRY(ws_get(h, WS_OPSC, 64, &sc));
     unsigned int* xmax = reinterpret_cast<unsigned int*>(sc);
@@ -407,21 +410,28 @@ int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N,
     hipLaunchKernelGGL(k_xmax_bits, dim3(256), dim3(256), 0, h->stream, X, ldx, N, (int)p, xmax);
     hipLaunchKernelGGL(k_pack_x16, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, X, ldx, N,
                        (int)p, lw, (const unsigned int*)xmax, (_Float16*)wh, (_Float16*)wl);
-    {
-        const dim3 grid((unsigned)(M / 128));
+    const dim3 grid((unsigned)(M / 128));
 #define ZXH(NC)                                                                                                               \
     hipLaunchKernelGGL((k_zx_h<NC>), grid, dim3(256), 0, h->stream, Z, ldz, (const _Float16*)wh, (const _Float16*)wl, t32, M, (int)N, \
                        zmax_bits, (const unsigned int*)xmax, tmax)
-        switch (nct) {
-            case 1: ZXH(1); break;
-            case 2: ZXH(2); break;
-            case 3: ZXH(3); break;
-            case 4: ZXH(4); break;
-            default: ZXH(5); break;
-        }
-#undef ZXH
+    switch (nct) {
+        case 1: ZXH(1); break;
+        case 2: ZXH(2); break;
+        case 3: ZXH(3); break;
+        case 4: ZXH(4); break;
+        default: ZXH(5); break;
     }
+#undef ZXH
     TLSQ_HIP(h, hipGetLastError());
+    if (tmax_out) *tmax_out = tmax;
+    return TLSQ_OK;
+}
+
+int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, const double* X, int64_t ldx, float* t32, double* Y,
+                   int64_t ldy, int64_t p, const unsigned int* zmax_bits) {
+    const int nct = (int)((p + 15) / 16), lw = 16 * nct;
+    unsigned int* tmax = nullptr;
+    TLSQ_TRY(tsmm_f32_h3(h, Z, ldz, M, N, X, ldx, p, lw, t32, zmax_bits, &tmax));
     const int64_t ntiles = (N + QZ_COLS - 1) / QZ_COLS;
     int64_t nsplit = std::max<int64_t>(1, (1024 + ntiles - 1) / ntiles);
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, M / (4 * QZK)));

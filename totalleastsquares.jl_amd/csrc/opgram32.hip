@@ -411,13 +411,21 @@ int wide_factors_f32(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t 
     TLSQ_TRY(ws_get(h, WS_OPW, (size_t)N * lw * 8, &wt));
     TLSQ_TRY(ws_get(h, WS_T32, (size_t)M * lw * 4, &t32));
     TLSQ_TRY(ws_get(h, WS_VS32, (size_t)N * lw * 4, &vs32));
-    hipLaunchKernelGGL(k_pack_wt32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, Vg, N,
-                       (int)N, (int)r, lw, (float*)wt);
     hipLaunchKernelGGL(k_cols_to_f32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, Vs, N,
                        N, (int)r, lw, (float*)vs32);
-    const dim3 grid((unsigned)(M / 128));
-    if (lw == 64) hipLaunchKernelGGL((k_zx_f32<4>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
-    else hipLaunchKernelGGL((k_zx_f32<5>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
+    if (h->absmax_panel == (const void*)Z && ldz == M && !dev_is(DEV_OPGRAM_H3, '0')) {
+        // (the sweep that wrote the panel left its maximum: the product on the fp16 MFMA, operands split in registers - opgram16.hip)
+        void* sc;
+        TLSQ_TRY(ws_get(h, WS_H16S, 64, &sc));
+        const unsigned int* zmax = reinterpret_cast<const unsigned int*>(reinterpret_cast<char*>(sc) + 40);
+        TLSQ_TRY(tsmm_f32_h3(h, Z, ldz, M, N, Vg, N, r, lw, (float*)t32, zmax, nullptr));
+    } else {
+        hipLaunchKernelGGL(k_pack_wt32, dim3((unsigned)std::min<int64_t>((N * lw + 255) / 256, 1024)), dim3(256), 0, h->stream, Vg, N,
+                           (int)N, (int)r, lw, (float*)wt);
+        const dim3 grid((unsigned)(M / 128));
+        if (lw == 64) hipLaunchKernelGGL((k_zx_f32<4>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
+        else hipLaunchKernelGGL((k_zx_f32<5>), grid, dim3(256), 0, h->stream, Z, ldz, (const float*)wt, (float*)t32, M, (int)N);
+    }
     if (Tm)
         hipLaunchKernelGGL(k_cols_to_f64, dim3((unsigned)std::min<int64_t>((M * r + 255) / 256, 4096)), dim3(256), 0, h->stream,
                            (const float*)t32, M, M, (int)r, Tm);
