@@ -144,7 +144,8 @@ def test_rpca_returned_s_all_singular_values(eng):
     assert np.linalg.norm(Zg - Zo) / np.linalg.norm(Zo) < 1e-9
 
 
-@pytest.mark.parametrize("M,N,p", [(4096, 512, 20), (8192, 1024, 74), (5000, 700, 96), (3001, 257, 130), (65536, 4096, 74)])
+@pytest.mark.parametrize("M,N,p", [(4096, 512, 20), (8192, 1024, 74), (5000, 700, 96), (3001, 257, 130), (65536, 4096, 74),
+                                   (32768, 2304, 40), (16384, 4096, 20), (32768, 2304, 58), (16384, 4096, 9)])
 def test_operator_product_on_the_fp32_mfma(eng, torch_mod, M, N, p):
     """Y = Z'(Z X) for an fp32 panel (gemm.hip, op_gram_f32: both halves on the fp32 MFMA, fp64 fold-in) against numpy in
     float64 on the same fp32 data: per column 2e-6 of ||Z||_2^2 ||x|| (X rounded to fp32 on the way in, fp32 partial sums
