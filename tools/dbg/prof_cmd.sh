@@ -11,6 +11,6 @@ python3 - "$out/${tag}_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:12]:
-    n = r["Name"].replace("void tlsq::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
+    n = r["Name"].replace("(anonymous namespace)::", "").replace("void tlsq::", "").replace("tlsq::", "").split("(")[0][:60]
     print(f"{n:60s} calls {r['Calls']:>5s} avg {float(r['AverageNs']) / 1e3:9.1f} us")
 PY

@@ -9,7 +9,7 @@ key = sys.argv[2] if len(sys.argv) > 2 else "k_maxabs"
 starts = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
 lo = starts[-1] if starts else 0
 rows = rows[lo:]
-short = lambda n: n.split("(")[0].replace("void ", "").replace("tlsq::", "").replace("(anonymous namespace)::", "")[:44]
+short = lambda n: n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("tlsq::", "")[:44]
 t0 = int(rows[0]["Start_Timestamp"])
 prev_end = t0
 cur = None

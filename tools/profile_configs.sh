@@ -26,5 +26,6 @@ run c5r $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist --randomized
 run c4 $PWD/tools/large_case.py 200000 512 16 --no-hist
 run c3 $PWD/tools/scale_lowrankfilter.py --no-hist
 pmc c5 $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist
+pmc c5r $PWD/tools/large_case.py 65536 4096 64 --f32 --no-hist --randomized
 pmc c4 $PWD/tools/large_case.py 200000 512 16 --no-hist
 pmc c3 $PWD/tools/scale_lowrankfilter.py --no-hist

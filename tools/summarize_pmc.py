@@ -22,7 +22,7 @@ def collect(d, counter):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter or "tlsq::" not in row["Kernel_Name"]:
+                if row["Counter_Name"] != counter or "tlsq" not in row["Kernel_Name"]:   # ("_ZN4tlsq...": templates in unnamed namespaces stay mangled)
                     continue
                 a = acc[row["Kernel_Name"]]
                 a[0] += 1
@@ -50,6 +50,8 @@ def main():
     if out_json:
         per = {}
         for r in rows:
+            if "tlsq::" not in r[0]:
+                continue
             short = r[0].split("tlsq::")[1].split("<")[0].split("(")[0]
             if short in ("k_shrink", "k_first_shrink", "k_update", "k_update_shrink", "k_rebuild_update_shrink", "k_zsweep", "k_zsweep_lin", "k_final_e"):
                 per[short] = {"dispatches": r[1], "hbm_bytes_per_launch": r[6]}
