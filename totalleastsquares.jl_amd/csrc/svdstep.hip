@@ -359,7 +359,11 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         }();
         const unsigned int seed32 = (unsigned int)(st.hook_seed * 2654435761ull + 77u);
         int64_t carry = dev_is(DEV_HOOK_COLD, '1') ? 0 : std::min<int64_t>(st.hook_carry, p);
-        if (carry > 0) carry = std::max<int64_t>(0, std::min<int64_t>(carry, p - std::max<int64_t>(2, (p - st.hook_rank) / 2)));   // (pad refresh)
+        // (the last pad columns come from the hash generator at every call, so that a direction absent from the carried block can
+        //  still enter; HOOK_PAD_REFRESH=0 carries all of them - measured: the same seven Jacobi sweeps either way, the Ritz vectors
+        //  inside the dominant cluster rotate by O(1) from one ALM iteration to the next)
+        if (carry > 0 && !dev_is(DEV_HOOK_PAD_REFRESH, '0'))
+            carry = std::max<int64_t>(0, std::min<int64_t>(carry, p - std::max<int64_t>(2, (p - st.hook_rank) / 2)));
         st.hook_carry = 0;
         double* stat2 = lamH_dev + p;          // 3 status words per intermediate orthonormalisation (npow <= 6)
         std::vector<double> host2((size_t)3 * 6);
