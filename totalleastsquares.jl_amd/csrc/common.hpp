@@ -119,7 +119,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH)
+    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)

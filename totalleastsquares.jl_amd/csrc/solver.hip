@@ -760,6 +760,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     // count).  TLSQ_FULL_EIG=1 forces the full solver every iteration.
     SubspaceState sub;
     int64_t hook_cols = 0;   // columns of the block buffer (WS_SX) holding the last decomposition's sorted Ritz vectors: the hook's warm start
+    if (N > kFullEigMaxN && !dev_is(DEV_COLD_GROW, '0')) sub.cold_p = 34;   // (large mode: see the block growth below)
     // (the hook's Rayleigh-Ritz product Z Q and eigenvector matrix of this iteration, when they are still on the device: the
     //  factor of the rebuild is taken from them - SubspaceState::hook_zq)
     const float* hook_zq = nullptr;
@@ -1506,7 +1507,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                                   why == SubspaceState::FAIL_NUMERIC || attempt >= 2;
                 const int64_t cap = std::min<int64_t>(pmax, N);
                 if (grow) {
-                    const int64_t newp = std::min<int64_t>(cap, sub.p + std::max<int64_t>(16, sub.p / 2));
+                    // (large mode doubles: a cold round of a wide block costs a millisecond, and ranks there are rarely below 30 -
+                    //  18 -> 34 -> 51 -> 76 for BASELINE config 5's rank 64 became 34 -> 68; COLD_GROW=0: the old steps)
+                    const bool fast_grow = large && !dev_is(DEV_COLD_GROW, '0');
+                    const int64_t newp = std::min<int64_t>(cap, sub.p + std::max<int64_t>(16, fast_grow ? sub.p : sub.p / 2));
                     if (newp == sub.p && why == SubspaceState::FAIL_SMALL) break;   // the rank exceeds the largest block
                     if (sub.valid && newp > sub.p) {
                         double* X = (double*)h->ws[WS_SX].p;
