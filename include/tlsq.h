@@ -129,6 +129,11 @@ typedef struct tlsq_rpca_info {
      * of exactly those launches */
     int64_t sweeps_timed;
     double hbm_bytes_sweeps_timed;
+    /* launches of the kernels that only some shapes take, counted over this call (per GPU): the fp16-split Gram matrix
+     * (gram16.hip, k_gram_h3), the fp16-split operator products (opgram16.hip: k_zx_h alone = the rebuild's factor product,
+     * k_zx_h + k_zty_h = one Z'(Z X)), the wide-rank sweep (sweeps.hip, k_zsweep_wide) and the fused sweep + Gram kernel
+     * (fused.hip, k_fused_zgram).  The parity tests assert on them that a fixture exercised the path it was made for. */
+    int64_t kern_gram_h3, kern_zx_h, kern_zty_h, kern_zsweep_wide, kern_fused_zgram;
 } tlsq_rpca_info;
 
 const char* tlsq_version(void);

@@ -39,7 +39,7 @@ mutable struct RpcaOpts
     RpcaOpts() = new()
 end
 
-# mirrors `struct tlsq_rpca_info`, 216 bytes
+# mirrors `struct tlsq_rpca_info`, 256 bytes
 mutable struct RpcaInfo
     iters_done::Int64; converged::Int32; tsqr_iterations::Int32
     final_cost::Cdouble; final_mu::Cdouble; d_norm::Cdouble
@@ -50,6 +50,7 @@ mutable struct RpcaInfo
     residual_stores_skipped::Int64
     hbm_bytes_sweeps::Cdouble; hbm_bytes::Cdouble
     sweeps_timed::Int64; hbm_bytes_sweeps_timed::Cdouble
+    kern_gram_h3::Int64; kern_zx_h::Int64; kern_zty_h::Int64; kern_zsweep_wide::Int64; kern_fused_zgram::Int64
     RpcaInfo() = new()
 end
 

@@ -8,7 +8,7 @@ The oracle (oracle/rpca_oracle.py: LAPACK gesdd for both decompositions of an it
 reference) is itself pinned to the reference's known-answer vectors by tests/test_oracle_golden.py.  Build container,
 8 cores: config 2 takes about a minute, config 4 about a quarter of an hour and 7 GB.
 
-    python tests/golden/make_bench_vectors.py [c2] [c4]
+    python tests/golden/make_bench_vectors.py [c2] [c4] [c5]
 """
 import hashlib
 import json
@@ -29,7 +29,7 @@ W = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(W)
 
 OUT = os.path.join(HERE, "bench_vectors.json")
-STRIDES = {"c2": 4999, "c4": 49999}      # primes: the samples walk through all rows and columns (~2048 values each)
+STRIDES = {"c2": 4999, "c4": 49999, "c5": 131071}      # primes: the samples walk through all rows and columns (~2048 values each)
 
 
 def svp_hash(hist):
@@ -40,12 +40,17 @@ def problem(name):
     if name == "c2":
         D, _, _ = W.synth_lowrank_sparse(20000, 512, 16, seed=0)
         return D
+    if name == "c5":
+        # BASELINE config 5 (65536 x 4096 fp32, rank 64 + 5 % sparse) in the reference's default (exact) mode: fp32 LAPACK
+        # gesdd twice per iteration, about 100 TFLOP - tens of minutes and ~12 GB on the 8-core build box, once.
+        D, _, _ = W.synth_lowrank_sparse(65536, 4096, 64, seed=0, dtype=np.float32)
+        return D
     M4 = W.C4_SHAPE[0]
     return np.asfortranarray(W.c4_rows(0, M4))
 
 
 def main():
-    names = [a for a in sys.argv[1:] if a in STRIDES] or ["c2", "c4"]
+    names = [a for a in sys.argv[1:] if a in STRIDES] or ["c2", "c4", "c5"]
     out = {}
     if os.path.exists(OUT):
         with open(OUT) as f:
@@ -58,12 +63,12 @@ def main():
         st = STRIDES[name]
         out[name] = {
             "M": int(D.shape[0]), "N": int(D.shape[1]),
-            "D_sha256_of_float64_column_major": hashlib.sha256(D.tobytes(order="F")).hexdigest(),
+            "dtype": str(D.dtype), "D_sha256_of_float64_column_major": hashlib.sha256(D.tobytes(order="F")).hexdigest(),
             "iters": info.iters_done, "sv": int(sv), "converged": bool(info.converged),
             "svp_hist": [int(v) for v in info.svp_hist], "svp_hash": svp_hash(info.svp_hist),
             "cost_hist": [float(v) for v in info.cost_hist],
             "S": [float(v) for v in s[1]],
-            "normA2": float(np.sum(A * A)), "normE2": float(np.sum(E * E)),
+            "normA2": float(np.sum(A.astype(np.float64) ** 2)), "normE2": float(np.sum(E.astype(np.float64) ** 2)),
             "nnzE": int(np.count_nonzero(E)),
             "sample_stride": st,
             "A_sample": [float(v) for v in A.ravel(order="F")[::st]],

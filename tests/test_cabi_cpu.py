@@ -46,7 +46,7 @@ def test_version_and_default_opts():
 def test_struct_sizes_match_header():
     # natural alignment, no packing: these are the sizes the Julia shim's struct mirrors must have
     assert C.sizeof(L.RpcaOpts) == 128
-    assert C.sizeof(L.RpcaInfo) == 216
+    assert C.sizeof(L.RpcaInfo) == 256
     assert C.sizeof(L.GaOpts) == 56 and C.sizeof(L.GaInfo) == 64
 
 

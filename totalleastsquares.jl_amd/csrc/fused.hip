@@ -504,6 +504,11 @@ bool fused_zgram_ok(int64_t M, int64_t N, int64_t r, const void* D, const void* 
     return true;
 }
 
+// the shape part of the test alone (what a rank of a row-sharded group can tell the others before the loop: solver.hip)
+bool fused_zgram_shape_ok(int64_t M, int64_t N, bool hankel) {
+    return fused_zgram_ok(M, N, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hankel, 0.0, HankelGeom());
+}
+
 // K split and slabs of the fused kernel, as a GramPlan whose reduction is gram_reduce (gemm.hip)
 int fused_zgram_plan(Handle* h, int64_t M, int64_t N, GramPlan* pl) {
     int ncu = 256;
@@ -545,22 +550,20 @@ namespace {
 template <int RM, bool HKF, bool NNF, int RSF, bool FIRSTF, bool GRF = false>
 int fz_launch(Handle* h, const FusedArgs& a, unsigned grid) {
     const size_t lds = (size_t)FzLds<RM>::TOTAL * sizeof(double);
-    static bool attr_set = false;   // (per instantiation; idempotent)
-    if (!attr_set) {
-        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF, GRF>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // the attribute belongs to the function object of the CURRENT device: set on every launch, as gram16.hip / cholesky.hip /
+    // jacobi.hip do (a process-wide "already set" flag left ranks 1.. of a tlsq_create_multi group without it)
+    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF, GRF>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_fused_zgram<RM, HKF, NNF, RSF, FIRSTF, GRF>), dim3(grid), dim3(FZ_THREADS), lds, h->stream, a);
     TLSQ_HIP(h, hipGetLastError());
+    if (a.nz > 0) ++h->kern_fused_zgram;
     return TLSQ_OK;
 }
 }  // namespace
 
 // the dynamic-LDS attribute of every instantiation rpca_core may launch (a launch with zero workgroups each: nothing runs)
 int fused_zgram_warm(Handle* h) {
-    static bool done = false;
-    if (done) return TLSQ_OK;
+    if (h->fused_warm_done) return TLSQ_OK;   // (per handle = per device: the attributes belong to the device's function objects)
     FusedArgs a = {};
     a.nz = 0;
     a.N = FZ_NC;
@@ -575,7 +578,7 @@ int fused_zgram_warm(Handle* h) {
 #undef FZ_WARM
     TLSQ_TRY((fz_launch<8, true, false, FZ_RS_HK, true>(h, a, 1)));
     TLSQ_TRY((fz_launch<8, false, false, FZ_RS_D, true>(h, a, 1)));
-    done = true;
+    h->fused_warm_done = true;
     return TLSQ_OK;
 }
 

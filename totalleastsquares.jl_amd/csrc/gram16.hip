@@ -321,6 +321,7 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
     else if (fold == 4) H3_LAUNCH(4);
     else H3_LAUNCH(2);
 #undef H3_LAUNCH
+    ++h->kern_gram_h3;
     hipLaunchKernelGGL(k_h3_reduce, dim3(2048), dim3(256), 0, h->stream, (const double*)slab, slab_stride, (int)nsplit,
                        (const double*)sc, G, ldg, (int)N);
     TLSQ_HIP(h, hipGetLastError());

@@ -17,6 +17,7 @@ namespace tlsq {
 // in-place reduction over the row shards of a handle with a communicator (no-op otherwise)
 int comm_allreduce(Handle* h, double* dev, size_t count, ncclRedOp_t op);
 int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op);
+int comm_allreduce_host_vec(Handle* h, double* v, int count, ncclRedOp_t op);   // count <= 8
 // recv (nranks * count doubles, rank-major) <- every rank's send (count doubles)
 int comm_allgather(Handle* h, const double* send, double* recv, size_t count);
 int copy2d(Handle* h, void* dst, int64_t ldd, const void* src, int64_t lds, int64_t rows, int64_t cols, size_t esz,
@@ -198,7 +199,9 @@ inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, doubl
 int sigma_max_of_gram(Handle* h, const double* G, int64_t N, double rel_tol, double* out, int64_t* sweeps,
                       double stop_above_sigma = 0.0);
 int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps, bool allow_warm = false,
-             int vslot = WS_V, bool need_all_vectors = false);
+             int vslot = WS_V, bool need_all_vectors = false,
+             // hints for the spectrum slicer (sliced.hip): an upper bound of the eigenvalues, a known cluster away from the rest
+             double lam_hi = 0.0, int n_out = 0, double val_out = 0.0, double bulk_hi = 0.0);
 int gather_cols(Handle* h, const double* V, int64_t N, const std::vector<int32_t>& sel, double* X);
 // G (workspace slot `slot`) = Z'Z summed over the row shards
 template <typename T>

@@ -807,28 +807,48 @@ __global__ void k_jr_sweep_end(unsigned int* __restrict__ rot_count, int* __rest
     *reinterpret_cast<unsigned long long*>(rot_count + 4) = 0ull;
 }
 
+// tab (optional): the block pairs of this launch from a table instead of the round-robin schedule over all blocks - entry
+// blockIdx.x = (first column, columns) of the two blocks (at most 16 columns each; a first column < 0: nothing to do).  The
+// spectrum slicer (sliced.hip) sweeps within groups of columns this way; `round` == 0 still means "with the pairs inside
+// each block".
 template <int NW, int RPL>
 __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, int N, int nblk, int round, double tol,
                                                         const double* __restrict__ params,
-                                                        unsigned int* __restrict__ rot_count, const int* __restrict__ done) {
+                                                        unsigned int* __restrict__ rot_count, const int* __restrict__ done,
+                                                        const int4* __restrict__ tab) {
     if (*done) return;   // (converged in a sweep the host has not heard of yet)
     __shared__ JrShared<NW> sh;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = (w * 64 + lane) * RPL;   // this lane's rows: row .. row + RPL - 1
-    int bp, bq;
-    rr_pair(nblk, round, blockIdx.x, bp, bq);
-    if (bp > bq) {   // (keeps the lower block in c[0..15]: the order of the columns inside a pair is that of the LDS kernel)
-        const int t = bp;
-        bp = bq;
-        bq = t;
+    int cp0, lp, cq0, lq;   // first column and number of columns of the two blocks
+    if (tab) {
+        const int4 e = tab[blockIdx.x];
+        if (e.x < 0) return;
+        cp0 = e.x;
+        lp = e.y;
+        cq0 = e.z;
+        lq = e.w;
+    } else {
+        int bp, bq;
+        rr_pair(nblk, round, blockIdx.x, bp, bq);
+        if (bp > bq) {   // (keeps the lower block in c[0..15]: the order of the columns inside a pair is that of the LDS kernel)
+            const int t = bp;
+            bp = bq;
+            bq = t;
+        }
+        cp0 = bp * 16;
+        cq0 = bq * 16;
+        lp = N - cp0 < 16 ? (N - cp0 > 0 ? N - cp0 : 0) : 16;
+        lq = N - cq0 < 16 ? (N - cq0 > 0 ? N - cq0 : 0) : 16;
     }
     const double floor2 = params[0], tol2 = tol * tol;
     double c[RPL][32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
+        const bool have = (s < 16) ? s < lp : (s - 16) < lq;
+        const int col = (s < 16) ? cp0 + s : cq0 + (s - 16);
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) c[q][s] = (col < N && row + q < N) ? B[(size_t)col * N + row + q] : 0.0;
+        for (int q = 0; q < RPL; ++q) c[q][s] = (have && row + q < N) ? B[(size_t)col * N + row + q] : 0.0;
     }
     // squared column norms (32-value reduction as two butterflies), each wave keeps a full copy by column position
     {
@@ -909,10 +929,11 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
     // (16 cross rotations and 15 intra rotations are full cycles: the registers are in column order again)
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        const int col = (s < 16) ? bp * 16 + s : bq * 16 + (s - 16);
+        const bool have = (s < 16) ? s < lp : (s - 16) < lq;
+        const int col = (s < 16) ? cp0 + s : cq0 + (s - 16);
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
-            if (col < N && row + q < N) B[(size_t)col * N + row + q] = c[q][s];
+            if (have && row + q < N) B[(size_t)col * N + row + q] = c[q][s];
     }
     if (w == 0) {
         // lanes 4 I of wave 0 counted the rotations of "their" pairs
@@ -1196,6 +1217,59 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
     return TLSQ_OK;
 }
 
+// Sweeps of the register-resident kernel until one rotates nothing (or nothing above |tan| = 1e-8).  tab_dev == nullptr: the
+// round-robin schedule over all nblk blocks (nblk - 1 launches per sweep); otherwise `nrounds` launches per sweep, launch r taking
+// round_cnt[r] block pairs from tab_dev + round_off[r] (k_jacobi_reg's table form; r == 0 rotates inside the blocks as well).
+// state (device): [0] done, [1] sweeps performed; the host queues four sweeps at a time (kernels of sweeps behind the converged one
+// return at once) and reads the state once per batch instead of once per sweep.  rot: rotation count, largest |tan|.
+static int jr_run_sweeps(Handle* h, double* B, int64_t N, double tol_r, const double* params, unsigned int* rot, int* state,
+                         const int4* tab_dev, const int* round_off, const int* round_cnt, int nrounds, int max_sweeps, int* sweeps_done,
+                         bool* converged_out) {
+    int nblk = (int)((N + 15) / 16);
+    if (nblk & 1) ++nblk;
+    bool converged = false;
+    int sweep = 0;
+    TLSQ_HIP(h, hipMemsetAsync(rot, 0, 48, h->stream));   // rotation count, largest |tan|, sweeps_dev (unused here), state
+    const bool one = dev_is(DEV_JACOBI_RPL, '1');   // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
+    const int rounds = tab_dev ? nrounds : nblk - 1;
+    while (sweep < max_sweeps && !converged) {
+        const int batch = std::min(4, max_sweeps - sweep);
+        for (int sb = 0; sb < batch; ++sb) {
+            for (int r = 0; r < rounds; ++r) {
+                const int grid = tab_dev ? round_cnt[r] : nblk / 2;
+                if (grid <= 0) continue;
+                const int4* tab = tab_dev ? tab_dev + round_off[r] : nullptr;
+                if (N <= 256 && !one)
+                    hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(grid), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+                else if (N <= 512 && !one)
+                    hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(grid), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+                else if (N <= 512)
+                    hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(grid), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+                else if (!one)
+                    hipLaunchKernelGGL((k_jacobi_reg<8, 2>), dim3(grid), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+                else
+                    hipLaunchKernelGGL((k_jacobi_reg<16, 1>), dim3(grid), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+            }
+            hipLaunchKernelGGL(k_jr_sweep_end, dim3(1), dim3(1), 0, h->stream, rot, state);
+        }
+        TLSQ_HIP(h, hipGetLastError());
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, state, 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        int hs[2];
+        memcpy(hs, h->pinned, 8);
+        sweep = hs[1];
+        converged = hs[0] != 0;
+    }
+    *sweeps_done = sweep;
+    *converged_out = converged;
+    return TLSQ_OK;
+}
+
 // One-sided Jacobi on the columns of a square factor B (N x N, ld N, rotated in place): on return the columns of B are
 // mutually orthogonal, V (N x N, ld N) holds them normalised and sig_dev[i] their norms (unsorted).  For B = L with
 // G = L L' (Cholesky factor, or R' of a QR factorisation Z = Q R) these are the eigenvectors of G / right singular
@@ -1221,45 +1295,8 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
         const double tol_r = std::max(2.0 * eps * sqrt((double)N), 4.0 * eps);
         if (N >= 64 && N <= 1024 && !dev_is(DEV_NO_JACOBI_REG, '1')) {
             // register-resident block pairs (k_jacobi_reg): blocks of 16 columns, nblk - 1 launches per sweep
-            int nblk = (int)((N + 15) / 16);
-            if (nblk & 1) ++nblk;
-            const int max_sweeps = 40;
-            converged = false;
-            // state (device): [0] done, [1] sweeps performed - at scal + 160; the host queues four sweeps at a time (kernels of
-            // sweeps behind the converged one return at once) and reads the state once per batch instead of once per sweep
             int* state = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 160);
-            TLSQ_HIP(h, hipMemsetAsync(rot, 0, 48, h->stream));   // rotation count, largest |tan|, sweeps_dev (unused here), state
-            const bool one = dev_is(DEV_JACOBI_RPL, '1');   // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
-            while (sweep < max_sweeps && !converged) {
-                const int batch = std::min(4, max_sweeps - sweep);
-                for (int sb = 0; sb < batch; ++sb) {
-                    for (int r = 0; r < nblk - 1; ++r) {
-                        if (N <= 256 && !one)
-                            hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(nblk / 2), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                               (const double*)params, rot, (const int*)state);
-                        else if (N <= 512 && !one)
-                            hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(nblk / 2), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                               (const double*)params, rot, (const int*)state);
-                        else if (N <= 512)
-                            hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                               (const double*)params, rot, (const int*)state);
-                        else if (!one)
-                            hipLaunchKernelGGL((k_jacobi_reg<8, 2>), dim3(nblk / 2), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                               (const double*)params, rot, (const int*)state);
-                        else
-                            hipLaunchKernelGGL((k_jacobi_reg<16, 1>), dim3(nblk / 2), dim3(1024), 0, h->stream, B, (int)N, nblk, r, tol_r,
-                                               (const double*)params, rot, (const int*)state);
-                    }
-                    hipLaunchKernelGGL(k_jr_sweep_end, dim3(1), dim3(1), 0, h->stream, rot, state);
-                }
-                TLSQ_HIP(h, hipGetLastError());
-                TLSQ_HIP(h, hipMemcpyAsync(h->pinned, state, 8, hipMemcpyDeviceToHost, h->stream));
-                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-                int hs[2];
-                memcpy(hs, h->pinned, 8);
-                sweep = hs[1];
-                converged = hs[0] != 0;
-            }
+            TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, nullptr, nullptr, nullptr, 0, 40, &sweep, &converged));
             if (sweeps_out) *sweeps_out = sweep;
             TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
             if (!converged)
@@ -1318,6 +1355,75 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
     TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
     if (!converged)
         return set_err(h, TLSQ_ERR_NOCONV, "one-sided Jacobi did not converge in 40 sweeps (N=%lld)", (long long)N);
+    return TLSQ_OK;
+}
+
+// The same on a factor whose columns come in GROUPS that are already (nearly) orthogonal to each other - the spectrum slicer's
+// start (sliced.hip): first sweeps that only pair columns of the same group (a group of k columns costs ceil(k / 16) - 1
+// launches per sweep, and all groups share them), then sweeps over all pairs until nothing rotates.  groups: (first column,
+// columns), disjoint, inside [0, N).  sweeps_out[0] / [1]: sweeps of the two phases.
+int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector<std::pair<int, int>>& groups, double* V,
+                              double* sig_dev, double floor_rel, int64_t* sweeps_out) {
+    if (sweeps_out) sweeps_out[0] = sweeps_out[1] = 0;
+    if (N < 64 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "jacobi_factor_grouped_f64: N = %lld", (long long)N);
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* params = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 64);
+    unsigned int* rot = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(scal) + 128);
+    int* state = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 160);
+    const double eps = 2.220446049250313e-16;
+    hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, h->stream, (const double*)B, (int)N, params, floor_rel * floor_rel);
+    TLSQ_HIP(h, hipGetLastError());
+    const double tol_r = std::max(2.0 * eps * sqrt((double)N), 4.0 * eps);
+    // the table: per launch r of a sweep, the block pairs of every group that still has a round r
+    std::vector<int4> tab;
+    std::vector<int> off, cnt;
+    int maxr = 0;
+    for (const auto& g : groups) {
+        const int nb = (g.second + 15) / 16;
+        const int nbe = std::max(2, nb + (nb & 1));
+        if (g.second > 1) maxr = std::max(maxr, nbe - 1);
+    }
+    for (int r = 0; r < maxr; ++r) {
+        off.push_back((int)tab.size());
+        for (const auto& g : groups) {
+            if (g.second <= 1) continue;
+            const int nb = (g.second + 15) / 16;
+            const int nbe = std::max(2, nb + (nb & 1));
+            if (r >= nbe - 1) continue;
+            for (int idx = 0; idx < nbe / 2; ++idx) {
+                const int m = nbe - 1;
+                int bp = idx == 0 ? r % m : (r + idx) % m, bq = idx == 0 ? m : (r - idx + m) % m;
+                if (bp > bq) std::swap(bp, bq);
+                auto len = [&](int b) { return std::max(0, std::min(16, g.second - 16 * b)); };
+                const int lp = len(bp), lq = len(bq);
+                if (lp + lq == 0) continue;
+                if ((lp == 0 || lq == 0) && r != 0) continue;   // (a lone block only has work in the round with the inner pairs)
+                if (lp == 0) {   // keep the real block in the first slot
+                    tab.push_back(int4{g.first + 16 * bq, lq, g.first, 0});
+                } else {
+                    tab.push_back(int4{g.first + 16 * bp, lp, g.first + 16 * bq, lq});
+                }
+            }
+        }
+        cnt.push_back((int)tab.size() - off.back());
+    }
+    int sw0 = 0, sw1 = 0;
+    bool conv0 = true, conv1 = false;
+    if (!tab.empty()) {
+        void* tdev;
+        TLSQ_TRY(ws_get(h, WS_SL_TAB, tab.size() * sizeof(int4), &tdev));
+        TLSQ_HIP(h, hipMemcpyAsync(tdev, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (tab is a local: the copy must have left it)
+        TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, (const int4*)tdev, off.data(), cnt.data(), maxr, 40, &sw0, &conv0));
+    }
+    TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, nullptr, nullptr, nullptr, 0, 40, &sw1, &conv1));
+    if (sweeps_out) {
+        sweeps_out[0] = sw0;
+        sweeps_out[1] = sw1;
+    }
+    TLSQ_TRY(launch_normalize_cols(h, (const double*)B, N, V, sig_dev));
+    if (!conv1) return set_err(h, TLSQ_ERR_NOCONV, "one-sided Jacobi did not converge in 40 sweeps (N=%lld)", (long long)N);
     return TLSQ_OK;
 }
 

@@ -297,6 +297,222 @@ __global__ __launch_bounds__(512) void k_small_mm_blk(const double* __restrict__
     }
 }
 
+// The blocked product over a BATCH of N x N problems (blockIdx.y; element strides sA / sB / sC / sAdd, 0 = shared operand): the
+// spectrum slicer (sliced.hip) runs its sign iterations for several split points side by side - one matrix is 136 workgroups at
+// N = 512, half the chip.  Same tile code, same summation order as k_small_mm_blk.
+struct MfBatchCoef3 {   // per-problem coefficients of a batched product (at most 8 problems)
+    double alpha[8], beta[8], gamma[8];
+};
+template <bool SYM, bool PERZ>
+__global__ __launch_bounds__(512) void k_small_mm_blk_b(const double* __restrict__ A, int64_t sA, const double* __restrict__ B, int64_t sB,
+                                                        double* __restrict__ C, int64_t sC, int N, int nt, double alpha, double beta,
+                                                        const double* __restrict__ Add, int64_t sAdd, double gamma, MfBatchCoef3 cz) {
+    __shared__ double sR[8 * 1024];
+    const int z = blockIdx.y;
+    if (PERZ) {
+        alpha = cz.alpha[z];
+        beta = cz.beta[z];
+        gamma = cz.gamma[z];
+    }
+    A += (int64_t)z * sA;
+    B += (int64_t)z * sB;
+    C += (int64_t)z * sC;
+    if (Add) Add += (int64_t)z * sAdd;
+    int ti, tj;
+    double v[2];
+    smm_blk_tile<SYM>(A, B, N, nt, sR, ti, tj, v);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = tid + 512 * half;
+        const int sub2 = e >> 8, q2 = (e >> 6) & 3, l2 = e & 63;
+        const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
+        double out = alpha * v[half] + (i == j ? beta : 0.0);
+        if (Add) out += gamma * Add[i + (int64_t)j * N];
+        if (SYM) {
+            if (ti != tj || j <= i) {
+                C[i + (int64_t)j * N] = out;
+                C[j + (int64_t)i * N] = out;
+            }
+        } else {
+            C[i + (int64_t)j * N] = out;
+        }
+    }
+}
+
+// C_z = alpha A_z B_z + beta I (+ gamma Add_z), z < nb; N a multiple of 128, N <= 2048.  sym: commuting symmetric operands.
+int small_mm_batched(Handle* h, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC, int64_t N, int nb,
+                     double alpha, double beta, bool sym, const double* Add, int64_t sAdd, double gamma) {
+    if ((N % 128) != 0 || N > 2048 || nb < 1) return set_err(h, TLSQ_ERR_ARG, "small_mm_batched: N = %lld", (long long)N);
+    const int nt = (int)(N / 32);
+    const MfBatchCoef3 none = {};
+    if (sym)
+        hipLaunchKernelGGL((k_small_mm_blk_b<true, false>), dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)nb), dim3(512), 0, h->stream, A, sA,
+                           B, sB, C, sC, (int)N, nt, alpha, beta, Add, sAdd, gamma, none);
+    else
+        hipLaunchKernelGGL((k_small_mm_blk_b<false, false>), dim3((unsigned)(nt * nt), (unsigned)nb), dim3(512), 0, h->stream, A, sA, B, sB,
+                           C, sC, (int)N, nt, alpha, beta, Add, sAdd, gamma, none);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// X_z = alpha_z P_z K + beta_z I + gamma_z P_z for z < nb <= 8 (P_z, K commuting symmetric matrices; P_z: stride N^2, K shared):
+// the start of the sign iteration of a slice whose spectral projector is P_z (sliced.hip)
+int small_mm_batched_start(Handle* h, const double* P, const double* K, double* X, int64_t N, int nb, const double* alpha,
+                           const double* beta, const double* gamma) {
+    if ((N % 128) != 0 || N > 2048 || nb < 1 || nb > 8) return set_err(h, TLSQ_ERR_ARG, "small_mm_batched_start: N = %lld", (long long)N);
+    const int nt = (int)(N / 32);
+    MfBatchCoef3 cz = {};
+    for (int z = 0; z < nb; ++z) {
+        cz.alpha[z] = alpha[z];
+        cz.beta[z] = beta[z];
+        cz.gamma[z] = gamma[z];
+    }
+    const int64_t nn = N * N;
+    hipLaunchKernelGGL((k_small_mm_blk_b<true, true>), dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)nb), dim3(512), 0, h->stream, P, nn, K,
+                       (int64_t)0, X, nn, (int)N, nt, 0.0, 0.0, P, nn, 0.0, cz);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
+// X_z = a_z K + b_z I for z < nb (nb <= 8): the shifted and scaled starts of a batch of sign iterations
+struct MfBatchCoef {
+    double a[8], b[8];
+};
+__global__ __launch_bounds__(256) void k_mf_axpbi_b(const double* __restrict__ K, double* __restrict__ X, int N, MfBatchCoef cf) {
+    const int z = blockIdx.y;
+    const int64_t total = (int64_t)N * N;
+    double* Xz = X + (int64_t)z * total;
+    const double a = cf.a[z], b = cf.b[z];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        Xz[e] = a * K[e] + (i == j ? b : 0.0);
+    }
+}
+
+// out[4 z + {0, 1, 2, 3}] = trace(S_z), <S_z, K> = sum_ij S_ij K_ij, ||S_z||_F^2, <S_z, K2> (K2 optional: the square of K, for
+// second moments) for z < nb: one workgroup per matrix, fixed order
+__global__ __launch_bounds__(1024) void k_mf_slice_stats(const double* __restrict__ S, const double* __restrict__ K,
+                                                         const double* __restrict__ K2, int N, double* __restrict__ out) {
+    __shared__ double red[4][16];
+    const int z = blockIdx.x;
+    const int64_t total = (int64_t)N * N;
+    const double* Sz = S + (int64_t)z * total;
+    double tr = 0.0, ip = 0.0, fr = 0.0, ip2 = 0.0;
+    for (int64_t e = threadIdx.x; e < total; e += 1024) {
+        const double v = Sz[e];
+        const int i = (int)(e % N), j = (int)(e / N);
+        if (i == j) tr += v;
+        ip += v * K[e];
+        fr += v * v;
+        if (K2) ip2 += v * K2[e];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tr += __shfl_down(tr, off, 64);
+        ip += __shfl_down(ip, off, 64);
+        fr += __shfl_down(fr, off, 64);
+        ip2 += __shfl_down(ip2, off, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w] = tr;
+        red[1][w] = ip;
+        red[2][w] = fr;
+        red[3][w] = ip2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int k = 0; k < 16; ++k) {
+            a += red[0][k];
+            b += red[1][k];
+            c += red[2][k];
+            d += red[3][k];
+        }
+        out[4 * z + 0] = a;
+        out[4 * z + 1] = b;
+        out[4 * z + 2] = c;
+        out[4 * z + 3] = d;
+    }
+}
+
+// sign(K - t_z I) for nb <= 8 split points t_z side by side, on a FIXED schedule (no convergence tests, no host round trip):
+// X_0 = (K - t I) / max(hi - t, t) for a symmetric K with eigenvalues in [0, hi]; the growth quintic of matfun_sign until an
+// eigenvalue that started at l0 has reached 0.6, minimax quintics (quintic.hpp) down to 1e-6, one Newton-Schulz step.  An
+// eigenvalue of X_0 closer to zero than l0 arrives late: its direction is left between the two sides (the caller's Jacobi sweeps
+// deal with it - sliced.hip).  X: nb N^2 doubles (the starts are written here; t == nullptr: they are there already, symmetric
+// with eigenvalues in [-1, 1]), W1, W2: the same size each; *out = the buffer the signs are in (one of the three).  stats_dev
+// (4 nb doubles) receives k_mf_slice_stats of the result (K2 optional).
+int matfun_sign_batched(Handle* h, const double* K, const double* K2, int64_t N, int nb, const double* t, double hi, double l0, double* X,
+                        double* W1, double* W2, double** out, double* stats_dev, int* steps_out) {
+    if (nb < 1 || nb > 8 || (N % 128) != 0 || N > 2048) return set_err(h, TLSQ_ERR_ARG, "matfun_sign_batched: nb = %d, N = %lld", nb, (long long)N);
+    const int64_t nn = N * N;
+    if (t) {   // (t == nullptr: the caller has written the starts to X itself)
+        MfBatchCoef cf;
+        for (int z = 0; z < nb; ++z) {
+            const double nrm = std::max(hi - t[z], t[z]);
+            if (!(nrm > 0.0) || !std::isfinite(nrm)) return set_err(h, TLSQ_ERR_ARG, "matfun_sign_batched: split point %g of [0, %g]", t[z], hi);
+            cf.a[z] = 1.0 / nrm;
+            cf.b[z] = -t[z] / nrm;
+        }
+        int64_t g = (nn + 255) / 256;
+        if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(k_mf_axpbi_b, dim3((unsigned)g, (unsigned)nb), dim3(256), 0, h->stream, K, X, (int)N, cf);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    double *cur = X, *f1 = W1, *f2 = W2;
+    int it = 0;
+    auto quintic_step = [&](double a, double b, double c) -> int {
+        TLSQ_TRY(small_mm_batched(h, cur, nn, cur, nn, f1, nn, N, nb, 1.0, 0.0, true, nullptr, 0, 0.0));   // S = X^2
+        TLSQ_TRY(small_mm_batched(h, f1, nn, f1, nn, f2, nn, N, nb, c, a, true, f1, nn, b));               // T = c S^2 + b S + a I
+        TLSQ_TRY(small_mm_batched(h, cur, nn, f2, nn, f1, nn, N, nb, 1.0, 0.0, true, nullptr, 0, 0.0));    // X T
+        std::swap(cur, f1);
+        ++it;
+        return TLSQ_OK;
+    };
+    // image of [l, u] under p(x) = a x + b x^3 + c x^5 (sampled: the schedule only needs it to a per cent)
+    auto image = [](double a, double b, double c, double& l, double& u) {
+        double lo = 1e300, hi2 = -1e300;
+        for (int k = 0; k <= 4000; ++k) {
+            const double x = l + (u - l) * (double)k / 4000.0, x2 = x * x;
+            const double v = x * (a + x2 * (b + c * x2));
+            lo = std::min(lo, v);
+            hi2 = std::max(hi2, v);
+        }
+        l = lo;
+        u = hi2;
+    };
+    double l = std::min(std::max(l0, 1e-12), 0.5), u = 1.0;
+    const double ga = 3.4445, gb = -4.7750, gc = 2.0315;
+    const bool minimax_all = dev_is(DEV_SLICE_SCHED, 'm');
+    if (!minimax_all)
+        while (l < 0.60 && it < 40) {   // (the growth quintic takes [0.22, 1.2] into [0.68, 1.2]: its own minimum near x = 1.05)
+            TLSQ_TRY(quintic_step(ga, gb, gc));
+            image(ga, gb, gc, l, u);
+        }
+    for (int s = 0; s < 24 && it < 60; ++s) {
+        if (std::max(1.0 - l, u - 1.0) < 1e-6) break;
+        OddQuintic p;
+        if (!odd_quintic(l, u, &p)) break;
+        TLSQ_TRY(quintic_step(p.a, p.b, p.c));
+        l = 1.0 - p.E;
+        u = 1.0 + p.E;
+    }
+    // one Newton-Schulz step: X <- X (1.5 I - 0.5 X^2)
+    TLSQ_TRY(small_mm_batched(h, cur, nn, cur, nn, f1, nn, N, nb, -0.5, 1.5, true, nullptr, 0, 0.0));
+    TLSQ_TRY(small_mm_batched(h, cur, nn, f1, nn, f2, nn, N, nb, 1.0, 0.0, true, nullptr, 0, 0.0));
+    std::swap(cur, f2);
+    ++it;
+    if (stats_dev) {
+        hipLaunchKernelGGL(k_mf_slice_stats, dim3((unsigned)nb), dim3(1024), 0, h->stream, (const double*)cur, K, K2, (int)N, stats_dev);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    *out = cur;
+    if (steps_out) *steps_out = it;
+    return TLSQ_OK;
+}
+
 // ||S^2||_F^2 of the symmetric S, tile sums to the host-visible mailbox: k_sq_norm (subspace.hip) on the blocked tile kernel, for
 // N a multiple of 128 - same mailbox layout and ticket protocol (slot 16 + tile, off-diagonal tiles count twice, the workgroup
 // that arrives last publishes the sequence number)

@@ -423,6 +423,7 @@ int tsmm_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N, co
     }
 #undef ZXH
     TLSQ_HIP(h, hipGetLastError());
+    ++h->kern_zx_h;
     if (tmax_out) *tmax_out = tmax;
     return TLSQ_OK;
 }
@@ -453,6 +454,7 @@ int op_gram_f32_h3(Handle* h, const float* Z, int64_t ldz, int64_t M, int64_t N,
         default: ZTYH(5); break;
     }
 #undef ZTYH
+    ++h->kern_zty_h;
     hipLaunchKernelGGL(k_zty_h_reduce, dim3((unsigned)std::min<int64_t>((N * p + 255) / 256, 2048)), dim3(256), 0, h->stream,
                        (const double*)slab, slab_stride, (int)nsplit, lw, Y, ldy, N, (int)p);
     TLSQ_HIP(h, hipGetLastError());

@@ -336,17 +336,20 @@ int comm_allgather(Handle* h, const double* send, double* recv, size_t count) {
     return TLSQ_OK;
 }
 
-int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op) {
+int comm_allreduce_host_vec(Handle* h, double* v, int count, ncclRedOp_t op) {
     if (!h->comm) return TLSQ_OK;
+    if (count < 1 || count > 8) return set_err(h, TLSQ_ERR_ARG, "comm_allreduce_host_vec: count");
     void* slot;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
-    double* d = reinterpret_cast<double*>(reinterpret_cast<char*>(slot) + 256);
-    TLSQ_HIP(h, hipMemcpyAsync(d, v, 8, hipMemcpyHostToDevice, h->stream));
-    TLSQ_TRY(comm_allreduce(h, d, 1, op));
-    TLSQ_HIP(h, hipMemcpyAsync(v, d, 8, hipMemcpyDeviceToHost, h->stream));
+    double* d = reinterpret_cast<double*>(reinterpret_cast<char*>(slot) + 256);   // [256, 320): 8 doubles (320.. belongs to others)
+    TLSQ_HIP(h, hipMemcpyAsync(d, v, (size_t)count * 8, hipMemcpyHostToDevice, h->stream));
+    TLSQ_TRY(comm_allreduce(h, d, count, op));
+    TLSQ_HIP(h, hipMemcpyAsync(v, d, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
     return TLSQ_OK;
 }
+
+int comm_allreduce_host_scalar(Handle* h, double* v, ncclRedOp_t op) { return comm_allreduce_host_vec(h, v, 1, op); }
 
 // ------------------------------------------------------------------------------------------------
 // small helpers

@@ -126,7 +126,7 @@ static bool chol_route(int64_t N) {
 }
 
 int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s, int64_t* sweeps, bool allow_warm, int vslot,
-             bool need_all_vectors) {
+             bool need_all_vectors, double lam_hi, int n_out, double val_out, double bulk_hi) {
     void *B, *V, *lam;
     TLSQ_TRY(ws_get(h, WS_B, (size_t)N * N * 8, &B));
     TLSQ_TRY(ws_get(h, vslot, (size_t)N * N * 8, &V));
@@ -139,9 +139,14 @@ int eig_full(Handle* h, const double* G, int64_t N, double** V_out, SmallSvd& s,
         // no eigenvector accumulation.  Vectors of numerically-zero eigenvalues come back as zero columns, which
         // is fine for the ALM loop (only sigma_i >= 1/mu are used).
         double delta = 0.0;
-        TLSQ_TRY(symeig_chol_f64(h, G, N, N, (double*)B, (double*)V, (double*)lam, &delta, &sw));
+        // (round 6: the spectrum cut into slices of ~64 eigenvalues first - sliced.hip - where the shape allows; same result,
+        //  a third of the sequential Jacobi rounds)
+        bool sliced = false;
+        if (symeig_sliced_ok(N))
+            TLSQ_TRY(symeig_sliced_f64(h, G, N, N, (double*)B, (double*)V, (double*)lam, &delta, &sw, lam_hi, n_out, val_out, bulk_hi, &sliced));
+        if (!sliced) TLSQ_TRY(symeig_chol_f64(h, G, N, N, (double*)B, (double*)V, (double*)lam, &delta, &sw));
         if (vslot == WS_V) h->warm_n = 0;
-        if (dbg) fprintf(stderr, "  full eig (chol) N=%lld sweeps=%lld\n", (long long)N, (long long)sw);
+        if (dbg) fprintf(stderr, "  full eig (chol%s) N=%lld sweeps=%lld\n", sliced ? ", sliced" : "", (long long)N, (long long)sw);
         if (sweeps) *sweeps += sw;
         TLSQ_HIP(h, hipMemcpyAsync(s.sigma.data(), lam, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -556,6 +561,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     };
     h->out_factors = false;
     h->absmax_panel = nullptr;   // (no panel of this call has been written yet)
+    h->kern_gram_h3 = h->kern_zx_h = h->kern_zty_h = h->kern_zsweep_wide = h->kern_fused_zgram = 0;
     if (!(zmode && ro.factors_out)) TLSQ_TRY(need_A());
     // classic loop: E and Z are double-buffered: the fused update(k)+shrink(k+1) sweep writes E_{k+1}, Z_{k+1} while E_k, Z_k
     // must survive in case iteration k is the last one
@@ -696,7 +702,20 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const int force_implicit = [] { const char* e = dev_get(DEV_IMPLICIT_GRAM); return e ? atoi(e) : -1; }();
     // (round 5: fp32 panels the fp16-split Gram kernel takes - gram16.hip, 2x the fp32 MFMA's rate - keep the Gram matrix at
     //  N = 8192 as well: 16384 x 8192 rank 40, 176 ms per solve against 305 in operator form)
-    const bool h3_shape = Prec<T>::f32 && (N % 128) == 0 && (M % 64) == 0 && M >= 4096 && !dev_is(DEV_GRAM_H3, '0');
+    bool h3_shape = Prec<T>::f32 && (N % 128) == 0 && (M % 64) == 0 && M >= 4096 && !dev_is(DEV_GRAM_H3, '0');
+    // Row shards: decisions that change WHICH collectives an iteration enters must be the same on every rank, and these two
+    // depend on the rank-local row count: h3_shape moves the switch to the operator form at N = 8192 (an N x N Gram
+    // all-reduce against N x p ones), and the residual-Gram mode of the fused sweep kernel (fused_gr below) all-reduces R'R in
+    // the slot where the other ranks all-reduce Z'Z.  One min-all-reduce of the flags: taken only if every rank can.
+    bool group_fused_shape = true;
+    if (h->comm) {
+        double fl[2] = {h3_shape ? 1.0 : 0.0, 1.0};
+        if constexpr (std::is_same<T, double>::value)
+            fl[1] = fused_zgram_shape_ok(M, N, ro.hankel_y != nullptr) ? 1.0 : 0.0;
+        TLSQ_TRY(comm_allreduce_host_vec(h, fl, 2, ncclMin));
+        h3_shape = fl[0] != 0.0;
+        group_fused_shape = fl[1] != 0.0;
+    }
     const bool implicit_gram = N > kFullEigMaxN && (force_implicit >= 0 ? force_implicit == 1 : (h3_shape ? N > 8192 : N >= 8192));
     // The randomized hook in large mode (BASELINE config 5: `svd = rsvd`, src/robustPCA.jl:195-197, test/runtests.jl:388-398) is a
     // sketch: from iteration 2 on nothing but products with the panel - Y = Z'(Z Omega), orthonormalisation, the power passes, the
@@ -1792,7 +1811,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     //  C3 two of four such iterations are still settled by the bounds and would pay for the Gram of Z_{k+1}
                     //  they did not accumulate)
                     //  (N = 256 only: at N = 512 the off-diagonal block would need the stored R_k)
-                    fused_gr = Rst != nullptr && prev_cost_evaluated && N == 256 && !dev_is(DEV_NO_FUSED_GR, '1');
+                    fused_gr = Rst != nullptr && prev_cost_evaluated && N == 256 && group_fused_shape && !dev_is(DEV_NO_FUSED_GR, '1');
                     TLSQ_TRY(fused_zgram_plan(h, M, N, &fused_pl));
                     TLSQ_TRY(launch_fused_zgram(h, fused_pl, D, Tm_last, Vs_last, Ybuf[ycur], Ybuf[ycur ^ 1], Zbuf[zc], Zbuf[zc ^ 1],
                                                 Rst, M, N, svp, mu, inv_mu, ro.nonnegA ? 1 : 0, 1.0 / mu_next, lam / mu_next,
@@ -2098,6 +2117,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         info->residual_stores_skipped = n_rskip;
         info->sweeps_timed = n_timed;
         info->hbm_bytes_sweeps_timed = hbm_timed;
+        info->kern_gram_h3 = h->kern_gram_h3;
+        info->kern_zx_h = h->kern_zx_h;
+        info->kern_zty_h = h->kern_zty_h;
+        info->kern_zsweep_wide = h->kern_zsweep_wide;
+        info->kern_fused_zgram = h->kern_fused_zgram;
     }
     if (sv_out) *sv_out = sv;
 
@@ -2198,7 +2222,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(gram_allreduce<T>(h, R, M, N, M, &GP, WS_G2));
                 double* V2 = nullptr;
                 SmallSvd s2;
-                TLSQ_TRY(eig_full(h, GP, N, &V2, s2, &sweeps));
+                // (hints for the slicer: every eigenvalue of G_P is at most s^2, and |S| of them sit there)
+                // and everything else is at most next^2 - Ritz values converged to 1e-13 and the loop's count certificate)
+                TLSQ_TRY(eig_full(h, GP, N, &V2, s2, &sweeps, false, WS_V, false, slev * slev, (int)cnt, slev * slev, next * next));
                 bool good = s2.ncols == N;
                 for (int64_t i = 0; i < cnt && good; ++i)
                     good = std::fabs(s2.sigma[(size_t)s2.order[(size_t)i]] - slev) <= 1e-6 * slev;

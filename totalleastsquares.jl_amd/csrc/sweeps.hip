@@ -663,6 +663,7 @@ int launch_zsweep_wide(Handle* h, const float* D, const float* T32, int64_t ldt,
     else ZW_PICK(40);
 #undef ZW_PICK
 #undef ZW_LAUNCH
+    ++h->kern_zsweep_wide;
     TLSQ_HIP(h, hipGetLastError());
     if (leave_absmax) h->absmax_panel = Zout;
     return TLSQ_OK;

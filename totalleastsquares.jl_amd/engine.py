@@ -61,6 +61,7 @@ class RpcaReport:
         self.tsqr_iterations = int(info.tsqr_iterations)
         self.hbm_bytes_sweeps, self.hbm_bytes = float(info.hbm_bytes_sweeps), float(info.hbm_bytes)
         self.sweeps_timed, self.hbm_bytes_sweeps_timed = int(info.sweeps_timed), float(info.hbm_bytes_sweeps_timed)
+        self.kern = {k[5:]: int(getattr(info, k)) for k, _ in info._fields_ if k.startswith("kern_")}
         self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
 
 
