@@ -676,7 +676,9 @@ def test_lowrankfilter_never_stores_the_hankel_panel(torch_mod, tmp_path):
     K = Ns - n + 1
     panel = (K + 15) // 16 * 16 * n * 8
     assert rep.converged
-    assert (free0 - free1) < 4.4 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
+    # (four panels + the N x N workspace: Gram slabs, subspace blocks and - round 6 - the 45 N x N matrices of the spectrum
+    #  slicer, 24 MB at n = 256; the point of the bound is "four panels, not eight")
+    assert (free0 - free1) < 4.6 * panel, f"{(free0 - free1) / panel:.2f} panels resident"
     # the same call with the Hankel panel built and kept (development switches, tlsq_dev_set)
     with tlsq_amd.dev_switches(LAZY_HANKEL=0, IMPLICIT_HANKEL=0):
         e3 = tlsq_amd.Engine(0)

@@ -13,7 +13,7 @@ tlsq_amd.dev_from_env()
 D, _, _ = O.synth_lowrank_sparse(M, N, r, seed=0)
 eng = tlsq_amd.Engine(0)
 res = {}
-for tag, sw in (("sliced", {}), ("plain", dict(NO_SLICED_EIG=1))):
+for tag, sw in (("normwise", {}), ("factor", dict(SLICE_NORMWISE=0)), ("plain", dict(NO_SLICED_EIG=1))):
     with tlsq_amd.dev_switches(**sw):
         for rep_i in range(3):
             t0 = time.perf_counter()
@@ -25,8 +25,10 @@ for tag, sw in (("sliced", {}), ("plain", dict(NO_SLICED_EIG=1))):
     res[tag] = s
     Vt = np.asarray(s.Vt)
     U = np.asarray(s.U)
-    print(f"{tag:7s} call {dt*1e3:8.2f} ms (without s {dt0*1e3:7.2f})  total_ms {rep.ms['total']:.2f} loop_ms {rep.ms['loop']:.2f} "
+    print(f"{tag:9s} call {dt*1e3:8.2f} ms (without s {dt0*1e3:7.2f})  total_ms {rep.ms['total']:.2f} loop_ms {rep.ms['loop']:.2f} "
           f"sweeps {rep.jacobi_sweeps}  |VtVt'-I| {np.max(np.abs(Vt @ Vt.T - np.eye(N))):.2e}  |U'U-I| {np.max(np.abs(U.T @ U - np.eye(N))):.2e}")
-a, b = np.asarray(res["sliced"].S), np.asarray(res["plain"].S)
-print("max rel diff of S:", np.max(np.abs(a - b) / b), " S[0], S[r], S[-1]:", a[0], a[r], a[-1])
+b = np.asarray(res["plain"].S)
+for tag in ("normwise", "factor"):
+    a = np.asarray(res[tag].S)
+    print(tag, "max rel diff of S vs plain:", np.max(np.abs(a - b) / b), " S[0], S[r], S[-1]:", a[0], a[r], a[-1])
 eng.close()

@@ -123,7 +123,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
     X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW) \
-    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0)
+    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(SLICE_NORMWISE)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -165,6 +165,7 @@ enum WsSlot {
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
     WS_C32_F, WS_C32_D, WS_C32_A, WS_C32_E, WS_C32_U, WS_C32_V, WS_C32_S,   // ComplexF32 entry (api.hip): float staging, widened panels
+    WS_VTOUT,   // the returned Vt of a host-pointer call on its way out (entry.hip)
     WS_SL_BUF, WS_SL_TAB,   // spectrum slicer in front of the accurate route's Jacobi (sliced.hip): N x N iterates, block-pair table
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction
     WS_COUNT
@@ -250,6 +251,9 @@ int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N,
 // out = a - b
 template <typename T>
 int launch_diff(Handle* h, const T* a, const T* b, T* out, int64_t n);
+// Vt[p + j ld] = (T) V[j + order[p] N] for p < d, j < N (V: N x N fp64, ld N): the returned right singular vectors, sorted
+template <typename T>
+int launch_vt_out(Handle* h, const double* V, int64_t N, const int32_t* order_dev, int64_t d, T* Vt, int64_t ld);
 // dst[i] = (Tdst) src[i]
 template <typename TS, typename TD>
 int launch_convert(Handle* h, const TS* src, TD* dst, int64_t n);
@@ -423,6 +427,11 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
 bool symeig_sliced_ok(int64_t N);
 int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev, double* delta_host,
                       int64_t* sweeps_out, double lam_hi, int n_out, double val_out, double bulk_hi, bool* used);
+
+// ... normwise on G itself (no factor): V and the eigenvalues lam_dev, certified to 8 N eps lam_hi - for the deflated panel of the
+// returned `s` (see sliced.hip)
+int symeig_sliced_normwise_f64(Handle* h, const double* G, int64_t N, double* V, double* lam_dev, int64_t* sweeps_out, double lam_hi,
+                               int n_out, double val_out, double bulk_hi, bool* used);
 
 // ---------------- tsqr.hip ----------------
 // B (N x N, ld N) = R' (lower triangular) of the Householder TSQR factorisation Z = Q R; Z (M x N, ld ldz, fp32 when

@@ -203,6 +203,7 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
     // Host-pointer call that also returns s: A and E are final when the loop ends, 10+ ms before U, S, Vt are - their 164 MB go
     // back to the caller's memory on the staging workers WHILE the decomposition of the last Z runs (a thread of its own drives
     // the staged copy; the solver thread keeps queueing kernels).
+    bool vt_on_device = false;   // rpca_core has written Vt to device memory itself (ResolvedOpts::vt_dev)
     std::thread ae_thread;
     int ae_status = TLSQ_OK;
     bool ae_sent = false;
@@ -233,8 +234,21 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
             }
         };
         ro2.ae_final = &send_ae;
+        if (Vt) {   // Vt straight to device memory: the caller's own with TLSQ_MEM_DEVICE, a workspace buffer (one copy out) otherwise
+            if (dev) {
+                ro2.vt_dev = Vt;
+                ro2.vt_ld = ldVt;
+            } else {
+                void* vtb;
+                TLSQ_TRY(ws_get(h, WS_VTOUT, (size_t)d * N * es, &vtb));
+                ro2.vt_dev = vtb;
+                ro2.vt_ld = d;
+            }
+            ro2.vt_written = &vt_on_device;
+        }
         status = rpca_core<T>(h, dD, M, N, ro2, opts, dA, dE, U ? dU : nullptr, S ? hS.data() : nullptr,
                               Vt ? hVt.data() : nullptr, d, sv, info);
+        if (vt_on_device && !dev) TLSQ_TRY(copy2d(h, Vt, ldVt, ro2.vt_dev, d, d, N, es, hipMemcpyDeviceToHost));
         if (ae_thread.joinable()) ae_thread.join();
         (void)hipSetDevice(h->device);
         if (status < 0) return status;
@@ -308,7 +322,7 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         TLSQ_HIP(h, hipMemcpyAsync(S, tS.data(), (size_t)d * es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost,
                                    h->stream));
     }
-    if (Vt) {
+    if (Vt && !vt_on_device) {
         tVt.resize((size_t)d * N);
         for (size_t i = 0; i < tVt.size(); ++i) tVt[i] = (T)hVt[i];
         TLSQ_TRY(copy2d(h, Vt, ldVt, tVt.data(), d, d, N, es, dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost));

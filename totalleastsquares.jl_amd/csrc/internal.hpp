@@ -174,6 +174,12 @@ struct ResolvedOpts {
     // called once A and E are final (the loop is over, the stream synchronised), before the returned decomposition is computed:
     // a host-pointer call starts their way back to the caller's memory here, beside the SVD of the last Z (solver.hip, rpca_entry)
     const std::function<void()>* ae_final = nullptr;
+    // Vt on the device: when set, rpca_core writes the returned Vt (d x N, leading dimension vt_ld, element type of the call)
+    // there with one kernel - no 2 MB round trip through host loops - and says so in *vt_written (the paths that only have
+    // part of the decomposition keep the host form: Vt_host must be passed as well)
+    void* vt_dev = nullptr;
+    int64_t vt_ld = 0;
+    bool* vt_written = nullptr;
 };
 
 inline ResolvedOpts resolve(const tlsq_rpca_opts* o, int64_t M, int64_t N, double default_tol) {

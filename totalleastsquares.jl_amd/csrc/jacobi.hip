@@ -808,26 +808,33 @@ __global__ void k_jr_sweep_end(unsigned int* __restrict__ rot_count, int* __rest
 }
 
 // tab (optional): the block pairs of this launch from a table instead of the round-robin schedule over all blocks - entry
-// blockIdx.x = (first column, columns) of the two blocks (at most 16 columns each; a first column < 0: nothing to do).  The
+// blockIdx.x = (first column, columns) of the two blocks (at most 16 columns each; a first column < 0: nothing to do) and the
+// window of rows [row0, row0 + nrows) their columns are non-zero in (the workgroup's waves cover nrows, not N).  The
 // spectrum slicer (sliced.hip) sweeps within groups of columns this way; `round` == 0 still means "with the pairs inside
 // each block".
+struct JrPair {
+    int cp0, lp, cq0, lq, row0, nrows, pad0, pad1;
+};
 template <int NW, int RPL>
 __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, int N, int nblk, int round, double tol,
                                                         const double* __restrict__ params,
                                                         unsigned int* __restrict__ rot_count, const int* __restrict__ done,
-                                                        const int4* __restrict__ tab) {
+                                                        const JrPair* __restrict__ tab) {
     if (*done) return;   // (converged in a sweep the host has not heard of yet)
     __shared__ JrShared<NW> sh;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = (w * 64 + lane) * RPL;   // this lane's rows: row .. row + RPL - 1
+    int row = (w * 64 + lane) * RPL;   // this lane's rows: row .. row + RPL - 1
     int cp0, lp, cq0, lq;   // first column and number of columns of the two blocks
+    int nrows = N;          // rows the columns live in: [row0, row0 + nrows) (table form: the block's own window; everything else is zero)
     if (tab) {
-        const int4 e = tab[blockIdx.x];
-        if (e.x < 0) return;
-        cp0 = e.x;
-        lp = e.y;
-        cq0 = e.z;
-        lq = e.w;
+        const JrPair e = tab[blockIdx.x];
+        if (e.cp0 < 0) return;
+        cp0 = e.cp0;
+        lp = e.lp;
+        cq0 = e.cq0;
+        lq = e.lq;
+        nrows = e.nrows;
+        B += e.row0;        // (column offsets below are in units of N: the window only shifts the row origin)
     } else {
         int bp, bq;
         rr_pair(nblk, round, blockIdx.x, bp, bq);
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         const bool have = (s < 16) ? s < lp : (s - 16) < lq;
         const int col = (s < 16) ? cp0 + s : cq0 + (s - 16);
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) c[q][s] = (have && row + q < N) ? B[(size_t)col * N + row + q] : 0.0;
+        for (int q = 0; q < RPL; ++q) c[q][s] = (have && row + q < nrows) ? B[(size_t)col * N + row + q] : 0.0;
     }
     // squared column norms (32-value reduction as two butterflies), each wave keeps a full copy by column position
     {
@@ -933,7 +940,7 @@ __global__ __launch_bounds__(64 * NW) void k_jacobi_reg(double* __restrict__ B, 
         const int col = (s < 16) ? cp0 + s : cq0 + (s - 16);
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
-            if (have && row + q < N) B[(size_t)col * N + row + q] = c[q][s];
+            if (have && row + q < nrows) B[(size_t)col * N + row + q] = c[q][s];
     }
     if (w == 0) {
         // lanes 4 I of wave 0 counted the rotations of "their" pairs
@@ -1223,8 +1230,8 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
 // state (device): [0] done, [1] sweeps performed; the host queues four sweeps at a time (kernels of sweeps behind the converged one
 // return at once) and reads the state once per batch instead of once per sweep.  rot: rotation count, largest |tan|.
 static int jr_run_sweeps(Handle* h, double* B, int64_t N, double tol_r, const double* params, unsigned int* rot, int* state,
-                         const int4* tab_dev, const int* round_off, const int* round_cnt, int nrounds, int max_sweeps, int* sweeps_done,
-                         bool* converged_out) {
+                         const JrPair* tab_dev, const int* round_off, const int* round_cnt, int nrounds, int max_sweeps, int* sweeps_done,
+                         bool* converged_out, int64_t rows = 0) {   // rows: the largest row window of the table (0: N)
     int nblk = (int)((N + 15) / 16);
     if (nblk & 1) ++nblk;
     bool converged = false;
@@ -1232,20 +1239,24 @@ static int jr_run_sweeps(Handle* h, double* B, int64_t N, double tol_r, const do
     TLSQ_HIP(h, hipMemsetAsync(rot, 0, 48, h->stream));   // rotation count, largest |tan|, sweeps_dev (unused here), state
     const bool one = dev_is(DEV_JACOBI_RPL, '1');   // (JACOBI_RPL=1: one row per lane, the first form: 8 / 16 waves)
     const int rounds = tab_dev ? nrounds : nblk - 1;
+    const int64_t R = rows > 0 ? rows : N;   // rows a workgroup has to cover
     while (sweep < max_sweeps && !converged) {
         const int batch = std::min(4, max_sweeps - sweep);
         for (int sb = 0; sb < batch; ++sb) {
             for (int r = 0; r < rounds; ++r) {
                 const int grid = tab_dev ? round_cnt[r] : nblk / 2;
                 if (grid <= 0) continue;
-                const int4* tab = tab_dev ? tab_dev + round_off[r] : nullptr;
-                if (N <= 256 && !one)
+                const JrPair* tab = tab_dev ? tab_dev + round_off[r] : nullptr;
+                if (R <= 128 && !one)
+                    hipLaunchKernelGGL((k_jacobi_reg<1, 2>), dim3(grid), dim3(64), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
+                                       (const int*)state, tab);
+                else if (R <= 256 && !one)
                     hipLaunchKernelGGL((k_jacobi_reg<2, 2>), dim3(grid), dim3(128), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
                                        (const int*)state, tab);
-                else if (N <= 512 && !one)
+                else if (R <= 512 && !one)
                     hipLaunchKernelGGL((k_jacobi_reg<4, 2>), dim3(grid), dim3(256), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
                                        (const int*)state, tab);
-                else if (N <= 512)
+                else if (R <= 512)
                     hipLaunchKernelGGL((k_jacobi_reg<8, 1>), dim3(grid), dim3(512), 0, h->stream, B, (int)N, nblk, r, tol_r, params, rot,
                                        (const int*)state, tab);
                 else if (!one)
@@ -1362,8 +1373,11 @@ int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_de
 // start (sliced.hip): first sweeps that only pair columns of the same group (a group of k columns costs ceil(k / 16) - 1
 // launches per sweep, and all groups share them), then sweeps over all pairs until nothing rotates.  groups: (first column,
 // columns), disjoint, inside [0, N).  sweeps_out[0] / [1]: sweeps of the two phases.
+// block_diagonal: B is block diagonal - group g's columns are non-zero in rows [first, first + columns) only (the slices' own
+// small factors side by side): the workgroups only cover that window, and the sweeps over all pairs are not needed (nothing
+// couples the groups).
 int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector<std::pair<int, int>>& groups, double* V,
-                              double* sig_dev, double floor_rel, int64_t* sweeps_out) {
+                              double* sig_dev, double floor_rel, int64_t* sweeps_out, bool block_diagonal) {
     if (sweeps_out) sweeps_out[0] = sweeps_out[1] = 0;
     if (N < 64 || N > 1024) return set_err(h, TLSQ_ERR_ARG, "jacobi_factor_grouped_f64: N = %lld", (long long)N);
     void* scal;
@@ -1376,9 +1390,11 @@ int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector
     TLSQ_HIP(h, hipGetLastError());
     const double tol_r = std::max(2.0 * eps * sqrt((double)N), 4.0 * eps);
     // the table: per launch r of a sweep, the block pairs of every group that still has a round r
-    std::vector<int4> tab;
+    std::vector<JrPair> tab;
     std::vector<int> off, cnt;
     int maxr = 0;
+    int64_t maxrows = 0;
+    for (const auto& g : groups) maxrows = std::max<int64_t>(maxrows, g.second);
     for (const auto& g : groups) {
         const int nb = (g.second + 15) / 16;
         const int nbe = std::max(2, nb + (nb & 1));
@@ -1399,10 +1415,11 @@ int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector
                 const int lp = len(bp), lq = len(bq);
                 if (lp + lq == 0) continue;
                 if ((lp == 0 || lq == 0) && r != 0) continue;   // (a lone block only has work in the round with the inner pairs)
+                const int row0 = block_diagonal ? g.first : 0, nrows = block_diagonal ? g.second : (int)N;
                 if (lp == 0) {   // keep the real block in the first slot
-                    tab.push_back(int4{g.first + 16 * bq, lq, g.first, 0});
+                    tab.push_back(JrPair{g.first + 16 * bq, lq, g.first, 0, row0, nrows, 0, 0});
                 } else {
-                    tab.push_back(int4{g.first + 16 * bp, lp, g.first + 16 * bq, lq});
+                    tab.push_back(JrPair{g.first + 16 * bp, lp, g.first + 16 * bq, lq, row0, nrows, 0, 0});
                 }
             }
         }
@@ -1412,12 +1429,14 @@ int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector
     bool conv0 = true, conv1 = false;
     if (!tab.empty()) {
         void* tdev;
-        TLSQ_TRY(ws_get(h, WS_SL_TAB, tab.size() * sizeof(int4), &tdev));
-        TLSQ_HIP(h, hipMemcpyAsync(tdev, tab.data(), tab.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(ws_get(h, WS_SL_TAB, tab.size() * sizeof(JrPair), &tdev));
+        TLSQ_HIP(h, hipMemcpyAsync(tdev, tab.data(), tab.size() * sizeof(JrPair), hipMemcpyHostToDevice, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));   // (tab is a local: the copy must have left it)
-        TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, (const int4*)tdev, off.data(), cnt.data(), maxr, 40, &sw0, &conv0));
+        TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, (const JrPair*)tdev, off.data(), cnt.data(), maxr, 40, &sw0, &conv0,
+                               block_diagonal ? maxrows : 0));
     }
-    TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, nullptr, nullptr, nullptr, 0, 40, &sw1, &conv1));
+    if (block_diagonal) conv1 = conv0;
+    else TLSQ_TRY(jr_run_sweeps(h, B, N, tol_r, params, rot, state, nullptr, nullptr, nullptr, 0, 40, &sw1, &conv1));
     if (sweeps_out) {
         sweeps_out[0] = sw0;
         sweeps_out[1] = sw1;
@@ -1446,6 +1465,33 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
     if (delta_host) *delta_host = sv[1];
     return st;
 }
+
+// Vt[p + j ld] = V[j + order[p] N]: 32 x 32 tiles through LDS (reads along V's columns, writes along Vt's)
+template <typename T>
+__global__ __launch_bounds__(256) void k_vt_out(const double* __restrict__ V, int N, const int32_t* __restrict__ order, int d,
+                                                T* __restrict__ Vt, int64_t ld) {
+    __shared__ double tile[32][33];
+    const int p0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int pp = ty; pp < 32; pp += 8) {
+        const int p = p0 + pp, j = j0 + tx;
+        tile[pp][tx] = (p < d && j < N) ? V[j + (int64_t)order[p] * N] : 0.0;
+    }
+    __syncthreads();
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int p = p0 + tx, j = j0 + jj;
+        if (p < d && j < N) Vt[p + (int64_t)j * ld] = (T)tile[tx][jj];
+    }
+}
+template <typename T>
+int launch_vt_out(Handle* h, const double* V, int64_t N, const int32_t* order_dev, int64_t d, T* Vt, int64_t ld) {
+    hipLaunchKernelGGL((k_vt_out<T>), dim3((unsigned)((d + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, h->stream, V, (int)N,
+                       order_dev, (int)d, Vt, ld);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+template int launch_vt_out<double>(Handle*, const double*, int64_t, const int32_t*, int64_t, double*, int64_t);
+template int launch_vt_out<float>(Handle*, const double*, int64_t, const int32_t*, int64_t, float*, int64_t);
 
 int launch_gather_scale(Handle* h, const double* V, int64_t N, const int32_t* sel_dev,
                         const double* g_dev, int64_t r, double* Vg, double* Vs) {

@@ -391,15 +391,17 @@ __global__ __launch_bounds__(256) void k_mf_axpbi_b(const double* __restrict__ K
 }
 
 // out[4 z + {0, 1, 2, 3}] = trace(S_z), <S_z, K> = sum_ij S_ij K_ij, ||S_z||_F^2, <S_z, K2> (K2 optional: the square of K, for
-// second moments) for z < nb: one workgroup per matrix, fixed order
+// second moments) for z < nb: MF_SS_CHUNKS workgroups per matrix, their partial sums added in a fixed order by k_mf_slice_stats2
+constexpr int MF_SS_CHUNKS = 32;
 __global__ __launch_bounds__(1024) void k_mf_slice_stats(const double* __restrict__ S, const double* __restrict__ K,
-                                                         const double* __restrict__ K2, int N, double* __restrict__ out) {
+                                                         const double* __restrict__ K2, int N, double* __restrict__ part) {
     __shared__ double red[4][16];
-    const int z = blockIdx.x;
+    const int z = blockIdx.x, ch = blockIdx.y;
     const int64_t total = (int64_t)N * N;
+    const int64_t per = (total + MF_SS_CHUNKS - 1) / MF_SS_CHUNKS, e0 = ch * per, e1 = (e0 + per < total) ? e0 + per : total;
     const double* Sz = S + (int64_t)z * total;
     double tr = 0.0, ip = 0.0, fr = 0.0, ip2 = 0.0;
-    for (int64_t e = threadIdx.x; e < total; e += 1024) {
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
         const double v = Sz[e];
         const int i = (int)(e % N), j = (int)(e / N);
         if (i == j) tr += v;
@@ -430,11 +432,21 @@ __global__ __launch_bounds__(1024) void k_mf_slice_stats(const double* __restric
             c += red[2][k];
             d += red[3][k];
         }
-        out[4 * z + 0] = a;
-        out[4 * z + 1] = b;
-        out[4 * z + 2] = c;
-        out[4 * z + 3] = d;
+        double* o = part + ((int64_t)z * MF_SS_CHUNKS + ch) * 4;
+        o[0] = a;
+        o[1] = b;
+        o[2] = c;
+        o[3] = d;
     }
+}
+// the chunks of a matrix added in order (one thread per matrix and statistic)
+__global__ __launch_bounds__(64) void k_mf_slice_stats2(const double* __restrict__ part, int nb, double* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= 4 * nb) return;
+    const int z = t >> 2, q = t & 3;
+    double a = 0.0;
+    for (int ch = 0; ch < MF_SS_CHUNKS; ++ch) a += part[((int64_t)z * MF_SS_CHUNKS + ch) * 4 + q];
+    out[4 * z + q] = a;
 }
 
 // sign(K - t_z I) for nb <= 8 split points t_z side by side, on a FIXED schedule (no convergence tests, no host round trip):
@@ -505,7 +517,11 @@ int matfun_sign_batched(Handle* h, const double* K, const double* K2, int64_t N,
     std::swap(cur, f2);
     ++it;
     if (stats_dev) {
-        hipLaunchKernelGGL(k_mf_slice_stats, dim3((unsigned)nb), dim3(1024), 0, h->stream, (const double*)cur, K, K2, (int)N, stats_dev);
+        void* part;
+        TLSQ_TRY(ws_get(h, WS_MFP, (size_t)3 * 16 * 2048 * 8, &part));   // (the slot of mf_stats' partials, at its largest size: >= 8 x 32 x 4 doubles)
+        hipLaunchKernelGGL(k_mf_slice_stats, dim3((unsigned)nb, MF_SS_CHUNKS), dim3(1024), 0, h->stream, (const double*)cur, K, K2, (int)N,
+                           (double*)part);
+        hipLaunchKernelGGL(k_mf_slice_stats2, dim3(1), dim3(64), 0, h->stream, (const double*)part, nb, stats_dev);
         TLSQ_HIP(h, hipGetLastError());
     }
     *out = cur;

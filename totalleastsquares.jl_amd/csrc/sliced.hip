@@ -25,7 +25,14 @@
 //      the result is whatever the plain Cholesky + Jacobi route converges to, by the same kernel and the same stopping rule.
 //
 // Nothing here decides an answer: a slice that comes out wrong only costs sweeps in step 5.  Where a guard fails (a projector
-// far from idempotent, J0 not orthogonal) the caller falls back to the plain route.
+// far from idempotent, J0 not orthogonal) the caller falls back to the plain route.  (symeig_sliced_f64: serves eig_full's
+// Cholesky route, N a multiple of 128 in [256, 1024].  C2, returned s: 14 sweeps over all pairs -> 9 inside the slices + 1.)
+//
+// The NORMWISE form (symeig_sliced_normwise_f64, what the returned `s` of a plain call takes): the same slices and basis, of G
+// itself - no Cholesky factor (1.0 ms at N = 512), no sweeps over all pairs (0.8 ms each) - then the slices' own k x k problems
+// T_jj = J0_j' G J0_j (k <= 96) by Cholesky + one-sided Jacobi on windows of k rows, V = J0 blockdiag(W_j), one first-order
+// refinement from V'GV for what the projectors left between slices, and a certificate max |offdiag(V'GV)| <= 8 N eps ||G||.
+// Measured at C2 (20000 x 512, rank 16; profiles/r06_ws_*): the decomposition after the loop 14.8 -> 5.8 ms.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -154,51 +161,67 @@ int small_mm_batched_start(Handle* h, const double* P, const double* K, double* 
 int matfun_sign_batched(Handle* h, const double* K, const double* K2, int64_t N, int nb, const double* t, double hi, double l0, double* X,
                         double* W1, double* W2, double** out, double* stats_dev, int* steps_out);
 int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector<std::pair<int, int>>& groups, double* V,
-                              double* sig_dev, double floor_rel, int64_t* sweeps_out);
+                              double* sig_dev, double floor_rel, int64_t* sweeps_out, bool block_diagonal);
 
 bool symeig_sliced_ok(int64_t N) { return N >= 256 && N <= 1024 && (N % 128) == 0 && !dev_is(DEV_NO_SLICED_EIG, '1'); }
 
-// Same contract as symeig_chol_f64 (B, V: N x N workspace of the caller; V = normalised eigenvectors, sig_dev = sqrt(lambda +
-// delta), unsorted).  Hints, all optional (<= 0: none): lam_hi - an upper bound of the eigenvalues of G; n_out eigenvalues are
-// known to sit at val_out, and every other one is at most bulk_hi (the deflated cluster of solver.hip and the certified bound of
-// what is left) - they only place the first split and scale the iterations.  *used = false: a guard declined, nothing has been
-// computed that the caller may use.
-int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev, double* delta_host,
-                      int64_t* sweeps_out, double lam_hi, int n_out, double val_out, double bulk_hi, bool* used) {
-    *used = false;
-    if (sweeps_out) *sweeps_out = 0;
-    if (!symeig_sliced_ok(N)) return TLSQ_OK;
-    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+namespace {
+
+struct SlicePlan {
+    ProjMap pm;
+    int nsl = 0;
+    std::vector<std::pair<int, int>> groups;   // (first column, columns) of every slice, ascending eigenvalues
+};
+
+struct SliceBufs {
+    double *K, *K2, *J, *J2, *E, *X, *W1, *W2, *PJ;
+    double *sstats;
+    int* failflag;
+};
+
+int slice_bufs(Handle* h, int64_t N, SliceBufs* b) {
     const int64_t nn = N * N;
-    const int target = [] { const char* e = dev_get(DEV_SLICE_TARGET); const int v = e ? atoi(e) : 64; return v >= 16 ? v : 64; }();
-    const int maxlev = [] { const char* e = dev_get(DEV_SLICE_LEVELS); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 8 ? v : 6; }();
-    const double l0 = [] { const char* e = dev_get(DEV_SLICE_L0); const double v = e ? atof(e) : 1e-4; return v > 0.0 && v < 0.5 ? v : 1e-4; }();
     void *scal, *buf;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-    double* cstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 192);    // cholesky: max diagonal, delta
-    double* sstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 3072);   // 4 x 8 doubles of a sign batch (2048..2448 is the SpecCtrl)
-    int* failflag = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 3328);
+    b->sstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 3072);   // 4 x 8 doubles of a sign batch (2048..2448 is the SpecCtrl)
+    b->failflag = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 3328);
     // one slab: K | K^2 | J | J' | E | 3 x 8 iterates | projectors
     const int64_t nbuf = 5 + 24 + SL_MAXSL;
     TLSQ_TRY(ws_get(h, WS_SL_BUF, (size_t)nbuf * nn * 8, &buf));
     double* base = (double*)buf;
-    double *K = base, *K2 = base + nn, *J = base + 2 * nn, *J2 = base + 3 * nn, *E = base + 4 * nn;
-    double *X = base + 5 * nn, *W1 = X + 8 * nn, *W2 = W1 + 8 * nn, *PJ = W2 + 8 * nn;
+    b->K = base;
+    b->K2 = base + nn;
+    b->J = base + 2 * nn;
+    b->J2 = base + 3 * nn;
+    b->E = base + 4 * nn;
+    b->X = base + 5 * nn;
+    b->W1 = b->X + 8 * nn;
+    b->W2 = b->W1 + 8 * nn;
+    b->PJ = b->W2 + 8 * nn;
+    return TLSQ_OK;
+}
 
-    // 1. the Cholesky factor, K = L'L and its square (second moments of the slices)
-    TLSQ_TRY(cholesky_shifted(h, G, ldG, N, B, V /* scratch */, cstats));
-    TLSQ_TRY(gemm_f64(h, true, true, B, N, B, N, K, N, N, N, N, true));
+// Step 2: the spectrum of the symmetric positive semi-definite K (N x N, in b.K; b.K2 receives its square) cut into slices of at
+// most `want` eigenvalues (SLICE_TARGET overrides); a slice of more than maxk declines.  Projectors in b.PJ, the plan in *pl.
+// *ok = false: a guard declined.
+int slice_spectrum(Handle* h, int64_t N, const SliceBufs& b, double lam_hi, int n_out, double val_out, double bulk_hi, int want,
+                   int maxk, SlicePlan* pl, bool* ok) {
+    *ok = false;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+    const int64_t nn = N * N;
+    const int target = [&] { const char* e = dev_get(DEV_SLICE_TARGET); const int v = e ? atoi(e) : 0; return v >= 16 ? std::min(v, maxk) : want; }();
+    const int maxlev = [] { const char* e = dev_get(DEV_SLICE_LEVELS); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 8 ? v : 6; }();
+    const double l0 = [] { const char* e = dev_get(DEV_SLICE_L0); const double v = e ? atof(e) : 1e-4; return v > 0.0 && v < 0.5 ? v : 1e-4; }();
+    double *K = b.K, *K2 = b.K2, *X = b.X, *W1 = b.W1, *W2 = b.W2, *PJ = b.PJ;
     TLSQ_TRY(small_mm_batched(h, K, nn, K, nn, K2, nn, N, 1, 1.0, 0.0, true, nullptr, 0, 0.0));
     double st3[3], st3b[3];
     TLSQ_TRY(matfun_stats(h, K, N, st3));   // trace, row-sum norm (host round trip)
     TLSQ_TRY(matfun_stats(h, K2, N, st3b));
     const double trK = st3[1], trK2 = st3b[1];
-    // (the eigenvalues of K are those of G + delta: the caller's bound with a little room, or Gershgorin's, or the Frobenius norm)
+    // (an upper bound of the eigenvalues: the caller's with a little room, or Gershgorin's, or the Frobenius norm)
     double hi = std::min(st3[2], std::sqrt(std::max(trK2, 0.0)) * (1.0 + 1e-12));
     if (lam_hi > 0.0) hi = std::min(hi, lam_hi * (1.0 + 1e-6) + 8.0 * (double)N * 2.3e-16 * st3[2]);
     if (!(trK > 0.0) || !std::isfinite(trK) || !(hi > 0.0) || !std::isfinite(hi) || !std::isfinite(trK2)) return TLSQ_OK;
-
-    // 2. slices
     {
         int64_t g = (nn + 255) / 256;
         if (g > 1024) g = 1024;
@@ -258,10 +281,10 @@ int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double
         TLSQ_TRY(small_mm_batched_start(h, W2, K, X, N, nb, al.data(), be.data(), ga.data()));
         double* out = nullptr;
         int steps = 0;
-        TLSQ_TRY(matfun_sign_batched(h, K, K2, N, nb, nullptr, 0.0, lev_l0, X, W1, W2, &out, sstats, &steps));
+        TLSQ_TRY(matfun_sign_batched(h, K, K2, N, nb, nullptr, 0.0, lev_l0, X, W1, W2, &out, b.sstats, &steps));
         total_steps += steps;
         nsign += nb;
-        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sstats, (size_t)nb * 32, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, b.sstats, (size_t)nb * 32, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         std::vector<double> hs((size_t)nb * 4);
         memcpy(hs.data(), h->pinned, (size_t)nb * 32);
@@ -272,9 +295,9 @@ int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double
             if (!std::isfinite(tr) || !std::isfinite(ip) || !std::isfinite(fr) || !std::isfinite(ip2)) return TLSQ_OK;
             // ||S||_F^2 = N for an exact sign matrix; what is missing are eigenvalues the schedule did not carry to +-1
             if (dbg)
-                fprintf(stderr, "  slicer: level %d, slice [%.4e, %.4e] of %.1f cut at %.6e: %.2f below, N - ||S||_F^2 = %.3e\n", lev,
+                fprintf(stderr, "  slicer: level %d, slice [%.4e, %.4e] of %.1f cut at %.6e: %.2f below, N - ||S||_F^2 = %.3e (%d steps)\n", lev,
                         sl[(size_t)cut[(size_t)q]].lo, sl[(size_t)cut[(size_t)q]].hi, sl[(size_t)cut[(size_t)q]].cnt, t[(size_t)q],
-                        0.5 * ((double)N - tr), (double)N - fr);
+                        0.5 * ((double)N - tr), (double)N - fr, steps);
             if (std::fabs((double)N - fr) > 0.05 * (double)N) return TLSQ_OK;
             cm.parent[q] = sl[(size_t)cut[(size_t)q]].slot;
             cm.low[q] = nslot + q;
@@ -289,7 +312,6 @@ int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double
             const int j = cut[(size_t)q];
             const Slice s = sl[(size_t)j];
             const double tr = hs[(size_t)q * 4], ip = hs[(size_t)q * 4 + 1], ip2 = hs[(size_t)q * 4 + 3];
-            (void)ip;
             // below the cut the sign is -1: P_low = (I - S) / 2
             const double cnt_lo = 0.5 * ((double)N - tr), sum_lo = 0.5 * (trK - ip), sum2_lo = 0.5 * (trK2 - ip2);
             Slice lo_c{s.lo, t[(size_t)q], nslot + q, cnt_lo, sum_lo, sum2_lo};
@@ -324,62 +346,196 @@ int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double
         kcol[big] += d;
         have += d;
     }
-    ProjMap pm;
-    memset(&pm, 0, sizeof(pm));
-    std::vector<std::pair<int, int>> groups;
-    int col = 0, nsl = 0;
+    memset(&pl->pm, 0, sizeof(pl->pm));
+    pl->groups.clear();
+    pl->nsl = 0;
+    int col = 0;
     for (size_t j = 0; j < sl.size(); ++j) {
         if (kcol[j] <= 0) continue;
-        if (nsl >= SL_MAXSL || kcol[j] > SL_MAXK) return TLSQ_OK;
-        pm.slot[nsl] = sl[j].slot;
-        pm.start[nsl] = col;
-        pm.k[nsl] = kcol[j];
-        ++nsl;
-        groups.push_back({col, kcol[j]});
+        if (pl->nsl >= SL_MAXSL || kcol[j] > maxk) return TLSQ_OK;
+        pl->pm.slot[pl->nsl] = sl[j].slot;
+        pl->pm.start[pl->nsl] = col;
+        pl->pm.k[pl->nsl] = kcol[j];
+        ++pl->nsl;
+        pl->groups.push_back({col, kcol[j]});
         col += kcol[j];
     }
-    if (col != (int)N || nsl < 2) return TLSQ_OK;   // (nothing was split: the plain route is the same thing)
+    if (col != (int)N || pl->nsl < 2) return TLSQ_OK;   // (nothing was split: the plain route is the same thing)
     if (dbg) {
         fprintf(stderr, "  slicer: N=%lld, %d levels, %d sign matrices (%d polynomial steps), slices:", (long long)N, levels, nsign, total_steps);
-        for (auto& g : groups) fprintf(stderr, " %d", g.second);
+        for (auto& g : pl->groups) fprintf(stderr, " %d", g.second);
         fprintf(stderr, "\n");
     }
+    *ok = true;
+    return TLSQ_OK;
+}
 
-    // 3. J0 = the Cholesky factors of the projectors, polished to orthogonality; B0 = L J0
-    TLSQ_HIP(h, hipMemsetAsync(failflag, 0, 4, h->stream));
-    hipLaunchKernelGGL(k_proj_chol, dim3((unsigned)nsl), dim3(1024), 0, h->stream, (const double*)PJ, pm, (int)N, J, failflag);
-    TLSQ_HIP(h, hipGetLastError());
-    double *Jc = J, *Jn = J2;
-    double dev2 = 0.0;
-    for (int pass = 0; pass < 5; ++pass) {
+// E = Q'Q, then Q <- Q (1.5 I - 0.5 E) while ||E - I||_F > 1e-13.5 (at most `passes` times); *Qc = where the result is (Q or Q2).
+// *ok = false: Q was too far from orthogonal to begin with (||E - I||_F > 0.5) or did not get there.
+int polish_orthogonal(Handle* h, int64_t N, double* Q, double* Q2, double* E, int passes, double** Qc_out, bool* ok, const char* tag) {
+    *ok = false;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+    const int64_t nn = N * N;
+    double *Jc = Q, *Jn = Q2;
+    double dev2 = 0.0, st3[3];
+    for (int pass = 0; pass <= passes; ++pass) {
         TLSQ_TRY(gemm_f64(h, true, true, Jc, N, Jc, N, E, N, N, N, N, true));
         TLSQ_TRY(matfun_stats(h, E, N, st3));
         dev2 = st3[0];
-        if (pass == 0) {
-            int ff = 0;
-            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, failflag, 4, hipMemcpyDeviceToHost, h->stream));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-            memcpy(&ff, h->pinned, 4);
-            if (ff) {
-                if (dbg) fprintf(stderr, "  slicer: a projector is not of its rank (pivot below 1e-3): plain route\n");
-                return TLSQ_OK;
-            }
-        }
-        if (dbg) fprintf(stderr, "  slicer: ||J0'J0 - I||_F = %.3e\n", std::sqrt(std::max(dev2, 0.0)));
+        if (dbg) fprintf(stderr, "  slicer: ||%s'%s - I||_F = %.3e\n", tag, tag, std::sqrt(std::max(dev2, 0.0)));
         if (!std::isfinite(dev2) || dev2 > 0.25) return TLSQ_OK;
-        if (dev2 <= 1e-27) break;
+        if (dev2 <= 1e-27 || pass == passes) break;
         TLSQ_TRY(matfun_axpbi(h, E, E, N, -0.5, 1.5));
         TLSQ_TRY(small_mm_batched(h, Jc, nn, E, nn, Jn, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
         std::swap(Jc, Jn);
     }
     if (dev2 > 1e-24) return TLSQ_OK;
+    *Qc_out = Jc;
+    *ok = true;
+    return TLSQ_OK;
+}
+
+// Step 3: J0 = the Cholesky factors of the projectors (b.J / b.J2), polished to orthogonality
+int slices_to_basis(Handle* h, int64_t N, const SliceBufs& b, const SlicePlan& pl, double** J0, bool* ok) {
+    *ok = false;
+    TLSQ_HIP(h, hipMemsetAsync(b.failflag, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_proj_chol, dim3((unsigned)pl.nsl), dim3(1024), 0, h->stream, (const double*)b.PJ, pl.pm, (int)N, b.J, b.failflag);
+    TLSQ_HIP(h, hipGetLastError());
+    bool pok = false;
+    TLSQ_TRY(polish_orthogonal(h, N, b.J, b.J2, b.E, 4, J0, &pok, "J0"));
+    int ff = 0;
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, b.failflag, 4, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(&ff, h->pinned, 4);
+    if (ff) {
+        if (dev_get(DEV_DEBUG)) fprintf(stderr, "  slicer: a projector is not of its rank (pivot below 1e-3): plain route\n");
+        return TLSQ_OK;
+    }
+    *ok = pok;
+    return TLSQ_OK;
+}
+
+// ---- the slices' own eigenproblems: Cholesky factors of the diagonal blocks of T = J0' G J0, one workgroup per slice -----------
+// C_j C_j' = T_jj (k x k, k <= 96, in LDS; the eigenvalues of a slice lie within a few per cent of each other: no pivoting, no
+// shift) written to the diagonal block of Bd (N x N, zero elsewhere - cleared by the caller).  One-sided Jacobi on the columns of
+// Bd (jacobi.hip, the register kernel on the blocks' own row windows) then gives the eigenvectors of every T_jj at once.
+// fail[0] != 0: a pivot was not positive.
+__global__ __launch_bounds__(1024) void k_chol_blocks(const double* __restrict__ T, int N, ProjMap m, double* __restrict__ Bd,
+                                                      int* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) double cb_sm[];
+    const int blk = blockIdx.x, k = m.k[blk], c0 = m.start[blk];
+    const int LD = k + 1, tid = threadIdx.x;
+    double* S = cb_sm;   // S[c * LD + r], lower triangle used
+    for (int e = tid; e < k * k; e += 1024) {
+        const int r = e % k, c = e / k;
+        S[c * LD + r] = 0.5 * (T[(c0 + r) + (int64_t)(c0 + c) * N] + T[(c0 + c) + (int64_t)(c0 + r) * N]);
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const double piv = S[j * LD + j];
+        __syncthreads();   // (everybody has read the pivot before column j is scaled)
+        if (!(piv > 0.0)) {
+            if (tid == 0) atomicExch(fail, 1);
+            return;
+        }
+        const double inv = 1.0 / sqrt(piv);
+        for (int r = j + tid; r < k; r += 1024) S[j * LD + r] *= inv;
+        __syncthreads();
+        // trailing update: S[c][r] -= S[j][r] S[j][c] for j < c <= r < k
+        const int nc = k - j - 1;
+        for (int e = tid; e < nc * nc; e += 1024) {
+            const int c = j + 1 + e / nc, r = j + 1 + e % nc;
+            if (r >= c) S[c * LD + r] -= S[j * LD + r] * S[j * LD + c];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k * k; e += 1024) {
+        const int r = e % k, c = e / k;
+        Bd[(c0 + r) + (int64_t)(c0 + c) * N] = r >= c ? S[c * LD + r] : 0.0;
+    }
+}
+
+// X (N x N) from T = V'GV: X[i, j] = tan of the Jacobi angle of the pair (i, j) - to first order the rotation that removes
+// T[i, j] - antisymmetric; zero where |T[i, j]| <= floor_abs (the rounding level of T itself: pairs of equal eigenvalues - the
+// deflated cluster - would otherwise be "rotated" by their noise) or below the relative rotation threshold.  V <- V (I + X).
+// Pairs inside columns [c0, c1) - the caller's known cluster of equal eigenvalues, where every orthonormal basis is as good as any
+// other - and pairs whose tangent would exceed 0.05 (not a first-order correction any more) are left alone.
+__global__ __launch_bounds__(256) void k_refine_x(const double* __restrict__ T, int N, double tol, double floor_abs, int c0, int c1,
+                                                  double* __restrict__ X) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        double x = 0.0;
+        if (i != j && !(i >= c0 && i < c1 && j >= c0 && j < c1)) {
+            const double hii = T[i + (int64_t)i * N], hjj = T[j + (int64_t)j * N];
+            const double hij = 0.5 * (T[e] + T[j + (int64_t)i * N]);
+            if (fabs(hij) > floor_abs && hij * hij > tol * tol * fabs(hii * hjj)) {
+                const double d = hjj - hii;
+                x = (d >= 0.0 ? 2.0 : -2.0) * hij / (fabs(d) + sqrt(d * d + 4.0 * hij * hij));
+                if (fabs(x) > 0.05) x = 0.0;
+            }
+        }
+        X[e] = x;
+    }
+}
+
+// lam[i] = T[i, i]; out[0] = max over i != j (not both in [c0, c1)) of |T[i, j]| as bits (atomicMax on non-negative doubles)
+__global__ __launch_bounds__(256) void k_offdiag_max(const double* __restrict__ T, int N, int c0, int c1, double* __restrict__ lam,
+                                                     unsigned long long* __restrict__ out) {
+    const int64_t total = (int64_t)N * N;
+    double m = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % N), j = (int)(e / N);
+        const double v = T[e];
+        if (i == j) lam[i] = v;
+        else if (!(i >= c0 && i < c1 && j >= c0 && j < c1)) m = fabs(v) > m ? fabs(v) : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+}   // namespace
+
+// Same contract as symeig_chol_f64 (B, V: N x N workspace of the caller; V = normalised eigenvectors, sig_dev = sqrt(lambda +
+// delta), unsorted).  Hints, all optional (<= 0: none): lam_hi - an upper bound of the eigenvalues of G; n_out eigenvalues are
+// known to sit at val_out, and every other one is at most bulk_hi (the deflated cluster of solver.hip and the certified bound of
+// what is left) - they only place the first split and scale the iterations.  *used = false: a guard declined, nothing has been
+// computed that the caller may use.
+int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, double* sig_dev, double* delta_host,
+                      int64_t* sweeps_out, double lam_hi, int n_out, double val_out, double bulk_hi, bool* used) {
+    *used = false;
+    if (sweeps_out) *sweeps_out = 0;
+    if (!symeig_sliced_ok(N)) return TLSQ_OK;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+    const int64_t nn = N * N;
+    SliceBufs b;
+    TLSQ_TRY(slice_bufs(h, N, &b));
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    double* cstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 192);    // cholesky: max diagonal, delta
+
+    // 1. the Cholesky factor and K = L'L
+    TLSQ_TRY(cholesky_shifted(h, G, ldG, N, B, V /* scratch */, cstats));
+    TLSQ_TRY(gemm_f64(h, true, true, B, N, B, N, b.K, N, N, N, N, true));
+    // 2. slices, 3. their basis
+    SlicePlan pl;
+    bool ok = false;
+    TLSQ_TRY(slice_spectrum(h, N, b, lam_hi, n_out, val_out, bulk_hi, 80, SL_MAXK, &pl, &ok));
+    if (!ok) return TLSQ_OK;
+    double* J0 = nullptr;
+    TLSQ_TRY(slices_to_basis(h, N, b, pl, &J0, &ok));
+    if (!ok) return TLSQ_OK;
     // B0 = L J0 into K's place, then back into the caller's B (L is not needed any more)
-    TLSQ_TRY(small_mm_batched(h, B, nn, Jc, nn, K, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
-    TLSQ_HIP(h, hipMemcpyAsync(B, K, (size_t)nn * 8, hipMemcpyDeviceToDevice, h->stream));
+    TLSQ_TRY(small_mm_batched(h, B, nn, J0, nn, b.K, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
+    TLSQ_HIP(h, hipMemcpyAsync(B, b.K, (size_t)nn * 8, hipMemcpyDeviceToDevice, h->stream));
 
     // 4. + 5. sweeps inside the slices, then over all pairs
     int64_t sw[2] = {0, 0};
-    const int stj = jacobi_factor_grouped_f64(h, B, N, groups, V, sig_dev, (double)N * 2.220446049250313e-16, sw);
+    const int stj = jacobi_factor_grouped_f64(h, B, N, pl.groups, V, sig_dev, (double)N * 2.220446049250313e-16, sw, false);
     if (dbg) fprintf(stderr, "  slicer: %lld sweeps inside the slices, %lld over all pairs\n", (long long)sw[0], (long long)sw[1]);
     if (sweeps_out) *sweeps_out = sw[0] + sw[1];
     TLSQ_HIP(h, hipMemcpyAsync(h->pinned, cstats, 16, hipMemcpyDeviceToHost, h->stream));
@@ -388,6 +544,129 @@ int symeig_sliced_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double
     memcpy(cs, h->pinned, 16);
     if (delta_host) *delta_host = cs[1];
     if (stj < 0) return stj;
+    *used = true;
+    return TLSQ_OK;
+}
+
+// The normwise form, on G itself (no Cholesky factor, no sweeps over all pairs): slices of G, their basis J0, the slices' own
+// eigenproblems T_jj = J0_j' G J0_j by one-sided Jacobi on their Cholesky factors (all slices side by side, the register kernel
+// on windows of <= 96 rows), V = J0 blockdiag(W_j); what the
+// projectors left between the slices is removed to first order from T = V'GV (V <- V (I + X), X the pairwise Jacobi tangents,
+// polished back to orthogonality) - twice at most - and the result is CERTIFIED: max_{i != j} |(V'GV)_ij| <= 8 N eps lam_hi, i.e.
+// V diagonalises G to the accuracy of a backward-stable eigensolver; lam_dev = diag(V'GV).  (Pairs inside the caller's cluster of
+// n_out equal eigenvalues are exempt: its span is what matters, the caller replaces the basis by its own.)  That is an absolute statement
+// (eps ||G||): right for the deflated panel of the returned `s` (solver.hip), whose spectrum is one cluster and a flat bulk a
+// bounded factor below it - the caller's guards - and not a replacement for the factor route on graded spectra.
+// V: N x N result; lam_dev: N eigenvalues (unsorted).  *used = false: a guard or the certificate declined.
+int symeig_sliced_normwise_f64(Handle* h, const double* G, int64_t N, double* V, double* lam_dev, int64_t* sweeps_out, double lam_hi,
+                               int n_out, double val_out, double bulk_hi, bool* used) {
+    *used = false;
+    if (sweeps_out) *sweeps_out = 0;
+    if (!symeig_sliced_ok(N) || dev_is(DEV_SLICE_NORMWISE, '0') || !(lam_hi > 0.0)) return TLSQ_OK;
+    const bool dbg = dev_get(DEV_DEBUG) != nullptr;
+    const int64_t nn = N * N;
+    const double eps = 2.220446049250313e-16;
+    SliceBufs b;
+    TLSQ_TRY(slice_bufs(h, N, &b));
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    unsigned long long* omax = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scal) + 3336);
+    TLSQ_HIP(h, hipMemcpyAsync(b.K, G, (size_t)nn * 8, hipMemcpyDeviceToDevice, h->stream));
+    SlicePlan pl;
+    bool ok = false;
+    TLSQ_TRY(slice_spectrum(h, N, b, lam_hi, n_out, val_out, bulk_hi, 96, 96, &pl, &ok));
+    if (!ok) return TLSQ_OK;
+    double* J0 = nullptr;
+    TLSQ_TRY(slices_to_basis(h, N, b, pl, &J0, &ok));
+    if (!ok) return TLSQ_OK;
+    // T = J0' (G J0)
+    double *GJ = b.X, *T = b.X + nn, *Wb = b.X + 2 * nn, *Xr = b.X + 3 * nn, *Vn = b.W1, *Vn2 = b.W1 + nn;
+    TLSQ_TRY(small_mm_batched(h, b.K, nn, J0, nn, GJ, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
+    TLSQ_TRY(gemm_f64(h, true, true, J0, N, GJ, N, T, N, N, N, N, false));
+    // the slices' eigenproblems: Cholesky factors of the diagonal blocks, one-sided Jacobi on them side by side, W = the
+    // normalised rotated columns (block diagonal)
+    int maxk = 0;
+    for (auto& g : pl.groups) maxk = std::max(maxk, g.second);
+    const size_t lds = (size_t)maxk * (maxk + 1) * 8;
+    double* Bd = Xr;   // (free until the refinement)
+    TLSQ_HIP(h, hipMemsetAsync(Bd, 0, (size_t)nn * 8, h->stream));
+    TLSQ_HIP(h, hipMemsetAsync(b.failflag, 0, 4, h->stream));
+    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_chol_blocks, dim3((unsigned)pl.nsl), dim3(1024), lds, h->stream, (const double*)T, (int)N, pl.pm, Bd, b.failflag);
+    TLSQ_HIP(h, hipGetLastError());
+    int64_t swb[2] = {0, 0};
+    {
+        const int stj = jacobi_factor_grouped_f64(h, Bd, N, pl.groups, Wb, lam_dev /* scratch: the column norms */, 0.0, swb, true);
+        if (stj == TLSQ_ERR_NOCONV) return TLSQ_OK;
+        if (stj < 0) return stj;
+        int ff = 0;
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, b.failflag, 4, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        memcpy(&ff, h->pinned, 4);
+        if (ff) return TLSQ_OK;
+    }
+    // V = J0 W
+    TLSQ_TRY(small_mm_batched(h, J0, nn, Wb, nn, Vn, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
+    if (dbg) {   // diagnosis: orthogonality of W and of V = J0 W as they come out of the slices' eigenproblems
+        double st3[3];
+        TLSQ_TRY(gemm_f64(h, true, true, Wb, N, Wb, N, b.E, N, N, N, N, true));
+        TLSQ_TRY(matfun_stats(h, b.E, N, st3));
+        fprintf(stderr, "  slicer (normwise): ||W'W - I||_F = %.3e", std::sqrt(std::max(st3[0], 0.0)));
+        TLSQ_TRY(gemm_f64(h, true, true, Vn, N, Vn, N, b.E, N, N, N, N, true));
+        TLSQ_TRY(matfun_stats(h, b.E, N, st3));
+        fprintf(stderr, ", ||V'V - I||_F = %.3e, %lld sweeps inside the slices\n", std::sqrt(std::max(st3[0], 0.0)), (long long)swb[0]);
+    }
+    double* Vc = Vn;
+    double* Vo = Vn2;
+    const double cert = 8.0 * (double)N * eps * lam_hi;
+    // the caller's cluster (n_out eigenvalues at val_out): the columns of the top slice when it is exactly that; any orthonormal
+    // basis of its span serves (the caller puts its own vectors there), so pairs inside it are neither refined nor certified
+    int cl0 = 0, cl1 = 0;
+    if (n_out > 0 && !pl.groups.empty() && pl.groups.back().second == n_out) {
+        cl0 = pl.groups.back().first;
+        cl1 = cl0 + n_out;
+    }
+    double offmax = 0.0;
+    bool certified = false;
+    for (int pass = 0; pass < 3 && !certified; ++pass) {
+        // T = V'(G V), its largest off-diagonal entry and its diagonal
+        TLSQ_TRY(small_mm_batched(h, b.K, nn, Vc, nn, GJ, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
+        TLSQ_TRY(gemm_f64(h, true, true, Vc, N, GJ, N, T, N, N, N, N, false));
+        TLSQ_HIP(h, hipMemsetAsync(omax, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_offdiag_max, dim3(256), dim3(256), 0, h->stream, (const double*)T, (int)N, cl0, cl1, lam_dev, omax);
+        TLSQ_HIP(h, hipGetLastError());
+        TLSQ_HIP(h, hipMemcpyAsync(h->pinned, omax, 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        memcpy(&offmax, h->pinned, 8);
+        if (dbg) fprintf(stderr, "  slicer (normwise): max off-diagonal of V'GV = %.3e (certificate %.3e)\n", offmax, cert);
+        if (!std::isfinite(offmax)) return TLSQ_OK;
+        if (offmax <= cert) {
+            certified = true;
+            break;
+        }
+        if (pass == 2) break;
+        // V <- polish(V (I + X))
+        {
+            int64_t g = (nn + 255) / 256;
+            if (g > 1024) g = 1024;
+            hipLaunchKernelGGL(k_refine_x, dim3((unsigned)g), dim3(256), 0, h->stream, (const double*)T, (int)N, 2.0 * eps, 0.125 * cert, cl0, cl1, Xr);
+            TLSQ_HIP(h, hipGetLastError());
+        }
+        if (dbg) {
+            double st3[3];
+            TLSQ_TRY(matfun_stats(h, Xr, N, st3));
+            fprintf(stderr, "  slicer (normwise): ||X||_F = %.3e, row-sum norm %.3e\n", std::sqrt(std::max(st3[0] - (double)N, 0.0)), st3[2]);
+        }
+        TLSQ_TRY(small_mm_batched(h, Vc, nn, Xr, nn, Vo, nn, N, 1, 1.0, 0.0, false, Vc, nn, 1.0));
+        double* Vp = nullptr;
+        bool pok = false;
+        TLSQ_TRY(polish_orthogonal(h, N, Vo, Vc, b.E, 3, &Vp, &pok, "V"));
+        if (!pok) return TLSQ_OK;
+        if (Vp == Vo) std::swap(Vc, Vo);   // (the polished matrix is in Vo: it becomes the current one; otherwise it is in Vc already)
+    }
+    if (!certified) return TLSQ_OK;
+    TLSQ_HIP(h, hipMemcpyAsync(V, Vc, (size_t)nn * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (sweeps_out) *sweeps_out = swb[0];
     *used = true;
     return TLSQ_OK;
 }

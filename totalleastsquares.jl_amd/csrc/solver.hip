@@ -2222,9 +2222,30 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 TLSQ_TRY(gram_allreduce<T>(h, R, M, N, M, &GP, WS_G2));
                 double* V2 = nullptr;
                 SmallSvd s2;
-                // (hints for the slicer: every eigenvalue of G_P is at most s^2, and |S| of them sit there)
-                // and everything else is at most next^2 - Ritz values converged to 1e-13 and the loop's count certificate)
-                TLSQ_TRY(eig_full(h, GP, N, &V2, s2, &sweeps, false, WS_V, false, slev * slev, (int)cnt, slev * slev, next * next));
+                // (hints for the slicer: every eigenvalue of G_P is at most s^2, |S| of them sit there, and everything else is at
+                //  most next^2 - Ritz values converged to 1e-13 and the loop's count certificate)
+                // Round 6: the normwise sliced solver on G_P itself (sliced.hip) where it applies - the guards below hold its
+                // result to the same conditions - otherwise Cholesky + Jacobi as before.
+                bool nw = false;
+                {
+                    void *Vn, *lamn;
+                    TLSQ_TRY(ws_get(h, WS_V, (size_t)N * N * 8, &Vn));
+                    TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lamn));
+                    int64_t sw_n = 0;
+                    TLSQ_TRY(symeig_sliced_normwise_f64(h, GP, N, (double*)Vn, (double*)lamn, &sw_n, slev * slev, (int)cnt, slev * slev,
+                                                        next * next, &nw));
+                    if (nw) {
+                        s2.sigma.resize((size_t)N);
+                        TLSQ_HIP(h, hipMemcpyAsync(s2.sigma.data(), lamn, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+                        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                        for (auto& v : s2.sigma) v = std::sqrt(std::max(v, 0.0));
+                        s2.ncols = N;
+                        sort_desc(s2);
+                        V2 = (double*)Vn;
+                        sweeps += sw_n;
+                    }
+                }
+                if (!nw) TLSQ_TRY(eig_full(h, GP, N, &V2, s2, &sweeps, false, WS_V, false, slev * slev, (int)cnt, slev * slev, next * next));
                 bool good = s2.ncols == N;
                 for (int64_t i = 0; i < cnt && good; ++i)
                     good = std::fabs(s2.sigma[(size_t)s2.order[(size_t)i]] - slev) <= 1e-6 * slev;
@@ -2266,7 +2287,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     }
     if (S_host && V)
         for (int64_t p = 0; p < d; ++p) S_host[p] = s.sigma[s.order[p]];
-    if (Vt_host && V) {
+    if (Vt_host && V && ro.vt_dev && ro.vt_written && d <= N) {
+        // Vt[p, j] = V[j, order[p]] straight into the caller's (or the entry layer's) device buffer
+        void* ordp;
+        TLSQ_TRY(ws_get(h, WS_AUX0, (size_t)d * 16 + 64, &ordp));
+        TLSQ_TRY(upload_async(h, ordp, s.order.data(), (size_t)d * 4));
+        TLSQ_TRY(launch_vt_out<T>(h, V, N, (const int32_t*)ordp, d, (T*)ro.vt_dev, ro.vt_ld));
+        *ro.vt_written = true;
+    } else if (Vt_host && V) {
         std::vector<double> hv((size_t)N * N);
         TLSQ_HIP(h, hipMemcpyAsync(hv.data(), V, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
