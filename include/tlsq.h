@@ -59,7 +59,11 @@ enum { TLSQ_OPNORM_EXACT = 0, TLSQ_OPNORM_POWER = 1, TLSQ_OPNORM_CALLBACK = 2 };
  *              (buffers hold min(M,N) triplets); return 0, anything else aborts the call with TLSQ_ERR_ARG.
  *   opnorm_cb: returns the norm estimate of X (M x N, ldX).
  * For a wide input (M < N, unsharded) the library works on the transposed problem and the hooks receive that panel
- * (N x M): singular values and norms are the same, U and V swap roles consistently.  Not available on row shards. */
+ * (N x M): singular values and norms are the same, U and V swap roles consistently.
+ * Row shards (a tlsq_create_multi group, or one handle per GPU joined by tlsq_comm_init): every use of a hook gathers the
+ * shards, RANK 0 calls its hook on the whole M_global x N panel - on the calling thread of a group handle; in rank 0's
+ * process otherwise, the other ranks' pointers only have to be non-NULL - and the results are sent back to the ranks
+ * (the panel crosses PCIe twice per use: correct, and slow like every host hook). */
 typedef int (*tlsq_svd_cb)(const void* Z, int64_t M, int64_t N, int64_t ldZ, int64_t sv, void* U, int64_t ldU, void* S,
                            void* Vt, int64_t ldVt, int64_t* k_out, void* user);
 typedef double (*tlsq_opnorm_cb)(const void* X, int64_t M, int64_t N, int64_t ldX, void* user);

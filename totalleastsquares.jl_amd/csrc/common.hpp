@@ -165,6 +165,7 @@ enum WsSlot {
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
     WS_C32_F, WS_C32_D, WS_C32_A, WS_C32_E, WS_C32_U, WS_C32_V, WS_C32_S,   // ComplexF32 entry (api.hip): float staging, widened panels
+    WS_CBS, WS_CBR,   // svd / opnorm callbacks on row shards (solver.hip): send block, gathered panel
     WS_VTOUT,   // the returned Vt of a host-pointer call on its way out (entry.hip)
     WS_SL_BUF, WS_SL_TAB,   // spectrum slicer in front of the accurate route's Jacobi (sliced.hip): N x N iterates, block-pair table
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction

@@ -126,10 +126,10 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         if (dev_mem)
             return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: a multi-GPU handle takes host matrices (device pointers belong "
                            "to one GPU; use one handle per GPU with tlsq_comm_init for device-resident shards)");
-        // tall problems with enough rows per GPU are row-sharded; anything else - and every call with a caller's svd / opnorm
-        // hook, which needs the whole matrix in one place (include/tlsq.h) - runs on the first GPU alone
-        const bool hook_cb = opts && (opts->svd_mode == TLSQ_SVD_CALLBACK || opts->opnorm_mode == TLSQ_OPNORM_CALLBACK);
-        if (!hook_cb && M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
+        // tall problems with enough rows per GPU are row-sharded (a caller's svd / opnorm hook included: the shards are
+        // gathered for every call of the hook, which runs on the calling thread - rank 0's - solver.hip); anything else runs on
+        // the first GPU alone
+        if (M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
             return rpca_multi<T>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
     }
     TLSQ_HIP(h, hipSetDevice(h->device));

@@ -620,10 +620,90 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     if (opts && ((opts->svd_mode == TLSQ_SVD_CALLBACK && !opts->svd_cb) ||
                  (opts->opnorm_mode == TLSQ_OPNORM_CALLBACK && !opts->opnorm_cb)))
         return set_err(h, TLSQ_ERR_ARG, "rpca: callback mode without a callback");
-    if ((cb_svd || cb_opnorm) && h->comm)
-        return set_err(h, TLSQ_ERR_UNSUPPORTED, "rpca: svd / opnorm callbacks need the whole matrix on one GPU (not row shards)");
+    // Callbacks on ROW SHARDS (round 6; the reference takes hooks everywhere, :168-169): a closure of the host language needs the
+    // whole panel in one place, so every use gathers the shards (one all-gather of row-padded blocks), rank 0 assembles the
+    // M_global x N panel on its host and calls the hook there - on the calling thread of a group handle, in rank 0's process
+    // with one handle per GPU (the other ranks' callback pointers are never called) - and what comes back travels to the other
+    // ranks as sums with zeros.  Correct and slow by construction (the panel crosses PCIe twice per use), like the single-GPU form.
+    const bool cb_shards = (cb_svd || cb_opnorm) && h->comm != nullptr;
+    std::vector<int64_t> cb_rows;       // rows of every rank's shard
+    int64_t cb_maxM = M;                // largest shard
+    const int64_t Mg = ro.m_global;
+    if (cb_shards) {
+        void *s1, *g1;
+        TLSQ_TRY(ws_get(h, WS_AUX2, (size_t)std::max(h->nranks, 8) * 8, &g1));
+        TLSQ_TRY(ws_get(h, WS_AUX3, 64, &s1));
+        const double mine = (double)M;
+        std::vector<double> all((size_t)h->nranks);
+        TLSQ_HIP(h, hipMemcpyAsync(s1, &mine, 8, hipMemcpyHostToDevice, h->stream));
+        TLSQ_TRY(comm_allgather(h, (const double*)s1, (double*)g1, 1));
+        TLSQ_HIP(h, hipMemcpyAsync(all.data(), g1, (size_t)h->nranks * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        int64_t tot = 0;
+        for (int q = 0; q < h->nranks; ++q) {
+            cb_rows.push_back((int64_t)all[(size_t)q]);
+            cb_maxM = std::max(cb_maxM, cb_rows.back());
+            tot += cb_rows.back();
+        }
+        if (tot != Mg)
+            return set_err(h, TLSQ_ERR_ARG, "rpca: the row blocks of the ranks add up to %lld rows, m_global says %lld", (long long)tot,
+                           (long long)Mg);
+    }
     std::vector<T> cbZ, cbU, cbS, cbVt;
+    // the whole panel on rank 0's host (cbZ: Mg x N, ld Mg); the other ranks only take part in the collective
+    auto gather_panel = [&](const T* P) -> int {
+        const size_t chunk_bytes = ((size_t)cb_maxM * N * sizeof(T) + 7) / 8 * 8, cnt = chunk_bytes / 8;
+        void *sb, *rb;
+        TLSQ_TRY(ws_get(h, WS_CBS, chunk_bytes, &sb));
+        TLSQ_TRY(ws_get(h, WS_CBR, chunk_bytes * (size_t)h->nranks, &rb));
+        TLSQ_HIP(h, hipMemsetAsync(sb, 0, chunk_bytes, h->stream));
+        TLSQ_TRY(copy2d(h, sb, cb_maxM, P, M, M, N, sizeof(T), hipMemcpyDeviceToDevice));
+        TLSQ_TRY(comm_allgather(h, (const double*)sb, (double*)rb, cnt));
+        if (h->rank == 0) {
+            std::vector<T> tmp((size_t)cb_maxM * N);
+            cbZ.resize((size_t)Mg * N);
+            int64_t r0 = 0;
+            for (int q = 0; q < h->nranks; ++q) {
+                TLSQ_HIP(h, hipMemcpyAsync(tmp.data(), (const char*)rb + (size_t)q * chunk_bytes, (size_t)cb_maxM * N * sizeof(T),
+                                           hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                for (int64_t j = 0; j < N; ++j)
+                    memcpy(cbZ.data() + (size_t)(r0 + j * Mg), tmp.data() + (size_t)(j * cb_maxM), (size_t)cb_rows[(size_t)q] * sizeof(T));
+                r0 += cb_rows[(size_t)q];
+            }
+        } else {
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        return TLSQ_OK;
+    };
+    // `count` doubles that only rank 0 holds (host) -> every rank's host copy (a sum with zeros)
+    auto bcast_from_rank0 = [&](double* v, size_t count) -> int {
+        if (count == 0) return TLSQ_OK;
+        void* b;
+        TLSQ_TRY(ws_get(h, WS_CBS, count * 8, &b));
+        if (h->rank == 0) TLSQ_HIP(h, hipMemcpyAsync(b, v, count * 8, hipMemcpyHostToDevice, h->stream));
+        else TLSQ_HIP(h, hipMemsetAsync(b, 0, count * 8, h->stream));
+        TLSQ_TRY(comm_allreduce(h, (double*)b, count, ncclSum));
+        TLSQ_HIP(h, hipMemcpyAsync(v, b, count * 8, hipMemcpyDeviceToHost, h->stream));
+        TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        return TLSQ_OK;
+    };
     auto opnorm_callback = [&](const T* P, double* out) -> int {
+        if (cb_shards) {
+            TLSQ_TRY(gather_panel(P));
+            double v[2] = {0.0, 0.0};   // the value, "not usable"
+            if (h->rank == 0) {
+                v[0] = opts->opnorm_cb(cbZ.data(), Mg, N, Mg, opts->user);
+                if (!std::isfinite(v[0]) || v[0] < 0.0) {
+                    v[1] = 1.0;
+                    v[0] = 0.0;
+                }
+            }
+            TLSQ_TRY(bcast_from_rank0(v, 2));
+            if (v[1] != 0.0) return set_err(h, TLSQ_ERR_ARG, "rpca: the opnorm callback returned a negative or non-finite value");
+            *out = v[0];
+            return TLSQ_OK;
+        }
         cbZ.resize((size_t)n);
         TLSQ_HIP(h, hipMemcpyAsync(cbZ.data(), P, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -1341,22 +1421,44 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             // thread), and A = U[:,1:svp] diag(S - 1/mu) Vt[1:svp,:] is rebuilt from the returned factors exactly as the
             // reference does (:205-213) - the hook may be approximate, so Z V V' is not a substitute.
             pt.mark(true);
-            const int64_t dd = std::min(M, N);
-            cbZ.resize((size_t)n);
-            cbU.resize((size_t)M * dd);
-            cbS.resize((size_t)dd);
-            cbVt.resize((size_t)dd * N);
-            TLSQ_HIP(h, hipMemcpyAsync(cbZ.data(), Z, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+            const int64_t dd = std::min(cb_shards ? Mg : M, N);
             int64_t kout = 0;
-            const int cst = opts->svd_cb(cbZ.data(), M, N, M, sv, cbU.data(), M, cbS.data(), cbVt.data(), dd, &kout,
-                                         opts->user);
-            if (cst != 0 || kout < 0 || kout > dd)
-                return set_err(h, TLSQ_ERR_ARG, "rpca: the svd callback failed (status %d, %lld triplets)", cst, (long long)kout);
+            std::vector<double> shS;   // row shards: the hook's singular values on every rank
+            if (cb_shards) {
+                TLSQ_TRY(gather_panel(Z));
+                double hd[2] = {0.0, 0.0};   // triplets, "failed"
+                if (h->rank == 0) {
+                    cbU.resize((size_t)Mg * dd);
+                    cbS.resize((size_t)dd);
+                    cbVt.resize((size_t)dd * N);
+                    const int cst = opts->svd_cb(cbZ.data(), Mg, N, Mg, sv, cbU.data(), Mg, cbS.data(), cbVt.data(), dd, &kout, opts->user);
+                    if (cst != 0 || kout < 0 || kout > dd) hd[1] = 1.0;
+                    else hd[0] = (double)kout;
+                }
+                TLSQ_TRY(bcast_from_rank0(hd, 2));
+                if (hd[1] != 0.0) return set_err(h, TLSQ_ERR_ARG, "rpca: the svd callback failed on rank 0");
+                kout = (int64_t)hd[0];
+                shS.assign((size_t)std::max<int64_t>(kout, 1), 0.0);
+                if (h->rank == 0)
+                    for (int64_t i = 0; i < kout; ++i) shS[(size_t)i] = (double)cbS[(size_t)i];
+                TLSQ_TRY(bcast_from_rank0(shS.data(), (size_t)kout));
+            } else {
+                cbZ.resize((size_t)n);
+                cbU.resize((size_t)M * dd);
+                cbS.resize((size_t)dd);
+                cbVt.resize((size_t)dd * N);
+                TLSQ_HIP(h, hipMemcpyAsync(cbZ.data(), Z, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+                TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+                const int cst = opts->svd_cb(cbZ.data(), M, N, M, sv, cbU.data(), M, cbS.data(), cbVt.data(), dd, &kout,
+                                             opts->user);
+                if (cst != 0 || kout < 0 || kout > dd)
+                    return set_err(h, TLSQ_ERR_ARG, "rpca: the svd callback failed (status %d, %lld triplets)", cst, (long long)kout);
+            }
+            auto cb_sigma = [&](int64_t i) { return cb_shards ? shS[(size_t)i] : (double)cbS[(size_t)i]; };
             svp = 0;                                                   // :198
-            for (int64_t i = 0; i < kout; ++i) svp += ((double)cbS[(size_t)i] >= inv_mu) ? 1 : 0;
+            for (int64_t i = 0; i < kout; ++i) svp += (cb_sigma(i) >= inv_mu) ? 1 : 0;
             sv = std::min(std::max<int64_t>(svp, 1), ro.maxrank);      // :199-204
-            sigma_top = kout > 0 ? (double)cbS[0] : 0.0;
+            sigma_top = kout > 0 ? cb_sigma(0) : 0.0;
             sigma_top_prev = sigma_top;
             mu_next = std::min(mu * ro.rho, mubar);                    // :223
             fuse = !no_fuse && k < ro.iters;
@@ -1366,6 +1468,28 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             if (svp > 0) {
                 // the first svp triplets in the hook's order (the reference indexes 1:svp as well)
                 std::vector<double> hT((size_t)M * svp), hV((size_t)N * svp);
+                if (cb_shards) {
+                    // rank 0 holds U (Mg x dd) and Vt: the scaled left factors go out as one buffer of row-padded blocks (every
+                    // rank keeps its own), the right ones as they are
+                    std::vector<double> allT((size_t)h->nranks * cb_maxM * svp, 0.0);
+                    if (h->rank == 0) {
+                        int64_t r0 = 0;
+                        for (int q = 0; q < h->nranks; ++q) {
+                            for (int64_t p = 0; p < svp; ++p) {
+                                const double gp = ro.nukeA ? cb_sigma(p) - inv_mu : cb_sigma(p);     // :205-213
+                                for (int64_t i = 0; i < cb_rows[(size_t)q]; ++i)
+                                    allT[(size_t)(((int64_t)q * svp + p) * cb_maxM + i)] = (double)cbU[(size_t)(r0 + i + p * Mg)] * gp;
+                            }
+                            r0 += cb_rows[(size_t)q];
+                        }
+                        for (int64_t p = 0; p < svp; ++p)
+                            for (int64_t j = 0; j < N; ++j) hV[(size_t)(j + p * N)] = (double)cbVt[(size_t)(p + j * dd)];
+                    }
+                    TLSQ_TRY(bcast_from_rank0(allT.data(), allT.size()));
+                    TLSQ_TRY(bcast_from_rank0(hV.data(), hV.size()));
+                    for (int64_t p = 0; p < svp; ++p)
+                        for (int64_t i = 0; i < M; ++i) hT[(size_t)(i + p * M)] = allT[(size_t)(((int64_t)h->rank * svp + p) * cb_maxM + i)];
+                } else
                 for (int64_t p = 0; p < svp; ++p) {
                     const double sg = (double)cbS[(size_t)p];
                     const double gp = ro.nukeA ? sg - inv_mu : sg;     // :205-213

@@ -909,11 +909,38 @@ __global__ __launch_bounds__(256) void k_maxabs(const T* __restrict__ x, int64_t
                                                 unsigned long long* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double m = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double v = fabs((double)x[i]);
+    auto take = [&](T xv) {
+        double v = fabs((double)xv);
         if (!(v <= 1.7976931348623157e308)) v = __longlong_as_double(0x7FF0000000000000ll);   // NaN counts as Inf: "not finite"
         m = v > m ? v : m;
+    };
+    // 16-byte loads, four of them in flight per thread (8-byte loads one at a time: 2.3 TB/s, 35 us of the C2 set-up);
+    // the order of a maximum does not matter
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    int64_t i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int64_t nv = n / VE;
+        const vec_t* xv = reinterpret_cast<const vec_t*>(x);
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < nv; i += 4 * stride) {
+            const vec_t a = xv[i], b = xv[i + stride], c = xv[i + 2 * stride], d = xv[i + 3 * stride];
+#pragma unroll
+            for (int q = 0; q < VE; ++q) {
+                take(a[q]);
+                take(b[q]);
+                take(c[q]);
+                take(d[q]);
+            }
+        }
+        for (; i < nv; i += stride) {
+            const vec_t a = xv[i];
+#pragma unroll
+            for (int q = 0; q < VE; ++q) take(a[q]);
+        }
+        i0 = nv * VE;
     }
+    for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) take(x[i]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         double o = __shfl_down(m, off, 64);
