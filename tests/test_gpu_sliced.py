@@ -58,3 +58,46 @@ def test_rtls_through_the_slicer(eng):
         x1 = eng.rtls(Amat, y)
     assert np.linalg.norm(x - x1) <= 1e-9 * np.linalg.norm(x1)
     assert np.all(np.isfinite(x))
+
+
+# ---- lowrankfilter's plain truncation branch on the series itself (csrc/hankelop.hip, round 6) -------------------------------
+@pytest.mark.parametrize("Ns,n,sv,dtype", [(4000, 40, 2, np.float64), (30001, 256, 6, np.float64), (20000, 200, 32, np.float64),
+                                           (9000, 1000, 3, np.float64), (12000, 64, 4, np.float32)])
+def test_lowrankfilter_truncation_without_the_hankel_panel(eng, Ns, n, sv, dtype):
+    """`lowrankfilter(y, n; sv = k)` (src/robustPCA.jl:123-126: `s = svd(H); A = U[:, 1:sv] S V'`, then unhankel): the Gram
+    matrix of H from lagged autocorrelation sums and H V as FIR filters - H is never stored - against the panel form of the same
+    call (HANKEL_STRUCT=0) to 1e-12 and against the CPU oracle to 1e-8 (fp32 series: the element type's accuracy)."""
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    y, noise = O.synth_series(Ns, seed=Ns)
+    x = (y + noise).astype(dtype)
+    yf = eng.lowrankfilter(x, n, sv=sv)
+    with tlsq_amd.dev_switches(HANKEL_STRUCT=0):
+        yp = eng.lowrankfilter(x, n, sv=sv)
+    assert yf.dtype == dtype and yf.shape == x.shape
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.linalg.norm(yf - yp) <= tol * np.linalg.norm(yp)
+    if Ns <= 12000:
+        yo = O.lowrankfilter(x.astype(np.float64), n, sv=sv)
+        assert np.linalg.norm(yf - yo) <= (1e-8 if dtype == np.float64 else 1e-4) * np.linalg.norm(yo)
+
+
+def test_truncation_at_config3_size_holds_no_panel(eng):
+    """N = 1e7, n = 256 (BASELINE config 3's series) with sv = 4: the two 20 GB panels of the materialised form are never
+    allocated - a fresh handle ends up with the series, the 1e7 x 4 factor and small matrices - and the filter does what the
+    reference's test asks of it (test/runtests.jl:356-381)."""
+    import torch
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    Ns, n = 10_000_000, 256
+    y, noise = O.synth_series(Ns, seed=0)
+    free0, _ = torch.cuda.mem_get_info(0)
+    e2 = tlsq_amd.Engine(0)
+    try:
+        yf = e2.lowrankfilter(y + 0.1 * noise, n, sv=2)
+        free1, _ = torch.cuda.mem_get_info(0)
+    finally:
+        e2.close()
+    assert (free0 - free1) < 2.5e9, f"{(free0 - free1) / 1e9:.2f} GB resident"       # (a K x n panel is 20.5 GB)
+    qn = lambda v: v / np.quantile(np.abs(v), 0.9)
+    assert np.mean((y - qn(yf)) ** 2) / np.mean((0.1 * noise) ** 2) < 0.05

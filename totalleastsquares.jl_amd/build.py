@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libtlsqhip.so")
-SOURCES = ["sweeps.hip", "fused.hip", "gemm.hip", "opgram32.hip", "opgram16.hip", "gram16.hip", "jacobi.hip", "hankel.hip", "lanczos.hip", "subspace.hip", "matfun.hip", "cholesky.hip", "sliced.hip", "tsqr.hip", "batched.hip", "complex.hip", "grassmann.hip", "runtime.hip", "staging.hip", "svdstep.hip", "solver.hip", "solver_complex.hip", "entry.hip", "api.hip"]
+SOURCES = ["sweeps.hip", "fused.hip", "gemm.hip", "opgram32.hip", "opgram16.hip", "gram16.hip", "jacobi.hip", "hankel.hip", "hankelop.hip", "lanczos.hip", "subspace.hip", "matfun.hip", "cholesky.hip", "sliced.hip", "tsqr.hip", "batched.hip", "complex.hip", "grassmann.hip", "runtime.hip", "staging.hip", "svdstep.hip", "solver.hip", "solver_complex.hip", "entry.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include")]
 

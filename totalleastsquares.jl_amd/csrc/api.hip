@@ -189,14 +189,20 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
     // panels (E, Y, Z, R)
     const bool factors_ok = !dev_is(DEV_UNHANKEL_FACTORS, '0');
     const bool factors_out = lazy && !sharded && factors_ok && Dch == 1 && lag == 1 && (size_t)n * 32 * 8 <= 64 * 1024;
+    // The plain truncation branch (sv > 0, :123-126) on the series itself (round 6, hankelop.hip): the Gram matrix of H from n
+    // lagged autocorrelation sums, the factor H V[:, 1:sv] as sv FIR filters, the anti-diagonal means from the factors - neither H
+    // nor A is ever stored (one channel, lag 1, one GPU; otherwise the panels as before).  HANKEL_STRUCT=0: the panel form.
+    const int64_t r_sv = std::min<int64_t>(sv, std::min(Kg, LD));
+    const bool structured = sv > 0 && !sharded && Dch == 1 && lag == 1 && hankel_structured_ok(K, n, r_sv) &&
+                            (size_t)n * (size_t)r_sv * 8 <= 64 * 1024 && !dev_is(DEV_HANKEL_STRUCT, '0');
     void *dy, *H = nullptr, *A = nullptr, *E;
     TLSQ_TRY(ws_get(h, WS_AUX3, (size_t)Nx * Dch * ES, &dy));
-    if (!lazy) TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
-    if (!factors_out) TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
-    if (!lazy && Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
+    if (!lazy && !structured) TLSQ_TRY(ws_get(h, WS_D, (size_t)Kp * LD * ES, &H));
+    if (!factors_out && !structured) TLSQ_TRY(ws_get(h, WS_A, (size_t)Kp * LD * ES, &A));
+    if (!lazy && !structured && Kp != K) TLSQ_HIP(h, hipMemsetAsync(H, 0, (size_t)Kp * LD * ES, h->stream));
     TLSQ_TRY(copy2d(h, dy, Nx, y, ldy, Nx, Dch, ES, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     const T* yw = (const T*)dy + s0;                                                // this rank's window
-    if (!lazy) TLSQ_TRY(launch_hankel<T>(h, yw, Nw, Dch, Nx, n, lag, (T*)H, Kp));     // :120
+    if (!lazy && !structured) TLSQ_TRY(launch_hankel<T>(h, yw, Nw, Dch, Nx, n, lag, (T*)H, Kp));     // :120
     int status = TLSQ_OK;
     if (sv <= 0) {                                                                            // :121-122
         TLSQ_TRY(ws_get(h, WS_E, (size_t)Kp * LD * ES, &E));
@@ -237,6 +243,25 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
             status = rpca_core<T>(h, (const T*)H, Kp, LD, ro, &oo, (T*)A, (T*)E, nullptr, nullptr, nullptr, 0, nullptr, info);
         }
         if (status < 0) return status;
+    } else if (structured) {                                                                  // :123-126, H never stored
+        SmallSvd s;
+        double* V = nullptr;
+        int64_t sweeps = 0;
+        void *G, *Vs, *Tm;
+        TLSQ_TRY(ws_get(h, WS_G, (size_t)n * n * 8, &G));
+        TLSQ_TRY(hankel_gram<T>(h, yw, K, n, (double*)G));
+        TLSQ_TRY(eig_full(h, (const double*)G, n, &V, s, &sweeps, false, WS_V, true));
+        TLSQ_TRY(ws_get(h, WS_VS, (size_t)n * r_sv * 8, &Vs));
+        TLSQ_TRY(ws_get(h, WS_T, (size_t)Kp * r_sv * 8, &Tm));
+        SelWeights sw;
+        for (int64_t i = 0; i < 32; ++i) {
+            sw.sel[i] = i < r_sv ? s.order[(size_t)i] : 0;
+            sw.w[i] = 1.0;
+        }
+        TLSQ_TRY(launch_gather_scale_arg(h, V, n, sw, r_sv, nullptr, (double*)Vs));
+        TLSQ_TRY(hankel_times<T>(h, yw, K, Kp, n, (const double*)Vs, n, r_sv, (double*)Tm, Kp));
+        TLSQ_TRY(launch_unhankel_factors<T>(h, (const double*)Tm, Kp, (const double*)Vs, n, r_sv, K, n, Nx, (T*)dy));
+        if (info) info->jacobi_sweeps = sweeps;
     } else {                                                                                  // :123-126
         SmallSvd s;
         double* V = nullptr;
@@ -250,7 +275,9 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         if (info) info->jacobi_sweeps = sweeps;
     }
     // :127  (dy is reused for the filtered signal)
-    if (!sharded && factors_out && sv <= 0 && h->out_factors) {
+    if (structured) {
+        // (the filtered series is in dy already)
+    } else if (!sharded && factors_out && sv <= 0 && h->out_factors) {
         TLSQ_TRY(launch_unhankel_factors<T>(h, h->out_Tm, Kp, h->out_Vs, LD, h->out_r, K, n, Nx, (T*)dy));
     } else if (!sharded) {
         if (!A) A = h->ws[WS_A].p;   // (allocated inside the loop: some iteration needed the panel)

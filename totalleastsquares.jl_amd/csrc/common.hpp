@@ -123,7 +123,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
     X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
     X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW) \
-    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(SLICE_NORMWISE)
+    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(SLICE_NORMWISE) X(NO_MAXABS_ASYNC) X(HANKEL_STRUCT)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
@@ -203,6 +203,9 @@ int launch_div_scalar(Handle* h, const T* D, T* Y, int64_t n, T s);
 // out[0] = max |x_i|  (device scalar, as double bits in a uint64 slot)
 template <typename T>
 int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out);
+template <typename T>
+int launch_maxabs_begin(Handle* h, const T* x, int64_t n);   // ... queued on the second stream, read back by launch_maxabs_end
+int launch_maxabs_end(Handle* h, double* host_out);
 template <typename T>
 int launch_clamp_nonneg(Handle* h, T* A, int64_t n);
 template <typename T>
@@ -421,6 +424,16 @@ int symeig_chol_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* 
 // sig_dev = their norms (unsorted).  floor_rel * ||B||_F = norm below which a column takes no part (0: none).
 int jacobi_factor_f64(Handle* h, double* B, int64_t N, double* V, double* sig_dev, double floor_rel,
                       int64_t* sweeps_out);
+
+// ---------------- hankelop.hip ----------------
+// products with the Hankel matrix H[k, j] = y[k + j] (k < K, j < n; one channel, lag 1) that is never stored: G = H'H from n
+// lagged autocorrelation sums, Tm = H X as r FIR filters (r <= 32, n <= 1024)
+bool hankel_structured_ok(int64_t K, int64_t n, int64_t r);
+template <typename T>
+int hankel_gram(Handle* h, const T* y, int64_t K, int64_t n, double* G);
+template <typename T>
+int hankel_times(Handle* h, const T* y, int64_t K, int64_t Kp, int64_t n, const double* X, int64_t ldx, int64_t r, double* Tm,
+                 int64_t ldt);
 
 // ---------------- sliced.hip ----------------
 // The same decomposition with the spectrum cut into slices first (sign functions on the MFMA, Jacobi sweeps inside the slices,

@@ -816,6 +816,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         return o;
     };
     double maxabs = 0.0;
+    // (plain calls on one GPU: the max-abs pass runs on the second stream beside the Gram matrix of the set-up norm - it is
+    //  memory-bound, the Gram is not - and its result is read together with the norm's: one host round trip less, ~60 us at C2)
+    const bool maxabs_async = !(ro.hankel_lazy && ro.hankel_y) && !cb_opnorm && !hook_opnorm && !implicit_gram && !h->comm &&
+                              !dev_is(DEV_NO_MAXABS_ASYNC, '1');
     if (ro.hankel_lazy && ro.hankel_y) {   // every sample of the window appears in its Hankel matrix (lag <= L): max |H| = max |y|
         const HankelGeom& hg = ro.hankel_geom;
         const int64_t Nw = (ro.hankel_K - 1) * hg.lag + N / hg.Dch;
@@ -825,16 +829,29 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             maxabs = std::max(maxabs, md);
         }
     }
+    else if (maxabs_async)
+        TLSQ_TRY(launch_maxabs_begin<T>(h, D, n));                 // :178 norm(Y, Inf), beside the Gram matrix of :177 (read below)
     else
         TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));              // :178 norm(Y, Inf)
-    TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
-    // (the reference's svd! / opnorm go through LAPACK's chkfinite and throw ArgumentError("matrix contains Infs or NaNs") at
-    //  :177 before anything else happens: the same input is an error here, from the max-abs pass the set-up needs anyway)
-    if (!std::isfinite(maxabs)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
+    auto finish_maxabs = [&]() -> int {
+        if (maxabs_async) TLSQ_TRY(launch_maxabs_end(h, &maxabs));
+        TLSQ_TRY(comm_allreduce_host_scalar(h, &maxabs, ncclMax));
+        // (the reference's svd! / opnorm go through LAPACK's chkfinite and throw ArgumentError("matrix contains Infs or NaNs")
+        //  at :177 before anything else happens: the same input is an error here, from the max-abs pass the set-up needs anyway)
+        if (!std::isfinite(maxabs)) return set_err(h, TLSQ_ERR_NONFINITE, "matrix contains Infs or NaNs");
+        return TLSQ_OK;
+    };
+    if (!maxabs_async) TLSQ_TRY(finish_maxabs());
     if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
     else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));
-    else TLSQ_TRY(opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11));                   // :177 opnorm(Y), Y = copy(D)
+    else {
+        // (Infs / NaNs in D come out of the Gram matrix as NaNs: the norm's own failure is not reported before the max-abs pass
+        //  has had its say)
+        const int st_n = opnorm_gram<T>(h, D, M, N, M, &norm2, &sweeps, 1e-11);                   // :177 opnorm(Y), Y = copy(D)
+        if (maxabs_async) TLSQ_TRY(finish_maxabs());
+        if (st_n < 0) return st_n;
+    }
     const double lam = ro.lambda;
     const double norminf = maxabs / lam;
     const double dual_norm = std::max(norm2, norminf);             // :179

@@ -1387,6 +1387,35 @@ int launch_maxabs(Handle* h, const T* x, int64_t n, double* host_out) {
     return TLSQ_OK;
 }
 
+// The same in two halves: the pass is queued on the handle's SECOND stream (it is memory-bound and overlaps the Gram matrix of the
+// set-up, which is not) and its result is read when the caller needs it - no host round trip between the two kernels of the
+// set-up.  x must not be written by anything queued on the main stream in between.
+int second_stream(Handle* h);   // (runtime.hip)
+template <typename T>
+int launch_maxabs_begin(Handle* h, const T* x, int64_t n) {
+    TLSQ_TRY(second_stream(h));
+    void* slot;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(slot) + 3408);
+    // (the second stream may only start once everything queued so far on the main one is done: the workspace slot, x)
+    TLSQ_HIP(h, hipEventRecord(h->ev_b[8], h->stream));
+    TLSQ_HIP(h, hipStreamWaitEvent(h->stream_b, h->ev_b[8], 0));
+    TLSQ_HIP(h, hipMemsetAsync(d, 0, 8, h->stream_b));
+    if (n > 0) {
+        hipLaunchKernelGGL((k_maxabs<T>), dim3(grid_for(n)), dim3(256), 0, h->stream_b, x, n, d);
+        TLSQ_HIP(h, hipGetLastError());
+    }
+    TLSQ_HIP(h, hipMemcpyAsync(reinterpret_cast<char*>(h->pinned) + 2048, d, 8, hipMemcpyDeviceToHost, h->stream_b));
+    return TLSQ_OK;
+}
+int launch_maxabs_end(Handle* h, double* host_out) {
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream_b));
+    memcpy(host_out, reinterpret_cast<char*>(h->pinned) + 2048, 8);
+    return TLSQ_OK;
+}
+template int launch_maxabs_begin<double>(Handle*, const double*, int64_t);
+template int launch_maxabs_begin<float>(Handle*, const float*, int64_t);
+
 template <typename T>
 int launch_transpose(Handle* h, const T* src, int64_t lds, int64_t M, int64_t N, T* dst, int64_t ldd) {
     if (M <= 0 || N <= 0) return TLSQ_OK;
