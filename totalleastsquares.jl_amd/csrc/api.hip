@@ -250,7 +250,8 @@ static int lowrankfilter_impl(tlsq_handle h, const T* y, int64_t Nx, int64_t Dch
         void *G, *Vs, *Tm;
         TLSQ_TRY(ws_get(h, WS_G, (size_t)n * n * 8, &G));
         TLSQ_TRY(hankel_gram<T>(h, yw, K, n, (double*)G));
-        TLSQ_TRY(eig_full(h, (const double*)G, n, &V, s, &sweeps, false, WS_V, true));
+        // (only the leading sv vectors are used: the Cholesky route - zero columns for numerically zero eigenvalues - serves)
+        TLSQ_TRY(eig_full(h, (const double*)G, n, &V, s, &sweeps, false, WS_V, false));
         TLSQ_TRY(ws_get(h, WS_VS, (size_t)n * r_sv * 8, &Vs));
         TLSQ_TRY(ws_get(h, WS_T, (size_t)Kp * r_sv * 8, &Tm));
         SelWeights sw;

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_split_f16(const float* __restrict__ Z, 
 __device__ __forceinline__ int h3_sw(int c) { return (c >> 1) & 7; }
 
 template <int HFOLD>
-__global__ __launch_bounds__(512, 2) void k_gram_h3(const _Float16* __restrict__ H, const _Float16* __restrict__ L, int64_t ld,
+// (one workgroup per CU: 128 KB of stage buffers; the (512, 2) bound of round 5 only capped the registers - same time)
+__global__ __launch_bounds__(512, 1) void k_gram_h3(const _Float16* __restrict__ H, const _Float16* __restrict__ L, int64_t ld,
                                                     double* __restrict__ slab, int64_t N, int64_t K, int64_t kchunk,
                                                     int64_t slab_stride, int ntiles, int nsplit, const int32_t* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];   // 2 x HBUF
@@ -295,7 +296,7 @@ int gram_h3(Handle* h, const float* Z, int64_t ld, double* G, int64_t ldg, int64
                        (_Float16*)lp, (double*)sc);
     TLSQ_HIP(h, hipGetLastError());
     const int64_t nti = N / HT, ntiles = nti * (nti + 1) / 2;
-    // row splits: ~2 rounds of 512 work items (two workgroups per CU), at least 32 stages each, slabs below 2 GB
+    // row splits: ~4 rounds of 256 work items (one workgroup per CU), at least 32 stages each, slabs below 2 GB
     int64_t nsplit = std::max<int64_t>(1, (1024 + ntiles - 1) / ntiles);
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, K / (16 * HK)));
     nsplit = std::min<int64_t>(nsplit, std::max<int64_t>(1, (int64_t)(((size_t)2 << 30) / ((size_t)N * N * 8))));

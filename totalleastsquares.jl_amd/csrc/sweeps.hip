@@ -619,7 +619,11 @@ __global__ __launch_bounds__(256, 3) void k_zsweep_wide(const float* __restrict_
 }
 
 bool zsweep_wide_ok(int64_t M, int64_t N, int64_t r) {
-    return r > 32 && r <= 80 && (M % 32) == 0 && (N % 128) == 0 && M >= 4096 && M <= (1 << 24) && N <= 1000000;   // (32-bit byte offsets inside a strip: 108 M < 2^32)
+    // 32-bit byte offsets: inside a strip 108 M < 2^32, and the T32 scalar offset (2 KH - 1) * 4 * M with KH = 32 (r <= 64) or
+    // 40 (r <= 80) - the larger factor, 79 * 4 * M < 2^32, caps M at 13.5e6 for ranks above 64
+    const int64_t KH = r <= 64 ? 32 : 40;
+    const int64_t mmax = std::min<int64_t>((int64_t)1 << 24, (((int64_t)1 << 32) - 1) / (4 * (2 * KH - 1)));
+    return r > 32 && r <= 80 && (M % 32) == 0 && (N % 128) == 0 && M >= 4096 && M <= mmax && N <= 1000000;
 }
 
 // T32: M x 2 KH (ld ldt) and Vs32: N x 2 KH (ld N), KH = 32 for r <= 64 and 40 for r <= 80, columns r.. zero
