@@ -356,6 +356,12 @@ void tlsq_ga_opts_default(tlsq_ga_opts* o);
 int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64_t ldX, int64_t r,
                      const tlsq_ga_opts* opts, const double* q0, int64_t ldq0, double* Q, int64_t ldQ,
                      tlsq_ga_info* info);
+/* Float32 observations (the reference's method is generic in the element type): X, q0, Q in float.  The panel is widened once on
+ * the device and the iteration runs in the fp64 kernels (the library's small-arithmetic convention, as for ComplexF32 data); Q is
+ * rounded to float on the way out.  Same options, report and return codes as tlsq_rpca_ga_f64. */
+int tlsq_rpca_ga_f32(tlsq_handle h, const float* X, int64_t d, int64_t N, int64_t ldX, int64_t r,
+                     const tlsq_ga_opts* opts, const float* q0, int64_t ldq0, float* Q, int64_t ldQ,
+                     tlsq_ga_info* info);
 /* the averages on their own (exported by the reference, src/TotalLeastSquares.jl:3; tested at
  * test/runtests.jl:466-490): s (d) = average of the columns of U (d x N, ldU) with weights w (N) */
 int tlsq_ga_average_f64(tlsq_handle h, int average, double trim, const double* w, const double* U, int64_t d,

@@ -441,6 +441,33 @@ function rpca_ga(X::AbstractMatrix{Float64}, r = minimum(size(X)), U = nothing; 
     Q
 end
 
+# Float32 observations: the fp32 entry (the panel travels as Float32, is widened on the device; Q comes back in Float32).  A Julia
+# closure as the average goes through the Float64 method (the callback's signature).
+function rpca_ga(X::AbstractMatrix{Float32}, r = minimum(size(X)), U = nothing; μ = μ!, tol = 1e-7, iters = 1000,
+                 verbose = false, P = 0.1, q0 = randn(Float32, size(X, 1), r))
+    code = μ === μ! ? 0 : μ === entrywise_trimmed_mean ? 1 : μ === entrywise_median ? 2 : 3
+    code == 3 && return Matrix{Float32}(rpca_ga(Matrix{Float64}(X), r, U; μ = μ, tol = tol, iters = iters, verbose = verbose, P = P,
+                                                q0 = Matrix{Float64}(q0)))
+    Xm = Matrix(X); d, N = size(Xm); Q = zeros(Float32, d, r)
+    o = GaOpts(); ccall((:tlsq_ga_opts_default, LIB[]), Cvoid, (Ref{GaOpts},), o)
+    o.tol = tol; o.iters = iters; o.average = code; o.trim = P; o.memory = MEM_HOST
+    its = zeros(Int64, r); status = zeros(Int32, r); dq = zeros(r); hist = fill(NaN, verbose ? iters : 1, r)
+    info = GaInfo(); info.iters = pointer(its); info.status = pointer(status); info.dq = pointer(dq)
+    info.dq_hist = verbose ? pointer(hist) : C_NULL; info.hist_capacity = verbose ? iters : 0
+    st = GC.@preserve its status dq hist ccall((:tlsq_rpca_ga_f32, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Int64, Int64, Ref{GaOpts}, Ptr{Float32}, Int64, Ptr{Float32}, Int64,
+         Ref{GaInfo}), handle(), Xm, d, N, d, r, o, Matrix{Float32}(q0), d, Q, d, info)
+    st = check(st)
+    if verbose
+        for i in 1:r
+            for k in 1:its[i]; @info "Change at iteration $k: $(hist[k, i])"; end                  # :300
+            status[i] == 0 && @info "Converged after $(its[i]) iterations"                        # :302
+        end
+    end
+    st == 1 && @warn "Reached maximum number of iterations"                                      # :306
+    Q
+end
+
 # other real element types (the reference is generic): computed in Float64 on the device, returned in the input's float type
 function rpca_ga(X::AbstractMatrix{T}, args...; kwargs...) where {T<:Real}
     Q = rpca_ga(Matrix{Float64}(X), args...; kwargs...)

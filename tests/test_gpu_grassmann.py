@@ -304,3 +304,44 @@ def test_rpca_ga_device_pointers_and_leading_dimensions(eng, G, d, N, r):
     assert it.tolist() == ginfo.iters
     assert np.abs(got[:, :d].T - want).max() < 1e-9
     assert np.array_equal(dX.cpu().numpy()[:, :d].T, X)                # the input is not modified (:257)
+
+
+# ---- Float32 observations through the fp32 entry (tlsq_rpca_ga_f32, round 6) --------------------------------------------------
+@pytest.mark.parametrize("d,N,r,mode", [(10, 40, 3, "mean"), (64, 5000, 3, "mean"), (700, 1500, 2, "mean"),
+                                        (40, 301, 2, "entrywise_trimmed_mean"), (130, 900, 2, "entrywise_median")])
+def test_rpca_ga_float32_entry(eng, G, d, N, r, mode):
+    """`rpca_ga(X::Matrix{Float32})` (the reference's method is generic, src/robustPCA.jl:255): the panel travels as float32, is
+    widened once on the device and iterated in the fp64 kernels; Q comes back in float32.  Against the fp64 entry on the widened
+    panel: the same iterations per component, the same components to float32 rounding."""
+    rng = np.random.default_rng(3 * d + N)
+    _, X = _data(rng, d, N, r, outliers=0.01)
+    X32 = np.asfortranarray(X.astype(np.float32))
+    q0 = rng.standard_normal((d, r)).astype(np.float32)
+    kw = {} if mode == "mean" else {"mu": mode}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got, rep = eng.rpca_ga(X32, r, q0=q0, return_report=True, **kw)
+        want, rep64 = eng.rpca_ga(X32.astype(np.float64), r, q0=q0.astype(np.float64), return_report=True, **kw)
+    assert got.dtype == np.float32 and got.shape == (d, r)
+    assert rep["iters"] == rep64["iters"] and rep["status"] == rep64["status"]
+    assert np.abs(got.astype(np.float64) - want).max() < 2e-7
+    # raw C ABI with device pointers and leading dimensions
+    import ctypes as C
+    import torch
+    from tlsq_amd import _lib as L
+    ldX, ldq, ldQ = d + 3, d + 1, d + 5
+    def dev(a, ld):
+        buf = np.full((a.shape[1], ld), np.nan, dtype=np.float32)
+        buf[:, : a.shape[0]] = a.T
+        return torch.from_numpy(buf).cuda()
+    dX, dq0 = dev(X32, ldX), dev(q0, ldq)
+    dQ = torch.full((r, ldQ), float("nan"), dtype=torch.float32, device="cuda")
+    o = L.GaOpts()
+    eng.lib.tlsq_ga_opts_default(C.byref(o))
+    o.memory = L.MEM_DEVICE
+    o.average = {"mean": L.GA_MEAN, "entrywise_trimmed_mean": L.GA_TRIMMED_MEAN, "entrywise_median": L.GA_MEDIAN}[mode]
+    st = eng.lib.tlsq_rpca_ga_f32(eng.h, C.c_void_p(dX.data_ptr()), d, N, ldX, r, C.byref(o), C.c_void_p(dq0.data_ptr()), ldq,
+                                  C.c_void_p(dQ.data_ptr()), ldQ, None)
+    assert st == (1 if any(rep["status"]) else 0)        # (TLSQ_MAXITER = the reference's @warn, :306 - not an error)
+    gd = dQ.cpu().numpy()
+    assert np.array_equal(gd[:, :d].T, got) and np.all(np.isnan(gd[:, d:]))

@@ -76,7 +76,7 @@ EXPORTS = [
     "tlsq_hankel_f32", "tlsq_unhankel_f32", "tlsq_soft_hankel_f32",
     "tlsq_lowrankfilter_f64", "tlsq_lowrankfilter_f32", "tlsq_tls_f64", "tlsq_rtls_f64", "tlsq_tls_f32", "tlsq_rtls_f32", "tlsq_tls_from_vt_f64",
     "tlsq_rpca_batched_f64", "tlsq_rtls_batched_f64", "tlsq_rpca_batched_f32", "tlsq_rtls_batched_f32", "tlsq_rpca_c64", "tlsq_rpca_c64_svd", "tlsq_rpca_c32_svd",
-    "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_ga_average_f64",
+    "tlsq_ga_opts_default", "tlsq_rpca_ga_f64", "tlsq_rpca_ga_f32", "tlsq_ga_average_f64",
     "tlsq_k_shrink_f64", "tlsq_k_update_f64", "tlsq_k_shrink_f32", "tlsq_k_update_f32",
     "tlsq_k_update_shrink_f64", "tlsq_k_update_shrink_f32", "tlsq_k_rebuild_update_shrink_f64",
     "tlsq_k_zsweep_f64", "tlsq_k_zsweep_gram_f64", "tlsq_k_zsweep_wide_f32", "tlsq_k_final_e_f64", "tlsq_k_matfun_sign_f64", "tlsq_k_matfun_invsqrt_f64", "tlsq_k_rr_small_f64",
@@ -157,6 +157,7 @@ def load():
     lib.tlsq_ga_opts_default.argtypes = [P(GaOpts)]
     lib.tlsq_ga_opts_default.restype = None
     lib.tlsq_rpca_ga_f64.argtypes = [vp, vp, i64, i64, i64, i64, P(GaOpts), vp, i64, vp, i64, P(GaInfo)]
+    lib.tlsq_rpca_ga_f32.argtypes = lib.tlsq_rpca_ga_f64.argtypes
     lib.tlsq_ga_average_f64.argtypes = [vp, C.c_int, dbl, vp, vp, i64, i64, i64, vp, C.c_int]
     lib.tlsq_k_gram_f64.argtypes = [vp, vp, i64, i64, i64, vp, i64]
     lib.tlsq_k_gram_f32.argtypes = [vp, vp, i64, i64, i64, vp, i64, C.c_int]

@@ -161,7 +161,7 @@ enum WsSlot {
     WS_T2, WS_VS2, WS_VS3, WS_T3,
     WS_MF0, WS_MF1, WS_MF2, WS_MF3, WS_MFP,   // matrix-function route (solver.hip): N x N iterates, partials of k_mf_stats      // rebuild factors of the E-free loop (the factors of A_{k-1} are kept: WS_T2/WS_VS2 and WS_T/WS_VS3 in turn)
     WS_QRW, WS_QRY, WS_QRT, WS_QRP, WS_QRG, WS_QRS,   // TSQR (tsqr.hip): working copy, reflectors, T factors, packed / gathered / stacked factors
-    WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q,   // rpca_ga (grassmann.hip)
+    WS_GA_X, WS_GA_U, WS_GA_AUX, WS_GA_PART, WS_GA_MASK, WS_GA_KEYS, WS_GA_IDX, WS_GA_TMP, WS_GA_IO, WS_GA_Q, WS_GA_F32, WS_GA_X64, WS_GA_Q64,   // rpca_ga (grassmann.hip)
                                                              // two-level (precise) decomposition                                            // transposed problem (M < N)
     WS_G3,             // second Gram buffer of the speculative loop (solver.hip: the Gram of Z_{k+1} is queued while G_k is still read)
     WS_C32_F, WS_C32_D, WS_C32_A, WS_C32_E, WS_C32_U, WS_C32_V, WS_C32_S,   // ComplexF32 entry (api.hip): float staging, widened panels

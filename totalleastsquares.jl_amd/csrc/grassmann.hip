@@ -1313,6 +1313,70 @@ int tlsq_rpca_ga_f64(tlsq_handle h, const double* X, int64_t d, int64_t N, int64
     return rc;
 }
 
+// Float32 observations (`rpca_ga(X::Matrix{Float32})`: the reference's method is generic in the element type, src/robustPCA.jl:255):
+// the panel travels and lives as fp32 on its way in (half the PCIe bytes of a host-side conversion), is widened once on the
+// device, and the iteration runs in the fp64 kernels above - the library's small-arithmetic convention, as for ComplexF32 data;
+// Q is rounded to fp32 on the way out.  q0 (optional) is fp32 as well.  A group handle splits the columns like the fp64 entry
+// (the conversion then happens on the host: every rank needs its own block).
+int tlsq_rpca_ga_f32(tlsq_handle h, const float* X, int64_t d, int64_t N, int64_t ldX, int64_t r, const tlsq_ga_opts* opts,
+                     const float* q0, int64_t ldq0, float* Q, int64_t ldQ, tlsq_ga_info* info) {
+    TLSQ_TRY(check_handle(h));
+    if (!X || !Q || d <= 0 || N <= 0 || ldX < d || ldQ < d || r < 0 || (q0 && ldq0 < d))
+        return set_err(h, TLSQ_ERR_ARG, "rpca_ga: bad argument");
+    const bool dev = opts && opts->memory == TLSQ_MEM_DEVICE;
+    tlsq_ga_opts o;
+    if (opts) o = *opts; else tlsq_ga_opts_default(&o);
+    std::vector<double> q0d;
+    if (q0) {
+        std::vector<float> q0h((size_t)d * r);
+        if (dev) {
+            TLSQ_HIP(h, hipSetDevice(h->device));
+            TLSQ_HIP(h, hipMemcpy2D(q0h.data(), (size_t)d * 4, q0, (size_t)ldq0 * 4, (size_t)d * 4, (size_t)r, hipMemcpyDeviceToHost));
+        } else {
+            for (int64_t c = 0; c < r; ++c) memcpy(q0h.data() + (size_t)c * d, q0 + (size_t)c * ldq0, (size_t)d * 4);
+        }
+        q0d.assign(q0h.begin(), q0h.end());
+    }
+    std::vector<double> Qd((size_t)d * std::max<int64_t>(r, 1));
+    int st;
+    if (is_multi_call(h) && !dev) {
+        std::vector<double> Xd((size_t)d * N);
+        for (int64_t c = 0; c < N; ++c)
+            for (int64_t i = 0; i < d; ++i) Xd[(size_t)(i + c * d)] = (double)X[i + c * ldX];
+        o.memory = TLSQ_MEM_HOST;
+        st = tlsq_rpca_ga_f64(h, Xd.data(), d, N, d, r, &o, q0 ? q0d.data() : nullptr, d, Qd.data(), d, info);
+    } else {
+        TLSQ_HIP(h, hipSetDevice(h->device));
+        void *xf, *xd, *qd;
+        TLSQ_TRY(ws_get(h, WS_GA_F32, (size_t)d * N * 4, &xf));
+        TLSQ_TRY(ws_get(h, WS_GA_X64, (size_t)d * N * 8, &xd));
+        TLSQ_TRY(ws_get(h, WS_GA_Q64, (size_t)d * std::max<int64_t>(r, 1) * 8 * 2, &qd));
+        TLSQ_TRY(copy2d(h, xf, d, X, ldX, d, N, 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        TLSQ_TRY((launch_convert<float, double>(h, (const float*)xf, (double*)xd, d * N)));
+        double* q0dev = nullptr;
+        if (q0) {
+            q0dev = (double*)qd + (size_t)d * std::max<int64_t>(r, 1);
+            TLSQ_HIP(h, hipMemcpyAsync(q0dev, q0d.data(), (size_t)d * r * 8, hipMemcpyHostToDevice, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        o.memory = TLSQ_MEM_DEVICE;
+        st = tlsq_rpca_ga_f64(h, (const double*)xd, d, N, d, r, &o, q0dev, d, (double*)qd, d, info);
+        if (st >= 0 && r > 0) {
+            TLSQ_HIP(h, hipMemcpyAsync(Qd.data(), qd, (size_t)d * r * 8, hipMemcpyDeviceToHost, h->stream));
+            TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    if (st < 0) return st;
+    std::vector<float> Qf((size_t)d * std::max<int64_t>(r, 1));
+    for (size_t i = 0; i < (size_t)d * r; ++i) Qf[i] = (float)Qd[i];
+    if (r > 0) {
+        if (dev) TLSQ_HIP(h, hipMemcpy2D(Q, (size_t)ldQ * 4, Qf.data(), (size_t)d * 4, (size_t)d * 4, (size_t)r, hipMemcpyHostToDevice));
+        else
+            for (int64_t c = 0; c < r; ++c) memcpy(Q + (size_t)c * ldQ, Qf.data() + (size_t)c * d, (size_t)d * 4);
+    }
+    return st;
+}
+
 int tlsq_ga_average_f64(tlsq_handle h, int average, double trim, const double* w, const double* U, int64_t d, int64_t N,
                         int64_t ldU, double* s, int memory) {
     TLSQ_TRY(check_handle(h));

@@ -558,10 +558,15 @@ class Engine:
                 return_report=False):
         """Q = rpca_ga(X, r; tol, iters, μ): X is d x N with the observations in its columns; returns Q (d x r).
         q0 (d x r) gives the start vector of every component (the reference draws randn(d), :289)."""
-        Xf = _f(X)
+        Xa = np.asarray(X)
+        # Float32 observations take the fp32 entry (the panel travels as float, is widened on the device, Q comes back in float);
+        # a caller's own average always sees float64 (the callback's signature)
+        f32 = Xa.dtype == np.float32 and self._average_code(mu) != L.GA_CALLBACK
+        dt = np.float32 if f32 else np.float64
+        Xf = _f(Xa, dt)
         d, N = Xf.shape
         r = min(d, N) if r is None else int(r)
-        Q = np.zeros((d, r), order="F")
+        Q = np.zeros((d, r), dtype=dt, order="F")
         o = L.GaOpts()
         self.lib.tlsq_ga_opts_default(C.byref(o))
         o.tol, o.iters, o.average, o.trim, o.seed = float(tol), int(iters), self._average_code(mu), float(P), int(seed)
@@ -594,11 +599,11 @@ class Engine:
         info.dq = dq.ctypes.data_as(C.POINTER(C.c_double))
         info.dq_hist = hist.ctypes.data_as(C.POINTER(C.c_double)) if cap else None
         info.hist_capacity = cap
-        q0f = None if q0 is None else _f(np.asarray(q0, dtype=np.float64).reshape(d, -1))
+        q0f = None if q0 is None else _f(np.asarray(q0, dtype=dt).reshape(d, -1), dt)
         if q0f is not None and q0f.shape[1] < r:
             raise TlsqError(L.TLSQ_ERR_ARG, "rpca_ga: q0 needs one column per component")
-        st = self.lib.tlsq_rpca_ga_f64(self.h, _ptr(Xf), d, N, d, r, C.byref(o),
-                                       _ptr(q0f) if q0f is not None else None, d, _ptr(Q), d, C.byref(info))
+        fn = self.lib.tlsq_rpca_ga_f32 if f32 else self.lib.tlsq_rpca_ga_f64
+        st = fn(self.h, _ptr(Xf), d, N, d, r, C.byref(o), _ptr(q0f) if q0f is not None else None, d, _ptr(Q), d, C.byref(info))
         if errbox:
             raise errbox[0]          # the user's average raised: surface its own exception
         st = self._check(st)
