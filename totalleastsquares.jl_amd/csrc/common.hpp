@@ -109,26 +109,40 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
 // set through tlsq_dev_set(name, value) - the tests and tools call it; a name that is not on the list is an error - and,
 // only in a build with -DTLSQ_DEV_SWITCHES, from environment variables TLSQ_<NAME> read once at the first tlsq_create.
 // The shipped build reads no environment variable at all: a leaked or mistyped variable cannot change which solver runs.
-#define TLSQ_DEV_LIST(X)                                                                                                  \
-    X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP) X(FAIL_RANK)                                                \
-    X(NO_ZSWEEP) X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(FUSED_REBUILD) X(NO_REBUILD_STORE)            \
-    X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID) X(SWEEP_TIMING_STRIDE)                                                                                   \
-    X(NO_MAX_BOUND) X(RSKIP_MARGIN) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS)                                         \
-    X(FULL_EIG) X(NO_GRAM_DENSE) X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(MATFUN_COND) X(MATFUN_DEFL) X(NO_QUINTIC) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)    \
-    X(NO_CERT_OVERLAP) X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(CERT_EARLY) X(CERT_PRIO) X(NO_DEFLATED_SVD) X(NO_SMALL_MM) X(NO_FUSED_DEFLATE)                                                                                 \
-    X(NO_RR_FAST) X(NO_RR_BLOCKED) X(NO_U_POLISH) X(NO_GX_REUSE) X(COLD_CGS2) X(COLD_Q) X(WARM_Q0) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG) X(JACOBI_RPL) X(NO_CHOL) X(NO_SYMM_MFMA)             \
-    X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA) X(GEMM_WGS) X(IMPLICIT_GRAM) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS)    \
-    X(OVERLAP_LDS) X(OVERLAP_NOPRIO)                                                                                       \
-    X(NO_TSMM) X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL)                                                                                 \
-    X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(UNHANKEL_FACTORS) X(PAD)                                                           \
-    X(NO_MAILBOX) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_ZGRAM) X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(NO_FUSED_GR) X(FUSED_ZGRAM_N512) \
-    X(OPGRAM_OLD) X(OPGRAM_H3) X(NO_HOOK_ZQ) X(GRAM_H3) X(GRAM_H3_FOLD) X(NO_WIDE_SWEEP) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL) X(HOOK_PAD_REFRESH) X(COLD_GROW) \
-    X(NO_SLICED_EIG) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(SLICE_NORMWISE) X(NO_MAXABS_ASYNC) X(HANKEL_STRUCT)
+#define TLSQ_DEV_LIST_LIVE(X)                                                                                             \
+    X(DEBUG) X(DEBUG_HASH) X(PHASE_TIMING) X(WS_POISON) X(FORCE_COMM) X(FORCE_LOCALGROUP) X(FAIL_RANK) X(NO_ZSWEEP)   \
+    X(FUSED_REBUILD) X(RUS_ROWS) X(RUS_CT) X(SWEEP_GRID) X(RSKIP_MARGIN) X(MATFUN_DEFL) X(NO_QUINTIC)                 \
+    X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(CERT_EARLY) X(CERT_PRIO) X(NO_SMALL_MM) X(COLD_Q)           \
+    X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
+    X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
+    X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT)
+// Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
+// (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
+// tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
+// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  39 live switches, 67 ablation switches.
+#define TLSQ_DEV_LIST_ABLATION(X)                                                                                         \
+    X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(NO_REBUILD_STORE) X(SWEEP_TIMING_STRIDE)               \
+    X(NO_MAX_BOUND) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS) X(FULL_EIG) X(NO_GRAM_DENSE)       \
+    X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(MATFUN_COND) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)            \
+    X(NO_CERT_OVERLAP) X(NO_DEFLATED_SVD) X(NO_FUSED_DEFLATE) X(NO_RR_FAST) X(NO_RR_BLOCKED) X(NO_U_POLISH)           \
+    X(NO_GX_REUSE) X(COLD_CGS2) X(NO_ONEPASS) X(NO_CHOLQR) X(NO_BLOCKED_CGS2) X(JACOBI2) X(NO_JACOBI_REG)             \
+    X(JACOBI_RPL) X(NO_CHOL) X(NO_SYMM_MFMA) X(GRAM_OLD) X(GRAM_RHO) X(GRAM_SPLIT) X(GRAM_ROWWISE) X(GRAM_F32MFMA)    \
+    X(GEMM_WGS) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS) X(OVERLAP_LDS) X(OVERLAP_NOPRIO) X(NO_TSMM)         \
+    X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL) X(UNHANKEL_FACTORS) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_GR)            \
+    X(NO_HOOK_ZQ) X(GRAM_H3_FOLD) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)            \
+    X(HOOK_PAD_REFRESH) X(COLD_GROW) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(NO_MAXABS_ASYNC)
+#define TLSQ_DEV_LIST(X) TLSQ_DEV_LIST_LIVE(X) TLSQ_DEV_LIST_ABLATION(X)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,
     TLSQ_DEV_LIST(TLSQ_DEV_ENUM)
 #undef TLSQ_DEV_ENUM
     DEV_COUNT
+};
+// the first DEV_LIVE_COUNT keys are the live ones
+enum { DEV_LIVE_COUNT = 0
+#define TLSQ_DEV_ONE(n) +1
+    TLSQ_DEV_LIST_LIVE(TLSQ_DEV_ONE)
+#undef TLSQ_DEV_ONE
 };
 const char* dev_get(DevKey k);   // the value as a string, nullptr when the switch is not set
 inline bool dev_is(DevKey k, char c) {

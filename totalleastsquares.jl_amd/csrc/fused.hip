@@ -14,12 +14,14 @@
 //   * waves 0..7 ("MFMA waves", two per SIMD) accumulate Z_{k+1}' Z_{k+1} of the previous stage from the other buffer:
 //     v_mfma_f64_16x16x4_f64, 17 (16) accumulator tiles per wave, fragments by conflict-free ds_read_b64;
 //   * one s_barrier per stage (LDS traffic only: the global loads stay in flight across it).
-// N = 256: every workgroup owns all 136 tiles of the lower triangle (16 x 16 tiles of 16 x 16).  N = 512: four kinds of
-// workgroup per row chunk - two "diagonal" ones (columns 0..255 / 256..511: they store Y, Z, R and own the 136 tiles of their
-// diagonal block) and two "rectangular" ones (columns 0..255 + one 128-column block of the other half, 8 x 16 tiles of
-// the off-diagonal block; they sweep their 384 columns again but store nothing) - dealt to the XCDs so that the four kinds
-// of a chunk share one L2 and march through the same rows together.  The partial Gram matrices go to split-K slabs in
-// the layout of gemm.hip's k_gram_kc and are summed in a fixed order by its k_slab_reduce (deterministic).
+// N = 256: every workgroup owns all 136 tiles of the lower triangle (16 x 16 tiles of 16 x 16).  N = 512: two workgroups per row
+// chunk, one per diagonal 256-column block (columns 0..255 / 256..511: each stores its Y, Z, R columns and owns the 136 tiles of
+// its diagonal block); the off-diagonal 256 x 256 block of the Gram matrix is accumulated afterwards from the stored Z_{k+1} by
+// k_gram_kc's off-diagonal body on a four-tile list (gemm.hip, gram_offdiag_*) and one kernel sums both slab sets in a fixed
+// order (fused_zgram_finish).  (A first build gave the off-diagonal block to two more "rectangular" workgroups per chunk that
+// swept 384 columns a second time for their operands: fp64 MFMA and vector instructions of one SIMD do not overlap on gfx950, so
+// the redundant sweeps cost more matrix time than the fusion saved - dropped in round 5.)  The partial Gram matrices go to
+// split-K slabs in the layout of gemm.hip's k_gram_kc and are summed in a fixed order by its k_slab_reduce (deterministic).
 //
 // Floating-point contraction is OFF in this file for the same reason as in sweeps.hip: the sweep statements are compared
 // bit for bit with the oracle's.

@@ -36,7 +36,12 @@ const char* dev_get(DevKey k) { return g_dev_set[k] ? g_dev_val[k].c_str() : nul
 int dev_set(const char* name, const char* value) {
     if (!name) return TLSQ_ERR_ARG;
     if (strncmp(name, "TLSQ_", 5) == 0) name += 5;
-    for (int k = 0; k < DEV_COUNT; ++k)
+#ifdef TLSQ_DEV_SWITCHES
+    const int nkeys = DEV_COUNT;
+#else
+    const int nkeys = DEV_LIVE_COUNT;   // (the ablation switches exist in development builds only: common.hpp)
+#endif
+    for (int k = 0; k < nkeys; ++k)
         if (strcmp(name, kDevNames[k]) == 0) {
             g_dev_set[k] = value != nullptr;
             g_dev_val[k] = value ? value : "";
