@@ -177,6 +177,19 @@ def test_c5_full_size_properties(eng):
     assert np.linalg.norm((D[::3] - (A[::3] + E[::3])).astype(np.float64)) < math.sqrt(N) * tol * rep.d_norm
     assert relerr(A[::5].astype(np.float64), A0[::5].astype(np.float64)) < 1e-3
     assert np.mean((E[::11] != 0) == (S0[::11] != 0)) > 0.99
+    # The fp32 LAPACK oracle's run of THIS panel (tests/golden/make_bench_vectors.py c5: two sgesdd of 65536 x 4096 per
+    # iteration, hours on the 8-core build box), when the fixture holds it: the exact mode against it at the fp32 bar.
+    with open(os.path.join(ROOT, "tests", "golden", "bench_vectors.json")) as f:
+        c5 = json.load(f).get("c5")
+    if c5:
+        A2, E2, s2, sv2, rep2 = eng.rpca(D, return_report=True, want_U=False, want_s=False)
+        n = min(rep2.iters_done, c5["iters"])
+        assert abs(rep2.iters_done - c5["iters"]) <= 1 and sv2 == c5["sv"] and rep2.svp_hist[:n] == c5["svp_hist"][:n]
+        st = c5["sample_stride"]
+        for X, key in ((A2, "A_sample"), (E2, "E_sample")):
+            got = X.ravel(order="F")[::st].astype(np.float64)
+            assert relerr(got, np.asarray(c5[key])) < 1e-3
+        assert rep2.kern["gram_h3"] > 0 and rep2.kern["zx_h"] > 0 and rep2.kern["zsweep_wide"] > 0
 
 
 def test_large_mode_rank_beyond_the_old_block_limit(eng):
