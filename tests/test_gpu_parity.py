@@ -1065,7 +1065,10 @@ def test_sharded_lowrankfilter_and_rpca_ga_single_rank(torch_mod):
     g1, g2, g3 = e2.lowrankfilter(y0 + nz, 40), e2.lowrankfilter(y2, 30, lag=2), e2.lowrankfilter(y0 + nz, 40, sv=2)
     Q2 = e2.rpca_ga(X, 2, q0=q0)
     e2.close()
-    assert np.array_equal(f1, g1) and np.array_equal(f2, g2) and np.array_equal(f3, g3)
+    assert np.array_equal(f1, g1) and np.array_equal(f2, g2)
+    # (sv > 0 on one GPU takes the structured form since round 6 - Gram matrix of H from lagged autocorrelations, csrc/hankelop.hip -
+    #  the time-window shard keeps the panels: the same filter to rounding, not bit for bit)
+    assert np.linalg.norm(f3 - g3) <= 1e-12 * np.linalg.norm(g3)
     assert np.array_equal(Q, Q2)
     assert relerr(f1, O.lowrankfilter(y0 + nz, 40)) < 1e-8
 

@@ -115,11 +115,11 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(CERT_EARLY) X(CERT_PRIO) X(NO_SMALL_MM) X(COLD_Q)           \
     X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
     X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
-    X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT)
+    X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET)
 // Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
 // (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
 // tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
-// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  39 live switches, 67 ablation switches.
+// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  40 live switches, 66 ablation switches.
 #define TLSQ_DEV_LIST_ABLATION(X)                                                                                         \
     X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(NO_REBUILD_STORE) X(SWEEP_TIMING_STRIDE)               \
     X(NO_MAX_BOUND) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS) X(FULL_EIG) X(NO_GRAM_DENSE)       \
@@ -130,7 +130,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(GEMM_WGS) X(HOOK_SKETCH) X(NO_F32_SKINNY) X(OVERLAP_CHUNKS) X(OVERLAP_LDS) X(OVERLAP_NOPRIO) X(NO_TSMM)         \
     X(NO_TSMM_SELV) X(TSMM_MAXR) X(NO_TSMM_SEL) X(UNHANKEL_FACTORS) X(GA_BLOCKS) X(GA_SOLO) X(NO_FUSED_GR)            \
     X(NO_HOOK_ZQ) X(GRAM_H3_FOLD) X(HOOK_CLASSIC) X(HOOK_POWER) X(HOOK_COLD) X(HOOK_CGS2) X(HOOK_ORTH_ALL)            \
-    X(HOOK_PAD_REFRESH) X(COLD_GROW) X(SLICE_SCHED) X(SLICE_TARGET) X(SLICE_LEVELS) X(SLICE_L0) X(NO_MAXABS_ASYNC)
+    X(HOOK_PAD_REFRESH) X(COLD_GROW) X(SLICE_SCHED) X(SLICE_LEVELS) X(SLICE_L0) X(NO_MAXABS_ASYNC)
 #define TLSQ_DEV_LIST(X) TLSQ_DEV_LIST_LIVE(X) TLSQ_DEV_LIST_ABLATION(X)
 enum DevKey {
 #define TLSQ_DEV_ENUM(n) DEV_##n,

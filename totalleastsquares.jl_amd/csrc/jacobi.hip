@@ -742,6 +742,15 @@ __device__ __forceinline__ double jr_reduce16(double (&v)[16], int lane) {
     return v[0];
 }
 
+// 1 / sqrt(x) for x > 0: the hardware estimate (v_rsq_f64, ~2^-26) and two Newton steps y <- y (3/2 - x y^2 / 2)
+__device__ __forceinline__ double jr_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    return y;
+}
+
 // one round: rotate the 16 pairs (c[P1(k)], c[P2(k)]) given by the position maps of the schedule.  a, bb: squared norms of
 // the two members of "this lane's" pair I = lane >> 2 (the same numbers in the four lanes of a group and in every wave).
 // (RPL rows per lane: a wave covers 64 RPL rows, so half as many waves meet at the barrier and add up half as many partials)
@@ -760,19 +769,32 @@ __device__ __forceinline__ void jr_round(double (&c)[RPL][32], JrShared<NW>& sh,
     }
     const double tot = jr_reduce16(v, lane);
     const int I = lane >> 2;   // lanes 4 I .. 4 I + 3 hold the wave's partial of pair I:  I = b5 8 + b4 4 + b3 2 + b2
-    if ((lane & 3) == 0) sh.part[par][w][I] = tot;
-    __syncthreads();
-    // every wave adds the partials in wave order and works out the rotation of "its lane's" pair: the same bits everywhere
     double cc = 0.0;
+    if constexpr (NW == 1) {
+        // one wave covers all rows (the slices' own small problems, sliced.hip): the wave's sum IS the dot product - no LDS
+        // exchange, no barrier in the round
+        cc = tot;
+    } else {
+        if ((lane & 3) == 0) sh.part[par][w][I] = tot;
+        __syncthreads();
+        // every wave adds the partials in wave order and works out the rotation of "its lane's" pair: the same bits everywhere
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) cc += sh.part[par][ww][I];
+        for (int ww = 0; ww < NW; ++ww) cc += sh.part[par][ww][I];
+    }
     const double mn = a < bb ? a : bb;
     double cs = 1.0, sn = 0.0;
     if (cc * cc > tol2 * a * bb && mn > floor2) {
+        // The rotation from two reciprocal square roots and no division (round 6; the chain sqrt - divide - sqrt - divide of the
+        // textbook form was most of a round's latency): with h = sqrt(d^2 + 4 cc^2), cos 2theta = |d| / h, sin 2theta = sgn(d) 2 cc / h,
+        //   c = sqrt((1 + cos 2theta) / 2),   s = sin 2theta / (2 c),   t = s / c = 2 cc sgn(d) / (|d| + h)   (the same angle)
+        // v_rsq_f64 + two Newton steps: c^2 + s^2 = 1 to a few ulp.
         const double d = bb - a;
-        const double t = (d >= 0.0 ? 2.0 : -2.0) * cc / (fabs(d) + sqrt(d * d + 4.0 * cc * cc));
-        cs = 1.0 / sqrt(1.0 + t * t);
-        sn = cs * t;
+        const double r = jr_rsqrt(d * d + 4.0 * cc * cc);   // 1 / h
+        const double c2 = 0.5 + 0.5 * (fabs(d) * r);         // c^2, in [1/2, 1]
+        const double ic = jr_rsqrt(c2);                      // 1 / c
+        cs = c2 * ic;
+        sn = (d >= 0.0 ? cc : -cc) * r * ic;
+        const double t = sn * ic;
         const double na = a - t * cc, nb = bb + t * cc;
         a = na > 0.0 ? na : 0.0;
         bb = nb > 0.0 ? nb : 0.0;

@@ -356,6 +356,44 @@ int small_mm_batched(Handle* h, const double* A, int64_t sA, const double* B, in
     return TLSQ_OK;
 }
 
+// C_z = A_{idx[z]} B for z < nb <= 32: the first operand of problem z is matrix idx[z] of the array at Abase (stride N^2), B is
+// shared, the results are consecutive at C (stride N^2).  Commuting symmetric operands (lower tiles + mirror).  The slicer's
+// children P_z Q of a level (sliced.hip): the parents' projectors sit in scattered slots.
+struct MfBatchIdx {
+    int32_t a[32];
+};
+__global__ __launch_bounds__(512) void k_small_mm_blk_bi(const double* __restrict__ Abase, MfBatchIdx ix, const double* __restrict__ B,
+                                                         double* __restrict__ C, int N, int nt) {
+    __shared__ double sR[8 * 1024];
+    const int z = blockIdx.y;
+    const int64_t nn = (int64_t)N * N;
+    const double* A = Abase + (int64_t)ix.a[z] * nn;
+    double* Cz = C + (int64_t)z * nn;
+    int ti, tj;
+    double v[2];
+    smm_blk_tile<true>(A, B, N, nt, sR, ti, tj, v);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int e = tid + 512 * half;
+        const int sub2 = e >> 8, q2 = (e >> 6) & 3, l2 = e & 63;
+        const int i = ti * 32 + (sub2 & 1) * 16 + 4 * q2 + (l2 >> 4), j = tj * 32 + (sub2 >> 1) * 16 + (l2 & 15);
+        if (ti != tj || j <= i) {
+            Cz[i + (int64_t)j * N] = v[half];
+            Cz[j + (int64_t)i * N] = v[half];
+        }
+    }
+}
+int small_mm_batched_idx(Handle* h, const double* Abase, const int32_t* idx, int nb, const double* B, double* C, int64_t N) {
+    if ((N % 128) != 0 || N > 2048 || nb < 1 || nb > 32) return set_err(h, TLSQ_ERR_ARG, "small_mm_batched_idx: N = %lld, nb = %d", (long long)N, nb);
+    MfBatchIdx ix = {};
+    for (int z = 0; z < nb; ++z) ix.a[z] = idx[z];
+    const int nt = (int)(N / 32);
+    hipLaunchKernelGGL(k_small_mm_blk_bi, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)nb), dim3(512), 0, h->stream, Abase, ix, B, C, (int)N, nt);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 // X_z = alpha_z P_z K + beta_z I + gamma_z P_z for z < nb <= 8 (P_z, K commuting symmetric matrices; P_z: stride N^2, K shared):
 // the start of the sign iteration of a slice whose spectral projector is P_z (sliced.hip)
 int small_mm_batched_start(Handle* h, const double* P, const double* K, double* X, int64_t N, int nb, const double* alpha,
@@ -447,6 +485,17 @@ __global__ __launch_bounds__(64) void k_mf_slice_stats2(const double* __restrict
     double a = 0.0;
     for (int ch = 0; ch < MF_SS_CHUNKS; ++ch) a += part[((int64_t)z * MF_SS_CHUNKS + ch) * 4 + q];
     out[4 * z + q] = a;
+}
+
+// k_mf_slice_stats of nb <= 16 consecutive matrices at S (trace, <S, K>, ||S||_F^2, <S, K2>) into stats_dev (4 nb doubles)
+int slice_stats_batched(Handle* h, const double* S, const double* K, const double* K2, int64_t N, int nb, double* stats_dev) {
+    if (nb < 1 || nb > 16) return set_err(h, TLSQ_ERR_ARG, "slice_stats_batched: nb = %d", nb);
+    void* part;
+    TLSQ_TRY(ws_get(h, WS_MFP, (size_t)3 * 16 * 2048 * 8, &part));
+    hipLaunchKernelGGL(k_mf_slice_stats, dim3((unsigned)nb, MF_SS_CHUNKS), dim3(1024), 0, h->stream, S, K, K2, (int)N, (double*)part);
+    hipLaunchKernelGGL(k_mf_slice_stats2, dim3(1), dim3(64), 0, h->stream, (const double*)part, nb, stats_dev);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
 }
 
 // sign(K - t_z I) for nb <= 8 split points t_z side by side, on a FIXED schedule (no convergence tests, no host round trip):

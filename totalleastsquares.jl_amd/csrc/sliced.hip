@@ -44,25 +44,42 @@ namespace tlsq {
 
 namespace {
 
-constexpr int SL_MAXSL = 16;     // slices = projector matrices kept
+constexpr int SL_MAXSL = 32;     // slices = projector matrices kept
 constexpr int SL_MAXK = 256;     // columns of one slice the pivoted Cholesky takes
 
-struct ChildMap {   // per split z of a level: parent's projector slot (becomes the upper child), slot of the lower child
-    int32_t parent[8], low[8];
+struct ChildMap {   // per cut z of a level: the parent's projector slot (it becomes the upper child), the slot of the lower child
+    int32_t n;
+    int32_t parent[SL_MAXSL], low[SL_MAXSL];
 };
 
-// P_low = (I - S_z) / 2 into slot low[z];  P_parent <- P_parent - P_low (the upper child)
-__global__ __launch_bounds__(256) void k_slice_children(const double* __restrict__ S, double* __restrict__ PJ, int N, ChildMap m) {
+// P_parent <- P_parent - P_low (the upper child), for every cut of the level
+__global__ __launch_bounds__(256) void k_slice_children(double* __restrict__ PJ, int N, ChildMap m) {
     const int z = blockIdx.y;
     const int64_t total = (int64_t)N * N;
-    const double* Sz = S + (int64_t)z * total;
     double* Pp = PJ + (int64_t)m.parent[z] * total;
-    double* Pl = PJ + (int64_t)m.low[z] * total;
+    const double* Pl = PJ + (int64_t)m.low[z] * total;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) Pp[e] -= Pl[e];
+}
+
+struct CutMap {   // the cuts of a level: projector slot, 1 / nrm, -t / nrm - 1
+    int32_t n;
+    int32_t slot[SL_MAXSL];
+    double alpha[SL_MAXSL], beta1[SL_MAXSL];
+};
+
+// A = sum_z alpha_z P_z,  B = I + sum_z beta1_z P_z  (so that A K + B = sum_z P_z (K - t_z I) / nrm_z + (I - sum_z P_z))
+__global__ __launch_bounds__(256) void k_slice_start(const double* __restrict__ PJ, int N, CutMap m, double* __restrict__ A,
+                                                     double* __restrict__ B) {
+    const int64_t total = (int64_t)N * N;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int i = (int)(e % N), j = (int)(e / N);
-        const double pl = 0.5 * ((i == j ? 1.0 : 0.0) - Sz[e]);
-        Pl[e] = pl;
-        Pp[e] -= pl;
+        double a = 0.0, bsum = (e % N) == (e / N) ? 1.0 : 0.0;
+        for (int z = 0; z < m.n; ++z) {
+            const double pv = PJ[(int64_t)m.slot[z] * total + e];
+            a += m.alpha[z] * pv;
+            bsum += m.beta1[z] * pv;
+        }
+        A[e] = a;
+        B[e] = bsum;
     }
 }
 
@@ -156,8 +173,8 @@ struct Slice {
 
 int small_mm_batched(Handle* h, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC, int64_t N, int nb,
                      double alpha, double beta, bool sym, const double* Add, int64_t sAdd, double gamma);
-int small_mm_batched_start(Handle* h, const double* P, const double* K, double* X, int64_t N, int nb, const double* alpha,
-                           const double* beta, const double* gamma);
+int small_mm_batched_idx(Handle* h, const double* Abase, const int32_t* idx, int nb, const double* B, double* C, int64_t N);
+int slice_stats_batched(Handle* h, const double* S, const double* K, const double* K2, int64_t N, int nb, double* stats_dev);
 int matfun_sign_batched(Handle* h, const double* K, const double* K2, int64_t N, int nb, const double* t, double hi, double l0, double* X,
                         double* W1, double* W2, double** out, double* stats_dev, int* steps_out);
 int jacobi_factor_grouped_f64(Handle* h, double* B, int64_t N, const std::vector<std::pair<int, int>>& groups, double* V,
@@ -183,8 +200,8 @@ int slice_bufs(Handle* h, int64_t N, SliceBufs* b) {
     const int64_t nn = N * N;
     void *scal, *buf;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-    b->sstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 3072);   // 4 x 8 doubles of a sign batch (2048..2448 is the SpecCtrl)
-    b->failflag = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 3328);
+    b->sstats = reinterpret_cast<double*>(reinterpret_cast<char*>(scal) + 3072);   // 4 x 16 doubles of a level's children (2048..2448 is the SpecCtrl)
+    b->failflag = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 3584);
     // one slab: K | K^2 | J | J' | E | 3 x 8 iterates | projectors
     const int64_t nbuf = 5 + 24 + SL_MAXSL;
     TLSQ_TRY(ws_get(h, WS_SL_BUF, (size_t)nbuf * nn * 8, &buf));
@@ -232,17 +249,26 @@ int slice_spectrum(Handle* h, int64_t N, const SliceBufs& b, double lam_hi, int 
     sl.push_back(Slice{0.0, hi, 0, (double)N, trK, trK2});
     int nslot = 1, total_steps = 0, levels = 0, nsign = 0;
     const bool hint = n_out > 0 && val_out > 0.0 && bulk_hi > 0.0 && bulk_hi < 0.5 * val_out && n_out < (int)N;
+    double* Am = b.J;    // scratch of a level (the basis buffers are free until the slices exist): sum_z alpha_z P_z
+    double* Bm = b.J2;   // I + sum_z (beta_z - 1) P_z
+    double* Qm = b.E;    // (I - S) / 2
     for (int lev = 0; lev < maxlev; ++lev) {
-        // the slices to cut at this level: the largest first, at most 8, while projector slots are left
+        // the slices to cut at this level: every one that is still too large (the largest first while projector slots last)
         std::vector<int> pick;
         for (int j = 0; j < (int)sl.size(); ++j)
             if (sl[(size_t)j].cnt > (double)target + 0.5) pick.push_back(j);
         std::sort(pick.begin(), pick.end(), [&](int x, int y) { return sl[(size_t)x].cnt > sl[(size_t)y].cnt; });
-        const int room = std::min(8, SL_MAXSL - nslot);
+        const int room = std::min(16, SL_MAXSL - nslot);
         if ((int)pick.size() > room) pick.resize((size_t)std::max(0, room));
         if (pick.empty()) break;
         std::sort(pick.begin(), pick.end());
-        std::vector<double> t, al, be, ga;
+        // ONE sign iteration serves every cut of the level: the slices are invariant subspaces of K with mutually orthogonal
+        // projectors, so a function of  X_0 = sum_z P_z (K - t_z I) / nrm_z + (I - sum_z P_z)  acts on slice z as the function of
+        // (K - t_z I) / nrm_z - each slice scaled by its own width - and leaves everything else at +1.  (Round 6, first build: one
+        // iteration per cut, batched - four 512 x 512 iterations at the third level cost what the four levels cost now.)
+        CutMap cmap;
+        memset(&cmap, 0, sizeof(cmap));
+        std::vector<double> t;
         std::vector<int> cut;
         double lev_l0 = l0;
         for (int j : pick) {
@@ -265,55 +291,64 @@ int slice_spectrum(Handle* h, int64_t N, const SliceBufs& b, double lam_hi, int 
             // (the mean of at least two distinct eigenvalues lies strictly inside; anything else: leave the slice alone)
             if (!(tj > s.lo + 1e-9 * (s.hi - s.lo)) || !(tj < s.hi - 1e-9 * (s.hi - s.lo))) continue;
             const double nrm = std::max(tj - s.lo, s.hi - tj);
-            // X_0 = (K_s - t I) / nrm,  K_s = P K + hi (I - P)
+            cmap.slot[cmap.n] = s.slot;
+            cmap.alpha[cmap.n] = 1.0 / nrm;
+            cmap.beta1[cmap.n] = -tj / nrm - 1.0;
+            ++cmap.n;
             t.push_back(tj);
-            al.push_back(1.0 / nrm);
-            ga.push_back(-s.hi / nrm);
-            be.push_back((s.hi - tj) / nrm);
             cut.push_back(j);
         }
         if (t.empty()) break;
         const int nb = (int)t.size();
-        // the parents' projectors side by side (slots are not contiguous: gather through the iterate buffer W2)
-        for (int z = 0; z < nb; ++z)
-            TLSQ_HIP(h, hipMemcpyAsync(W2 + (int64_t)z * nn, PJ + (int64_t)sl[(size_t)cut[(size_t)z]].slot * nn, (size_t)nn * 8,
-                                       hipMemcpyDeviceToDevice, h->stream));
-        TLSQ_TRY(small_mm_batched_start(h, W2, K, X, N, nb, al.data(), be.data(), ga.data()));
+        {
+            int64_t g = (nn + 255) / 256;
+            if (g > 1024) g = 1024;
+            hipLaunchKernelGGL(k_slice_start, dim3((unsigned)g), dim3(256), 0, h->stream, (const double*)PJ, (int)N, cmap, Am, Bm);
+            TLSQ_HIP(h, hipGetLastError());
+        }
+        TLSQ_TRY(small_mm_batched(h, Am, nn, K, nn, X, nn, N, 1, 1.0, 0.0, true, Bm, nn, 1.0));   // X_0 = A K + B
         double* out = nullptr;
         int steps = 0;
-        TLSQ_TRY(matfun_sign_batched(h, K, K2, N, nb, nullptr, 0.0, lev_l0, X, W1, W2, &out, b.sstats, &steps));
+        TLSQ_TRY(matfun_sign_batched(h, K, K2, N, 1, nullptr, 0.0, lev_l0, X, W1, W2, &out, nullptr, &steps));
         total_steps += steps;
-        nsign += nb;
+        nsign += 1;
+        // below a cut the sign is -1: Q = (I - S) / 2 is the sum of the lower children's projectors, P_low_z = P_z Q
+        TLSQ_TRY(matfun_axpbi(h, out, Qm, N, -0.5, 0.5));
+        std::vector<int32_t> idx((size_t)nb);
+        for (int q = 0; q < nb; ++q) idx[(size_t)q] = sl[(size_t)cut[(size_t)q]].slot;
+        double* kids = PJ + (int64_t)nslot * nn;   // the lower children: consecutive new slots
+        TLSQ_TRY(small_mm_batched_idx(h, PJ, idx.data(), nb, Qm, kids, N));
+        TLSQ_TRY(slice_stats_batched(h, kids, K, K2, N, nb, b.sstats));
         TLSQ_HIP(h, hipMemcpyAsync(h->pinned, b.sstats, (size_t)nb * 32, hipMemcpyDeviceToHost, h->stream));
         TLSQ_HIP(h, hipStreamSynchronize(h->stream));
         std::vector<double> hs((size_t)nb * 4);
         memcpy(hs.data(), h->pinned, (size_t)nb * 32);
         ChildMap cm;
         memset(&cm, 0, sizeof(cm));
+        double soft = 0.0;
         for (int q = 0; q < nb; ++q) {
             const double tr = hs[(size_t)q * 4], ip = hs[(size_t)q * 4 + 1], fr = hs[(size_t)q * 4 + 2], ip2 = hs[(size_t)q * 4 + 3];
             if (!std::isfinite(tr) || !std::isfinite(ip) || !std::isfinite(fr) || !std::isfinite(ip2)) return TLSQ_OK;
-            // ||S||_F^2 = N for an exact sign matrix; what is missing are eigenvalues the schedule did not carry to +-1
+            // ||P||_F^2 = trace(P) for a projector; what is missing are eigenvalues the schedule did not carry to +-1
             if (dbg)
-                fprintf(stderr, "  slicer: level %d, slice [%.4e, %.4e] of %.1f cut at %.6e: %.2f below, N - ||S||_F^2 = %.3e (%d steps)\n", lev,
-                        sl[(size_t)cut[(size_t)q]].lo, sl[(size_t)cut[(size_t)q]].hi, sl[(size_t)cut[(size_t)q]].cnt, t[(size_t)q],
-                        0.5 * ((double)N - tr), (double)N - fr, steps);
-            if (std::fabs((double)N - fr) > 0.05 * (double)N) return TLSQ_OK;
+                fprintf(stderr, "  slicer: level %d, slice [%.4e, %.4e] of %.1f cut at %.6e: %.2f below, trace - ||P||_F^2 = %.3e (%d steps)\n", lev,
+                        sl[(size_t)cut[(size_t)q]].lo, sl[(size_t)cut[(size_t)q]].hi, sl[(size_t)cut[(size_t)q]].cnt, t[(size_t)q], tr, tr - fr, steps);
+            soft += std::fabs(tr - fr);
             cm.parent[q] = sl[(size_t)cut[(size_t)q]].slot;
             cm.low[q] = nslot + q;
         }
+        if (soft > 0.05 * (double)N) return TLSQ_OK;
+        cm.n = nb;
         {
             int64_t g = (nn + 255) / 256;
             if (g > 512) g = 512;
-            hipLaunchKernelGGL(k_slice_children, dim3((unsigned)g, (unsigned)nb), dim3(256), 0, h->stream, (const double*)out, PJ, (int)N, cm);
+            hipLaunchKernelGGL(k_slice_children, dim3((unsigned)g, (unsigned)nb), dim3(256), 0, h->stream, PJ, (int)N, cm);
             TLSQ_HIP(h, hipGetLastError());
         }
         for (int q = nb - 1; q >= 0; --q) {
             const int j = cut[(size_t)q];
             const Slice s = sl[(size_t)j];
-            const double tr = hs[(size_t)q * 4], ip = hs[(size_t)q * 4 + 1], ip2 = hs[(size_t)q * 4 + 3];
-            // below the cut the sign is -1: P_low = (I - S) / 2
-            const double cnt_lo = 0.5 * ((double)N - tr), sum_lo = 0.5 * (trK - ip), sum2_lo = 0.5 * (trK2 - ip2);
+            const double cnt_lo = hs[(size_t)q * 4], sum_lo = hs[(size_t)q * 4 + 1], sum2_lo = hs[(size_t)q * 4 + 3];
             Slice lo_c{s.lo, t[(size_t)q], nslot + q, cnt_lo, sum_lo, sum2_lo};
             Slice hi_c{t[(size_t)q], s.hi, s.slot, s.cnt - cnt_lo, s.sum - sum_lo, s.sum2 - sum2_lo};
             hi_c.hi = std::min(hi_c.hi, std::max(hi_c.lo, std::sqrt(std::max(hi_c.sum2, 0.0)) * (1.0 + 1e-9)));
@@ -570,7 +605,7 @@ int symeig_sliced_normwise_f64(Handle* h, const double* G, int64_t N, double* V,
     TLSQ_TRY(slice_bufs(h, N, &b));
     void* scal;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
-    unsigned long long* omax = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scal) + 3336);
+    unsigned long long* omax = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scal) + 3592);
     TLSQ_HIP(h, hipMemcpyAsync(b.K, G, (size_t)nn * 8, hipMemcpyDeviceToDevice, h->stream));
     SlicePlan pl;
     bool ok = false;

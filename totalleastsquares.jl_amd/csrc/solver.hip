@@ -818,8 +818,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     double maxabs = 0.0;
     // (plain calls on one GPU: the max-abs pass runs on the second stream beside the Gram matrix of the set-up norm - it is
     //  memory-bound, the Gram is not - and its result is read together with the norm's: one host round trip less, ~60 us at C2)
+    // (large fp32 panels: the fp16-split Gram matrix of the set-up needs max |D| for its scale BEFORE it runs - the pass stays in
+    //  line there and its result doubles as that scale, see below)
     const bool maxabs_async = !(ro.hankel_lazy && ro.hankel_y) && !cb_opnorm && !hook_opnorm && !implicit_gram && !h->comm &&
-                              !dev_is(DEV_NO_MAXABS_ASYNC, '1');
+                              !(Prec<T>::f32 && N > kFullEigMaxN) && !dev_is(DEV_NO_MAXABS_ASYNC, '1');
     if (ro.hankel_lazy && ro.hankel_y) {   // every sample of the window appears in its Hankel matrix (lag <= L): max |H| = max |y|
         const HankelGeom& hg = ro.hankel_geom;
         const int64_t Nw = (ro.hankel_K - 1) * hg.lag + N / hg.Dch;
@@ -842,6 +844,20 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         return TLSQ_OK;
     };
     if (!maxabs_async) TLSQ_TRY(finish_maxabs());
+    if constexpr (Prec<T>::f32) {
+        // max |D| is also the scale of the fp16 split of D (gram16.hip): left where a sweep would leave it (Handle::absmax_panel),
+        // so that the set-up's Gram matrix does not make a max pass of its own (0.3 ms at 65536 x 4096).  An upper bound serves
+        // (on row shards the all-reduced maximum).
+        if (!maxabs_async && N > kFullEigMaxN && !(ro.hankel_lazy && ro.hankel_y) && maxabs > 0.0 && maxabs < 3.0e38) {
+            void* sc;
+            TLSQ_TRY(ws_get(h, WS_H16S, 64, &sc));
+            const float mf = std::nextafter((float)maxabs, std::numeric_limits<float>::infinity());   // (rounded up: still a bound)
+            unsigned int bits;
+            memcpy(&bits, &mf, 4);
+            TLSQ_TRY(upload_async(h, reinterpret_cast<char*>(sc) + 40, &bits, 4));
+            h->absmax_panel = (const void*)D;
+        }
+    }
     if (cb_opnorm) TLSQ_TRY(opnorm_callback(D, &norm2));                             // :177 through the caller's hook
     else if (hook_opnorm) TLSQ_TRY(opnorm_power<T>(h, D, M, N, M, mvps, seed, &norm2));   // :177 through the hook
     else if (implicit_gram) TLSQ_TRY(sigma_max_of_op(h, panel_op(D), N, 1e-13, &norm2));

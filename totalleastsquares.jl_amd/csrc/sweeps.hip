@@ -1400,7 +1400,7 @@ int launch_maxabs_begin(Handle* h, const T* x, int64_t n) {
     TLSQ_TRY(second_stream(h));
     void* slot;
     TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &slot));
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(slot) + 3408);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(slot) + 3600);   // (3072..3600: the slicer's statistics and flags, sliced.hip)
     // (the second stream may only start once everything queued so far on the main one is done: the workspace slot, x)
     TLSQ_HIP(h, hipEventRecord(h->ev_b[8], h->stream));
     TLSQ_HIP(h, hipStreamWaitEvent(h->stream_b, h->ev_b[8], 0));
