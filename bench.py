@@ -282,13 +282,16 @@ def main():
             run5 = lambda: eng.rpca_device(d5.data_ptr(), M5, N5, a5.data_ptr(), e5.data_ptr(), want_hist=False, dtype=np.float32, **kw)
             run5()
             torch.cuda.synchronize()
-            t5 = time.perf_counter()
+            # (every call timed on its own - blocking call + device synchronisation - and added up: what lies BETWEEN two calls
+            #  of this process - the allocator returning the gigabytes of the panel generation to the system - is not the solve's)
+            t5 = 0.0
             n5 = 0
             for _ in range(2):
+                t5a = time.perf_counter()
                 sv5, rep5, st5 = run5()
+                torch.cuda.synchronize()
+                t5 += time.perf_counter() - t5a
                 n5 += rep5.iters_done
-            torch.cuda.synchronize()
-            t5 = time.perf_counter() - t5
             err5 = float(torch.linalg.norm(a5 - A05) / torch.linalg.norm(A05))
             c5[tag] = {"ms_per_iter": t5 / n5 * 1e3, "ms_per_solve": t5 / 2 * 1e3, "iters_per_solve": rep5.iters_done, "sv": int(sv5),
                        "converged": bool(rep5.converged), "rel_err_A_vs_planted": err5}
@@ -484,7 +487,7 @@ def main():
         # same command (rocprofv3 --pmc in separate passes, tools/profile_round.sh; a counter pass cannot run inside this
         # process), committed under profiles/
         out["roofline"]["traffic_pmc"] = None
-        for pmc_file in ("r05_pmc_sweeps.json", "r04_pmc_sweeps.json", "r03_pmc_sweeps.json", "r02_pmc_sweeps.json"):
+        for pmc_file in ("r06_pmc_sweeps.json", "r05_pmc_sweeps.json", "r04_pmc_sweeps.json", "r03_pmc_sweeps.json", "r02_pmc_sweeps.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     pmc = json.load(f)

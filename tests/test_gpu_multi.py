@@ -338,6 +338,39 @@ def test_loopback_large_panel_shards_fused_rebuild_sweep():
     assert relerr(A2, A0) < 1e-6
 
 
+def test_loopback_uneven_shards_agree_on_the_collective_sequence():
+    """decisions that depend on the rank-local row count and change WHICH collectives an iteration enters are agreed on
+    before the loop (one min-all-reduce of the shape flags, solver.hip).  (a) 800003 x 256 fp64 on two ranks = 400002 + 400001
+    rows: the fused sweep + Gram kernel (fused.hip: even row count, >= 400000 rows) can serve one shard and not the other - its
+    residual-Gram mode would all-reduce R'R where the other rank all-reduces Z'Z.  (b) 16385 x 8192 fp32 = 8193 + 8192 rows: the
+    fp16-split shape (M % 64 == 0) holds on one rank only, and at N = 8192 it decides between an N x N Gram all-reduce and the
+    N x p all-reduces of the operator form.  Both complete (a mismatch is a hang that the loop-back barrier turns into an error) and
+    reproduce the one-GPU solve."""
+    import torch  # noqa: F401
+    import tlsq_amd
+    from oracle import rpca_oracle as O
+    plain = tlsq_amd.Engine(0)
+    multi = tlsq_amd.Engine(devices=[0, 0])
+    try:
+        D, A0, _ = O.synth_lowrank_sparse(800_003, 256, 4, seed=8)
+        A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+        A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+        assert rep1.converged and rep2.converged and sv2 == sv1 == 4
+        assert rep2.iters_done == rep1.iters_done and rep2.svp_hist == rep1.svp_hist
+        assert relerr(A2, A1) < 1e-9 and relerr(E2, E1) < 1e-9
+        del D, A0, A1, E1, A2, E2
+        D, A0, _ = O.synth_lowrank_sparse(16385, 8192, 12, seed=9, dtype=np.float32)
+        A1, E1, s1, sv1, rep1 = plain.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+        A2, E2, s2, sv2, rep2 = multi.rpca(D, return_report=True, want_U=False, want_s=False, cost_history=False)
+        assert rep1.converged and rep2.converged and sv2 == sv1 == 12
+        assert abs(rep2.iters_done - rep1.iters_done) <= 1
+        assert relerr(A2.astype(np.float64), A1.astype(np.float64)) < 1e-3
+        assert relerr(A2.astype(np.float64), A0.astype(np.float64)) < 1e-3
+    finally:
+        multi.close()
+        plain.close()
+
+
 def test_loopback_large_mode_fp32_shards():
     """BASELINE config 5's shape class on row shards: fp32, min(M, N) > 2048 (large mode: subspace solver only, the Gram
     of every shard on the fp32 MFMA with fp64 fold-in, all-reduced), two ranks; against the one-GPU solve."""

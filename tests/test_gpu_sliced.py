@@ -101,3 +101,53 @@ def test_truncation_at_config3_size_holds_no_panel(eng):
     assert (free0 - free1) < 2.5e9, f"{(free0 - free1) / 1e9:.2f} GB resident"       # (a K x n panel is 20.5 GB)
     qn = lambda v: v / np.quantile(np.abs(v), 0.9)
     assert np.mean((y - qn(yf)) ** 2) / np.mean((0.1 * noise) ** 2) < 0.05
+
+
+# ---- the factor form on its own: eig_full's Cholesky route through the kernel-level entry -------------------------------------
+def _spd(kind, N, rng):
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    if kind == "flat":            # a flat bulk: what the returned `s` leaves after the deflation
+        lam = rng.uniform(1.0, 2.0, N)
+    elif kind == "outliers":      # a few large eigenvalues above a flat bulk (an undeflated Gram matrix)
+        lam = np.concatenate([rng.uniform(1e4, 1e6, 12), rng.uniform(1.0, 1.5, N - 12)])
+    elif kind == "graded":        # five decades, evenly in the logarithm
+        lam = np.geomspace(1.0, 1e-5, N)
+    elif kind == "clusters":      # eight tight clusters
+        lam = np.repeat(np.arange(1.0, 9.0), N // 8) * (1.0 + 1e-9 * rng.standard_normal(N))
+    else:                         # two eigenvalues 1e-7 apart right where the first cut goes (the mean)
+        lam = np.linspace(1.0, 2.0, N)
+        lam[N // 2] = lam.mean() * (1 - 5e-8)
+        lam[N // 2 + 1] = lam.mean() * (1 + 5e-8)
+    return (Q * lam) @ Q.T, np.sort(lam)[::-1]
+
+
+@pytest.mark.parametrize("kind", ["flat", "outliers", "graded", "clusters", "knife"])
+@pytest.mark.parametrize("N", [256, 384, 512, 1024])
+def test_symeig_through_the_slicer_on_synthetic_spectra(eng, N, kind):
+    """tlsq_k_symeig_chol_f64 = eig_full's Cholesky route: with the slicer in front (default) and without (NO_SLICED_EIG=1) - the
+    same eigenvalues (N eps lambda_max, the accuracy of the Cholesky factor), orthonormal vectors, small residuals; whatever the
+    slicer declines (too many equal eigenvalues for a slice) must come out of the plain route unchanged."""
+    import ctypes as C
+    import torch
+    import tlsq_amd
+    rng = np.random.default_rng(N + len(kind))
+    G, ref = _spd(kind, N, rng)
+    G = (G + G.T) / 2
+    dG = torch.from_numpy(np.ascontiguousarray(G.T)).cuda()
+    out = {}
+    for tag, sw in (("sliced", {}), ("plain", dict(NO_SLICED_EIG=1))):
+        dl = torch.zeros(N, dtype=torch.float64, device="cuda")
+        dV = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+        sweeps = C.c_int64()
+        with tlsq_amd.dev_switches(**sw):
+            st = eng.lib.tlsq_k_symeig_chol_f64(eng.h, C.c_void_p(dG.data_ptr()), N, N, C.c_void_p(dl.data_ptr()),
+                                                C.c_void_p(dV.data_ptr()), N, C.byref(sweeps))
+        assert st == 0, eng.lib.tlsq_last_error(eng.h)
+        out[tag] = (dl.cpu().numpy(), dV.cpu().numpy().T, sweeps.value)
+    for tag in ("sliced", "plain"):
+        lam, V, sw = out[tag]
+        assert np.all(np.diff(lam) <= 0)
+        assert np.max(np.abs(lam - ref)) < 32 * N * 2.2e-16 * ref[0], (tag, np.max(np.abs(lam - ref)) / ref[0])
+        assert np.max(np.abs(V.T @ V - np.eye(N))) < 1e-10, tag
+        assert np.linalg.norm(G @ V - V * lam[None, :]) < 1e-11 * np.linalg.norm(G) * np.sqrt(N), tag
+    assert np.max(np.abs(out["sliced"][0] - out["plain"][0])) < 32 * N * 2.2e-16 * ref[0]

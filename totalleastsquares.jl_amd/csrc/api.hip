@@ -1003,7 +1003,11 @@ int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ld
     TLSQ_TRY(ws_get(h, WS_LAM, (size_t)N * 8, &lamw));
     int64_t sw = 0;
     double delta = 0.0;
-    TLSQ_TRY(symeig_chol_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw));
+    // (as eig_full does it: the spectrum cut into slices first where the shape allows - sliced.hip, factor form, no hints)
+    bool sliced = false;
+    if (symeig_sliced_ok(N))
+        TLSQ_TRY(symeig_sliced_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw, 0.0, 0, 0.0, 0.0, &sliced));
+    if (!sliced) TLSQ_TRY(symeig_chol_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw));
     if (sweeps) *sweeps = sw;
     std::vector<double> hl((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lamw, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
