@@ -12,7 +12,7 @@ spec = importlib.util.spec_from_file_location("w", os.path.join(os.path.dirname(
 from oracle import rpca_oracle as O
 M5, N5, r5 = 65536, 4096, 64
 eng = tlsq_amd.Engine(0)
-for panel in ("numpy",):
+for panel in ("torch", "numpy"):
     if panel == "torch":
         g5 = torch.Generator(device="cuda").manual_seed(5)
         A05 = (torch.randn(N5, r5, device="cuda", generator=g5) @ torch.randn(r5, M5, device="cuda", generator=g5))

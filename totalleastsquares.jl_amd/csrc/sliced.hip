@@ -8,12 +8,15 @@
 //
 //   1. L = chol(G + delta I) as before (cholesky.hip), K = L'L - the matrix whose eigenvectors the Jacobi rotations converge to.
 //   2. Split the spectrum of K into slices of at most ~64 eigenvalues with matrix sign functions on the fp64 MFMA (matfun.hip,
-//      fixed polynomial schedules, the slices of a level side by side in one batch).  A slice is its spectral projector P and an
-//      interval [lo, hi]; it is cut at the MEAN t of its eigenvalues, trace(P K) / trace(P), by the sign function of
-//      K_s - t I with K_s = P K + hi (I - P) - everything outside the slice moved to its upper end, so that the iteration is
-//      scaled by the slice's own width, not by the spectrum's (a deflated cluster 50 times above a flat bulk would otherwise
-//      leave ten bulk eigenvalues within the resolution of every split).  Children: P_low = (I - sign) / 2, P_up = P - P_low;
-//      counts and means come from traces, no eigenvalue is ever computed.
+//      fixed polynomial schedules).  A slice is its spectral projector P and an interval [lo, hi]; it is cut at the MEAN t of
+//      its eigenvalues, trace(P K) / trace(P), scaled by the slice's own width, not by the spectrum's (a deflated cluster 50
+//      times above a flat bulk would otherwise leave ten bulk eigenvalues within the resolution of every split).  All the cuts
+//      of a level share ONE sign iteration: the slices' projectors commute with K and are mutually orthogonal, so
+//          X0 = sum_z P_z (K - t_z I) / nrm_z + (I - sum_z P_z) = A K + B        (k_slice_start builds A and B)
+//      is block diagonal in the eigenbasis with every slice scaled by its own nrm_z, sign(X0) = S cuts all of them at once,
+//      Q = (I - S) / 2, and the children are P_low_z = P_z Q (one batched, indexed product), P_up_z = P_z - P_low_z.
+//      Counts and means come from traces, no eigenvalue is ever computed.  (C2: 4 levels = 4 sign matrices, 46 polynomial
+//      steps in all, where one iteration per cut took 15 sign matrices.)
 //   3. The Cholesky factor of an orthogonal projector has orthonormal columns (P = C C', P^2 = P => C'C = I): a pivoted Cholesky
 //      of every P_j, one workgroup per slice, gives J0 = [C_1 | C_2 | ...] - orthogonal up to what the projectors lack, which is
 //      measured and polished (J0 <- J0 (1.5 I - 0.5 J0'J0)) to 1e-14 - and B0 = L J0: a factor of G whose column groups are
@@ -32,7 +35,9 @@
 // itself - no Cholesky factor (1.0 ms at N = 512), no sweeps over all pairs (0.8 ms each) - then the slices' own k x k problems
 // T_jj = J0_j' G J0_j (k <= 96) by Cholesky + one-sided Jacobi on windows of k rows, V = J0 blockdiag(W_j), one first-order
 // refinement from V'GV for what the projectors left between slices, and a certificate max |offdiag(V'GV)| <= 8 N eps ||G||.
-// Measured at C2 (20000 x 512, rank 16; profiles/r06_ws_*): the decomposition after the loop 14.8 -> 5.8 ms.
+// Measured at C2 (20000 x 512, rank 16; profiles/r06_ws_*): the decomposition after the loop 14.8 -> 4.9 ms (under the profiler:
+// slicing 2.06, pivoted Cholesky of the projectors 0.35, polish 0.3, the slices' Jacobi 1.3, refinement + certificate 0.8, U and
+// the cluster 1.2).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
