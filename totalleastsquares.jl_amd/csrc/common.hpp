@@ -46,6 +46,9 @@ struct Handle {
     size_t mailbox_bytes = 0;
     double* mailbox_dev = nullptr;   // device address of the same memory
     double mail_seq = 0.0;
+    bool lz_multi_off = false;    // k_lanczos_multi timed out once on this handle (lanczos.hip)
+    unsigned int lz_salt = 0;     // run counter: part of the granule tags of k_lanczos_multi
+    void* lz_xch_clean = nullptr; // the granule buffer that has been cleared (WS_LZX)
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     int64_t gram_tab2_nti = 0;
     // max |z| of an fp32 panel as a bit pattern, left by the kernel that wrote it (k_zsweep_wide) for the split Gram kernel that
@@ -115,7 +118,8 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(NO_CERT_ASYNC) X(FAIL_CERT_AT) X(NO_SPEC_REBUILD) X(CERT_EARLY) X(CERT_PRIO) X(NO_SMALL_MM) X(COLD_Q)           \
     X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
     X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
-    X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET)
+    X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET) X(COLD_TOP) X(COLD_TOL0)         \
+    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT)
 // Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
 // (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
 // tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
@@ -182,6 +186,7 @@ enum WsSlot {
     WS_CBS, WS_CBR,   // svd / opnorm callbacks on row shards (solver.hip): send block, gathered panel
     WS_VTOUT,   // the returned Vt of a host-pointer call on its way out (entry.hip)
     WS_SL_BUF, WS_SL_TAB,   // spectrum slicer in front of the accurate route's Jacobi (sliced.hip): N x N iterates, block-pair table
+    WS_LZX,   // granule buffers of k_lanczos_multi (lanczos.hip): written by nothing else
     WS_UPOL, WS_UPB,   // orthonormal polish of the derived singular vectors (solver.hip): second M x d panel, d x d Gram + correction
     WS_COUNT
 };
@@ -486,6 +491,12 @@ struct LanczosRun {
     bool mail_ok = false, use_mail = false;   // read-back through the handle's mailbox (polled) instead of copy + event
     double seq = 0.0;
     const double* v0 = nullptr;   // start vector (device, N; need not be normalised); nullptr: fixed pseudo-random vector
+    // k_lanczos_multi (N <= 1024): a chunk of steps per launch, the matrix in the LDS of 64 workgroups
+    bool multi = false;
+    double* xch = nullptr;
+    size_t lds_multi = 0;
+    int rows_per = 0;
+    unsigned int salt = 0;
 };
 int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t ldG, double rel_tol, int max_steps,
                   double accept_below, double stop_above, const double* v0 = nullptr);
@@ -508,6 +519,7 @@ int power_lower_bound(Handle* h, const double* G, int64_t N, int64_t ldG, bool i
 // ---------------- subspace.hip ----------------
 int subspace_max_block(int64_t N);
 int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev);
+int launch_project_out(Handle* h, const double* X, int64_t c, double* Yb, int64_t pb, double* W, int64_t N);
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr, bool one_pass = false, int64_t c_start = 0);   // c_start: the columns in
                 // front of it are orthonormal already (Gram-Schmidt path only): they are projected out of the rest, not touched
@@ -557,7 +569,8 @@ int launch_deflate_vec(Handle* h, const double* Vs, const double* Vg, int64_t r,
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p, const double* status = nullptr,
                        double* mailbox_dev = nullptr, unsigned int* arrivals = nullptr, double seq = 0.0,
-                       SpecCtrl* ctrl = nullptr, double inv_mu = 0.0, int nukeA = 1);
+                       SpecCtrl* ctrl = nullptr, double inv_mu = 0.0, int nukeA = 1, const double* sort_keys = nullptr,
+                       const double* sort_guard = nullptr);
 int launch_panel_rot2(Handle* h, const double* Q, const double* GQ, const double* S, double* X1, double* X2,
                       int64_t N, int64_t p);
 int launch_fill_hash(Handle* h, double* X, int64_t n, unsigned int seed);

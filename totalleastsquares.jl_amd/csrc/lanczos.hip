@@ -219,6 +219,202 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_step(const double* __res
     if (tid == 0) part[(size_t)(j % 2) * LZ_WGS_MAX + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- several Lanczos steps in ONE launch (round 6) --------------------------------------------------------------
+// A step of k_lanczos_step is a kernel boundary: ~10 us for 2 MB of matrix that a single CU could multiply in 1.  Up to
+// N = 1024 the matrix fits the LDS of 64 workgroups (N / 64 rows each: 32 KB at N = 512, 128 KB at 1024), and what a step
+// exchanges is one N-vector: every workgroup publishes its rows of u = G q as data-tagged granules (8 bytes = {tag, half a
+// double}, write-through agent-scope stores: the data is the flag, no fence, no counter), every thread polls the granules
+// of ITS OWN elements of u (agent-scope loads, never through L1), and alpha, w, beta, q_new are computed by every
+// workgroup redundantly and identically - the same threads add the same numbers in the same order as in k_lanczos_step's
+// phase A.  Two granule buffers in turn (a workgroup publishes step j + 2 only after it has read every workgroup's j + 1,
+// which they publish only after reading j).  tag = (run salt, step + 1): nothing left by an earlier run or step matches.
+// Nothing depends on where the workgroups run; they only have to be resident together (64 x 256 threads on 256 CUs), and
+// every poll is bounded: a wave that waits longer than ~20 ms flags st[3], the workgroup leaves at its next barrier, the
+// host repeats the run with one launch per step and never uses this kernel on the handle again.
+typedef __attribute__((address_space(1))) unsigned long long lz_gu64;
+
+__device__ __forceinline__ unsigned long long lz_now() { return wall_clock64(); }   // constant 100 MHz
+
+__global__ __launch_bounds__(LZ_THREADS) void k_lanczos_multi(const double* __restrict__ G, int64_t ldG, int N,
+                                                              double* __restrict__ st, double* __restrict__ ab, int cap,
+                                                              int j0, int nsteps, double* mailbox, double seq,
+                                                              const double* __restrict__ v0, unsigned long long* xch,
+                                                              unsigned int salt, int rows_per) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* q = sm;                       // N
+    double* red = sm + N;                 // 8: [0..4) reductions, [4] bail flag
+    double* Gs = sm + N + 8;              // rows_per x N
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r0 = blockIdx.x * rows_per;
+    if (r0 >= N) return;
+    const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
+    double* vec = st + 8 + 2 * (size_t)cap;   // [0, N): the current Lanczos vector, [N, 2N): the one before (between launches)
+    for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
+        const double* __restrict__ col = G + (int64_t)r * ldG;
+        for (int c = lane; c < N; c += 64) Gs[(size_t)(r - r0) * N + c] = col[c];
+    }
+    constexpr int EPT = 4;                // elements per thread: N <= 1024
+    double qc[EPT], qp[EPT];
+    double beta_prev = 0.0;
+    if (tid == 0) red[4] = 0.0;
+    if (j0 == 0) {
+        double nrm = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + k * LZ_THREADS;
+            double v = 0.0;
+            if (i < N) {
+                if (v0) {
+                    v = v0[i];
+                } else {   // (the start vector of k_lanczos_step)
+                    unsigned int x = (unsigned int)i * 2654435761u + 12345u;
+                    x ^= x >> 16;
+                    x *= 2246822519u;
+                    x ^= x >> 13;
+                    x *= 3266489917u;
+                    x ^= x >> 16;
+                    v = ((double)(x & 0xFFFFFF) + 0.5) / 16777216.0 - 0.5;
+                }
+            }
+            qc[k] = v;
+            qp[k] = 0.0;
+            nrm += v * v;
+        }
+        nrm = block_sum4(nrm, red);
+        const double inv = 1.0 / sqrt(nrm);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) qc[k] *= inv;
+        if (blockIdx.x == 0 && tid == 0) {
+            st[1] = 0.0;
+            st[2] = 0.0;
+            st[3] = 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + k * LZ_THREADS;
+            qc[k] = i < N ? vec[i] : 0.0;
+            qp[k] = i < N ? vec[(size_t)N + i] : 0.0;
+        }
+        beta_prev = ab[cap + (j0 - 1)];
+    }
+    bool broke = false;
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+        const int j = j0 + sidx;
+        const unsigned long long epoch = ((unsigned long long)(salt & 0xFFFFFu) << 12) | (unsigned long long)((j + 1) & 0xFFF);
+        lz_gu64* xp = (lz_gu64*)(xch + (size_t)(j & 1) * 2 * (size_t)N);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + k * LZ_THREADS;
+            if (i < N) q[i] = qc[k];
+        }
+        __syncthreads();
+        // this workgroup's rows of u = G q, published as they are finished
+        for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
+            const double* row = Gs + (size_t)(r - r0) * N;
+            double a0 = 0.0, a1 = 0.0;
+            int c = 2 * lane;
+            for (; c + 1 < N; c += 128) {
+                const lz_d2 g = *reinterpret_cast<const lz_d2*>(row + c);
+                const lz_d2 x = *reinterpret_cast<const lz_d2*>(q + c);
+                a0 += g[0] * x[0];
+                a1 += g[1] * x[1];
+            }
+            if ((N & 1) && lane == 0) a0 += row[N - 1] * q[N - 1];
+            const double acc = wsum(a0 + a1);
+            if (lane < 2) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+                const unsigned long long half = lane ? (bits >> 32) : (bits & 0xFFFFFFFFull);
+                __hip_atomic_store(xp + 2 * (size_t)r + lane, (epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // every thread collects its own elements of u
+        double u[EPT];
+        {
+            bool have[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                have[k] = tid + k * LZ_THREADS >= N;
+                u[k] = 0.0;
+            }
+            const unsigned long long t_start = lz_now();
+            bool timed_out = false;
+            for (unsigned int spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    if (!have[k]) {
+                        const int i = tid + k * LZ_THREADS;
+                        const unsigned long long x0 = __hip_atomic_load(xp + 2 * (size_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long x1 = __hip_atomic_load(xp + 2 * (size_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((x0 >> 32) == epoch && (x1 >> 32) == epoch) {
+                            u[k] = __longlong_as_double((long long)(((x1 & 0xFFFFFFFFull) << 32) | (x0 & 0xFFFFFFFFull)));
+                            have[k] = true;
+                        } else {
+                            ok = false;
+                        }
+                    }
+                }
+                if (__all(ok)) break;
+                if ((spins & 63u) == 63u && lz_now() - t_start > 2000000ull) {   // 20 ms
+                    timed_out = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (timed_out && lane == 0) red[4] = 1.0;
+        }
+        // alpha = q . u,  w = u - alpha q - beta_prev q_prev,  beta = ||w||,  q_new = w / beta
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) a += qc[k] * u[k];
+        const double alpha = block_sum4(a, red);
+        if (red[4] != 0.0) {   // (uniform: read behind block_sum4's barriers)
+            if (tid == 0) st[3] = 1.0;
+            broke = true;
+            break;
+        }
+        double nn = 0.0, wv[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            double v = u[k] - alpha * qc[k];
+            if (j >= 1) v -= beta_prev * qp[k];
+            wv[k] = v;
+            nn += v * v;
+        }
+        const double beta = sqrt(block_sum4(nn, red));
+        if (blockIdx.x == 0 && tid == 0) {
+            ab[j] = alpha;
+            ab[cap + j] = beta;
+            st[2] = (double)(j + 1);
+        }
+        if (!(beta > 1e-290)) {
+            if (blockIdx.x == 0 && tid == 0) st[1] = 1.0;
+            broke = true;
+            break;
+        }
+        const double inv = 1.0 / beta;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            qp[k] = qc[k];
+            qc[k] = wv[k] * inv;
+        }
+        beta_prev = beta;
+    }
+    if (blockIdx.x != 0) return;
+    if (!broke) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = tid + k * LZ_THREADS;
+            if (i < N) {
+                vec[i] = qc[k];
+                vec[(size_t)N + i] = qp[k];
+            }
+        }
+    }
+    if (mailbox) lz_publish(st, ab, cap, mailbox, seq);
+}
+
 // ---- host: largest eigenvalue of the symmetric tridiagonal (alpha[0..m), beta[0..m-1)) + residual bound
 static int sturm_count_below(const double* a, const double* b, int m, double x) {
     // number of eigenvalues < x
@@ -287,6 +483,20 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
     const int n = std::min(r.chunk, r.max_steps + 1 - r.launched);
     r.use_mail = r.mail_ok && n >= 2;
     if (r.use_mail) r.seq = (h->mail_seq += 1.0);
+    if (r.multi) {   // (launch j of the one-step kernel completes pair j - 1: the same pairs per chunk here)
+        const int pairs_before = std::max(r.launched - 1, 0);
+        r.launched += n;
+        const int nsteps = (r.launched - 1) - pairs_before;
+        if (nsteps > 0) {
+            hipLaunchKernelGGL(k_lanczos_multi, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds_multi, h->stream, r.G, r.ldG, (int)r.N, r.st, r.ab,
+                               r.cap, pairs_before, nsteps, r.use_mail ? h->mailbox_dev : (double*)nullptr, r.seq, r.v0,
+                               (unsigned long long*)r.xch, r.salt, r.rows_per);
+            TLSQ_HIP(h, hipGetLastError());
+        }
+        if (!r.use_mail)
+            TLSQ_HIP(h, hipMemcpyAsync(h->pinned, r.st, 64 + (size_t)2 * r.cap * 8, hipMemcpyDeviceToHost, h->stream));
+        return TLSQ_OK;
+    }
     for (int k = 0; k < n; ++k, ++r.launched) {
         const bool last = r.use_mail && k == n - 1;
         hipLaunchKernelGGL(k_lanczos_step, dim3(lz_wgs(r.N)), dim3(LZ_THREADS), r.lds, h->stream, r.G, r.ldG, (int)r.N, r.st,
@@ -321,6 +531,25 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     TLSQ_TRY(ws_get(h, WS_AUX4, st_doubles * 8, &stv));
     r.st = (double*)stv;
     r.ab = r.st + 8;
+    r.rows_per = (int)((N + LZ_WGS - 1) / LZ_WGS);
+    r.lds_multi = ((size_t)N + 8 + (size_t)r.rows_per * N) * 8;
+    r.multi = N >= 64 && N <= 1024 && r.lds_multi <= 150 * 1024 && !h->lz_multi_off && !dev_is(DEV_LZ_MULTI, '0');
+    if (r.multi) {
+        // the granule buffers: a slot nothing else writes, so that whatever they hold carries the tag of an earlier run; cleared
+        // when the slot is new and when the run counter wraps (2^20 runs)
+        void* xv;
+        TLSQ_TRY(ws_get(h, WS_LZX, 4 * (size_t)1024 * 8, &xv));
+        r.xch = (double*)xv;
+        if (h->lz_xch_clean != xv || h->lz_salt >= 0xFFFFEu) {
+            TLSQ_HIP(h, hipMemsetAsync(xv, 0, 4 * (size_t)1024 * 8, h->stream));
+            h->lz_xch_clean = xv;
+            h->lz_salt = 0;
+        }
+        r.salt = ++h->lz_salt;
+        if (r.lds_multi > 48 * 1024)
+            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_lanczos_multi),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)r.lds_multi));
+    }
     r.lds = (size_t)(N + 8) * 8;
     if (r.lds > 150 * 1024 || (size_t)(2 * r.cap) * 8 + 64 > h->pinned_bytes) {
         r.unsupported = true;
@@ -382,6 +611,14 @@ int lanczos_finish(Handle* h, LanczosRun& r, double* lmax, int* steps_used) {
             }
             memcpy(hs, h->pinned, 64);
             memcpy(hab.data(), (char*)h->pinned + 64, (size_t)2 * r.cap * 8);
+        }
+        if (r.multi && hs[3] != 0.0) {
+            // a workgroup of k_lanczos_multi gave up waiting for the others (never seen; they were not resident together):
+            // the same run again with one launch per step, and no further use of that kernel on this handle
+            h->lz_multi_off = true;
+            const LanczosRun o = r;
+            TLSQ_TRY(lanczos_begin(h, r, o.G, o.N, o.ldG, o.rel_tol, o.max_steps, o.accept_below, o.stop_above, o.v0));
+            continue;
         }
         const int m = (int)hs[2];
         const bool broke = hs[1] != 0.0;

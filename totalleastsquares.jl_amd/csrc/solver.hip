@@ -2221,9 +2221,8 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     }
     if (k > ro.iters) k = ro.iters;
     h->absmax_panel = nullptr;   // (what follows may rewrite Z: the maximum a sweep left for it does not describe it any more)
-    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    // (no synchronisation here: the final A and E are queued first, the phase timer's events are read behind the one below)
     if (dev_get(DEV_DEBUG)) fprintf(stderr, "  speculative factor products used: %lld of %lld iterations\n", (long long)n_spec_hits, (long long)k);
-    pt.finish(acc);
     T* Z = zmode ? Zbuf[zc] : Zbuf[cur];
     // (factors_out: the caller takes A as factors - unhankel reads them directly - and does not want E)
     const bool give_factors = ro.factors_out && zmode && a_pending && !ro.nonnegA && r_last <= 32 && !(S_host || Vt_host || U_dev);
@@ -2258,6 +2257,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (ro.hankel) TLSQ_TRY(soft_hankel(E, (T)(lam / mu)));  // :234-236
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    pt.finish(acc);
     if (ro.ae_final && *ro.ae_final && (S_host || Vt_host || U_dev)) (*ro.ae_final)();
     if (info) {
         info->ms_loop = now_ms() - t_loop0;

@@ -870,6 +870,18 @@ int launch_cgs2(Handle* h, double* Y, int64_t N, int64_t p, double* status_dev) 
 // CQ_ONEPASS again (it did in the previous step of the same warm block), so only the first pass is queued - in place -
 // and the two launches of a second pass that would find nothing to do are not.  The caller checks status[2] of THIS
 // step (it arrives with the Ritz values) and repeats the step with both passes when the guess was wrong.
+// Yb (N x pb) -= X (X' Yb) for the orthonormal columns X (N x c, c <= 512); W: c * pb doubles of scratch
+int launch_project_out(Handle* h, const double* X, int64_t c, double* Yb, int64_t pb, double* W, int64_t N) {
+    if (c <= 0 || pb <= 0) return TLSQ_OK;
+    if (c > 512) return set_err(h, TLSQ_ERR_UNSUPPORTED, "project_out: %lld columns", (long long)c);
+    hipLaunchKernelGGL(k_panel_tn2, dim3((unsigned)((c * pb + 3) / 4)), dim3(256), 0, h->stream, X, (int)c, (const double*)Yb, (int)pb,
+                       W, (int)N, (const double*)nullptr);
+    hipLaunchKernelGGL(k_panel_sub, dim3((unsigned)((N + 63) / 64), (unsigned)((pb + 7) / 8)), dim3(64), (size_t)c * 8 * 8, h->stream,
+                       X, (int)c, (const double*)W, Yb, (int)pb, (int)N, (const double*)nullptr);
+    TLSQ_HIP(h, hipGetLastError());
+    return TLSQ_OK;
+}
+
 int launch_orth(Handle* h, double* Y, double* tmp, double* W, int64_t N, int64_t p, double* status_dev,
                 bool allow_cholqr, bool* used_cholqr, bool one_pass, int64_t c_start) {
     const bool no_cholqr = dev_is(DEV_NO_CHOLQR, '1');
@@ -1222,7 +1234,10 @@ __global__ __launch_bounds__(256) void k_rr_small(const double* __restrict__ Bg,
             bool conv = false;
             double sq[4] = {0.0, 0.0, 0.0, 0.0}, rq[4] = {0.0, 0.0, 0.0, 0.0};
             double numax_prev = 1.0e300;
-            for (int it = 0; it < 8; ++it) {
+            // (12 corrections at most - 8 until round 6: the first warm step of a solve, two fresh pad columns and the largest change
+            //  of the panel there is, converged in its eighth or not at all depending on the last bit of ||D||_2: a miss is a
+            //  second step on the Jacobi path, 150 us against 6 per correction; stalls still leave through the progress test)
+            for (int it = 0; it < 12; ++it) {
                 oa_its = it + 1;
                 const sm_d4 bc = rs_mfma<false, false>(sBh, sV, L, nk);
                 const sm_d4 hc = rs_mfma<false, false>(sH, sV, L, nk);
@@ -1399,13 +1414,35 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
                                                      double* __restrict__ res, int N, int p,
                                                      const double* __restrict__ status, double* mailbox,
                                                      unsigned int* arrivals, double seq, SpecCtrl* ctrl, double inv_mu,
-                                                     int nukeA) {
+                                                     int nukeA, const double* __restrict__ keys,
+                                                     const double* __restrict__ keys_guard) {
     __shared__ double sS[CQ_PMAX * 16];   // p <= 512
     __shared__ double red[4];
-    __shared__ int s_last;
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int k = tid; k < p; k += 256) sS[k] = S[k + (size_t)c * p];
+    __shared__ int s_last, s_dest;
+    const int cs = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = tid; k < p; k += 256) sS[k] = S[k + (size_t)cs * p];
+    // keys (round 6): the eigenvalues of the p x p problem, in the order of S's columns.  The Ritz pair of column cs is written
+    // to the position its key has in descending order (ties by column index, NaN last: a permutation whatever the keys are),
+    // so that the block arrives sorted and the host does not queue two panel copies and two gathers to sort it.  Not when the
+    // guard (the status of a CholeskyQR orthonormalisation, where one ran) says the step is going to be repeated.
+    if (tid == 0) s_dest = cs;
     __syncthreads();
+    if (keys && !(keys_guard && keys_guard[1] != 0.0)) {
+        if (tid < 64) {
+            const double kc = keys[cs];
+            const double mine = kc == kc ? kc : -__builtin_inf();
+            int cnt = 0;
+            for (int i = tid; i < p; i += 64) {
+                const double ki = keys[i];
+                const double other = ki == ki ? ki : -__builtin_inf();
+                cnt += (other > mine || (other == mine && i < cs)) ? 1 : 0;
+            }
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (tid == 0) s_dest = cnt;
+        }
+        __syncthreads();
+    }
+    const int c = s_dest;
     double dot = 0.0;
     for (int r = tid; r < N; r += 256) {
         double x = 0.0, g = 0.0;
@@ -1502,10 +1539,11 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
 // for blocks of more than 256 columns (k_panel_rot2 keeps S in LDS: p <= 90 there)
 int launch_ritz_finish(Handle* h, const double* Q, const double* GQ, const double* S, double* X, double* GX,
                        double* theta, double* res, int64_t N, int64_t p, const double* status, double* mailbox_dev,
-                       unsigned int* arrivals, double seq, SpecCtrl* ctrl, double inv_mu, int nukeA) {
+                       unsigned int* arrivals, double seq, SpecCtrl* ctrl, double inv_mu, int nukeA, const double* sort_keys,
+                       const double* sort_guard) {
     if (p <= 512) {   // (always, for the block sizes in use: at most 2 p^2 N doubles of L2 traffic, 0.5 ms at p = 192, N = 4096)
         hipLaunchKernelGGL(k_ritz_finish, dim3((unsigned)p), dim3(256), 0, h->stream, Q, GQ, S, X, GX, theta, res, (int)N,
-                           (int)p, status, mailbox_dev, arrivals, seq, mailbox_dev ? ctrl : nullptr, inv_mu, nukeA);
+                           (int)p, status, mailbox_dev, arrivals, seq, mailbox_dev ? ctrl : nullptr, inv_mu, nukeA, sort_keys, sort_guard);
         TLSQ_HIP(h, hipGetLastError());
         return TLSQ_OK;
     }

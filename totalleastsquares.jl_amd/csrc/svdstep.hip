@@ -487,13 +487,18 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         if (gx_valid) TLSQ_HIP(h, hipMemcpyAsync(Q, GX, (size_t)N * p * 8, hipMemcpyDeviceToDevice, h->stream));
         else TLSQ_TRY(op_apply(h, op, N, (const double*)X, (double*)Q, p));
         gx_valid = false;
-        const int64_t nt_step = cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);   // leading columns treated as wanted
+        // (cold, round 6: after the first step the block is sorted and its count known - only the counted columns take the extra
+        //  multiplications from then on, and more of them: every column to the power 4 is what the pad columns' condition number
+        //  allows, (lambda_pad / lambda_1)^4 ~ 1e-7 at C2; the counted columns alone take 7 and the second step lands under the
+        //  residual bound that used to need a third - 100 us of the first ALM iteration.  COLD_TOP=0: as before)
+        const bool cold_top = cold && !hook && step >= 1 && svp >= 1 && svp <= p - 2 && !dev_is(DEV_COLD_TOP, '0');
+        const int64_t nt_step = cold_top ? svp : cold ? p : std::min<int64_t>(step == 0 ? ntop : svp, p);   // leading columns treated as wanted
         {
             const int64_t nt = nt_step;
             // (cold: 2 on the random block; from the second step on the block consists of Ritz vectors and takes a higher power
             //  as well as any warm block - one step less to the residual bound, TLSQ_COLD_Q)
             const int cold_q = [] { const char* e = dev_get(DEV_COLD_Q); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 7 ? v : 4; }();
-            const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
+            const int q = cold ? ((step == 0 || force_cgs2) ? 2 : cold_top ? std::max(cold_q, 7) : cold_q) : st.q_warm;   // adapted below: a multiplication of the top columns costs ~12 us, a step ~200
             // Cold start of a wide block (large mode: 76 columns of length 4096 at BASELINE config 5): the random block is
             // orthonormalised after its FIRST product as well (round 5) - G X has the condition number of G on the block, its second
             // product the square of it, which CholeskyQR2 cannot take and the column-sequential CGS2 needs 0.26 ms per 16 columns
@@ -542,7 +547,10 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         dbg_hash(h, "sub.GQ", GQ, (size_t)N * p * 8);
         dbg_hash(h, "sub.H", H, (size_t)p * p * 8);
         int64_t sw = 0;
-        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true));
+        // (the Ritz vectors of a random block's first step only sort the block and count: rotations down to 1e-8 instead of
+        //  2 eps sqrt(p) - two or three sweeps of the eight; COLD_TOL0=0: full accuracy)
+        const double rot_tol0 = cold && !hook && step == 0 && force_cgs2 && p <= 96 && !dev_is(DEV_COLD_TOL0, '0') ? 1e-8 : 0.0;
+        TLSQ_TRY(symeig_f64(h, (const double*)H, p, p, (double*)HB, (double*)S, true, lamH_dev, &sw, true, false, true, rot_tol0));
         dbg_hash(h, "sub.S", S, (size_t)p * p * 8);
         if (sweeps) *sweeps += sw;
         }
@@ -551,6 +559,9 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
         // Ritz values did not come out in descending order)
         const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
         const bool mail = h->mailbox && !no_mailbox && p <= 512 && (size_t)(2 * p + 10) * 8 <= h->mailbox_bytes;
+        // (classic path: the Jacobi solver's eigenvalues come in no order - the kernel writes the pairs sorted by them;
+        //  k_rr_small's blocks are sorted to begin with)
+        const double* sort_keys = !rr_fast && p <= 512 && !dev_is(DEV_RITZ_SORT, '0') ? lamH_dev : nullptr;
         if (mail) {
             void* scal;
             TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
@@ -564,7 +575,7 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
             SpecCtrl* ctrl = spec_now ? reinterpret_cast<SpecCtrl*>(reinterpret_cast<char*>(scal) + 2048) : nullptr;
             TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
                                         (double*)GX, theta_dev, res_dev, N, p, stat_dev, h->mailbox_dev, arrivals, seq, ctrl,
-                                        inv_mu, st.spec.nukeA ? 1 : 0));
+                                        inv_mu, st.spec.nukeA ? 1 : 0, sort_keys, used_cholqr ? stat_dev : nullptr));
             if (spec_now) {
                 if (st.spec.before_launch) st.spec.before_launch();
                 st.spec.nct = nt_step <= 16 ? 1 : 2;
@@ -598,7 +609,7 @@ int svd_subspace(Handle* h, const GramOp& op, int64_t N, double inv_mu, Subspace
             }
         } else {
             TLSQ_TRY(launch_ritz_finish(h, (const double*)Q, (const double*)GQ, (const double*)S, (double*)X,
-                                        (double*)GX, theta_dev, res_dev, N, p));
+                                        (double*)GX, theta_dev, res_dev, N, p, nullptr, nullptr, nullptr, 0.0, nullptr, 0.0, 1, sort_keys, used_cholqr ? stat_dev : nullptr));
             TLSQ_HIP(h, hipMemcpyAsync(host.data(), theta_dev, (size_t)(2 * p + 3) * 8, hipMemcpyDeviceToHost,
                                        h->stream));
             TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -919,8 +930,19 @@ int carry_block(Handle* h, const double* V, int64_t N, const SmallSvd& s, int64_
     if (identity && h->ws[WS_SX].p && V == (const double*)h->ws[WS_SX].p) {
         // the usual case: V is the sorted block the subspace solver left in WS_SX - its leading columns stay where
         // they are, only missing pad columns are (re)filled
-        if (have < want)
-            TLSQ_TRY(launch_fill_hash(h, (double*)h->ws[WS_SX].p + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
+        if (have < want) {
+            double* Xb = (double*)h->ws[WS_SX].p;
+            TLSQ_TRY(launch_fill_hash(h, Xb + (size_t)N * have, N * (want - have), 0x85EBCA6Bu));
+            // (round 6: the fresh pad columns are taken out of the span of the block first.  A random column is mostly dominant
+            //  subspace after its first product, the block's Gram matrix 2.1 away from I, and whether the fused Rayleigh-Ritz
+            //  kernel still converged on it in the second ALM iteration of BASELINE config 2 - or that iteration and the next
+            //  two went through the Jacobi path, +0.36 ms - hung on the last bit of ||D||_2.  PAD_PROJECT=0: as before)
+            if (have <= 512 && !dev_is(DEV_PAD_PROJECT, '0')) {
+                void* W;
+                TLSQ_TRY(ws_get(h, WS_SH, (size_t)std::max<int64_t>(want * want, have * (want - have)) * 8, &W));
+                TLSQ_TRY(launch_project_out(h, Xb, have, Xb + (size_t)N * have, want - have, (double*)W, N));
+            }
+        }
         sub.p = want;
         sub.ntop = svp;
         sub.valid = true;

@@ -44,25 +44,38 @@ def _ptr(a):
 
 
 class RpcaReport:
-    """Python view of tlsq_rpca_info."""
+    """Python view of tlsq_rpca_info.  The fields are read out of the C struct on first use (a solve of the headline config takes
+    9 ms: twenty conversions per call are not free)."""
 
     def __init__(self, info, cost, svp):
-        self.iters_done = int(info.iters_done)
-        self.converged = bool(info.converged)
-        self.final_cost = float(info.final_cost)
-        self.final_mu = float(info.final_mu)
-        self.d_norm = float(info.d_norm)
-        self.cost_hist = cost[: self.iters_done].tolist()
-        self.svp_hist = svp[: self.iters_done].tolist()
-        self.jacobi_sweeps = int(info.jacobi_sweeps)
-        self.eig_full, self.eig_fast = int(info.eig_full), int(info.eig_fast)
-        self.subspace_steps = int(info.subspace_steps)
-        self.residual_stores_skipped = int(info.residual_stores_skipped)
-        self.tsqr_iterations = int(info.tsqr_iterations)
-        self.hbm_bytes_sweeps, self.hbm_bytes = float(info.hbm_bytes_sweeps), float(info.hbm_bytes)
-        self.sweeps_timed, self.hbm_bytes_sweeps_timed = int(info.sweeps_timed), float(info.hbm_bytes_sweeps_timed)
-        self.kern = {k[5:]: int(getattr(info, k)) for k, _ in info._fields_ if k.startswith("kern_")}
-        self.ms = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
+        self._raw = (info, cost, svp)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        d = self.__dict__
+        if "iters_done" not in d:
+            info, cost, svp = d["_raw"]
+            d["iters_done"] = int(info.iters_done)
+            d["converged"] = bool(info.converged)
+            d["final_cost"] = float(info.final_cost)
+            d["final_mu"] = float(info.final_mu)
+            d["d_norm"] = float(info.d_norm)
+            d["cost_hist"] = cost[: d["iters_done"]].tolist()
+            d["svp_hist"] = svp[: d["iters_done"]].tolist()
+            d["jacobi_sweeps"] = int(info.jacobi_sweeps)
+            d["eig_full"], d["eig_fast"] = int(info.eig_full), int(info.eig_fast)
+            d["subspace_steps"] = int(info.subspace_steps)
+            d["residual_stores_skipped"] = int(info.residual_stores_skipped)
+            d["tsqr_iterations"] = int(info.tsqr_iterations)
+            d["hbm_bytes_sweeps"], d["hbm_bytes"] = float(info.hbm_bytes_sweeps), float(info.hbm_bytes)
+            d["sweeps_timed"], d["hbm_bytes_sweeps_timed"] = int(info.sweeps_timed), float(info.hbm_bytes_sweeps_timed)
+            d["kern"] = {k[5:]: int(getattr(info, k)) for k, _ in info._fields_ if k.startswith("kern_")}
+            d["ms"] = {k[3:]: float(getattr(info, k)) for k, _ in info._fields_ if k.startswith("ms_")}
+        try:
+            return d[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 class Engine:
