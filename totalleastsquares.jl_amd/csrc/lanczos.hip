@@ -239,7 +239,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_multi(const double* __re
                                                               double* __restrict__ st, double* __restrict__ ab, int cap,
                                                               int j0, int nsteps, double* mailbox, double seq,
                                                               const double* __restrict__ v0, unsigned long long* xch,
-                                                              unsigned int salt, int rows_per) {
+                                                              unsigned int salt, int rows_per, int drop_wg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* q = sm;                       // N
     double* red = sm + N;                 // 8: [0..4) reductions, [4] bail flag
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(LZ_THREADS) void k_lanczos_multi(const double* __re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r0 = blockIdx.x * rows_per;
     if (r0 >= N) return;
+    if ((int)blockIdx.x == drop_wg) return;   // (LZ_MULTI=drop, tests: a workgroup that never publishes - the others must give up and say so)
     const int r1 = (r0 + rows_per < N) ? r0 + rows_per : N;
     double* vec = st + 8 + 2 * (size_t)cap;   // [0, N): the current Lanczos vector, [N, 2N): the one before (between launches)
     for (int r = r0 + w; r < r1; r += LZ_THREADS / 64) {
@@ -490,7 +491,7 @@ static int lz_launch_chunk(Handle* h, LanczosRun& r) {
         if (nsteps > 0) {
             hipLaunchKernelGGL(k_lanczos_multi, dim3(LZ_WGS), dim3(LZ_THREADS), r.lds_multi, h->stream, r.G, r.ldG, (int)r.N, r.st, r.ab,
                                r.cap, pairs_before, nsteps, r.use_mail ? h->mailbox_dev : (double*)nullptr, r.seq, r.v0,
-                               (unsigned long long*)r.xch, r.salt, r.rows_per);
+                               (unsigned long long*)r.xch, r.salt, r.rows_per, dev_is(DEV_LZ_MULTI, 'd') ? 1 : -1);
             TLSQ_HIP(h, hipGetLastError());
         }
         if (!r.use_mail)
