@@ -49,6 +49,7 @@ struct Handle {
     bool lz_multi_off = false;    // k_lanczos_multi timed out once on this handle (lanczos.hip)
     unsigned int lz_salt = 0;     // run counter: part of the granule tags of k_lanczos_multi
     void* lz_xch_clean = nullptr; // the granule buffer that has been cleared (WS_LZX)
+    int lz_first_chunk = 0;       // hint for the next lanczos_begin (consumed there): pairs of its first chunk
     bool mail_counter_ready = false;   // the device-side arrival counter of k_ritz_finish has been cleared
     int64_t gram_tab2_nti = 0;
     // max |z| of an fp32 panel as a bit pattern, left by the kernel that wrote it (k_zsweep_wide) for the split Gram kernel that
@@ -119,7 +120,7 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
     X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
     X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET) X(COLD_TOP) X(COLD_TOL0)         \
-    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT)
+    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT) X(HOST_TRACE)
 // Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
 // (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
 // tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
@@ -156,6 +157,8 @@ inline bool dev_is(DevKey k, char c) {
 // name with or without the TLSQ_ prefix; value == nullptr clears the switch.  TLSQ_ERR_ARG for a name not on the list.
 int dev_set(const char* name, const char* value);
 void dev_load_env();             // (no-op unless built with -DTLSQ_DEV_SWITCHES)
+void host_mark(const char* tag);   // HOST_TRACE=1: a wall-clock mark of the host side of the call (runtime.hip)
+void host_trace_dump();
 // DEBUG_HASH=1: "[hash] <tag> <64-bit FNV-1a of the buffer>" on stderr after a stream synchronisation - two runs of the same
 // call must print identical lines; the first line that differs names the kernel that is not reproducible
 struct Handle;

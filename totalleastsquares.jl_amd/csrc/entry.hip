@@ -132,6 +132,7 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         if (M >= N && M >= 32 * (int64_t)h->multi_n && (!opts || opts->m_global <= 0 || opts->m_global == M))
             return rpca_multi<T>(h, D, M, N, ldD, opts, A, ldA, E, ldE, U, ldU, S, Vt, ldVt, sv, info);
     }
+    host_mark("entry");
     TLSQ_HIP(h, hipSetDevice(h->device));
     const double t0 = now_ms();
     reset_info(info);
@@ -332,6 +333,8 @@ int rpca_entry(tlsq_handle h, const T* D, int64_t M, int64_t N, int64_t ldD, con
         info->ms_d2h = now_ms() - th;
         info->ms_total = now_ms() - t0;
     }
+    host_mark("return");
+    host_trace_dump();
     return status;
 }
 

@@ -562,6 +562,10 @@ int lanczos_begin(Handle* h, LanczosRun& r, const double* G, int64_t N, int64_t 
     // launch j completes pair j-1.  Yes/no questions (accept_below / stop_above) are usually settled by the
     // first few Ritz values: start with 4 pairs and double
     r.chunk = stop_above > 0.0 ? 5 : (accept_below > 0.0 ? 11 : 16);
+    // (a caller that knows the question will not be settled by the first Ritz values - the cost of an ALM iteration whose power
+    //  bound has just failed to say "not converged" - asks for a longer first chunk: one launch and one round trip less)
+    if (r.multi && h->lz_first_chunk > r.chunk) r.chunk = h->lz_first_chunk;
+    h->lz_first_chunk = 0;
     const bool no_mailbox = dev_is(DEV_NO_MAILBOX, '1');
     r.mail_ok = h->mailbox && !no_mailbox && (size_t)(16 + 2 * r.cap) * 8 <= h->mailbox_bytes;
     TLSQ_TRY(lz_launch_chunk(h, r));

@@ -50,6 +50,24 @@ int dev_set(const char* name, const char* value) {
     return TLSQ_ERR_ARG;
 }
 
+double now_ms();
+// HOST_TRACE=1: wall-clock marks of the host side of a call (where the time between two kernels of the trace goes when the GPU
+// is waiting for the host), printed to stderr when the call returns
+static struct { const char* tag; double t; } g_host_marks[64];
+static int g_host_nmarks = 0;
+void host_mark(const char* tag) {
+    if (!g_dev_set[DEV_HOST_TRACE]) return;
+    if (g_host_nmarks < 64) g_host_marks[g_host_nmarks++] = {tag, now_ms()};
+}
+void host_trace_dump() {
+    if (!g_dev_set[DEV_HOST_TRACE] || g_host_nmarks == 0) return;
+    fprintf(stderr, "[host]");
+    for (int i = 0; i < g_host_nmarks; ++i)
+        fprintf(stderr, " %s %+.1f us |", g_host_marks[i].tag, i ? (g_host_marks[i].t - g_host_marks[i - 1].t) * 1e3 : 0.0);
+    fprintf(stderr, " total %.1f us\n", (g_host_marks[g_host_nmarks - 1].t - g_host_marks[0].t) * 1e3);
+    g_host_nmarks = 0;
+}
+
 void dev_load_env() {
 #ifdef TLSQ_DEV_SWITCHES
     static bool done = false;

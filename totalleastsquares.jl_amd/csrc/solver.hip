@@ -520,6 +520,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                      double* Vt_host, int64_t ldVt, int64_t* sv_out, tlsq_rpca_info* info) {
     const int64_t n = M * N;
     const bool timing = info != nullptr;
+    host_mark("core");
     void *Yv = nullptr, *Zv = nullptr, *Rv = nullptr;
     {
         // The panels first, and on row shards an agreement on the outcome: a rank that runs out of memory here (the one with
@@ -608,10 +609,15 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     const double *Tm_last = nullptr, *Vs_last = nullptr;   // factors of the last A (see fuse_rebuild below)
     int64_t r_last = 0;
     bool a_pending = false;                                // the last A exists only as Tm_last * Vs_last'
-    double prev_lower = 0.0;                               // Frobenius lower bound of the previous iteration's cost
+    // lower bound of the previous iteration's cost (Frobenius / largest entry).  Before the first one: "far above tol" - the first
+    // sweep of a solve does not store a residual panel nobody is likely to read (a wrong guess recomputes it)
+    double prev_lower = std::numeric_limits<double>::infinity();
     int64_t n_rskip = 0;
     bool sumsq_ready = false;   // the two accumulator sets of the Frobenius bound have been cleared
-    const double rskip_margin = [] { const char* e = dev_get(DEV_RSKIP_MARGIN); return e ? atof(e) : 8.0; }();
+    // (3 since round 6, 8 before: with the max-entry bound `prev_lower` is within a few per cent of the cost itself, which shrinks
+    //  by 0.45-0.75 per iteration where the test is about to pass: a store is wanted once the bound is within 1 / 0.45 of tol.
+    //  8 stored R in the last five iterations of BASELINE config 2, 20 us each, to avoid one 60 us recomputation)
+    const double rskip_margin = [] { const char* e = dev_get(DEV_RSKIP_MARGIN); return e ? atof(e) : 3.0; }();
     int64_t sweeps = 0;
     // arbitrary hooks of the host language (src/robustPCA.jl:168-169): the panel visits the host and the caller's
     // own function runs there, on the calling thread ("the CPU path with the user's closure")
@@ -831,8 +837,10 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
             maxabs = std::max(maxabs, md);
         }
     }
-    else if (maxabs_async)
+    else if (maxabs_async) {
+        host_mark("first launch");
         TLSQ_TRY(launch_maxabs_begin<T>(h, D, n));                 // :178 norm(Y, Inf), beside the Gram matrix of :177 (read below)
+    }
     else
         TLSQ_TRY(launch_maxabs<T>(h, D, n, &maxabs));              // :178 norm(Y, Inf)
     auto finish_maxabs = [&]() -> int {
@@ -868,6 +876,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         if (maxabs_async) TLSQ_TRY(finish_maxabs());
         if (st_n < 0) return st_n;
     }
+    host_mark("norm known");
     const double lam = ro.lambda;
     const double norminf = maxabs / lam;
     const double dual_norm = std::max(norm2, norminf);             // :179
@@ -1304,6 +1313,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     }
                 }
                 if (!first_fused)
+                    host_mark("first shrink");
                     TLSQ_TRY(launch_first_shrink<T>(h, D, Y, zmode ? (T*)nullptr : E, Z, n, (T)dual_norm, (T)inv_mu, (T)thr,
                                                     ro.nonnegE ? 1 : 0));
                 y_pending = false;
@@ -1880,7 +1890,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         //  within 1.6 tol: this iteration is then most likely the last one, and a Gram queued now would be the wasted one;
         //  should the loop go on after all, the Gram is computed at the top of the next iteration instead)
         const double last_guess = [] { const char* e = dev_get(DEV_LAST_GUESS); return e ? atof(e) : 1.6; }();
-        const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;
+        const bool likely_last = maxslot >= 0 && prev_lower > 0.0 && prev_lower < last_guess * ro.tol;   // (infinity before the first bound: false)
         const bool gram_next = sumsq_dev && !r_next && !implicit_gram && !likely_last && !hook_sketch;
         bool gram_queued = false;
         bool fused_gram = false;   // the sweep kernel has accumulated the Gram of Z_{k+1} as well (fused.hip): only its slabs are left to add
@@ -2169,6 +2179,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     TLSQ_TRY(comm_allreduce(h, (double*)Gc, (size_t)N * N, ncclSum));
                 }
                 bool settled = false;
+                bool power_tried = false;
                 if (stop_sigma > 0.0 && !no_power_lb) {
                     // "not converged" from three power steps on the vector carried over from the previous evaluation
                     // (||G v|| <= lambda_max for unit v): no Lanczos run unless the bound falls short of the mark
@@ -2177,13 +2188,17 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     if (pst < 0) return pst;
                     if (pst == 0) {
                         power_vec_valid = true;
+                        power_tried = true;
                         if (lb >= stop_sigma * stop_sigma) {
                             rn = std::sqrt(lb);
                             settled = true;
                         }
                     }
                 }
-                if (!settled) TLSQ_TRY(sigma_max_of_gram(h, (const double*)Gc, N, cost_rel, &rn, &sweeps, stop_sigma));
+                if (!settled) {
+                    if (power_tried) h->lz_first_chunk = 17;   // (16 pairs: what a flat residual spectrum takes to 1e-6)
+                    TLSQ_TRY(sigma_max_of_gram(h, (const double*)Gc, N, cost_rel, &rn, &sweeps, stop_sigma));
+                }
             }
             if (!gr_ready) hbm_other += panel_bytes;
             cost = rn / d_norm;
@@ -2220,6 +2235,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         }
     }
     if (k > ro.iters) k = ro.iters;
+    host_mark("loop left");
     h->absmax_panel = nullptr;   // (what follows may rewrite Z: the maximum a sweep left for it does not describe it any more)
     // (no synchronisation here: the final A and E are queued first, the phase timer's events are read behind the one below)
     if (dev_get(DEV_DEBUG)) fprintf(stderr, "  speculative factor products used: %lld of %lld iterations\n", (long long)n_spec_hits, (long long)k);
@@ -2256,7 +2272,9 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     if (cur != 0)   // the last E_k sits in the spare buffer: move it to the caller's panel
         TLSQ_HIP(h, hipMemcpyAsync(E, Ebuf[cur], (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     if (ro.hankel) TLSQ_TRY(soft_hankel(E, (T)(lam / mu)));  // :234-236
+    host_mark("A, E queued");
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    host_mark("synchronised");
     pt.finish(acc);
     if (ro.ae_final && *ro.ae_final && (S_host || Vt_host || U_dev)) (*ro.ae_final)();
     if (info) {

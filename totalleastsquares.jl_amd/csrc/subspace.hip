@@ -1510,7 +1510,8 @@ __global__ __launch_bounds__(256) void k_ritz_finish(const double* __restrict__ 
         const double t = mine && p <= 64 ? sT[tid] : 0.0;   // (one wave: its LDS writes above are ordered before this read)
         const double sg = sqrt(t > 0.0 ? t : 0.0);
         const double up = __shfl_up(sg, 1, 64);
-        const bool bad = mine && (!(t - t == 0.0) || (tid > 0 && sg > up));   // (the host's stable sort would move this column)
+        // (the host's sort would move this column - unless it is a pad column far below the threshold: svdstep.hip, pads_only)
+        const bool bad = mine && (!(t - t == 0.0) || (tid > 0 && sg > up && !(sg < 0.5 * inv_mu)));
         const bool above = mine && sg >= inv_mu;
         const unsigned long long mb_above = __ballot(above);
         if (__ballot(bad) != 0ull) ok = false;
