@@ -144,8 +144,10 @@ def main():
     sweeps_timed_total = 0
     ms = {}
     last = None
-    for _ in range(args.steps):
-        sv, rep, st = solve()
+    runs = [solve() for _ in range(args.steps)]   # (the reports are read after the clock has stopped)
+    barrier()
+    dt = allmax(time.perf_counter() - t0)
+    for sv, rep, st in runs:
         iters_total += rep.iters_done
         rskip_total += rep.residual_stores_skipped
         hbm_sweeps_total += rep.hbm_bytes_sweeps
@@ -155,8 +157,6 @@ def main():
         for k, v in rep.ms.items():
             ms[k] = ms.get(k, 0.0) + v
         last = (sv, rep, st)
-    barrier()
-    dt = allmax(time.perf_counter() - t0)
     sv, rep, st = last
 
     # ---- validation of the timed work against the oracle's frozen run (outside the timing) -------------------------------

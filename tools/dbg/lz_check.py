@@ -50,7 +50,7 @@ for mode in ("1", "0", "1", "0"):
         ts = np.array(ts[2:]) * 1e3
         print(f"LZ_MULTI={mode}: {ts.mean():.3f} ms per solve (min {ts.min():.3f}), lib total {rep.ms['total']:.3f}; iters {rep.iters_done}, sv {sv}, "
               f"d_norm {rep.d_norm!r}, final cost {rep.final_cost!r}", flush=True)
-for sw in (dict(COLD_TOP="0"), dict(COLD_TOL0="0"), dict(RITZ_SORT="0"), dict(PAD_PROJECT="0"), dict(RSKIP_MARGIN="8"), dict(),
+for sw in (dict(COLD_TOP="0"), dict(COLD_TOL0="0"), dict(RITZ_SORT="0"), dict(PAD_PROJECT="0"), dict(RSKIP_MARGIN="8"), dict(SWEEP_TIMING_STRIDE="8"), dict(SWEEP_TIMING_STRIDE="1000"), dict(),
            dict(LZ_MULTI="0", COLD_TOP="0", COLD_TOL0="0", RITZ_SORT="0", PAD_PROJECT="0", RSKIP_MARGIN="8"), dict()):
     with tlsq_amd.dev_switches(**sw):
         ts = []

@@ -120,13 +120,13 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
     X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
     X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET) X(COLD_TOP) X(COLD_TOL0)         \
-    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT) X(HOST_TRACE)
+    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT) X(HOST_TRACE) X(SWEEP_TIMING_STRIDE)
 // Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
 // (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
 // tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
-// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  40 live switches, 66 ablation switches.
+// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  47 live switches, 65 ablation switches.
 #define TLSQ_DEV_LIST_ABLATION(X)                                                                                         \
-    X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(NO_REBUILD_STORE) X(SWEEP_TIMING_STRIDE)               \
+    X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(NO_REBUILD_STORE)                                      \
     X(NO_MAX_BOUND) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS) X(FULL_EIG) X(NO_GRAM_DENSE)       \
     X(NO_MATFUN_ROUTE) X(MATFUN_SYM) X(MATFUN_COND) X(NO_DEFLATED_CERT) X(NO_DEEP_POWERS) X(NO_POWER_CERT)            \
     X(NO_CERT_OVERLAP) X(NO_DEFLATED_SVD) X(NO_FUSED_DEFLATE) X(NO_RR_FAST) X(NO_RR_BLOCKED) X(NO_U_POLISH)           \
