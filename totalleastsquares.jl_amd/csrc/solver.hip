@@ -2180,7 +2180,11 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 }
                 bool settled = false;
                 bool power_tried = false;
-                if (stop_sigma > 0.0 && !no_power_lb) {
+                // (not when the lower bounds of this iteration already sit 10 % below tol: the largest entry of the residual is
+                //  within a few per cent of its norm, so "not converged" is not what three power steps are going to say - the last
+                //  iteration of a solve went through them, and a host round trip, for nothing)
+                const bool likely_converged = maxslot >= 0 && prev_lower < 0.9 * ro.tol;
+                if (stop_sigma > 0.0 && !no_power_lb && !likely_converged) {
                     // "not converged" from three power steps on the vector carried over from the previous evaluation
                     // (||G v|| <= lambda_max for unit v): no Lanczos run unless the bound falls short of the mark
                     double lb = 0.0;
@@ -2196,7 +2200,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     }
                 }
                 if (!settled) {
-                    if (power_tried) h->lz_first_chunk = 17;   // (16 pairs: what a flat residual spectrum takes to 1e-6)
+                    if (power_tried || likely_converged) h->lz_first_chunk = 17;   // (16 pairs: what a flat residual spectrum takes to 1e-6)
                     TLSQ_TRY(sigma_max_of_gram(h, (const double*)Gc, N, cost_rel, &rn, &sweeps, stop_sigma));
                 }
             }
