@@ -614,10 +614,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
     double prev_lower = std::numeric_limits<double>::infinity();
     int64_t n_rskip = 0;
     bool sumsq_ready = false;   // the two accumulator sets of the Frobenius bound have been cleared
-    // (3 since round 6, 8 before: with the max-entry bound `prev_lower` is within a few per cent of the cost itself, which shrinks
-    //  by 0.45-0.75 per iteration where the test is about to pass: a store is wanted once the bound is within 1 / 0.45 of tol.
-    //  8 stored R in the last five iterations of BASELINE config 2, 20 us each, to avoid one 60 us recomputation)
-    const double rskip_margin = [] { const char* e = dev_get(DEV_RSKIP_MARGIN); return e ? atof(e) : 3.0; }();
+    // (round 6: 3 where the max-entry bound is in use - `prev_lower` is then within a few per cent of the cost itself, the test
+    //  is only evaluated once that bound is below tol, and the cost shrinks by 0.45-0.75 per iteration there: a store is wanted
+    //  once the bound is within 1 / 0.33 of tol.  8 stored R in the last five iterations of BASELINE config 2, 20 us each, to
+    //  avoid one 60 us recomputation.  6 where the Frobenius bound is the larger of the two (Hankel residuals have no isolated
+    //  entries): the cost is then evaluated from 2 tol on; 3 there cost config 3 a recomputation of R from the Y panels - 60 GB,
+    //  11 ms)
+    bool prev_lower_from_max = false;   // the previous iteration's bound was the largest entry of R, not the Frobenius one
+    const double rskip_env = [] { const char* e = dev_get(DEV_RSKIP_MARGIN); return e ? atof(e) : -1.0; }();
     int64_t sweeps = 0;
     // arbitrary hooks of the host language (src/robustPCA.jl:168-169): the panel visits the host and the caller's
     // own function runs there, on the calling thread ("the CPU path with the user's closure")
@@ -1877,6 +1881,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
         // The residual panel R_k is only read by the cost evaluation.  While the Frobenius bound of the previous
         // iteration was far above tol this one's will be too (the cost shrinks by ~rho per iteration): the sweep then
         // does not store R_k at all (one panel pass less); should the bound disagree, R_k is recomputed below.
+        const double rskip_margin = rskip_env >= 0.0 ? rskip_env : (prev_lower_from_max ? 3.0 : 6.0);
         const bool store_R = !(sumsq_dev && prev_lower > rskip_margin * ro.tol);
         T* Rst = store_R ? R : nullptr;
         if (!store_R) ++n_rskip;
@@ -2119,8 +2124,14 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                     if (std::isfinite(part[i]) && part[i] > mx) mx = part[i];
                 const double lower_mx = mx / d_norm;               // max |R[i, j]| / ||D||_2 <= cost
                 max_settles = lower_mx > ro.tol * (1.0 + 1e-6);   // (the entries of R carry ~1e-8 relative rounding)
+                prev_lower_from_max = lower_mx > lower;
                 if (lower_mx > lower) lower = lower_mx;
+            } else {
+                prev_lower_from_max = false;
             }
+            if (dev_get(DEV_DEBUG))
+                fprintf(stderr, "  iteration %lld: cost bound %.4e (%.2f tol), residual %s, settles %d\n", (long long)k, lower, lower / ro.tol,
+                        store_R ? "stored" : "not stored", (int)(lower > 2.0 * ro.tol || max_settles));
             prev_lower = lower;
             if (lower > 2.0 * ro.tol || max_settles) {
                 cost = lower;          // a lower bound of the true cost: only "not converged yet" is known
