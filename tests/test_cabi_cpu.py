@@ -135,3 +135,26 @@ def test_dev_switches_restore_the_previous_value():
         assert got == {"TLSQ_PAD": "4"} and any("NO_SUCH_SWITCH" in str(x.message) for x in w)
     finally:
         tlsq_amd.dev_set("PAD", None)
+
+
+def test_report_reads_the_info_struct_on_first_use():
+    """RpcaReport (round 6) converts tlsq_rpca_info lazily: nothing is read at construction, everything on the first attribute,
+    unknown names are AttributeErrors, and the live-switch list of the shipped library accepts the round's new names."""
+    from tlsq_amd.engine import Engine, RpcaReport
+    info, cost, svp = Engine._info(8, True)
+    rep = RpcaReport(info, cost, svp)
+    assert "iters_done" not in rep.__dict__
+    info.iters_done, info.converged, info.final_cost, info.d_norm = 3, 1, 0.25, 7.5
+    info.kern_gram_h3, info.ms_total = 5, 1.5
+    cost[:3] = [1.0, 0.5, 0.25]
+    svp[:3] = [4, 4, 5]
+    assert rep.iters_done == 3 and rep.converged and rep.final_cost == 0.25 and rep.d_norm == 7.5
+    assert rep.cost_hist == [1.0, 0.5, 0.25] and rep.svp_hist == [4, 4, 5]
+    assert rep.kern["gram_h3"] == 5 and rep.ms["total"] == 1.5
+    with pytest.raises(AttributeError):
+        rep.no_such_field
+    for name in ("LZ_MULTI", "COLD_TOP", "COLD_TOL0", "RITZ_SORT", "PAD_PROJECT", "HOST_TRACE", "SWEEP_TIMING_STRIDE"):
+        tlsq_amd.dev_set(name, "1")
+        tlsq_amd.dev_set(name, None)
+    with pytest.raises(Exception):
+        tlsq_amd.dev_set("NO_FUSED_SWEEP", "1")   # an ablation switch: refused by the shipped library
