@@ -2194,7 +2194,7 @@ int rpca_core(Handle* h, const T* D, int64_t M, int64_t N, const ResolvedOpts& r
                 // (not when the lower bounds of this iteration already sit 10 % below tol: the largest entry of the residual is
                 //  within a few per cent of its norm, so "not converged" is not what three power steps are going to say - the last
                 //  iteration of a solve went through them, and a host round trip, for nothing)
-                const bool likely_converged = maxslot >= 0 && prev_lower < 0.9 * ro.tol;
+                const bool likely_converged = maxslot >= 0 && prev_lower_from_max && prev_lower < 0.9 * ro.tol;
                 if (stop_sigma > 0.0 && !no_power_lb && !likely_converged) {
                     // "not converged" from three power steps on the vector carried over from the previous evaluation
                     // (||G v|| <= lambda_max for unit v): no Lanczos run unless the bound falls short of the mark
