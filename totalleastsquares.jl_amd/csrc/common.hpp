@@ -120,11 +120,11 @@ int ws_get(Handle* h, int slot, size_t bytes, void** out);
     X(WARM_Q0) X(IMPLICIT_GRAM) X(LAZY_HANKEL) X(IMPLICIT_HANKEL) X(PAD) X(NO_MAILBOX) X(NO_FUSED_ZGRAM)              \
     X(FUSED_ZGRAM_MINROWS) X(FUSED_ABLATE) X(FUSED_ZGRAM_N512) X(OPGRAM_OLD) X(OPGRAM_H3) X(GRAM_H3)                  \
     X(NO_WIDE_SWEEP) X(NO_SLICED_EIG) X(SLICE_NORMWISE) X(HANKEL_STRUCT) X(SLICE_TARGET) X(COLD_TOP) X(COLD_TOL0)         \
-    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT) X(HOST_TRACE) X(SWEEP_TIMING_STRIDE)
+    X(LZ_MULTI) X(RITZ_SORT) X(PAD_PROJECT) X(HOST_TRACE) X(SWEEP_TIMING_STRIDE) X(SLICE_MIDJ)
 // Ablation switches: every one of them selects a path that was measured against its successor and is kept for that comparison
 // (docs/HISTORY.md).  No committed test or tool uses them; the SHIPPED library does not accept them - 
 // tlsq_dev_set answers TLSQ_ERR_ARG as for an unknown name, so dev_get() of these is always "not set" - only a build with
-// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  47 live switches, 65 ablation switches.
+// -DTLSQ_DEV_SWITCHES (TLSQ_EXTRA_FLAGS of the build recipe) does.  48 live switches, 65 ablation switches.
 #define TLSQ_DEV_LIST_ABLATION(X)                                                                                         \
     X(NO_FUSED_SWEEP) X(NO_FIRST_SHRINK) X(NO_FUSED_REBUILD) X(NO_REBUILD_STORE)                                      \
     X(NO_MAX_BOUND) X(LAST_GUESS) X(NO_POWER_LB) X(NO_POWER_START) X(POWER_LEVELS) X(FULL_EIG) X(NO_GRAM_DENSE)       \
@@ -418,6 +418,8 @@ int matfun_lin2(Handle* h, const double* X1, double a1, const double* X2, double
 // columns, lam_dev[i] = ||B[:,i]|| (unsorted), V orthogonal (ld N) unless want_v == false.
 // B and V are workspace buffers owned by the caller (N*N each).
 // async_small: when the matrix fits the single-workgroup path, do not read the sweep count back (no host sync).
+int jacobi_mid_blocks_f64(Handle* h, const double* T, int64_t N, const std::vector<std::pair<int, int>>& blocks, double* W, double* lam,
+                          int64_t* sweeps_out);   // one-sided Jacobi on the diagonal blocks of T, one workgroup each (k <= 96)
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V,
                bool want_v, double* lam_dev, int64_t* sweeps_out, bool async_small = false,
                bool warm_v = false, bool two_sided = false,    // two_sided (N <= 64): rotate G itself (absolute accuracy)

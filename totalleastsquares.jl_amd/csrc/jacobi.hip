@@ -524,12 +524,13 @@ __device__ __forceinline__ double row_allsum(double v) {   // sum over the 16 la
     v += dpp_perm<0x140>(v);
     return v;
 }
-template <bool WANT_V>
-__global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ G, int64_t ldG,
-                                                       double* __restrict__ Bout, double* __restrict__ Vout,
-                                                       double* __restrict__ lam, int N, double tol, double nfloor,
-                                                       int max_sweeps, int* __restrict__ sweeps_done) {
-    extern __shared__ __attribute__((aligned(16))) double jm_sm[];   // sB[N*LD], sV[N*LD] (WANT_V), sN[N]
+// (the body of k_jacobi_mid and of k_jacobi_mid_blocks: G with leading dimension ldG, symmetrised on the way in when SYMM; Bout /
+//  lam may be null; Vout with leading dimension ldV; sweeps_done: the sweep count, or with SW_MAX the maximum over the launch's
+//  workgroups)
+template <bool WANT_V, bool SYMM, bool SW_MAX>
+__device__ __forceinline__ void jacobi_mid_body(double* jm_sm, const double* __restrict__ G, int64_t ldG, double* __restrict__ Bout,
+                                                double* __restrict__ Vout, int64_t ldV, double* __restrict__ lam, int N, double tol,
+                                                double nfloor, int max_sweeps, int* __restrict__ sweeps_done) {
     __shared__ double red[16];
     __shared__ unsigned int s_rot;
     __shared__ unsigned long long s_max;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
     double fro = 0.0;
     for (int e = tid; e < N * N; e += nthr) {
         const int r = e % N, c = e / N;
-        const double v = G[r + (int64_t)c * ldG];
+        const double v = SYMM ? 0.5 * (G[r + (int64_t)c * ldG] + G[c + (int64_t)r * ldG]) : G[r + (int64_t)c * ldG];
         sB[c * LD + r] = v;
         if (WANT_V) sV[c * LD + r] = (r == c) ? 1.0 : 0.0;
         fro += v * v;
@@ -666,11 +667,11 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
     __syncthreads();
     for (int e = tid; e < N * N; e += nthr) {
         const int r = e % N, c = e / N;
-        Bout[e] = sB[c * LD + r];
-        if (WANT_V) Vout[e] = sV[c * LD + r];
+        if (Bout) Bout[e] = sB[c * LD + r];
+        if (WANT_V) Vout[r + (int64_t)c * ldV] = sV[c * LD + r];
     }
     // lam[c] = ||B[:,c]||: lane row per column
-    for (int c = hw; c < N; c += nhw) {
+    for (int c = hw; lam && c < N; c += nhw) {
         const double* x = sB + c * LD;
         double acc = 0.0;
 #pragma unroll
@@ -682,8 +683,41 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ 
         const double ssum = row_allsum(acc);
         if (hl == 0) lam[c] = sqrt(ssum);
     }
-    if (tid == 0 && sweeps_done) *sweeps_done = sweep;
+    if (tid == 0 && sweeps_done) {
+        if (SW_MAX) atomicMax(sweeps_done, sweep);
+        else *sweeps_done = sweep;
+    }
 }
+
+template <bool WANT_V>
+__global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ G, int64_t ldG,
+                                                       double* __restrict__ Bout, double* __restrict__ Vout,
+                                                       double* __restrict__ lam, int N, double tol, double nfloor,
+                                                       int max_sweeps, int* __restrict__ sweeps_done) {
+    extern __shared__ __attribute__((aligned(16))) double jm_sm[];   // sB[N*LD], sV[N*LD] (WANT_V), sN[N]
+    jacobi_mid_body<WANT_V, false, false>(jm_sm, G, ldG, Bout, Vout, N, lam, N, tol, nfloor, max_sweeps, sweeps_done);
+}
+
+// The same solver on the DIAGONAL BLOCKS of a symmetric T (N x N, ld N), one workgroup per block (round 6: the slices'
+// own eigenproblems of the normwise sliced solver, sliced.hip - k <= 96 columns each, side by side): W (N x N, ld N, zero
+// outside the blocks: cleared by the caller) receives the blocks' eigenvector matrices on its diagonal, lam (N) the
+// eigenvalues' magnitudes in the order of W's columns, sweeps_done the largest sweep count (cleared by the caller).
+struct JmBlocks {
+    int32_t n;
+    int32_t start[32], k[32];
+};
+__global__ __launch_bounds__(1024) void k_jacobi_mid_blocks(const double* __restrict__ T, int N, JmBlocks m, double* __restrict__ W,
+                                                            double* __restrict__ lam, double tol_scale, double nfloor_scale,
+                                                            int max_sweeps, int* __restrict__ sweeps_done) {
+    extern __shared__ __attribute__((aligned(16))) double jm_sm[];
+    const int c0 = m.start[blockIdx.x], k = m.k[blockIdx.x];
+    if (k < 1) return;
+    const double eps0 = 2.220446049250313e-16;
+    const double tol = tol_scale * 2.0 * eps0 * sqrt((double)k);
+    jacobi_mid_body<true, true, true>(jm_sm, T + (int64_t)c0 * (N + 1), N, nullptr, W + (int64_t)c0 * (N + 1), N, lam ? lam + c0 : nullptr, k,
+                                      tol, nfloor_scale * (double)k * eps0, max_sweeps, sweeps_done);
+}
+
 
 // ---- register-resident block pair (no eigenvector accumulation, 64 <= N <= 1024): the accurate route's Jacobi ---------------
 // k_jacobi_round keeps its 2b columns in LDS and gives every column pair to one wave: a rotation is a chain of LDS round
@@ -1073,6 +1107,41 @@ static int pick_block(int64_t N, bool want_v, bool* single) {
     const int64_t bcap = want_v ? 8 : 16;   // waves per workgroup (1024 threads at most)
     if (b > bcap) b = bcap;
     return (int)b;
+}
+
+// the diagonal blocks [start_j, start_j + k_j) of the symmetric T (N x N, ld N): W = blockdiag(eigenvector matrices) (the rest of
+// W is cleared here), lam (N) the eigenvalue magnitudes in the order of W's columns; at most 32 blocks of at most 96 columns
+int jacobi_mid_blocks_f64(Handle* h, const double* T, int64_t N, const std::vector<std::pair<int, int>>& blocks, double* W, double* lam,
+                          int64_t* sweeps_out) {
+    if (blocks.empty() || blocks.size() > 32) return set_err(h, TLSQ_ERR_ARG, "jacobi_mid_blocks: %zu blocks", blocks.size());
+    JmBlocks m = {};
+    m.n = (int32_t)blocks.size();
+    int maxk = 0;
+    for (size_t j = 0; j < blocks.size(); ++j) {
+        m.start[j] = blocks[j].first;
+        m.k[j] = blocks[j].second;
+        maxk = std::max(maxk, blocks[j].second);
+        if (blocks[j].second > 96 || blocks[j].first < 0 || blocks[j].first + blocks[j].second > N)
+            return set_err(h, TLSQ_ERR_ARG, "jacobi_mid_blocks: block %zu = [%d, +%d)", j, blocks[j].first, blocks[j].second);
+    }
+    void* scal;
+    TLSQ_TRY(ws_get(h, WS_SCAL, 4096, &scal));
+    int* sweeps_dev = reinterpret_cast<int*>(reinterpret_cast<char*>(scal) + 136);
+    TLSQ_HIP(h, hipMemsetAsync(W, 0, (size_t)N * N * 8, h->stream));
+    TLSQ_HIP(h, hipMemsetAsync(sweeps_dev, 0, 4, h->stream));
+    const size_t lds = ((size_t)2 * maxk * (maxk + 1) + maxk) * 8;
+    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int max_sweeps = 40;
+    hipLaunchKernelGGL(k_jacobi_mid_blocks, dim3((unsigned)blocks.size()), dim3(1024), lds, h->stream, T, (int)N, m, W, lam, 1.0, 1.0, max_sweeps,
+                       sweeps_dev);
+    TLSQ_HIP(h, hipGetLastError());
+    TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
+    TLSQ_HIP(h, hipStreamSynchronize(h->stream));
+    int sd;
+    memcpy(&sd, h->pinned, 4);
+    if (sweeps_out) *sweeps_out = sd;
+    if (sd >= max_sweeps) return TLSQ_ERR_NOCONV;   // (the caller falls back: no error text)
+    return TLSQ_OK;
 }
 
 int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, double* V, bool want_v,

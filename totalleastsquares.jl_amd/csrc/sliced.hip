@@ -33,10 +33,12 @@
 //
 // The NORMWISE form (symeig_sliced_normwise_f64, what the returned `s` of a plain call takes): the same slices and basis, of G
 // itself - no Cholesky factor (1.0 ms at N = 512), no sweeps over all pairs (0.8 ms each) - then the slices' own k x k problems
-// T_jj = J0_j' G J0_j (k <= 96) by Cholesky + one-sided Jacobi on windows of k rows, V = J0 blockdiag(W_j), one first-order
+// T_jj = J0_j' G J0_j (k <= 96), one workgroup per slice with the whole problem in LDS and every sweep in one launch
+// (jacobi.hip, k_jacobi_mid_blocks: 0.6 ms; Cholesky + the register kernel on windows of k rows, 45 launches, took 1.3 -
+// SLICE_MIDJ=0), V = J0 blockdiag(W_j), one first-order
 // refinement from V'GV for what the projectors left between slices, and a certificate max |offdiag(V'GV)| <= 8 N eps ||G||.
-// Measured at C2 (20000 x 512, rank 16; profiles/r06_ws_*): the decomposition after the loop 14.8 -> 4.9 ms (under the profiler:
-// slicing 2.06, pivoted Cholesky of the projectors 0.35, polish 0.3, the slices' Jacobi 1.3, refinement + certificate 0.8, U and
+// Measured at C2 (20000 x 512, rank 16; profiles/r06_ws_*): the decomposition after the loop 14.8 -> 4.35 ms (under the profiler:
+// slicing 2.06, pivoted Cholesky of the projectors 0.35, polish 0.3, the slices' Jacobi 0.65, refinement + certificate 0.8, U and
 // the cluster 1.2).
 #include <algorithm>
 #include <cmath>
@@ -623,19 +625,28 @@ int symeig_sliced_normwise_f64(Handle* h, const double* G, int64_t N, double* V,
     double *GJ = b.X, *T = b.X + nn, *Wb = b.X + 2 * nn, *Xr = b.X + 3 * nn, *Vn = b.W1, *Vn2 = b.W1 + nn;
     TLSQ_TRY(small_mm_batched(h, b.K, nn, J0, nn, GJ, nn, N, 1, 1.0, 0.0, false, nullptr, 0, 0.0));
     TLSQ_TRY(gemm_f64(h, true, true, J0, N, GJ, N, T, N, N, N, N, false));
-    // the slices' eigenproblems: Cholesky factors of the diagonal blocks, one-sided Jacobi on them side by side, W = the
-    // normalised rotated columns (block diagonal)
+    // the slices' eigenproblems, side by side: W = blockdiag(eigenvector matrices of the T_jj)
     int maxk = 0;
     for (auto& g : pl.groups) maxk = std::max(maxk, g.second);
-    const size_t lds = (size_t)maxk * (maxk + 1) * 8;
-    double* Bd = Xr;   // (free until the refinement)
-    TLSQ_HIP(h, hipMemsetAsync(Bd, 0, (size_t)nn * 8, h->stream));
-    TLSQ_HIP(h, hipMemsetAsync(b.failflag, 0, 4, h->stream));
-    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_chol_blocks, dim3((unsigned)pl.nsl), dim3(1024), lds, h->stream, (const double*)T, (int)N, pl.pm, Bd, b.failflag);
-    TLSQ_HIP(h, hipGetLastError());
     int64_t swb[2] = {0, 0};
-    {
+    if (maxk <= 96 && pl.groups.size() <= 32 && !dev_is(DEV_SLICE_MIDJ, '0')) {
+        // One workgroup per slice, the whole k x k problem in LDS, every sweep of it in ONE launch (jacobi.hip,
+        // k_jacobi_mid_blocks: one-sided Jacobi on T_jj itself - normwise accurate, which is all the certificate below asks of
+        // this stage).  The register kernel on the blocks' Cholesky factors (below) needed 9 sweeps x 5 launches of 28 us for
+        // eight slices: 1.3 ms against 0.6.
+        const int stj = jacobi_mid_blocks_f64(h, T, N, pl.groups, Wb, lam_dev /* scratch */, &swb[0]);
+        if (stj == TLSQ_ERR_NOCONV) return TLSQ_OK;
+        if (stj < 0) return stj;
+    } else {
+        // Cholesky factors of the diagonal blocks, one-sided Jacobi on them (the register kernel on the blocks' own row windows),
+        // W = the normalised rotated columns (block diagonal)
+        const size_t lds = (size_t)maxk * (maxk + 1) * 8;
+        double* Bd = Xr;   // (free until the refinement)
+        TLSQ_HIP(h, hipMemsetAsync(Bd, 0, (size_t)nn * 8, h->stream));
+        TLSQ_HIP(h, hipMemsetAsync(b.failflag, 0, 4, h->stream));
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_chol_blocks, dim3((unsigned)pl.nsl), dim3(1024), lds, h->stream, (const double*)T, (int)N, pl.pm, Bd, b.failflag);
+        TLSQ_HIP(h, hipGetLastError());
         const int stj = jacobi_factor_grouped_f64(h, Bd, N, pl.groups, Wb, lam_dev /* scratch: the column norms */, 0.0, swb, true);
         if (stj == TLSQ_ERR_NOCONV) return TLSQ_OK;
         if (stj < 0) return stj;
