@@ -16,7 +16,7 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize("variant", ["normwise", "factor"])
+@pytest.mark.parametrize("variant", ["normwise", "normwise_reg", "factor"])
 @pytest.mark.parametrize("shape", [(20000, 512, 16), (6000, 256, 8), (9000, 384, 24), (5000, 1024, 12)])
 def test_returned_svd_with_and_without_the_slicer(eng, shape, variant):
     """variant `normwise`: the default of the returned `s` (slices of the deflated Gram matrix itself, certified to 8 N eps ||G||);
@@ -25,7 +25,9 @@ def test_returned_svd_with_and_without_the_slicer(eng, shape, variant):
     from oracle import rpca_oracle as O
     M, N, r = shape
     D, _, _ = O.synth_lowrank_sparse(M, N, r, seed=M + N)
-    with tlsq_amd.dev_switches(**({} if variant == "normwise" else dict(SLICE_NORMWISE=0))):
+    # (`normwise_reg`, SLICE_MIDJ=0: the slices' eigenproblems by Cholesky + the register kernel on row windows instead of one
+    #  LDS-resident workgroup per slice)
+    with tlsq_amd.dev_switches(**({} if variant == "normwise" else dict(SLICE_MIDJ=0) if variant == "normwise_reg" else dict(SLICE_NORMWISE=0))):
         A, E, s, sv, rep = eng.rpca(D, return_report=True)
     with tlsq_amd.dev_switches(NO_SLICED_EIG=1):
         A1, E1, s1, sv1, rep1 = eng.rpca(D, return_report=True)
