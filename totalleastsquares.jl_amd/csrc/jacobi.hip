@@ -527,14 +527,13 @@ __device__ __forceinline__ double row_allsum(double v) {   // sum over the 16 la
 // (the body of k_jacobi_mid and of k_jacobi_mid_blocks: G with leading dimension ldG, symmetrised on the way in when SYMM; Bout /
 //  lam may be null; Vout with leading dimension ldV; sweeps_done: the sweep count, or with SW_MAX the maximum over the launch's
 //  workgroups)
-template <bool WANT_V, bool SYMM, bool SW_MAX>
+template <bool WANT_V, bool SYMM, bool SW_MAX, int RL>   // RL: rows per lane, 16 RL >= N
 __device__ __forceinline__ void jacobi_mid_body(double* jm_sm, const double* __restrict__ G, int64_t ldG, double* __restrict__ Bout,
                                                 double* __restrict__ Vout, int64_t ldV, double* __restrict__ lam, int N, double tol,
                                                 double nfloor, int max_sweeps, int* __restrict__ sweeps_done) {
     __shared__ double red[16];
     __shared__ unsigned int s_rot;
     __shared__ unsigned long long s_max;
-    constexpr int RL = 6;                     // rows per lane: 16 RL >= 96
     const int LD = N + 1;
     double* sB = jm_sm;
     double* sV = jm_sm + (size_t)N * LD;
@@ -689,13 +688,13 @@ __device__ __forceinline__ void jacobi_mid_body(double* jm_sm, const double* __r
     }
 }
 
-template <bool WANT_V>
+template <bool WANT_V, int RL>
 __global__ __launch_bounds__(1024) void k_jacobi_mid(const double* __restrict__ G, int64_t ldG,
                                                        double* __restrict__ Bout, double* __restrict__ Vout,
                                                        double* __restrict__ lam, int N, double tol, double nfloor,
                                                        int max_sweeps, int* __restrict__ sweeps_done) {
     extern __shared__ __attribute__((aligned(16))) double jm_sm[];   // sB[N*LD], sV[N*LD] (WANT_V), sN[N]
-    jacobi_mid_body<WANT_V, false, false>(jm_sm, G, ldG, Bout, Vout, N, lam, N, tol, nfloor, max_sweeps, sweeps_done);
+    jacobi_mid_body<WANT_V, false, false, RL>(jm_sm, G, ldG, Bout, Vout, N, lam, N, tol, nfloor, max_sweeps, sweeps_done);
 }
 
 // The same solver on the DIAGONAL BLOCKS of a symmetric T (N x N, ld N), one workgroup per block (round 6: the slices'
@@ -706,6 +705,7 @@ struct JmBlocks {
     int32_t n;
     int32_t start[32], k[32];
 };
+template <int RL>
 __global__ __launch_bounds__(1024) void k_jacobi_mid_blocks(const double* __restrict__ T, int N, JmBlocks m, double* __restrict__ W,
                                                             double* __restrict__ lam, double tol_scale, double nfloor_scale,
                                                             int max_sweeps, int* __restrict__ sweeps_done) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_mid_blocks(const double* __rest
     if (k < 1) return;
     const double eps0 = 2.220446049250313e-16;
     const double tol = tol_scale * 2.0 * eps0 * sqrt((double)k);
-    jacobi_mid_body<true, true, true>(jm_sm, T + (int64_t)c0 * (N + 1), N, nullptr, W + (int64_t)c0 * (N + 1), N, lam ? lam + c0 : nullptr, k,
+    jacobi_mid_body<true, true, true, RL>(jm_sm, T + (int64_t)c0 * (N + 1), N, nullptr, W + (int64_t)c0 * (N + 1), N, lam ? lam + c0 : nullptr, k,
                                       tol, nfloor_scale * (double)k * eps0, max_sweeps, sweeps_done);
 }
 
@@ -1130,10 +1130,19 @@ int jacobi_mid_blocks_f64(Handle* h, const double* T, int64_t N, const std::vect
     TLSQ_HIP(h, hipMemsetAsync(W, 0, (size_t)N * N * 8, h->stream));
     TLSQ_HIP(h, hipMemsetAsync(sweeps_dev, 0, 4, h->stream));
     const size_t lds = ((size_t)2 * maxk * (maxk + 1) + maxk) * 8;
-    TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int max_sweeps = 40;
-    hipLaunchKernelGGL(k_jacobi_mid_blocks, dim3((unsigned)blocks.size()), dim3(1024), lds, h->stream, T, (int)N, m, W, lam, 1.0, 1.0, max_sweeps,
-                       sweeps_dev);
+    // (rows per lane by the largest block: the lanes of a column pair walk 16 RL rows whatever the block has)
+#define JMB_LAUNCH(RLV)                                                                                                              \
+    do {                                                                                                                             \
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid_blocks<RLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                                  \
+        hipLaunchKernelGGL(k_jacobi_mid_blocks<RLV>, dim3((unsigned)blocks.size()), dim3(1024), lds, h->stream, T, (int)N, m, W, lam, 1.0, 1.0, \
+                           max_sweeps, sweeps_dev);                                                                                  \
+    } while (0)
+    if (maxk <= 64) JMB_LAUNCH(4);
+    else if (maxk <= 80) JMB_LAUNCH(5);
+    else JMB_LAUNCH(6);
+#undef JMB_LAUNCH
     TLSQ_HIP(h, hipGetLastError());
     TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
@@ -1192,17 +1201,22 @@ int symeig_f64(Handle* h, const double* G, int64_t N, int64_t ldG, double* B, do
         const double tol0 = std::max(2.0 * eps0 * sqrt((double)N), rot_tol);
         const int max_sweeps0 = 40;
         const size_t lds = ((size_t)(want_v ? 2 : 1) * N * (N + 1) + N) * 8;
+        // (rows per lane: 5 up to 80 columns, 6 up to 96 - the lanes of a column pair walk 16 RL rows whatever N is)
+#define JM_LAUNCH(WV, RLV)                                                                                                          \
+    do {                                                                                                                             \
+        TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid<WV, RLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                                  \
+        hipLaunchKernelGGL((k_jacobi_mid<WV, RLV>), dim3(1), dim3(1024), lds, h->stream, G, ldG, B, V, lam_dev, (int)N, tol0,        \
+                           (double)N * eps0, max_sweeps0, sweeps_dev);                                                               \
+    } while (0)
         if (want_v) {
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_jacobi_mid<true>, dim3(1), dim3(1024), lds, h->stream, G, ldG, B, V, lam_dev, (int)N, tol0,
-                               (double)N * eps0, max_sweeps0, sweeps_dev);
+            if (N <= 80) JM_LAUNCH(true, 5);
+            else JM_LAUNCH(true, 6);
         } else {
-            TLSQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi_mid<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_jacobi_mid<false>, dim3(1), dim3(1024), lds, h->stream, G, ldG, B, V, lam_dev, (int)N,
-                               tol0, (double)N * eps0, max_sweeps0, sweeps_dev);
+            if (N <= 80) JM_LAUNCH(false, 5);
+            else JM_LAUNCH(false, 6);
         }
+#undef JM_LAUNCH
         TLSQ_HIP(h, hipGetLastError());
         if (async_small) return TLSQ_OK;
         TLSQ_HIP(h, hipMemcpyAsync(h->pinned, sweeps_dev, 4, hipMemcpyDeviceToHost, h->stream));
