@@ -137,7 +137,10 @@ def test_symeig_through_the_slicer_on_synthetic_spectra(eng, N, kind):
     G = (G + G.T) / 2
     dG = torch.from_numpy(np.ascontiguousarray(G.T)).cuda()
     out = {}
-    for tag, sw in (("sliced", {}), ("plain", dict(NO_SLICED_EIG=1))):
+    # (`normwise`, SLICE_NORMWISE=force: the form the returned `s` of rpca takes - slices of G itself, the slices' eigenproblems one
+    #  LDS-resident workgroup each, one refinement, certified to 8 N eps ||G||_F; the entry reports a negative sweep count when
+    #  that form served the call - it may decline, e.g. clusters wider than a slice, and leave the call to the other two)
+    for tag, sw in (("sliced", {}), ("plain", dict(NO_SLICED_EIG=1)), ("normwise", dict(SLICE_NORMWISE="force"))):
         dl = torch.zeros(N, dtype=torch.float64, device="cuda")
         dV = torch.zeros((N, N), dtype=torch.float64, device="cuda")
         sweeps = C.c_int64()
@@ -146,10 +149,13 @@ def test_symeig_through_the_slicer_on_synthetic_spectra(eng, N, kind):
                                                 C.c_void_p(dV.data_ptr()), N, C.byref(sweeps))
         assert st == 0, eng.lib.tlsq_last_error(eng.h)
         out[tag] = (dl.cpu().numpy(), dV.cpu().numpy().T, sweeps.value)
-    for tag in ("sliced", "plain"):
+    for tag in ("sliced", "plain", "normwise"):
         lam, V, sw = out[tag]
         assert np.all(np.diff(lam) <= 0)
-        assert np.max(np.abs(lam - ref)) < 32 * N * 2.2e-16 * ref[0], (tag, np.max(np.abs(lam - ref)) / ref[0])
+        bar = 32 * N * 2.2e-16 * (np.linalg.norm(G) if (tag == "normwise" and sw < 0) else ref[0])
+        assert np.max(np.abs(lam - ref)) < bar, (tag, np.max(np.abs(lam - ref)) / ref[0])
         assert np.max(np.abs(V.T @ V - np.eye(N))) < 1e-10, tag
         assert np.linalg.norm(G @ V - V * lam[None, :]) < 1e-11 * np.linalg.norm(G) * np.sqrt(N), tag
+    if kind == "flat":
+        assert out["normwise"][2] < 0     # a flat spectrum the normwise form must serve itself (outliers need the caller's hints)
     assert np.max(np.abs(out["sliced"][0] - out["plain"][0])) < 32 * N * 2.2e-16 * ref[0]

@@ -1004,15 +1004,25 @@ int tlsq_k_symeig_chol_f64(tlsq_handle h, const double* G, int64_t N, int64_t ld
     int64_t sw = 0;
     double delta = 0.0;
     // (as eig_full does it: the spectrum cut into slices first where the shape allows - sliced.hip, factor form, no hints)
-    bool sliced = false;
-    if (symeig_sliced_ok(N))
+    bool sliced = false, normwise = false;
+    // (SLICE_NORMWISE=force, tests: the NORMWISE sliced form - what the returned `s` of rpca takes, certified to 8 N eps ||G||_F
+    //  here since no tighter bound of lambda_max is at hand - so that it can be held to synthetic spectra by itself; lam comes
+    //  back as the eigenvalues themselves there, not as singular values of a factor)
+    if (symeig_sliced_ok(N) && ldG == N && dev_is(DEV_SLICE_NORMWISE, 'f')) {
+        double st3[3];
+        TLSQ_TRY(matfun_stats(h, G, N, st3));
+        const double fro = std::sqrt(std::max(st3[0] + 2.0 * st3[1] - (double)N, 0.0));   // ||G||_F from ||G - I||_F^2 and the trace
+        TLSQ_TRY(symeig_sliced_normwise_f64(h, G, N, (double*)Vw, (double*)lamw, &sw, fro, 0, 0.0, 0.0, &normwise));
+    }
+    if (!normwise && symeig_sliced_ok(N))
         TLSQ_TRY(symeig_sliced_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw, 0.0, 0, 0.0, 0.0, &sliced));
-    if (!sliced) TLSQ_TRY(symeig_chol_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw));
-    if (sweeps) *sweeps = sw;
+    if (!normwise && !sliced) TLSQ_TRY(symeig_chol_f64(h, G, N, ldG, (double*)B, (double*)Vw, (double*)lamw, &delta, &sw));
+    if (sweeps) *sweeps = normwise ? -sw : sw;   // (negative: the normwise form served the call)
     std::vector<double> hl((size_t)N);
     TLSQ_HIP(h, hipMemcpyAsync(hl.data(), lamw, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
     TLSQ_HIP(h, hipStreamSynchronize(h->stream));
-    for (auto& v : hl) v = std::max(v * v - delta, 0.0);
+    if (!normwise)
+        for (auto& v : hl) v = std::max(v * v - delta, 0.0);
     std::vector<int32_t> order((size_t)N);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return hl[a] > hl[b]; });
