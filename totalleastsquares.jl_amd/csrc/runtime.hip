@@ -52,7 +52,8 @@ int dev_set(const char* name, const char* value) {
 
 double now_ms();
 // HOST_TRACE=1: wall-clock marks of the host side of a call (where the time between two kernels of the trace goes when the GPU
-// is waiting for the host), printed to stderr when the call returns
+// is waiting for the host), printed to stderr when the call returns.  One table for the process: a tool for single-handle runs
+// (the worker threads of a multi-GPU group would interleave their marks)
 static struct { const char* tag; double t; } g_host_marks[64];
 static int g_host_nmarks = 0;
 void host_mark(const char* tag) {
